@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""bench.py — STFT frames/s (fp32, N=1024 hop=256) on MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 60 s mono 48 kHz fp32 streams, N=1024, hop=256, periodic
+Hann, :valid padding, no scaling -> 11 247 frames per stream.  One 60 s stream is 103.7 MB of traffic
+(~18 us at the roofline) and fits the 256 MiB Infinity Cache, so a STEP is one launch over a batch of
+`--streams` (default 32) independent 60 s streams per GPU (3.3 GB working set >> L3): steady-state HBM
+numbers.  The single-stream figure (config 2 exactly as written) is reported beside it in `single_stream`.
+Inputs and outputs are device-resident (HBM) when the timed region starts; N GPUs each process their own
+batch (weak scaling, no data-path collective — frames are independent).
+
+Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch
+(hop*4 + K*8 = 9216 B/frame x frames) / mean kernel time measured with HIP events on the library's stream.
+`cpu_baseline` = the oracle's C restatement of the BinaryBackend path (oracle/bb_baseline.c) timed on this
+box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SR = 48000
+SECONDS = 60
+N_FFT = 1024
+HOP = 256
+L = SR * SECONDS                      # 2 880 000 samples
+M = (L - N_FFT) // HOP + 1            # 11 247 frames
+BYTES_PER_FRAME = HOP * 4 + N_FFT * 8  # 9 216 algorithmic bytes / frame
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md chip table (spec); measured copy ceiling 6290
+
+
+def synth(seed: int) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.standard_normal(L, dtype=np.float32)  # N(0,1), never zero-filled (DVFS)
+
+
+def cpu_baseline(max_seconds: float):
+    """oracle C port (single thread, like one BEAM scheduler) on a bounded sample of the same workload."""
+    from oracle import bb_baseline, nx_oracle as O
+
+    w = O.hann(N_FFT)
+    x = synth(1234)
+    nfr = 1024  # calibrate
+    t0 = time.perf_counter()
+    bb_baseline.stft(x[: (nfr - 1) * HOP + N_FFT], w, HOP, N_FFT, threads=1)
+    dt = time.perf_counter() - t0
+    frames = int(min(M, max(nfr, nfr * (max_seconds * 0.6) / max(dt, 1e-6))))
+    seg = x[: (frames - 1) * HOP + N_FFT]
+    t0 = time.perf_counter()
+    bb_baseline.stft(seg, w, HOP, N_FFT, threads=1)
+    dt1 = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    bb_baseline.stft(seg, w, HOP, N_FFT, threads=cores)
+    dtn = time.perf_counter() - t0
+    return {
+        "value": frames / dt1,
+        "unit": "frames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {frames} frames of one 60 s mono 48 kHz stream (N=1024 hop=256 Hann), oracle/bb_baseline.c "
+                  f"recursive radix-2 in f64, 1 thread; Nx.BinaryBackend itself cannot run here (no BEAM: "
+                  f"elixir={'found' if _which('elixir') else 'not found'})",
+        "all_cores": {"value": frames / dtn, "cores": cores},
+    }
+
+
+def _which(exe):
+    import shutil
+
+    return shutil.which(exe)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=32, help="independent 60 s streams per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)  # nccl == RCCL over xGMI
+        dist = dist_mod
+
+    import nx_signal_amd as S
+    from nx_signal_amd import _lib
+    import ctypes as C
+
+    ctx = S.Context(local_rank)
+    lib = _lib.load()
+    w = S.windows.hann(N_FFT)
+    B = args.streams
+
+    # inputs resident in HBM before the timed region: B independent streams, seed = 1234 + global stream index
+    xd = ctx.empty((B, L), np.float32)
+    for b in range(B):
+        xb = synth(1234 + rank * B + b)
+        _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(xd.ptr + b * L * 4), xb.ctypes.data_as(C.c_void_p), xb.nbytes))
+        if b == 0:
+            x0 = xb
+    zd = ctx.empty((B, M, N_FFT), np.complex64)
+    p = _lib.StftParams(N_FFT, HOP, N_FFT, _lib.PAD_VALID, 0, 0, _lib.SCALE_NONE, 0, float(SR))
+    wp = w.ctypes.data_as(C.c_void_p)
+
+    def step(batch=B):
+        _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier(device_ids=[local_rank])
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+    kernel_ms_total = ctx.timer_stop()  # HIP events on the stream the kernels run on (synchronises)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed, kernel_ms_total], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms_total = float(t[0]), float(t[1])
+
+    frames_per_step = B * M * world
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = frames_per_step / (elapsed / args.steps)
+    kernel_ms = kernel_ms_total / args.steps
+    achieved = (B * M * BYTES_PER_FRAME) / (kernel_ms * 1e-3) / 1e9  # GB/s per GPU, algorithmic bytes
+
+    # config 2 exactly as written: ONE 60 s stream per launch, back-to-back launches (L3-resident, launch-bound)
+    for _ in range(20):
+        step(1)
+    ctx.sync()
+    ctx.timer_start()
+    reps = 200
+    for _ in range(reps):
+        step(1)
+    single_ms = ctx.timer_stop() / reps
+    single = {
+        "workload": "1 x 60 s mono (config 2 as written, 103.7 MB: Infinity-Cache resident, launch-bound)",
+        "ms_per_launch": single_ms,
+        "frames_per_s": M / (single_ms * 1e-3),
+        "algorithmic_GBps": M * BYTES_PER_FRAME / (single_ms * 1e-3) / 1e9,
+    }
+
+    verify = None
+    if not args.no_verify and rank == 0:
+        from oracle import nx_oracle as O  # checker only, outside the timed region
+
+        nchk = 512
+        z0 = np.empty((nchk, N_FFT), np.complex64)
+        _lib.check(lib.nxsig_download(ctx.handle, z0.ctypes.data_as(C.c_void_p), C.c_void_p(zd.ptr), z0.nbytes))
+        zo, _, _ = O.stft(x0[: (nchk - 1) * HOP + N_FFT], w, overlap_length=N_FFT - HOP, fft_length=N_FFT, sampling_rate=SR)
+        verify = float(np.max(np.abs(z0 - zo)) / np.max(np.abs(zo)))
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("stft_batch%d_bytes_per_launch" % B)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "STFT frames/sec (fp32, N=1024 hop=256)",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{B} x (60 s mono 48 kHz f32) per GPU per step, N=1024 hop=256 periodic Hann, :valid, "
+                            f"c64 full spectrum out; inputs/outputs device-resident",
+                "streams_per_gpu": B, "frames_per_stream": M, "frame_length": N_FFT, "hop": HOP, "fft_length": N_FFT,
+                "parallelism": f"streams sharded over {world} GPU(s), no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel_ms": kernel_ms, "bytes_per_frame": BYTES_PER_FRAME, "frac_of_measured_copy_6290": achieved / 6290.0,
+            },
+            "single_stream": single,
+            "max_norm_err_vs_oracle": verify,
+            "device": ctx.name(),
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

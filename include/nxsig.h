@@ -1,0 +1,187 @@
+/*
+ * nxsig.h — C ABI of the MI355X-native STFT / iSTFT / FIR hot path behind the NxSignal API.
+ *
+ * This is the drop-in boundary: everything a host language needs
+ * (the Elixir dirty-NIF shim in nif/nxsig_nif.c, the Python mirror in nx_signal_amd/, the C++
+ * tests) goes through these `extern "C"` entry points — plain pointers and sizes, no torch /
+ * C++ types.  The reference has no native code; each entry point replaces the Nx primitives
+ * the cited reference lines compose on Nx.BinaryBackend (file:line are relative to the
+ * reference root, elixir-nx/nx_signal v0.3.0).
+ *
+ * Conventions
+ *   - every function returns NXSIG_OK (0) or a negative nxsig_status; a human readable message
+ *     for the calling thread is available from nxsig_last_error().  Nothing aborts, throws or
+ *     longjmps across this boundary (dirty-NIF safe).
+ *   - buffers are caller-allocated and never retained after the call returns.
+ *   - `mem` says where the SIGNAL buffers (x, z, y ...) live: NXSIG_HOST (the library stages
+ *     them through HBM — PCIe-bound, convenience path) or NXSIG_DEVICE (HBM pointers from
+ *     nxsig_alloc or any other HIP allocator — the hot path; the call is asynchronous on the
+ *     context's stream and returns once the kernels are enqueued).
+ *   - small parameter tables (window, FIR taps) are ALWAYS host pointers: they are user-built
+ *     tensors of a few KB, hashed and cached in HBM per context.
+ *   - c64 = interleaved little-endian (f32 re, f32 im), row-major — Nx's native layout.
+ *   - a context is bound to one GPU and one HIP stream; calls on one context are serialised
+ *     by an internal mutex, different contexts may be used concurrently from any OS thread.
+ */
+#ifndef NXSIG_H
+#define NXSIG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NXSIG_ABI_VERSION 1
+
+typedef struct nxsig_ctx nxsig_ctx;
+
+typedef struct nxsig_c64 {
+  float re, im;
+} nxsig_c64;
+
+typedef enum nxsig_status {
+  NXSIG_OK = 0,
+  NXSIG_ERR_INVALID_ARG = -1, /* maps to ArgumentError on the Elixir side */
+  NXSIG_ERR_UNSUPPORTED = -2, /* valid in the reference, not built here yet (message says what) */
+  NXSIG_ERR_HIP = -3,         /* a HIP runtime call failed */
+  NXSIG_ERR_NO_DEVICE = -4,
+  NXSIG_ERR_OOM = -5
+} nxsig_status;
+
+typedef enum nxsig_mem { NXSIG_HOST = 0, NXSIG_DEVICE = 1 } nxsig_mem;
+
+/* as_windowed padding modes — lib/nx_signal.ex:303-331, :343-352 */
+typedef enum nxsig_pad {
+  NXSIG_PAD_VALID = 0,    /* :valid (default of stft, :76) */
+  NXSIG_PAD_REFLECT = 1,  /* :reflect — div(N,2) each side, mirror without edge repeat (:262, :348-349) */
+  NXSIG_PAD_SAME = 2,     /* :same — k-1 total, floor left / ceil right (:308-312) */
+  NXSIG_PAD_EXPLICIT = 3  /* [{lo, hi}] zero padding (negative = crop, as Nx.pad) (:314-323) */
+} nxsig_pad;
+
+/* stft/istft :scaling — lib/nx_signal.ex:113-127, :611-625 */
+typedef enum nxsig_scaling { NXSIG_SCALE_NONE = 0, NXSIG_SCALE_SPECTRUM = 1, NXSIG_SCALE_PSD = 2 } nxsig_scaling;
+
+/* NxSignal.Windows — lib/nx_signal/windows.ex */
+typedef enum nxsig_window_kind {
+  NXSIG_WIN_RECTANGULAR = 0, /* :33  */
+  NXSIG_WIN_BARTLETT = 1,    /* :57  */
+  NXSIG_WIN_TRIANGULAR = 2,  /* :98  */
+  NXSIG_WIN_BLACKMAN = 3,    /* :160 */
+  NXSIG_WIN_HAMMING = 4,     /* :225 */
+  NXSIG_WIN_HANN = 5,        /* :278 */
+  NXSIG_WIN_KAISER = 6       /* :341 */
+} nxsig_window_kind;
+
+/* Convolution modes — lib/nx_signal/convolution.ex:300-329 */
+typedef enum nxsig_conv_mode { NXSIG_CONV_FULL = 0, NXSIG_CONV_SAME = 1, NXSIG_CONV_VALID = 2 } nxsig_conv_mode;
+
+/* options of NxSignal.stft/3 (lib/nx_signal.ex:71-85) and istft/3 (:583) after default resolution */
+typedef struct nxsig_stft_params {
+  int32_t frame_length;  /* N = size of the window tensor (:69) */
+  int32_t hop;           /* N - overlap_length (:99, :702) */
+  int32_t fft_length;    /* K; :power_of_two already resolved by the caller (nxsig_next_pow2) */
+  int32_t pad_mode;      /* nxsig_pad (stft only) */
+  int64_t pad_lo, pad_hi;/* NXSIG_PAD_EXPLICIT only */
+  int32_t scaling;       /* nxsig_scaling */
+  int32_t reserved;
+  double sampling_rate;  /* used by :psd scaling only */
+} nxsig_stft_params;
+
+/* ---------------------------------------------------------------- context / errors ---- */
+int nxsig_abi_version(void);
+int nxsig_device_count(int* count);
+int nxsig_ctx_create(int device, nxsig_ctx** out);
+void nxsig_ctx_destroy(nxsig_ctx* ctx);
+const char* nxsig_last_error(void); /* thread-local, valid until the next call on this thread */
+/* human readable device line ("AMD Instinct MI355X gfx950 256 CUs") into buf */
+int nxsig_device_name(nxsig_ctx* ctx, char* buf, size_t buflen);
+
+/* ---------------------------------------------------------------- memory / stream ----- */
+int nxsig_alloc(nxsig_ctx* ctx, size_t bytes, void** dptr);
+int nxsig_free(nxsig_ctx* ctx, void* dptr);
+int nxsig_upload(nxsig_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);   /* synchronous */
+int nxsig_download(nxsig_ctx* ctx, void* dst_host, const void* src_device, size_t bytes); /* synchronous */
+int nxsig_sync(nxsig_ctx* ctx);                       /* wait for everything enqueued on the ctx stream */
+int nxsig_set_stream(nxsig_ctx* ctx, void* hip_stream); /* adopt a caller-owned hipStream_t (NULL = own stream) */
+void* nxsig_get_stream(nxsig_ctx* ctx);
+/* HIP-event stopwatch on the ctx stream (used by bench.py: events live on the stream the kernels run on) */
+int nxsig_timer_start(nxsig_ctx* ctx);
+int nxsig_timer_stop(nxsig_ctx* ctx, float* elapsed_ms); /* records + synchronises the stop event */
+
+/* ---------------------------------------------------------------- shape helpers (pure) - */
+int32_t nxsig_next_pow2(int32_t n); /* :power_of_two of Nx.fft */
+/* number of frames of as_windowed — lib/nx_signal.ex:289-298; negative status on error */
+int64_t nxsig_num_frames(int64_t length, int32_t frame_length, int32_t hop, int32_t pad_mode, int64_t pad_lo,
+                         int64_t pad_hi);
+/* output length of overlap_and_add / istft: M*hop + (N-hop) — lib/nx_signal.ex:703 */
+int64_t nxsig_ola_length(int64_t num_frames, int32_t frame_length, int32_t hop);
+/* output length of convolve for a mode — lib/nx_signal/convolution.ex:300-347 */
+int64_t nxsig_conv_length(int64_t n1, int64_t n2, int32_t mode);
+
+/* ------------------------------------------ host-side generators (BinaryBackend rounding) */
+/* NxSignal.Windows.* (n, is_periodic:, type: f32) — lib/nx_signal/windows.ex; beta/eps: kaiser only */
+int nxsig_window_f32(int32_t kind, int32_t n, int32_t is_periodic, double beta, double eps, float* out);
+/* NxSignal.Waveforms.sinc — lib/nx_signal/waveforms.ex:451-457 */
+int nxsig_sinc_f32(const float* t, int64_t n, float* out);
+/* NxSignal.Filters.firwin/3 — lib/nx_signal/filters.ex:147-279 (cutoff in sampling_rate units) */
+int nxsig_firwin_f32(int32_t num_taps, const double* cutoff, int32_t n_cutoff, int32_t window_kind, double kaiser_beta,
+                     int32_t pass_zero, int32_t scale, double sampling_rate, float* out);
+/* NxSignal.fft_frequencies/2 — lib/nx_signal.ex:154-166 */
+int nxsig_fft_frequencies_f32(double sampling_rate, int32_t fft_length, int32_t endpoint, float* out);
+/* the `times` output of stft — lib/nx_signal.ex:108-111 */
+int nxsig_stft_times_f32(int32_t frame_length, double sampling_rate, int64_t num_frames, float* out);
+
+/* ---------------------------------------------------------------- the hot path -------- */
+/*
+ * NxSignal.stft/3 — lib/nx_signal.ex:68-130 (as_windowed :94-100, Nx.multiply :101, Nx.fft :102,
+ * scaling :113-127) fused in one launch.
+ *   x      f32[batch][length], rows `batch_stride` elements apart (batch = vectorized channels, B16)
+ *   window f32[N] HOST
+ *   z      c64[batch][M][K]
+ *   M      = nxsig_num_frames(length, N, hop, pad...) written to *num_frames_out (may be NULL)
+ */
+int nxsig_stft_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride,
+                   const float* window, const nxsig_stft_params* params, nxsig_c64* z, int64_t* num_frames_out,
+                   int32_t mem);
+
+/*
+ * NxSignal.istft/3 — lib/nx_signal.ex:582-638 (Nx.ifft :609, inverse scaling :611-625, x window and
+ * overlap_and_add :627-628, OLA(|w|^2) normaliser with the 1e-10 guard :630-637).
+ *   z c64[batch][M][K]  ->  y c64[batch][M*hop + N-hop]   (complex output)
+ *   requires fft_length == frame_length (the reference's broadcast {M,K} x {N} requires it too).
+ */
+int nxsig_istft_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
+                    const nxsig_stft_params* params, nxsig_c64* y, int32_t mem);
+
+/* NxSignal.as_windowed/2 — lib/nx_signal.ex:249-364: f32[batch][length] -> f32[batch][M][N] */
+int nxsig_as_windowed_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride,
+                          int32_t window_length, int32_t stride, int32_t pad_mode, int64_t pad_lo, int64_t pad_hi,
+                          float* out, int64_t* num_frames_out, int32_t mem);
+
+/* NxSignal.overlap_and_add/2 — lib/nx_signal.ex:684-736: [batch][M][N] -> [batch][M*hop + N-hop].
+ * `components` = 1 for f32 tensors, 2 for c64 (interleaved); deterministic (fixed frame order). */
+int nxsig_overlap_and_add(nxsig_ctx* ctx, const float* frames, int64_t num_frames, int32_t batch, int32_t frame_length,
+                          int32_t overlap_length, int32_t components, float* out, int32_t mem);
+
+/* Nx.fft / Nx.ifft(length: K) over the last axis as NxSignal.Transforms.fft_nd / ifft_nd reach them
+ * (lib/nx_signal/transforms.ex:5-21): rows of n_in elements are zero-padded / truncated to K.
+ * in: c64[rows][n_in] (in_is_real = 0) or f32[rows][n_in] (in_is_real = 1); out: c64[rows][K]. */
+int nxsig_fft(nxsig_ctx* ctx, const void* in, int32_t in_is_real, int64_t rows, int32_t n_in, int32_t fft_length,
+              int32_t inverse, nxsig_c64* out, int32_t mem);
+
+/*
+ * FIR filtering: y = Convolution.convolve(x, h, method: :fft, mode:) for real 1-D x (per batch row) and
+ * real taps h — lib/nx_signal/convolution.ex:252-329 as used by guides/filtering.livemd:126-128 —
+ * computed by overlap-save block FFT convolution (the `Filters.fir` of BASELINE config 5; the reference
+ * does one length-(L+K-1) FFT, results agree to fp32 rounding).
+ *   x f32[batch][length], h f32[num_taps] HOST, y f32[batch][nxsig_conv_length(length, num_taps, mode)]
+ */
+int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
+                  int32_t num_taps, int32_t mode, float* y, int32_t mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NXSIG_H */

@@ -1,0 +1,301 @@
+"""nx_signal_amd — MI355X-native STFT / iSTFT / FIR hot path behind the NxSignal API.
+
+Python host mirror of the reference's function-level interface (elixir-nx/nx_signal v0.3.0):
+
+    NxSignal.stft/3, istft/3, as_windowed/2, overlap_and_add/2, fft_frequencies/2   -> this module
+    NxSignal.Windows.*            -> nx_signal_amd.windows
+    NxSignal.Filters.firwin/3     -> nx_signal_amd.filters  (+ the new `fir`)
+    NxSignal.Convolution.*        -> nx_signal_amd.convolution (FFT method, 1-D)
+    NxSignal.Waveforms.sinc/1     -> nx_signal_amd.waveforms
+    NxSignal.Transforms.fft_nd    -> nx_signal_amd.transforms (last axis)
+
+Same option names, defaults, return shapes and failure cases (ArgumentError) as the reference; atoms
+become strings ("valid", "reflect", "spectrum", ...), tensors become numpy arrays (host) or DeviceBuffers
+(HBM-resident, returned when the input is device-resident).  All arithmetic runs in hand-written HIP
+kernels behind the C ABI in include/nxsig.h; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ArgumentError, NxSignalDeviceError, NxSignalLibraryError, NxSignalUnsupported, StftParams
+from .device import Context, DeviceBuffer, default_context, device_view, is_device
+
+__all__ = [
+    "stft", "istft", "as_windowed", "overlap_and_add", "fft_frequencies",
+    "Context", "DeviceBuffer", "default_context", "ArgumentError",
+    "NxSignalDeviceError", "NxSignalLibraryError", "NxSignalUnsupported",
+]
+
+_PAD_ATOMS = {"valid": _lib.PAD_VALID, "reflect": _lib.PAD_REFLECT, "same": _lib.PAD_SAME}
+_SCALING = {None: _lib.SCALE_NONE, "spectrum": _lib.SCALE_SPECTRUM, "psd": _lib.SCALE_PSD}
+
+
+def _validate(opts: dict, allowed: dict, fn: str) -> dict:
+    """Keyword.validate!/keyword! — unknown keys raise ArgumentError."""
+    unknown = [k for k in opts if k not in allowed]
+    if unknown:
+        raise ArgumentError(f"unknown keys {unknown} in {fn} options, the allowed keys are: {list(allowed)}")
+    out = dict(allowed)
+    out.update(opts)
+    return out
+
+
+def _host_f32(x, what: str) -> np.ndarray:
+    a = np.asarray(x)
+    if a.dtype == np.float32:
+        return np.ascontiguousarray(a)
+    if a.dtype.kind in "iub":  # integer tensors are legal inputs
+        return np.ascontiguousarray(a.astype(np.float32))
+    if a.dtype == np.float64:
+        raise ArgumentError(
+            f"{what}: float64 input would produce a c128 result in the reference; this path computes f32/c64 — "
+            "cast to float32 explicitly"
+        )
+    raise ArgumentError(f"{what}: unsupported dtype {a.dtype}")
+
+
+def _window_host(window) -> np.ndarray:
+    w = np.asarray(window)
+    if w.ndim != 1:
+        raise ArgumentError(f"window must be a rank-1 tensor, got shape {w.shape}")
+    if w.dtype == np.float64:
+        raise ArgumentError("window: float64 is outside this path; NxSignal.Windows produce f32")
+    return np.ascontiguousarray(w.astype(np.float32))
+
+
+def _pad_args(padding, fn="as_windowed"):
+    if isinstance(padding, str):
+        if padding not in _PAD_ATOMS:  # lib/nx_signal.ex:325-329 (":zeros" and nil raise despite the docs, B2)
+            raise ArgumentError(
+                "invalid padding mode specified, padding must be one of :valid, :same, or a padding configuration, "
+                f"got: {padding!r}"
+            )
+        return _PAD_ATOMS[padding], 0, 0
+    if isinstance(padding, (list, tuple)):
+        ok = len(padding) == 1 and len(padding[0]) == 2 and all(isinstance(v, (int, np.integer)) for v in padding[0])
+        if not ok:  # :319-323
+            raise ArgumentError(
+                "padding must be a list of {high, low} tuples, where each element is an integer. " f"Got: {padding!r}"
+            )
+        return _lib.PAD_EXPLICIT, int(padding[0][0]), int(padding[0][1])
+    raise ArgumentError(
+        "invalid padding mode specified, padding must be one of :valid, :same, or a padding configuration, "
+        f"got: {padding!r}"
+    )
+
+
+def _ctx_of(obj, ctx):
+    if ctx is not None:
+        return ctx
+    if isinstance(obj, DeviceBuffer):
+        return obj.ctx
+    return default_context()
+
+
+def _as_ptr(arr: np.ndarray):
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+def _resolve_fft_length(fft_length, n: int) -> int:
+    if fft_length in (None, "power_of_two"):
+        return int(_lib.load().nxsig_next_pow2(int(n)))
+    if isinstance(fft_length, (int, np.integer)) and fft_length >= 1:
+        return int(fft_length)
+    raise ArgumentError(f"expected :fft_length to be a positive integer or :power_of_two, got: {fft_length!r}")
+
+
+# ------------------------------------------------------------------------------------------------
+def fft_frequencies(sampling_rate, **opts):
+    """NxSignal.fft_frequencies/2 — lib/nx_signal.ex:154-166."""
+    o = _validate(opts, {"fft_length": None, "type": "f32", "name": "frequencies", "endpoint": False}, "fft_frequencies")
+    if o["fft_length"] is None:
+        raise ArgumentError("missing :fft_length option")
+    K = int(o["fft_length"])
+    out = np.empty(K, dtype=np.float32)
+    _lib.check(_lib.load().nxsig_fft_frequencies_f32(float(sampling_rate), K, int(bool(o["endpoint"])), _as_ptr(out)))
+    return out
+
+
+def as_windowed(tensor, ctx: Context | None = None, **opts):
+    """NxSignal.as_windowed/2 — lib/nx_signal.ex:249-364.  (..., L) -> (..., M, window_length)."""
+    o = _validate(opts, {"window_length": None, "padding": "valid", "stride": 1}, "as_windowed")
+    if o["window_length"] is None:
+        raise ArgumentError("missing :window_length option")
+    stride = o["stride"]
+    if not (isinstance(stride, (int, np.integer)) and stride >= 1):  # :282-284
+        raise ArgumentError(f"expected an integer >= 1 or a list of integers, got: {stride!r}")
+    mode, lo, hi = _pad_args(o["padding"])
+    N = int(o["window_length"])
+    lib = _lib.load()
+    M = C.c_int64()
+    if is_device(tensor):
+        ptr, shape, dt = device_view(tensor)
+        if dt != np.float32:
+            raise ArgumentError("as_windowed: device input must be float32")
+        c = _ctx_of(tensor, ctx)
+        L = shape[-1]
+        batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
+        m = _lib.check(lib.nxsig_num_frames(L, N, int(stride), mode, lo, hi))
+        out = c.empty(shape[:-1] + (m, N), np.float32)
+        _lib.check(lib.nxsig_as_windowed_f32(c.handle, C.c_void_p(ptr), L, batch, L, N, int(stride), mode, lo, hi,
+                                             C.c_void_p(out.ptr), C.byref(M), _lib.DEVICE))
+        return out
+    src = np.asarray(tensor)
+    x = _host_f32(src, "as_windowed")
+    c = _ctx_of(None, ctx)
+    L = x.shape[-1]
+    batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
+    m = _lib.check(lib.nxsig_num_frames(L, N, int(stride), mode, lo, hi))
+    out = np.empty(x.shape[:-1] + (m, N), dtype=np.float32)
+    _lib.check(lib.nxsig_as_windowed_f32(c.handle, _as_ptr(x), L, batch, L, N, int(stride), mode, lo, hi, _as_ptr(out),
+                                         C.byref(M), _lib.HOST))
+    if src.dtype.kind in "iub":  # framing is a pure gather: integer tensors keep their type (doctests :182-246)
+        return out.astype(src.dtype)
+    return out
+
+
+def stft(data, window, ctx: Context | None = None, **opts):
+    """NxSignal.stft/3 — lib/nx_signal.ex:68-130.  Returns (z c64[..., M, K], times f32[M], frequencies f32[K]).
+
+    Defaults follow the code, not the doc: window_padding "valid", sampling_rate 100,
+    fft_length "power_of_two", overlap_length div(N, 2); the :window key is accepted and ignored.
+    """
+    o = _validate(
+        opts,
+        {"overlap_length": None, "window": None, "scaling": None, "window_padding": "valid", "sampling_rate": 100,
+         "fft_length": "power_of_two"},
+        "stft",
+    )
+    w = _window_host(window)
+    N = int(w.shape[0])
+    if o["sampling_rate"] is None:
+        raise ArgumentError("missing sampling_rate option")  # :81
+    fs = float(o["sampling_rate"])
+    overlap = N // 2 if o["overlap_length"] is None else int(o["overlap_length"])  # :83
+    hop = N - overlap
+    if o["scaling"] not in _SCALING:  # :124-126
+        raise ArgumentError(f"invalid :scaling, expected one of :spectrum, :psd or nil, got: {o['scaling']!r}")
+    mode, lo, hi = _pad_args(o["window_padding"])
+    K = _resolve_fft_length(o["fft_length"], N)
+    p = StftParams(N, hop, K, mode, lo, hi, _SCALING[o["scaling"]], 0, fs)
+    lib = _lib.load()
+    M = C.c_int64()
+    if is_device(data):
+        ptr, shape, dt = device_view(data)
+        if dt != np.float32:
+            raise ArgumentError("stft: device input must be float32")
+        c = _ctx_of(data, ctx)
+        L = shape[-1]
+        batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
+        m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
+        z = c.empty(shape[:-1] + (m, K), np.complex64)
+        _lib.check(lib.nxsig_stft_f32(c.handle, C.c_void_p(ptr), L, batch, L, _as_ptr(w), C.byref(p), C.c_void_p(z.ptr),
+                                      C.byref(M), _lib.DEVICE))
+    else:
+        x = _host_f32(data, "stft")
+        if x.ndim < 1:
+            raise ArgumentError("stft expects a tensor of rank >= 1")
+        c = _ctx_of(None, ctx)
+        L = x.shape[-1]
+        batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
+        m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
+        z = np.empty(x.shape[:-1] + (m, K), dtype=np.complex64)
+        _lib.check(lib.nxsig_stft_f32(c.handle, _as_ptr(x), L, batch, L, _as_ptr(w), C.byref(p), _as_ptr(z), C.byref(M),
+                                      _lib.HOST))
+    times = np.empty(m, dtype=np.float32)
+    _lib.check(lib.nxsig_stft_times_f32(N, fs, m, _as_ptr(times)))
+    freqs = fft_frequencies(fs, fft_length=K)
+    return z, times, freqs
+
+
+def istft(data, window, ctx: Context | None = None, **opts):
+    """NxSignal.istft/3 — lib/nx_signal.ex:582-638.  c64[..., M, K] -> c64[..., M*hop + overlap] (complex, B8)."""
+    o = _validate(opts, {"fft_length": None, "overlap_length": None, "scaling": None, "sampling_rate": 1000}, "istft")
+    w = _window_host(window)
+    N = int(w.shape[0])
+    overlap = N // 2 if o["overlap_length"] is None else int(o["overlap_length"])  # :594-601
+    if o["scaling"] not in _SCALING:  # :622-624
+        raise ArgumentError(f"invalid :scaling, expected one of :spectrum, :psd or nil, got: {o['scaling']!r}")
+    if o["scaling"] == "psd" and o["sampling_rate"] is None:  # :605
+        raise ArgumentError(":sampling_rate is mandatory if scaling is :psd")
+    fs = float(o["sampling_rate"]) if o["sampling_rate"] is not None else 0.0
+    if overlap >= N:  # overlap_and_add check, :692-695
+        raise ArgumentError(f"overlap_length must be a number less than the window size {N}, got: {N}")
+    hop = N - overlap
+    lib = _lib.load()
+    if is_device(data):
+        ptr, shape, dt = device_view(data)
+        if dt != np.complex64:
+            raise ArgumentError("istft: device input must be complex64")
+        c = _ctx_of(data, ctx)
+    else:
+        zin = np.asarray(data)
+        if zin.dtype == np.complex128:
+            raise ArgumentError("istft: complex128 input is outside this path; cast to complex64")
+        zin = np.ascontiguousarray(zin.astype(np.complex64))
+        shape = zin.shape
+        c = _ctx_of(None, ctx)
+    if len(shape) < 2:
+        raise ArgumentError("istft expects a tensor of shape {..., frames, frequencies}")
+    Mf, Kin = int(shape[-2]), int(shape[-1])
+    K = _resolve_fft_length(o["fft_length"], Kin)
+    if K != Kin:
+        raise NxSignalUnsupported("istft: fft_length different from the spectrum's last axis (ifft pad/truncate) is not built")
+    batch = int(np.prod(shape[:-2], dtype=np.int64)) if len(shape) > 2 else 1
+    p = StftParams(N, hop, K, 0, 0, 0, _SCALING[o["scaling"]], 0, fs)
+    out_len = _lib.check(lib.nxsig_ola_length(Mf, N, hop))
+    if is_device(data):
+        y = c.empty(tuple(shape[:-2]) + (out_len,), np.complex64)
+        _lib.check(lib.nxsig_istft_c64(c.handle, C.c_void_p(ptr), Mf, batch, _as_ptr(w), C.byref(p), C.c_void_p(y.ptr), _lib.DEVICE))
+        return y
+    y = np.empty(tuple(shape[:-2]) + (out_len,), dtype=np.complex64)
+    _lib.check(lib.nxsig_istft_c64(c.handle, _as_ptr(zin), Mf, batch, _as_ptr(w), C.byref(p), _as_ptr(y), _lib.HOST))
+    return y
+
+
+def overlap_and_add(tensor, ctx: Context | None = None, **opts):
+    """NxSignal.overlap_and_add/2 — lib/nx_signal.ex:684-736.  {..., M, N} -> {..., M*hop + overlap}."""
+    o = _validate(opts, {"overlap_length": None, "type": None}, "overlap_and_add")
+    if o["overlap_length"] is None:
+        raise ArgumentError("missing :overlap_length option")
+    overlap = int(o["overlap_length"])
+    lib = _lib.load()
+    dev = is_device(tensor)
+    if dev:
+        ptr, shape, dt = device_view(tensor)
+        c = _ctx_of(tensor, ctx)
+        src_dtype = dt
+    else:
+        src = np.asarray(tensor)
+        src_dtype = src.dtype
+        if src.dtype.kind == "c":
+            arr = np.ascontiguousarray(src.astype(np.complex64))
+        else:
+            arr = _host_f32(src, "overlap_and_add")
+        shape, dt = arr.shape, arr.dtype
+    if len(shape) < 2:
+        raise ArgumentError("overlap_and_add expects a tensor of shape {..., M, N}")
+    Mf, N = int(shape[-2]), int(shape[-1])
+    if overlap >= N:  # :692-695 — the message prints the window size twice (quirk B10)
+        raise ArgumentError(f"overlap_length must be a number less than the window size {N}, got: {N}")
+    if not dev:
+        c = _ctx_of(None, ctx)
+    comps = 2 if np.dtype(dt) == np.complex64 else 1
+    batch = int(np.prod(shape[:-2], dtype=np.int64)) if len(shape) > 2 else 1
+    out_len = Mf * (N - overlap) + overlap
+    out_shape = tuple(shape[:-2]) + (out_len,)
+    if dev:
+        out = c.empty(out_shape, dt)
+        _lib.check(lib.nxsig_overlap_and_add(c.handle, C.c_void_p(ptr), Mf, batch, N, overlap, comps, C.c_void_p(out.ptr), _lib.DEVICE))
+        return out
+    out = np.empty(out_shape, dtype=dt)
+    _lib.check(lib.nxsig_overlap_and_add(c.handle, _as_ptr(arr), Mf, batch, N, overlap, comps, _as_ptr(out), _lib.HOST))
+    target = o["type"] if o["type"] is not None else src_dtype  # code default: the input type (:685, B10)
+    return out.astype(target) if np.dtype(target) != out.dtype else out
+
+
+from . import convolution, filters, transforms, waveforms, windows  # noqa: E402,F401

@@ -1,0 +1,73 @@
+"""Builds libnxsig.so (HIP kernels + C ABI) for gfx950 in-tree with hipcc.
+
+    python -m nx_signal_amd.build            # incremental
+    python -m nx_signal_amd.build --force
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
+gpurun snapshot.  No torch, no cmake: three translation units and one link line.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(HERE, "libnxsig.so")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+
+ARCH = "gfx950"
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}"]
+UNITS = [
+    # (source, extra flags)
+    ("host_numerics.cpp", ["-x", "hip", "-ffp-contract=off"]),  # BinaryBackend rounding: no FMA contraction
+    ("api.cpp", ["-x", "hip"]),
+    ("kernels_generic.hip", []),
+    ("kernels_wave.hip", []),
+]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the nxsig product path cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+        os.path.join(ROOT, "include", "nxsig.h"),
+        os.path.abspath(__file__),
+    ]
+    objs = []
+    cc = hipcc()
+    for src, extra in UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [cc, f"--offload-arch={ARCH}", *COMMON, *extra, "-c", s, "-o", o]
+            if verbose:
+                print("[nxsig build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(OUT, objs):
+        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", OUT]
+        if verbose:
+            print("[nxsig build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

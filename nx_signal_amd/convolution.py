@@ -1,0 +1,87 @@
+"""NxSignal.Convolution (FFT method, 1-D real) — lib/nx_signal/convolution.ex:38-58, :252-347.
+
+`method: :direct` (n-D Nx.conv) is out of scope for the hot path and raises
+NxSignalUnsupported; the FFT method is served by the overlap-save kernel."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ArgumentError, NxSignalUnsupported
+from .device import default_context, device_view, is_device
+
+_MODES = {"full": _lib.CONV_FULL, "same": _lib.CONV_SAME, "valid": _lib.CONV_VALID}
+
+
+def convolve(in1, in2, ctx=None, **opts):
+    allowed = {"mode": "full", "method": "direct"}
+    unknown = [k for k in opts if k not in allowed]
+    if unknown:
+        raise ArgumentError(f"unknown keys {unknown} in convolve options, the allowed keys are: {list(allowed)}")
+    o = dict(allowed)
+    o.update(opts)
+    if o["mode"] not in _MODES:  # convolution.ex:41-44 (mode is validated before method, quirk B12)
+        raise ArgumentError(f"expected mode to be one of [:full, :same, :valid], got: {o['mode']!r}")
+    if o["method"] not in ("direct", "fft"):  # :46-49
+        raise ArgumentError(f"expected method to be one of [:direct, :fft], got: {o['method']!r}")
+    if o["method"] == "direct":
+        raise NxSignalUnsupported("convolve(method: :direct) (n-D Nx.conv) is outside the FFT/FIR hot path; use method='fft'")
+    return fftconvolve(in1, in2, ctx=ctx, mode=o["mode"])
+
+
+def fftconvolve(in1, in2, ctx=None, **opts):
+    """1-D real case of fftconvolve: the longer operand streams through HBM, the shorter one is the FIR kernel.
+    in1 may carry leading batch axes (independent channels) when it is the signal."""
+    allowed = {"mode": "full", "method": "direct"}  # :method accepted and ignored (quirk B12)
+    unknown = [k for k in opts if k not in allowed]
+    if unknown:
+        raise ArgumentError(f"unknown keys {unknown} in fftconvolve options, the allowed keys are: {list(allowed)}")
+    mode = opts.get("mode", "full")
+    if mode not in _MODES:
+        raise ArgumentError(f"expected mode to be one of [:full, :same, :valid], got: {mode!r}")
+    lib = _lib.load()
+    dev = is_device(in1)
+    h = np.asarray(in2) if not is_device(in2) else None
+    if h is None:
+        raise ArgumentError("fftconvolve: the second operand (filter taps) must be a host tensor")
+    if np.iscomplexobj(h) or (not dev and np.iscomplexobj(np.asarray(in1))):
+        raise NxSignalUnsupported("complex fftconvolve is not built yet (real 1-D FIR path only)")
+    if h.ndim != 1:
+        raise NxSignalUnsupported("fftconvolve: n-D kernels are outside the hot path")
+    h32 = np.ascontiguousarray(h.astype(np.float32))
+    if dev:
+        ptr, shape, dt = device_view(in1)
+        if dt != np.float32:
+            raise ArgumentError("fftconvolve: device input must be float32")
+        c = ctx or getattr(in1, "ctx", None) or default_context()
+        L = int(shape[-1])
+        batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
+        n_out = _lib.check(lib.nxsig_conv_length(L, h32.size, _MODES[mode]))
+        y = c.empty(tuple(shape[:-1]) + (n_out,), np.float32)
+        _lib.check(lib.nxsig_fir_f32(c.handle, C.c_void_p(ptr), L, batch, L, h32.ctypes.data_as(C.c_void_p), h32.size,
+                                     _MODES[mode], C.c_void_p(y.ptr), _lib.DEVICE))
+        return y
+    a = np.asarray(in1)
+    if a.ndim != 1 and a.ndim != h.ndim and a.ndim < 1:
+        raise ArgumentError("Rank of in1 and in2 must be equal.")
+    if a.dtype == np.float64 or h.dtype == np.float64:
+        raise ArgumentError("fftconvolve: float64 is outside this path (f32/c64); cast to float32 explicitly")
+    x = np.ascontiguousarray(a.astype(np.float32))
+    if x.ndim == 1 and x.shape[0] < h32.shape[0]:
+        x, h32 = h32, x  # convolution commutes; keep the longer operand as the stream
+        if mode == "same":
+            # :same is centred on in1 (convolution.ex:304-306): compute full and slice like the reference
+            full = fftconvolve(x, h32, ctx=ctx, mode="full")
+            new = a.shape[0]
+            start = (full.shape[0] - new) // 2
+            return full[start:start + new]
+    c = ctx or default_context()
+    L = int(x.shape[-1])
+    batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
+    n_out = _lib.check(lib.nxsig_conv_length(L, h32.size, _MODES[mode]))
+    y = np.empty(x.shape[:-1] + (n_out,), dtype=np.float32)
+    _lib.check(lib.nxsig_fir_f32(c.handle, x.ctypes.data_as(C.c_void_p), L, batch, L, h32.ctypes.data_as(C.c_void_p),
+                                 h32.size, _MODES[mode], y.ctypes.data_as(C.c_void_p), _lib.HOST))
+    return y

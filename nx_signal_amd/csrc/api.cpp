@@ -1,0 +1,611 @@
+// C-ABI entry points declared in include/nxsig.h.  Validates arguments the way the reference's
+// deftransforms do (same failure cases -> NXSIG_ERR_INVALID_ARG, which the host mirrors turn into
+// ArgumentError), resolves framing geometry, stages host buffers when asked to, and enqueues the HIP
+// kernels on the context's stream.  No C++ exception may leave this file: every entry point is wrapped.
+#include <cmath>
+#include <cstring>
+#include <exception>
+#include <new>
+
+#include "nxsig_internal.h"
+
+namespace nxsig {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+const char* last_error_cstr() { return g_last_error.c_str(); }
+
+uint64_t fnv1a(uint64_t seed, const void* data, size_t bytes) {
+  uint64_t h = 1469598103934665603ull ^ seed;
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  for (size_t i = 0; i < bytes; ++i) {
+    h ^= p[i];
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+int make_framing(int64_t L, int32_t N, int32_t hop, int32_t pad_mode, int64_t pad_lo, int64_t pad_hi, Framing* out) {
+  if (N < 1) return set_error(NXSIG_ERR_INVALID_ARG, "window_length must be >= 1");
+  if (hop < 1)  // lib/nx_signal.ex:282-284
+    return set_error(NXSIG_ERR_INVALID_ARG, "expected an integer >= 1 or a list of integers, got: " + std::to_string(hop));
+  if (L < 1) return set_error(NXSIG_ERR_INVALID_ARG, "signal length must be >= 1");
+  Framing f;
+  f.L = L; f.N = N; f.hop = hop; f.reflect = 0; f.lo = 0; f.hi = 0;
+  switch (pad_mode) {
+    case NXSIG_PAD_VALID: break;
+    case NXSIG_PAD_REFLECT: f.reflect = 1; f.lo = N / 2; f.hi = N / 2; break;                 // :262
+    case NXSIG_PAD_SAME: { const int64_t tot = N - 1; f.lo = tot / 2; f.hi = tot - tot / 2; } break;  // :308-312
+    case NXSIG_PAD_EXPLICIT: f.lo = pad_lo; f.hi = pad_hi; break;
+    default:  // :325-329
+      return set_error(NXSIG_ERR_INVALID_ARG,
+                       "invalid padding mode specified, padding must be one of :valid, :same, or a padding configuration");
+  }
+  const int64_t Lp = L + f.lo + f.hi;
+  if (Lp < N)
+    return set_error(NXSIG_ERR_INVALID_ARG, "window of length " + std::to_string(N) +
+                                                " does not fit the (padded) signal of length " + std::to_string(Lp));
+  f.M = (Lp - N) / hop + 1;  // pooled shape of Nx.window_max, :289-298
+  *out = f;
+  return NXSIG_OK;
+}
+
+int ctx_twiddles(Ctx* c, int K, const float2** out) {
+  auto it = c->twiddles.find(K);
+  if (it == c->twiddles.end()) {
+    std::vector<float2> tw(K);
+    for (int j = 0; j < K; ++j) {
+      const double ang = -2.0 * 3.14159265358979323846 * (double)j / (double)K;
+      tw[j] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    DeviceTable t;
+    t.bytes = (size_t)K * sizeof(float2);
+    NXSIG_HIP_TRY(hipMalloc(&t.ptr, t.bytes));
+    NXSIG_HIP_TRY(hipMemcpyAsync(t.ptr, tw.data(), t.bytes, hipMemcpyHostToDevice, c->stream));
+    NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));  // tw goes out of scope
+    it = c->twiddles.emplace(K, t).first;
+  }
+  *out = reinterpret_cast<const float2*>(it->second.ptr);
+  return NXSIG_OK;
+}
+
+int ctx_table(Ctx* c, uint64_t tag, const void* host, size_t bytes, const void** out) {
+  const uint64_t key = fnv1a(tag, host, bytes) ^ (uint64_t)bytes;
+  auto it = c->tables.find(key);
+  if (it == c->tables.end()) {
+    DeviceTable t;
+    t.bytes = bytes;
+    NXSIG_HIP_TRY(hipMalloc(&t.ptr, bytes ? bytes : 4));
+    NXSIG_HIP_TRY(hipMemcpyAsync(t.ptr, host, bytes, hipMemcpyHostToDevice, c->stream));
+    NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+    it = c->tables.emplace(key, t).first;
+  }
+  *out = it->second.ptr;
+  return NXSIG_OK;
+}
+
+int ctx_scratch(Ctx* c, int slot, size_t bytes, void** out) {
+  if (c->scratch_bytes[slot] < bytes) {
+    if (c->scratch[slot]) {
+      NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+      NXSIG_HIP_TRY(hipFree(c->scratch[slot]));
+      c->scratch[slot] = nullptr;
+      c->scratch_bytes[slot] = 0;
+    }
+    NXSIG_HIP_TRY(hipMalloc(&c->scratch[slot], bytes));
+    c->scratch_bytes[slot] = bytes;
+  }
+  *out = c->scratch[slot];
+  return NXSIG_OK;
+}
+
+// declared here, implemented in the .hip files
+int launch_stft_generic(Ctx* c, const StftLaunch& a);
+int launch_istft_generic(Ctx* c, const IstftLaunch& a);
+int launch_fir_generic(Ctx* c, const FirLaunch& a);
+int launch_stft_wave(Ctx* c, const StftLaunch& a, bool* handled);
+int launch_istft_wave(Ctx* c, const IstftLaunch& a, bool* handled);
+int launch_fir_wave(Ctx* c, const FirLaunch& a, bool* handled);
+
+int launch_stft(Ctx* c, const StftLaunch& a) {
+  bool handled = false;
+  int rc = launch_stft_wave(c, a, &handled);
+  if (rc || handled) return rc;
+  return launch_stft_generic(c, a);
+}
+int launch_istft(Ctx* c, const IstftLaunch& a) {
+  bool handled = false;
+  int rc = launch_istft_wave(c, a, &handled);
+  if (rc || handled) return rc;
+  return launch_istft_generic(c, a);
+}
+int launch_fir(Ctx* c, const FirLaunch& a) {
+  bool handled = false;
+  int rc = launch_fir_wave(c, a, &handled);
+  if (rc || handled) return rc;
+  return launch_fir_generic(c, a);
+}
+
+struct DeviceGuard {
+  explicit DeviceGuard(Ctx* c) : lock(c->mu) {
+    ok = (hipSetDevice(c->device) == hipSuccess);
+    // bound the content-addressed table cache.  Done at API entry only, never while a call holds table pointers.
+    if (ok && c->tables.size() > 256) {
+      (void)hipStreamSynchronize(c->stream);
+      for (auto& kv : c->tables) (void)hipFree(kv.second.ptr);
+      c->tables.clear();
+    }
+  }
+  std::lock_guard<std::mutex> lock;
+  bool ok;
+};
+
+// staging of host signal buffers through scratch slots (convenience path, PCIe-bound)
+struct Staged {
+  Ctx* c;
+  explicit Staged(Ctx* ctx) : c(ctx) {}
+  int in(int slot, const void* host, size_t bytes, const void** dev) {
+    void* d = nullptr;
+    int rc = ctx_scratch(c, slot, bytes ? bytes : 4, &d);
+    if (rc) return rc;
+    NXSIG_HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = d;
+    return NXSIG_OK;
+  }
+  int out_alloc(int slot, size_t bytes, void** dev) { return ctx_scratch(c, slot, bytes ? bytes : 4, dev); }
+  int out_copy(void* host, const void* dev, size_t bytes) {
+    NXSIG_HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+    return NXSIG_OK;
+  }
+};
+
+}  // namespace nxsig
+
+using namespace nxsig;
+
+#define NXSIG_API_BEGIN try {
+#define NXSIG_API_END                                                                   \
+  }                                                                                     \
+  catch (const std::bad_alloc&) { return set_error(NXSIG_ERR_OOM, "host out of memory"); } \
+  catch (const std::exception& e) { return set_error(NXSIG_ERR_INVALID_ARG, std::string("internal error: ") + e.what()); } \
+  catch (...) { return set_error(NXSIG_ERR_INVALID_ARG, "internal error"); }
+
+#define NXSIG_CHECK_CTX(ctx)                                                            \
+  if (!(ctx)) return set_error(NXSIG_ERR_INVALID_ARG, "null context");                  \
+  Ctx* c = reinterpret_cast<Ctx*>(ctx);                                                 \
+  DeviceGuard guard(c);                                                                 \
+  if (!guard.ok) return set_error(NXSIG_ERR_HIP, "hipSetDevice failed");
+
+static int check_mem(int32_t mem) {
+  if (mem != NXSIG_HOST && mem != NXSIG_DEVICE) return set_error(NXSIG_ERR_INVALID_ARG, "mem must be NXSIG_HOST or NXSIG_DEVICE");
+  return NXSIG_OK;
+}
+
+extern "C" {
+
+int nxsig_abi_version(void) { return NXSIG_ABI_VERSION; }
+
+const char* nxsig_last_error(void) { return last_error_cstr(); }
+
+int nxsig_device_count(int* count) {
+  NXSIG_API_BEGIN
+  if (!count) return set_error(NXSIG_ERR_INVALID_ARG, "count is null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return set_error(NXSIG_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+  *count = n;
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_ctx_create(int device, nxsig_ctx** out) {
+  NXSIG_API_BEGIN
+  if (!out) return set_error(NXSIG_ERR_INVALID_ARG, "out is null");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return set_error(NXSIG_ERR_NO_DEVICE, "no ROCm-capable device: the nxsig hot path has no CPU fallback");
+  if (device < 0 || device >= n) return set_error(NXSIG_ERR_INVALID_ARG, "device index out of range");
+  NXSIG_HIP_TRY(hipSetDevice(device));
+  Ctx* c = new Ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  NXSIG_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  c->num_cus = prop.multiProcessorCount;
+  c->dev_name = std::string(prop.name) + " " + prop.gcnArchName + " " + std::to_string(prop.multiProcessorCount) + " CUs";
+  NXSIG_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  NXSIG_HIP_TRY(hipEventCreate(&c->ev_start));
+  NXSIG_HIP_TRY(hipEventCreate(&c->ev_stop));
+  *out = reinterpret_cast<nxsig_ctx*>(c);
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+void nxsig_ctx_destroy(nxsig_ctx* ctx) {
+  if (!ctx) return;
+  Ctx* c = reinterpret_cast<Ctx*>(ctx);
+  try {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->twiddles) (void)hipFree(kv.second.ptr);
+    for (auto& kv : c->tables) (void)hipFree(kv.second.ptr);
+    for (auto& s : c->scratch) if (s) (void)hipFree(s);
+    (void)hipEventDestroy(c->ev_start);
+    (void)hipEventDestroy(c->ev_stop);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  } catch (...) {
+  }
+  delete c;
+}
+
+int nxsig_device_name(nxsig_ctx* ctx, char* buf, size_t buflen) {
+  NXSIG_API_BEGIN
+  if (!ctx || !buf || buflen == 0) return set_error(NXSIG_ERR_INVALID_ARG, "bad arguments");
+  Ctx* c = reinterpret_cast<Ctx*>(ctx);
+  std::strncpy(buf, c->dev_name.c_str(), buflen - 1);
+  buf[buflen - 1] = 0;
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_alloc(nxsig_ctx* ctx, size_t bytes, void** dptr) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!dptr) return set_error(NXSIG_ERR_INVALID_ARG, "dptr is null");
+  NXSIG_HIP_TRY(hipMalloc(dptr, bytes ? bytes : 4));
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_free(nxsig_ctx* ctx, void* dptr) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!dptr) return NXSIG_OK;
+  NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+  NXSIG_HIP_TRY(hipFree(dptr));
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_upload(nxsig_ctx* ctx, void* dst_device, const void* src_host, size_t bytes) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  NXSIG_HIP_TRY(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+  NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_download(nxsig_ctx* ctx, void* dst_host, const void* src_device, size_t bytes) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  NXSIG_HIP_TRY(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, c->stream));
+  NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_sync(nxsig_ctx* ctx) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_set_stream(nxsig_ctx* ctx, void* hip_stream) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->own_stream) NXSIG_HIP_TRY(hipStreamDestroy(c->stream));
+  if (hip_stream) {
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+  } else {
+    NXSIG_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+void* nxsig_get_stream(nxsig_ctx* ctx) { return ctx ? reinterpret_cast<Ctx*>(ctx)->stream : nullptr; }
+
+int nxsig_timer_start(nxsig_ctx* ctx) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  NXSIG_HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_timer_stop(nxsig_ctx* ctx, float* elapsed_ms) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!elapsed_ms) return set_error(NXSIG_ERR_INVALID_ARG, "elapsed_ms is null");
+  NXSIG_HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+  NXSIG_HIP_TRY(hipEventSynchronize(c->ev_stop));
+  NXSIG_HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev_start, c->ev_stop));
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+/* ---------------------------------------------------------------- shape helpers */
+int32_t nxsig_next_pow2(int32_t n) {
+  int32_t p = 1;
+  while (p < n && p < (1 << 30)) p <<= 1;
+  return p;
+}
+
+int64_t nxsig_num_frames(int64_t length, int32_t frame_length, int32_t hop, int32_t pad_mode, int64_t pad_lo,
+                         int64_t pad_hi) {
+  Framing f;
+  int rc = make_framing(length, frame_length, hop, pad_mode, pad_lo, pad_hi, &f);
+  return rc ? (int64_t)rc : f.M;
+}
+
+int64_t nxsig_ola_length(int64_t num_frames, int32_t frame_length, int32_t hop) {
+  if (num_frames < 0 || frame_length < 1 || hop < 1 || hop > frame_length)
+    return set_error(NXSIG_ERR_INVALID_ARG, "ola_length: need num_frames >= 0 and 1 <= hop <= frame_length");
+  return num_frames * hop + (frame_length - hop);
+}
+
+int64_t nxsig_conv_length(int64_t n1, int64_t n2, int32_t mode) {
+  if (n1 < 1 || n2 < 1) return set_error(NXSIG_ERR_INVALID_ARG, "conv_length: lengths must be >= 1");
+  switch (mode) {
+    case NXSIG_CONV_FULL: return n1 + n2 - 1;
+    case NXSIG_CONV_SAME: return n1;
+    case NXSIG_CONV_VALID: return (n1 >= n2 ? n1 - n2 : n2 - n1) + 1;
+    default: return set_error(NXSIG_ERR_INVALID_ARG, "expected mode to be one of [:full, :same, :valid]");
+  }
+}
+
+/* ---------------------------------------------------------------- host generators */
+int nxsig_window_f32(int32_t kind, int32_t n, int32_t is_periodic, double beta, double eps, float* out) {
+  NXSIG_API_BEGIN
+  return window_f32(kind, n, is_periodic != 0, beta, eps, out);
+  NXSIG_API_END
+}
+
+int nxsig_sinc_f32(const float* t, int64_t n, float* out) {
+  NXSIG_API_BEGIN
+  if (n < 0 || (n > 0 && (!t || !out))) return set_error(NXSIG_ERR_INVALID_ARG, "sinc: bad arguments");
+  sinc_f32(t, n, out);
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_firwin_f32(int32_t num_taps, const double* cutoff, int32_t n_cutoff, int32_t window_kind, double kaiser_beta,
+                     int32_t pass_zero, int32_t scale, double sampling_rate, float* out) {
+  NXSIG_API_BEGIN
+  return firwin_f32(num_taps, cutoff, n_cutoff, window_kind, kaiser_beta, pass_zero != 0, scale != 0, sampling_rate, out);
+  NXSIG_API_END
+}
+
+int nxsig_fft_frequencies_f32(double sampling_rate, int32_t fft_length, int32_t endpoint, float* out) {
+  NXSIG_API_BEGIN
+  if (fft_length < 1 || !out) return set_error(NXSIG_ERR_INVALID_ARG, "fft_frequencies: fft_length must be >= 1");
+  fft_frequencies_f32(sampling_rate, fft_length, endpoint != 0, out);
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_stft_times_f32(int32_t frame_length, double sampling_rate, int64_t num_frames, float* out) {
+  NXSIG_API_BEGIN
+  if (num_frames < 0 || (num_frames > 0 && !out)) return set_error(NXSIG_ERR_INVALID_ARG, "stft_times: bad arguments");
+  stft_times_f32(frame_length, sampling_rate, num_frames, out);
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+/* ---------------------------------------------------------------- hot path */
+static int check_scaling(int32_t s) {
+  if (s != NXSIG_SCALE_NONE && s != NXSIG_SCALE_SPECTRUM && s != NXSIG_SCALE_PSD)  // lib/nx_signal.ex:124-126, :622-624
+    return set_error(NXSIG_ERR_INVALID_ARG, "invalid :scaling, expected one of :spectrum, :psd or nil");
+  return NXSIG_OK;
+}
+
+int nxsig_stft_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride,
+                   const float* window, const nxsig_stft_params* p, nxsig_c64* z, int64_t* num_frames_out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!x || !window || !p || !z) return set_error(NXSIG_ERR_INVALID_ARG, "stft: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch must be in [1, 65535]");
+  if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch_stride < length");
+  if (p->fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft: fft_length must be >= 1");
+  rc = check_scaling(p->scaling);
+  if (rc) return rc;
+  Framing fr;
+  rc = make_framing(length, p->frame_length, p->hop, p->pad_mode, p->pad_lo, p->pad_hi, &fr);
+  if (rc) return rc;
+  if (num_frames_out) *num_frames_out = fr.M;
+
+  StftLaunch a;
+  a.fr = fr; a.batch = batch; a.batch_stride = batch_stride; a.K = p->fft_length;
+  a.has_scale = p->scaling != NXSIG_SCALE_NONE;
+  a.inv_scale_div = a.has_scale ? scaling_factor(window, p->frame_length, p->scaling, p->sampling_rate) : 1.0f;
+  const void* wdev = nullptr;
+  rc = ctx_table(c, 0x57494Eull, window, (size_t)p->frame_length * sizeof(float), &wdev);
+  if (rc) return rc;
+  a.window = reinterpret_cast<const float*>(wdev);
+  const size_t zbytes = (size_t)batch * fr.M * p->fft_length * sizeof(float2);
+  if (mem == NXSIG_DEVICE) {
+    a.x = x; a.z = reinterpret_cast<float2*>(z);
+    return launch_stft(c, a);
+  }
+  Staged st(c);
+  const void* xd = nullptr; void* zd = nullptr;
+  const size_t xbytes = ((size_t)(batch - 1) * batch_stride + length) * sizeof(float);
+  if ((rc = st.in(1, x, xbytes, &xd))) return rc;
+  if ((rc = st.out_alloc(2, zbytes, &zd))) return rc;
+  a.x = reinterpret_cast<const float*>(xd); a.z = reinterpret_cast<float2*>(zd);
+  if ((rc = launch_stft(c, a))) return rc;
+  return st.out_copy(z, zd, zbytes);
+  NXSIG_API_END
+}
+
+int nxsig_istft_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
+                    const nxsig_stft_params* p, nxsig_c64* y, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!z || !window || !p || !y) return set_error(NXSIG_ERR_INVALID_ARG, "istft: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "istft: batch must be in [1, 65535]");
+  if (num_frames < 1) return set_error(NXSIG_ERR_INVALID_ARG, "istft: num_frames must be >= 1");
+  rc = check_scaling(p->scaling);
+  if (rc) return rc;
+  const int N = p->frame_length, hop = p->hop, K = p->fft_length;
+  if (N < 1 || hop < 1) return set_error(NXSIG_ERR_INVALID_ARG, "istft: frame_length and hop must be >= 1");
+  if (hop > N)  // overlap_length < 0 cannot be expressed; overlap >= N -> hop <= 0 handled above (lib/nx_signal.ex:692-695)
+    return set_error(NXSIG_ERR_INVALID_ARG, "overlap_length must be a number less than the window size");
+  if (K != N)
+    return set_error(NXSIG_ERR_INVALID_ARG,
+                     "istft: fft_length must equal the window length (the reference broadcasts {M,K} x {N}, lib/nx_signal.ex:628)");
+  IstftLaunch a;
+  a.M = num_frames; a.batch = batch; a.N = N; a.hop = hop; a.K = K;
+  a.has_scale = p->scaling != NXSIG_SCALE_NONE;
+  a.scale_mul = a.has_scale ? scaling_factor(window, N, p->scaling, p->sampling_rate) : 1.0f;
+  const void* wdev = nullptr;
+  rc = ctx_table(c, 0x57494Eull, window, (size_t)N * sizeof(float), &wdev);
+  if (rc) return rc;
+  a.window = reinterpret_cast<const float*>(wdev);
+  const int64_t out_len = num_frames * hop + (N - hop);
+  const size_t zbytes = (size_t)batch * num_frames * K * sizeof(float2), ybytes = (size_t)batch * out_len * sizeof(float2);
+  if (mem == NXSIG_DEVICE) {
+    a.z = reinterpret_cast<const float2*>(z); a.y = reinterpret_cast<float2*>(y);
+    return launch_istft(c, a);
+  }
+  Staged st(c);
+  const void* zd = nullptr; void* yd = nullptr;
+  if ((rc = st.in(1, z, zbytes, &zd))) return rc;
+  if ((rc = st.out_alloc(2, ybytes, &yd))) return rc;
+  a.z = reinterpret_cast<const float2*>(zd); a.y = reinterpret_cast<float2*>(yd);
+  if ((rc = launch_istft(c, a))) return rc;
+  return st.out_copy(y, yd, ybytes);
+  NXSIG_API_END
+}
+
+int nxsig_as_windowed_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride,
+                          int32_t window_length, int32_t stride, int32_t pad_mode, int64_t pad_lo, int64_t pad_hi,
+                          float* out, int64_t* num_frames_out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!x || !out) return set_error(NXSIG_ERR_INVALID_ARG, "as_windowed: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "as_windowed: batch must be in [1, 65535]");
+  if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "as_windowed: batch_stride < length");
+  Framing fr;
+  rc = make_framing(length, window_length, stride, pad_mode, pad_lo, pad_hi, &fr);
+  if (rc) return rc;
+  if (num_frames_out) *num_frames_out = fr.M;
+  const size_t obytes = (size_t)batch * fr.M * fr.N * sizeof(float);
+  if (mem == NXSIG_DEVICE) return launch_as_windowed(c, x, batch_stride, batch, fr, out);
+  Staged st(c);
+  const void* xd = nullptr; void* od = nullptr;
+  const size_t xbytes = ((size_t)(batch - 1) * batch_stride + length) * sizeof(float);
+  if ((rc = st.in(1, x, xbytes, &xd))) return rc;
+  if ((rc = st.out_alloc(2, obytes, &od))) return rc;
+  if ((rc = launch_as_windowed(c, reinterpret_cast<const float*>(xd), batch_stride, batch, fr, reinterpret_cast<float*>(od)))) return rc;
+  return st.out_copy(out, od, obytes);
+  NXSIG_API_END
+}
+
+int nxsig_overlap_and_add(nxsig_ctx* ctx, const float* frames, int64_t num_frames, int32_t batch, int32_t frame_length,
+                          int32_t overlap_length, int32_t components, float* out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!frames || !out) return set_error(NXSIG_ERR_INVALID_ARG, "overlap_and_add: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (components != 1 && components != 2) return set_error(NXSIG_ERR_INVALID_ARG, "overlap_and_add: components must be 1 (f32) or 2 (c64)");
+  if (batch < 1 || batch > 65535 || num_frames < 1 || frame_length < 1)
+    return set_error(NXSIG_ERR_INVALID_ARG, "overlap_and_add: batch, num_frames and frame_length must be >= 1");
+  if (overlap_length >= frame_length)  // lib/nx_signal.ex:692-695 (message prints the window size twice, quirk B10)
+    return set_error(NXSIG_ERR_INVALID_ARG, "overlap_length must be a number less than the window size " +
+                                                std::to_string(frame_length) + ", got: " + std::to_string(frame_length));
+  if (overlap_length < 0) return set_error(NXSIG_ERR_INVALID_ARG, "overlap_and_add: overlap_length must be >= 0");
+  const int hop = frame_length - overlap_length;
+  const int64_t out_len = num_frames * hop + overlap_length;
+  const size_t ibytes = (size_t)batch * num_frames * frame_length * components * sizeof(float);
+  const size_t obytes = (size_t)batch * out_len * components * sizeof(float);
+  if (mem == NXSIG_DEVICE) return launch_overlap_and_add(c, frames, num_frames, batch, frame_length, hop, components, out);
+  Staged st(c);
+  const void* fd = nullptr; void* od = nullptr;
+  if ((rc = st.in(1, frames, ibytes, &fd))) return rc;
+  if ((rc = st.out_alloc(2, obytes, &od))) return rc;
+  if ((rc = launch_overlap_and_add(c, reinterpret_cast<const float*>(fd), num_frames, batch, frame_length, hop, components,
+                                   reinterpret_cast<float*>(od)))) return rc;
+  return st.out_copy(out, od, obytes);
+  NXSIG_API_END
+}
+
+int nxsig_fft(nxsig_ctx* ctx, const void* in, int32_t in_is_real, int64_t rows, int32_t n_in, int32_t fft_length,
+              int32_t inverse, nxsig_c64* out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!in || !out) return set_error(NXSIG_ERR_INVALID_ARG, "fft: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (rows < 1 || n_in < 1 || fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fft: rows, n_in and fft_length must be >= 1");
+  const size_t ibytes = (size_t)rows * n_in * (in_is_real ? sizeof(float) : sizeof(float2));
+  const size_t obytes = (size_t)rows * fft_length * sizeof(float2);
+  if (mem == NXSIG_DEVICE) return launch_fft(c, in, in_is_real != 0, rows, n_in, fft_length, inverse != 0, reinterpret_cast<float2*>(out));
+  Staged st(c);
+  const void* id = nullptr; void* od = nullptr;
+  if ((rc = st.in(1, in, ibytes, &id))) return rc;
+  if ((rc = st.out_alloc(2, obytes, &od))) return rc;
+  if ((rc = launch_fft(c, id, in_is_real != 0, rows, n_in, fft_length, inverse != 0, reinterpret_cast<float2*>(od)))) return rc;
+  return st.out_copy(out, od, obytes);
+  NXSIG_API_END
+}
+
+int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
+                  int32_t num_taps, int32_t mode, float* y, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!x || !h || !y) return set_error(NXSIG_ERR_INVALID_ARG, "fir: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535 || length < 1 || num_taps < 1)
+    return set_error(NXSIG_ERR_INVALID_ARG, "fir: batch, length and num_taps must be >= 1");
+  if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "fir: batch_stride < length");
+  const int64_t full = length + num_taps - 1;
+  int64_t out_len, start;
+  switch (mode) {  // lib/nx_signal/convolution.ex:300-329: centered(out, shape) starts at div(full - new, 2)
+    case NXSIG_CONV_FULL: out_len = full; start = 0; break;
+    case NXSIG_CONV_SAME: out_len = length; start = (full - out_len) / 2; break;
+    case NXSIG_CONV_VALID:
+      out_len = (length >= num_taps ? length - num_taps : num_taps - length) + 1;
+      start = (full - out_len) / 2;
+      break;
+    default:  // convolution.ex:41-44
+      return set_error(NXSIG_ERR_INVALID_ARG, "expected mode to be one of [:full, :same, :valid]");
+  }
+  FirLaunch a;
+  a.L = length; a.batch = batch; a.batch_stride = batch_stride; a.h_host = h; a.taps = num_taps;
+  a.out_start = start; a.out_len = out_len;
+  const size_t ybytes = (size_t)batch * out_len * sizeof(float);
+  if (mem == NXSIG_DEVICE) {
+    a.x = x; a.y = y;
+    return launch_fir(c, a);
+  }
+  Staged st(c);
+  const void* xd = nullptr; void* yd = nullptr;
+  const size_t xbytes = ((size_t)(batch - 1) * batch_stride + length) * sizeof(float);
+  if ((rc = st.in(1, x, xbytes, &xd))) return rc;
+  if ((rc = st.out_alloc(2, ybytes, &yd))) return rc;
+  a.x = reinterpret_cast<const float*>(xd); a.y = reinterpret_cast<float*>(yd);
+  if ((rc = launch_fir(c, a))) return rc;
+  return st.out_copy(y, yd, ybytes);
+  NXSIG_API_END
+}
+
+}  // extern "C"

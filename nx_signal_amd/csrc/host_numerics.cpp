@@ -1,0 +1,239 @@
+// Host-side generators of the small parameter tensors of the hot path: windows, sinc, firwin,
+// fft_frequencies, stft times.  They are O(N) on a few KB and must reproduce Nx.BinaryBackend's
+// rounding bit-for-bit (every elementwise op rounded to f32, transcendental functions in double
+// on the f32 operand — SURVEY.md Appendix A), which a device `cosf` would not.  Compile this file
+// with -ffp-contract=off: a fused multiply-add would skip a rounding the reference performs.
+//
+// Reference: lib/nx_signal/windows.ex, lib/nx_signal/waveforms.ex:451-457,
+//            lib/nx_signal/filters.ex:147-279, lib/nx_signal.ex:108-111, :154-166.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "nxsig_internal.h"
+
+namespace nxsig {
+
+static const double kPi = 3.14159265358979323846;
+
+static inline float cos32(float x) { return (float)std::cos((double)x); }
+static inline float sin32(float x) { return (float)std::sin((double)x); }
+static inline float sqrt32(float x) { return (float)std::sqrt((double)x); }
+static inline float exp32(float x) { return (float)std::exp((double)x); }
+static inline float pow32(float x, double p) { return (float)std::pow((double)x, p); }
+
+// Nx.linspace(start, stop, n:, endpoint:) in f32: iota * step + start
+static void linspace32(float start, float stop, int64_t n, bool endpoint, float* out) {
+  const float div = (float)(endpoint ? n - 1 : n);
+  const float step = (stop - start) / div;
+  for (int64_t i = 0; i < n; ++i) out[i] = (float)i * step + start;
+}
+
+// Nx.cos(mult * @pi * n / (l - 1)): `mult * @pi` folds in double, becomes an f32 constant, then
+// (c * n) and the division are each rounded to f32 (windows.ex:185-186, :244, :298).
+static inline float cos_term(float k, double mult, int lm1) {
+  const float c = (float)(mult * kPi);
+  const float ang = (c * k) / (float)lm1;
+  return cos32(ang);
+}
+
+static void win_bartlett(int n, float* w) {  // windows.ex:57-78
+  const int n2 = n / 2, left = n2 + n % 2;
+  const float nf = (float)n;
+  for (int i = 0; i < left; ++i) w[i] = ((float)i * 2.0f) / nf;
+  for (int i = 0; i < n2; ++i) {
+    const float idx = (float)i + (float)left;
+    w[left + i] = 2.0f - (idx * 2.0f) / nf;
+  }
+}
+
+static void win_triangular(int n, float* w) {  // windows.ex:98-126
+  const int h = (n + 1) / 2;
+  std::vector<float> left(h);
+  if (n % 2 == 1) {
+    for (int i = 0; i < h; ++i) left[i] = (((float)i + 1.0f) * 2.0f) / (float)(n + 1);
+    for (int i = 0; i < h; ++i) w[i] = left[i];
+    for (int i = 1; i < h; ++i) w[h + i - 1] = left[h - 1 - i];
+  } else {
+    for (int i = 0; i < h; ++i) left[i] = (2.0f * ((float)i + 1.0f) - 1.0f) / (float)n;
+    for (int i = 0; i < h; ++i) w[i] = left[i];
+    for (int i = 0; i < h; ++i) w[h + i] = left[h - 1 - i];
+  }
+}
+
+static void win_blackman(int n, bool periodic, float* w) {  // windows.ex:160-202
+  const int l = periodic ? n + 1 : n;
+  const int m = (l + 1) / 2;
+  std::vector<float> left(m), full;
+  for (int i = 0; i < m; ++i) {
+    const float k = (float)i;
+    const float a = 0.42f - 0.5f * cos_term(k, 2.0, l - 1);
+    left[i] = a + 0.08f * cos_term(k, 4.0, l - 1);
+  }
+  full = left;
+  if (l % 2 == 0) {
+    for (int i = m - 1; i >= 0; --i) full.push_back(left[i]);
+  } else {
+    for (int i = m - 2; i >= 0; --i) full.push_back(left[i]);
+  }
+  for (int i = 0; i < n; ++i) w[i] = full[i];  // periodic: drop the last sample
+}
+
+static void win_cosine2(int n, bool periodic, float a0, float a1, bool hann, float* w) {
+  // hamming (windows.ex:225-250): 0.54 - 0.46*cos(.) ; hann (:278-305): 0.5*(1 - cos(.))
+  const int l = periodic ? n + 1 : n;
+  for (int i = 0; i < n; ++i) {
+    const float c = cos_term((float)i, 2.0, l - 1);
+    w[i] = hann ? 0.5f * (1.0f - c) : a0 - a1 * c;
+  }
+}
+
+static float kaiser_i0(float x) {  // windows.ex:371-386
+  const float ax = std::fabs(x);
+  if (ax < 3.75f) {
+    float s = 1.0f + pow32(ax, 2) / 4.0f;
+    s = s + pow32(ax, 4) / 64.0f;
+    s = s + pow32(ax, 6) / 2304.0f;
+    s = s + pow32(ax, 8) / 147456.0f;
+    return s;
+  }
+  const float two_pi = 2.0f * (float)kPi;
+  // The bracket reproduces the reference's kaiser doctests (windows.ex:322-338) bit-for-bit only when
+  // evaluated in double and rounded once (empirical; see oracle/nx_oracle.py:_kaiser_i0).
+  const double a = (double)ax;
+  const float bracket = (float)(1.0 + 1.0 / (8.0 * a) + 9.0 / (128.0 * a * a));
+  return exp32(ax) / sqrt32(two_pi * ax) * bracket;
+}
+
+static void win_kaiser(int n, bool periodic, double beta, double eps, float* w) {  // windows.ex:341-369
+  const int wl = periodic ? n + 1 : n;
+  std::vector<float> ratio(wl);
+  linspace32(-1.0f, 1.0f, wl, true, ratio.data());
+  const float den = kaiser_i0((float)beta);
+  for (int i = 0; i < n; ++i) {
+    float arg = 1.0f - pow32(ratio[i], 2);
+    arg = std::max(arg, (float)eps);
+    const float r = (float)beta * sqrt32(arg);
+    w[i] = kaiser_i0(r) / den;
+  }
+}
+
+int window_f32(int kind, int n, bool periodic, double beta, double eps, float* out) {
+  if (n < 0 || !out) return set_error(NXSIG_ERR_INVALID_ARG, "window: n must be >= 0 and out non-null");
+  switch (kind) {
+    case NXSIG_WIN_RECTANGULAR:
+      for (int i = 0; i < n; ++i) out[i] = 1.0f;
+      return NXSIG_OK;
+    case NXSIG_WIN_BARTLETT: win_bartlett(n, out); return NXSIG_OK;
+    case NXSIG_WIN_TRIANGULAR: win_triangular(n, out); return NXSIG_OK;
+    case NXSIG_WIN_BLACKMAN: win_blackman(n, periodic, out); return NXSIG_OK;
+    case NXSIG_WIN_HAMMING: win_cosine2(n, periodic, 0.54f, 0.46f, false, out); return NXSIG_OK;
+    case NXSIG_WIN_HANN: win_cosine2(n, periodic, 0.f, 0.f, true, out); return NXSIG_OK;
+    case NXSIG_WIN_KAISER: win_kaiser(n, periodic, beta, eps, out); return NXSIG_OK;
+    default: return set_error(NXSIG_ERR_INVALID_ARG, "unknown window kind " + std::to_string(kind));
+  }
+}
+
+void sinc_f32(const float* t, int64_t n, float* out) {  // waveforms.ex:451-457
+  const float pi32 = (float)kPi;
+  for (int64_t i = 0; i < n; ++i) {
+    const float x = t[i] * pi32;
+    out[i] = (x == 0.0f) ? 1.0f : sin32(x) / x;
+  }
+}
+
+int firwin_f32(int num_taps, const double* cutoff, int n_cutoff, int window_kind, double beta, bool pass_zero,
+               bool scale, double sampling_rate, float* out) {  // filters.ex:147-252
+  if (num_taps < 1 || n_cutoff < 1 || !cutoff || !out)
+    return set_error(NXSIG_ERR_INVALID_ARG, "firwin: num_taps >= 1 and a non-empty cutoff list are required");
+  const double nyq = sampling_rate / 2.0;
+  std::vector<double> cl(cutoff, cutoff + n_cutoff);
+  for (auto& c : cl) c = c / nyq;
+  std::sort(cl.begin(), cl.end());
+  if (cl.front() <= 0.0)
+    return set_error(NXSIG_ERR_INVALID_ARG, "cutoff must be strictly between 0 and Nyquist (exclusive), got: " +
+                                                std::to_string(cl.front() * nyq));
+  if (cl.back() >= 1.0)
+    return set_error(NXSIG_ERR_INVALID_ARG, "cutoff must be strictly between 0 and Nyquist (exclusive), got: " +
+                                                std::to_string(cl.back() * nyq));
+  const bool even_n_cuts = (n_cutoff % 2) == 0;
+  const bool nyquist_gain = (pass_zero && even_n_cuts) || (!pass_zero && !even_n_cuts);
+  if (nyquist_gain && num_taps % 2 == 0)
+    return set_error(NXSIG_ERR_INVALID_ARG,
+                     "a filter with non-zero gain at Nyquist (e.g. highpass) requires an odd number of taps, got: " +
+                         std::to_string(num_taps));
+  switch (window_kind) {
+    case NXSIG_WIN_HAMMING: case NXSIG_WIN_HANN: case NXSIG_WIN_BLACKMAN: case NXSIG_WIN_BARTLETT:
+    case NXSIG_WIN_RECTANGULAR: case NXSIG_WIN_KAISER: break;
+    default:
+      return set_error(NXSIG_ERR_INVALID_ARG,
+                       "unknown window, supported: :hamming, :hann, :blackman, :bartlett, :rectangular, {:kaiser, beta}");
+  }
+  const float m = (float)((num_taps - 1) / 2.0);
+  std::vector<float> alpha(num_taps), h(num_taps, 0.0f), tmp(num_taps), sa(num_taps), sb(num_taps);
+  for (int i = 0; i < num_taps; ++i) alpha[i] = (float)i - m;
+  std::vector<double> freqs;
+  freqs.push_back(0.0);
+  for (double c : cl) freqs.push_back(c);
+  freqs.push_back(1.0);
+  for (size_t i = 0; i + 1 < freqs.size(); ++i) {
+    const bool use = pass_zero ? (i % 2 == 0) : (i % 2 == 1);
+    if (!use) continue;
+    const float a = (float)freqs[i], b = (float)freqs[i + 1];  // defnp args: floats become f32 tensors
+    for (int k = 0; k < num_taps; ++k) tmp[k] = a * alpha[k];
+    sinc_f32(tmp.data(), num_taps, sa.data());
+    for (int k = 0; k < num_taps; ++k) tmp[k] = b * alpha[k];
+    sinc_f32(tmp.data(), num_taps, sb.data());
+    for (int k = 0; k < num_taps; ++k) {  // acc + b*sinc(b*alpha) - a*sinc(a*alpha)  (:223-227)
+      const float ca = a * sa[k], cb = b * sb[k];
+      h[k] = (h[k] + cb) - ca;
+    }
+  }
+  std::vector<float> w(num_taps);
+  int rc = window_f32(window_kind, num_taps, /*periodic=*/false, beta, 1.0e-7, w.data());  // :254-279
+  if (rc != NXSIG_OK) return rc;
+  for (int k = 0; k < num_taps; ++k) h[k] = h[k] * w[k];
+  if (scale) {  // firwin_scale :229-252
+    double sf;
+    if (pass_zero) sf = 0.0;
+    else if (n_cutoff == 1) sf = 1.0;
+    else sf = (cl[0] + cl[1]) / 2.0;
+    const float c = (float)(kPi * sf);
+    double acc = 0.0;  // Nx.dot: accumulate in double, round once
+    for (int k = 0; k < num_taps; ++k) acc += (double)h[k] * (double)cos32(alpha[k] * c);
+    const float s = std::fabs((float)acc);
+    for (int k = 0; k < num_taps; ++k) h[k] = h[k] / s;
+  }
+  std::copy(h.begin(), h.end(), out);
+  return NXSIG_OK;
+}
+
+void fft_frequencies_f32(double fs, int K, bool endpoint, float* out) {  // nx_signal.ex:154-166
+  const float step = (float)fs / (float)K;
+  linspace32(0.0f, step * (float)K, K, endpoint, out);
+}
+
+void stft_times_f32(int N, double fs, int64_t M, float* out) {  // nx_signal.ex:108-111
+  const float two_fs = 2.0f * (float)fs;
+  const float time_step = (float)((double)N / (double)two_fs);
+  const float last = time_step * (float)M;
+  linspace32(time_step, last, M, true, out);
+}
+
+// f32 scalar the spectrum is divided by (stft :116/:119) or multiplied by (istft :614/:617).
+// Nx.sum accumulates in double and rounds once; window ** 2 is an exact f32 product.
+float scaling_factor(const float* w, int N, int scaling, double fs) {
+  double acc = 0.0;
+  if (scaling == NXSIG_SCALE_SPECTRUM) {
+    for (int i = 0; i < N; ++i) acc += (double)w[i];
+    return (float)acc;
+  }
+  for (int i = 0; i < N; ++i) acc += (double)(w[i] * w[i]);
+  const float s2 = (float)acc;
+  const float prod = (float)fs * s2;
+  return sqrt32(prod);
+}
+
+}  // namespace nxsig

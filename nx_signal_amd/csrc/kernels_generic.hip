@@ -1,0 +1,555 @@
+// Generic gfx950 kernels of the STFT / iSTFT / FIR path: correct for EVERY shape the reference accepts
+// (any frame length, hop, fft_length, padding mode, batch).  The tuned wave-per-frame kernels in
+// kernels_stft_wave.hip take over for the power-of-two sizes the benchmarks run.
+//
+//   k_stft_pow2      frame slice x window -> workgroup Stockham radix-4/2 FFT in LDS -> scale -> c64 store
+//   k_stft_dft       same fusion for non-power-of-two fft_length (direct DFT, table twiddles)
+//   k_fft_rows_*     Nx.fft / Nx.ifft(length:) over rows (+ optional x scale x window epilogue for istft)
+//   k_ola            deterministic overlap-add (+ |w|^2 normaliser with the 1e-10 guard) in fixed frame order
+//   k_as_windowed    framing gather
+//   k_fir_os         overlap-save block convolution, two real blocks packed as re/im of one complex FFT
+//
+// Twiddles are generated on the host in double and read from a table (never __sinf/__cosf).
+// Reference lines: lib/nx_signal.ex:94-102 (frame/window/fft), :113-127 (scaling), :609-637 (istft),
+// :684-736 (overlap_and_add), lib/nx_signal/convolution.ex:252-329 (fftconvolve).
+#include <hip/hip_runtime.h>
+
+#include "nxsig_internal.h"
+
+namespace nxsig {
+
+static constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -i (forward) or +i (inverse)
+template <bool INV>
+__device__ __forceinline__ float2 mul_mi(float2 a) {
+  return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+template <bool INV>
+__device__ __forceinline__ float2 twid(const float2* __restrict__ tw, int idx) {
+  float2 w = tw[idx];
+  if (INV) w.y = -w.y;
+  return w;
+}
+
+struct FrameGeom {
+  int64_t L, lo, M;
+  int32_t N, hop, reflect;
+};
+
+// sample of the (virtually) padded signal at padded index q — lib/nx_signal.ex:338 (Nx.pad, zeros) / :349 (Nx.reflect)
+__device__ __forceinline__ float fetch_padded(const float* __restrict__ x, const FrameGeom& g, int64_t q) {
+  int64_t pos = q - g.lo;
+  if (g.reflect) {
+    if (g.L == 1) return x[0];
+    const int64_t period = 2 * (g.L - 1);
+    pos %= period;
+    if (pos < 0) pos += period;
+    if (pos >= g.L) pos = period - pos;
+    return x[pos];
+  }
+  return (pos >= 0 && pos < g.L) ? x[pos] : 0.0f;
+}
+
+// Workgroup-wide Stockham autosort FFT of F rows of K points (K = 2^logK), ping-ponging between LDS
+// buffers a (input) and b.  Pass with radix R and current sub-length p: for i in [0, K/R):
+//   k = i mod p ; u_t = a[i + t K/R] * w^(t k K/(pR)) ; v = DFT_R(u) ; b[(i-k) R + k + r p] = v_r.
+// Returns the buffer that holds the natural-order result.
+template <bool INV>
+__device__ float2* lds_fft_pow2(float2* a, float2* b, int K, int logK, int F, const float2* __restrict__ tw) {
+  const int tid = threadIdx.x;
+  int p = 1, logp = 0;
+  while (logK - logp >= 2) {
+    const int q = K >> 2;
+    const int logq = logK - 2;
+    const int total = F * q;
+    const int step = K >> (logp + 2);
+    for (int w = tid; w < total; w += kThreads) {
+      const int f = w >> logq, i = w & (q - 1);
+      const int k = i & (p - 1);
+      const float2* src = a + (size_t)f * K;
+      float2 u0 = src[i], u1 = src[i + q], u2 = src[i + 2 * q], u3 = src[i + 3 * q];
+      if (p > 1) {
+        u1 = cmul(u1, twid<INV>(tw, k * step));
+        u2 = cmul(u2, twid<INV>(tw, 2 * k * step));
+        u3 = cmul(u3, twid<INV>(tw, 3 * k * step));
+      }
+      const float2 s02 = cadd(u0, u2), d02 = csub(u0, u2);
+      const float2 s13 = cadd(u1, u3), d13 = mul_mi<INV>(csub(u1, u3));
+      float2* dst = b + (size_t)f * K + ((i - k) << 2) + k;
+      dst[0] = cadd(s02, s13);
+      dst[p] = cadd(d02, d13);
+      dst[2 * p] = csub(s02, s13);
+      dst[3 * p] = csub(d02, d13);
+    }
+    __syncthreads();
+    float2* t = a; a = b; b = t;
+    p <<= 2;
+    logp += 2;
+  }
+  if (logK - logp == 1) {
+    const int q = K >> 1;
+    const int logq = logK - 1;
+    const int total = F * q;
+    const int step = K >> (logp + 1);
+    for (int w = tid; w < total; w += kThreads) {
+      const int f = w >> logq, i = w & (q - 1);
+      const int k = i & (p - 1);
+      const float2* src = a + (size_t)f * K;
+      float2 u0 = src[i], u1 = src[i + q];
+      if (p > 1) u1 = cmul(u1, twid<INV>(tw, k * step));
+      float2* dst = b + (size_t)f * K + ((i - k) << 1) + k;
+      dst[0] = cadd(u0, u1);
+      dst[p] = csub(u0, u1);
+    }
+    __syncthreads();
+    float2* t = a; a = b; b = t;
+  }
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------ STFT
+struct StftArgs {
+  const float* x;
+  int64_t batch_stride;
+  FrameGeom g;
+  int32_t K, logK, F;       // F rows per workgroup
+  const float* window;
+  const float2* tw;
+  float div;                // spectrum / div
+  int32_t has_scale;
+  float2* z;
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+
+__global__ __launch_bounds__(kThreads) void k_stft_pow2(StftArgs a) {
+  float2* A = reinterpret_cast<float2*>(g_smem);
+  float2* B = A + (size_t)a.F * a.K;
+  const int tid = threadIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.x * a.F;
+  const float* x = a.x + (size_t)blockIdx.y * a.batch_stride;
+  const int nuse = a.g.N < a.K ? a.g.N : a.K;  // Nx.fft(length: K): rows zero-padded or truncated to K
+  const int total = a.F * a.K;
+  for (int idx = tid; idx < total; idx += kThreads) {
+    const int f = idx >> a.logK, n = idx & (a.K - 1);
+    const int64_t m = m0 + f;
+    float v = 0.0f;
+    if (m < a.g.M && n < nuse) v = fetch_padded(x, a.g, m * a.g.hop + n) * a.window[n];  // :101 exact f32 product
+    A[idx] = make_float2(v, 0.0f);
+  }
+  __syncthreads();
+  float2* R = lds_fft_pow2<false>(A, B, a.K, a.logK, a.F, a.tw);
+  float2* z = a.z + ((size_t)blockIdx.y * a.g.M + m0) * a.K;
+  for (int idx = tid; idx < total; idx += kThreads) {
+    const int f = idx >> a.logK;
+    if (m0 + f >= a.g.M) break;
+    float2 v = R[idx];
+    if (a.has_scale) { v.x = v.x / a.div; v.y = v.y / a.div; }  // :116/:119 true division, like the reference
+    z[idx] = v;
+  }
+}
+
+// non-power-of-two fft_length: one workgroup per frame, direct DFT with table twiddles
+__global__ __launch_bounds__(kThreads) void k_stft_dft(StftArgs a) {
+  float* s = reinterpret_cast<float*>(g_smem);
+  const int tid = threadIdx.x;
+  const int64_t m = blockIdx.x;
+  const float* x = a.x + (size_t)blockIdx.y * a.batch_stride;
+  const int nuse = a.g.N < a.K ? a.g.N : a.K;
+  for (int n = tid; n < nuse; n += kThreads) s[n] = fetch_padded(x, a.g, m * a.g.hop + n) * a.window[n];
+  __syncthreads();
+  float2* z = a.z + ((size_t)blockIdx.y * a.g.M + m) * a.K;
+  for (int k = tid; k < a.K; k += kThreads) {
+    float re = 0.0f, im = 0.0f;
+    int idx = 0;
+    for (int n = 0; n < nuse; ++n) {
+      const float2 w = a.tw[idx];
+      re = fmaf(s[n], w.x, re);
+      im = fmaf(s[n], w.y, im);
+      idx += k;
+      if (idx >= a.K) idx -= a.K;
+    }
+    if (a.has_scale) { re = re / a.div; im = im / a.div; }
+    z[k] = make_float2(re, im);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ row FFTs
+struct FftRowsArgs {
+  const void* in;           // f32[rows][n_in] or c64[rows][n_in]
+  int32_t in_is_real;
+  int64_t rows;
+  int32_t n_in, K, logK, F;
+  const float2* tw;
+  // epilogue (istft :611-628): out = (v * scale) * window[k]; inverse transforms also apply 1/K first
+  const float* post_window;
+  float post_scale;
+  int32_t has_post_scale;
+  float2* out;              // c64[rows][K]
+};
+
+template <bool INV>
+__device__ __forceinline__ float2 fft_epilogue(const FftRowsArgs& a, float2 v, int k) {
+  if (INV) {
+    const float invK = 1.0f / (float)a.K;  // exact for powers of two; the DFT path divides instead
+    v.x *= invK; v.y *= invK;
+  }
+  if (a.has_post_scale) { v.x *= a.post_scale; v.y *= a.post_scale; }
+  if (a.post_window) { const float w = a.post_window[k]; v.x *= w; v.y *= w; }
+  return v;
+}
+
+template <bool INV>
+__global__ __launch_bounds__(kThreads) void k_fft_rows_pow2(FftRowsArgs a) {
+  float2* A = reinterpret_cast<float2*>(g_smem);
+  float2* B = A + (size_t)a.F * a.K;
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * a.F;
+  const int nuse = a.n_in < a.K ? a.n_in : a.K;
+  const int total = a.F * a.K;
+  for (int idx = tid; idx < total; idx += kThreads) {
+    const int f = idx >> a.logK, n = idx & (a.K - 1);
+    const int64_t r = r0 + f;
+    float2 v = make_float2(0.0f, 0.0f);
+    if (r < a.rows && n < nuse) {
+      if (a.in_is_real) v.x = reinterpret_cast<const float*>(a.in)[(size_t)r * a.n_in + n];
+      else v = reinterpret_cast<const float2*>(a.in)[(size_t)r * a.n_in + n];
+    }
+    A[idx] = v;
+  }
+  __syncthreads();
+  float2* R = lds_fft_pow2<INV>(A, B, a.K, a.logK, a.F, a.tw);
+  float2* out = a.out + (size_t)r0 * a.K;
+  for (int idx = tid; idx < total; idx += kThreads) {
+    const int f = idx >> a.logK;
+    if (r0 + f >= a.rows) break;
+    out[idx] = fft_epilogue<INV>(a, R[idx], idx & (a.K - 1));
+  }
+}
+
+template <bool INV>
+__global__ __launch_bounds__(kThreads) void k_fft_rows_dft(FftRowsArgs a) {
+  float2* s = reinterpret_cast<float2*>(g_smem);
+  const int tid = threadIdx.x;
+  const int64_t r = blockIdx.x;
+  const int nuse = a.n_in < a.K ? a.n_in : a.K;
+  for (int n = tid; n < nuse; n += kThreads) {
+    float2 v = make_float2(0.0f, 0.0f);
+    if (a.in_is_real) v.x = reinterpret_cast<const float*>(a.in)[(size_t)r * a.n_in + n];
+    else v = reinterpret_cast<const float2*>(a.in)[(size_t)r * a.n_in + n];
+    s[n] = v;
+  }
+  __syncthreads();
+  float2* out = a.out + (size_t)r * a.K;
+  for (int k = tid; k < a.K; k += kThreads) {
+    float re = 0.0f, im = 0.0f;
+    int idx = 0;
+    for (int n = 0; n < nuse; ++n) {
+      const float2 w = twid<INV>(a.tw, idx);
+      const float2 v = s[n];
+      re += v.x * w.x - v.y * w.y;
+      im += v.x * w.y + v.y * w.x;
+      idx += k;
+      if (idx >= a.K) idx -= a.K;
+    }
+    float2 v = make_float2(re, im);
+    if (INV) { v.x = v.x / (float)a.K; v.y = v.y / (float)a.K; }
+    if (a.has_post_scale) { v.x *= a.post_scale; v.y *= a.post_scale; }
+    if (a.post_window) { const float w = a.post_window[k]; v.x *= w; v.y *= w; }
+    out[k] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ OLA
+// out[n] = sum over frames m (ascending) of frames[m][n - m hop]; contributions are accumulated in double
+// and rounded once (what Nx.indexed_add does on BinaryBackend, SURVEY App. A rule 8) -> deterministic.
+// NORM: also den[n] = sum_m w2[n - m hop] (w2 = f32(|w|^2)), out /= (den > 1e-10 ? den : 1)  (:630-637)
+template <int COMPS, bool NORM>
+__global__ __launch_bounds__(kThreads) void k_ola(const float* __restrict__ frames, int64_t M, int32_t N, int32_t hop,
+                                                 const float* __restrict__ window, float* __restrict__ out,
+                                                 int64_t out_len) {
+  const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (n >= out_len) return;
+  const float* fr = frames + (size_t)blockIdx.y * M * N * COMPS;
+  int64_t m_hi = n / hop;
+  if (m_hi > M - 1) m_hi = M - 1;
+  int64_t m_lo = (n - N + hop) / hop;  // ceil((n - N + 1) / hop) for n-N+1 > 0
+  if (n - N + 1 <= 0) m_lo = 0;
+  double acc[COMPS];
+#pragma unroll
+  for (int c = 0; c < COMPS; ++c) acc[c] = 0.0;
+  double den = 0.0;
+  for (int64_t m = m_lo; m <= m_hi; ++m) {
+    const int32_t j = (int32_t)(n - m * hop);
+    const float* p = fr + ((size_t)m * N + j) * COMPS;
+#pragma unroll
+    for (int c = 0; c < COMPS; ++c) acc[c] += (double)p[c];
+    if (NORM) { const float w = fabsf(window[j]); den += (double)(w * w); }
+  }
+  float* o = out + ((size_t)blockIdx.y * out_len + n) * COMPS;
+  if (NORM) {
+    float d = (float)den;
+    d = d > 1.0e-10f ? d : 1.0f;
+#pragma unroll
+    for (int c = 0; c < COMPS; ++c) o[c] = (float)acc[c] / d;
+  } else {
+#pragma unroll
+    for (int c = 0; c < COMPS; ++c) o[c] = (float)acc[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ framing
+__global__ __launch_bounds__(kThreads) void k_as_windowed(const float* __restrict__ x, int64_t batch_stride, FrameGeom g,
+                                                         float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int64_t total = g.M * g.N;
+  if (idx >= total) return;
+  const int64_t m = idx / g.N;
+  const int32_t n = (int32_t)(idx - m * g.N);
+  out[(size_t)blockIdx.y * total + idx] = fetch_padded(x + (size_t)blockIdx.y * batch_stride, g, m * g.hop + n);
+}
+
+// ------------------------------------------------------------------------------------------ FIR (generic)
+// Overlap-save: block b produces full-convolution outputs [b V, (b+1) V), V = B - (taps-1), from the B input
+// samples x[b V - (taps-1) + t].  Two consecutive blocks ride in the real and imaginary lanes of ONE complex
+// FFT (h is real, so IFFT(FFT(x1 + i x2) H) = x1*h + i x2*h): no Hermitian split pass is needed.
+struct FirArgs {
+  const float* x;
+  int64_t L, batch_stride;
+  int32_t B, logB, taps;
+  int64_t nblocks;          // number of V-sized output blocks covering the requested slice
+  int64_t first_block;      // index of the first block
+  int64_t out_start, out_len;
+  const float2* H;          // device c64[B] = FFT_B(h zero-padded), computed on the host in double
+  const float2* tw;
+  float* y;
+};
+
+__global__ __launch_bounds__(kThreads) void k_fir_os(FirArgs a) {
+  float2* A = reinterpret_cast<float2*>(g_smem);
+  float2* Bf = A + a.B;
+  const int tid = threadIdx.x;
+  const int64_t V = a.B - (a.taps - 1);
+  const int64_t b1 = a.first_block + 2 * (int64_t)blockIdx.x, b2 = b1 + 1;
+  const bool have2 = (b2 - a.first_block) < a.nblocks;
+  const float* x = a.x + (size_t)blockIdx.y * a.batch_stride;
+  const int64_t s1 = b1 * V - (a.taps - 1), s2 = b2 * V - (a.taps - 1);
+  for (int t = tid; t < a.B; t += kThreads) {
+    const int64_t p1 = s1 + t, p2 = s2 + t;
+    const float v1 = (p1 >= 0 && p1 < a.L) ? x[p1] : 0.0f;
+    const float v2 = (have2 && p2 >= 0 && p2 < a.L) ? x[p2] : 0.0f;
+    A[t] = make_float2(v1, v2);
+  }
+  __syncthreads();
+  float2* R = lds_fft_pow2<false>(A, Bf, a.B, a.logB, 1, a.tw);
+  float2* O = (R == A) ? Bf : A;
+  for (int t = tid; t < a.B; t += kThreads) R[t] = cmul(R[t], a.H[t]);
+  __syncthreads();
+  float2* Y = lds_fft_pow2<true>(R, O, a.B, a.logB, 1, a.tw);
+  const float invB = 1.0f / (float)a.B;
+  float* y = a.y + (size_t)blockIdx.y * a.out_len;
+  for (int t = a.taps - 1 + tid; t < a.B; t += kThreads) {
+    const float2 v = Y[t];
+    const int64_t n1 = b1 * V + (t - (a.taps - 1)) - a.out_start;
+    if (n1 >= 0 && n1 < a.out_len) y[n1] = v.x * invB;
+    const int64_t n2 = n1 + V;
+    if (have2 && n2 >= 0 && n2 < a.out_len) y[n2] = v.y * invB;
+  }
+}
+
+// ========================================================================================== launchers
+static int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static constexpr int kMaxLdsPow2 = 8192;  // 2 x 8192 x 8 B = 128 KiB of the CU's 160 KiB LDS
+
+template <typename KernelT>
+static int ensure_lds(KernelT kernel, size_t bytes) {
+  if (bytes > 64 * 1024) NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return NXSIG_OK;
+}
+
+static FrameGeom to_geom(const Framing& fr) {
+  FrameGeom g;
+  g.L = fr.L; g.lo = fr.lo; g.M = fr.M; g.N = fr.N; g.hop = fr.hop; g.reflect = fr.reflect;
+  return g;
+}
+
+int launch_stft_generic(Ctx* c, const StftLaunch& s) {
+  StftArgs a;
+  a.x = s.x; a.batch_stride = s.batch_stride; a.g = to_geom(s.fr);
+  a.K = s.K; a.window = s.window; a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = s.z;
+  if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
+  int rc = ctx_twiddles(c, s.K, &a.tw);
+  if (rc) return rc;
+  if (is_pow2(s.K) && s.K <= kMaxLdsPow2) {
+    a.logK = ilog2(s.K);
+    a.F = s.K >= 1024 ? 1 : 1024 / s.K;
+    const size_t lds = (size_t)2 * a.F * a.K * sizeof(float2);
+    rc = ensure_lds(k_stft_pow2, lds);
+    if (rc) return rc;
+    dim3 grid((unsigned)((s.fr.M + a.F - 1) / a.F), (unsigned)s.batch);
+    hipLaunchKernelGGL(k_stft_pow2, grid, dim3(kThreads), lds, c->stream, a);
+  } else {
+    if (s.K > 16384)
+      return set_error(NXSIG_ERR_UNSUPPORTED, "stft: non-power-of-two fft_length > 16384 is not supported yet");
+    a.logK = 0; a.F = 1;
+    const int nuse = s.fr.N < s.K ? s.fr.N : s.K;
+    const size_t lds = (size_t)nuse * sizeof(float);
+    dim3 grid((unsigned)s.fr.M, (unsigned)s.batch);
+    hipLaunchKernelGGL(k_stft_dft, grid, dim3(kThreads), lds, c->stream, a);
+  }
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse,
+                           const float* post_window, float post_scale, bool has_post_scale, float2* out) {
+  if (rows == 0) return NXSIG_OK;
+  FftRowsArgs a;
+  a.in = in; a.in_is_real = in_is_real ? 1 : 0; a.rows = rows; a.n_in = n_in; a.K = K;
+  a.post_window = post_window; a.post_scale = post_scale; a.has_post_scale = has_post_scale ? 1 : 0; a.out = out;
+  int rc = ctx_twiddles(c, K, &a.tw);
+  if (rc) return rc;
+  if (is_pow2(K) && K <= kMaxLdsPow2) {
+    a.logK = ilog2(K);
+    a.F = K >= 1024 ? 1 : 1024 / K;
+    const size_t lds = (size_t)2 * a.F * K * sizeof(float2);
+    dim3 grid((unsigned)((rows + a.F - 1) / a.F));
+    if (inverse) {
+      rc = ensure_lds(k_fft_rows_pow2<true>, lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_fft_rows_pow2<true>, grid, dim3(kThreads), lds, c->stream, a);
+    } else {
+      rc = ensure_lds(k_fft_rows_pow2<false>, lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_fft_rows_pow2<false>, grid, dim3(kThreads), lds, c->stream, a);
+    }
+  } else {
+    if (K > 16384) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: length > 16384 that is not a power of two <= 8192 is not supported yet");
+    a.logK = 0; a.F = 1;
+    const int nuse = n_in < K ? n_in : K;
+    const size_t lds = (size_t)nuse * sizeof(float2);
+    dim3 grid((unsigned)rows);
+    if (inverse) hipLaunchKernelGGL(k_fft_rows_dft<true>, grid, dim3(kThreads), lds, c->stream, a);
+    else hipLaunchKernelGGL(k_fft_rows_dft<false>, grid, dim3(kThreads), lds, c->stream, a);
+  }
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+int launch_fft(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse, float2* out) {
+  return launch_fft_rows(c, in, in_is_real, rows, n_in, K, inverse, nullptr, 1.0f, false, out);
+}
+
+// generic istft: rows IFFT (x scale x window) into a scratch frames tensor, then the deterministic OLA + normaliser
+int launch_istft_generic(Ctx* c, const IstftLaunch& s) {
+  if (s.M == 0 || s.batch == 0) return NXSIG_OK;
+  void* frames = nullptr;
+  const size_t fbytes = (size_t)s.batch * s.M * s.N * sizeof(float2);
+  int rc = ctx_scratch(c, 0, fbytes, &frames);
+  if (rc) return rc;
+  rc = launch_fft_rows(c, s.z, false, (int64_t)s.batch * s.M, s.K, s.K, true, s.window, s.scale_mul, s.has_scale != 0,
+                       reinterpret_cast<float2*>(frames));
+  if (rc) return rc;
+  const int64_t out_len = s.M * s.hop + (s.N - s.hop);
+  dim3 grid((unsigned)((out_len + kThreads - 1) / kThreads), (unsigned)s.batch);
+  hipLaunchKernelGGL((k_ola<2, true>), grid, dim3(kThreads), 0, c->stream, reinterpret_cast<const float*>(frames), s.M,
+                     s.N, s.hop, s.window, reinterpret_cast<float*>(s.y), out_len);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+int launch_as_windowed(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, const Framing& fr, float* out) {
+  if (fr.M == 0 || batch == 0) return NXSIG_OK;
+  const int64_t total = fr.M * fr.N;
+  dim3 grid((unsigned)((total + kThreads - 1) / kThreads), (unsigned)batch);
+  hipLaunchKernelGGL(k_as_windowed, grid, dim3(kThreads), 0, c->stream, x, batch_stride, to_geom(fr), out);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+int launch_overlap_and_add(Ctx* c, const float* frames, int64_t M, int32_t batch, int32_t N, int32_t hop, int32_t comps,
+                           float* out) {
+  const int64_t out_len = M * hop + (N - hop);
+  if (out_len == 0 || batch == 0) return NXSIG_OK;
+  dim3 grid((unsigned)((out_len + kThreads - 1) / kThreads), (unsigned)batch);
+  if (comps == 1)
+    hipLaunchKernelGGL((k_ola<1, false>), grid, dim3(kThreads), 0, c->stream, frames, M, N, hop, nullptr, out, out_len);
+  else
+    hipLaunchKernelGGL((k_ola<2, false>), grid, dim3(kThreads), 0, c->stream, frames, M, N, hop, nullptr, out, out_len);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+// host FFT in double for the filter spectrum H (tiny: B <= 8192 points, once per distinct filter)
+static void host_fft_f64(std::vector<double>& re, std::vector<double>& im) {
+  const size_t n = re.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const double ang = -2.0 * 3.14159265358979323846 / (double)len;
+    for (size_t i = 0; i < n; i += len) {
+      for (size_t k = 0; k < len / 2; ++k) {
+        const double wr = cos(ang * (double)k), wi = sin(ang * (double)k);
+        const size_t u = i + k, v = i + k + len / 2;
+        const double tr = re[v] * wr - im[v] * wi, ti = re[v] * wi + im[v] * wr;
+        re[v] = re[u] - tr; im[v] = im[u] - ti;
+        re[u] += tr; im[u] += ti;
+      }
+    }
+  }
+}
+
+int launch_fir_generic(Ctx* c, const FirLaunch& s) {
+  if (s.out_len <= 0 || s.batch == 0) return NXSIG_OK;
+  if (s.taps > 4096)
+    return set_error(NXSIG_ERR_UNSUPPORTED, "fir: more than 4096 taps is not supported yet (overlap-save block <= 8192)");
+  int B = 1024;
+  while (B < 8 * s.taps && B < 8192) B <<= 1;
+  while (B < 2 * s.taps) B <<= 1;
+  // filter spectrum, computed in double on the host, cached in HBM by content
+  std::vector<double> re(B, 0.0), im(B, 0.0);
+  for (int i = 0; i < s.taps; ++i) re[i] = (double)s.h_host[i];
+  host_fft_f64(re, im);
+  std::vector<float2> H(B);
+  for (int i = 0; i < B; ++i) H[i] = make_float2((float)re[i], (float)im[i]);
+  FirArgs a;
+  const void* Hd = nullptr;
+  int rc = ctx_table(c, 0xF1A0000000000000ull ^ (uint64_t)B, H.data(), H.size() * sizeof(float2), &Hd);
+  if (rc) return rc;
+  a.H = reinterpret_cast<const float2*>(Hd);
+  rc = ctx_twiddles(c, B, &a.tw);
+  if (rc) return rc;
+  a.x = s.x; a.L = s.L; a.batch_stride = s.batch_stride; a.B = B; a.logB = ilog2(B); a.taps = s.taps;
+  const int64_t V = B - (s.taps - 1);
+  a.first_block = s.out_start / V;
+  const int64_t last_block = (s.out_start + s.out_len - 1) / V;
+  a.nblocks = last_block - a.first_block + 1;
+  a.out_start = s.out_start; a.out_len = s.out_len; a.y = s.y;
+  const size_t lds = (size_t)2 * B * sizeof(float2);
+  rc = ensure_lds(k_fir_os, lds);
+  if (rc) return rc;
+  dim3 grid((unsigned)((a.nblocks + 1) / 2), (unsigned)s.batch);
+  hipLaunchKernelGGL(k_fir_os, grid, dim3(kThreads), lds, c->stream, a);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+}  // namespace nxsig

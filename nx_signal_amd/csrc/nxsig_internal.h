@@ -1,0 +1,119 @@
+// Internal declarations shared by the C-ABI layer (api.cpp), the host-side generators
+// (host_numerics.cpp) and the HIP launchers (*.hip).  Nothing here is exported.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/nxsig.h"
+
+namespace nxsig {
+
+// ---- error plumbing: thread-local message, never throws across the C ABI ----
+int set_error(int code, const std::string& msg);
+const char* last_error_cstr();
+
+#define NXSIG_HIP_TRY(expr)                                                                          \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      return ::nxsig::set_error(_e == hipErrorOutOfMemory ? NXSIG_ERR_OOM : NXSIG_ERR_HIP,           \
+                                std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+  } while (0)
+
+// ---- host numerics (host_numerics.cpp) ----
+int window_f32(int kind, int n, bool periodic, double beta, double eps, float* out);
+void sinc_f32(const float* t, int64_t n, float* out);
+int firwin_f32(int num_taps, const double* cutoff, int n_cutoff, int window_kind, double beta, bool pass_zero,
+               bool scale, double sampling_rate, float* out);
+void fft_frequencies_f32(double fs, int K, bool endpoint, float* out);
+void stft_times_f32(int N, double fs, int64_t M, float* out);
+float scaling_factor(const float* w, int N, int scaling, double fs);
+
+// ---- framing geometry (as_windowed, lib/nx_signal.ex:257-331) ----
+struct Framing {
+  int64_t L;       // signal length
+  int32_t N;       // frame (window) length
+  int32_t hop;     // stride
+  int32_t reflect; // 1 = mirror padding, 0 = zero padding
+  int64_t lo, hi;  // padding (may be negative for explicit crop)
+  int64_t M;       // number of frames
+};
+int make_framing(int64_t L, int32_t N, int32_t hop, int32_t pad_mode, int64_t pad_lo, int64_t pad_hi, Framing* out);
+
+// ---- device tables cached per context ----
+struct DeviceTable {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+};
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  std::mutex mu;
+  int num_cus = 0;
+  std::string dev_name;
+  // twiddle tables w_K^j = exp(-2 pi i j / K), j in [0,K), generated in double, stored as float2
+  std::map<int, DeviceTable> twiddles;
+  // content-addressed small tables (windows, filter spectra ...): key = fnv1a(tag, bytes)
+  std::map<uint64_t, DeviceTable> tables;
+  // scratch buffer reused by multi-stage paths (generic istft, host staging)
+  void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes[4] = {0, 0, 0, 0};
+};
+
+int ctx_twiddles(Ctx* c, int K, const float2** out);
+int ctx_table(Ctx* c, uint64_t tag, const void* host, size_t bytes, const void** out);
+int ctx_scratch(Ctx* c, int slot, size_t bytes, void** out);
+uint64_t fnv1a(uint64_t seed, const void* data, size_t bytes);
+
+// ---- kernel launchers (implemented in the .hip files; all enqueue on c->stream) ----
+struct StftLaunch {
+  const float* x;        // device, [batch][L] rows batch_stride apart
+  int64_t batch_stride;
+  int32_t batch;
+  Framing fr;
+  int32_t K;             // fft length
+  const float* window;   // device f32[N]
+  float inv_scale_div;   // spectrum is DIVIDED by this (1.0 = none); division kept exact like the reference
+  int32_t has_scale;
+  float2* z;             // device c64[batch][M][K]
+};
+int launch_stft(Ctx* c, const StftLaunch& a);
+
+struct IstftLaunch {
+  const float2* z;       // device c64[batch][M][K]
+  int64_t M;
+  int32_t batch;
+  int32_t N, hop, K;
+  const float* window;   // device f32[N]
+  float scale_mul;       // frames are MULTIPLIED by this (istft :614/:617)
+  int32_t has_scale;
+  float2* y;             // device c64[batch][M*hop + N-hop]
+};
+int launch_istft(Ctx* c, const IstftLaunch& a);
+
+int launch_as_windowed(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, const Framing& fr, float* out);
+int launch_overlap_and_add(Ctx* c, const float* frames, int64_t M, int32_t batch, int32_t N, int32_t hop, int32_t comps,
+                           float* out);
+int launch_fft(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse, float2* out);
+
+struct FirLaunch {
+  const float* x;
+  int64_t L, batch_stride;
+  int32_t batch;
+  const float* h_host;
+  int32_t taps;
+  int64_t out_start, out_len;  // requested slice of the full convolution
+  float* y;                    // device f32[batch][out_len]
+};
+int launch_fir(Ctx* c, const FirLaunch& a);
+
+}  // namespace nxsig

@@ -1,0 +1,13 @@
+"""NxSignal.Waveforms.sinc — lib/nx_signal/waveforms.ex:451-457 (the only waveform on the FIR path)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def sinc(t):
+    a = np.ascontiguousarray(np.asarray(t, dtype=np.float32))
+    out = np.empty_like(a)
+    _lib.check(_lib.load().nxsig_sinc_f32(a.ctypes.data_as(_lib.C.c_void_p), a.size, out.ctypes.data_as(_lib.C.c_void_p)))
+    return out

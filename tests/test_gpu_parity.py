@@ -1,0 +1,301 @@
+"""GPU parity tests (pytest -m gpu, run on a real MI355X through gpurun).
+
+Every test drives the HIP path through the C ABI (nx_signal_amd -> ctypes -> libnxsig.so) and compares
+with the CPU oracle (oracle/nx_oracle.py, the BinaryBackend restatement) on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star / SURVEY §0.9): normalised max error
+    max|got - ref| / max|ref| < 1e-5       (fp32 butterflies vs an f64-internal reference land at ~2e-7)
+plus rel-L2 < 1e-6.  Index-only operations (as_windowed) are bit-exact; overlap_and_add accumulates in
+double and rounds once like the reference, so it is bit-exact too.
+"""
+import numpy as np
+import pytest
+
+from conftest import f32_list, nx_all_close
+from oracle import nx_oracle as O
+
+import nx_signal_amd as S
+
+pytestmark = pytest.mark.gpu
+
+TOL_MAX = 1e-5
+TOL_L2 = 1e-6
+
+
+def nerr(got, ref):
+    got = np.asarray(got)
+    ref = np.asarray(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    d = np.abs(got.astype(np.complex128) - ref.astype(np.complex128))
+    scale = max(float(np.max(np.abs(ref))), 1e-30)
+    l2 = float(np.sqrt(np.sum(d ** 2)) / max(np.sqrt(np.sum(np.abs(ref.astype(np.complex128)) ** 2)), 1e-30))
+    return float(d.max()) / scale, l2
+
+
+def assert_close(got, ref, what="", tol_max=TOL_MAX, tol_l2=TOL_L2):
+    assert np.all(np.isfinite(np.asarray(got).view(np.float32))), what
+    m, l2 = nerr(got, ref)
+    assert m < tol_max and l2 < tol_l2, f"{what}: normalised max err {m:.3e}, rel-L2 {l2:.3e}"
+    return m, l2
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return S.default_context()
+
+
+def test_library_loaded_and_gpu_is_gfx950(ctx):
+    name = ctx.name()
+    assert "gfx950" in name, name
+
+
+# ------------------------------------------------------------------------------- golden vectors
+def test_stft_doctest_golden(golden):
+    for v in golden["stft"]:
+        z, t, f = S.stft(np.array(v["x"]), S.windows.rectangular(v["window"]["n"]), **v["opts"])
+        exp = np.array([[complex(float(c[0]), float(c[1])) for c in row] for row in v["z"]], dtype=np.complex64)
+        assert z.dtype == np.complex64 and z.shape == exp.shape
+        assert np.array_equal(z, exp), v["src"]  # small integers: exact
+        assert np.array_equal(t, f32_list(v["t"])) and np.array_equal(f, f32_list(v["f"]))
+
+
+def test_stft_istft_roundtrip_doctests(golden):
+    for v in golden["stft_istft_roundtrip"]:
+        x = np.array(v["x"], dtype=np.float32)
+        w = S.windows.hann(v["window"]["n"])
+        z, _, _ = S.stft(x, w, **v["opts"])
+        y = S.istft(z, w, **v["opts"])
+        assert y.dtype == np.complex64 and y.shape == (8,)
+        exp = np.array([float(e) for e in v["expect"]], dtype=np.float32)
+        assert nx_all_close(y.real, exp, atol=1e-5, rtol=1e-5), (v["src"], y)
+        assert np.max(np.abs(y.imag)) < 1e-5
+        assert y.real[0] == 0.0  # OLA normaliser guard: first sample comes back 0 with Hann (B9)
+        zo, _, _ = O.stft(x, w, **v["opts"])
+        assert_close(z, zo, v["src"])
+        assert_close(y, O.istft(zo, w, **v["opts"]), v["src"])
+
+
+def test_as_windowed_golden(golden):
+    for v in golden["as_windowed"]:
+        pad = v["padding"]
+        if isinstance(pad, list):
+            pad = [tuple(p) for p in pad]
+        got = S.as_windowed(np.array(v["x"]), window_length=v["window_length"], stride=v["stride"], padding=pad)
+        assert got.tolist() == v["expect"], v["src"]
+
+
+def test_overlap_and_add_golden(golden):
+    for v in golden["overlap_and_add"]:
+        t = np.arange(np.prod(v["shape"])).reshape(v["shape"]) if v.get("iota") else np.array(v["t"])
+        got = S.overlap_and_add(t, overlap_length=v["overlap_length"])
+        assert got.tolist() == v["expect"], v["src"]
+
+
+def test_fftconvolve_golden(golden):
+    for v in golden["fftconvolve"]:
+        got = S.convolution.convolve(np.array(v["a"], np.float32), np.array(v["b"], np.float32), method="fft", mode=v["mode"])
+        exp = np.array([float(e) for e in v["expect"]])
+        assert got.dtype == np.float32
+        assert nx_all_close(got, exp, 1e-4, 1e-4), (v["src"], got)
+
+
+def test_fft_rows_golden(golden):
+    for v in golden["fft_rows"]:
+        z = S.transforms.fft_nd(np.array(v["x"]), axes=[-1], lengths=[v["length"]])
+        assert nx_all_close(z[0] + z[1], np.array([complex(*c) for c in v["expect_sum"]]), v["atol"], v["rtol"])
+        assert nx_all_close(z[0] - z[1], np.array([complex(*c) for c in v["expect_diff"]]), v["atol"], v["rtol"])
+
+
+# ------------------------------------------------------------------------------- STFT vs oracle
+STFT_CASES = [
+    # (L, N, overlap, fft_length, padding, scaling, fs, batch_shape)
+    (64, 4, 2, 4, "valid", None, 100, ()),
+    (100, 8, 6, 16, "reflect", None, 100, ()),
+    (1000, 64, 48, 64, "valid", "spectrum", 8000, ()),
+    (1000, 64, 32, 128, "same", "psd", 8000, (3,)),
+    (1000, 100, 50, "power_of_two", "valid", None, 100, ()),  # N=100 -> K=128 zero-pad
+    (1000, 100, 25, 100, "valid", None, 100, ()),  # non power of two: direct DFT path
+    (700, 48, 47, 12, "valid", None, 100, ()),  # fft_length < N: truncation; hop 1
+    (4000, 256, 192, 256, "reflect", "psd", 16000, (2, 2)),
+    (5000, 512, 384, 512, [(7, 300)], None, 100, ()),
+    (5000, 512, 384, 512, [(-5, -9)], None, 100, ()),  # negative explicit padding crops (Nx.pad)
+    (9000, 1024, 768, 1024, "valid", None, 48000, ()),
+    (9000, 1024, 768, 1024, "reflect", "spectrum", 48000, (2,)),
+    (9000, 1024, 512, 2048, "valid", None, 48000, ()),  # zero-padded K=2048 from N=1024
+    (20000, 2048, 1536, 2048, "valid", None, 48000, (3,)),
+    (20000, 2048, 1536, 2048, "same", "psd", 48000, ()),
+    (40000, 4096, 3072, 4096, "valid", None, 48000, ()),
+    (40000, 8192, 4096, 8192, "valid", None, 48000, ()),
+    (3000, 1000, 500, 1000, "valid", None, 100, ()),  # K=1000 direct DFT
+    (5, 4, 2, 4, "reflect", None, 100, ()),  # tiny ragged input
+    (4, 4, 0, 4, "valid", None, 100, ()),  # exactly one frame, no overlap
+]
+
+
+@pytest.mark.parametrize("case", STFT_CASES, ids=lambda c: f"L{c[0]}-N{c[1]}-ov{c[2]}-K{c[3]}-{c[4] if isinstance(c[4], str) else 'explicit'}-{c[5]}")
+def test_stft_matches_oracle(case):
+    L, N, overlap, K, pad, scaling, fs, bshape = case
+    rng = np.random.default_rng(1234 + L + N)
+    x = rng.standard_normal(bshape + (L,)).astype(np.float32)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=overlap, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=fs)
+    z, t, f = S.stft(x, w, **opts)
+    zo, to, fo = O.stft(x, w, **opts)
+    assert z.dtype == np.complex64
+    assert_close(z, zo, str(case))
+    assert np.array_equal(t, to) and np.array_equal(f, fo)
+
+
+def test_stft_other_windows_and_integer_input():
+    x = (np.arange(300) % 17 - 8).astype(np.int32)  # integer tensors are legal (B15)
+    for w in (S.windows.hamming(32), S.windows.blackman(32), S.windows.kaiser(32, beta=8.0), S.windows.rectangular(32)):
+        z, _, _ = S.stft(x, w, overlap_length=24, fft_length=32)
+        zo, _, _ = O.stft(x, w, overlap_length=24, fft_length=32)
+        assert_close(z, zo)
+
+
+def test_stft_config1_one_second_mono():
+    """BASELINE config 1: 1 s mono 48 kHz, N=1024 hop=256 Hann -> 184 frames."""
+    x = O.synth_signal(48000, seed=1234)
+    w = S.windows.hann(1024)
+    z, t, f = S.stft(x, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert z.shape == (184, 1024)
+    zo, to, fo = O.stft(x, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    m, l2 = assert_close(z, zo, "config1")
+    assert np.array_equal(t, to) and np.array_equal(f, fo)
+    # real input -> Hermitian spectrum
+    assert np.max(np.abs(z[:, 1:] - np.conj(z[:, :0:-1]))) / np.max(np.abs(z)) < 1e-6
+
+
+def test_stft_config2_sixty_seconds_full_size():
+    """BASELINE config 2 at full size (11 247 frames) against the oracle, host and device-resident."""
+    x = O.synth_signal(2880000, seed=1234)
+    w = S.windows.hann(1024)
+    opts = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)
+    z, _, _ = S.stft(x, w, **opts)
+    assert z.shape == (11247, 1024)
+    zo, _, _ = O.stft(x, w, **opts)
+    assert_close(z, zo, "config2")
+    ctx = S.default_context()
+    xd = ctx.to_device(x)
+    zd, _, _ = S.stft(xd, w, **opts)
+    assert isinstance(zd, S.DeviceBuffer) and zd.shape == (11247, 1024)
+    assert np.array_equal(zd.numpy().view(np.uint32), z.view(np.uint32))  # host-staged == device-resident, bit for bit
+
+
+def test_stft_linearity_and_shift_properties_full_size():
+    """size-independent properties at config-2 size: linearity and hop-shift covariance."""
+    L, N, hop = 2880000, 1024, 256
+    a = O.synth_signal(L, seed=1)
+    b = O.synth_signal(L, seed=2)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+    za, _, _ = S.stft(a, w, **opts)
+    zb, _, _ = S.stft(b, w, **opts)
+    zab, _, _ = S.stft((a + np.float32(0.5) * b).astype(np.float32), w, **opts)
+    m, _ = nerr(zab, za + np.float32(0.5) * zb)
+    assert m < 1e-5
+    zs, _, _ = S.stft(a[hop:], w, **opts)  # shifting the signal by one hop shifts the frames by one
+    assert np.array_equal(zs.view(np.uint32), za[1:].view(np.uint32))
+
+
+# ------------------------------------------------------------------------------- iSTFT vs oracle
+ISTFT_CASES = [
+    (64, 4, 2, None, 1000), (100, 8, 6, "spectrum", 1000), (1000, 64, 48, "psd", 8000), (1000, 64, 0, None, 1000),
+    (1000, 100, 75, None, 1000),  # non power of two
+    (9000, 1024, 768, None, 48000), (9000, 1024, 768, "psd", 48000), (9000, 1024, 1023, None, 48000),
+    (20000, 2048, 1536, "spectrum", 48000), (40000, 4096, 2048, None, 48000), (3000, 1000, 900, None, 100),
+]
+
+
+@pytest.mark.parametrize("case", ISTFT_CASES, ids=lambda c: f"L{c[0]}-N{c[1]}-ov{c[2]}-{c[3]}")
+def test_istft_matches_oracle(case):
+    L, N, overlap, scaling, fs = case
+    rng = np.random.default_rng(99 + L + N)
+    x = rng.standard_normal((2, L)).astype(np.float32)
+    w = S.windows.hann(N)
+    zo, _, _ = O.stft(x, w, overlap_length=overlap, fft_length=N, scaling=scaling, sampling_rate=fs)
+    # perturb so the spectrum is NOT Hermitian (users edit spectra: guides/filtering.livemd:143)
+    zo = (zo * (1 + 0.1j)).astype(np.complex64)
+    y = S.istft(zo, w, overlap_length=overlap, fft_length=N, scaling=scaling, sampling_rate=fs)
+    yo = O.istft(zo, w, overlap_length=overlap, fft_length=N, scaling=scaling, sampling_rate=fs)
+    assert y.dtype == np.complex64 and y.shape == yo.shape
+    assert_close(y, yo, str(case))
+
+
+def test_roundtrip_config3_sixty_seconds():
+    """BASELINE config 3: stft -> istft on 60 s mono; max rel err < 1e-5 vs the oracle AND vs the input."""
+    x = O.synth_signal(2880000, seed=1234)
+    w = S.windows.hann(1024)
+    opts = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)
+    ctx = S.default_context()
+    zd, _, _ = S.stft(ctx.to_device(x), w, **opts)  # chain stays in HBM
+    yd = S.istft(zd, w, **opts)
+    y = yd.numpy()
+    assert y.shape == (2880000,) and y.dtype == np.complex64
+    zo, _, _ = O.stft(x, w, **opts)
+    yo = O.istft(zo, w, **opts)
+    assert_close(y, yo, "config3 vs oracle")
+    interior = slice(1024, 2880000 - 1024)
+    m, _ = nerr(y.real[interior], x[interior])
+    assert m < 1e-5, m
+    assert y.real[0] == 0.0  # B9
+    y2 = S.istft(zd, w, **opts).numpy()
+    assert np.array_equal(y2.view(np.uint32), y.view(np.uint32))  # deterministic OLA: run-to-run bit-stable
+
+
+def test_as_windowed_and_ola_vs_oracle_exact():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 5000)).astype(np.float32)
+    for N, stride, pad in [(64, 16, "valid"), (100, 33, "reflect"), (7, 7, "same"), (128, 1, [(3, 200)])]:
+        got = S.as_windowed(x, window_length=N, stride=stride, padding=pad)
+        exp = O.as_windowed(x, N, stride, pad)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (N, stride, pad)
+    fr = rng.standard_normal((2, 40, 64)).astype(np.float32)
+    for ov in (0, 16, 48, 63):
+        got = S.overlap_and_add(fr, overlap_length=ov)
+        assert np.array_equal(got.view(np.uint32), O.overlap_and_add(fr, ov).view(np.uint32)), ov
+    frc = (fr + 1j * fr[::-1]).astype(np.complex64)
+    got = S.overlap_and_add(frc, overlap_length=48)
+    assert np.array_equal(got.view(np.uint32), O.overlap_and_add(frc, 48).view(np.uint32))
+
+
+@pytest.mark.parametrize("n_in,K", [(8, 8), (5, 5), (3, 8), (16, 4), (1024, 1024), (1000, 1024), (257, 257), (4096, 8192)])
+def test_fft_rows_vs_oracle(n_in, K):
+    rng = np.random.default_rng(n_in * 7 + K)
+    a = (rng.standard_normal((5, n_in)) + 1j * rng.standard_normal((5, n_in))).astype(np.complex64)
+    assert_close(S.transforms.fft_nd(a, lengths=[K]), O.fft(a, length=K), "fft")
+    assert_close(S.transforms.ifft_nd(a, lengths=[K]), O.ifft(a, length=K), "ifft")
+    r = rng.standard_normal((5, n_in)).astype(np.float32)
+    assert_close(S.transforms.fft_nd(r, lengths=[K]), O.fft(r, length=K), "fft real")
+
+
+# ------------------------------------------------------------------------------- FIR
+@pytest.mark.parametrize("L,taps,mode", [(100, 9, "full"), (100, 9, "same"), (100, 9, "valid"), (5000, 257, "same"),
+                                         (5000, 256, "same"), (100000, 257, "same"), (100000, 31, "full"),
+                                         (40000, 1025, "valid"), (300, 257, "same"), (64, 257, "full")])
+def test_fir_matches_reference_fftconvolve(L, taps, mode):
+    rng = np.random.default_rng(L + taps)
+    x = rng.standard_normal(L).astype(np.float32)
+    h = S.filters.firwin(taps if taps % 2 else taps + 1, [0.25])[:taps]
+    got = S.convolution.convolve(x, h, method="fft", mode=mode)
+    if L * 1.0 * (L + taps) < 4e8 and L <= 5000:
+        exp = O.fftconvolve(x, h, mode=mode)  # the reference formulation: one FFT of length L+K-1
+        assert_close(got, exp, "vs fftconvolve oracle")
+    full = O.direct_convolve_f64(x, h)  # independent check: direct convolution in double
+    n = {"full": L + taps - 1, "same": L, "valid": abs(L - taps) + 1}[mode]
+    start = (full.shape[0] - n) // 2 if mode != "full" else 0
+    assert_close(got, full[start:start + n].astype(np.float32), "vs direct f64")
+
+
+def test_fir_config5_one_million_samples_batched():
+    """BASELINE config 5 shape (257-tap low-pass, 48 kHz) on a 1 M-sample slice x 4 channels vs direct f64."""
+    h = S.filters.firwin(257, [4000], sampling_rate=48000)
+    x = O.synth_signal(1_000_000, seed=7, channels=4)
+    ctx = S.default_context()
+    yd = S.filters.fir(ctx.to_device(x), h, mode="same")
+    y = yd.numpy()
+    assert y.shape == (4, 1_000_000)
+    for ch in range(4):
+        full = O.direct_convolve_f64(x[ch], h)
+        assert_close(y[ch], full[128:128 + 1_000_000].astype(np.float32), f"ch{ch}")

@@ -117,11 +117,13 @@ int launch_stft(Ctx* c, const StftLaunch& a) {
   if (rc || handled) return rc;
   return launch_stft_generic(c, a);
 }
-int launch_istft(Ctx* c, const IstftLaunch& a) {
+int launch_istft_edge_fix(Ctx* c, const IstftLaunch& a, const float* window_host);
+int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
   bool handled = false;
   int rc = launch_istft_wave(c, a, &handled);
-  if (rc || handled) return rc;
-  return launch_istft_generic(c, a);
+  if (rc) return rc;
+  if (!handled && (rc = launch_istft_generic(c, a))) return rc;
+  return launch_istft_edge_fix(c, a, window_host);  // ill-conditioned edge samples recomputed in double
 }
 int launch_fir(Ctx* c, const FirLaunch& a) {
   bool handled = false;
@@ -480,14 +482,14 @@ int nxsig_istft_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int3
   const size_t zbytes = (size_t)batch * num_frames * K * sizeof(float2), ybytes = (size_t)batch * out_len * sizeof(float2);
   if (mem == NXSIG_DEVICE) {
     a.z = reinterpret_cast<const float2*>(z); a.y = reinterpret_cast<float2*>(y);
-    return launch_istft(c, a);
+    return launch_istft(c, a, window);
   }
   Staged st(c);
   const void* zd = nullptr; void* yd = nullptr;
   if ((rc = st.in(1, z, zbytes, &zd))) return rc;
   if ((rc = st.out_alloc(2, ybytes, &yd))) return rc;
   a.z = reinterpret_cast<const float2*>(zd); a.y = reinterpret_cast<float2*>(yd);
-  if ((rc = launch_istft(c, a))) return rc;
+  if ((rc = launch_istft(c, a, window))) return rc;
   return st.out_copy(y, yd, ybytes);
   NXSIG_API_END
 }

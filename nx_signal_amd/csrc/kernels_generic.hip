@@ -305,6 +305,74 @@ __global__ __launch_bounds__(kThreads) void k_ola(const float* __restrict__ fram
   }
 }
 
+// ------------------------------------------------------------------------------------------ iSTFT edge fix-up
+// Where the OLA normaliser den[n] is tiny (signal edges under a tapered window, or every frame boundary when
+// hop == N) the division amplifies the fp32 round-off of the IFFT by 1/sqrt(den): the reference does not suffer
+// from it because Nx.ifft works in double and rounds each (tiny) sample RELATIVELY (SURVEY App. A rule 7).  Those
+// few samples are recomputed here exactly along the reference's chain: frame sample by direct evaluation of the
+// inverse DFT in double -> round to f32 -> x scale -> x window (f32 roundings, lib/nx_signal.ex:611-628) ->
+// summed over frames in double, rounded once (:724) -> / den (:637).  One workgroup per candidate sample.
+struct EdgeFixArgs {
+  const float2* z;          // c64[batch][M][K]
+  int64_t M;
+  int32_t N, hop;           // K == N
+  const float* window;
+  float scale;
+  int32_t has_scale;
+  float2* y;                // c64[batch][out_len]
+  int64_t out_len;
+  int64_t head_cnt, tail_start;  // candidates: [0, head_cnt) and [tail_start, out_len)
+  float tau;                // recompute when 1e-10 < den < tau
+};
+
+__global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
+  __shared__ double red[2 * kThreads];
+  const int tid = threadIdx.x;
+  const int64_t n = (int64_t)blockIdx.x < a.head_cnt ? (int64_t)blockIdx.x : a.tail_start + ((int64_t)blockIdx.x - a.head_cnt);
+  if (n >= a.out_len) return;
+  int64_t m_hi = n / a.hop;
+  if (m_hi > a.M - 1) m_hi = a.M - 1;
+  int64_t m_lo = (n - a.N + 1 <= 0) ? 0 : (n - a.N + a.hop) / a.hop;
+  double den = 0.0;
+  for (int64_t m = m_lo; m <= m_hi; ++m) {
+    const float w = fabsf(a.window[n - m * a.hop]);
+    den += (double)(w * w);
+  }
+  const float d = (float)den;
+  if (!(d > 1.0e-10f) || d >= a.tau) return;  // uniform across the block
+  const float2* zb = a.z + (size_t)blockIdx.y * a.M * a.N;
+  double acc_re = 0.0, acc_im = 0.0;
+  for (int64_t m = m_lo; m <= m_hi; ++m) {
+    const int j = (int)(n - m * a.hop);
+    const float2* zr = zb + (size_t)m * a.N;
+    double sr = 0.0, si = 0.0;
+    for (int k = tid; k < a.N; k += kThreads) {
+      const int64_t jk = ((int64_t)j * k) % a.N;
+      double sn, cs;
+      sincospi(2.0 * (double)jk / (double)a.N, &sn, &cs);
+      const float2 v = zr[k];
+      sr += (double)v.x * cs - (double)v.y * sn;
+      si += (double)v.x * sn + (double)v.y * cs;
+    }
+    red[tid] = sr;
+    red[kThreads + tid] = si;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+      if (tid < s) { red[tid] += red[tid + s]; red[kThreads + tid] += red[kThreads + tid + s]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      float fr = (float)(red[0] / (double)a.N), fi = (float)(red[kThreads] / (double)a.N);  // Nx.ifft rounds to c64
+      if (a.has_scale) { fr *= a.scale; fi *= a.scale; }
+      const float w = a.window[j];
+      fr *= w; fi *= w;
+      acc_re += (double)fr; acc_im += (double)fi;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) a.y[(size_t)blockIdx.y * a.out_len + n] = make_float2((float)acc_re / d, (float)acc_im / d);
+}
+
 // ------------------------------------------------------------------------------------------ framing
 __global__ __launch_bounds__(kThreads) void k_as_windowed(const float* __restrict__ x, int64_t batch_stride, FrameGeom g,
                                                          float* __restrict__ out) {
@@ -548,6 +616,41 @@ int launch_fir_generic(Ctx* c, const FirLaunch& s) {
   if (rc) return rc;
   dim3 grid((unsigned)((a.nblocks + 1) / 2), (unsigned)s.batch);
   hipLaunchKernelGGL(k_fir_os, grid, dim3(kThreads), lds, c->stream, a);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+// launched after ANY istft main kernel (generic or tuned): see k_istft_edge_fix
+int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host) {
+  if (s.M == 0 || s.batch == 0) return NXSIG_OK;
+  const int N = s.N, hop = s.hop;
+  const int64_t out_len = s.M * hop + (N - hop);
+  // interior normaliser is periodic in n with period hop: den_mid[r] = sum_{j = r (mod hop)} |w[j]|^2
+  const int period = hop < N ? hop : N;
+  double dmin = 1e300, dmax = 0.0;
+  for (int r = 0; r < period; ++r) {
+    double d = 0.0;
+    for (int j = r; j < N; j += hop) { const float w = std::fabs(window_host[j]); d += (double)(w * w); }
+    dmin = d < dmin ? d : dmin;
+    dmax = d > dmax ? d : dmax;
+  }
+  if (!(dmax > 0.0)) return NXSIG_OK;
+  EdgeFixArgs a;
+  a.tau = (float)(0.02 * dmax);
+  a.z = s.z; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
+  a.y = s.y; a.out_len = out_len;
+  if (hop < N && dmin >= (double)a.tau) {  // well-conditioned interior: only the partial-overlap edges are candidates
+    a.head_cnt = (N - hop) < out_len ? (N - hop) : out_len;
+    a.tail_start = s.M * hop > a.head_cnt ? s.M * hop : a.head_cnt;
+  } else {
+    a.head_cnt = out_len;
+    a.tail_start = out_len;
+  }
+  const int64_t blocks = a.head_cnt + (out_len - a.tail_start);
+  if (blocks <= 0) return NXSIG_OK;
+  if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "istft: signal too long for the edge fix-up grid");
+  dim3 grid((unsigned)blocks, (unsigned)s.batch);
+  hipLaunchKernelGGL(k_istft_edge_fix, grid, dim3(kThreads), 0, c->stream, a);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
 }

@@ -98,7 +98,7 @@ struct IstftLaunch {
   int32_t has_scale;
   float2* y;             // device c64[batch][M*hop + N-hop]
 };
-int launch_istft(Ctx* c, const IstftLaunch& a);
+int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host);
 
 int launch_as_windowed(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, const Framing& fr, float* out);
 int launch_overlap_and_add(Ctx* c, const float* frames, int64_t M, int32_t batch, int32_t N, int32_t hop, int32_t comps,

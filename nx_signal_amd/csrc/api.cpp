@@ -103,6 +103,27 @@ int ctx_scratch(Ctx* c, int slot, size_t bytes, void** out) {
   return NXSIG_OK;
 }
 
+int ctx_window(Ctx* c, const float* w, int N, int K, const float** dev, const float** devK) {
+  if (c->memo_dev && c->memo_K == K && (int)c->memo_win.size() == N &&
+      std::memcmp(c->memo_win.data(), w, (size_t)N * sizeof(float)) == 0) {
+    *dev = c->memo_dev; *devK = c->memo_devK;
+    return NXSIG_OK;
+  }
+  const void *d = nullptr, *dk = nullptr;
+  int rc = ctx_table(c, 0x57494Eull, w, (size_t)N * sizeof(float), &d);
+  if (rc) return rc;
+  std::vector<float> padded((size_t)K, 0.0f);
+  for (int i = 0; i < K && i < N; ++i) padded[i] = w[i];
+  rc = ctx_table(c, 0x57494E4Bull, padded.data(), padded.size() * sizeof(float), &dk);
+  if (rc) return rc;
+  c->memo_win.assign(w, w + N);
+  c->memo_K = K;
+  c->memo_dev = reinterpret_cast<const float*>(d);
+  c->memo_devK = reinterpret_cast<const float*>(dk);
+  *dev = c->memo_dev; *devK = c->memo_devK;
+  return NXSIG_OK;
+}
+
 // declared here, implemented in the .hip files
 int launch_stft_generic(Ctx* c, const StftLaunch& a);
 int launch_istft_generic(Ctx* c, const IstftLaunch& a);
@@ -140,6 +161,8 @@ struct DeviceGuard {
       (void)hipStreamSynchronize(c->stream);
       for (auto& kv : c->tables) (void)hipFree(kv.second.ptr);
       c->tables.clear();
+      c->wave_tables.clear();
+      c->memo_dev = c->memo_devK = nullptr;
     }
   }
   std::lock_guard<std::mutex> lock;
@@ -432,10 +455,8 @@ int nxsig_stft_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch
   a.fr = fr; a.batch = batch; a.batch_stride = batch_stride; a.K = p->fft_length;
   a.has_scale = p->scaling != NXSIG_SCALE_NONE;
   a.inv_scale_div = a.has_scale ? scaling_factor(window, p->frame_length, p->scaling, p->sampling_rate) : 1.0f;
-  const void* wdev = nullptr;
-  rc = ctx_table(c, 0x57494Eull, window, (size_t)p->frame_length * sizeof(float), &wdev);
+  rc = ctx_window(c, window, p->frame_length, p->fft_length, &a.window, &a.window_padK);
   if (rc) return rc;
-  a.window = reinterpret_cast<const float*>(wdev);
   const size_t zbytes = (size_t)batch * fr.M * p->fft_length * sizeof(float2);
   if (mem == NXSIG_DEVICE) {
     a.x = x; a.z = reinterpret_cast<float2*>(z);

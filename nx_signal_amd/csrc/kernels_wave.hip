@@ -1,9 +1,377 @@
-// Tuned wave-per-frame kernels (gfx950).  PLACEHOLDER until the generic path is parity-green on hardware:
-// every launcher reports "not handled" so the dispatcher in api.cpp falls through to kernels_generic.hip.
+// Tuned gfx950 STFT kernel: ONE WAVE transforms TWO adjacent real frames as the real / imaginary lanes of one
+// K-point complex FFT (K = 1024 or 2048), entirely wave-private — no workgroup barrier anywhere.
+//
+//   global load (frame slice x window fused, lib/nx_signal.ex:94-101)          64 lanes x P = K/64 points
+//   pass A  radix-16, registers                      -> LDS exchange 1 (padded e + e/16: conflict-free)
+//   pass B  radix-16, twiddles w_256^(t k) from LDS  -> LDS exchange 2
+//   pass C  radix-4 (K=1024) / radix-8 (K=2048), butterflies i = 2l+e+128u so every lane owns ADJACENT bins
+//   Hermitian untangle of the two real spectra through partner lanes (ds_bpermute, no LDS storage):
+//           XA[k] = (Z[k] + conj Z[K-k]) / 2 ,  XB[k] = -i (Z[k] - conj Z[K-k]) / 2
+//   optional :spectrum / :psd division (lib/nx_signal.ex:113-127), 16-byte non-temporal stores of the full
+//   two-sided c64 spectrum (:129), 1 KiB per wave instruction.
+//
+// The path is HBM-bound (9 216 algorithmic B/frame at K=1024, 89 % stores), MFMA is deliberately unused.
+// Index math and LDS bank behaviour are modelled lane by lane in tools/emulate_wave_fft.py.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+
 #include "nxsig_internal.h"
 
 namespace nxsig {
-int launch_stft_wave(Ctx*, const StftLaunch&, bool* handled) { *handled = false; return NXSIG_OK; }
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+static constexpr int kWaveThreads = 256;  // 4 independent waves per workgroup
+static constexpr int kWavesPerBlock = kWaveThreads / 64;
+
+__device__ __forceinline__ v2f wcmul(v2f a, v2f b) { return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ v2f mul_neg_i(v2f a) { return v2f{a.y, -a.x}; }  // a * (-i)
+
+// natural-order forward DFTs on registers
+__device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+  const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = mul_neg_i(a1 - a3);
+  a0 = s02 + s13; a1 = d02 + d13; a2 = s02 - s13; a3 = d02 - d13;
+}
+
+__device__ __forceinline__ void dft8(v2f* u) {
+  // t = 2 t1 + t0: A[t0][r0] = DFT4_{t1}(u[2 t1 + t0]); A[1][r0] *= W8^r0; v[r0] = A0 + A1, v[r0+4] = A0 - A1
+  v2f a0 = u[0], a1 = u[2], a2 = u[4], a3 = u[6];
+  v2f b0 = u[1], b1 = u[3], b2 = u[5], b3 = u[7];
+  dft4(a0, a1, a2, a3);
+  dft4(b0, b1, b2, b3);
+  const float h = 0.70710678118654752f;
+  b1 = v2f{(b1.x + b1.y) * h, (b1.y - b1.x) * h};   // * (1 - i)/sqrt2
+  b2 = mul_neg_i(b2);                                // * -i
+  b3 = v2f{(b3.y - b3.x) * h, -(b3.x + b3.y) * h};  // * (-1 - i)/sqrt2
+  u[0] = a0 + b0; u[4] = a0 - b0;
+  u[1] = a1 + b1; u[5] = a1 - b1;
+  u[2] = a2 + b2; u[6] = a2 - b2;
+  u[3] = a3 + b3; u[7] = a3 - b3;
+}
+
+__device__ __forceinline__ void dft16(v2f* u) {
+  // t = 4 t1 + t0, r = r0 + 4 r1:  A[t0][r0] = DFT4_{t1}(u[4 t1 + t0]); A *= W16^(t0 r0); v[r0 + 4 r1] = DFT4_{t0}(A[.][r0])
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+  v2f A[4][4];
+#pragma unroll
+  for (int t0 = 0; t0 < 4; ++t0) {
+    A[t0][0] = u[t0]; A[t0][1] = u[4 + t0]; A[t0][2] = u[8 + t0]; A[t0][3] = u[12 + t0];
+    dft4(A[t0][0], A[t0][1], A[t0][2], A[t0][3]);
+  }
+  // W16^j = (cos, -sin)(2 pi j / 16)
+  A[1][1] = wcmul(A[1][1], v2f{c1, -s1});                               // W^1
+  A[1][2] = v2f{(A[1][2].x + A[1][2].y) * h, (A[1][2].y - A[1][2].x) * h};  // W^2
+  A[1][3] = wcmul(A[1][3], v2f{s1, -c1});                               // W^3
+  A[2][1] = v2f{(A[2][1].x + A[2][1].y) * h, (A[2][1].y - A[2][1].x) * h};  // W^2
+  A[2][2] = mul_neg_i(A[2][2]);                                         // W^4
+  A[2][3] = v2f{(A[2][3].y - A[2][3].x) * h, -(A[2][3].x + A[2][3].y) * h}; // W^6
+  A[3][1] = wcmul(A[3][1], v2f{s1, -c1});                               // W^3
+  A[3][2] = v2f{(A[3][2].y - A[3][2].x) * h, -(A[3][2].x + A[3][2].y) * h}; // W^6
+  A[3][3] = wcmul(A[3][3], v2f{-c1, s1});                               // W^9
+#pragma unroll
+  for (int r0 = 0; r0 < 4; ++r0) {
+    dft4(A[0][r0], A[1][r0], A[2][r0], A[3][r0]);
+    u[r0] = A[0][r0]; u[r0 + 4] = A[1][r0]; u[r0 + 8] = A[2][r0]; u[r0 + 12] = A[3][r0];
+  }
+}
+
+// compiler-level ordering of this wave's LDS traffic (the hardware executes a wave's DS ops in order;
+// no s_barrier, no s_waitcnt vmcnt: outstanding global stores keep flying)
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct WaveArgs {
+  const float* x;
+  int64_t batch_stride, L, lo, M;
+  int32_t N, hop, reflect, batch;
+  int64_t pairs_per_row;      // ceil(M / 2)
+  int64_t total_pairs;        // batch * pairs_per_row
+  int64_t chunk;              // pairs per workgroup (contiguous)
+  const float* wtab;          // device f32[K]: window zero-padded / truncated to K
+  const v2f* twB;             // device c64[16][16]: w_256^(t k)
+  const v2f* twC;             // device c64[R3][256]: w_K^(t i)
+  float div;
+  int32_t has_scale;
+  v2f* z;
+  v2f* dummy;                 // device c64[K]: sink for the phantom second frame of an odd tail (keeps the loop branch-free)
+};
+
+__device__ __forceinline__ float fetch_any(const float* __restrict__ x, const WaveArgs& a, int64_t q) {
+  int64_t pos = q - a.lo;
+  if (a.reflect) {
+    if (a.L == 1) return x[0];
+    const int64_t period = 2 * (a.L - 1);
+    pos %= period;
+    if (pos < 0) pos += period;
+    if (pos >= a.L) pos = period - pos;
+    return x[pos];
+  }
+  return (pos >= 0 && pos < a.L) ? x[pos] : 0.0f;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char g_wave_smem[];
+
+typedef __attribute__((address_space(1))) v4f gv4f;  // explicit global address space: global_store, not flat_store
+
+// GENERAL = false: :valid framing with every existing frame fully inside the signal (the streaming case);
+// GENERAL = true : any padding mode / ragged tail, per-sample bounds and mirror math.  SCALE: :spectrum / :psd.
+template <int K, bool GENERAL, bool SCALE>
+__global__ __launch_bounds__(kWaveThreads) void k_stft_wave(WaveArgs a) {
+  constexpr int P = K / 64;     // complex points per lane
+  constexpr int R3 = K / 256;   // last radix: 4 or 8
+  constexpr int B12 = P / 16;   // radix-16 butterflies per lane in passes A and B
+  constexpr int NQ = K / 128;   // bins per lane per parity
+  constexpr int XCH = K + K / 16 + 16;  // padded exchange buffer, complex elements (keeps 16-B alignment)
+
+  // ---- LDS carve: [window K f32][twB 256 c64][twC R3*256 c64][4 x exchange]
+  float* s_w = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_twB = reinterpret_cast<v2f*>(s_w + K);
+  v2f* s_twC = s_twB + 256;
+  v2f* s_x = s_twC + R3 * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < K; i += kWaveThreads) s_w[i] = a.wtab[i];
+  s_twB[tid] = a.twB[tid];
+  for (int i = tid; i < R3 * 256; i += kWaveThreads) s_twC[i] = a.twC[i];
+  __syncthreads();  // the only workgroup barrier: tables are read-only afterwards
+  v2f* xb = s_x + wave * XCH;
+
+  const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
+  int64_t p_end = p_begin + a.chunk;
+  if (p_end > a.total_pairs) p_end = a.total_pairs;
+
+  // Streaming kernels are software-pipelined one pair deep.  Iteration i: issue the raw loads of pair i+1 ->
+  // FFT passes of pair i -> multiply the (long since landed) samples of pair i+1 by the window -> untangle and
+  // store pair i.  The loads are consumed BEFORE this pair's stores are issued, so the only VMEM ops ahead of
+  // them in gfx9's in-order queue are the previous iteration's stores (a whole iteration old): no wait ever
+  // drains fresh stores, and HBM latency hides under the butterflies.
+  float ra[P], rb[P];
+  auto issue_loads = [&](int64_t row, int64_t pin) {
+    const int64_t mA = pin * 2;
+    const float* pa = a.x + (size_t)row * a.batch_stride + mA * a.hop + lane;
+    const float* pb = pa + ((mA + 1 < a.M) ? a.hop : 0);  // phantom frame B of an odd tail: reload A, never stored
+#pragma unroll
+    for (int s = 0; s < P; ++s) { ra[s] = pa[64 * s]; rb[s] = pb[64 * s]; }
+  };
+  // (row, pair-in-row) of this wave's current and next pair, advanced incrementally (no division in the loop)
+  int64_t row = (p_begin + wave) / a.pairs_per_row;
+  int64_t pin = (p_begin + wave) - row * a.pairs_per_row;
+  int64_t nrow = row, npin = pin;
+  auto advance = [&](int64_t& r, int64_t& q) {
+    q += kWavesPerBlock;
+    while (q >= a.pairs_per_row) { q -= a.pairs_per_row; ++r; }
+  };
+  advance(nrow, npin);
+  v2f d[P];  // windowed samples of the current pair: re = frame A, im = frame B (exact f32 products, :101)
+  if (!GENERAL && p_begin + wave < p_end) {
+    issue_loads(row, pin);
+#pragma unroll
+    for (int s = 0; s < P; ++s) { const float w = s_w[lane + 64 * s]; d[s] = v2f{ra[s] * w, rb[s] * w}; }
+  }
+
+  for (int64_t pr = p_begin + wave; pr < p_end; pr += kWavesPerBlock) {
+    const int64_t mA = pin * 2, mB = mA + 1;
+    const bool haveB = mB < a.M;
+    const int64_t crow = row;
+    if (!GENERAL) {
+      // unconditional prefetch (the last iteration harmlessly re-reads its own pair) keeps the loop branch-free
+      const bool more = pr + kWavesPerBlock < p_end;
+      issue_loads(more ? nrow : row, more ? npin : pin);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      const float* xr = a.x + (size_t)row * a.batch_stride;
+      const int64_t qA = mA * a.hop, qB = qA + a.hop;
+#pragma unroll
+      for (int s = 0; s < P; ++s) {
+        const int n = lane + 64 * s;
+        const float w = s_w[n];
+        const float va = (n < a.N) ? fetch_any(xr, a, qA + n) : 0.0f;
+        const float vb = (haveB && n < a.N) ? fetch_any(xr, a, qB + n) : 0.0f;
+        d[s] = v2f{va * w, vb * w};
+      }
+    }
+
+    // ---- pass A: radix-16, p = 1; butterfly i = lane + 64 u takes points i + t K/16  (= d[u + B12 t])
+#pragma unroll
+    for (int u = 0; u < B12; ++u) {
+      v2f b[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) b[t] = d[u + B12 * t];
+      dft16(b);
+      const int base = 17 * (lane + 64 * u);  // pad1(16 i + r) = 17 i + r
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xb[base + r] = b[r];
+    }
+    wave_lds_fence();
+
+    // ---- pass B: radix-16, p = 16; reads pad1(i + t K/16), twiddle w_256^(t k), k = lane & 15
+    const int k16 = lane & 15;
+    v2f e[B12][16];
+#pragma unroll
+    for (int u = 0; u < B12; ++u) {
+      const int base = lane + (lane >> 4) + 68 * u;  // pad1(l + 64 u + 64 B12 t) = l + l/16 + 68 u + 68 B12 t
+#pragma unroll
+      for (int t = 0; t < 16; ++t) e[u][t] = xb[base + 68 * B12 * t];
+    }
+#pragma unroll
+    for (int u = 0; u < B12; ++u) {
+#pragma unroll
+      for (int t = 1; t < 16; ++t) e[u][t] = wcmul(e[u][t], s_twB[t * 16 + k16]);
+      dft16(e[u]);
+    }
+    wave_lds_fence();  // every exchange-1 read is issued before exchange 2 overwrites the buffer
+#pragma unroll
+    for (int u = 0; u < B12; ++u) {
+      const int base = 16 * (lane + 64 * u) - 15 * k16;  // (i - k) 16 + k
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xb[base + 16 * r] = e[u][r];
+    }
+    wave_lds_fence();
+
+    // ---- pass C: radix-R3, p = 256; butterflies i = 2 lane + par + 128 u2 (adjacent pair per 16-byte LDS read)
+    v2f zz[2][NQ];  // zz[par][q] = Z[2 lane + par + 128 q], q = u2 + 2 r
+#pragma unroll
+    for (int u2 = 0; u2 < 2; ++u2) {
+      v2f c0[R3], c1[R3];
+      const int i0 = 2 * lane + 128 * u2;
+#pragma unroll
+      for (int t = 0; t < R3; ++t) {
+        const v4f v = *reinterpret_cast<const v4f*>(&xb[i0 + 256 * t]);
+        c0[t] = v2f{v.x, v.y};
+        c1[t] = v2f{v.z, v.w};
+        if (t > 0) {
+          const v4f w = *reinterpret_cast<const v4f*>(&s_twC[t * 256 + i0]);
+          c0[t] = wcmul(c0[t], v2f{w.x, w.y});
+          c1[t] = wcmul(c1[t], v2f{w.z, w.w});
+        }
+      }
+      if (R3 == 4) { dft4(c0[0], c0[1], c0[2], c0[3]); dft4(c1[0], c1[1], c1[2], c1[3]); }
+      else { dft8(c0); dft8(c1); }
+#pragma unroll
+      for (int r = 0; r < R3; ++r) { zz[0][u2 + 2 * r] = c0[r]; zz[1][u2 + 2 * r] = c1[r]; }
+    }
+    wave_lds_fence();  // next iteration's pass-A writes come after these reads
+
+    if (!GENERAL) {  // next pair: raw samples landed during the butterflies
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < P; ++s) { const float w = s_w[lane + 64 * s]; d[s] = v2f{ra[s] * w, rb[s] * w}; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- Hermitian untangle through partner lanes + store
+    const int src0 = ((64 - lane) & 63) << 2, src1 = (63 - lane) << 2;
+    v2f* zA = a.z + ((size_t)crow * a.M + mA) * K + 2 * lane;
+    v2f* zB = (GENERAL || haveB) ? zA + K : a.dummy + 2 * lane;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      // partner of bin k = 2l+par+128q is K-k = 2l'+par+128(NQ-1-q) on lane l' (lane 0 / par 0: own (NQ-q) % NQ)
+      const v2f own0 = zz[0][(NQ - q) % NQ];
+      v2f p0, p1;
+      p0.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(zz[0][NQ - 1 - q].x)));
+      p0.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(zz[0][NQ - 1 - q].y)));
+      p1.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(zz[1][NQ - 1 - q].x)));
+      p1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(zz[1][NQ - 1 - q].y)));
+      if (lane == 0) p0 = own0;
+      const v2f z0 = zz[0][q], z1 = zz[1][q];
+      // XA = ((a + c), (b - d)) / 2 ; XB = ((b + d), (c - a)) / 2   with Z = a + ib, Z[K-k] = c + id
+      v4f xa = v4f{z0.x + p0.x, z0.y - p0.y, z1.x + p1.x, z1.y - p1.y} * 0.5f;
+      v4f xbv = v4f{z0.y + p0.y, p0.x - z0.x, z1.y + p1.y, p1.x - z1.x} * 0.5f;
+      if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }  // true division like the reference (:116/:119)
+      __builtin_nontemporal_store(xa, (gv4f*)(zA + 128 * q));
+      if (!GENERAL || haveB) __builtin_nontemporal_store(xbv, (gv4f*)(zB + 128 * q));
+    }
+    row = nrow; pin = npin;
+    advance(nrow, npin);
+  }
+}
+
+// ============================================================================================ host side
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : dflt;
+}
+
+template <int K>
+static int launch_wave_K(Ctx* c, const StftLaunch& s) {
+  constexpr int R3 = K / 256;
+  constexpr int XCH = K + K / 16 + 16;
+  const double two_pi = 6.283185307179586476925286766559;
+  // s.window_padK: the window zero-padded (K > N) or truncated (K < N) to K — Nx.fft(length: K) semantics
+  WaveArgs a;
+  a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
+  a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
+  a.pairs_per_row = (s.fr.M + 1) / 2;
+  a.total_pairs = a.pairs_per_row * s.batch;
+  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
+
+  // twiddle tables, generated in double once per (context, K)
+  Ctx::WaveTables& wt = c->wave_tables[K];
+  if (!wt.twB) {
+    std::vector<float2> twB(256), twC((size_t)R3 * 256);
+    for (int t = 0; t < 16; ++t)
+      for (int k = 0; k < 16; ++k) {
+        const double ang = -two_pi * (double)(t * k) / 256.0;
+        twB[t * 16 + k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      }
+    for (int t = 0; t < R3; ++t)
+      for (int i = 0; i < 256; ++i) {
+        const double ang = -two_pi * (double)(t * i) / (double)K;
+        twC[(size_t)t * 256 + i] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      }
+    int rc = ctx_table(c, 0x7742ull, twB.data(), twB.size() * sizeof(float2), &wt.twB);
+    if (rc) return rc;
+    rc = ctx_table(c, 0x7743ull ^ (uint64_t)K, twC.data(), twC.size() * sizeof(float2), &wt.twC);
+    if (rc) { wt.twB = nullptr; return rc; }
+  }
+  a.twB = reinterpret_cast<const v2f*>(wt.twB);
+  a.twC = reinterpret_cast<const v2f*>(wt.twC);
+  a.wtab = s.window_padK;
+  void* dummy = nullptr;
+  { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
+  a.dummy = reinterpret_cast<v2f*>(dummy);
+
+  const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)kWavesPerBlock * XCH * 8;
+  // contiguous chunk of frame pairs per workgroup: input halos are re-read only at chunk seams
+  const int blocks_per_cu = env_int("NXSIG_WAVE_BLOCKS_PER_CU", 12);
+  int64_t max_blocks = (int64_t)c->num_cus * blocks_per_cu;
+  int64_t want = (a.total_pairs + kWavesPerBlock - 1) / kWavesPerBlock;
+  int64_t blocks = want < max_blocks ? want : max_blocks;
+  if (blocks < 1) blocks = 1;
+  a.chunk = (a.total_pairs + blocks - 1) / blocks;
+  a.chunk = ((a.chunk + kWavesPerBlock - 1) / kWavesPerBlock) * kWavesPerBlock;
+  blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
+  // streaming case: no padding and every existing frame reads K samples inside the signal
+  const bool streaming = s.fr.reflect == 0 && s.fr.lo == 0 && ((s.fr.M - 1) * (int64_t)s.fr.hop + K <= s.fr.L);
+  const bool scale = s.has_scale != 0;
+  auto go = [&](auto kernel) -> int {
+    if (lds > 64 * 1024)
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kWaveThreads), lds, c->stream, a);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  };
+  if (streaming && !scale) return go(k_stft_wave<K, false, false>);
+  if (streaming && scale) return go(k_stft_wave<K, false, true>);
+  if (!scale) return go(k_stft_wave<K, true, false>);
+  return go(k_stft_wave<K, true, true>);
+}
+
+int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
+  *handled = false;
+  if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
+  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (s.window_padK == nullptr) return NXSIG_OK;
+  if (s.K == 1024) { *handled = true; return launch_wave_K<1024>(c, s); }
+  if (s.K == 2048) { *handled = true; return launch_wave_K<2048>(c, s); }
+  return NXSIG_OK;
+}
+
 int launch_istft_wave(Ctx*, const IstftLaunch&, bool* handled) { *handled = false; return NXSIG_OK; }
 int launch_fir_wave(Ctx*, const FirLaunch&, bool* handled) { *handled = false; return NXSIG_OK; }
+
 }  // namespace nxsig

@@ -67,11 +67,21 @@ struct Ctx {
   // scratch buffer reused by multi-stage paths (generic istft, host staging)
   void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t scratch_bytes[4] = {0, 0, 0, 0};
+  // per-K tables of the tuned wave kernels (pass-B / pass-C twiddles), built once
+  struct WaveTables { const void* twB = nullptr; const void* twC = nullptr; const void* twI = nullptr; };
+  std::map<int, WaveTables> wave_tables;
+  // memo of the last window seen (the common case: the same window tensor call after call)
+  std::vector<float> memo_win;
+  int memo_K = 0;
+  const float* memo_dev = nullptr;   // f32[N]
+  const float* memo_devK = nullptr;  // f32[K], zero-padded / truncated to the fft length
 };
 
 int ctx_twiddles(Ctx* c, int K, const float2** out);
 int ctx_table(Ctx* c, uint64_t tag, const void* host, size_t bytes, const void** out);
 int ctx_scratch(Ctx* c, int slot, size_t bytes, void** out);
+// device copies of a host window: raw f32[N] and the K-point table (Nx.fft(length: K) pads / truncates rows)
+int ctx_window(Ctx* c, const float* window_host, int N, int K, const float** dev, const float** devK);
 uint64_t fnv1a(uint64_t seed, const void* data, size_t bytes);
 
 // ---- kernel launchers (implemented in the .hip files; all enqueue on c->stream) ----
@@ -82,6 +92,7 @@ struct StftLaunch {
   Framing fr;
   int32_t K;             // fft length
   const float* window;   // device f32[N]
+  const float* window_padK = nullptr;  // device f32[K] (zero-padded / truncated), used by the wave kernel
   float inv_scale_div;   // spectrum is DIVIDED by this (1.0 = none); division kept exact like the reference
   int32_t has_scale;
   float2* z;             // device c64[batch][M][K]

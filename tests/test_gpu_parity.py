@@ -197,7 +197,8 @@ def test_stft_linearity_and_shift_properties_full_size():
     m, _ = nerr(zab, za + np.float32(0.5) * zb)
     assert m < 1e-5
     zs, _, _ = S.stft(a[hop:], w, **opts)  # shifting the signal by one hop shifts the frames by one
-    assert np.array_equal(zs.view(np.uint32), za[1:].view(np.uint32))
+    m, _ = nerr(zs, za[1:])  # (frames change real/imag lanes in the packed FFT, so equal to rounding, not bitwise)
+    assert m < 1e-6
 
 
 # ------------------------------------------------------------------------------- iSTFT vs oracle

@@ -1,0 +1,63 @@
+// Empirical HBM ceilings on MI355X for the STFT traffic mix (tools only, not part of the library).
+//   copy   : float4 read + float4 write (the 6.29 TB/s figure of MI355X_MICROARCH.md)
+//   fill   : 16 B/lane stores only
+//   stftmix: per "frame" read 1 KiB (hop*4) and write 8 KiB (K*8), no FFT — the best any STFT kernel can do
+// usage: hbm_ceiling [MiB_out]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void k_fill(float4* __restrict__ out, size_t n, float v) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = make_float4(v, v + 1, v + 2, v + 3);
+}
+// one wave per frame: lane reads float4 (1 KiB per frame... 64 lanes x 16 B), writes 8 x float4 (8 KiB)
+template <int NT>
+__global__ __launch_bounds__(256) void k_stftmix(const float4* __restrict__ in, float4* __restrict__ out, size_t frames) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * 256) >> 6;
+  for (size_t f = wave; f < frames; f += nw) {
+    float4 v = in[f * 64 + lane];
+    float4* o = out + f * 512;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float4 r = make_float4(v.x + j, v.y - j, v.z * (j + 1), v.w);
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      v4f rv = {r.x, r.y, r.z, r.w};
+      if (NT) __builtin_nontemporal_store(rv, reinterpret_cast<v4f*>(&o[j * 64 + lane])); else o[j * 64 + lane] = r;
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  size_t mib = argc > 1 ? atol(argv[1]) : 2048;
+  size_t bytes = mib << 20;
+  float4 *a, *b;
+  CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
+  CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  size_t n = bytes / 16;
+  auto time = [&](auto launch, int reps) { for (int i = 0; i < 3; ++i) launch(); CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / reps; };
+  for (int grid : {2048, 4096, 8192, 16384}) {
+    float ms = time([&] { hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, a, b, n); }, 20);
+    printf("copy     grid %6d: %8.3f ms  %7.1f GB/s (r+w)\n", grid, ms, 2.0 * bytes / ms / 1e6);
+  }
+  for (int grid : {2048, 8192}) {
+    float ms = time([&] { hipLaunchKernelGGL(k_fill, dim3(grid), dim3(256), 0, 0, b, n, 1.0f); }, 20);
+    printf("fill     grid %6d: %8.3f ms  %7.1f GB/s (w)\n", grid, ms, 1.0 * bytes / ms / 1e6);
+  }
+  size_t frames = bytes / 8192;
+  for (int grid : {1024, 2048, 4096, 8192, 16384}) {
+    float ms = time([&] { hipLaunchKernelGGL(k_stftmix<0>, dim3(grid), dim3(256), 0, 0, a, b, frames); }, 20);
+    printf("stftmix  grid %6d: %8.3f ms  %7.1f GB/s (9216 B/frame) %7.1f Mframes/s\n", grid, ms, frames * 9216.0 / ms / 1e6, frames / ms / 1e3);
+    ms = time([&] { hipLaunchKernelGGL(k_stftmix<1>, dim3(grid), dim3(256), 0, 0, a, b, frames); }, 20);
+    printf("stftmix nt    %6d: %8.3f ms  %7.1f GB/s\n", grid, ms, frames * 9216.0 / ms / 1e6);
+  }
+  return 0;
+}

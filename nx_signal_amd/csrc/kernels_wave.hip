@@ -24,8 +24,11 @@ namespace nxsig {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-static constexpr int kWaveThreads = 256;  // 4 independent waves per workgroup
-static constexpr int kWavesPerBlock = kWaveThreads / 64;
+// front-ends of the C-point complex core
+enum : int {
+  kModePair = 0,    // two adjacent real frames of length C as re / im          (fft_length == C)
+  kModeReal2x = 1,  // ONE real frame of length 2C as even / odd samples        (fft_length == 2C)
+};
 
 __device__ __forceinline__ v2f wcmul(v2f a, v2f b) { return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 __device__ __forceinline__ v2f mul_neg_i(v2f a) { return v2f{a.y, -a.x}; }  // a * (-i)
@@ -89,12 +92,13 @@ struct WaveArgs {
   const float* x;
   int64_t batch_stride, L, lo, M;
   int32_t N, hop, reflect, batch;
-  int64_t pairs_per_row;      // ceil(M / 2)
+  int64_t pairs_per_row;      // work units per row: ceil(M / 2) frame pairs (pair mode) or M frames (real-2x mode)
   int64_t total_pairs;        // batch * pairs_per_row
-  int64_t chunk;              // pairs per workgroup (contiguous)
-  const float* wtab;          // device f32[K]: window zero-padded / truncated to K
+  int64_t chunk;              // units per workgroup (contiguous)
+  const float* wtab;          // device f32[fft_length]: window zero-padded / truncated to the fft length
   const v2f* twB;             // device c64[16][16]: w_256^(t k)
-  const v2f* twC;             // device c64[R3][256]: w_K^(t i)
+  const v2f* twC;             // device c64[R3][256]: w_C^(t i)
+  const v2f* twR;             // device c64[C]: w_2C^k (real-2x mode only)
   float div;
   int32_t has_scale;
   v2f* z;
@@ -120,23 +124,30 @@ typedef __attribute__((address_space(1))) v4f gv4f;  // explicit global address 
 
 // GENERAL = false: :valid framing with every existing frame fully inside the signal (the streaming case);
 // GENERAL = true : any padding mode / ragged tail, per-sample bounds and mirror math.  SCALE: :spectrum / :psd.
-template <int K, bool GENERAL, bool SCALE>
-__global__ __launch_bounds__(kWaveThreads) void k_stft_wave(WaveArgs a) {
+// W = waves per workgroup (tables in LDS are shared by the W waves; waves never synchronise with each other).
+template <int K, int MODE, bool GENERAL, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   constexpr int P = K / 64;     // complex points per lane
   constexpr int R3 = K / 256;   // last radix: 4 or 8
   constexpr int B12 = P / 16;   // radix-16 butterflies per lane in passes A and B
   constexpr int NQ = K / 128;   // bins per lane per parity
   constexpr int XCH = K + K / 16 + 16;  // padded exchange buffer, complex elements (keeps 16-B alignment)
+  constexpr int KOUT = MODE == kModeReal2x ? 2 * K : K;  // fft_length = bins per frame
+  constexpr int kWavesPerBlock = W;
+  constexpr int kWaveThreads = 64 * W;
 
-  // ---- LDS carve: [window K f32][twB 256 c64][twC R3*256 c64][4 x exchange]
+  // ---- LDS carve: [window KOUT f32][twB 256 c64][twC R3*256 c64][twR K c64 (real-2x)][W x exchange]
   float* s_w = reinterpret_cast<float*>(g_wave_smem);
-  v2f* s_twB = reinterpret_cast<v2f*>(s_w + K);
+  v2f* s_twB = reinterpret_cast<v2f*>(s_w + KOUT);
   v2f* s_twC = s_twB + 256;
-  v2f* s_x = s_twC + R3 * 256;
+  v2f* s_twR = s_twC + R3 * 256;
+  v2f* s_x = s_twR + (MODE == kModeReal2x ? K : 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < K; i += kWaveThreads) s_w[i] = a.wtab[i];
-  s_twB[tid] = a.twB[tid];
+  for (int i = tid; i < KOUT; i += kWaveThreads) s_w[i] = a.wtab[i];
+  for (int i = tid; i < 256; i += kWaveThreads) s_twB[i] = a.twB[i];
   for (int i = tid; i < R3 * 256; i += kWaveThreads) s_twC[i] = a.twC[i];
+  if (MODE == kModeReal2x)
+    for (int i = tid; i < K; i += kWaveThreads) s_twR[i] = a.twR[i];
   __syncthreads();  // the only workgroup barrier: tables are read-only afterwards
   v2f* xb = s_x + wave * XCH;
 
@@ -151,11 +162,29 @@ __global__ __launch_bounds__(kWaveThreads) void k_stft_wave(WaveArgs a) {
   // drains fresh stores, and HBM latency hides under the butterflies.
   float ra[P], rb[P];
   auto issue_loads = [&](int64_t row, int64_t pin) {
-    const int64_t mA = pin * 2;
-    const float* pa = a.x + (size_t)row * a.batch_stride + mA * a.hop + lane;
-    const float* pb = pa + ((mA + 1 < a.M) ? a.hop : 0);  // phantom frame B of an odd tail: reload A, never stored
+    if (MODE == kModePair) {
+      const int64_t mA = pin * 2;
+      const float* pa = a.x + (size_t)row * a.batch_stride + mA * a.hop + lane;
+      const float* pb = pa + ((mA + 1 < a.M) ? a.hop : 0);  // phantom frame B of an odd tail: reload A, never stored
 #pragma unroll
-    for (int s = 0; s < P; ++s) { ra[s] = pa[64 * s]; rb[s] = pb[64 * s]; }
+      for (int s = 0; s < P; ++s) { ra[s] = pa[64 * s]; rb[s] = pb[64 * s]; }
+    } else {  // complex point n = (x[2n], x[2n+1])
+      const float* pa = a.x + (size_t)row * a.batch_stride + pin * a.hop + 2 * lane;
+#pragma unroll
+      for (int s = 0; s < P; ++s) { ra[s] = pa[128 * s]; rb[s] = pa[128 * s + 1]; }
+    }
+  };
+  auto window_mul = [&](v2f* d) {
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+      if (MODE == kModePair) {
+        const float w = s_w[lane + 64 * s];
+        d[s] = v2f{ra[s] * w, rb[s] * w};
+      } else {
+        const v2f w = *reinterpret_cast<const v2f*>(&s_w[2 * (lane + 64 * s)]);
+        d[s] = v2f{ra[s] * w.x, rb[s] * w.y};
+      }
+    }
   };
   // (row, pair-in-row) of this wave's current and next pair, advanced incrementally (no division in the loop)
   int64_t row = (p_begin + wave) / a.pairs_per_row;
@@ -169,16 +198,15 @@ __global__ __launch_bounds__(kWaveThreads) void k_stft_wave(WaveArgs a) {
   v2f d[P];  // windowed samples of the current pair: re = frame A, im = frame B (exact f32 products, :101)
   if (!GENERAL && p_begin + wave < p_end) {
     issue_loads(row, pin);
-#pragma unroll
-    for (int s = 0; s < P; ++s) { const float w = s_w[lane + 64 * s]; d[s] = v2f{ra[s] * w, rb[s] * w}; }
+    window_mul(d);
   }
 
   for (int64_t pr = p_begin + wave; pr < p_end; pr += kWavesPerBlock) {
-    const int64_t mA = pin * 2, mB = mA + 1;
-    const bool haveB = mB < a.M;
+    const int64_t mA = MODE == kModePair ? pin * 2 : pin, mB = mA + 1;
+    const bool haveB = MODE == kModePair ? (mB < a.M) : true;
     const int64_t crow = row;
     if (!GENERAL) {
-      // unconditional prefetch (the last iteration harmlessly re-reads its own pair) keeps the loop branch-free
+      // unconditional prefetch (the last iteration harmlessly re-reads its own unit) keeps the loop branch-free
       const bool more = pr + kWavesPerBlock < p_end;
       issue_loads(more ? nrow : row, more ? npin : pin);
       __builtin_amdgcn_sched_barrier(0);
@@ -188,10 +216,16 @@ __global__ __launch_bounds__(kWaveThreads) void k_stft_wave(WaveArgs a) {
 #pragma unroll
       for (int s = 0; s < P; ++s) {
         const int n = lane + 64 * s;
-        const float w = s_w[n];
-        const float va = (n < a.N) ? fetch_any(xr, a, qA + n) : 0.0f;
-        const float vb = (haveB && n < a.N) ? fetch_any(xr, a, qB + n) : 0.0f;
-        d[s] = v2f{va * w, vb * w};
+        if (MODE == kModePair) {
+          const float w = s_w[n];
+          const float va = (n < a.N) ? fetch_any(xr, a, qA + n) : 0.0f;
+          const float vb = (haveB && n < a.N) ? fetch_any(xr, a, qB + n) : 0.0f;
+          d[s] = v2f{va * w, vb * w};
+        } else {
+          const float va = (2 * n < a.N) ? fetch_any(xr, a, qA + 2 * n) : 0.0f;
+          const float vb = (2 * n + 1 < a.N) ? fetch_any(xr, a, qA + 2 * n + 1) : 0.0f;
+          d[s] = v2f{va * s_w[2 * n], vb * s_w[2 * n + 1]};
+        }
       }
     }
 
@@ -256,17 +290,16 @@ __global__ __launch_bounds__(kWaveThreads) void k_stft_wave(WaveArgs a) {
     }
     wave_lds_fence();  // next iteration's pass-A writes come after these reads
 
-    if (!GENERAL) {  // next pair: raw samples landed during the butterflies
+    if (!GENERAL) {  // next unit: raw samples landed during the butterflies
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < P; ++s) { const float w = s_w[lane + 64 * s]; d[s] = v2f{ra[s] * w, rb[s] * w}; }
+      window_mul(d);
       __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- Hermitian untangle through partner lanes + store
     const int src0 = ((64 - lane) & 63) << 2, src1 = (63 - lane) << 2;
-    v2f* zA = a.z + ((size_t)crow * a.M + mA) * K + 2 * lane;
-    v2f* zB = (GENERAL || haveB) ? zA + K : a.dummy + 2 * lane;
+    v2f* zA = a.z + ((size_t)crow * a.M + mA) * KOUT + 2 * lane;
+    v2f* zB = (GENERAL || haveB) ? zA + K : a.dummy + 2 * lane;  // pair: frame B; real-2x: bins K..2K-1
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       // partner of bin k = 2l+par+128q is K-k = 2l'+par+128(NQ-1-q) on lane l' (lane 0 / par 0: own (NQ-q) % NQ)
@@ -281,6 +314,14 @@ __global__ __launch_bounds__(kWaveThreads) void k_stft_wave(WaveArgs a) {
       // XA = ((a + c), (b - d)) / 2 ; XB = ((b + d), (c - a)) / 2   with Z = a + ib, Z[K-k] = c + id
       v4f xa = v4f{z0.x + p0.x, z0.y - p0.y, z1.x + p1.x, z1.y - p1.y} * 0.5f;
       v4f xbv = v4f{z0.y + p0.y, p0.x - z0.x, z1.y + p1.y, p1.x - z1.x} * 0.5f;
+      if (MODE == kModeReal2x) {
+        // xa = E[k], xbv = O[k] (spectra of the even / odd samples): X[k] = E + w_2K^k O, X[k+K] = E - w_2K^k O
+        const v4f t = *reinterpret_cast<const v4f*>(&s_twR[2 * lane + 128 * q]);
+        const v2f o0 = wcmul(v2f{xbv.x, xbv.y}, v2f{t.x, t.y}), o1 = wcmul(v2f{xbv.z, xbv.w}, v2f{t.z, t.w});
+        const v4f to = v4f{o0.x, o0.y, o1.x, o1.y};
+        xbv = xa - to;
+        xa = xa + to;
+      }
       if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }  // true division like the reference (:116/:119)
       __builtin_nontemporal_store(xa, (gv4f*)(zA + 128 * q));
       if (!GENERAL || haveB) __builtin_nontemporal_store(xbv, (gv4f*)(zB + 128 * q));
@@ -296,23 +337,24 @@ static int env_int(const char* name, int dflt) {
   return v ? std::atoi(v) : dflt;
 }
 
-template <int K>
-static int launch_wave_K(Ctx* c, const StftLaunch& s) {
-  constexpr int R3 = K / 256;
-  constexpr int XCH = K + K / 16 + 16;
+// C = complex core size (1024 here), MODE = front-end, W = waves per workgroup
+template <int C, int MODE, int W>
+static int launch_wave(Ctx* c, const StftLaunch& s) {
+  constexpr int R3 = C / 256;
+  constexpr int XCH = C + C / 16 + 16;
+  constexpr int KOUT = MODE == kModeReal2x ? 2 * C : C;
   const double two_pi = 6.283185307179586476925286766559;
-  // s.window_padK: the window zero-padded (K > N) or truncated (K < N) to K — Nx.fft(length: K) semantics
   WaveArgs a;
   a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
   a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
-  a.pairs_per_row = (s.fr.M + 1) / 2;
+  a.pairs_per_row = MODE == kModePair ? (s.fr.M + 1) / 2 : s.fr.M;
   a.total_pairs = a.pairs_per_row * s.batch;
   a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
 
-  // twiddle tables, generated in double once per (context, K)
-  Ctx::WaveTables& wt = c->wave_tables[K];
+  // twiddle tables, generated in double once per (context, core size)
+  Ctx::WaveTables& wt = c->wave_tables[C];
   if (!wt.twB) {
-    std::vector<float2> twB(256), twC((size_t)R3 * 256);
+    std::vector<float2> twB(256), twC((size_t)R3 * 256), twR((size_t)C);
     for (int t = 0; t < 16; ++t)
       for (int k = 0; k < 16; ++k) {
         const double ang = -two_pi * (double)(t * k) / 256.0;
@@ -320,45 +362,53 @@ static int launch_wave_K(Ctx* c, const StftLaunch& s) {
       }
     for (int t = 0; t < R3; ++t)
       for (int i = 0; i < 256; ++i) {
-        const double ang = -two_pi * (double)(t * i) / (double)K;
+        const double ang = -two_pi * (double)(t * i) / (double)C;
         twC[(size_t)t * 256 + i] = make_float2((float)std::cos(ang), (float)std::sin(ang));
       }
+    for (int k = 0; k < C; ++k) {
+      const double ang = -two_pi * (double)k / (double)(2 * C);
+      twR[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
     int rc = ctx_table(c, 0x7742ull, twB.data(), twB.size() * sizeof(float2), &wt.twB);
     if (rc) return rc;
-    rc = ctx_table(c, 0x7743ull ^ (uint64_t)K, twC.data(), twC.size() * sizeof(float2), &wt.twC);
+    rc = ctx_table(c, 0x7743ull ^ (uint64_t)C, twC.data(), twC.size() * sizeof(float2), &wt.twC);
+    if (rc) { wt.twB = nullptr; return rc; }
+    rc = ctx_table(c, 0x7744ull ^ (uint64_t)C, twR.data(), twR.size() * sizeof(float2), &wt.twI);
     if (rc) { wt.twB = nullptr; return rc; }
   }
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
+  a.twR = reinterpret_cast<const v2f*>(wt.twI);
   a.wtab = s.window_padK;
   void* dummy = nullptr;
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);
 
-  const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)kWavesPerBlock * XCH * 8;
-  // contiguous chunk of frame pairs per workgroup: input halos are re-read only at chunk seams
-  const int blocks_per_cu = env_int("NXSIG_WAVE_BLOCKS_PER_CU", 12);
-  int64_t max_blocks = (int64_t)c->num_cus * blocks_per_cu;
-  int64_t want = (a.total_pairs + kWavesPerBlock - 1) / kWavesPerBlock;
+  const size_t lds = (size_t)KOUT * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (MODE == kModeReal2x ? (size_t)C * 8 : 0) +
+                     (size_t)W * XCH * 8;
+  // contiguous chunk of work units per workgroup: input halos are re-read only at chunk seams
+  const int units_per_cu = env_int("NXSIG_WAVE_UNITS_PER_CU", MODE == kModeReal2x ? 192 : 96);  // workgroups x W per CU (oversubscription for balance)
+  int64_t max_blocks = ((int64_t)c->num_cus * units_per_cu + W - 1) / W;
+  int64_t want = (a.total_pairs + W - 1) / W;
   int64_t blocks = want < max_blocks ? want : max_blocks;
   if (blocks < 1) blocks = 1;
   a.chunk = (a.total_pairs + blocks - 1) / blocks;
-  a.chunk = ((a.chunk + kWavesPerBlock - 1) / kWavesPerBlock) * kWavesPerBlock;
+  a.chunk = ((a.chunk + W - 1) / W) * W;
   blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
-  // streaming case: no padding and every existing frame reads K samples inside the signal
-  const bool streaming = s.fr.reflect == 0 && s.fr.lo == 0 && ((s.fr.M - 1) * (int64_t)s.fr.hop + K <= s.fr.L);
+  // streaming case: no padding and every existing frame reads its fft_length samples inside the signal
+  const bool streaming = s.fr.reflect == 0 && s.fr.lo == 0 && ((s.fr.M - 1) * (int64_t)s.fr.hop + KOUT <= s.fr.L);
   const bool scale = s.has_scale != 0;
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kWaveThreads), lds, c->stream, a);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
-  if (streaming && !scale) return go(k_stft_wave<K, false, false>);
-  if (streaming && scale) return go(k_stft_wave<K, false, true>);
-  if (!scale) return go(k_stft_wave<K, true, false>);
-  return go(k_stft_wave<K, true, true>);
+  if (streaming && !scale) return go(k_stft_wave<C, MODE, false, false, W>);
+  if (streaming && scale) return go(k_stft_wave<C, MODE, false, true, W>);
+  if (!scale) return go(k_stft_wave<C, MODE, true, false, W>);
+  return go(k_stft_wave<C, MODE, true, true, W>);
 }
 
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
@@ -366,8 +416,19 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
   if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
   if (s.window_padK == nullptr) return NXSIG_OK;
-  if (s.K == 1024) { *handled = true; return launch_wave_K<1024>(c, s); }
-  if (s.K == 2048) { *handled = true; return launch_wave_K<2048>(c, s); }
+  const int w = env_int("NXSIG_WAVE_W", 0);
+  if (s.K == 1024) {  // two frames per 1024-point complex FFT
+    *handled = true;
+    if (w == 16) return launch_wave<1024, kModePair, 16>(c, s);
+    if (w == 8) return launch_wave<1024, kModePair, 8>(c, s);
+    return launch_wave<1024, kModePair, 4>(c, s);
+  }
+  if (s.K == 2048) {  // one frame as even/odd samples of a 1024-point complex FFT
+    *handled = true;
+    if (w == 12) return launch_wave<1024, kModeReal2x, 12>(c, s);
+    if (w == 8) return launch_wave<1024, kModeReal2x, 8>(c, s);
+    return launch_wave<1024, kModeReal2x, 4>(c, s);
+  }
   return NXSIG_OK;
 }
 

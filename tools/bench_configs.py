@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+"""Secondary measurements for the other BASELINE configs (not the headline bench.py line): HIP-event timing of
+stft N=2048 (config 4 shape, per-GPU shard), istft (config 3) and FIR (config 5) on device-resident data.
+Prints one JSON object per line.  usage: python tools/bench_configs.py [stft2048] [istft] [fir] [stft1024]"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nx_signal_amd as S  # noqa: E402
+from nx_signal_amd import _lib  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timeit(ctx, fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(reps):
+        fn()
+    return ctx.timer_stop() / reps
+
+
+def fill_normal(ctx, buf, shape, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rows = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
+    L = shape[-1]
+    lib = _lib.load()
+    chunk = rng.standard_normal(L, dtype=np.float32)
+    for r in range(rows):  # same stream with a per-row roll: cheap to generate, still full-entropy data
+        xr = np.roll(chunk, 977 * r)
+        _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(buf.ptr + r * L * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
+    return chunk
+
+
+def stft_case(ctx, N, hop, L, batch, name):
+    lib = _lib.load()
+    w = S.windows.hann(N)
+    M = (L - N) // hop + 1
+    xd = ctx.empty((batch, L), np.float32)
+    fill_normal(ctx, xd, (batch, L), 7)
+    zd = ctx.empty((batch, M, N), np.complex64)
+    p = _lib.StftParams(N, hop, N, _lib.PAD_VALID, 0, 0, _lib.SCALE_NONE, 0, 48000.0)
+    wp = w.ctypes.data_as(C.c_void_p)
+    fn = lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
+    ms = timeit(ctx, fn)
+    bpf = hop * 4 + N * 8
+    gbs = batch * M * bpf / (ms * 1e-3) / 1e9
+    print(json.dumps({"case": name, "N": N, "hop": hop, "batch": batch, "frames": batch * M, "ms": ms,
+                      "frames_per_s": batch * M / (ms * 1e-3), "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / PEAK}), flush=True)
+    return xd, zd, w, M
+
+
+def main():
+    which = sys.argv[1:] or ["stft1024", "stft2048", "istft", "fir"]
+    ctx = S.Context(0)
+    lib = _lib.load()
+    if "stft1024" in which:
+        stft_case(ctx, 1024, 256, 2880000, 32, "stft N=1024 hop=256, 32 x 60 s (config 2 batched)")
+    if "stft2048" in which:
+        # config 4 per-GPU shard: 8 channels x 10 min @ 48 kHz would be 7.4 GB of output; use 8 ch x 150 s (1.8 GB out)
+        stft_case(ctx, 2048, 512, 7200000, 8, "stft N=2048 hop=512, 8 ch x 150 s (config 4 shard, shortened)")
+    if "istft" in which:
+        N, hop, L, batch = 1024, 256, 2880000, 16
+        w = S.windows.hann(N)
+        M = (L - N) // hop + 1
+        xd = ctx.empty((batch, L), np.float32)
+        fill_normal(ctx, xd, (batch, L), 9)
+        zd, _, _ = S.stft(xd, w, overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+        out_len = M * hop + N - hop
+        yd = ctx.empty((batch, out_len), np.complex64)
+        p = _lib.StftParams(N, hop, N, 0, 0, 0, _lib.SCALE_NONE, 0, 48000.0)
+        wp = w.ctypes.data_as(C.c_void_p)
+        fn = lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(zd.ptr), M, batch, wp, C.byref(p), C.c_void_p(yd.ptr), _lib.DEVICE))
+        ms = timeit(ctx, fn, reps=10)
+        bpf = N * 8 + hop * 8
+        gbs = batch * M * bpf / (ms * 1e-3) / 1e9
+        print(json.dumps({"case": "istft N=1024 hop=256, 16 x 60 s (config 3 batched)", "ms": ms, "frames_per_s": batch * M / (ms * 1e-3),
+                          "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / PEAK}), flush=True)
+    if "fir" in which:
+        L, batch = 28800000, 8  # config 5 per-GPU shard: 8 channels x 10 min
+        h = S.filters.firwin(257, [4000], sampling_rate=48000)
+        xd = ctx.empty((batch, L), np.float32)
+        fill_normal(ctx, xd, (batch, L), 11)
+        yd = ctx.empty((batch, L), np.float32)
+        hp = h.ctypes.data_as(C.c_void_p)
+        fn = lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, hp, 257, _lib.CONV_SAME, C.c_void_p(yd.ptr), _lib.DEVICE))
+        ms = timeit(ctx, fn, reps=10)
+        gbs = batch * L * 8 / (ms * 1e-3) / 1e9
+        print(json.dumps({"case": "fir 257 taps :same, 8 ch x 10 min @48k (config 5 shard)", "ms": ms, "samples_per_s": batch * L / (ms * 1e-3),
+                          "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / PEAK}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -129,7 +129,7 @@ int launch_stft_generic(Ctx* c, const StftLaunch& a);
 int launch_istft_generic(Ctx* c, const IstftLaunch& a);
 int launch_fir_generic(Ctx* c, const FirLaunch& a);
 int launch_stft_wave(Ctx* c, const StftLaunch& a, bool* handled);
-int launch_istft_wave(Ctx* c, const IstftLaunch& a, bool* handled);
+int launch_istft_wave(Ctx* c, const IstftLaunch& a, const float* window_host, bool* handled);
 int launch_fir_wave(Ctx* c, const FirLaunch& a, bool* handled);
 
 int launch_stft(Ctx* c, const StftLaunch& a) {
@@ -141,7 +141,7 @@ int launch_stft(Ctx* c, const StftLaunch& a) {
 int launch_istft_edge_fix(Ctx* c, const IstftLaunch& a, const float* window_host);
 int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
   bool handled = false;
-  int rc = launch_istft_wave(c, a, &handled);
+  int rc = launch_istft_wave(c, a, window_host, &handled);
   if (rc) return rc;
   if (!handled && (rc = launch_istft_generic(c, a))) return rc;
   return launch_istft_edge_fix(c, a, window_host);  // ill-conditioned edge samples recomputed in double

@@ -88,6 +88,77 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// The K-point complex forward FFT of one wave: in  d[s] = x[lane + 64 s]  (P = K/64 points per lane),
+// out zz[par][q] = X[2 lane + par + 128 q].  xb = this wave's private LDS exchange buffer (XCH complex).
+template <int K>
+__device__ __forceinline__ void wave_fft_core(const v2f* d, v2f (*zz)[K / 128], v2f* xb, const v2f* s_twB, const v2f* s_twC,
+                                              const int lane) {
+  constexpr int P = K / 64;
+  constexpr int R3 = K / 256;
+  constexpr int B12 = P / 16;
+  {
+    // ---- pass A: radix-16, p = 1; butterfly i = lane + 64 u takes points i + t K/16  (= d[u + B12 t])
+#pragma unroll
+    for (int u = 0; u < B12; ++u) {
+      v2f b[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) b[t] = d[u + B12 * t];
+      dft16(b);
+      const int base = 17 * (lane + 64 * u);  // pad1(16 i + r) = 17 i + r
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xb[base + r] = b[r];
+    }
+    wave_lds_fence();
+
+    // ---- pass B: radix-16, p = 16; reads pad1(i + t K/16), twiddle w_256^(t k), k = lane & 15
+    const int k16 = lane & 15;
+    v2f e[B12][16];
+#pragma unroll
+    for (int u = 0; u < B12; ++u) {
+      const int base = lane + (lane >> 4) + 68 * u;  // pad1(l + 64 u + 64 B12 t) = l + l/16 + 68 u + 68 B12 t
+#pragma unroll
+      for (int t = 0; t < 16; ++t) e[u][t] = xb[base + 68 * B12 * t];
+    }
+#pragma unroll
+    for (int u = 0; u < B12; ++u) {
+#pragma unroll
+      for (int t = 1; t < 16; ++t) e[u][t] = wcmul(e[u][t], s_twB[t * 16 + k16]);
+      dft16(e[u]);
+    }
+    wave_lds_fence();  // every exchange-1 read is issued before exchange 2 overwrites the buffer
+#pragma unroll
+    for (int u = 0; u < B12; ++u) {
+      const int base = 16 * (lane + 64 * u) - 15 * k16;  // (i - k) 16 + k
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xb[base + 16 * r] = e[u][r];
+    }
+    wave_lds_fence();
+
+    // ---- pass C: radix-R3, p = 256; butterflies i = 2 lane + par + 128 u2 (adjacent pair per 16-byte LDS read)
+#pragma unroll
+    for (int u2 = 0; u2 < 2; ++u2) {
+      v2f c0[R3], c1[R3];
+      const int i0 = 2 * lane + 128 * u2;
+#pragma unroll
+      for (int t = 0; t < R3; ++t) {
+        const v4f v = *reinterpret_cast<const v4f*>(&xb[i0 + 256 * t]);
+        c0[t] = v2f{v.x, v.y};
+        c1[t] = v2f{v.z, v.w};
+        if (t > 0) {
+          const v4f w = *reinterpret_cast<const v4f*>(&s_twC[t * 256 + i0]);
+          c0[t] = wcmul(c0[t], v2f{w.x, w.y});
+          c1[t] = wcmul(c1[t], v2f{w.z, w.w});
+        }
+      }
+      if (R3 == 4) { dft4(c0[0], c0[1], c0[2], c0[3]); dft4(c1[0], c1[1], c1[2], c1[3]); }
+      else { dft8(c0); dft8(c1); }
+#pragma unroll
+      for (int r = 0; r < R3; ++r) { zz[0][u2 + 2 * r] = c0[r]; zz[1][u2 + 2 * r] = c1[r]; }
+    }
+    wave_lds_fence();  // next iteration's pass-A writes come after these reads
+  }
+}
+
 struct WaveArgs {
   const float* x;
   int64_t batch_stride, L, lo, M;
@@ -229,66 +300,8 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
       }
     }
 
-    // ---- pass A: radix-16, p = 1; butterfly i = lane + 64 u takes points i + t K/16  (= d[u + B12 t])
-#pragma unroll
-    for (int u = 0; u < B12; ++u) {
-      v2f b[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) b[t] = d[u + B12 * t];
-      dft16(b);
-      const int base = 17 * (lane + 64 * u);  // pad1(16 i + r) = 17 i + r
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xb[base + r] = b[r];
-    }
-    wave_lds_fence();
-
-    // ---- pass B: radix-16, p = 16; reads pad1(i + t K/16), twiddle w_256^(t k), k = lane & 15
-    const int k16 = lane & 15;
-    v2f e[B12][16];
-#pragma unroll
-    for (int u = 0; u < B12; ++u) {
-      const int base = lane + (lane >> 4) + 68 * u;  // pad1(l + 64 u + 64 B12 t) = l + l/16 + 68 u + 68 B12 t
-#pragma unroll
-      for (int t = 0; t < 16; ++t) e[u][t] = xb[base + 68 * B12 * t];
-    }
-#pragma unroll
-    for (int u = 0; u < B12; ++u) {
-#pragma unroll
-      for (int t = 1; t < 16; ++t) e[u][t] = wcmul(e[u][t], s_twB[t * 16 + k16]);
-      dft16(e[u]);
-    }
-    wave_lds_fence();  // every exchange-1 read is issued before exchange 2 overwrites the buffer
-#pragma unroll
-    for (int u = 0; u < B12; ++u) {
-      const int base = 16 * (lane + 64 * u) - 15 * k16;  // (i - k) 16 + k
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xb[base + 16 * r] = e[u][r];
-    }
-    wave_lds_fence();
-
-    // ---- pass C: radix-R3, p = 256; butterflies i = 2 lane + par + 128 u2 (adjacent pair per 16-byte LDS read)
-    v2f zz[2][NQ];  // zz[par][q] = Z[2 lane + par + 128 q], q = u2 + 2 r
-#pragma unroll
-    for (int u2 = 0; u2 < 2; ++u2) {
-      v2f c0[R3], c1[R3];
-      const int i0 = 2 * lane + 128 * u2;
-#pragma unroll
-      for (int t = 0; t < R3; ++t) {
-        const v4f v = *reinterpret_cast<const v4f*>(&xb[i0 + 256 * t]);
-        c0[t] = v2f{v.x, v.y};
-        c1[t] = v2f{v.z, v.w};
-        if (t > 0) {
-          const v4f w = *reinterpret_cast<const v4f*>(&s_twC[t * 256 + i0]);
-          c0[t] = wcmul(c0[t], v2f{w.x, w.y});
-          c1[t] = wcmul(c1[t], v2f{w.z, w.w});
-        }
-      }
-      if (R3 == 4) { dft4(c0[0], c0[1], c0[2], c0[3]); dft4(c1[0], c1[1], c1[2], c1[3]); }
-      else { dft8(c0); dft8(c1); }
-#pragma unroll
-      for (int r = 0; r < R3; ++r) { zz[0][u2 + 2 * r] = c0[r]; zz[1][u2 + 2 * r] = c1[r]; }
-    }
-    wave_lds_fence();  // next iteration's pass-A writes come after these reads
+    v2f zz[2][NQ];  // zz[par][q] = Z[2 lane + par + 128 q]
+    wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);
 
     if (!GENERAL) {  // next unit: raw samples landed during the butterflies
       __builtin_amdgcn_sched_barrier(0);
@@ -331,11 +344,140 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   }
 }
 
+// ============================================================================================ iSTFT
+// NxSignal.istft/3 fused in one launch (lib/nx_signal.ex:609-637): one wave walks a RUN of consecutive frames of one
+// row.  Per frame: c64 load -> inverse FFT (= conj . forward core . conj, x 1/K) -> x scale x window -> the frame's
+// R = N/hop hop-sized segments are folded into R-1 pending accumulators held in registers, always in ascending
+// frame order (deterministic: no atomics, run-to-run bit-stable) -> the finished segment is divided by the OLA
+// normaliser sum |w|^2 (guard 1e-10 -> 1, :635) and stored as c64 with 16-byte stores.  The lane layout of the
+// core (sample n = 2 lane + par + 128 q) keeps a lane's position inside every hop segment identical, so the
+// overlap-add needs no data movement at all.  Runs start R-1 frames early to rebuild their pending sums (halo
+// recompute) instead of exchanging partial sums between waves.
+struct IstftWaveArgs {
+  const v2f* z;               // c64[batch][M][K]
+  int64_t M;
+  int32_t batch, hop;
+  int64_t segs_per_row;       // M + R - 1  (out_len = segs_per_row * hop)
+  int64_t run_len, runs_per_row, total_runs;
+  const float* wtab;          // f32[K]
+  const v2f* twB;
+  const v2f* twC;
+  float scale;
+  const float* den;           // f32[2R-1][hop]: guarded OLA normaliser of head segments 0..R-2, interior, tail segments
+  v2f* y;                     // c64[batch][segs_per_row * hop]
+  v2f* dummy;
+};
+
+template <int K, int R, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
+  constexpr int P = K / 64;
+  constexpr int R3 = K / 256;
+  constexpr int NQ = K / 128;
+  constexpr int QS = NQ / R;            // q values (of 128 samples each) per hop segment, per parity
+  constexpr int XCH = K + K / 16 + 16;
+  static_assert(NQ % R == 0, "hop must be a multiple of 128");
+  float* s_w = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_twB = reinterpret_cast<v2f*>(s_w + K);
+  v2f* s_twC = s_twB + 256;
+  v2f* s_x = s_twC + R3 * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < K; i += 64 * W) s_w[i] = a.wtab[i];
+  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
+  for (int i = tid; i < R3 * 256; i += 64 * W) s_twC[i] = a.twC[i];
+  __syncthreads();
+  v2f* xb = s_x + wave * XCH;
+  const int64_t run = (int64_t)blockIdx.x * W + wave;
+  if (run >= a.total_runs) return;  // whole wave leaves; no barrier follows
+  const int64_t row = run / a.runs_per_row;
+  const int64_t j0 = (run - row * a.runs_per_row) * a.run_len;
+  int64_t j1 = j0 + a.run_len;
+  if (j1 > a.segs_per_row) j1 = a.segs_per_row;
+  const int64_t m_start = j0 >= (R - 1) ? j0 - (R - 1) : 0;
+
+  // this lane's window values wv[par][q] = w[2 lane + par + 128 q]
+  float wv[2][NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const v2f w = *reinterpret_cast<const v2f*>(&s_w[2 * lane + 128 * q]);
+    wv[0][q] = w.x; wv[1][q] = w.y;
+  }
+  const float invK = 1.0f / (float)K;
+  v2f pend[R - 1 > 0 ? R - 1 : 1][2][QS];
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int qq = 0; qq < QS; ++qq) pend[i][e][qq] = v2f{0.f, 0.f};
+
+  const v2f* zrow = a.z + (size_t)row * a.M * K + lane;
+  v2f r[P];
+  auto issue_loads = [&](int64_t m) {
+    const v2f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * K;  // clamped: frames past the end contribute zero
+#pragma unroll
+    for (int s = 0; s < P; ++s) r[s] = pz[64 * s];
+  };
+  issue_loads(m_start);
+  v2f d[P];
+#pragma unroll
+  for (int s = 0; s < P; ++s) d[s] = v2f{r[s].x, -r[s].y};  // conj: IFFT(z) = conj(FFT(conj z)) / K
+
+  for (int64_t m = m_start; m < j1; ++m) {
+    issue_loads(m + 1 < j1 ? m + 1 : m);  // unconditional prefetch keeps the loop branch-free
+    __builtin_amdgcn_sched_barrier(0);
+    v2f zz[2][NQ];
+    wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < P; ++s) d[s] = v2f{r[s].x, -r[s].y};
+    __builtin_amdgcn_sched_barrier(0);
+
+    const float live = m < a.M ? 1.0f : 0.0f;  // tail flush: frames m >= M do not exist
+    const int64_t j = m;                        // segment j is complete once frame j has been folded in
+    // guarded normaliser of segment j from the host table (head rows 0..R-2, interior row R-1, tail rows R..2R-2)
+    const int64_t trow = j < R - 1 ? j : (j >= a.M ? R + (j - a.M) : R - 1);
+    const float* dp = a.den + trow * a.hop + 2 * lane;
+    v2f den[QS];
+#pragma unroll
+    for (int qq = 0; qq < QS; ++qq) den[qq] = *reinterpret_cast<const v2f*>(dp + 128 * qq);
+    // frame samples ((conj X / K) * scale) * window (lib/nx_signal.ex:609-628, same rounding order) are folded
+    // straight into the pending overlap sums, always in ascending frame order
+    v2f out[2][QS];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int qq = 0; qq < QS; ++qq) {
+        v2f f[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          v2f v = v2f{zz[e][i * QS + qq].x, -zz[e][i * QS + qq].y} * invK;
+          if (SCALE) v = v * a.scale;
+          f[i] = v * (wv[e][i * QS + qq] * live);
+        }
+        if (R == 1) { out[e][qq] = f[0]; }
+        else {
+          out[e][qq] = pend[0][e][qq] + f[0];
+#pragma unroll
+          for (int i = 0; i + 1 < R - 1; ++i) pend[i][e][qq] = pend[i + 1][e][qq] + f[i + 1];
+          pend[R - 2][e][qq] = f[R - 1];
+        }
+      }
+    v2f* yp = (j >= j0) ? a.y + (size_t)row * a.segs_per_row * a.hop + j * a.hop + 2 * lane : a.dummy + 2 * lane;
+#pragma unroll
+    for (int qq = 0; qq < QS; ++qq) {
+      const v4f o = v4f{out[0][qq].x / den[qq].x, out[0][qq].y / den[qq].x, out[1][qq].x / den[qq].y, out[1][qq].y / den[qq].y};
+      __builtin_nontemporal_store(o, (gv4f*)(yp + 128 * qq));
+    }
+  }
+}
+
 // ============================================================================================ host side
 static int env_int(const char* name, int dflt) {
   const char* v = std::getenv(name);
   return v ? std::atoi(v) : dflt;
 }
+
+static int ensure_wave_tables_1024(Ctx* c);
 
 // C = complex core size (1024 here), MODE = front-end, W = waves per workgroup
 template <int C, int MODE, int W>
@@ -343,7 +485,6 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
   constexpr int R3 = C / 256;
   constexpr int XCH = C + C / 16 + 16;
   constexpr int KOUT = MODE == kModeReal2x ? 2 * C : C;
-  const double two_pi = 6.283185307179586476925286766559;
   WaveArgs a;
   a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
   a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
@@ -351,31 +492,9 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
   a.total_pairs = a.pairs_per_row * s.batch;
   a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
 
-  // twiddle tables, generated in double once per (context, core size)
+  static_assert(C == 1024, "only the 1024-point core is instantiated");
+  { int rc = ensure_wave_tables_1024(c); if (rc) return rc; }
   Ctx::WaveTables& wt = c->wave_tables[C];
-  if (!wt.twB) {
-    std::vector<float2> twB(256), twC((size_t)R3 * 256), twR((size_t)C);
-    for (int t = 0; t < 16; ++t)
-      for (int k = 0; k < 16; ++k) {
-        const double ang = -two_pi * (double)(t * k) / 256.0;
-        twB[t * 16 + k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-      }
-    for (int t = 0; t < R3; ++t)
-      for (int i = 0; i < 256; ++i) {
-        const double ang = -two_pi * (double)(t * i) / (double)C;
-        twC[(size_t)t * 256 + i] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-      }
-    for (int k = 0; k < C; ++k) {
-      const double ang = -two_pi * (double)k / (double)(2 * C);
-      twR[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-    }
-    int rc = ctx_table(c, 0x7742ull, twB.data(), twB.size() * sizeof(float2), &wt.twB);
-    if (rc) return rc;
-    rc = ctx_table(c, 0x7743ull ^ (uint64_t)C, twC.data(), twC.size() * sizeof(float2), &wt.twC);
-    if (rc) { wt.twB = nullptr; return rc; }
-    rc = ctx_table(c, 0x7744ull ^ (uint64_t)C, twR.data(), twR.size() * sizeof(float2), &wt.twI);
-    if (rc) { wt.twB = nullptr; return rc; }
-  }
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
   a.twR = reinterpret_cast<const v2f*>(wt.twI);
@@ -432,7 +551,107 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   return NXSIG_OK;
 }
 
-int launch_istft_wave(Ctx*, const IstftLaunch&, bool* handled) { *handled = false; return NXSIG_OK; }
+template <int R, int W>
+static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window_padK, const float* window_host) {
+  constexpr int K = 1024, R3 = K / 256, XCH = K + K / 16 + 16;
+  IstftWaveArgs a;
+  a.z = reinterpret_cast<const v2f*>(s.z); a.M = s.M; a.batch = s.batch; a.hop = s.hop;
+  a.segs_per_row = s.M + R - 1;
+  a.wtab = window_padK;
+  Ctx::WaveTables& wt = c->wave_tables[K];
+  if (!wt.twB) return NXSIG_ERR_UNSUPPORTED;  // tables are created by ensure_wave_tables below
+  a.twB = reinterpret_cast<const v2f*>(wt.twB);
+  a.twC = reinterpret_cast<const v2f*>(wt.twC);
+  a.scale = s.scale_mul;
+  {  // guarded normaliser rows (lib/nx_signal.ex:630-635): double accumulation in ascending frame order, one rounding
+    const int hop = s.hop;
+    std::vector<float> den((size_t)(2 * R - 1) * hop);
+    auto w2 = [&](int idx) { const float w = std::fabs(window_host[idx]); return (double)(w * w); };
+    for (int row = 0; row < 2 * R - 1; ++row)
+      for (int pos = 0; pos < hop; ++pos) {
+        double acc = 0.0;
+        for (int rr = R - 1; rr >= 0; --rr) {  // frame j - rr contributes w2[rr*hop + pos]
+          bool have;
+          if (row < R - 1) have = rr <= row;             // head segment j = row: frames j - rr >= 0
+          else if (row == R - 1) have = true;            // interior
+          else have = rr >= row - R + 1;                 // tail segment j = M + (row - R): frames j - rr <= M - 1
+          if (have) acc += w2(rr * hop + pos);
+        }
+        const float d = (float)acc;
+        den[(size_t)row * hop + pos] = d > 1.0e-10f ? d : 1.0f;
+      }
+    const void* dd = nullptr;
+    int rc3 = ctx_table(c, 0xDE17ull ^ ((uint64_t)R << 32), den.data(), den.size() * sizeof(float), &dd);
+    if (rc3) return rc3;
+    a.den = reinterpret_cast<const float*>(dd);
+  }
+  a.y = reinterpret_cast<v2f*>(s.y);
+  void* dummy = nullptr;
+  { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
+  a.dummy = reinterpret_cast<v2f*>(dummy);
+  const int64_t total_segs = a.segs_per_row * s.batch;
+  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", 12);
+  int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
+  const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", 8);
+  if (run_len < min_run) run_len = min_run;
+  a.run_len = run_len;
+  a.runs_per_row = (a.segs_per_row + run_len - 1) / run_len;
+  a.total_runs = a.runs_per_row * s.batch;
+  const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8;
+  const int64_t blocks = (a.total_runs + W - 1) / W;
+  if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+  else hipLaunchKernelGGL((k_istft_wave<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+static int ensure_wave_tables_1024(Ctx* c) {
+  constexpr int C = 1024, R3 = 4;
+  const double two_pi = 6.283185307179586476925286766559;
+  Ctx::WaveTables& wt = c->wave_tables[C];
+  if (wt.twB) return NXSIG_OK;
+  std::vector<float2> twB(256), twC((size_t)R3 * 256), twR((size_t)C);
+  for (int t = 0; t < 16; ++t)
+    for (int k = 0; k < 16; ++k) {
+      const double ang = -two_pi * (double)(t * k) / 256.0;
+      twB[t * 16 + k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+  for (int t = 0; t < R3; ++t)
+    for (int i = 0; i < 256; ++i) {
+      const double ang = -two_pi * (double)(t * i) / (double)C;
+      twC[(size_t)t * 256 + i] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+  for (int k = 0; k < C; ++k) {
+    const double ang = -two_pi * (double)k / (double)(2 * C);
+    twR[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+  }
+  int rc = ctx_table(c, 0x7742ull, twB.data(), twB.size() * sizeof(float2), &wt.twB);
+  if (rc) return rc;
+  rc = ctx_table(c, 0x7743ull ^ (uint64_t)C, twC.data(), twC.size() * sizeof(float2), &wt.twC);
+  if (rc) { wt.twB = nullptr; return rc; }
+  rc = ctx_table(c, 0x7744ull ^ (uint64_t)C, twR.data(), twR.size() * sizeof(float2), &wt.twI);
+  if (rc) { wt.twB = nullptr; return rc; }
+  return NXSIG_OK;
+}
+
+int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
+  *handled = false;
+  if (s.M == 0 || s.batch == 0) return NXSIG_OK;
+  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (s.K != 1024 || s.N != 1024) return NXSIG_OK;       // other sizes: generic two-stage path
+  if (s.hop != 128 && s.hop != 256 && s.hop != 512 && s.hop != 1024) return NXSIG_OK;
+  if (s.M < 2 * (1024 / s.hop) - 1 || window_host == nullptr) return NXSIG_OK;  // head and tail rows must not overlap
+  int rc = ensure_wave_tables_1024(c);
+  if (rc) return rc;
+  *handled = true;
+  // the window table of the istft is the raw window (N == K)
+  switch (1024 / s.hop) {
+    case 1: return launch_istft_wave_R<1, 4>(c, s, s.window, window_host);
+    case 2: return launch_istft_wave_R<2, 4>(c, s, s.window, window_host);
+    case 4: return launch_istft_wave_R<4, 4>(c, s, s.window, window_host);
+    default: return launch_istft_wave_R<8, 4>(c, s, s.window, window_host);
+  }
+}
 int launch_fir_wave(Ctx*, const FirLaunch&, bool* handled) { *handled = false; return NXSIG_OK; }
 
 }  // namespace nxsig

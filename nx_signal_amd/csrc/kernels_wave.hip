@@ -159,6 +159,73 @@ __device__ __forceinline__ void wave_fft_core(const v2f* d, v2f (*zz)[K / 128], 
   }
 }
 
+// The same K-point forward DFT computed by the TRANSPOSED passes in reverse order (the DFT matrix is symmetric:
+// F = C B A = A^T B^T C^T): in  zz[par][q] = x[2 lane + par + 128 q]  (the layout wave_fft_core PRODUCES),
+// out d[s] = X[lane + 64 s]  (the layout wave_fft_core CONSUMES).  Chaining core_T -> pointwise -> core gives
+// FFT -> multiply -> inverse FFT with no transposition pass in between (overlap-save FIR).
+template <int K>
+__device__ __forceinline__ void wave_fft_core_T(const v2f (*zz)[K / 128], v2f* d, v2f* xb, const v2f* s_twB,
+                                                const v2f* s_twC, const int lane) {
+  constexpr int P = K / 64;
+  constexpr int R3 = K / 256;
+  constexpr int B12 = P / 16;
+  // ---- C^T: butterflies i = 2 lane + par + 128 u2 over the points i + 256 r; output t gets w_K^(t i); 16-byte writes
+#pragma unroll
+  for (int u2 = 0; u2 < 2; ++u2) {
+    v2f c0[R3], c1[R3];
+    const int i0 = 2 * lane + 128 * u2;
+#pragma unroll
+    for (int r = 0; r < R3; ++r) { c0[r] = zz[0][u2 + 2 * r]; c1[r] = zz[1][u2 + 2 * r]; }
+    if (R3 == 4) { dft4(c0[0], c0[1], c0[2], c0[3]); dft4(c1[0], c1[1], c1[2], c1[3]); }
+    else { dft8(c0); dft8(c1); }
+#pragma unroll
+    for (int t = 0; t < R3; ++t) {
+      if (t > 0) {
+        const v4f w = *reinterpret_cast<const v4f*>(&s_twC[t * 256 + i0]);
+        c0[t] = wcmul(c0[t], v2f{w.x, w.y});
+        c1[t] = wcmul(c1[t], v2f{w.z, w.w});
+      }
+      *reinterpret_cast<v4f*>(&xb[i0 + 256 * t]) = v4f{c0[t].x, c0[t].y, c1[t].x, c1[t].y};
+    }
+  }
+  wave_lds_fence();
+  // ---- B^T: butterfly i = lane + 64 u reads (i - k) 16 + k + 16 r, output t gets w_256^(t k), goes to pad1(i + t K/16)
+  const int k16 = lane & 15;
+  v2f e[B12][16];
+#pragma unroll
+  for (int u = 0; u < B12; ++u) {
+    const int base = 16 * (lane + 64 * u) - 15 * k16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[u][r] = xb[base + 16 * r];
+  }
+#pragma unroll
+  for (int u = 0; u < B12; ++u) {
+    dft16(e[u]);
+#pragma unroll
+    for (int t = 1; t < 16; ++t) e[u][t] = wcmul(e[u][t], s_twB[t * 16 + k16]);
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int u = 0; u < B12; ++u) {
+    const int base = lane + (lane >> 4) + 68 * u;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) xb[base + 68 * B12 * t] = e[u][t];
+  }
+  wave_lds_fence();
+  // ---- A^T: butterfly i reads pad1(16 i + r) = 17 i + r, outputs X[i + t K/16]
+#pragma unroll
+  for (int u = 0; u < B12; ++u) {
+    v2f b[16];
+    const int base = 17 * (lane + 64 * u);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b[r] = xb[base + r];
+    dft16(b);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) d[u + B12 * t] = b[t];
+  }
+  wave_lds_fence();
+}
+
 struct WaveArgs {
   const float* x;
   int64_t batch_stride, L, lo, M;
@@ -471,6 +538,111 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
   }
 }
 
+// ============================================================================================ FIR (overlap-save)
+// y = x * h by overlap-save block FFT convolution (the `Filters.fir` of BASELINE config 5; equals the reference's
+// Convolution.convolve(x, h, method: :fft) of lib/nx_signal/convolution.ex:252-329 to fp32 rounding).  One wave
+// filters TWO consecutive blocks of K samples packed as re / im of one complex FFT (h is real):
+//   load (adjacent-pair layout) -> core_T (forward) -> x H/K, conj -> core (forward again = inverse up to conj)
+//   -> the K - (taps-1) valid samples of both blocks leave with 8-byte stores.
+// Block b covers full-convolution outputs [b V, (b+1) V), V = K - (taps-1), from x[b V - (taps-1) + n].
+struct FirWaveArgs {
+  const float* x;
+  int64_t L, batch_stride;
+  int32_t batch, taps;
+  int64_t V, nblocks, first_block;     // blocks (per row) covering the requested output slice
+  int64_t pairs_per_row, total_pairs, chunk;
+  int64_t out_start, out_len;
+  const v2f* H;                        // c64[K] natural order, pre-scaled by 1/K
+  const v2f* twB;
+  const v2f* twC;
+  float* y;                            // f32[batch][out_len]
+};
+
+// FAST: (taps-1) % 128 == 0 and every offset even -> interior pairs use 8-byte loads / stores without predicates
+template <int K, bool FAST, int W>
+__global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
+  constexpr int P = K / 64;
+  constexpr int R3 = K / 256;
+  constexpr int NQ = K / 128;
+  constexpr int XCH = K + K / 16 + 16;
+  v2f* s_twB = reinterpret_cast<v2f*>(g_wave_smem);
+  v2f* s_twC = s_twB + 256;
+  v2f* s_x = s_twC + R3 * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
+  for (int i = tid; i < R3 * 256; i += 64 * W) s_twC[i] = a.twC[i];
+  __syncthreads();
+  v2f* xb = s_x + wave * XCH;
+  v2f h[P];  // filter spectrum of this lane's bins k = lane + 64 s (registers for the whole kernel)
+#pragma unroll
+  for (int s = 0; s < P; ++s) h[s] = a.H[lane + 64 * s];
+
+  const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
+  int64_t p_end = p_begin + a.chunk;
+  if (p_end > a.total_pairs) p_end = a.total_pairs;
+  const int tm1 = a.taps - 1;
+
+  for (int64_t pr = p_begin + wave; pr < p_end; pr += W) {
+    const int64_t row = pr / a.pairs_per_row;
+    const int64_t b1 = a.first_block + 2 * (pr - row * a.pairs_per_row), b2 = b1 + 1;
+    const bool have2 = (b2 - a.first_block) < a.nblocks;
+    const float* xr = a.x + (size_t)row * a.batch_stride;
+    float* yr = a.y + (size_t)row * a.out_len;
+    const int64_t s1 = b1 * a.V - tm1, s2 = s1 + a.V;
+    const int64_t o1 = b1 * a.V - a.out_start - tm1;  // y index of block-1 sample n is o1 + n (n >= taps-1)
+    const bool interior = FAST && have2 && s1 >= 0 && s2 + K <= a.L && o1 + tm1 >= 0 && o1 + a.V + K <= a.out_len;
+
+    v2f zz[2][NQ];  // zz[par][q] = (x1[n], x2[n]), n = 2 lane + par + 128 q
+    if (interior) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const v2f u1 = *reinterpret_cast<const v2f*>(xr + s1 + 2 * lane + 128 * q);
+        const v2f u2 = *reinterpret_cast<const v2f*>(xr + s2 + 2 * lane + 128 * q);
+        zz[0][q] = v2f{u1.x, u2.x};
+        zz[1][q] = v2f{u1.y, u2.y};
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int n = 2 * lane + e + 128 * q;
+          const int64_t p1 = s1 + n, p2 = s2 + n;
+          const float v1 = (p1 >= 0 && p1 < a.L) ? xr[p1] : 0.0f;
+          const float v2 = (have2 && p2 >= 0 && p2 < a.L) ? xr[p2] : 0.0f;
+          zz[e][q] = v2f{v1, v2};
+        }
+    }
+    v2f d[P];
+    wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);
+#pragma unroll
+    for (int s = 0; s < P; ++s) { const v2f t = wcmul(d[s], h[s]); d[s] = v2f{t.x, -t.y}; }  // conj(Z H / K)
+    wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);  // zz = U with ifft = conj(U): y1 = U.x, y2 = -U.y
+    if (interior) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (128 * q >= tm1) {  // uniform: (taps-1) % 128 == 0
+          float* p1 = yr + o1 + 2 * lane + 128 * q;
+          *reinterpret_cast<v2f*>(p1) = v2f{zz[0][q].x, zz[1][q].x};
+          *reinterpret_cast<v2f*>(p1 + a.V) = v2f{-zz[0][q].y, -zz[1][q].y};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int n = 2 * lane + e + 128 * q;
+          if (n >= tm1) {
+            const int64_t y1 = o1 + n, y2 = y1 + a.V;
+            if (y1 >= 0 && y1 < a.out_len) yr[y1] = zz[e][q].x;
+            if (have2 && y2 >= 0 && y2 < a.out_len) yr[y2] = -zz[e][q].y;
+          }
+        }
+    }
+  }
+}
+
 // ============================================================================================ host side
 static int env_int(const char* name, int dflt) {
   const char* v = std::getenv(name);
@@ -652,6 +824,75 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
     default: return launch_istft_wave_R<8, 4>(c, s, s.window, window_host);
   }
 }
-int launch_fir_wave(Ctx*, const FirLaunch&, bool* handled) { *handled = false; return NXSIG_OK; }
+// spectrum of the zero-padded taps in double (radix-2, 1024 points, once per distinct filter)
+static void host_fft1024_f64(std::vector<double>& re, std::vector<double>& im) {
+  const size_t n = re.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const double ang = -6.283185307179586476925286766559 / (double)len;
+    for (size_t i = 0; i < n; i += len)
+      for (size_t k = 0; k < len / 2; ++k) {
+        const double wr = std::cos(ang * (double)k), wi = std::sin(ang * (double)k);
+        const size_t u = i + k, v = i + k + len / 2;
+        const double tr = re[v] * wr - im[v] * wi, ti = re[v] * wi + im[v] * wr;
+        re[v] = re[u] - tr; im[v] = im[u] - ti;
+        re[u] += tr; im[u] += ti;
+      }
+  }
+}
+
+int launch_fir_wave(Ctx* c, const FirLaunch& s, bool* handled) {
+  *handled = false;
+  constexpr int K = 1024, R3 = 4, XCH = K + K / 16 + 16, W = 4;
+  if (s.out_len <= 0 || s.batch == 0) return NXSIG_OK;
+  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (s.taps > 513) return NXSIG_OK;  // block of 1024 would be < 50 % efficient: generic path uses bigger blocks
+  int rc = ensure_wave_tables_1024(c);
+  if (rc) return rc;
+  *handled = true;
+  std::vector<double> re(K, 0.0), im(K, 0.0);
+  for (int i = 0; i < s.taps; ++i) re[i] = (double)s.h_host[i];
+  host_fft1024_f64(re, im);
+  std::vector<float2> H(K);
+  for (int i = 0; i < K; ++i) H[i] = make_float2((float)(re[i] / K), (float)(im[i] / K));
+  const void* Hd = nullptr;
+  rc = ctx_table(c, 0xF1A1ull, H.data(), H.size() * sizeof(float2), &Hd);
+  if (rc) return rc;
+  FirWaveArgs a;
+  a.x = s.x; a.L = s.L; a.batch_stride = s.batch_stride; a.batch = s.batch; a.taps = s.taps;
+  a.V = K - (s.taps - 1);
+  a.first_block = s.out_start / a.V;
+  const int64_t last_block = (s.out_start + s.out_len - 1) / a.V;
+  a.nblocks = last_block - a.first_block + 1;
+  a.pairs_per_row = (a.nblocks + 1) / 2;
+  a.total_pairs = a.pairs_per_row * s.batch;
+  a.out_start = s.out_start; a.out_len = s.out_len;
+  a.H = reinterpret_cast<const v2f*>(Hd);
+  Ctx::WaveTables& wt = c->wave_tables[K];
+  a.twB = reinterpret_cast<const v2f*>(wt.twB);
+  a.twC = reinterpret_cast<const v2f*>(wt.twC);
+  a.y = s.y;
+  const int units_per_cu = env_int("NXSIG_FIR_UNITS_PER_CU", 96);
+  int64_t max_blocks = ((int64_t)c->num_cus * units_per_cu + W - 1) / W;
+  int64_t want = (a.total_pairs + W - 1) / W;
+  int64_t blocks = want < max_blocks ? want : max_blocks;
+  if (blocks < 1) blocks = 1;
+  a.chunk = (a.total_pairs + blocks - 1) / blocks;
+  a.chunk = ((a.chunk + W - 1) / W) * W;
+  blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
+  const size_t lds = 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8;
+  // 8-byte vector access needs every offset even: taps-1 multiple of 128 (=> V even), even strides, aligned bases
+  const bool fast = ((s.taps - 1) % 128 == 0) && (s.batch_stride % 2 == 0) && (s.out_len % 2 == 0) && (s.out_start % 2 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(s.x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 7) == 0);
+  if (fast) hipLaunchKernelGGL((k_fir_wave<K, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+  else hipLaunchKernelGGL((k_fir_wave<K, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
 
 }  // namespace nxsig

@@ -301,7 +301,7 @@ def fft(x, length=None, eps=FFT_EPS):
     n = x.shape[-1]
     k = n if length is None else _resolve_len(length, n)
     z = np.fft.fft(xin, n=k, axis=-1)
-    return _eps_clean(z, eps).astype(c64)
+    return np.ascontiguousarray(_eps_clean(z, eps).astype(c64))
 
 
 def ifft(x, length=None, eps=FFT_EPS):
@@ -310,7 +310,7 @@ def ifft(x, length=None, eps=FFT_EPS):
     n = x.shape[-1]
     k = n if length is None else _resolve_len(length, n)
     z = np.fft.ifft(xin, n=k, axis=-1)
-    return _eps_clean(z, eps).astype(c64)
+    return np.ascontiguousarray(_eps_clean(z, eps).astype(c64))
 
 
 # --------------------------------------------------------------------------------------

@@ -321,14 +321,16 @@ struct EdgeFixArgs {
   int32_t has_scale;
   float2* y;                // c64[batch][out_len]
   int64_t out_len;
-  int64_t head_cnt, tail_start;  // candidates: [0, head_cnt) and [tail_start, out_len)
-  float tau;                // recompute when 1e-10 < den < tau
+  const int64_t* idx;       // flagged sample indices (host-computed: 1e-10 < den[n] < tau), or nullptr = scan all n
+  int64_t n_idx;
+  float tau;
+  const double2* tw;        // w_N^j = exp(+2 pi i j / N) in double, j in [0, N)
 };
 
 __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
   __shared__ double red[2 * kThreads];
   const int tid = threadIdx.x;
-  const int64_t n = (int64_t)blockIdx.x < a.head_cnt ? (int64_t)blockIdx.x : a.tail_start + ((int64_t)blockIdx.x - a.head_cnt);
+  const int64_t n = a.idx ? a.idx[blockIdx.x] : (int64_t)blockIdx.x;
   if (n >= a.out_len) return;
   int64_t m_hi = n / a.hop;
   if (m_hi > a.M - 1) m_hi = a.M - 1;
@@ -347,12 +349,10 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
     const float2* zr = zb + (size_t)m * a.N;
     double sr = 0.0, si = 0.0;
     for (int k = tid; k < a.N; k += kThreads) {
-      const int64_t jk = ((int64_t)j * k) % a.N;
-      double sn, cs;
-      sincospi(2.0 * (double)jk / (double)a.N, &sn, &cs);
+      const double2 t = a.tw[((int64_t)j * k) % a.N];
       const float2 v = zr[k];
-      sr += (double)v.x * cs - (double)v.y * sn;
-      si += (double)v.x * sn + (double)v.y * cs;
+      sr += (double)v.x * t.x - (double)v.y * t.y;
+      si += (double)v.x * t.y + (double)v.y * t.x;
     }
     red[tid] = sr;
     red[kThreads + tid] = si;
@@ -639,15 +639,47 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
   a.tau = (float)(0.02 * dmax);
   a.z = s.z; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
   a.y = s.y; a.out_len = out_len;
-  if (hop < N && dmin >= (double)a.tau) {  // well-conditioned interior: only the partial-overlap edges are candidates
-    a.head_cnt = (N - hop) < out_len ? (N - hop) : out_len;
-    a.tail_start = s.M * hop > a.head_cnt ? s.M * hop : a.head_cnt;
-  } else {
-    a.head_cnt = out_len;
-    a.tail_start = out_len;
+  a.idx = nullptr; a.n_idx = 0;
+  // inverse twiddles in double (host libm), cached per N
+  {
+    std::vector<double2> tw((size_t)N);
+    for (int j = 0; j < N; ++j) {
+      const double ang = 6.283185307179586476925286766559 * (double)j / (double)N;
+      tw[j] = make_double2(std::cos(ang), std::sin(ang));
+    }
+    const void* d = nullptr;
+    int rc = ctx_table(c, 0xED6Eull, tw.data(), tw.size() * sizeof(double2), &d);
+    if (rc) return rc;
+    a.tw = reinterpret_cast<const double2*>(d);
   }
-  const int64_t blocks = a.head_cnt + (out_len - a.tail_start);
-  if (blocks <= 0) return NXSIG_OK;
+  int64_t blocks;
+  if (hop < N && dmin >= (double)a.tau) {
+    // well-conditioned interior: only samples of the partial-overlap head / tail can be flagged, and which ones is a
+    // pure function of the window -> list them on the host (a few hundred), launch exactly those
+    const int64_t head_cnt = (N - hop) < out_len ? (N - hop) : out_len;
+    const int64_t tail_start = s.M * hop > head_cnt ? s.M * hop : head_cnt;
+    std::vector<int64_t> idx;
+    auto consider = [&](int64_t n) {
+      int64_t m_hi = n / hop;
+      if (m_hi > s.M - 1) m_hi = s.M - 1;
+      const int64_t m_lo = (n - N + 1 <= 0) ? 0 : (n - N + hop) / hop;
+      double den = 0.0;
+      for (int64_t m = m_lo; m <= m_hi; ++m) { const float w = std::fabs(window_host[n - m * hop]); den += (double)(w * w); }
+      const float d = (float)den;
+      if (d > 1.0e-10f && d < a.tau) idx.push_back(n);
+    };
+    for (int64_t n = 0; n < head_cnt; ++n) consider(n);
+    for (int64_t n = tail_start; n < out_len; ++n) consider(n);
+    if (idx.empty()) return NXSIG_OK;
+    const void* d = nullptr;
+    int rc = ctx_table(c, 0x1D8ull, idx.data(), idx.size() * sizeof(int64_t), &d);
+    if (rc) return rc;
+    a.idx = reinterpret_cast<const int64_t*>(d);
+    a.n_idx = (int64_t)idx.size();
+    blocks = a.n_idx;
+  } else {
+    blocks = out_len;  // ill-conditioned interior (e.g. hop == N under a tapered window): every sample is a candidate
+  }
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "istft: signal too long for the edge fix-up grid");
   dim3 grid((unsigned)blocks, (unsigned)s.batch);
   hipLaunchKernelGGL(k_istft_edge_fix, grid, dim3(kThreads), 0, c->stream, a);

@@ -31,52 +31,70 @@ enum : int {
 };
 
 __device__ __forceinline__ v2f wcmul(v2f a, v2f b) { return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ v2f mul_neg_i(v2f a) { return v2f{a.y, -a.x}; }  // a * (-i)
+// a * (-i) for the forward transform, a * (+i) for the inverse (INV)
+template <bool INV>
+__device__ __forceinline__ v2f rot90(v2f a) { return INV ? v2f{-a.y, a.x} : v2f{a.y, -a.x}; }
+// a * conj^INV(c + i s) for a compile-time constant twiddle given as (cos, -sin) of the forward transform
+template <bool INV>
+__device__ __forceinline__ v2f cmulc(v2f a, float c, float ms) { return wcmul(a, v2f{c, INV ? -ms : ms}); }
+// a * (1 -+ i)/sqrt2  and  a * (-1 -+ i)/sqrt2
+template <bool INV>
+__device__ __forceinline__ v2f rot45(v2f a) {
+  const float h = 0.70710678118654752f;
+  return INV ? v2f{(a.x - a.y) * h, (a.x + a.y) * h} : v2f{(a.x + a.y) * h, (a.y - a.x) * h};
+}
+template <bool INV>
+__device__ __forceinline__ v2f rot135(v2f a) {
+  const float h = 0.70710678118654752f;
+  return INV ? v2f{-(a.x + a.y) * h, (a.x - a.y) * h} : v2f{(a.y - a.x) * h, -(a.x + a.y) * h};
+}
 
-// natural-order forward DFTs on registers
+// natural-order DFTs on registers (forward: e^{-2 pi i ..}; INV: e^{+2 pi i ..}, unscaled)
+template <bool INV = false>
 __device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
-  const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = mul_neg_i(a1 - a3);
+  const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = rot90<INV>(a1 - a3);
   a0 = s02 + s13; a1 = d02 + d13; a2 = s02 - s13; a3 = d02 - d13;
 }
 
+template <bool INV = false>
 __device__ __forceinline__ void dft8(v2f* u) {
   // t = 2 t1 + t0: A[t0][r0] = DFT4_{t1}(u[2 t1 + t0]); A[1][r0] *= W8^r0; v[r0] = A0 + A1, v[r0+4] = A0 - A1
   v2f a0 = u[0], a1 = u[2], a2 = u[4], a3 = u[6];
   v2f b0 = u[1], b1 = u[3], b2 = u[5], b3 = u[7];
-  dft4(a0, a1, a2, a3);
-  dft4(b0, b1, b2, b3);
-  const float h = 0.70710678118654752f;
-  b1 = v2f{(b1.x + b1.y) * h, (b1.y - b1.x) * h};   // * (1 - i)/sqrt2
-  b2 = mul_neg_i(b2);                                // * -i
-  b3 = v2f{(b3.y - b3.x) * h, -(b3.x + b3.y) * h};  // * (-1 - i)/sqrt2
+  dft4<INV>(a0, a1, a2, a3);
+  dft4<INV>(b0, b1, b2, b3);
+  b1 = rot45<INV>(b1);
+  b2 = rot90<INV>(b2);
+  b3 = rot135<INV>(b3);
   u[0] = a0 + b0; u[4] = a0 - b0;
   u[1] = a1 + b1; u[5] = a1 - b1;
   u[2] = a2 + b2; u[6] = a2 - b2;
   u[3] = a3 + b3; u[7] = a3 - b3;
 }
 
+template <bool INV = false>
 __device__ __forceinline__ void dft16(v2f* u) {
   // t = 4 t1 + t0, r = r0 + 4 r1:  A[t0][r0] = DFT4_{t1}(u[4 t1 + t0]); A *= W16^(t0 r0); v[r0 + 4 r1] = DFT4_{t0}(A[.][r0])
-  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f;
   v2f A[4][4];
 #pragma unroll
   for (int t0 = 0; t0 < 4; ++t0) {
     A[t0][0] = u[t0]; A[t0][1] = u[4 + t0]; A[t0][2] = u[8 + t0]; A[t0][3] = u[12 + t0];
-    dft4(A[t0][0], A[t0][1], A[t0][2], A[t0][3]);
+    dft4<INV>(A[t0][0], A[t0][1], A[t0][2], A[t0][3]);
   }
-  // W16^j = (cos, -sin)(2 pi j / 16)
-  A[1][1] = wcmul(A[1][1], v2f{c1, -s1});                               // W^1
-  A[1][2] = v2f{(A[1][2].x + A[1][2].y) * h, (A[1][2].y - A[1][2].x) * h};  // W^2
-  A[1][3] = wcmul(A[1][3], v2f{s1, -c1});                               // W^3
-  A[2][1] = v2f{(A[2][1].x + A[2][1].y) * h, (A[2][1].y - A[2][1].x) * h};  // W^2
-  A[2][2] = mul_neg_i(A[2][2]);                                         // W^4
-  A[2][3] = v2f{(A[2][3].y - A[2][3].x) * h, -(A[2][3].x + A[2][3].y) * h}; // W^6
-  A[3][1] = wcmul(A[3][1], v2f{s1, -c1});                               // W^3
-  A[3][2] = v2f{(A[3][2].y - A[3][2].x) * h, -(A[3][2].x + A[3][2].y) * h}; // W^6
-  A[3][3] = wcmul(A[3][3], v2f{-c1, s1});                               // W^9
+  // W16^j = (cos, -sin)(2 pi j / 16), conjugated for INV
+  A[1][1] = cmulc<INV>(A[1][1], c1, -s1);   // W^1
+  A[1][2] = rot45<INV>(A[1][2]);            // W^2
+  A[1][3] = cmulc<INV>(A[1][3], s1, -c1);   // W^3
+  A[2][1] = rot45<INV>(A[2][1]);            // W^2
+  A[2][2] = rot90<INV>(A[2][2]);            // W^4
+  A[2][3] = rot135<INV>(A[2][3]);           // W^6
+  A[3][1] = cmulc<INV>(A[3][1], s1, -c1);   // W^3
+  A[3][2] = rot135<INV>(A[3][2]);           // W^6
+  A[3][3] = cmulc<INV>(A[3][3], -c1, s1);   // W^9
 #pragma unroll
   for (int r0 = 0; r0 < 4; ++r0) {
-    dft4(A[0][r0], A[1][r0], A[2][r0], A[3][r0]);
+    dft4<INV>(A[0][r0], A[1][r0], A[2][r0], A[3][r0]);
     u[r0] = A[0][r0]; u[r0 + 4] = A[1][r0]; u[r0 + 8] = A[2][r0]; u[r0 + 12] = A[3][r0];
   }
 }
@@ -90,7 +108,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // The K-point complex forward FFT of one wave: in  d[s] = x[lane + 64 s]  (P = K/64 points per lane),
 // out zz[par][q] = X[2 lane + par + 128 q].  xb = this wave's private LDS exchange buffer (XCH complex).
-template <int K>
+// INV = true computes the UNSCALED inverse DFT: pass the conjugated twiddle tables (twBi / twCi).
+template <int K, bool INV = false>
 __device__ __forceinline__ void wave_fft_core(const v2f* d, v2f (*zz)[K / 128], v2f* xb, const v2f* s_twB, const v2f* s_twC,
                                               const int lane) {
   constexpr int P = K / 64;
@@ -103,7 +122,7 @@ __device__ __forceinline__ void wave_fft_core(const v2f* d, v2f (*zz)[K / 128], 
       v2f b[16];
 #pragma unroll
       for (int t = 0; t < 16; ++t) b[t] = d[u + B12 * t];
-      dft16(b);
+      dft16<INV>(b);
       const int base = 17 * (lane + 64 * u);  // pad1(16 i + r) = 17 i + r
 #pragma unroll
       for (int r = 0; r < 16; ++r) xb[base + r] = b[r];
@@ -123,7 +142,7 @@ __device__ __forceinline__ void wave_fft_core(const v2f* d, v2f (*zz)[K / 128], 
     for (int u = 0; u < B12; ++u) {
 #pragma unroll
       for (int t = 1; t < 16; ++t) e[u][t] = wcmul(e[u][t], s_twB[t * 16 + k16]);
-      dft16(e[u]);
+      dft16<INV>(e[u]);
     }
     wave_lds_fence();  // every exchange-1 read is issued before exchange 2 overwrites the buffer
 #pragma unroll
@@ -150,8 +169,8 @@ __device__ __forceinline__ void wave_fft_core(const v2f* d, v2f (*zz)[K / 128], 
           c1[t] = wcmul(c1[t], v2f{w.z, w.w});
         }
       }
-      if (R3 == 4) { dft4(c0[0], c0[1], c0[2], c0[3]); dft4(c1[0], c1[1], c1[2], c1[3]); }
-      else { dft8(c0); dft8(c1); }
+      if (R3 == 4) { dft4<INV>(c0[0], c0[1], c0[2], c0[3]); dft4<INV>(c1[0], c1[1], c1[2], c1[3]); }
+      else { dft8<INV>(c0); dft8<INV>(c1); }
 #pragma unroll
       for (int r = 0; r < R3; ++r) { zz[0][u2 + 2 * r] = c0[r]; zz[1][u2 + 2 * r] = c1[r]; }
     }
@@ -413,7 +432,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
 
 // ============================================================================================ iSTFT
 // NxSignal.istft/3 fused in one launch (lib/nx_signal.ex:609-637): one wave walks a RUN of consecutive frames of one
-// row.  Per frame: c64 load -> inverse FFT (= conj . forward core . conj, x 1/K) -> x scale x window -> the frame's
+// row.  Per frame: c64 load -> inverse FFT (the core with conjugated twiddles, x 1/K) -> x scale x window -> the frame's
 // R = N/hop hop-sized segments are folded into R-1 pending accumulators held in registers, always in ascending
 // frame order (deterministic: no atomics, run-to-run bit-stable) -> the finished segment is divided by the OLA
 // normaliser sum |w|^2 (guard 1e-10 -> 1, :635) and stored as c64 with 16-byte stores.  The lane layout of the
@@ -430,7 +449,7 @@ struct IstftWaveArgs {
   const v2f* twB;
   const v2f* twC;
   float scale;
-  const float* den;           // f32[2R-1][hop]: guarded OLA normaliser of head segments 0..R-2, interior, tail segments
+  const float* den;           // f32[2R-1][hop]: RECIPROCAL of the guarded OLA normaliser: head segments 0..R-2, interior, tail segments
   v2f* y;                     // c64[batch][segs_per_row * hop]
   v2f* dummy;
 };
@@ -487,16 +506,16 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
   issue_loads(m_start);
   v2f d[P];
 #pragma unroll
-  for (int s = 0; s < P; ++s) d[s] = v2f{r[s].x, -r[s].y};  // conj: IFFT(z) = conj(FFT(conj z)) / K
+  for (int s = 0; s < P; ++s) d[s] = r[s];
 
   for (int64_t m = m_start; m < j1; ++m) {
     issue_loads(m + 1 < j1 ? m + 1 : m);  // unconditional prefetch keeps the loop branch-free
     __builtin_amdgcn_sched_barrier(0);
     v2f zz[2][NQ];
-    wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);
+    wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);  // inverse direction (tables are conjugated)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < P; ++s) d[s] = v2f{r[s].x, -r[s].y};
+    for (int s = 0; s < P; ++s) d[s] = r[s];
     __builtin_amdgcn_sched_barrier(0);
 
     const float live = m < a.M ? 1.0f : 0.0f;  // tail flush: frames m >= M do not exist
@@ -507,7 +526,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
     v2f den[QS];
 #pragma unroll
     for (int qq = 0; qq < QS; ++qq) den[qq] = *reinterpret_cast<const v2f*>(dp + 128 * qq);
-    // frame samples ((conj X / K) * scale) * window (lib/nx_signal.ex:609-628, same rounding order) are folded
+    // frame samples ((IDFT / K) * scale) * window (lib/nx_signal.ex:609-628, same rounding order) are folded
     // straight into the pending overlap sums, always in ascending frame order
     v2f out[2][QS];
 #pragma unroll
@@ -517,7 +536,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
         v2f f[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          v2f v = v2f{zz[e][i * QS + qq].x, -zz[e][i * QS + qq].y} * invK;
+          v2f v = zz[e][i * QS + qq] * invK;
           if (SCALE) v = v * a.scale;
           f[i] = v * (wv[e][i * QS + qq] * live);
         }
@@ -532,7 +551,8 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
     v2f* yp = (j >= j0) ? a.y + (size_t)row * a.segs_per_row * a.hop + j * a.hop + 2 * lane : a.dummy + 2 * lane;
 #pragma unroll
     for (int qq = 0; qq < QS; ++qq) {
-      const v4f o = v4f{out[0][qq].x / den[qq].x, out[0][qq].y / den[qq].x, out[1][qq].x / den[qq].y, out[1][qq].y / den[qq].y};
+      // the table holds 1 / max-guarded normaliser (rounded from double): a multiply instead of 4 divisions, <= 1 ulp
+      const v4f o = v4f{out[0][qq].x * den[qq].x, out[0][qq].y * den[qq].x, out[1][qq].x * den[qq].y, out[1][qq].y * den[qq].y};
       __builtin_nontemporal_store(o, (gv4f*)(yp + 128 * qq));
     }
   }
@@ -732,8 +752,8 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   a.wtab = window_padK;
   Ctx::WaveTables& wt = c->wave_tables[K];
   if (!wt.twB) return NXSIG_ERR_UNSUPPORTED;  // tables are created by ensure_wave_tables below
-  a.twB = reinterpret_cast<const v2f*>(wt.twB);
-  a.twC = reinterpret_cast<const v2f*>(wt.twC);
+  a.twB = reinterpret_cast<const v2f*>(wt.twBi);  // conjugated tables: the kernel runs the core in inverse direction
+  a.twC = reinterpret_cast<const v2f*>(wt.twCi);
   a.scale = s.scale_mul;
   {  // guarded normaliser rows (lib/nx_signal.ex:630-635): double accumulation in ascending frame order, one rounding
     const int hop = s.hop;
@@ -750,7 +770,7 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
           if (have) acc += w2(rr * hop + pos);
         }
         const float d = (float)acc;
-        den[(size_t)row * hop + pos] = d > 1.0e-10f ? d : 1.0f;
+        den[(size_t)row * hop + pos] = (float)(1.0 / (double)(d > 1.0e-10f ? d : 1.0f));  // reciprocal of the guarded normaliser
       }
     const void* dd = nullptr;
     int rc3 = ctx_table(c, 0xDE17ull ^ ((uint64_t)R << 32), den.data(), den.size() * sizeof(float), &dd);
@@ -802,6 +822,12 @@ static int ensure_wave_tables_1024(Ctx* c) {
   rc = ctx_table(c, 0x7743ull ^ (uint64_t)C, twC.data(), twC.size() * sizeof(float2), &wt.twC);
   if (rc) { wt.twB = nullptr; return rc; }
   rc = ctx_table(c, 0x7744ull ^ (uint64_t)C, twR.data(), twR.size() * sizeof(float2), &wt.twI);
+  if (rc) { wt.twB = nullptr; return rc; }
+  for (auto& t : twB) t.y = -t.y;  // conjugated copies for the inverse transform
+  for (auto& t : twC) t.y = -t.y;
+  rc = ctx_table(c, 0x7745ull, twB.data(), twB.size() * sizeof(float2), &wt.twBi);
+  if (rc) { wt.twB = nullptr; return rc; }
+  rc = ctx_table(c, 0x7746ull ^ (uint64_t)C, twC.data(), twC.size() * sizeof(float2), &wt.twCi);
   if (rc) { wt.twB = nullptr; return rc; }
   return NXSIG_OK;
 }

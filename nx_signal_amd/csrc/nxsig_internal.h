@@ -68,7 +68,8 @@ struct Ctx {
   void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t scratch_bytes[4] = {0, 0, 0, 0};
   // per-K tables of the tuned wave kernels (pass-B / pass-C twiddles), built once
-  struct WaveTables { const void* twB = nullptr; const void* twC = nullptr; const void* twI = nullptr; };
+  struct WaveTables { const void* twB = nullptr; const void* twC = nullptr; const void* twI = nullptr;
+                      const void* twBi = nullptr; const void* twCi = nullptr; };  // ...i = conjugated (inverse transform)
   std::map<int, WaveTables> wave_tables;
   // memo of the last window seen (the common case: the same window tensor call after call)
   std::vector<float> memo_win;

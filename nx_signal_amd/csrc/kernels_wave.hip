@@ -570,16 +570,22 @@ struct FirWaveArgs {
   int64_t L, batch_stride;
   int32_t batch, taps;
   int64_t V, nblocks, first_block;     // blocks (per row) covering the requested output slice
-  int64_t pairs_per_row, total_pairs, chunk;
+  int64_t pairs_per_row;               // block pairs per row
+  int64_t pb_lo, pb_hi;                // interior pairs [pb_lo, pb_hi): both blocks fully inside input and output
+  int64_t units_per_row, total_units, chunk;  // STREAM: interior pairs; EDGE: the other pairs of each row
   int64_t out_start, out_len;
   const v2f* H;                        // c64[K] natural order, pre-scaled by 1/K
   const v2f* twB;
   const v2f* twC;
+  const v2f* twBi;
+  const v2f* twCi;
   float* y;                            // f32[batch][out_len]
 };
 
-// FAST: (taps-1) % 128 == 0 and every offset even -> interior pairs use 8-byte loads / stores without predicates
-template <int K, bool FAST, int W>
+// STREAM = true : interior pairs only, 8-byte vector access, branch-free and software-pipelined like k_stft_wave
+//                 (requires (taps-1) % 128 == 0 and even offsets — checked by the launcher)
+// STREAM = false: the few edge pairs of every row (and every pair when the fast conditions fail): bounds-checked
+template <int K, bool STREAM, int W>
 __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
   constexpr int P = K / 64;
   constexpr int R3 = K / 256;
@@ -587,76 +593,110 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
   constexpr int XCH = K + K / 16 + 16;
   v2f* s_twB = reinterpret_cast<v2f*>(g_wave_smem);
   v2f* s_twC = s_twB + 256;
-  v2f* s_x = s_twC + R3 * 256;
+  v2f* s_twBi = s_twC + R3 * 256;
+  v2f* s_twCi = s_twBi + 256;
+  v2f* s_H = s_twCi + R3 * 256;
+  v2f* s_x = s_H + K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
-  for (int i = tid; i < R3 * 256; i += 64 * W) s_twC[i] = a.twC[i];
+  for (int i = tid; i < 256; i += 64 * W) { s_twB[i] = a.twB[i]; s_twBi[i] = a.twBi[i]; }
+  for (int i = tid; i < R3 * 256; i += 64 * W) { s_twC[i] = a.twC[i]; s_twCi[i] = a.twCi[i]; }
+  for (int i = tid; i < K; i += 64 * W) s_H[i] = a.H[i];
   __syncthreads();
   v2f* xb = s_x + wave * XCH;
-  v2f h[P];  // filter spectrum of this lane's bins k = lane + 64 s (registers for the whole kernel)
-#pragma unroll
-  for (int s = 0; s < P; ++s) h[s] = a.H[lane + 64 * s];
 
   const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
   int64_t p_end = p_begin + a.chunk;
-  if (p_end > a.total_pairs) p_end = a.total_pairs;
+  if (p_end > a.total_units) p_end = a.total_units;
   const int tm1 = a.taps - 1;
 
-  for (int64_t pr = p_begin + wave; pr < p_end; pr += W) {
-    const int64_t row = pr / a.pairs_per_row;
-    const int64_t b1 = a.first_block + 2 * (pr - row * a.pairs_per_row), b2 = b1 + 1;
-    const bool have2 = (b2 - a.first_block) < a.nblocks;
-    const float* xr = a.x + (size_t)row * a.batch_stride;
-    float* yr = a.y + (size_t)row * a.out_len;
-    const int64_t s1 = b1 * a.V - tm1, s2 = s1 + a.V;
-    const int64_t o1 = b1 * a.V - a.out_start - tm1;  // y index of block-1 sample n is o1 + n (n >= taps-1)
-    const bool interior = FAST && have2 && s1 >= 0 && s2 + K <= a.L && o1 + tm1 >= 0 && o1 + a.V + K <= a.out_len;
-
-    v2f zz[2][NQ];  // zz[par][q] = (x1[n], x2[n]), n = 2 lane + par + 128 q
-    if (interior) {
+  if (STREAM) {
+    int64_t row = (p_begin + wave) / a.units_per_row;
+    int64_t pin = (p_begin + wave) - row * a.units_per_row;
+    int64_t nrow = row, npin = pin;
+    auto advance = [&](int64_t& r, int64_t& q) {
+      q += W;
+      while (q >= a.units_per_row) { q -= a.units_per_row; ++r; }
+    };
+    advance(nrow, npin);
+    v2f r1[NQ], r2[NQ];
+    auto issue_loads = [&](int64_t rw, int64_t pi) {
+      const int64_t b1 = a.first_block + 2 * (a.pb_lo + pi);
+      const float* p1 = a.x + (size_t)rw * a.batch_stride + (b1 * a.V - tm1) + 2 * lane;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const v2f u1 = *reinterpret_cast<const v2f*>(xr + s1 + 2 * lane + 128 * q);
-        const v2f u2 = *reinterpret_cast<const v2f*>(xr + s2 + 2 * lane + 128 * q);
-        zz[0][q] = v2f{u1.x, u2.x};
-        zz[1][q] = v2f{u1.y, u2.y};
+        r1[q] = *reinterpret_cast<const v2f*>(p1 + 128 * q);
+        r2[q] = *reinterpret_cast<const v2f*>(p1 + a.V + 128 * q);
       }
-    } else {
+    };
+    v2f zz[2][NQ];  // zz[par][q] = (x1[n], x2[n]), n = 2 lane + par + 128 q
+    auto pack = [&]() {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
+      for (int q = 0; q < NQ; ++q) { zz[0][q] = v2f{r1[q].x, r2[q].x}; zz[1][q] = v2f{r1[q].y, r2[q].y}; }
+    };
+    if (p_begin + wave < p_end) { issue_loads(row, pin); pack(); }
+    for (int64_t pr = p_begin + wave; pr < p_end; pr += W) {
+      const bool more = pr + W < p_end;
+      issue_loads(more ? nrow : row, more ? npin : pin);  // unconditional prefetch: branch-free loop
+      __builtin_amdgcn_sched_barrier(0);
+      v2f d[P];
+      wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int n = 2 * lane + e + 128 * q;
-          const int64_t p1 = s1 + n, p2 = s2 + n;
-          const float v1 = (p1 >= 0 && p1 < a.L) ? xr[p1] : 0.0f;
-          const float v2 = (have2 && p2 >= 0 && p2 < a.L) ? xr[p2] : 0.0f;
-          zz[e][q] = v2f{v1, v2};
-        }
-    }
-    v2f d[P];
-    wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);
-#pragma unroll
-    for (int s = 0; s < P; ++s) { const v2f t = wcmul(d[s], h[s]); d[s] = v2f{t.x, -t.y}; }  // conj(Z H / K)
-    wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);  // zz = U with ifft = conj(U): y1 = U.x, y2 = -U.y
-    if (interior) {
+      for (int s = 0; s < P; ++s) d[s] = wcmul(d[s], s_H[lane + 64 * s]);  // Z H / K
+      v2f u[2][NQ];
+      wave_fft_core<K, true>(d, u, xb, s_twBi, s_twCi, lane);  // inverse: u = (y1[n], y2[n])
+      __builtin_amdgcn_sched_barrier(0);
+      pack();  // next pair (its samples landed during the two transforms)
+      __builtin_amdgcn_sched_barrier(0);
+      const int64_t b1 = a.first_block + 2 * (a.pb_lo + pin);
+      float* p1 = a.y + (size_t)row * a.out_len + (b1 * a.V - a.out_start - tm1) + 2 * lane;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (128 * q >= tm1) {  // uniform: (taps-1) % 128 == 0
-          float* p1 = yr + o1 + 2 * lane + 128 * q;
-          *reinterpret_cast<v2f*>(p1) = v2f{zz[0][q].x, zz[1][q].x};
-          *reinterpret_cast<v2f*>(p1 + a.V) = v2f{-zz[0][q].y, -zz[1][q].y};
+          *reinterpret_cast<v2f*>(p1 + 128 * q) = v2f{u[0][q].x, u[1][q].x};
+          *reinterpret_cast<v2f*>(p1 + a.V + 128 * q) = v2f{u[0][q].y, u[1][q].y};
         }
       }
-    } else {
+      row = nrow; pin = npin;
+      advance(nrow, npin);
+    }
+  } else {
+    const int64_t n_lo = a.pb_lo, n_hi = a.pairs_per_row - a.pb_hi;  // edge pairs per row: [0, pb_lo) and [pb_hi, pairs)
+    for (int64_t pr = p_begin + wave; pr < p_end; pr += W) {
+      const int64_t row = pr / a.units_per_row;
+      const int64_t e = pr - row * a.units_per_row;
+      const int64_t pb = e < n_lo ? e : a.pb_hi + (e - n_lo);
+      (void)n_hi;
+      const int64_t b1 = a.first_block + 2 * pb, b2 = b1 + 1;
+      const bool have2 = (b2 - a.first_block) < a.nblocks;
+      const float* xr = a.x + (size_t)row * a.batch_stride;
+      float* yr = a.y + (size_t)row * a.out_len;
+      const int64_t s1 = b1 * a.V - tm1, s2 = s1 + a.V;
+      const int64_t o1 = b1 * a.V - a.out_start - tm1;  // y index of block-1 sample n is o1 + n (n >= taps-1)
+      v2f zz[2][NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int n = 2 * lane + e + 128 * q;
+        for (int e2 = 0; e2 < 2; ++e2) {
+          const int n = 2 * lane + e2 + 128 * q;
+          const int64_t p1 = s1 + n, p2 = s2 + n;
+          const float v1 = (p1 >= 0 && p1 < a.L) ? xr[p1] : 0.0f;
+          const float v2 = (have2 && p2 >= 0 && p2 < a.L) ? xr[p2] : 0.0f;
+          zz[e2][q] = v2f{v1, v2};
+        }
+      v2f d[P];
+      wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);
+#pragma unroll
+      for (int s = 0; s < P; ++s) d[s] = wcmul(d[s], s_H[lane + 64 * s]);
+      wave_fft_core<K, true>(d, zz, xb, s_twBi, s_twCi, lane);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          const int n = 2 * lane + e2 + 128 * q;
           if (n >= tm1) {
             const int64_t y1 = o1 + n, y2 = y1 + a.V;
-            if (y1 >= 0 && y1 < a.out_len) yr[y1] = zz[e][q].x;
-            if (have2 && y2 >= 0 && y2 < a.out_len) yr[y2] = -zz[e][q].y;
+            if (y1 >= 0 && y1 < a.out_len) yr[y1] = zz[e2][q].x;
+            if (have2 && y2 >= 0 && y2 < a.out_len) yr[y2] = zz[e2][q].y;
           }
         }
     }
@@ -872,9 +912,10 @@ static void host_fft1024_f64(std::vector<double>& re, std::vector<double>& im) {
   }
 }
 
-int launch_fir_wave(Ctx* c, const FirLaunch& s, bool* handled) {
+template <int W>
+static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
   *handled = false;
-  constexpr int K = 1024, R3 = 4, XCH = K + K / 16 + 16, W = 4;
+  constexpr int K = 1024, R3 = 4, XCH = K + K / 16 + 16;
   if (s.out_len <= 0 || s.batch == 0) return NXSIG_OK;
   if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
   if (s.taps > 513) return NXSIG_OK;  // block of 1024 would be < 50 % efficient: generic path uses bigger blocks
@@ -896,29 +937,71 @@ int launch_fir_wave(Ctx* c, const FirLaunch& s, bool* handled) {
   const int64_t last_block = (s.out_start + s.out_len - 1) / a.V;
   a.nblocks = last_block - a.first_block + 1;
   a.pairs_per_row = (a.nblocks + 1) / 2;
-  a.total_pairs = a.pairs_per_row * s.batch;
   a.out_start = s.out_start; a.out_len = s.out_len;
   a.H = reinterpret_cast<const v2f*>(Hd);
   Ctx::WaveTables& wt = c->wave_tables[K];
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
+  a.twBi = reinterpret_cast<const v2f*>(wt.twBi);
+  a.twCi = reinterpret_cast<const v2f*>(wt.twCi);
   a.y = s.y;
-  const int units_per_cu = env_int("NXSIG_FIR_UNITS_PER_CU", 96);
-  int64_t max_blocks = ((int64_t)c->num_cus * units_per_cu + W - 1) / W;
-  int64_t want = (a.total_pairs + W - 1) / W;
-  int64_t blocks = want < max_blocks ? want : max_blocks;
-  if (blocks < 1) blocks = 1;
-  a.chunk = (a.total_pairs + blocks - 1) / blocks;
-  a.chunk = ((a.chunk + W - 1) / W) * W;
-  blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
-  const size_t lds = 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8;
   // 8-byte vector access needs every offset even: taps-1 multiple of 128 (=> V even), even strides, aligned bases
   const bool fast = ((s.taps - 1) % 128 == 0) && (s.batch_stride % 2 == 0) && (s.out_len % 2 == 0) && (s.out_start % 2 == 0) &&
                     ((reinterpret_cast<uintptr_t>(s.x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 7) == 0);
-  if (fast) hipLaunchKernelGGL((k_fir_wave<K, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-  else hipLaunchKernelGGL((k_fir_wave<K, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-  NXSIG_HIP_TRY(hipGetLastError());
-  return NXSIG_OK;
+  // interior pairs pb in [pb_lo, pb_hi): block pair (b1, b1+1), b1 = first_block + 2 pb, reads x[b1 V - (taps-1) .. +V+K)
+  // inside [0, L) and writes y[b1 V - out_start .. + 2V) inside [0, out_len)
+  a.pb_lo = 0; a.pb_hi = 0;
+  if (fast) {
+    const int64_t tm1 = s.taps - 1;
+    int64_t lo = 0;
+    while (lo < a.pairs_per_row) {
+      const int64_t b1 = a.first_block + 2 * lo;
+      if (b1 * a.V - tm1 >= 0 && b1 * a.V - a.out_start >= 0) break;
+      ++lo;
+    }
+    int64_t hi = a.pairs_per_row;
+    while (hi > lo) {
+      const int64_t b1 = a.first_block + 2 * (hi - 1);
+      const bool have2 = (b1 + 1 - a.first_block) < a.nblocks;
+      if (have2 && b1 * a.V - tm1 + a.V + K <= s.L && b1 * a.V - a.out_start + 2 * a.V <= s.out_len) break;
+      --hi;
+    }
+    a.pb_lo = lo; a.pb_hi = hi;
+  }
+  const size_t lds = 2 * (256 * 8 + (size_t)R3 * 256 * 8) + (size_t)K * 8 + (size_t)W * XCH * 8;
+  auto launch = [&](bool stream, int64_t units_per_row) -> int {
+    if (units_per_row <= 0) return NXSIG_OK;
+    a.units_per_row = units_per_row;
+    a.total_units = units_per_row * s.batch;
+    const int units_per_cu = env_int("NXSIG_FIR_UNITS_PER_CU", 96);
+    int64_t max_blocks = ((int64_t)c->num_cus * units_per_cu + W - 1) / W;
+    int64_t want = (a.total_units + W - 1) / W;
+    int64_t blocks = want < max_blocks ? want : max_blocks;
+    if (blocks < 1) blocks = 1;
+    a.chunk = (a.total_units + blocks - 1) / blocks;
+    a.chunk = ((a.chunk + W - 1) / W) * W;
+    blocks = (a.total_units + a.chunk - 1) / a.chunk;
+    if (lds > 64 * 1024) {
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_wave<K, true, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_wave<K, false, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    else hipLaunchKernelGGL((k_fir_wave<K, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  };
+  rc = launch(true, a.pb_hi - a.pb_lo);
+  if (rc) return rc;
+  return launch(false, a.pairs_per_row - (a.pb_hi - a.pb_lo));
+}
+
+int launch_fir_wave(Ctx* c, const FirLaunch& s, bool* handled) {
+  switch (env_int("NXSIG_FIR_W", 14)) {
+    case 4: return launch_fir_wave_W<4>(c, s, handled);
+    case 6: return launch_fir_wave_W<6>(c, s, handled);
+    case 12: return launch_fir_wave_W<12>(c, s, handled);
+    default: return launch_fir_wave_W<14>(c, s, handled);
+  }
 }
 
 }  // namespace nxsig

@@ -1,0 +1,160 @@
+"""GPU parity tests aimed at the tuned wave kernels (kernels_wave.hip): every template variant and every seam
+(odd frame counts, batch rows, chunk boundaries, run boundaries of the istft, stream/edge split of the FIR) against
+the oracle, and against the generic kernels (NXSIG_DISABLE_WAVE=1 cannot be flipped inside one process, so the
+generic path is exercised through shapes the tuned kernels decline)."""
+import numpy as np
+import pytest
+
+from oracle import nx_oracle as O
+
+import nx_signal_amd as S
+
+pytestmark = pytest.mark.gpu
+
+
+def nerr(got, ref):
+    d = np.abs(np.asarray(got).astype(np.complex128) - np.asarray(ref).astype(np.complex128))
+    return float(d.max()) / max(float(np.max(np.abs(ref))), 1e-30)
+
+
+@pytest.mark.parametrize("K,N,hop,L,batch", [
+    (1024, 1024, 256, 1024 + 256 * 6, 3),        # M = 7 (odd) per row, 3 rows: phantom second frame at every row end
+    (1024, 1024, 256, 1024, 2),                  # M = 1: a lone frame per row
+    (1024, 1024, 1, 1024 + 37, 1),               # hop 1
+    (1024, 1024, 333, 1024 + 333 * 40 + 5, 2),   # hop not a multiple of anything, ragged tail dropped (:valid)
+    (1024, 1000, 250, 20000, 2),                 # N < K: zero-padded frames (general path: reads must stop at N)
+    (1024, 1500, 500, 20000, 1),                 # N > K: truncated frames
+    (2048, 2048, 512, 2048 + 512 * 9, 3),        # real-2x front-end, odd M, 3 rows
+    (2048, 2048, 511, 50000, 1),                 # odd hop: unaligned 4-byte loads
+    (2048, 1024, 256, 30000, 2),                 # N < K on the real-2x front-end
+])
+def test_stft_wave_variants(K, N, hop, L, batch):
+    rng = np.random.default_rng(K + N + hop + L)
+    x = rng.standard_normal((batch, L)).astype(np.float32)
+    w = S.windows.hann(N)
+    for scaling in (None, "psd"):
+        opts = dict(overlap_length=N - hop, fft_length=K, sampling_rate=16000, scaling=scaling)
+        z, _, _ = S.stft(x, w, **opts)
+        zo, _, _ = O.stft(x, w, **opts)
+        assert z.shape == zo.shape
+        assert nerr(z, zo) < 1e-5, (K, N, hop, scaling, nerr(z, zo))
+
+
+def test_stft_wave_chunk_seams_many_rows():
+    """more rows x frames than workgroups: chunks straddle row boundaries"""
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((37, 1024 + 256 * 300 + 3)).astype(np.float32)
+    w = S.windows.hamming(1024)
+    z, _, _ = S.stft(x, w, overlap_length=768, fft_length=1024)
+    zo, _, _ = O.stft(x, w, overlap_length=768, fft_length=1024)
+    assert nerr(z, zo) < 1e-5
+
+
+@pytest.mark.parametrize("pad", ["reflect", "same", [(100, 900)], [(-3, 50)]])
+@pytest.mark.parametrize("K", [1024, 2048])
+def test_stft_wave_general_padding(pad, K):
+    rng = np.random.default_rng(5 + K)
+    x = rng.standard_normal((2, 9000)).astype(np.float32)
+    w = S.windows.blackman(K)
+    opts = dict(overlap_length=K - K // 4, fft_length=K, window_padding=pad, scaling="spectrum", sampling_rate=8000)
+    z, t, f = S.stft(x, w, **opts)
+    zo, to, fo = O.stft(x, w, **opts)
+    assert z.shape == zo.shape and nerr(z, zo) < 1e-5
+    assert np.array_equal(t, to) and np.array_equal(f, fo)
+
+
+@pytest.mark.parametrize("hop", [128, 256, 512, 1024])
+@pytest.mark.parametrize("M", [7, 15, 64, 301])
+def test_istft_wave_all_hops_and_run_seams(hop, M):
+    """tuned istft (N = 1024): R = 8, 4, 2, 1; M spans 'fewer frames than 2R-1' (generic path) to several runs"""
+    N = 1024
+    rng = np.random.default_rng(hop + M)
+    z = (rng.standard_normal((3, M, N)) + 1j * rng.standard_normal((3, M, N))).astype(np.complex64)
+    w = S.windows.hann(N)
+    for scaling in (None, "spectrum"):
+        y = S.istft(z, w, overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=48000)
+        yo = O.istft(z, w, overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=48000)
+        assert y.shape == yo.shape
+        assert nerr(y, yo) < 1e-5, (hop, M, scaling, nerr(y, yo))
+
+
+def test_istft_rectangular_window_no_edge_fix_needed():
+    N, hop, M = 1024, 256, 40
+    rng = np.random.default_rng(3)
+    z = (rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))).astype(np.complex64)
+    w = S.windows.rectangular(N, type="f32")
+    y = S.istft(z, w, overlap_length=N - hop, fft_length=N)
+    assert nerr(y, O.istft(z, w, overlap_length=N - hop, fft_length=N)) < 1e-5
+
+
+@pytest.mark.parametrize("taps", [1, 2, 65, 129, 257, 385, 513, 300, 514, 1000])
+@pytest.mark.parametrize("mode", ["full", "same", "valid"])
+def test_fir_wave_stream_edge_split(taps, mode):
+    """taps-1 multiples of 128 take the vectorised streaming kernel for interior block pairs and the bounds-checked
+    kernel at the row ends; other tap counts take the bounds-checked kernel throughout; > 513 taps the generic one"""
+    rng = np.random.default_rng(taps)
+    L = 20000 + (taps % 7)
+    x = rng.standard_normal((3, L)).astype(np.float32)
+    h = rng.standard_normal(taps).astype(np.float32) / max(1, taps) ** 0.5
+    ctx = S.default_context()
+    y = S.convolution.convolve(ctx.to_device(x), h, method="fft", mode=mode).numpy()
+    n = {"full": L + taps - 1, "same": L, "valid": abs(L - taps) + 1}[mode]
+    assert y.shape == (3, n)
+    for r in range(3):
+        full = O.direct_convolve_f64(x[r], h)
+        start = (full.shape[0] - n) // 2 if mode != "full" else 0
+        ref = full[start:start + n]
+        assert nerr(y[r], ref) < 1e-5, (taps, mode, r, nerr(y[r], ref))
+
+
+def test_fir_short_signal_and_odd_alignment():
+    rng = np.random.default_rng(9)
+    for L in (1, 5, 700, 1023, 1025, 3001):
+        x = rng.standard_normal(L).astype(np.float32)
+        h = S.filters.firwin(257, [0.2])
+        y = S.filters.fir(x, h, mode="same")
+        full = O.direct_convolve_f64(x, h)
+        ref = full[128:128 + L]
+        assert y.shape == (L,) and nerr(y, ref) < 1e-5, L
+
+
+def test_device_resident_chain_matches_host_path():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 50000)).astype(np.float32)
+    w = S.windows.hann(1024)
+    opts = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)
+    ctx = S.default_context()
+    zd, _, _ = S.stft(ctx.to_device(x), w, **opts)
+    yd = S.istft(zd, w, **opts)
+    zh, _, _ = S.stft(x, w, **opts)
+    yh = S.istft(zh, w, **opts)
+    assert np.array_equal(zd.numpy().view(np.uint32), zh.view(np.uint32))
+    assert np.array_equal(yd.numpy().view(np.uint32), yh.view(np.uint32))
+    fr = S.as_windowed(ctx.to_device(x), window_length=64, stride=16)
+    assert np.array_equal(fr.numpy(), S.as_windowed(x, window_length=64, stride=16))
+    ola = S.overlap_and_add(fr, overlap_length=48)
+    assert np.array_equal(ola.numpy(), S.overlap_and_add(fr.numpy(), overlap_length=48))
+
+
+def test_concurrent_contexts_and_threads():
+    """dirty-NIF style usage: several OS threads, one context each, same GPU"""
+    import threading
+
+    x = O.synth_signal(100000, seed=4)
+    w = S.windows.hann(1024)
+    ref, _, _ = O.stft(x, w, overlap_length=768, fft_length=1024)
+    errs = []
+
+    def work():
+        c = S.Context(0)
+        for _ in range(5):
+            z, _, _ = S.stft(x, w, ctx=c, overlap_length=768, fft_length=1024)
+            errs.append(nerr(z, ref))
+        c.close()
+
+    ts = [threading.Thread(target=work) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert len(errs) == 20 and max(errs) < 1e-5

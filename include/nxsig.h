@@ -181,6 +181,15 @@ int nxsig_fft(nxsig_ctx* ctx, const void* in, int32_t in_is_real, int64_t rows, 
 int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
                   int32_t num_taps, int32_t mode, float* y, int32_t mem);
 
+/*
+ * 1-D complex case of Convolution.fftconvolve/3 — lib/nx_signal/convolution.ex:252-329 (tests: "FFT complex",
+ * test/nx_signal/convolutions_test.exs:473-487): out = ifft(fft(a, P) * fft(b, P)) sliced per mode, with
+ * P = next power of two >= n1 + n2 - 1 (same linear convolution as the reference's length n1 + n2 - 1).
+ *   a c64[n1], b c64[n2], out c64[nxsig_conv_length(n1, n2, mode)]; n1 + n2 - 1 <= 8192 (one LDS-resident FFT).
+ */
+int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const nxsig_c64* b, int64_t n2, int32_t mode,
+                          nxsig_c64* out, int32_t mem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,7 @@ SIGNATURES = {
     "nxsig_overlap_and_add": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32]),
     "nxsig_fft": (C.c_int, [_p, _p, _i32, _i64, _i32, _i32, _i32, _p, _i32]),
     "nxsig_fir_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _i32, _i32, _p, _i32]),
+    "nxsig_fftconvolve_c64": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32]),
 }
 
 _lib = None

@@ -47,7 +47,23 @@ def fftconvolve(in1, in2, ctx=None, **opts):
     if h is None:
         raise ArgumentError("fftconvolve: the second operand (filter taps) must be a host tensor")
     if np.iscomplexobj(h) or (not dev and np.iscomplexobj(np.asarray(in1))):
-        raise NxSignalUnsupported("complex fftconvolve is not built yet (real 1-D FIR path only)")
+        if dev:
+            raise NxSignalUnsupported("complex fftconvolve takes host tensors")
+        a = np.asarray(in1)
+        if a.ndim != 1 or h.ndim != 1:
+            if a.ndim != h.ndim:
+                raise ArgumentError("Rank of in1 and in2 must be equal.")
+            raise NxSignalUnsupported("fftconvolve: n-D complex convolution is outside the hot path")
+        if a.dtype == np.complex128 or h.dtype == np.complex128:
+            raise ArgumentError("fftconvolve: complex128 is outside this path (f32/c64); cast to complex64 explicitly")
+        ac = np.ascontiguousarray(a.astype(np.complex64))
+        bc = np.ascontiguousarray(h.astype(np.complex64))
+        n_out = _lib.check(lib.nxsig_conv_length(ac.size, bc.size, _MODES[mode]))
+        out = np.empty(n_out, dtype=np.complex64)
+        c = ctx or default_context()
+        _lib.check(lib.nxsig_fftconvolve_c64(c.handle, ac.ctypes.data_as(C.c_void_p), ac.size, bc.ctypes.data_as(C.c_void_p),
+                                             bc.size, _MODES[mode], out.ctypes.data_as(C.c_void_p), _lib.HOST))
+        return out
     if h.ndim != 1:
         raise NxSignalUnsupported("fftconvolve: n-D kernels are outside the hot path")
     h32 = np.ascontiguousarray(h.astype(np.float32))

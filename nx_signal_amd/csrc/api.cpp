@@ -631,4 +631,35 @@ int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch,
   NXSIG_API_END
 }
 
+int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const nxsig_c64* b, int64_t n2, int32_t mode,
+                          nxsig_c64* out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!a || !b || !out) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (n1 < 1 || n2 < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: lengths must be >= 1");
+  const int64_t full = n1 + n2 - 1;
+  int64_t out_len, start;
+  switch (mode) {  // lib/nx_signal/convolution.ex:300-329
+    case NXSIG_CONV_FULL: out_len = full; start = 0; break;
+    case NXSIG_CONV_SAME: out_len = n1; start = (full - out_len) / 2; break;
+    case NXSIG_CONV_VALID: out_len = (n1 >= n2 ? n1 - n2 : n2 - n1) + 1; start = (full - out_len) / 2; break;
+    default: return set_error(NXSIG_ERR_INVALID_ARG, "expected mode to be one of [:full, :same, :valid]");
+  }
+  if (mem == NXSIG_DEVICE)
+    return launch_fftconvolve_c64(c, reinterpret_cast<const float2*>(a), n1, reinterpret_cast<const float2*>(b), n2, start, out_len,
+                                  reinterpret_cast<float2*>(out));
+  Staged st(c);
+  const void *ad = nullptr, *bd = nullptr;
+  void* od = nullptr;
+  if ((rc = st.in(1, a, (size_t)n1 * sizeof(float2), &ad))) return rc;
+  if ((rc = st.in(2, b, (size_t)n2 * sizeof(float2), &bd))) return rc;
+  if ((rc = ctx_scratch(c, 3, (size_t)(out_len > 8192 ? out_len : 8192) * sizeof(float2), &od))) return rc;
+  if ((rc = launch_fftconvolve_c64(c, reinterpret_cast<const float2*>(ad), n1, reinterpret_cast<const float2*>(bd), n2, start, out_len,
+                                   reinterpret_cast<float2*>(od)))) return rc;
+  return st.out_copy(out, od, (size_t)out_len * sizeof(float2));
+  NXSIG_API_END
+}
+
 }  // extern "C"

@@ -432,6 +432,12 @@ __global__ __launch_bounds__(kThreads) void k_fir_os(FirArgs a) {
   }
 }
 
+// pointwise complex product a[i] *= b[i] (the `Nx.multiply(sp1, sp2)` of convolution.ex:282)
+__global__ __launch_bounds__(kThreads) void k_cmul_inplace(float2* __restrict__ a, const float2* __restrict__ b, int n) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) a[i] = cmul(a[i], b[i]);
+}
+
 // ========================================================================================== launchers
 static int ilog2(int v) {
   int l = 0;
@@ -684,6 +690,29 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
   dim3 grid((unsigned)blocks, (unsigned)s.batch);
   hipLaunchKernelGGL(k_istft_edge_fix, grid, dim3(kThreads), 0, c->stream, a);
   NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+// complex 1-D fftconvolve through the row-FFT kernels; a, b, out are device pointers
+int launch_fftconvolve_c64(Ctx* c, const float2* a, int64_t n1, const float2* b, int64_t n2, int64_t start, int64_t len,
+                           float2* out) {
+  const int64_t full = n1 + n2 - 1;
+  int P = 1;
+  while (P < full) P <<= 1;
+  if (P > kMaxLdsPow2)
+    return set_error(NXSIG_ERR_UNSUPPORTED, "fftconvolve (complex): n1 + n2 - 1 > 8192 is not supported yet");
+  void* sc = nullptr;
+  int rc = ctx_scratch(c, 0, (size_t)3 * P * sizeof(float2), &sc);
+  if (rc) return rc;
+  float2* A = reinterpret_cast<float2*>(sc);
+  float2* B = A + P;
+  float2* C = B + P;
+  if ((rc = launch_fft(c, a, false, 1, (int32_t)n1, P, false, A))) return rc;
+  if ((rc = launch_fft(c, b, false, 1, (int32_t)n2, P, false, B))) return rc;
+  hipLaunchKernelGGL(k_cmul_inplace, dim3((P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, A, B, P);
+  NXSIG_HIP_TRY(hipGetLastError());
+  if ((rc = launch_fft(c, A, false, 1, P, P, true, C))) return rc;
+  NXSIG_HIP_TRY(hipMemcpyAsync(out, C + start, (size_t)len * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
   return NXSIG_OK;
 }
 

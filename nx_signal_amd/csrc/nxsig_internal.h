@@ -127,5 +127,7 @@ struct FirLaunch {
   float* y;                    // device f32[batch][out_len]
 };
 int launch_fir(Ctx* c, const FirLaunch& a);
+int launch_fftconvolve_c64(Ctx* c, const float2* a, int64_t n1, const float2* b, int64_t n2, int64_t start, int64_t len,
+                           float2* out);
 
 }  // namespace nxsig

@@ -99,6 +99,25 @@ def test_fftconvolve_golden(golden):
         assert nx_all_close(got, exp, 1e-4, 1e-4), (v["src"], got)
 
 
+def test_fftconvolve_complex_golden_and_oracle(golden):
+    for v in golden["fftconvolve_complex"]:
+        a = np.array([complex(*c) for c in v["a"]], dtype=np.complex64)
+        b = np.array([complex(*c) for c in v["b"]], dtype=np.complex64)
+        got = S.convolution.convolve(a, b, method="fft", mode=v["mode"])
+        assert got.dtype == np.complex64
+        assert nx_all_close(got, np.array([complex(*c) for c in v["expect"]]), v["atol"], v["rtol"]), v["src"]
+    rng = np.random.default_rng(12)
+    for n1, n2 in [(3, 3), (100, 9), (9, 100), (4000, 4000), (1, 7)]:
+        a = (rng.standard_normal(n1) + 1j * rng.standard_normal(n1)).astype(np.complex64)
+        b = (rng.standard_normal(n2) + 1j * rng.standard_normal(n2)).astype(np.complex64)
+        for mode in ("full", "same", "valid"):
+            got = S.convolution.fftconvolve(a, b, mode=mode)
+            exp = O.fftconvolve(a, b, mode=mode)
+            assert_close(got, exp, f"complex {n1}x{n2} {mode}")
+    mixed = S.convolution.fftconvolve(np.array([1, 2, 3], np.float32), np.array([1j, 2, 3], np.complex64))
+    assert mixed.dtype == np.complex64  # "don't complexify" only when both are real (convolutions_test.exs:392-416)
+
+
 def test_fft_rows_golden(golden):
     for v in golden["fft_rows"]:
         z = S.transforms.fft_nd(np.array(v["x"]), axes=[-1], lengths=[v["length"]])

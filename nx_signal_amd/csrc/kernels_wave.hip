@@ -737,15 +737,14 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
 
   const size_t lds = (size_t)KOUT * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (MODE == kModeReal2x ? (size_t)C * 8 : 0) +
                      (size_t)W * XCH * 8;
-  // contiguous chunk of work units per workgroup: input halos are re-read only at chunk seams
-  const int units_per_cu = env_int("NXSIG_WAVE_UNITS_PER_CU", MODE == kModeReal2x ? 192 : 96);  // workgroups x W per CU (oversubscription for balance)
-  int64_t max_blocks = ((int64_t)c->num_cus * units_per_cu + W - 1) / W;
-  int64_t want = (a.total_pairs + W - 1) / W;
-  int64_t blocks = want < max_blocks ? want : max_blocks;
-  if (blocks < 1) blocks = 1;
-  a.chunk = (a.total_pairs + blocks - 1) / blocks;
-  a.chunk = ((a.chunk + W - 1) / W) * W;
-  blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
+  // Work distribution: each workgroup takes a SHORT contiguous chunk (a few units per wave) and the hardware
+  // dispatcher hands chunks out in order.  Many short-lived workgroups balance the load across CUs / XCDs
+  // dynamically: measured +12 % over a static equal partition with long-lived workgroups (the slowest CU set
+  // the kernel time), at the price of re-loading the 12 KB of tables per workgroup from L2.
+  const int units_per_wave = env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModeReal2x ? 8 : 2);  // measured optima
+  a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
+  int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
+  if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
   // streaming case: no padding and every existing frame reads its fft_length samples inside the signal
   const bool streaming = s.fr.reflect == 0 && s.fr.lo == 0 && ((s.fr.M - 1) * (int64_t)s.fr.hop + KOUT <= s.fr.L);
   const bool scale = s.has_scale != 0;
@@ -973,14 +972,10 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
     if (units_per_row <= 0) return NXSIG_OK;
     a.units_per_row = units_per_row;
     a.total_units = units_per_row * s.batch;
-    const int units_per_cu = env_int("NXSIG_FIR_UNITS_PER_CU", 96);
-    int64_t max_blocks = ((int64_t)c->num_cus * units_per_cu + W - 1) / W;
-    int64_t want = (a.total_units + W - 1) / W;
-    int64_t blocks = want < max_blocks ? want : max_blocks;
-    if (blocks < 1) blocks = 1;
-    a.chunk = (a.total_units + blocks - 1) / blocks;
-    a.chunk = ((a.chunk + W - 1) / W) * W;
-    blocks = (a.total_units + a.chunk - 1) / a.chunk;
+    const int units_per_wave = env_int("NXSIG_FIR_UNITS_PER_WAVE", 16);  // short chunks, many workgroups (see launch_wave)
+    a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
+    const int64_t blocks = (a.total_units + a.chunk - 1) / a.chunk;
+    if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: signal too long for one launch");
     if (lds > 64 * 1024) {
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_wave<K, true, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_wave<K, false, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

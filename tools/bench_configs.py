@@ -18,7 +18,7 @@ from nx_signal_amd import _lib  # noqa: E402
 PEAK = 8000.0
 
 
-def timeit(ctx, fn, reps=20, warm=3):
+def timeit(ctx, fn, reps=30, warm=20):
     for _ in range(warm):
         fn()
     ctx.sync()

@@ -28,6 +28,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 enum : int {
   kModePair = 0,    // two adjacent real frames of length C as re / im          (fft_length == C)
   kModeReal2x = 1,  // ONE real frame of length 2C as even / odd samples        (fft_length == 2C)
+  kModeQuad = 2,    // FOUR adjacent real frames of length C/2: z[2n] = a[n] + i b[n], z[2n+1] = d[n] + i e[n], so that
+                    // Z[k] = C[k] + w_C^k F[k]; C and F separate lane-locally (k and k + C/2 share a lane)  (fft_length == C/2)
 };
 
 __device__ __forceinline__ v2f wcmul(v2f a, v2f b) { return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   constexpr int B12 = P / 16;   // radix-16 butterflies per lane in passes A and B
   constexpr int NQ = K / 128;   // bins per lane per parity
   constexpr int XCH = K + K / 16 + 16;  // padded exchange buffer, complex elements (keeps 16-B alignment)
-  constexpr int KOUT = MODE == kModeReal2x ? 2 * K : K;  // fft_length = bins per frame
+  constexpr int KOUT = MODE == kModeReal2x ? 2 * K : (MODE == kModeQuad ? K / 2 : K);  // fft_length = bins per frame
   constexpr int kWavesPerBlock = W;
   constexpr int kWaveThreads = 64 * W;
 
@@ -298,13 +300,15 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   v2f* s_twB = reinterpret_cast<v2f*>(s_w + KOUT);
   v2f* s_twC = s_twB + 256;
   v2f* s_twR = s_twC + R3 * 256;
-  v2f* s_x = s_twR + (MODE == kModeReal2x ? K : 0);
+  v2f* s_x = s_twR + (MODE == kModeReal2x ? K : (MODE == kModeQuad ? K / 2 : 0));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < KOUT; i += kWaveThreads) s_w[i] = a.wtab[i];
   for (int i = tid; i < 256; i += kWaveThreads) s_twB[i] = a.twB[i];
   for (int i = tid; i < R3 * 256; i += kWaveThreads) s_twC[i] = a.twC[i];
   if (MODE == kModeReal2x)
     for (int i = tid; i < K; i += kWaveThreads) s_twR[i] = a.twR[i];
+  if (MODE == kModeQuad)
+    for (int i = tid; i < K / 2; i += kWaveThreads) s_twR[i] = a.twR[i];  // conj(w_K^k), k < K/2
   __syncthreads();  // the only workgroup barrier: tables are read-only afterwards
   v2f* xb = s_x + wave * XCH;
 
@@ -325,10 +329,17 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
       const float* pb = pa + ((mA + 1 < a.M) ? a.hop : 0);  // phantom frame B of an odd tail: reload A, never stored
 #pragma unroll
       for (int s = 0; s < P; ++s) { ra[s] = pa[64 * s]; rb[s] = pb[64 * s]; }
-    } else {  // complex point n = (x[2n], x[2n+1])
+    } else if (MODE == kModeReal2x) {  // complex point n = (x[2n], x[2n+1])
       const float* pa = a.x + (size_t)row * a.batch_stride + pin * a.hop + 2 * lane;
 #pragma unroll
       for (int s = 0; s < P; ++s) { ra[s] = pa[128 * s]; rb[s] = pa[128 * s + 1]; }
+    } else {  // quad: even lanes carry frames (m0, m0+1), odd lanes (m0+2, m0+3); core point lane + 64 s = 2 n + par
+      const int64_t fa = pin * 4 + 2 * (lane & 1), fb = fa + 1, last = a.M - 1;
+      const float* base = a.x + (size_t)row * a.batch_stride + (lane >> 1);
+      const float* pa = base + (fa < last ? fa : last) * a.hop;  // phantom frames of a ragged tail: reload, never stored
+      const float* pb = base + (fb < last ? fb : last) * a.hop;
+#pragma unroll
+      for (int s = 0; s < P; ++s) { ra[s] = pa[32 * s]; rb[s] = pb[32 * s]; }
     }
   };
   auto window_mul = [&](v2f* d) {
@@ -337,9 +348,12 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
       if (MODE == kModePair) {
         const float w = s_w[lane + 64 * s];
         d[s] = v2f{ra[s] * w, rb[s] * w};
-      } else {
+      } else if (MODE == kModeReal2x) {
         const v2f w = *reinterpret_cast<const v2f*>(&s_w[2 * (lane + 64 * s)]);
         d[s] = v2f{ra[s] * w.x, rb[s] * w.y};
+      } else {
+        const float w = s_w[(lane >> 1) + 32 * s];
+        d[s] = v2f{ra[s] * w, rb[s] * w};
       }
     }
   };
@@ -359,8 +373,8 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   }
 
   for (int64_t pr = p_begin + wave; pr < p_end; pr += kWavesPerBlock) {
-    const int64_t mA = MODE == kModePair ? pin * 2 : pin, mB = mA + 1;
-    const bool haveB = MODE == kModePair ? (mB < a.M) : true;
+    const int64_t mA = MODE == kModePair ? pin * 2 : (MODE == kModeQuad ? pin * 4 : pin), mB = mA + 1;
+    const bool haveB = MODE == kModeReal2x ? true : (mB < a.M);
     const int64_t crow = row;
     if (!GENERAL) {
       // unconditional prefetch (the last iteration harmlessly re-reads its own unit) keeps the loop branch-free
@@ -378,10 +392,17 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
           const float va = (n < a.N) ? fetch_any(xr, a, qA + n) : 0.0f;
           const float vb = (haveB && n < a.N) ? fetch_any(xr, a, qB + n) : 0.0f;
           d[s] = v2f{va * w, vb * w};
-        } else {
+        } else if (MODE == kModeReal2x) {
           const float va = (2 * n < a.N) ? fetch_any(xr, a, qA + 2 * n) : 0.0f;
           const float vb = (2 * n + 1 < a.N) ? fetch_any(xr, a, qA + 2 * n + 1) : 0.0f;
           d[s] = v2f{va * s_w[2 * n], vb * s_w[2 * n + 1]};
+        } else {
+          const int nn = (lane >> 1) + 32 * s;                    // sample index inside the 512-sample frames
+          const int64_t fa = mA + 2 * (lane & 1), fb = fa + 1;   // even lanes: frames m0, m0+1; odd lanes: m0+2, m0+3
+          const float w = s_w[nn];
+          const float va = (fa < a.M && nn < a.N) ? fetch_any(xr, a, fa * a.hop + nn) : 0.0f;
+          const float vb = (fb < a.M && nn < a.N) ? fetch_any(xr, a, fb * a.hop + nn) : 0.0f;
+          d[s] = v2f{va * w, vb * w};
         }
       }
     }
@@ -397,6 +418,45 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
 
     // ---- Hermitian untangle through partner lanes + store
     const int src0 = ((64 - lane) & 63) << 2, src1 = (63 - lane) << 2;
+    if (MODE == kModeQuad) {
+      constexpr int HQ = NQ / 2;  // bins per lane per parity of the half-length spectra
+      // C[k] = (Z[k] + Z[k + K/2]) / 2 , F[k] = (Z[k] - Z[k + K/2]) / 2 * conj(w_K^k) ; k = 2 lane + par + 128 q, q < HQ
+      v2f cc[2][HQ], ff[2][HQ];
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) {
+        const v4f t = *reinterpret_cast<const v4f*>(&s_twR[2 * lane + 128 * q]);
+        cc[0][q] = (zz[0][q] + zz[0][q + HQ]) * 0.5f;
+        cc[1][q] = (zz[1][q] + zz[1][q + HQ]) * 0.5f;
+        ff[0][q] = wcmul((zz[0][q] - zz[0][q + HQ]) * 0.5f, v2f{t.x, t.y});
+        ff[1][q] = wcmul((zz[1][q] - zz[1][q + HQ]) * 0.5f, v2f{t.z, t.w});
+      }
+      v2f* z0 = a.z + ((size_t)crow * a.M + mA) * KOUT + 2 * lane;
+      v2f* dm = a.dummy + 2 * lane;
+      v2f* zf[4] = {z0, (mA + 1 < a.M) ? z0 + KOUT : dm, (mA + 2 < a.M) ? z0 + 2 * KOUT : dm, (mA + 3 < a.M) ? z0 + 3 * KOUT : dm};
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // h = 0: C -> frames m0, m0+1 ; h = 1: F -> frames m0+2, m0+3
+          v2f (*sp)[HQ] = h == 0 ? cc : ff;
+          const v2f own0 = sp[0][(HQ - q) % HQ];
+          v2f p0, p1;
+          p0.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(sp[0][HQ - 1 - q].x)));
+          p0.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(sp[0][HQ - 1 - q].y)));
+          p1.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(sp[1][HQ - 1 - q].x)));
+          p1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(sp[1][HQ - 1 - q].y)));
+          if (lane == 0) p0 = own0;
+          const v2f z0v = sp[0][q], z1v = sp[1][q];
+          v4f xa = v4f{z0v.x + p0.x, z0v.y - p0.y, z1v.x + p1.x, z1v.y - p1.y} * 0.5f;
+          v4f xbv = v4f{z0v.y + p0.y, p0.x - z0v.x, z1v.y + p1.y, p1.x - z1v.x} * 0.5f;
+          if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }
+          __builtin_nontemporal_store(xa, (gv4f*)(zf[2 * h] + 128 * q));
+          __builtin_nontemporal_store(xbv, (gv4f*)(zf[2 * h + 1] + 128 * q));
+        }
+      }
+      row = nrow; pin = npin;
+      advance(nrow, npin);
+      continue;
+    }
     v2f* zA = a.z + ((size_t)crow * a.M + mA) * KOUT + 2 * lane;
     v2f* zB = (GENERAL || haveB) ? zA + K : a.dummy + 2 * lane;  // pair: frame B; real-2x: bins K..2K-1
 #pragma unroll
@@ -716,11 +776,11 @@ template <int C, int MODE, int W>
 static int launch_wave(Ctx* c, const StftLaunch& s) {
   constexpr int R3 = C / 256;
   constexpr int XCH = C + C / 16 + 16;
-  constexpr int KOUT = MODE == kModeReal2x ? 2 * C : C;
+  constexpr int KOUT = MODE == kModeReal2x ? 2 * C : (MODE == kModeQuad ? C / 2 : C);
   WaveArgs a;
   a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
   a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
-  a.pairs_per_row = MODE == kModePair ? (s.fr.M + 1) / 2 : s.fr.M;
+  a.pairs_per_row = MODE == kModePair ? (s.fr.M + 1) / 2 : (MODE == kModeQuad ? (s.fr.M + 3) / 4 : s.fr.M);
   a.total_pairs = a.pairs_per_row * s.batch;
   a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
 
@@ -729,19 +789,20 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
   Ctx::WaveTables& wt = c->wave_tables[C];
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
-  a.twR = reinterpret_cast<const v2f*>(wt.twI);
+  a.twR = reinterpret_cast<const v2f*>(MODE == kModeQuad ? wt.twQ : wt.twI);
   a.wtab = s.window_padK;
   void* dummy = nullptr;
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);
 
-  const size_t lds = (size_t)KOUT * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (MODE == kModeReal2x ? (size_t)C * 8 : 0) +
+  const size_t lds = (size_t)KOUT * 4 + 256 * 8 + (size_t)R3 * 256 * 8 +
+                     (MODE == kModeReal2x ? (size_t)C * 8 : (MODE == kModeQuad ? (size_t)C * 4 : 0)) +
                      (size_t)W * XCH * 8;
   // Work distribution: each workgroup takes a SHORT contiguous chunk (a few units per wave) and the hardware
   // dispatcher hands chunks out in order.  Many short-lived workgroups balance the load across CUs / XCDs
   // dynamically: measured +12 % over a static equal partition with long-lived workgroups (the slowest CU set
   // the kernel time), at the price of re-loading the 12 KB of tables per workgroup from L2.
-  const int units_per_wave = env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModeReal2x ? 8 : 2);  // measured optima
+  const int units_per_wave = env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : 8);  // measured optima
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
@@ -772,6 +833,10 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
     if (w == 16) return launch_wave<1024, kModePair, 16>(c, s);
     if (w == 8) return launch_wave<1024, kModePair, 8>(c, s);
     return launch_wave<1024, kModePair, 4>(c, s);
+  }
+  if (s.K == 512) {  // four frames interleaved into one 1024-point complex FFT
+    *handled = true;
+    return launch_wave<1024, kModeQuad, 4>(c, s);
   }
   if (s.K == 2048) {  // one frame as even/odd samples of a 1024-point complex FFT
     *handled = true;
@@ -862,6 +927,15 @@ static int ensure_wave_tables_1024(Ctx* c) {
   if (rc) { wt.twB = nullptr; return rc; }
   rc = ctx_table(c, 0x7744ull ^ (uint64_t)C, twR.data(), twR.size() * sizeof(float2), &wt.twI);
   if (rc) { wt.twB = nullptr; return rc; }
+  {  // quad front-end: conj(w_C^k), k < C/2
+    std::vector<float2> twQ((size_t)C / 2);
+    for (int k = 0; k < C / 2; ++k) {
+      const double ang = two_pi * (double)k / (double)C;
+      twQ[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    rc = ctx_table(c, 0x7747ull ^ (uint64_t)C, twQ.data(), twQ.size() * sizeof(float2), &wt.twQ);
+    if (rc) { wt.twB = nullptr; return rc; }
+  }
   for (auto& t : twB) t.y = -t.y;  // conjugated copies for the inverse transform
   for (auto& t : twC) t.y = -t.y;
   rc = ctx_table(c, 0x7745ull, twB.data(), twB.size() * sizeof(float2), &wt.twBi);

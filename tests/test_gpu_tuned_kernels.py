@@ -24,6 +24,13 @@ def nerr(got, ref):
     (1024, 1024, 333, 1024 + 333 * 40 + 5, 2),   # hop not a multiple of anything, ragged tail dropped (:valid)
     (1024, 1000, 250, 20000, 2),                 # N < K: zero-padded frames (general path: reads must stop at N)
     (1024, 1500, 500, 20000, 1),                 # N > K: truncated frames
+    (512, 512, 128, 512 + 128 * 8, 3),           # quad front-end: M = 9 (M % 4 == 1): three phantom frames per row
+    (512, 512, 128, 512 + 128 * 9, 2),           # M % 4 == 2
+    (512, 512, 128, 512 + 128 * 10, 2),          # M % 4 == 3
+    (512, 512, 128, 512 + 128 * 11, 2),          # M % 4 == 0
+    (512, 512, 160, 40000, 2),                   # speech-style hop
+    (512, 400, 160, 16000, 1),                   # N = 400 < K = 512 (25 ms frames at 16 kHz): general path
+    (512, 512, 128, 512, 1),                     # a lone frame
     (2048, 2048, 512, 2048 + 512 * 9, 3),        # real-2x front-end, odd M, 3 rows
     (2048, 2048, 511, 50000, 1),                 # odd hop: unaligned 4-byte loads
     (2048, 1024, 256, 30000, 2),                 # N < K on the real-2x front-end
@@ -51,7 +58,7 @@ def test_stft_wave_chunk_seams_many_rows():
 
 
 @pytest.mark.parametrize("pad", ["reflect", "same", [(100, 900)], [(-3, 50)]])
-@pytest.mark.parametrize("K", [1024, 2048])
+@pytest.mark.parametrize("K", [512, 1024, 2048])
 def test_stft_wave_general_padding(pad, K):
     rng = np.random.default_rng(5 + K)
     x = rng.standard_normal((2, 9000)).astype(np.float32)

@@ -67,6 +67,12 @@ def main():
     if "stft2048" in which:
         # config 4 per-GPU shard: 8 channels x 10 min @ 48 kHz would be 7.4 GB of output; use 8 ch x 150 s (1.8 GB out)
         stft_case(ctx, 2048, 512, 7200000, 8, "stft N=2048 hop=512, 8 ch x 150 s (config 4 shard, shortened)")
+    for name in which:
+        if name.startswith("gen"):  # e.g. gen512: generic-kernel sizes, ~1.7 GB of output each
+            n = int(name[3:])
+            b = 16
+            Lg = (1700 * 1024 * 1024 // (b * 8 * 4)) // n * n  # hop = n/4 -> 8n bytes out per hop samples
+            stft_case(ctx, n, n // 4, Lg, b, f"stft N={n} hop={n // 4}, {b} rows (generic kernels unless tuned)")
     if "istft" in which:
         N, hop, L, batch = 1024, 256, 2880000, 16
         w = S.windows.hann(N)

@@ -28,8 +28,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 enum : int {
   kModePair = 0,    // two adjacent real frames of length C as re / im          (fft_length == C)
   kModeReal2x = 1,  // ONE real frame of length 2C as even / odd samples        (fft_length == 2C)
-  kModeQuad = 2,    // FOUR adjacent real frames of length C/2: z[2n] = a[n] + i b[n], z[2n+1] = d[n] + i e[n], so that
-                    // Z[k] = C[k] + w_C^k F[k]; C and F separate lane-locally (k and k + C/2 share a lane)  (fft_length == C/2)
+  kModeQuad = 2,    // 2J adjacent real frames of length C/J (J = 2, 4, 8): J complex sequences c_j = frame 2j + i frame 2j+1
+                    // are interleaved, z[J n + j] = c_j[n], so Z[k0 + (C/J) m] = sum_j w_J^(jm) w_C^(j k0) C_j[k0]; the J values
+                    // k0 + (C/J) m share a lane, so the C_j separate with a lane-local inverse radix-J butterfly  (fft_length == C/J)
 };
 
 __device__ __forceinline__ v2f wcmul(v2f a, v2f b) { return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -284,14 +285,15 @@ typedef __attribute__((address_space(1))) v4f gv4f;  // explicit global address 
 // GENERAL = false: :valid framing with every existing frame fully inside the signal (the streaming case);
 // GENERAL = true : any padding mode / ragged tail, per-sample bounds and mirror math.  SCALE: :spectrum / :psd.
 // W = waves per workgroup (tables in LDS are shared by the W waves; waves never synchronise with each other).
-template <int K, int MODE, bool GENERAL, bool SCALE, int W>
+template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2>
 __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   constexpr int P = K / 64;     // complex points per lane
   constexpr int R3 = K / 256;   // last radix: 4 or 8
   constexpr int B12 = P / 16;   // radix-16 butterflies per lane in passes A and B
   constexpr int NQ = K / 128;   // bins per lane per parity
   constexpr int XCH = K + K / 16 + 16;  // padded exchange buffer, complex elements (keeps 16-B alignment)
-  constexpr int KOUT = MODE == kModeReal2x ? 2 * K : (MODE == kModeQuad ? K / 2 : K);  // fft_length = bins per frame
+  constexpr int KOUT = MODE == kModeReal2x ? 2 * K : (MODE == kModeQuad ? K / J : K);  // fft_length = bins per frame
+  constexpr int TWQ = (J - 1) * (K / J);  // quad-mode separation twiddles conj(w_K^(j k0)), j = 1..J-1
   constexpr int kWavesPerBlock = W;
   constexpr int kWaveThreads = 64 * W;
 
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   v2f* s_twB = reinterpret_cast<v2f*>(s_w + KOUT);
   v2f* s_twC = s_twB + 256;
   v2f* s_twR = s_twC + R3 * 256;
-  v2f* s_x = s_twR + (MODE == kModeReal2x ? K : (MODE == kModeQuad ? K / 2 : 0));
+  v2f* s_x = s_twR + (MODE == kModeReal2x ? K : (MODE == kModeQuad ? TWQ : 0));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < KOUT; i += kWaveThreads) s_w[i] = a.wtab[i];
   for (int i = tid; i < 256; i += kWaveThreads) s_twB[i] = a.twB[i];
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   if (MODE == kModeReal2x)
     for (int i = tid; i < K; i += kWaveThreads) s_twR[i] = a.twR[i];
   if (MODE == kModeQuad)
-    for (int i = tid; i < K / 2; i += kWaveThreads) s_twR[i] = a.twR[i];  // conj(w_K^k), k < K/2
+    for (int i = tid; i < TWQ; i += kWaveThreads) s_twR[i] = a.twR[i];  // [j-1][k0] = conj(w_K^(j k0))
   __syncthreads();  // the only workgroup barrier: tables are read-only afterwards
   v2f* xb = s_x + wave * XCH;
 
@@ -333,13 +335,13 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
       const float* pa = a.x + (size_t)row * a.batch_stride + pin * a.hop + 2 * lane;
 #pragma unroll
       for (int s = 0; s < P; ++s) { ra[s] = pa[128 * s]; rb[s] = pa[128 * s + 1]; }
-    } else {  // quad: even lanes carry frames (m0, m0+1), odd lanes (m0+2, m0+3); core point lane + 64 s = 2 n + par
-      const int64_t fa = pin * 4 + 2 * (lane & 1), fb = fa + 1, last = a.M - 1;
-      const float* base = a.x + (size_t)row * a.batch_stride + (lane >> 1);
+    } else {  // quad: lane carries sequence j = lane % J = frames (m0 + 2j, m0 + 2j + 1); core point lane + 64 s = J n + j
+      const int64_t fa = pin * (2 * J) + 2 * (lane % J), fb = fa + 1, last = a.M - 1;
+      const float* base = a.x + (size_t)row * a.batch_stride + (lane / J);
       const float* pa = base + (fa < last ? fa : last) * a.hop;  // phantom frames of a ragged tail: reload, never stored
       const float* pb = base + (fb < last ? fb : last) * a.hop;
 #pragma unroll
-      for (int s = 0; s < P; ++s) { ra[s] = pa[32 * s]; rb[s] = pb[32 * s]; }
+      for (int s = 0; s < P; ++s) { ra[s] = pa[(64 / J) * s]; rb[s] = pb[(64 / J) * s]; }
     }
   };
   auto window_mul = [&](v2f* d) {
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
         const v2f w = *reinterpret_cast<const v2f*>(&s_w[2 * (lane + 64 * s)]);
         d[s] = v2f{ra[s] * w.x, rb[s] * w.y};
       } else {
-        const float w = s_w[(lane >> 1) + 32 * s];
+        const float w = s_w[(lane / J) + (64 / J) * s];
         d[s] = v2f{ra[s] * w, rb[s] * w};
       }
     }
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   }
 
   for (int64_t pr = p_begin + wave; pr < p_end; pr += kWavesPerBlock) {
-    const int64_t mA = MODE == kModePair ? pin * 2 : (MODE == kModeQuad ? pin * 4 : pin), mB = mA + 1;
+    const int64_t mA = MODE == kModePair ? pin * 2 : (MODE == kModeQuad ? pin * (2 * J) : pin), mB = mA + 1;
     const bool haveB = MODE == kModeReal2x ? true : (mB < a.M);
     const int64_t crow = row;
     if (!GENERAL) {
@@ -397,8 +399,8 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
           const float vb = (2 * n + 1 < a.N) ? fetch_any(xr, a, qA + 2 * n + 1) : 0.0f;
           d[s] = v2f{va * s_w[2 * n], vb * s_w[2 * n + 1]};
         } else {
-          const int nn = (lane >> 1) + 32 * s;                    // sample index inside the 512-sample frames
-          const int64_t fa = mA + 2 * (lane & 1), fb = fa + 1;   // even lanes: frames m0, m0+1; odd lanes: m0+2, m0+3
+          const int nn = (lane / J) + (64 / J) * s;               // sample index inside the K/J-sample frames
+          const int64_t fa = mA + 2 * (lane % J), fb = fa + 1;   // lane % J selects the frame pair
           const float w = s_w[nn];
           const float va = (fa < a.M && nn < a.N) ? fetch_any(xr, a, fa * a.hop + nn) : 0.0f;
           const float vb = (fb < a.M && nn < a.N) ? fetch_any(xr, a, fb * a.hop + nn) : 0.0f;
@@ -419,38 +421,47 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
     // ---- Hermitian untangle through partner lanes + store
     const int src0 = ((64 - lane) & 63) << 2, src1 = (63 - lane) << 2;
     if (MODE == kModeQuad) {
-      constexpr int HQ = NQ / 2;  // bins per lane per parity of the half-length spectra
-      // C[k] = (Z[k] + Z[k + K/2]) / 2 , F[k] = (Z[k] - Z[k + K/2]) / 2 * conj(w_K^k) ; k = 2 lane + par + 128 q, q < HQ
-      v2f cc[2][HQ], ff[2][HQ];
+      constexpr int HQ = NQ / J;  // bins per lane per parity of the short spectra
+      // C_j[k0] = conj(w_K^(j k0)) / J * sum_m Z[k0 + (K/J) m] conj(w_J^(jm)),  k0 = 2 lane + par + 128 q, q < HQ
+      v2f cs[J][2][HQ];
 #pragma unroll
-      for (int q = 0; q < HQ; ++q) {
-        const v4f t = *reinterpret_cast<const v4f*>(&s_twR[2 * lane + 128 * q]);
-        cc[0][q] = (zz[0][q] + zz[0][q + HQ]) * 0.5f;
-        cc[1][q] = (zz[1][q] + zz[1][q + HQ]) * 0.5f;
-        ff[0][q] = wcmul((zz[0][q] - zz[0][q + HQ]) * 0.5f, v2f{t.x, t.y});
-        ff[1][q] = wcmul((zz[1][q] - zz[1][q + HQ]) * 0.5f, v2f{t.z, t.w});
-      }
+      for (int q = 0; q < HQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          v2f u[J];
+#pragma unroll
+          for (int m = 0; m < J; ++m) u[m] = zz[e][q + HQ * m];
+          if (J == 2) { const v2f s0 = u[0] + u[1], s1 = u[0] - u[1]; u[0] = s0; u[1] = s1; }
+          else if (J == 4) dft4<true>(u[0], u[1], u[2], u[3]);
+          else dft8<true>(u);
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            v2f v = u[j] * (1.0f / (float)J);
+            if (j > 0) v = wcmul(v, s_twR[(j - 1) * (K / J) + 2 * lane + e + 128 * q]);
+            cs[j][e][q] = v;
+          }
+        }
       v2f* z0 = a.z + ((size_t)crow * a.M + mA) * KOUT + 2 * lane;
       v2f* dm = a.dummy + 2 * lane;
-      v2f* zf[4] = {z0, (mA + 1 < a.M) ? z0 + KOUT : dm, (mA + 2 < a.M) ? z0 + 2 * KOUT : dm, (mA + 3 < a.M) ? z0 + 3 * KOUT : dm};
 #pragma unroll
-      for (int q = 0; q < HQ; ++q) {
+      for (int j = 0; j < J; ++j) {
+        v2f* zfa = (mA + 2 * j < a.M) ? z0 + (size_t)(2 * j) * KOUT : dm;      // frame m0 + 2j      (real part of c_j)
+        v2f* zfb = (mA + 2 * j + 1 < a.M) ? z0 + (size_t)(2 * j + 1) * KOUT : dm;  // frame m0 + 2j + 1 (imaginary part)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {  // h = 0: C -> frames m0, m0+1 ; h = 1: F -> frames m0+2, m0+3
-          v2f (*sp)[HQ] = h == 0 ? cc : ff;
-          const v2f own0 = sp[0][(HQ - q) % HQ];
+        for (int q = 0; q < HQ; ++q) {
+          const v2f own0 = cs[j][0][(HQ - q) % HQ];
           v2f p0, p1;
-          p0.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(sp[0][HQ - 1 - q].x)));
-          p0.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(sp[0][HQ - 1 - q].y)));
-          p1.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(sp[1][HQ - 1 - q].x)));
-          p1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(sp[1][HQ - 1 - q].y)));
+          p0.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(cs[j][0][HQ - 1 - q].x)));
+          p0.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(cs[j][0][HQ - 1 - q].y)));
+          p1.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(cs[j][1][HQ - 1 - q].x)));
+          p1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(cs[j][1][HQ - 1 - q].y)));
           if (lane == 0) p0 = own0;
-          const v2f z0v = sp[0][q], z1v = sp[1][q];
+          const v2f z0v = cs[j][0][q], z1v = cs[j][1][q];
           v4f xa = v4f{z0v.x + p0.x, z0v.y - p0.y, z1v.x + p1.x, z1v.y - p1.y} * 0.5f;
           v4f xbv = v4f{z0v.y + p0.y, p0.x - z0v.x, z1v.y + p1.y, p1.x - z1v.x} * 0.5f;
           if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }
-          __builtin_nontemporal_store(xa, (gv4f*)(zf[2 * h] + 128 * q));
-          __builtin_nontemporal_store(xbv, (gv4f*)(zf[2 * h + 1] + 128 * q));
+          __builtin_nontemporal_store(xa, (gv4f*)(zfa + 128 * q));
+          __builtin_nontemporal_store(xbv, (gv4f*)(zfb + 128 * q));
         }
       }
       row = nrow; pin = npin;
@@ -772,15 +783,16 @@ static int env_int(const char* name, int dflt) {
 static int ensure_wave_tables_1024(Ctx* c);
 
 // C = complex core size (1024 here), MODE = front-end, W = waves per workgroup
-template <int C, int MODE, int W>
+template <int C, int MODE, int W, int J = 2>
 static int launch_wave(Ctx* c, const StftLaunch& s) {
   constexpr int R3 = C / 256;
   constexpr int XCH = C + C / 16 + 16;
-  constexpr int KOUT = MODE == kModeReal2x ? 2 * C : (MODE == kModeQuad ? C / 2 : C);
+  constexpr int KOUT = MODE == kModeReal2x ? 2 * C : (MODE == kModeQuad ? C / J : C);
+  constexpr int TWQ = (J - 1) * (C / J);
   WaveArgs a;
   a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
   a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
-  a.pairs_per_row = MODE == kModePair ? (s.fr.M + 1) / 2 : (MODE == kModeQuad ? (s.fr.M + 3) / 4 : s.fr.M);
+  a.pairs_per_row = MODE == kModePair ? (s.fr.M + 1) / 2 : (MODE == kModeQuad ? (s.fr.M + 2 * J - 1) / (2 * J) : s.fr.M);
   a.total_pairs = a.pairs_per_row * s.batch;
   a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
 
@@ -789,14 +801,14 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
   Ctx::WaveTables& wt = c->wave_tables[C];
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
-  a.twR = reinterpret_cast<const v2f*>(MODE == kModeQuad ? wt.twQ : wt.twI);
+  a.twR = reinterpret_cast<const v2f*>(MODE == kModeQuad ? wt.twQ[J == 2 ? 0 : (J == 4 ? 1 : 2)] : wt.twI);
   a.wtab = s.window_padK;
   void* dummy = nullptr;
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);
 
   const size_t lds = (size_t)KOUT * 4 + 256 * 8 + (size_t)R3 * 256 * 8 +
-                     (MODE == kModeReal2x ? (size_t)C * 8 : (MODE == kModeQuad ? (size_t)C * 4 : 0)) +
+                     (MODE == kModeReal2x ? (size_t)C * 8 : (MODE == kModeQuad ? (size_t)TWQ * 8 : 0)) +
                      (size_t)W * XCH * 8;
   // Work distribution: each workgroup takes a SHORT contiguous chunk (a few units per wave) and the hardware
   // dispatcher hands chunks out in order.  Many short-lived workgroups balance the load across CUs / XCDs
@@ -816,10 +828,10 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
-  if (streaming && !scale) return go(k_stft_wave<C, MODE, false, false, W>);
-  if (streaming && scale) return go(k_stft_wave<C, MODE, false, true, W>);
-  if (!scale) return go(k_stft_wave<C, MODE, true, false, W>);
-  return go(k_stft_wave<C, MODE, true, true, W>);
+  if (streaming && !scale) return go(k_stft_wave<C, MODE, false, false, W, J>);
+  if (streaming && scale) return go(k_stft_wave<C, MODE, false, true, W, J>);
+  if (!scale) return go(k_stft_wave<C, MODE, true, false, W, J>);
+  return go(k_stft_wave<C, MODE, true, true, W, J>);
 }
 
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
@@ -834,9 +846,17 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
     if (w == 8) return launch_wave<1024, kModePair, 8>(c, s);
     return launch_wave<1024, kModePair, 4>(c, s);
   }
-  if (s.K == 512) {  // four frames interleaved into one 1024-point complex FFT
+  if (s.K == 512) {  // 4 frames interleaved into one 1024-point complex FFT
     *handled = true;
-    return launch_wave<1024, kModeQuad, 4>(c, s);
+    return launch_wave<1024, kModeQuad, 4, 2>(c, s);
+  }
+  if (s.K == 256) {  // 8 frames
+    *handled = true;
+    return launch_wave<1024, kModeQuad, 4, 4>(c, s);
+  }
+  if (s.K == 128) {  // 16 frames
+    *handled = true;
+    return launch_wave<1024, kModeQuad, 4, 8>(c, s);
   }
   if (s.K == 2048) {  // one frame as even/odd samples of a 1024-point complex FFT
     *handled = true;
@@ -927,13 +947,15 @@ static int ensure_wave_tables_1024(Ctx* c) {
   if (rc) { wt.twB = nullptr; return rc; }
   rc = ctx_table(c, 0x7744ull ^ (uint64_t)C, twR.data(), twR.size() * sizeof(float2), &wt.twI);
   if (rc) { wt.twB = nullptr; return rc; }
-  {  // quad front-end: conj(w_C^k), k < C/2
-    std::vector<float2> twQ((size_t)C / 2);
-    for (int k = 0; k < C / 2; ++k) {
-      const double ang = two_pi * (double)k / (double)C;
-      twQ[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-    }
-    rc = ctx_table(c, 0x7747ull ^ (uint64_t)C, twQ.data(), twQ.size() * sizeof(float2), &wt.twQ);
+  for (int ji = 0; ji < 3; ++ji) {  // quad front-ends J = 2, 4, 8: [j-1][k0] = conj(w_C^(j k0)), k0 < C/J
+    const int Jv = 2 << ji, KO = C / Jv;
+    std::vector<float2> twQ((size_t)(Jv - 1) * KO);
+    for (int j = 1; j < Jv; ++j)
+      for (int k0 = 0; k0 < KO; ++k0) {
+        const double ang = two_pi * (double)((int64_t)j * k0 % C) / (double)C;
+        twQ[(size_t)(j - 1) * KO + k0] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      }
+    rc = ctx_table(c, 0x7747ull ^ ((uint64_t)C << 8) ^ (uint64_t)Jv, twQ.data(), twQ.size() * sizeof(float2), &wt.twQ[ji]);
     if (rc) { wt.twB = nullptr; return rc; }
   }
   for (auto& t : twB) t.y = -t.y;  // conjugated copies for the inverse transform

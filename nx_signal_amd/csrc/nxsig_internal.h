@@ -70,7 +70,7 @@ struct Ctx {
   // per-K tables of the tuned wave kernels (pass-B / pass-C twiddles), built once
   struct WaveTables { const void* twB = nullptr; const void* twC = nullptr; const void* twI = nullptr;
                       const void* twBi = nullptr; const void* twCi = nullptr;    // ...i = conjugated (inverse transform)
-                      const void* twQ = nullptr; };                              // conj(w_C^k), k < C/2 (quad front-end)
+                      const void* twQ[3] = {nullptr, nullptr, nullptr}; };       // quad front-ends J = 2, 4, 8
   std::map<int, WaveTables> wave_tables;
   // memo of the last window seen (the common case: the same window tensor call after call)
   std::vector<float> memo_win;

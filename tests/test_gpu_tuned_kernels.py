@@ -31,6 +31,14 @@ def nerr(got, ref):
     (512, 512, 160, 40000, 2),                   # speech-style hop
     (512, 400, 160, 16000, 1),                   # N = 400 < K = 512 (25 ms frames at 16 kHz): general path
     (512, 512, 128, 512, 1),                     # a lone frame
+    (256, 256, 64, 256 + 64 * 16, 3),            # J = 4: M = 17 (M % 8 == 1), 3 rows
+    (256, 256, 64, 256 + 64 * 21, 2),            # M % 8 == 6
+    (256, 200, 80, 30000, 2),                    # N < K
+    (256, 256, 64, 256, 1),
+    (128, 128, 32, 128 + 32 * 32, 3),            # J = 8: M = 33 (M % 16 == 1)
+    (128, 128, 32, 128 + 32 * 46, 2),            # M % 16 == 15
+    (128, 128, 1, 128 + 100, 1),                 # hop 1
+    (128, 100, 50, 9000, 2),
     (2048, 2048, 512, 2048 + 512 * 9, 3),        # real-2x front-end, odd M, 3 rows
     (2048, 2048, 511, 50000, 1),                 # odd hop: unaligned 4-byte loads
     (2048, 1024, 256, 30000, 2),                 # N < K on the real-2x front-end
@@ -58,9 +66,11 @@ def test_stft_wave_chunk_seams_many_rows():
 
 
 @pytest.mark.parametrize("pad", ["reflect", "same", [(100, 900)], [(-3, 50)]])
-@pytest.mark.parametrize("K", [512, 1024, 2048])
+@pytest.mark.parametrize("K", [128, 256, 512, 1024, 2048])
 def test_stft_wave_general_padding(pad, K):
     rng = np.random.default_rng(5 + K)
+    if isinstance(pad, list) and K < 1024:
+        pad = [(pad[0][0] // 8, pad[0][1] // 8)] if pad[0][0] > 0 else pad
     x = rng.standard_normal((2, 9000)).astype(np.float32)
     w = S.windows.blackman(K)
     opts = dict(overlap_length=K - K // 4, fft_length=K, window_padding=pad, scaling="spectrum", sampling_rate=8000)

@@ -182,6 +182,22 @@ int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch,
                   int32_t num_taps, int32_t mode, float* y, int32_t mem);
 
 /*
+ * NxSignal.mel_filters/4 — lib/nx_signal.ex:397-445 (Slaney-style filterbank, host-side with BinaryBackend rounding):
+ * out f32[mel_bins][fft_length].  Defaults of the reference: max_mel 3016, mel_frequency_spacing 200/3.
+ */
+int nxsig_mel_filters_f32(int32_t fft_length, int32_t mel_bins, double sampling_rate, double max_mel,
+                          double mel_frequency_spacing, float* out);
+
+/*
+ * NxSignal.stft_to_mel/3 — lib/nx_signal.ex:486-513: |z|^2 of the first fft_length/2 bins x filterbank
+ * -> log10(max(., 1e-10)) -> max(., global max - 8) -> (. + 4) / 4.   z c64[rows][fft_length] (rows = every frame of
+ * every batch element: the reference's reduce_max runs over the whole tensor) -> out f32[rows][mel_bins].
+ * `filters` f32[mel_bins][fft_length] is a HOST table (nxsig_mel_filters_f32 or user supplied).
+ */
+int nxsig_stft_to_mel(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int32_t fft_length, int32_t mel_bins,
+                      const float* filters, float* out, int32_t mem);
+
+/*
  * 1-D complex case of Convolution.fftconvolve/3 — lib/nx_signal/convolution.ex:252-329 (tests: "FFT complex",
  * test/nx_signal/convolutions_test.exs:473-487): out = ifft(fft(a, P) * fft(b, P)) sliced per mode, with
  * P = next power of two >= n1 + n2 - 1 (same linear convolution as the reference's length n1 + n2 - 1).

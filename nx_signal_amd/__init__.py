@@ -25,7 +25,7 @@ from ._lib import ArgumentError, NxSignalDeviceError, NxSignalLibraryError, NxSi
 from .device import Context, DeviceBuffer, default_context, device_view, is_device
 
 __all__ = [
-    "stft", "istft", "as_windowed", "overlap_and_add", "fft_frequencies",
+    "stft", "istft", "as_windowed", "overlap_and_add", "fft_frequencies", "mel_filters", "stft_to_mel",
     "Context", "DeviceBuffer", "default_context", "ArgumentError",
     "NxSignalDeviceError", "NxSignalLibraryError", "NxSignalUnsupported",
 ]
@@ -296,6 +296,49 @@ def overlap_and_add(tensor, ctx: Context | None = None, **opts):
     _lib.check(lib.nxsig_overlap_and_add(c.handle, _as_ptr(arr), Mf, batch, N, overlap, comps, _as_ptr(out), _lib.HOST))
     target = o["type"] if o["type"] is not None else src_dtype  # code default: the input type (:685, B10)
     return out.astype(target) if np.dtype(target) != out.dtype else out
+
+
+def mel_filters(fft_length, mel_bins, sampling_rate, **opts):
+    """NxSignal.mel_filters/4 — lib/nx_signal.ex:397-445.  f32[mels: mel_bins][frequencies: fft_length]."""
+    o = _validate(opts, {"max_mel": 3016, "mel_frequency_spacing": 200 / 3, "type": "f32"}, "mel_filters")
+    if o["type"] not in ("f32", np.float32):
+        raise ArgumentError("mel_filters: only type f32 is built")
+    out = np.empty((int(mel_bins), int(fft_length)), dtype=np.float32)
+    _lib.check(_lib.load().nxsig_mel_filters_f32(int(fft_length), int(mel_bins), float(sampling_rate), float(o["max_mel"]),
+                                                 float(o["mel_frequency_spacing"]), _as_ptr(out)))
+    return out
+
+
+def stft_to_mel(z, sampling_rate, ctx: Context | None = None, **opts):
+    """NxSignal.stft_to_mel/3 — lib/nx_signal.ex:486-513.  c64[..., frames, K] -> f32[..., frames, mel_bins]
+    (the global maximum of the reference's `reduce_max` runs over the whole tensor)."""
+    o = _validate(opts, {"fft_length": None, "mel_bins": 128, "max_mel": None, "mel_frequency_spacing": None, "type": "f32"},
+                  "stft_to_mel")
+    if o["fft_length"] is None:
+        raise ArgumentError("missing :fft_length option")
+    K, mb = int(o["fft_length"]), int(o["mel_bins"])
+    fopts = {k: o[k] for k in ("max_mel", "mel_frequency_spacing") if o[k] is not None}
+    filt = mel_filters(K, mb, sampling_rate, **fopts)
+    lib = _lib.load()
+    if is_device(z):
+        ptr, shape, dt = device_view(z)
+        if dt != np.complex64:
+            raise ArgumentError("stft_to_mel: device input must be complex64")
+        if shape[-1] != K:
+            raise ArgumentError("stft_to_mel: the last axis must be fft_length")
+        c = _ctx_of(z, ctx)
+        rows = int(np.prod(shape[:-1], dtype=np.int64))
+        out = c.empty(tuple(shape[:-1]) + (mb,), np.float32)
+        _lib.check(lib.nxsig_stft_to_mel(c.handle, C.c_void_p(ptr), rows, K, mb, _as_ptr(filt), C.c_void_p(out.ptr), _lib.DEVICE))
+        return out
+    zin = np.ascontiguousarray(np.asarray(z).astype(np.complex64))
+    if zin.shape[-1] != K:
+        raise ArgumentError("stft_to_mel: the last axis must be fft_length")
+    c = _ctx_of(None, ctx)
+    rows = int(np.prod(zin.shape[:-1], dtype=np.int64))
+    out = np.empty(zin.shape[:-1] + (mb,), dtype=np.float32)
+    _lib.check(lib.nxsig_stft_to_mel(c.handle, _as_ptr(zin), rows, K, mb, _as_ptr(filt), _as_ptr(out), _lib.HOST))
+    return out
 
 
 from . import convolution, filters, transforms, waveforms, windows  # noqa: E402,F401

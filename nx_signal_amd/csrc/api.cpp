@@ -662,4 +662,34 @@ int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const 
   NXSIG_API_END
 }
 
+int nxsig_mel_filters_f32(int32_t fft_length, int32_t mel_bins, double sampling_rate, double max_mel,
+                          double mel_frequency_spacing, float* out) {
+  NXSIG_API_BEGIN
+  if (fft_length < 2 || mel_bins < 1 || !out || !(mel_frequency_spacing > 0.0))
+    return set_error(NXSIG_ERR_INVALID_ARG, "mel_filters: fft_length >= 2, mel_bins >= 1 and a positive spacing are required");
+  mel_filters_f32(fft_length, mel_bins, sampling_rate, max_mel, mel_frequency_spacing, out);
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_stft_to_mel(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int32_t fft_length, int32_t mel_bins,
+                      const float* filters, float* out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!z || !filters || !out) return set_error(NXSIG_ERR_INVALID_ARG, "stft_to_mel: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (rows < 1 || fft_length < 2 || mel_bins < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft_to_mel: rows, fft_length, mel_bins must be positive");
+  if (fft_length / 2 > 8192) return set_error(NXSIG_ERR_UNSUPPORTED, "stft_to_mel: fft_length > 16384 is not supported");
+  const size_t zbytes = (size_t)rows * fft_length * sizeof(float2), obytes = (size_t)rows * mel_bins * sizeof(float);
+  if (mem == NXSIG_DEVICE) return launch_stft_to_mel(c, reinterpret_cast<const float2*>(z), rows, fft_length, mel_bins, filters, out);
+  Staged st(c);
+  const void* zd = nullptr; void* od = nullptr;
+  if ((rc = st.in(1, z, zbytes, &zd))) return rc;
+  if ((rc = st.out_alloc(2, obytes, &od))) return rc;
+  if ((rc = launch_stft_to_mel(c, reinterpret_cast<const float2*>(zd), rows, fft_length, mel_bins, filters, reinterpret_cast<float*>(od)))) return rc;
+  return st.out_copy(out, od, obytes);
+  NXSIG_API_END
+}
+
 }  // extern "C"

@@ -222,6 +222,34 @@ void stft_times_f32(int N, double fs, int64_t M, float* out) {  // nx_signal.ex:
   linspace32(time_step, last, M, true, out);
 }
 
+// NxSignal.mel_filters/4 — lib/nx_signal.ex:412-445, op by op in f32 with double transcendentals
+void mel_filters_f32(int K, int mel_bins, double fs, double max_mel, double f_sp, float* out) {
+  std::vector<float> fftfreqs(K), mels(mel_bins + 2), mel_f(mel_bins + 2);
+  fft_frequencies_f32(fs, K, false, fftfreqs.data());
+  linspace32(0.0f, (float)max_mel / (float)f_sp, mel_bins + 2, true, mels.data());
+  const float fsp = (float)f_sp;
+  const float min_log_hz = 1000.0f;
+  const float min_log_mel = min_log_hz / fsp;
+  const float logstep = (float)std::log((double)6.4f) / 27.0f;  // Nx.log(6.4) / 27
+  for (int i = 0; i < mel_bins + 2; ++i) {
+    const float lin = fsp * mels[i];
+    const float arg = logstep * (mels[i] - min_log_mel);
+    const float lg = min_log_hz * exp32(arg);
+    mel_f[i] = (mels[i] >= min_log_mel) ? lg : lin;
+  }
+  for (int b = 0; b < mel_bins; ++b) {
+    const float fd_lo = mel_f[b + 1] - mel_f[b], fd_hi = mel_f[b + 2] - mel_f[b + 1];
+    const float enorm = 2.0f / (mel_f[b + 2] - mel_f[b]);
+    for (int k = 0; k < K; ++k) {
+      const float lower = -(mel_f[b] - fftfreqs[k]) / fd_lo;       // -ramps[b] / fdiff[b]
+      const float upper = (mel_f[b + 2] - fftfreqs[k]) / fd_hi;    // ramps[b+2] / fdiff[b+1]
+      float w = lower < upper ? lower : upper;
+      w = (w > 0.0f) ? w : 0.0f;                                    // Nx.max(0, .): +0.0 for w <= 0
+      out[(size_t)b * K + k] = w * enorm;
+    }
+  }
+}
+
 // f32 scalar the spectrum is divided by (stft :116/:119) or multiplied by (istft :614/:617).
 // Nx.sum accumulates in double and rounds once; window ** 2 is an exact f32 product.
 float scaling_factor(const float* w, int N, int scaling, double fs) {

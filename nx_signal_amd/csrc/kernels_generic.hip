@@ -438,6 +438,75 @@ __global__ __launch_bounds__(kThreads) void k_cmul_inplace(float2* __restrict__ 
   if (i < n) a[i] = cmul(a[i], b[i]);
 }
 
+// ------------------------------------------------------------------------------------------ stft_to_mel
+// lib/nx_signal.ex:486-513.  The Slaney filters are triangles: band b is non-zero on a short bin range, so the
+// `Nx.dot` over frequencies is a sparse band sum (per band a [lo, hi) range into the dense filter row).
+// Pass 1: per frame |z|^2 of bins < K/2 into LDS, per (frame, band) the band sum in double (the reference's dot
+//         accumulates in double), log10 as log(x) / log(10) in f32 steps, block max -> ordered-int atomicMax.
+// Pass 2: max(x, gmax - 8), (x + 4) / 4.
+struct MelArgs {
+  const float2* z;
+  int64_t rows;
+  int32_t K, half, mel_bins;
+  const float* filt;        // device f32[mel_bins][K]
+  const int2* band;         // device [mel_bins]: non-zero bin range [lo, hi) within [0, K/2)
+  float* out;               // f32[rows][mel_bins]
+  int* gmax;                // ordered-int encoding of the running maximum
+  float ln10;               // f32(log(10))
+};
+
+__device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+static constexpr int kMelFramesPerBlock = 4;
+
+__global__ __launch_bounds__(kThreads) void k_mel_pass1(MelArgs a) {
+  float* mags = reinterpret_cast<float*>(g_smem);  // [frames per block][half]
+  __shared__ int s_max;
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * kMelFramesPerBlock;
+  if (tid == 0) s_max = f2ord(-3.0e38f);
+  for (int idx = tid; idx < kMelFramesPerBlock * a.half; idx += kThreads) {
+    const int f = idx / a.half, k = idx - f * a.half;
+    float m = 0.0f;
+    if (r0 + f < a.rows) {
+      const float2 v = a.z[(size_t)(r0 + f) * a.K + k];
+      const float ab = (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);  // Nx.abs(c64) -> f32
+      m = ab * ab;                                                                          // ** 2
+    }
+    mags[idx] = m;
+  }
+  __syncthreads();
+  int lmax = f2ord(-3.0e38f);
+  for (int idx = tid; idx < kMelFramesPerBlock * a.mel_bins; idx += kThreads) {
+    const int f = idx / a.mel_bins, b = idx - f * a.mel_bins;
+    if (r0 + f >= a.rows) continue;
+    const int2 rg = a.band[b];
+    const float* fr = a.filt + (size_t)b * a.K;
+    const float* mg = mags + f * a.half;
+    double acc = 0.0;
+    for (int k = rg.x; k < rg.y; ++k) acc += (double)mg[k] * (double)fr[k];
+    float v = (float)acc;
+    v = v > 1.0e-10f ? v : 1.0e-10f;                       // Nx.clip(mel_spec, 1.0e-10, :infinity)
+    v = (float)log((double)v) / a.ln10;                    // Nx.log(.) / Nx.log(10)
+    a.out[(size_t)(r0 + f) * a.mel_bins + b] = v;
+    const int o = f2ord(v);
+    lmax = o > lmax ? o : lmax;
+  }
+  atomicMax(&s_max, lmax);
+  __syncthreads();
+  if (tid == 0) atomicMax(a.gmax, s_max);
+}
+
+__global__ __launch_bounds__(kThreads) void k_mel_pass2(float* __restrict__ out, int64_t n, const int* __restrict__ gmax) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const float floor_v = ord2f(*gmax) - 8.0f;               // Nx.reduce_max(log_spec) - 8
+  float v = out[i];
+  v = v > floor_v ? v : floor_v;
+  out[i] = (v + 4.0f) / 4.0f;
+}
+
 // ========================================================================================== launchers
 static int ilog2(int v) {
   int l = 0;
@@ -713,6 +782,46 @@ int launch_fftconvolve_c64(Ctx* c, const float2* a, int64_t n1, const float2* b,
   NXSIG_HIP_TRY(hipGetLastError());
   if ((rc = launch_fft(c, A, false, 1, P, P, true, C))) return rc;
   NXSIG_HIP_TRY(hipMemcpyAsync(out, C + start, (size_t)len * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+  return NXSIG_OK;
+}
+
+int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t mel_bins, const float* filters_host,
+                       float* out) {
+  if (rows == 0 || mel_bins == 0) return NXSIG_OK;
+  const int half = K / 2;
+  std::vector<int2> band(mel_bins);
+  for (int b = 0; b < mel_bins; ++b) {
+    int lo = half, hi = 0;
+    for (int k = 0; k < half; ++k)
+      if (filters_host[(size_t)b * K + k] != 0.0f) { if (k < lo) lo = k; hi = k + 1; }
+    if (hi <= lo) { lo = 0; hi = 0; }
+    band[b] = make_int2(lo, hi);
+  }
+  MelArgs a;
+  const void *fd = nullptr, *bd = nullptr;
+  int rc = ctx_table(c, 0x3E1F11ull, filters_host, (size_t)mel_bins * K * sizeof(float), &fd);
+  if (rc) return rc;
+  rc = ctx_table(c, 0x3E1BA2Dull, band.data(), band.size() * sizeof(int2), &bd);
+  if (rc) return rc;
+  void* gm = nullptr;
+  rc = ctx_scratch(c, 0, 256, &gm);
+  if (rc) return rc;
+  static const int init = (int)0x80000000;  // below every ordered-int value
+  NXSIG_HIP_TRY(hipMemcpyAsync(gm, &init, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  a.z = z; a.rows = rows; a.K = K; a.half = half; a.mel_bins = mel_bins;
+  a.filt = reinterpret_cast<const float*>(fd); a.band = reinterpret_cast<const int2*>(bd);
+  a.out = out; a.gmax = reinterpret_cast<int*>(gm);
+  a.ln10 = (float)std::log(10.0);
+  const size_t lds = (size_t)kMelFramesPerBlock * half * sizeof(float);
+  int rc2 = ensure_lds(k_mel_pass1, lds);
+  if (rc2) return rc2;
+  hipLaunchKernelGGL(k_mel_pass1, dim3((unsigned)((rows + kMelFramesPerBlock - 1) / kMelFramesPerBlock)), dim3(kThreads), lds,
+                     c->stream, a);
+  NXSIG_HIP_TRY(hipGetLastError());
+  const int64_t n = rows * mel_bins;
+  hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, out, n,
+                     reinterpret_cast<const int*>(gm));
+  NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
 }
 

@@ -34,6 +34,7 @@ int firwin_f32(int num_taps, const double* cutoff, int n_cutoff, int window_kind
 void fft_frequencies_f32(double fs, int K, bool endpoint, float* out);
 void stft_times_f32(int N, double fs, int64_t M, float* out);
 float scaling_factor(const float* w, int N, int scaling, double fs);
+void mel_filters_f32(int K, int mel_bins, double fs, double max_mel, double f_sp, float* out);
 
 // ---- framing geometry (as_windowed, lib/nx_signal.ex:257-331) ----
 struct Framing {
@@ -128,6 +129,8 @@ struct FirLaunch {
   float* y;                    // device f32[batch][out_len]
 };
 int launch_fir(Ctx* c, const FirLaunch& a);
+int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t mel_bins, const float* filters_host,
+                       float* out);
 int launch_fftconvolve_c64(Ctx* c, const float2* a, int64_t n1, const float2* b, int64_t n2, int64_t start, int64_t len,
                            float2* out);
 

@@ -109,6 +109,17 @@ def test_firwin_errors(golden):
         S.filters.firwin(5, 0.3)
 
 
+def test_mel_filters_golden_and_oracle(golden):
+    for v in golden["mel_filters"]:
+        got = S.mel_filters(v["fft_length"], v["mel_bins"], v["sampling_rate"])
+        exp = np.array([f32_list(row) for row in v["expect"]])
+        assert np.array_equal(_bits(got), _bits(exp)), v["src"]  # bit-exact with the reference doctest
+    for K, mb, fs in [(16, 4, 8000.0), (400, 80, 16000), (1024, 128, 16000), (2048, 128, 48000)]:
+        assert np.array_equal(_bits(S.mel_filters(K, mb, fs)), _bits(O.mel_filters(K, mb, fs)))
+    with pytest.raises(S.ArgumentError, match="unknown keys"):
+        S.mel_filters(16, 4, 8000.0, bogus=1)
+
+
 def test_num_frames_matches_oracle():
     lib = _lib.load()
     modes = {"valid": (0, 0, 0), "reflect": (1, 0, 0), "same": (2, 0, 0)}

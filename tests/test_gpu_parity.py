@@ -118,6 +118,31 @@ def test_fftconvolve_complex_golden_and_oracle(golden):
     assert mixed.dtype == np.complex64  # "don't complexify" only when both are real (convolutions_test.exs:392-416)
 
 
+def test_stft_to_mel_doctest_and_oracle(golden):
+    """NxSignal.stft_to_mel/3 (lib/nx_signal.ex:465-483 doctest) on top of the HIP stft"""
+    for v in golden["stft_to_mel"]:
+        x = np.arange(v["x_iota"])
+        w = S.windows.hann(v["window"]["n"])
+        z, _, _ = S.stft(x, w, **v["opts"])
+        mel = S.stft_to_mel(z, v["opts"]["sampling_rate"], fft_length=v["opts"]["fft_length"], mel_bins=v["mel_bins"])
+        exp = np.array([f32_list(row) for row in v["expect"]])
+        assert mel.shape == exp.shape and mel.dtype == np.float32
+        assert nx_all_close(mel, exp, atol=1e-5, rtol=1e-5), (mel, exp)
+    rng = np.random.default_rng(21)
+    xs = rng.standard_normal((3, 40000)).astype(np.float32)
+    for K, mb, fs in [(1024, 128, 16000), (512, 80, 16000), (2048, 64, 48000)]:
+        w = S.windows.hann(K)
+        opts = dict(overlap_length=K - K // 4, fft_length=K, sampling_rate=fs)
+        zo, _, _ = O.stft(xs, w, **opts)
+        ref = O.stft_to_mel(zo.reshape(-1, K), fs, K, mel_bins=mb).reshape(zo.shape[:-1] + (mb,))
+        got_same = S.stft_to_mel(zo, fs, fft_length=K, mel_bins=mb)           # same spectrum through both
+        assert np.max(np.abs(got_same - ref)) < 2e-6, np.max(np.abs(got_same - ref))
+        ctx = S.default_context()
+        zd, _, _ = S.stft(ctx.to_device(xs), w, **opts)                       # device-resident chain
+        got = S.stft_to_mel(zd, fs, fft_length=K, mel_bins=mb).numpy()
+        assert got.shape == ref.shape and np.max(np.abs(got - ref)) < 1e-4
+
+
 def test_fft_rows_golden(golden):
     for v in golden["fft_rows"]:
         z = S.transforms.fft_nd(np.array(v["x"]), axes=[-1], lengths=[v["length"]])

@@ -198,6 +198,16 @@ int nxsig_stft_to_mel(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int32_t 
                       const float* filters, float* out, int32_t mem);
 
 /*
+ * Fused NxSignal.stft/3 -> NxSignal.stft_to_mel/3: the log-mel spectrogram of x without ever writing the
+ * complex spectrum to HBM (mel_bins * 4 B/frame leave the chip instead of fft_length * 8).  Same result as
+ * nxsig_stft_f32 followed by nxsig_stft_to_mel, to fp32 rounding.  x f32[batch][length] -> out f32[batch][M][mel_bins];
+ * the global maximum runs over the whole output.  Shapes the fused kernel does not cover run the two-step path.
+ */
+int nxsig_stft_mel_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride,
+                       const float* window, const nxsig_stft_params* params, int32_t mel_bins, const float* filters,
+                       float* out, int64_t* num_frames_out, int32_t mem);
+
+/*
  * 1-D complex case of Convolution.fftconvolve/3 — lib/nx_signal/convolution.ex:252-329 (tests: "FFT complex",
  * test/nx_signal/convolutions_test.exs:473-487): out = ifft(fft(a, P) * fft(b, P)) sliced per mode, with
  * P = next power of two >= n1 + n2 - 1 (same linear convolution as the reference's length n1 + n2 - 1).

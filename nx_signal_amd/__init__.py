@@ -25,7 +25,7 @@ from ._lib import ArgumentError, NxSignalDeviceError, NxSignalLibraryError, NxSi
 from .device import Context, DeviceBuffer, default_context, device_view, is_device
 
 __all__ = [
-    "stft", "istft", "as_windowed", "overlap_and_add", "fft_frequencies", "mel_filters", "stft_to_mel",
+    "stft", "istft", "as_windowed", "overlap_and_add", "fft_frequencies", "mel_filters", "stft_to_mel", "mel_spectrogram",
     "Context", "DeviceBuffer", "default_context", "ArgumentError",
     "NxSignalDeviceError", "NxSignalLibraryError", "NxSignalUnsupported",
 ]
@@ -338,6 +338,56 @@ def stft_to_mel(z, sampling_rate, ctx: Context | None = None, **opts):
     rows = int(np.prod(zin.shape[:-1], dtype=np.int64))
     out = np.empty(zin.shape[:-1] + (mb,), dtype=np.float32)
     _lib.check(lib.nxsig_stft_to_mel(c.handle, _as_ptr(zin), rows, K, mb, _as_ptr(filt), _as_ptr(out), _lib.HOST))
+    return out
+
+
+def mel_spectrogram(data, window, ctx: Context | None = None, **opts):
+    """Extension (not in the reference API): `stft_to_mel(stft(data, window, ...)[0], sampling_rate, ...)` fused in one
+    kernel — the spectrum never goes to HBM.  Takes the stft options plus :mel_bins (128), :max_mel,
+    :mel_frequency_spacing.  Returns f32[..., frames, mel_bins], equal to the two-step result to fp32 rounding."""
+    mel_keys = {"mel_bins": 128, "max_mel": None, "mel_frequency_spacing": None}
+    mo = {k: opts.pop(k) for k in list(opts) if k in mel_keys}
+    o = _validate(
+        opts,
+        {"overlap_length": None, "window": None, "scaling": None, "window_padding": "valid", "sampling_rate": 100,
+         "fft_length": "power_of_two"},
+        "mel_spectrogram",
+    )
+    w = _window_host(window)
+    N = int(w.shape[0])
+    fs = float(o["sampling_rate"])
+    overlap = N // 2 if o["overlap_length"] is None else int(o["overlap_length"])
+    hop = N - overlap
+    if o["scaling"] not in _SCALING:
+        raise ArgumentError(f"invalid :scaling, expected one of :spectrum, :psd or nil, got: {o['scaling']!r}")
+    mode, lo, hi = _pad_args(o["window_padding"])
+    K = _resolve_fft_length(o["fft_length"], N)
+    mb = int(mo.get("mel_bins", 128))
+    fopts = {k: mo[k] for k in ("max_mel", "mel_frequency_spacing") if mo.get(k) is not None}
+    filt = mel_filters(K, mb, fs, **fopts)
+    p = StftParams(N, hop, K, mode, lo, hi, _SCALING[o["scaling"]], 0, fs)
+    lib = _lib.load()
+    M = C.c_int64()
+    if is_device(data):
+        ptr, shape, dt = device_view(data)
+        if dt != np.float32:
+            raise ArgumentError("mel_spectrogram: device input must be float32")
+        c = _ctx_of(data, ctx)
+        L = shape[-1]
+        batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
+        m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
+        out = c.empty(tuple(shape[:-1]) + (m, mb), np.float32)
+        _lib.check(lib.nxsig_stft_mel_f32(c.handle, C.c_void_p(ptr), L, batch, L, _as_ptr(w), C.byref(p), mb, _as_ptr(filt),
+                                          C.c_void_p(out.ptr), C.byref(M), _lib.DEVICE))
+        return out
+    x = _host_f32(data, "mel_spectrogram")
+    c = _ctx_of(None, ctx)
+    L = x.shape[-1]
+    batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
+    m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
+    out = np.empty(x.shape[:-1] + (m, mb), dtype=np.float32)
+    _lib.check(lib.nxsig_stft_mel_f32(c.handle, _as_ptr(x), L, batch, L, _as_ptr(w), C.byref(p), mb, _as_ptr(filt), _as_ptr(out),
+                                      C.byref(M), _lib.HOST))
     return out
 
 

@@ -804,7 +804,7 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
   rc = ctx_table(c, 0x3E1BA2Dull, band.data(), band.size() * sizeof(int2), &bd);
   if (rc) return rc;
   void* gm = nullptr;
-  rc = ctx_scratch(c, 0, 256, &gm);
+  rc = ctx_scratch(c, 5, 256, &gm);
   if (rc) return rc;
   static const int init = (int)0x80000000;  // below every ordered-int value
   NXSIG_HIP_TRY(hipMemcpyAsync(gm, &init, sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -821,6 +821,23 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
   const int64_t n = rows * mel_bins;
   hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, out, n,
                      reinterpret_cast<const int*>(gm));
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+// shared by the fused stft->mel kernel: running-maximum cell and the clamp pass
+int launch_mel_init(Ctx* c, int** gmax) {
+  void* gm = nullptr;
+  int rc = ctx_scratch(c, 5, 256, &gm);
+  if (rc) return rc;
+  static const int init = (int)0x80000000;
+  NXSIG_HIP_TRY(hipMemcpyAsync(gm, &init, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  *gmax = reinterpret_cast<int*>(gm);
+  return NXSIG_OK;
+}
+int launch_mel_finish(Ctx* c, float* out, int64_t n, int* gmax) {
+  if (n <= 0) return NXSIG_OK;
+  hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, out, n, gmax);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
 }

@@ -66,8 +66,9 @@ struct Ctx {
   // content-addressed small tables (windows, filter spectra ...): key = fnv1a(tag, bytes)
   std::map<uint64_t, DeviceTable> tables;
   // scratch buffer reused by multi-stage paths (generic istft, host staging)
-  void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_bytes[4] = {0, 0, 0, 0};
+  // slots: 0 multi-stage temporaries, 1/2 host staging in/out, 3 wave-kernel dummy sink, 4 fused-path spectrum, 5 reduction cells
+  void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
   // per-K tables of the tuned wave kernels (pass-B / pass-C twiddles), built once
   struct WaveTables { const void* twB = nullptr; const void* twC = nullptr; const void* twI = nullptr;
                       const void* twBi = nullptr; const void* twCi = nullptr;    // ...i = conjugated (inverse transform)
@@ -131,6 +132,7 @@ struct FirLaunch {
 int launch_fir(Ctx* c, const FirLaunch& a);
 int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t mel_bins, const float* filters_host,
                        float* out);
+int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled);
 int launch_fftconvolve_c64(Ctx* c, const float2* a, int64_t n1, const float2* b, int64_t n2, int64_t start, int64_t len,
                            float2* out);
 

@@ -143,6 +143,32 @@ def test_stft_to_mel_doctest_and_oracle(golden):
         assert got.shape == ref.shape and np.max(np.abs(got - ref)) < 1e-4
 
 
+@pytest.mark.parametrize("K,N,hop,pad,scaling,mb", [
+    (1024, 1024, 256, "valid", None, 128),      # fused wave kernel, streaming
+    (1024, 1024, 256, "reflect", "psd", 80),    # fused, general loader + scaling
+    (1024, 1000, 250, "valid", None, 64),       # fused, N < K
+    (1024, 1024, 256, "valid", None, 7),        # fewer bands than lanes
+    (512, 512, 128, "valid", None, 80),         # not covered by the fused kernel: two-step path behind the same entry
+    (2048, 2048, 512, "valid", "spectrum", 128),
+])
+def test_mel_spectrogram_fused_matches_two_step_and_oracle(K, N, hop, pad, scaling, mb):
+    rng = np.random.default_rng(K + mb)
+    x = rng.standard_normal((3, 30000 + 7)).astype(np.float32)  # odd frame counts per row
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=K, sampling_rate=16000, window_padding=pad, scaling=scaling)
+    got = S.mel_spectrogram(x, w, mel_bins=mb, **opts)
+    z, _, _ = S.stft(x, w, **opts)
+    two = S.stft_to_mel(z, 16000, fft_length=K, mel_bins=mb)
+    zo, _, _ = O.stft(x, w, **opts)
+    ref = O.stft_to_mel(zo.reshape(-1, K), 16000, K, mel_bins=mb).reshape(zo.shape[:-1] + (mb,))
+    assert got.shape == two.shape == ref.shape and got.dtype == np.float32
+    assert np.max(np.abs(got - two)) < 2e-5, np.max(np.abs(got - two))
+    assert np.max(np.abs(got - ref)) < 1e-4, np.max(np.abs(got - ref))
+    ctx = S.default_context()
+    gd = S.mel_spectrogram(ctx.to_device(x), w, mel_bins=mb, **opts)
+    assert np.array_equal(gd.numpy().view(np.uint32), got.view(np.uint32))
+
+
 def test_fft_rows_golden(golden):
     for v in golden["fft_rows"]:
         z = S.transforms.fft_nd(np.array(v["x"]), axes=[-1], lengths=[v["length"]])

@@ -73,6 +73,27 @@ def main():
             b = 16
             Lg = (1700 * 1024 * 1024 // (b * 8 * 4)) // n * n  # hop = n/4 -> 8n bytes out per hop samples
             stft_case(ctx, n, n // 4, Lg, b, f"stft N={n} hop={n // 4}, {b} rows (generic kernels unless tuned)")
+    if "mel" in which:
+        N, hop, L, batch, mb = 1024, 256, 2880000, 32, 128
+        w = S.windows.hann(N)
+        M = (L - N) // hop + 1
+        xd = ctx.empty((batch, L), np.float32)
+        fill_normal(ctx, xd, (batch, L), 13)
+        filt = S.mel_filters(N, mb, 48000.0)
+        od = ctx.empty((batch, M, mb), np.float32)
+        zd = ctx.empty((batch, M, N), np.complex64)
+        p = _lib.StftParams(N, hop, N, 0, 0, 0, 0, 0, 48000.0)
+        wp, fp = w.ctypes.data_as(C.c_void_p), filt.ctypes.data_as(C.c_void_p)
+        fused = lambda: _lib.check(lib.nxsig_stft_mel_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), mb, fp, C.c_void_p(od.ptr), None, _lib.DEVICE))
+
+        def two_step():
+            _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
+            _lib.check(lib.nxsig_stft_to_mel(ctx.handle, C.c_void_p(zd.ptr), batch * M, N, mb, fp, C.c_void_p(od.ptr), _lib.DEVICE))
+
+        for name, fn in (("log-mel fused (stft+mel in one kernel)", fused), ("log-mel two-step (stft, then stft_to_mel)", two_step)):
+            ms = timeit(ctx, fn)
+            print(json.dumps({"case": f"{name}, N=1024 hop=256, {mb} mel bins, 32 x 60 s", "ms": ms, "frames_per_s": batch * M / (ms * 1e-3),
+                              "bytes_per_frame_fused": hop * 4 + mb * 4}), flush=True)
     if "istft" in which:
         N, hop, L, batch = 1024, 256, 2880000, 16
         w = S.windows.hann(N)

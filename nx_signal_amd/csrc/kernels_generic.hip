@@ -167,15 +167,16 @@ __global__ __launch_bounds__(kThreads) void k_stft_dft(StftArgs a) {
   __syncthreads();
   float2* z = a.z + ((size_t)blockIdx.y * a.g.M + m) * a.K;
   for (int k = tid; k < a.K; k += kThreads) {
-    float re = 0.0f, im = 0.0f;
+    double dre = 0.0, dim = 0.0;  // long sums (this path serves K > 4096): accumulate in double
     int idx = 0;
     for (int n = 0; n < nuse; ++n) {
       const float2 w = a.tw[idx];
-      re = fmaf(s[n], w.x, re);
-      im = fmaf(s[n], w.y, im);
+      dre += (double)s[n] * (double)w.x;
+      dim += (double)s[n] * (double)w.y;
       idx += k;
       if (idx >= a.K) idx -= a.K;
     }
+    float re = (float)dre, im = (float)dim;
     if (a.has_scale) { re = re / a.div; im = im / a.div; }
     z[k] = make_float2(re, im);
   }
@@ -249,18 +250,114 @@ __global__ __launch_bounds__(kThreads) void k_fft_rows_dft(FftRowsArgs a) {
   __syncthreads();
   float2* out = a.out + (size_t)r * a.K;
   for (int k = tid; k < a.K; k += kThreads) {
-    float re = 0.0f, im = 0.0f;
+    double dre = 0.0, dim = 0.0;
     int idx = 0;
     for (int n = 0; n < nuse; ++n) {
       const float2 w = twid<INV>(a.tw, idx);
       const float2 v = s[n];
-      re += v.x * w.x - v.y * w.y;
-      im += v.x * w.y + v.y * w.x;
+      dre += (double)v.x * (double)w.x - (double)v.y * (double)w.y;
+      dim += (double)v.x * (double)w.y + (double)v.y * (double)w.x;
       idx += k;
       if (idx >= a.K) idx -= a.K;
     }
-    float2 v = make_float2(re, im);
+    float2 v = make_float2((float)dre, (float)dim);
     if (INV) { v.x = v.x / (float)a.K; v.y = v.y / (float)a.K; }
+    if (a.has_post_scale) { v.x *= a.post_scale; v.y *= a.post_scale; }
+    if (a.post_window) { const float w = a.post_window[k]; v.x *= w; v.y *= w; }
+    out[k] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ Bluestein (chirp-z)
+// Non-power-of-two lengths K in (64, 4096]: X[k] = c[k] * sum_n (x[n] c[n]) conj(c)[k - n], c[n] = exp(-i pi n^2 / K),
+// i.e. one circular convolution of length P = 2^ceil(log2(2K-1)) done with the LDS Stockham FFT:
+// FFT_P -> x Bf (spectrum of the conj-chirp kernel, host-computed in double, pre-scaled by 1/P) -> IFFT_P -> x c[k].
+// n^2 mod 2K is reduced in integers on the host, so the chirp tables are accurate to f32 rounding.
+struct BlueTables {
+  int32_t K, P, logP;
+  const float2* chirp;   // [K]
+  const float2* Bf;      // [P]
+  const float2* twP;     // [P] forward twiddles of the P-point FFT
+};
+
+// A holds the row (complex, natural order) in [0, nuse), zeros up to P; returns the buffer whose first K entries are X
+template <bool INV>
+__device__ float2* bluestein_lds(float2* A, float2* B, const BlueTables& t, int nuse) {
+  const int tid = threadIdx.x;
+  for (int n = tid; n < nuse; n += kThreads) {
+    float2 v = A[n];
+    if (INV) v.y = -v.y;  // IDFT(z) = conj(DFT(conj z)) / K
+    A[n] = cmul(v, t.chirp[n]);
+  }
+  __syncthreads();
+  float2* R = lds_fft_pow2<false>(A, B, t.P, t.logP, 1, t.twP);
+  float2* O = (R == A) ? B : A;
+  for (int i = tid; i < t.P; i += kThreads) R[i] = cmul(R[i], t.Bf[i]);
+  __syncthreads();
+  float2* Y = lds_fft_pow2<true>(R, O, t.P, t.logP, 1, t.twP);
+  for (int k = tid; k < t.K; k += kThreads) {
+    float2 v = cmul(Y[k], t.chirp[k]);
+    if (INV) { v.y = -v.y; v.x = v.x / (float)t.K; v.y = v.y / (float)t.K; }
+    Y[k] = v;
+  }
+  __syncthreads();
+  return Y;
+}
+
+struct StftBlueArgs {
+  StftArgs s;
+  BlueTables t;
+};
+
+__global__ __launch_bounds__(kThreads) void k_stft_blue(StftBlueArgs b) {
+  const StftArgs& a = b.s;
+  float2* A = reinterpret_cast<float2*>(g_smem);
+  float2* Bb = A + b.t.P;
+  const int tid = threadIdx.x;
+  const int64_t m = blockIdx.x;
+  const float* x = a.x + (size_t)blockIdx.y * a.batch_stride;
+  const int nuse = a.g.N < a.K ? a.g.N : a.K;
+  for (int n = tid; n < b.t.P; n += kThreads) {
+    float v = 0.0f;
+    if (n < nuse) v = fetch_padded(x, a.g, m * a.g.hop + n) * a.window[n];
+    A[n] = make_float2(v, 0.0f);
+  }
+  __syncthreads();
+  float2* Y = bluestein_lds<false>(A, Bb, b.t, nuse);
+  float2* z = a.z + ((size_t)blockIdx.y * a.g.M + m) * a.K;
+  for (int k = tid; k < a.K; k += kThreads) {
+    float2 v = Y[k];
+    if (a.has_scale) { v.x = v.x / a.div; v.y = v.y / a.div; }
+    z[k] = v;
+  }
+}
+
+struct FftBlueArgs {
+  FftRowsArgs f;
+  BlueTables t;
+};
+
+template <bool INV>
+__global__ __launch_bounds__(kThreads) void k_fft_rows_blue(FftBlueArgs b) {
+  const FftRowsArgs& a = b.f;
+  float2* A = reinterpret_cast<float2*>(g_smem);
+  float2* Bb = A + b.t.P;
+  const int tid = threadIdx.x;
+  const int64_t r = blockIdx.x;
+  const int nuse = a.n_in < a.K ? a.n_in : a.K;
+  for (int n = tid; n < b.t.P; n += kThreads) {
+    float2 v = make_float2(0.0f, 0.0f);
+    if (n < nuse) {
+      if (a.in_is_real) v.x = reinterpret_cast<const float*>(a.in)[(size_t)r * a.n_in + n];
+      else v = reinterpret_cast<const float2*>(a.in)[(size_t)r * a.n_in + n];
+    }
+    A[n] = v;
+  }
+  __syncthreads();
+  float2* Y = bluestein_lds<INV>(A, Bb, b.t, nuse);
+  float2* out = a.out + (size_t)r * a.K;
+  for (int k = tid; k < a.K; k += kThreads) {
+    float2 v = Y[k];
     if (a.has_post_scale) { v.x *= a.post_scale; v.y *= a.post_scale; }
     if (a.post_window) { const float w = a.post_window[k]; v.x *= w; v.y *= w; }
     out[k] = v;
@@ -524,6 +621,36 @@ static int ensure_lds(KernelT kernel, size_t bytes) {
   return NXSIG_OK;
 }
 
+static void host_fft_f64(std::vector<double>& re, std::vector<double>& im);
+
+// chirp / kernel-spectrum tables of the Bluestein path, cached per context by content
+static int blue_tables(Ctx* c, int K, BlueTables* t) {
+  int P = 1, logP = 0;
+  while (P < 2 * K - 1) { P <<= 1; ++logP; }
+  std::vector<float2> chirp((size_t)K), Bf((size_t)P);
+  std::vector<double> cre((size_t)K), cim((size_t)K), bre((size_t)P, 0.0), bim((size_t)P, 0.0);
+  for (int n = 0; n < K; ++n) {
+    const int64_t q = ((int64_t)n * n) % (2 * (int64_t)K);  // exact phase index
+    const double ang = -3.14159265358979323846 * (double)q / (double)K;
+    cre[n] = std::cos(ang); cim[n] = std::sin(ang);
+    chirp[n] = make_float2((float)cre[n], (float)cim[n]);
+  }
+  bre[0] = cre[0]; bim[0] = -cim[0];
+  for (int n = 1; n < K; ++n) { bre[n] = cre[n]; bim[n] = -cim[n]; bre[P - n] = cre[n]; bim[P - n] = -cim[n]; }
+  host_fft_f64(bre, bim);
+  for (int i = 0; i < P; ++i) Bf[i] = make_float2((float)(bre[i] / P), (float)(bim[i] / P));
+  const void *dc = nullptr, *db = nullptr;
+  int rc = ctx_table(c, 0xB10E0ull ^ (uint64_t)K, chirp.data(), chirp.size() * sizeof(float2), &dc);
+  if (rc) return rc;
+  rc = ctx_table(c, 0xB10E1ull ^ (uint64_t)K, Bf.data(), Bf.size() * sizeof(float2), &db);
+  if (rc) return rc;
+  t->K = K; t->P = P; t->logP = logP;
+  t->chirp = reinterpret_cast<const float2*>(dc);
+  t->Bf = reinterpret_cast<const float2*>(db);
+  return ctx_twiddles(c, P, &t->twP);
+}
+static bool use_bluestein(int K) { return !is_pow2(K) && K > 64 && K <= 4096; }
+
 static FrameGeom to_geom(const Framing& fr) {
   FrameGeom g;
   g.L = fr.L; g.lo = fr.lo; g.M = fr.M; g.N = fr.N; g.hop = fr.hop; g.reflect = fr.reflect;
@@ -545,6 +672,16 @@ int launch_stft_generic(Ctx* c, const StftLaunch& s) {
     if (rc) return rc;
     dim3 grid((unsigned)((s.fr.M + a.F - 1) / a.F), (unsigned)s.batch);
     hipLaunchKernelGGL(k_stft_pow2, grid, dim3(kThreads), lds, c->stream, a);
+  } else if (use_bluestein(s.K)) {
+    StftBlueArgs b;
+    b.s = a; b.s.logK = 0; b.s.F = 1;
+    rc = blue_tables(c, s.K, &b.t);
+    if (rc) return rc;
+    const size_t lds = (size_t)2 * b.t.P * sizeof(float2);
+    rc = ensure_lds(k_stft_blue, lds);
+    if (rc) return rc;
+    dim3 grid((unsigned)s.fr.M, (unsigned)s.batch);
+    hipLaunchKernelGGL(k_stft_blue, grid, dim3(kThreads), lds, c->stream, b);
   } else {
     if (s.K > 16384)
       return set_error(NXSIG_ERR_UNSUPPORTED, "stft: non-power-of-two fft_length > 16384 is not supported yet");
@@ -579,6 +716,22 @@ static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows
       rc = ensure_lds(k_fft_rows_pow2<false>, lds);
       if (rc) return rc;
       hipLaunchKernelGGL(k_fft_rows_pow2<false>, grid, dim3(kThreads), lds, c->stream, a);
+    }
+  } else if (use_bluestein(K)) {
+    FftBlueArgs b;
+    b.f = a; b.f.logK = 0; b.f.F = 1;
+    rc = blue_tables(c, K, &b.t);
+    if (rc) return rc;
+    const size_t lds = (size_t)2 * b.t.P * sizeof(float2);
+    dim3 grid((unsigned)rows);
+    if (inverse) {
+      rc = ensure_lds(k_fft_rows_blue<true>, lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_fft_rows_blue<true>, grid, dim3(kThreads), lds, c->stream, b);
+    } else {
+      rc = ensure_lds(k_fft_rows_blue<false>, lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_fft_rows_blue<false>, grid, dim3(kThreads), lds, c->stream, b);
     }
   } else {
     if (K > 16384) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: length > 16384 that is not a power of two <= 8192 is not supported yet");

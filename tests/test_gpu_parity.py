@@ -217,6 +217,30 @@ def test_stft_matches_oracle(case):
     assert np.array_equal(t, to, equal_nan=True) and np.array_equal(f, fo)
 
 
+@pytest.mark.parametrize("K,N,hop", [(100, 100, 25), (1000, 1000, 250), (400, 400, 160), (65, 65, 13), (3000, 3000, 750),
+                                     (4095, 4000, 1000), (640, 400, 160), (300, 500, 100), (4097, 4097, 2000), (7, 7, 3)])
+def test_stft_non_power_of_two_lengths(K, N, hop):
+    """Bluestein path for 64 < K <= 4096 (incl. zero-padded and truncated frames), direct DFT outside it"""
+    rng = np.random.default_rng(K)
+    x = rng.standard_normal((2, max(5 * N, 3000))).astype(np.float32)
+    w = S.windows.hamming(N)
+    for scaling in (None, "spectrum"):
+        opts = dict(overlap_length=N - hop, fft_length=K, scaling=scaling, sampling_rate=8000)
+        z, _, _ = S.stft(x, w, **opts)
+        zo, _, _ = O.stft(x, w, **opts)
+        assert_close(z, zo, f"K={K} N={N}")
+
+
+@pytest.mark.parametrize("n_in,K", [(100, 100), (1000, 1000), (257, 300), (3000, 2999), (66, 66)])
+def test_fft_rows_non_power_of_two_bluestein(n_in, K):
+    rng = np.random.default_rng(n_in + K)
+    a = (rng.standard_normal((3, n_in)) + 1j * rng.standard_normal((3, n_in))).astype(np.complex64)
+    assert_close(S.transforms.fft_nd(a, lengths=[K]), O.fft(a, length=K), "fft")
+    assert_close(S.transforms.ifft_nd(a, lengths=[K]), O.ifft(a, length=K), "ifft")
+    r = rng.standard_normal((3, n_in)).astype(np.float32)
+    assert_close(S.transforms.fft_nd(r, lengths=[K]), O.fft(r, length=K), "fft real")
+
+
 def test_stft_other_windows_and_integer_input():
     x = (np.arange(300) % 17 - 8).astype(np.int32)  # integer tensors are legal (B15)
     for w in (S.windows.hamming(32), S.windows.blackman(32), S.windows.kaiser(32, beta=8.0), S.windows.rectangular(32)):

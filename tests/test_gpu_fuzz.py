@@ -1,0 +1,117 @@
+"""Seeded differential fuzzing of the HIP path against the oracle: random frame lengths, hops, fft lengths (powers of
+two — tuned and generic —, Bluestein and direct-DFT lengths), padding modes, scalings, batch shapes, ragged tails.
+Deterministic (fixed seeds) so a failure reproduces."""
+import numpy as np
+import pytest
+
+from oracle import nx_oracle as O
+
+import nx_signal_amd as S
+
+pytestmark = pytest.mark.gpu
+
+FFT_LENGTHS = [8, 32, 64, 128, 256, 512, 1024, 2048, 4096, 100, 400, 640, 1000, 48, 3000]
+WINDOWS = ["hann", "hamming", "blackman", "bartlett", "triangular", "kaiser", "rectangular"]
+
+
+def nerr(got, ref):
+    d = np.abs(np.asarray(got).astype(np.complex128) - np.asarray(ref).astype(np.complex128))
+    return float(d.max()) / max(float(np.max(np.abs(ref))), 1e-30)
+
+
+def make_window(rng, n):
+    name = WINDOWS[rng.integers(len(WINDOWS))]
+    if name == "rectangular":
+        return S.windows.rectangular(n, type="f32")
+    if name in ("bartlett", "triangular"):
+        return getattr(S.windows, name)(n)
+    return getattr(S.windows, name)(n, is_periodic=bool(rng.integers(2)))
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_stft(seed):
+    rng = np.random.default_rng(1000 + seed)
+    K = FFT_LENGTHS[rng.integers(len(FFT_LENGTHS))]
+    N = int(rng.choice([K, K, K, max(2, K // 2), max(2, int(K * 0.8)), min(K + K // 4, 5000)]))
+    hop = int(rng.integers(1, N + 1))
+    bshape = [(), (), (2,), (3,), (2, 2)][rng.integers(5)]
+    pad = ["valid", "valid", "reflect", "same", [(int(rng.integers(0, N)), int(rng.integers(0, N)))]][rng.integers(5)]
+    M_target = int(rng.integers(1, 40))
+    L = max(N + (M_target - 1) * hop + int(rng.integers(0, hop)), 2 if pad == "reflect" else 1)
+    if pad == "reflect":
+        L = max(L, N // 2 + 2)
+    scaling = [None, None, "spectrum", "psd"][rng.integers(4)]
+    fs = float(rng.choice([100, 8000, 44100, 48000]))
+    x = rng.standard_normal(bshape + (L,)).astype(np.float32)
+    w = make_window(rng, N)
+    opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=fs)
+    z, t, f = S.stft(x, w, **opts)
+    zo, to, fo = O.stft(x, w, **opts)
+    assert z.shape == zo.shape, (opts, L)
+    assert np.all(np.isfinite(z.view(np.float32)))
+    assert nerr(z, zo) < 1e-5, (K, N, hop, L, pad, scaling, bshape, nerr(z, zo))
+    assert np.array_equal(t, to, equal_nan=True) and np.array_equal(f, fo)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_istft(seed):
+    rng = np.random.default_rng(2000 + seed)
+    N = int(rng.choice([8, 64, 100, 256, 512, 1024, 1024, 1024, 2048, 300]))
+    hop = int(rng.choice([N, N // 2, N // 4, max(1, N // 8), int(rng.integers(1, N + 1))]))
+    if N == 1024 and rng.integers(2):
+        hop = int(rng.choice([128, 256, 512, 1024]))  # the tuned kernel's hops
+    M = int(rng.integers(1, 70))
+    bshape = [(), (2,), (3,)][rng.integers(3)]
+    scaling = [None, "spectrum", "psd"][rng.integers(3)]
+    z = (rng.standard_normal(bshape + (M, N)) + 1j * rng.standard_normal(bshape + (M, N))).astype(np.complex64)
+    w = S.windows.hann(N) if rng.integers(2) else S.windows.hamming(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=16000)
+    y = S.istft(z, w, **opts)
+    yo = O.istft(z, w, **opts)
+    assert y.shape == yo.shape
+    assert nerr(y, yo) < 1e-5, (N, hop, M, bshape, scaling, nerr(y, yo))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_fir(seed):
+    rng = np.random.default_rng(3000 + seed)
+    taps = int(rng.choice([1, 3, 17, 64, 129, 257, 257, 385, 513, 700, 100, 255]))
+    L = int(rng.integers(1, 30000))
+    bshape = [(), (2,), (5,)][rng.integers(3)]
+    mode = ["full", "same", "valid"][rng.integers(3)]
+    x = rng.standard_normal(bshape + (L,)).astype(np.float32)
+    h = (rng.standard_normal(taps) / np.sqrt(taps)).astype(np.float32)
+    if len(bshape) == 0:
+        y = S.convolution.convolve(x, h, method="fft", mode=mode)
+        rows_x, rows_y = [x], [y]
+        if L < taps:  # operands are swapped internally; :same stays centred on in1
+            assert y.shape[0] == {"full": L + taps - 1, "same": L, "valid": taps - L + 1}[mode]
+    else:
+        y = S.filters.fir(x, h, mode=mode)
+        rows_x, rows_y = list(x), list(y)
+    for xr, yr in zip(rows_x, rows_y):
+        full = O.direct_convolve_f64(xr, h)
+        n = {"full": L + taps - 1, "same": L, "valid": abs(L - taps) + 1}[mode]
+        start = (full.shape[0] - n) // 2 if mode != "full" else 0
+        ref = full[start:start + n]
+        assert yr.shape == ref.shape, (taps, L, mode)
+        assert nerr(yr, ref) < 1e-5, (taps, L, mode, nerr(yr, ref))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_framing_and_ola(seed):
+    rng = np.random.default_rng(4000 + seed)
+    N = int(rng.integers(1, 200))
+    stride = int(rng.integers(1, N + 3))
+    L = int(rng.integers(N, 4000))
+    pad = ["valid", "reflect", "same", [(int(rng.integers(-3, 50)), int(rng.integers(-3, 50)))]][rng.integers(4)]
+    if pad == "reflect" and L < N // 2 + 2:
+        L = N // 2 + 2
+    x = rng.standard_normal((2, L)).astype(np.float32)
+    got = S.as_windowed(x, window_length=N, stride=stride, padding=pad)
+    exp = O.as_windowed(x, N, stride, pad)
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(exp).view(np.uint32)), (N, stride, L, pad)
+    M = int(rng.integers(1, 50))
+    ov = int(rng.integers(0, N))
+    fr = rng.standard_normal((2, M, N)).astype(np.float32)
+    assert np.array_equal(S.overlap_and_add(fr, overlap_length=ov).view(np.uint32), O.overlap_and_add(fr, ov).view(np.uint32))

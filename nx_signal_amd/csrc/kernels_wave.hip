@@ -669,6 +669,7 @@ struct IstftWaveArgs {
   const float* wtab;          // f32[K]
   const v2f* twB;
   const v2f* twC;
+  const v2f* twH;             // w_K^k0, k0 < K/2 (two-frames-per-FFT variant only)
   float scale;
   const float* den;           // f32[2R-1][hop]: RECIPROCAL of the guarded OLA normaliser: head segments 0..R-2, interior, tail segments
   v2f* y;                     // c64[batch][segs_per_row * hop]
@@ -775,6 +776,113 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
       // the table holds 1 / max-guarded normaliser (rounded from double): a multiply instead of 4 divisions, <= 1 ulp
       const v4f o = v4f{out[0][qq].x * den[qq].x, out[0][qq].y * den[qq].x, out[1][qq].x * den[qq].y, out[1][qq].y * den[qq].y};
       __builtin_nontemporal_store(o, (gv4f*)(yp + 128 * qq));
+    }
+  }
+}
+
+// ---- iSTFT for N = K/2 (512): TWO consecutive frames per 1024-point inverse FFT.  Z[k0] = C0 + w_K^k0 C1,
+// Z[k0 + K/2] = C0 - w_K^k0 C1 is built lane-locally in the core's input layout (k0 = lane + 64 s'), and the inverse
+// core returns sample n = lane + 64 q of frame 0 in zz[0][q] and of frame 1 in zz[1][q]: the overlap-add between the
+// two frames and with the pending sums stays in registers for every hop that is a multiple of 64.
+template <int K, int R, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) void k_istft_wave_half(IstftWaveArgs a) {
+  constexpr int NH = K / 2;              // frame length (= fft_length)
+  constexpr int R3 = K / 256;
+  constexpr int NQ = K / 128;            // samples per lane per frame (n = lane + 64 q, q < NQ)
+  constexpr int QS = NQ / R;             // samples per lane per hop segment
+  constexpr int XCH = K + K / 16 + 16;
+  static_assert(NQ % R == 0, "hop must be a multiple of 64");
+  float* s_w = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_twB = reinterpret_cast<v2f*>(s_w + NH);
+  v2f* s_twC = s_twB + 256;
+  v2f* s_twH = s_twC + R3 * 256;          // w_K^k0, k0 < K/2 (forward)
+  v2f* s_x = s_twH + NH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < NH; i += 64 * W) { s_w[i] = a.wtab[i]; s_twH[i] = a.twH[i]; }
+  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
+  for (int i = tid; i < R3 * 256; i += 64 * W) s_twC[i] = a.twC[i];
+  __syncthreads();
+  v2f* xb = s_x + wave * XCH;
+  const int64_t run = (int64_t)blockIdx.x * W + wave;
+  if (run >= a.total_runs) return;
+  const int64_t row = run / a.runs_per_row;
+  const int64_t j0 = (run - row * a.runs_per_row) * a.run_len;  // run_len is even
+  int64_t j1 = j0 + a.run_len;
+  if (j1 > a.segs_per_row) j1 = a.segs_per_row;
+  int64_t m_start = j0 >= (R - 1) ? j0 - (R - 1) : 0;
+  m_start &= ~(int64_t)1;                 // frame pairs start at even frames
+
+  float wv[NQ], tw_re[NQ], tw_im[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    wv[q] = s_w[lane + 64 * q];
+    const v2f t = s_twH[lane + 64 * q];
+    tw_re[q] = t.x; tw_im[q] = t.y;
+  }
+  const float invK = 1.0f / (float)K;
+  v2f pend[R - 1 > 0 ? R - 1 : 1][QS];
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i)
+#pragma unroll
+    for (int qq = 0; qq < QS; ++qq) pend[i][qq] = v2f{0.f, 0.f};
+
+  const v2f* zrow = a.z + (size_t)row * a.M * NH + lane;
+  v2f r0[NQ], r1[NQ];
+  auto issue_loads = [&](int64_t m) {
+    const int64_t last = a.M - 1;
+    const v2f* p0 = zrow + (size_t)(m < last ? m : last) * NH;
+    const v2f* p1 = zrow + (size_t)(m + 1 < last ? m + 1 : last) * NH;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { r0[q] = p0[64 * q]; r1[q] = p1[64 * q]; }
+  };
+  v2f d[2 * NQ];
+  auto combine = [&]() {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const v2f t = wcmul(r1[q], v2f{tw_re[q], tw_im[q]});
+      d[q] = r0[q] + t;
+      d[q + NQ] = r0[q] - t;
+    }
+  };
+  issue_loads(m_start);
+  combine();
+
+  for (int64_t m = m_start; m < j1; m += 2) {
+    issue_loads(m + 2 < j1 ? m + 2 : m);
+    __builtin_amdgcn_sched_barrier(0);
+    v2f zz[2][NQ];
+    wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    combine();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int64_t j = m + e;              // frame index = index of the segment it completes
+      const float live = j < a.M ? 1.0f : 0.0f;
+      const int64_t trow = j < R - 1 ? j : (j >= a.M ? R + (j - a.M) : R - 1);
+      const float* dp = a.den + trow * a.hop + lane;
+      const bool store = (j >= j0) && (j < j1);
+      v2f* yp = store ? a.y + (size_t)row * a.segs_per_row * a.hop + j * a.hop + lane : a.dummy + lane;
+#pragma unroll
+      for (int qq = 0; qq < QS; ++qq) {
+        v2f f[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          v2f v = zz[e][i * QS + qq] * invK;
+          if (SCALE) v = v * a.scale;
+          f[i] = v * (wv[i * QS + qq] * live);
+        }
+        v2f out;
+        if (R == 1) { out = f[0]; }
+        else {
+          out = pend[0][qq] + f[0];
+#pragma unroll
+          for (int i = 0; i + 1 < R - 1; ++i) pend[i][qq] = pend[i + 1][qq] + f[i + 1];
+          pend[R - 2][qq] = f[R - 1];
+        }
+        const float rd = dp[64 * qq];
+        __builtin_nontemporal_store(out * rd, (__attribute__((address_space(1))) v2f*)(yp + 64 * qq));
+      }
     }
   }
 }
@@ -1087,7 +1195,7 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   return NXSIG_OK;
 }
 
-template <int R, int W>
+template <int R, int W, bool HALF = false>
 static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window_padK, const float* window_host) {
   constexpr int K = 1024, R3 = K / 256, XCH = K + K / 16 + 16;
   IstftWaveArgs a;
@@ -1130,13 +1238,30 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", 8);
   if (run_len < min_run) run_len = min_run;
+  if (HALF) run_len = (run_len + 1) & ~(int64_t)1;  // frame pairs: runs start at even segments
   a.run_len = run_len;
   a.runs_per_row = (a.segs_per_row + run_len - 1) / run_len;
   a.total_runs = a.runs_per_row * s.batch;
-  const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8;
   const int64_t blocks = (a.total_runs + W - 1) / W;
-  if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-  else hipLaunchKernelGGL((k_istft_wave<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+  if (HALF) {
+    std::vector<float2> twH((size_t)K / 2);
+    for (int k0 = 0; k0 < K / 2; ++k0) {
+      const double ang = -6.283185307179586476925286766559 * (double)k0 / (double)K;
+      twH[k0] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    const void* dh = nullptr;
+    int rc4 = ctx_table(c, 0x7748ull ^ (uint64_t)K, twH.data(), twH.size() * sizeof(float2), &dh);
+    if (rc4) return rc4;
+    a.twH = reinterpret_cast<const v2f*>(dh);
+    const size_t lds = (size_t)(K / 2) * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)(K / 2) * 8 + (size_t)W * XCH * 8;
+    if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_half<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    else hipLaunchKernelGGL((k_istft_wave_half<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+  } else {
+    a.twH = nullptr;
+    const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8;
+    if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    else hipLaunchKernelGGL((k_istft_wave<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+  }
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
 }
@@ -1191,9 +1316,23 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
   *handled = false;
   if (s.M == 0 || s.batch == 0) return NXSIG_OK;
   if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (window_host == nullptr) return NXSIG_OK;
+  if (s.K == 512 && s.N == 512) {  // two frames per 1024-point inverse FFT
+    if (s.hop != 64 && s.hop != 128 && s.hop != 256 && s.hop != 512) return NXSIG_OK;
+    if (s.M < 2 * (512 / s.hop) - 1) return NXSIG_OK;
+    int rc5 = ensure_wave_tables_1024(c);
+    if (rc5) return rc5;
+    *handled = true;
+    switch (512 / s.hop) {
+      case 1: return launch_istft_wave_R<1, 4, true>(c, s, s.window, window_host);
+      case 2: return launch_istft_wave_R<2, 4, true>(c, s, s.window, window_host);
+      case 4: return launch_istft_wave_R<4, 4, true>(c, s, s.window, window_host);
+      default: return launch_istft_wave_R<8, 4, true>(c, s, s.window, window_host);
+    }
+  }
   if (s.K != 1024 || s.N != 1024) return NXSIG_OK;       // other sizes: generic two-stage path
   if (s.hop != 128 && s.hop != 256 && s.hop != 512 && s.hop != 1024) return NXSIG_OK;
-  if (s.M < 2 * (1024 / s.hop) - 1 || window_host == nullptr) return NXSIG_OK;  // head and tail rows must not overlap
+  if (s.M < 2 * (1024 / s.hop) - 1) return NXSIG_OK;  // head and tail rows must not overlap
   int rc = ensure_wave_tables_1024(c);
   if (rc) return rc;
   *handled = true;

@@ -95,6 +95,21 @@ def test_istft_wave_all_hops_and_run_seams(hop, M):
         assert nerr(y, yo) < 1e-5, (hop, M, scaling, nerr(y, yo))
 
 
+@pytest.mark.parametrize("hop", [64, 128, 256, 512])
+@pytest.mark.parametrize("M", [3, 16, 17, 64, 301])
+def test_istft_wave_half_n512(hop, M):
+    """N = 512: two frames per 1024-point inverse FFT (odd and even frame counts, every supported hop, run seams)"""
+    N = 512
+    rng = np.random.default_rng(hop * 7 + M)
+    z = (rng.standard_normal((3, M, N)) + 1j * rng.standard_normal((3, M, N))).astype(np.complex64)
+    w = S.windows.hann(N)
+    for scaling in (None, "psd"):
+        y = S.istft(z, w, overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=16000)
+        yo = O.istft(z, w, overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=16000)
+        assert y.shape == yo.shape
+        assert nerr(y, yo) < 1e-5, (hop, M, scaling, nerr(y, yo))
+
+
 def test_istft_rectangular_window_no_edge_fix_needed():
     N, hop, M = 1024, 256, 40
     rng = np.random.default_rng(3)

@@ -73,6 +73,27 @@ def main():
             b = 16
             Lg = (1700 * 1024 * 1024 // (b * 8 * 4)) // n * n  # hop = n/4 -> 8n bytes out per hop samples
             stft_case(ctx, n, n // 4, Lg, b, f"stft N={n} hop={n // 4}, {b} rows (generic kernels unless tuned)")
+    for name in which:
+        if name.startswith("ist") and name != "istft":  # e.g. ist512: generic-path istft sizes
+            n = int(name[3:]); hop = n // 4; b = 8
+            Mi = (900 * 1024 * 1024 // (b * n * 8))
+            w = S.windows.hann(n)
+            rng = np.random.Generator(np.random.PCG64(5))
+            zrow = (rng.standard_normal((64, n), dtype=np.float32) + 1j * rng.standard_normal((64, n), dtype=np.float32)).astype(np.complex64)
+            zd = ctx.empty((b, Mi, n), np.complex64)
+            for r in range(b):
+                for blk in range(0, Mi, 64):
+                    cnt = min(64, Mi - blk)
+                    _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(zd.ptr + ((r * Mi + blk) * n) * 8), zrow.ctypes.data_as(C.c_void_p), cnt * n * 8))
+            out_len = Mi * hop + n - hop
+            yd = ctx.empty((b, out_len), np.complex64)
+            p = _lib.StftParams(n, hop, n, 0, 0, 0, 0, 0, 48000.0)
+            wp = w.ctypes.data_as(C.c_void_p)
+            fn = lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(zd.ptr), Mi, b, wp, C.byref(p), C.c_void_p(yd.ptr), _lib.DEVICE))
+            ms = timeit(ctx, fn, reps=10, warm=5)
+            gbs = b * Mi * (n * 8 + hop * 8) / (ms * 1e-3) / 1e9
+            print(json.dumps({"case": f"istft N={n} hop={hop}, {b} rows", "ms": ms, "frames_per_s": b * Mi / (ms * 1e-3), "algorithmic_GBps": gbs,
+                              "frac_of_8TBps": gbs / PEAK}), flush=True)
     if "mel" in which:
         N, hop, L, batch, mb = 1024, 256, 2880000, 32, 128
         w = S.windows.hann(N)

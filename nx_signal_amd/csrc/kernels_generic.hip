@@ -1,17 +1,21 @@
 // Generic gfx950 kernels of the STFT / iSTFT / FIR path: correct for EVERY shape the reference accepts
-// (any frame length, hop, fft_length, padding mode, batch).  The tuned wave-per-frame kernels in
-// kernels_stft_wave.hip take over for the power-of-two sizes the benchmarks run.
+// (any frame length, hop, fft_length, padding mode, batch).  The tuned wave kernels in kernels_wave.hip take over for
+// fft_length 128..2048 (stft), N = 512 / 1024 (istft) and <= 513 taps (fir).
 //
-//   k_stft_pow2      frame slice x window -> workgroup Stockham radix-4/2 FFT in LDS -> scale -> c64 store
-//   k_stft_dft       same fusion for non-power-of-two fft_length (direct DFT, table twiddles)
-//   k_fft_rows_*     Nx.fft / Nx.ifft(length:) over rows (+ optional x scale x window epilogue for istft)
-//   k_ola            deterministic overlap-add (+ |w|^2 normaliser with the 1e-10 guard) in fixed frame order
-//   k_as_windowed    framing gather
-//   k_fir_os         overlap-save block convolution, two real blocks packed as re/im of one complex FFT
+//   k_stft_pow2       frame slice x window -> workgroup Stockham radix-4/2 FFT in LDS -> scale -> c64 store
+//   k_stft_blue       non-power-of-two fft_length 65..4096: Bluestein chirp-z through the same LDS FFT
+//   k_stft_dft        remaining lengths: direct DFT, table twiddles, double accumulation
+//   k_fft_rows_*      Nx.fft / Nx.ifft(length:) over rows (+ optional x scale x window epilogue for istft)
+//   k_ola             deterministic overlap-add (+ |w|^2 normaliser with the 1e-10 guard) in fixed frame order
+//   k_istft_edge_fix  f64 recomputation of the few ill-conditioned OLA samples (see the comment at the kernel)
+//   k_as_windowed     framing gather
+//   k_fir_os          overlap-save block convolution, two real blocks packed as re/im of one complex FFT
+//   k_cmul_inplace    pointwise product of complex fftconvolve
+//   k_mel_pass1/2     stft_to_mel: sparse band sums + log10, global max, clamp
 //
 // Twiddles are generated on the host in double and read from a table (never __sinf/__cosf).
-// Reference lines: lib/nx_signal.ex:94-102 (frame/window/fft), :113-127 (scaling), :609-637 (istft),
-// :684-736 (overlap_and_add), lib/nx_signal/convolution.ex:252-329 (fftconvolve).
+// Reference lines: lib/nx_signal.ex:94-102 (frame/window/fft), :113-127 (scaling), :486-513 (stft_to_mel),
+// :609-637 (istft), :684-736 (overlap_and_add), lib/nx_signal/convolution.ex:252-329 (fftconvolve).
 #include <hip/hip_runtime.h>
 
 #include "nxsig_internal.h"

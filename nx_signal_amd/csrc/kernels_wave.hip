@@ -1,16 +1,26 @@
-// Tuned gfx950 STFT kernel: ONE WAVE transforms TWO adjacent real frames as the real / imaginary lanes of one
-// K-point complex FFT (K = 1024 or 2048), entirely wave-private — no workgroup barrier anywhere.
+// Tuned gfx950 kernels built around ONE wave-private 1024-point complex FFT core (wave_fft_core / wave_fft_core_T):
+// 64 lanes x 16 points, radix 16 x 16 x 4, two LDS exchanges in an 8.8 KB wave-private buffer, no workgroup barrier
+// after the table preload.  Every kernel below is a different way of feeding that core and draining it:
 //
+//   k_stft_wave       pair   : two adjacent real frames as re / im                        fft_length 1024
+//                     real-2x: one 2048-sample frame as even / odd samples                fft_length 2048
+//                     quad   : 2J frames, J complex sequences interleaved (J = 2, 4, 8)   fft_length 512 / 256 / 128
+//   k_stft_mel_wave   pair mode + |X|^2 -> sparse mel filterbank -> log10 (fused stft_to_mel)
+//   k_istft_wave      one complex frame per inverse FFT, run of frames per wave, pending overlap sums in registers (N = 1024)
+//   k_istft_wave_half two consecutive frames per inverse FFT (N = 512)
+//   k_fir_wave        overlap-save: transposed-pass forward FFT -> x H -> inverse core, two blocks as re / im
+//
+// The core in pair mode, step by step:
 //   global load (frame slice x window fused, lib/nx_signal.ex:94-101)          64 lanes x P = K/64 points
 //   pass A  radix-16, registers                      -> LDS exchange 1 (padded e + e/16: conflict-free)
 //   pass B  radix-16, twiddles w_256^(t k) from LDS  -> LDS exchange 2
-//   pass C  radix-4 (K=1024) / radix-8 (K=2048), butterflies i = 2l+e+128u so every lane owns ADJACENT bins
+//   pass C  radix-4, butterflies i = 2l+e+128u so every lane owns ADJACENT bins
 //   Hermitian untangle of the two real spectra through partner lanes (ds_bpermute, no LDS storage):
 //           XA[k] = (Z[k] + conj Z[K-k]) / 2 ,  XB[k] = -i (Z[k] - conj Z[K-k]) / 2
 //   optional :spectrum / :psd division (lib/nx_signal.ex:113-127), 16-byte non-temporal stores of the full
 //   two-sided c64 spectrum (:129), 1 KiB per wave instruction.
 //
-// The path is HBM-bound (9 216 algorithmic B/frame at K=1024, 89 % stores), MFMA is deliberately unused.
+// The STFT path is HBM-bound (9 216 algorithmic B/frame at K=1024, 89 % stores), MFMA is deliberately unused.
 // Index math and LDS bank behaviour are modelled lane by lane in tools/emulate_wave_fft.py.
 #include <hip/hip_runtime.h>
 

@@ -413,3 +413,38 @@ def test_fir_config5_one_million_samples_batched():
     for ch in range(4):
         full = O.direct_convolve_f64(x[ch], h)
         assert_close(y[ch], full[128:128 + 1_000_000].astype(np.float32), f"ch{ch}")
+
+
+def test_stft_config4_shard_full_size_beyond_4gb():
+    """BASELINE config 4, one GPU's shard at FULL size: 8 channels x 10 min @ 48 kHz, N=2048 hop=512 -> 8 x 56 247
+    frames = 7.37 GB of spectrum.  Frames sampled across the whole output (incl. byte offsets > 4 GiB) are compared
+    with the oracle; guards the 64-bit index arithmetic of the kernels."""
+    import ctypes as C
+
+    from nx_signal_amd import _lib
+
+    ch, L, N, hop = 8, 28_800_000, 2048, 512
+    M = (L - N) // hop + 1
+    assert M == 56247
+    ctx = S.default_context()
+    lib = _lib.load()
+    base = O.synth_signal(L, seed=4321)
+    xd = ctx.empty((ch, L), np.float32)
+    rows = []
+    for c in range(ch):
+        xr = np.roll(base, 100_003 * c) * np.float32(1.0 + 0.1 * c)
+        rows.append(xr)
+        _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(xd.ptr + c * L * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+    zd, _, _ = S.stft(xd, w, **opts)
+    assert zd.shape == (ch, M, N) and zd.nbytes == ch * M * N * 8 > 6 * 2**30
+    ctx.sync()
+    for c, m in [(0, 0), (0, M - 1), (3, 12345), (4, 33000), (5, 17), (7, M - 1), (7, M - 2), (6, 50001)]:
+        got = np.empty(N, np.complex64)
+        off = (c * M + m) * N * 8
+        _lib.check(lib.nxsig_download(ctx.handle, got.ctypes.data_as(C.c_void_p), C.c_void_p(zd.ptr + off), got.nbytes))
+        ref, _, _ = O.stft(rows[c][m * hop: m * hop + N], w, **opts)
+        assert_close(got, ref[0], f"channel {c} frame {m} (byte offset {off})")
+    zd.free()
+    xd.free()

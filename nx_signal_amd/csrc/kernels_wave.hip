@@ -897,6 +897,95 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_half(IstftWaveArgs a) {
   }
 }
 
+// ---- iSTFT for N = 2K (2048): ONE frame per TWO 1024-point inverse FFTs (decimation in frequency).  A 16-byte load
+// yields Z[2k'] and Z[2k'+1] together; E = IDFT_K(even bins), O = IDFT_K(odd bins) come out of the inverse core in the
+// adjacent-pair layout, and x[n] = E[n] + t O[n], x[n + K] = E[n] - t O[n], t = exp(+2 pi i n / 2K), is lane-local,
+// as is the overlap-add for every hop that is a multiple of 128.
+template <int K, int R, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) void k_istft_wave_dbl(IstftWaveArgs a) {
+  constexpr int N2 = 2 * K;              // frame length (= fft_length)
+  constexpr int P = K / 64;
+  constexpr int R3 = K / 256;
+  constexpr int NQ = K / 128;
+  constexpr int NQ2 = 2 * NQ;            // q' values of 128 samples per frame, per parity
+  constexpr int QS = NQ2 / R;            // q' values per hop segment
+  constexpr int XCH = K + K / 16 + 16;
+  static_assert(NQ2 % R == 0, "hop must be a multiple of 128");
+  float* s_w = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_twB = reinterpret_cast<v2f*>(s_w + N2);
+  v2f* s_twC = s_twB + 256;
+  v2f* s_twH = s_twC + R3 * 256;          // exp(+2 pi i n / 2K), n < K
+  v2f* s_x = s_twH + K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < N2; i += 64 * W) s_w[i] = a.wtab[i];
+  for (int i = tid; i < K; i += 64 * W) s_twH[i] = a.twH[i];
+  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
+  for (int i = tid; i < R3 * 256; i += 64 * W) s_twC[i] = a.twC[i];
+  __syncthreads();
+  v2f* xb = s_x + wave * XCH;
+  const int64_t run = (int64_t)blockIdx.x * W + wave;
+  if (run >= a.total_runs) return;
+  const int64_t row = run / a.runs_per_row;
+  const int64_t j0 = (run - row * a.runs_per_row) * a.run_len;
+  int64_t j1 = j0 + a.run_len;
+  if (j1 > a.segs_per_row) j1 = a.segs_per_row;
+  const int64_t m_start = j0 >= (R - 1) ? j0 - (R - 1) : 0;
+  const float invN = 1.0f / (float)N2;
+  v2f pend[R - 1 > 0 ? R - 1 : 1][2][QS];
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int qq = 0; qq < QS; ++qq) pend[i][e][qq] = v2f{0.f, 0.f};
+
+  const v4f* zrow = reinterpret_cast<const v4f*>(a.z + (size_t)row * a.M * N2) + lane;
+  for (int64_t m = m_start; m < j1; ++m) {
+    // ---- load even / odd bins (k' = lane + 64 s): one 16-byte load per point pair
+    const v4f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * K;
+    v2f de[P], dq[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) { const v4f v = pz[64 * s]; de[s] = v2f{v.x, v.y}; dq[s] = v2f{v.z, v.w}; }
+    v2f ze[2][NQ], zo[2][NQ];
+    wave_fft_core<K, true>(de, ze, xb, s_twB, s_twC, lane);
+    wave_fft_core<K, true>(dq, zo, xb, s_twB, s_twC, lane);
+    const float live = m < a.M ? 1.0f : 0.0f;
+    const int64_t j = m;
+    const int64_t trow = j < R - 1 ? j : (j >= a.M ? R + (j - a.M) : R - 1);
+    const float* dp = a.den + trow * a.hop + 2 * lane;
+    v2f* yp = (j >= j0) ? a.y + (size_t)row * a.segs_per_row * a.hop + j * a.hop + 2 * lane : a.dummy + 2 * lane;
+    // frame samples x[n'] for n' = 2 lane + e + 128 q', q' < NQ2 (q' >= NQ is the upper half n + K)
+    auto sample = [&](int e, int qp) -> v2f {
+      const int q = qp % NQ;
+      const v2f t = s_twH[2 * lane + e + 128 * q];
+      const v2f to = wcmul(zo[e][q], t);
+      v2f v = (qp < NQ ? ze[e][q] + to : ze[e][q] - to) * invN;
+      if (SCALE) v = v * a.scale;
+      return v * (s_w[2 * lane + e + 128 * qp] * live);
+    };
+#pragma unroll
+    for (int qq = 0; qq < QS; ++qq) {
+      v2f out[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        v2f f[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) f[i] = sample(e, i * QS + qq);
+        if (R == 1) { out[e] = f[0]; }
+        else {
+          out[e] = pend[0][e][qq] + f[0];
+#pragma unroll
+          for (int i = 0; i + 1 < R - 1; ++i) pend[i][e][qq] = pend[i + 1][e][qq] + f[i + 1];
+          pend[R - 2][e][qq] = f[R - 1];
+        }
+      }
+      const v2f rd = *reinterpret_cast<const v2f*>(dp + 128 * qq);
+      const v4f o = v4f{out[0].x * rd.x, out[0].y * rd.x, out[1].x * rd.y, out[1].y * rd.y};
+      __builtin_nontemporal_store(o, (gv4f*)(yp + 128 * qq));
+    }
+  }
+}
+
 // ============================================================================================ FIR (overlap-save)
 // y = x * h by overlap-save block FFT convolution (the `Filters.fir` of BASELINE config 5; equals the reference's
 // Convolution.convolve(x, h, method: :fft) of lib/nx_signal/convolution.ex:252-329 to fp32 rounding).  One wave
@@ -1205,7 +1294,7 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   return NXSIG_OK;
 }
 
-template <int R, int W, bool HALF = false>
+template <int R, int W, bool HALF = false, bool DBL = false>
 static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window_padK, const float* window_host) {
   constexpr int K = 1024, R3 = K / 256, XCH = K + K / 16 + 16;
   IstftWaveArgs a;
@@ -1244,7 +1333,7 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t total_segs = a.segs_per_row * s.batch;
-  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", 12);
+  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", DBL ? 8 : 12);  // = resident waves per CU: one even round
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", 8);
   if (run_len < min_run) run_len = min_run;
@@ -1266,6 +1355,19 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
     const size_t lds = (size_t)(K / 2) * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)(K / 2) * 8 + (size_t)W * XCH * 8;
     if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_half<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     else hipLaunchKernelGGL((k_istft_wave_half<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+  } else if (DBL) {
+    std::vector<float2> twH((size_t)K);
+    for (int n = 0; n < K; ++n) {
+      const double ang = 6.283185307179586476925286766559 * (double)n / (double)(2 * K);
+      twH[n] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    const void* dh = nullptr;
+    int rc4 = ctx_table(c, 0x7749ull ^ (uint64_t)K, twH.data(), twH.size() * sizeof(float2), &dh);
+    if (rc4) return rc4;
+    a.twH = reinterpret_cast<const v2f*>(dh);
+    const size_t lds = (size_t)(2 * K) * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)K * 8 + (size_t)W * XCH * 8;
+    if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_dbl<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    else hipLaunchKernelGGL((k_istft_wave_dbl<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
   } else {
     a.twH = nullptr;
     const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8;
@@ -1338,6 +1440,19 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
       case 2: return launch_istft_wave_R<2, 4, true>(c, s, s.window, window_host);
       case 4: return launch_istft_wave_R<4, 4, true>(c, s, s.window, window_host);
       default: return launch_istft_wave_R<8, 4, true>(c, s, s.window, window_host);
+    }
+  }
+  if (s.K == 2048 && s.N == 2048) {  // one frame per two 1024-point inverse FFTs
+    if (s.hop != 256 && s.hop != 512 && s.hop != 1024 && s.hop != 2048) return NXSIG_OK;
+    if (s.M < 2 * (2048 / s.hop) - 1) return NXSIG_OK;
+    int rc5 = ensure_wave_tables_1024(c);
+    if (rc5) return rc5;
+    *handled = true;
+    switch (2048 / s.hop) {
+      case 1: return launch_istft_wave_R<1, 4, false, true>(c, s, s.window, window_host);
+      case 2: return launch_istft_wave_R<2, 4, false, true>(c, s, s.window, window_host);
+      case 4: return launch_istft_wave_R<4, 4, false, true>(c, s, s.window, window_host);
+      default: return launch_istft_wave_R<8, 4, false, true>(c, s, s.window, window_host);
     }
   }
   if (s.K != 1024 || s.N != 1024) return NXSIG_OK;       // other sizes: generic two-stage path

@@ -110,6 +110,22 @@ def test_istft_wave_half_n512(hop, M):
         assert nerr(y, yo) < 1e-5, (hop, M, scaling, nerr(y, yo))
 
 
+@pytest.mark.parametrize("hop", [256, 512, 1024, 2048])
+@pytest.mark.parametrize("M", [2, 9, 15, 64, 157])
+def test_istft_wave_dbl_n2048(hop, M):
+    """N = 2048: one frame per two 1024-point inverse FFTs (even / odd bins); every supported hop, run seams, and
+    frame counts below 2R-1 that take the generic path"""
+    N = 2048
+    rng = np.random.default_rng(hop * 3 + M)
+    z = (rng.standard_normal((2, M, N)) + 1j * rng.standard_normal((2, M, N))).astype(np.complex64)
+    w = S.windows.hann(N)
+    for scaling in (None, "spectrum"):
+        y = S.istft(z, w, overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=48000)
+        yo = O.istft(z, w, overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=48000)
+        assert y.shape == yo.shape
+        assert nerr(y, yo) < 1e-5, (hop, M, scaling, nerr(y, yo))
+
+
 def test_istft_rectangular_window_no_edge_fix_needed():
     N, hop, M = 1024, 256, 40
     rng = np.random.default_rng(3)

@@ -43,30 +43,53 @@ enum : int {
                     // k0 + (C/J) m share a lane, so the C_j separate with a lane-local inverse radix-J butterfly  (fft_length == C/J)
 };
 
-__device__ __forceinline__ v2f wcmul(v2f a, v2f b) { return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// ---- packed-FP32 helpers.  gfx950 issues v_pk_{mul,add,fma}_f32 at full rate (two floats per lane per instruction),
+// and VOP3P source modifiers (op_sel / op_sel_hi pick the low or high half per result half, neg_lo / neg_hi negate per
+// half) make a complex multiply two instructions and a +-i rotation free inside the add that consumes it.  The compiler
+// folds neither per-half negation nor the half swap (it emits 4-5 instructions per complex multiply), hence the asm.
+// a * b
+__device__ __forceinline__ v2f wcmul(v2f a, v2f b) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));             // (a.y b.y, a.y b.x)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (a.x b.x - t.x, a.x b.y + t.y)
+  return r;
+}
+// x + (-i) y = (x.x + y.y, x.y - y.x)      and      x + (+i) y = (x.x - y.y, x.y + y.x)
+__device__ __forceinline__ v2f add_mi(v2f x, v2f y) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ v2f add_pi(v2f x, v2f y) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
 // a * (-i) for the forward transform, a * (+i) for the inverse (INV)
 template <bool INV>
 __device__ __forceinline__ v2f rot90(v2f a) { return INV ? v2f{-a.y, a.x} : v2f{a.y, -a.x}; }
 // a * conj^INV(c + i s) for a compile-time constant twiddle given as (cos, -sin) of the forward transform
 template <bool INV>
 __device__ __forceinline__ v2f cmulc(v2f a, float c, float ms) { return wcmul(a, v2f{c, INV ? -ms : ms}); }
-// a * (1 -+ i)/sqrt2  and  a * (-1 -+ i)/sqrt2
+// a * (1 -+ i)/sqrt2  and  a * (-1 -+ i)/sqrt2:  (1 - i) a = a + (-i) a = add_mi(a, a),  (1 + i) a = add_pi(a, a)
 template <bool INV>
 __device__ __forceinline__ v2f rot45(v2f a) {
   const float h = 0.70710678118654752f;
-  return INV ? v2f{(a.x - a.y) * h, (a.x + a.y) * h} : v2f{(a.x + a.y) * h, (a.y - a.x) * h};
+  return (INV ? add_pi(a, a) : add_mi(a, a)) * h;
 }
 template <bool INV>
 __device__ __forceinline__ v2f rot135(v2f a) {
-  const float h = 0.70710678118654752f;
-  return INV ? v2f{-(a.x + a.y) * h, (a.x - a.y) * h} : v2f{(a.y - a.x) * h, -(a.x + a.y) * h};
+  const float h = -0.70710678118654752f;   // (-1 - i) = -(1 + i),  (-1 + i) = -(1 - i)
+  return (INV ? add_mi(a, a) : add_pi(a, a)) * h;
 }
 
 // natural-order DFTs on registers (forward: e^{-2 pi i ..}; INV: e^{+2 pi i ..}, unscaled)
 template <bool INV = false>
 __device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
-  const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = rot90<INV>(a1 - a3);
-  a0 = s02 + s13; a1 = d02 + d13; a2 = s02 - s13; a3 = d02 - d13;
+  const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, e13 = a1 - a3;
+  a0 = s02 + s13; a2 = s02 - s13;
+  a1 = INV ? add_pi(d02, e13) : add_mi(d02, e13);
+  a3 = INV ? add_mi(d02, e13) : add_pi(d02, e13);
 }
 
 template <bool INV = false>

@@ -35,6 +35,38 @@ __global__ __launch_bounds__(256) void k_stftmix(const float4* __restrict__ in, 
   }
 }
 
+
+// read-only: float4 loads, xor-reduced, one conditional store per thread (never taken)
+__global__ __launch_bounds__(256) void k_read(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { float4 v = in[i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+  if (acc.x == 12345.678f) out[threadIdx.x] = acc;
+}
+// istft mix: one wave per frame reads 8 KiB (LB bytes per lane per load) and NT-stores 2 KiB
+template <int LB>
+__global__ __launch_bounds__(256) void k_istftmix(const float* __restrict__ in, float4* __restrict__ out, size_t frames, size_t chunk) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  size_t f0 = wave * chunk, f1 = f0 + chunk; if (f1 > frames) f1 = frames;
+  for (size_t f = f0; f < f1; ++f) {
+    v4f acc = {0, 0, 0, 0};
+    if (LB == 16) {
+      const v4f* p = reinterpret_cast<const v4f*>(in + f * 2048) + lane;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += p[64 * j];
+    } else {
+      const v2f* p = reinterpret_cast<const v2f*>(in + f * 2048) + lane;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { v2f v = p[64 * j]; acc.x += v.x; acc.y += v.y; }
+    }
+    v4f* o = reinterpret_cast<v4f*>(out) + f * 128 + lane;
+    __builtin_nontemporal_store(acc, o);
+    __builtin_nontemporal_store(acc + 1.0f, o + 64);
+  }
+}
+
 int main(int argc, char** argv) {
   size_t mib = argc > 1 ? atol(argv[1]) : 2048;
   size_t bytes = mib << 20;
@@ -58,6 +90,20 @@ int main(int argc, char** argv) {
     printf("stftmix  grid %6d: %8.3f ms  %7.1f GB/s (9216 B/frame) %7.1f Mframes/s\n", grid, ms, frames * 9216.0 / ms / 1e6, frames / ms / 1e3);
     ms = time([&] { hipLaunchKernelGGL(k_stftmix<1>, dim3(grid), dim3(256), 0, 0, a, b, frames); }, 20);
     printf("stftmix nt    %6d: %8.3f ms  %7.1f GB/s\n", grid, ms, frames * 9216.0 / ms / 1e6);
+  }
+  for (int grid : {2048, 8192, 16384}) {
+    float ms = time([&] { hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, a, b, n); }, 20);
+    printf("read     grid %6d: %8.3f ms  %7.1f GB/s (r)\n", grid, ms, 1.0 * bytes / ms / 1e6);
+  }
+  {
+    size_t fr = bytes / 8192;
+    for (size_t chunk : {8, 16, 64, 256}) {
+      unsigned grid = (unsigned)((fr + chunk * 4 - 1) / (chunk * 4));
+      float ms = time([&] { hipLaunchKernelGGL(k_istftmix<16>, dim3(grid), dim3(256), 0, 0, (const float*)a, b, fr, chunk); }, 20);
+      printf("istftmix 16B chunk %4zu: %8.3f ms  %7.1f GB/s (10240 B/frame)\n", chunk, ms, fr * 10240.0 / ms / 1e6);
+      ms = time([&] { hipLaunchKernelGGL(k_istftmix<8>, dim3(grid), dim3(256), 0, 0, (const float*)a, b, fr, chunk); }, 20);
+      printf("istftmix  8B chunk %4zu: %8.3f ms  %7.1f GB/s\n", chunk, ms, fr * 10240.0 / ms / 1e6);
+    }
   }
   return 0;
 }

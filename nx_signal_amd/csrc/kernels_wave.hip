@@ -1161,6 +1161,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 static int ensure_wave_tables_1024(Ctx* c);
+static int ensure_wave_tables(Ctx* c, int C);
 
 // C = complex core size (1024 here), MODE = front-end, W = waves per workgroup
 template <int C, int MODE, int W, int J = 2>
@@ -1176,8 +1177,8 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
   a.total_pairs = a.pairs_per_row * s.batch;
   a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
 
-  static_assert(C == 1024, "only the 1024-point core is instantiated");
-  { int rc = ensure_wave_tables_1024(c); if (rc) return rc; }
+  static_assert(C == 1024 || C == 2048, "wave_fft_core covers 1024 (16*16*4) and 2048 (16*16*8, two butterflies per lane)");
+  { int rc = ensure_wave_tables(c, C); if (rc) return rc; }
   Ctx::WaveTables& wt = c->wave_tables[C];
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
@@ -1308,6 +1309,12 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
     *handled = true;
     return launch_wave<1024, kModeQuad, 4, 8>(c, s);
   }
+  if (s.K == 4096) {  // one frame as even/odd samples of a 2048-point complex FFT (32 points per lane)
+    *handled = true;
+    if (w == 2) return launch_wave<2048, kModeReal2x, 2>(c, s);
+    if (w == 6) return launch_wave<2048, kModeReal2x, 6>(c, s);
+    return launch_wave<2048, kModeReal2x, 4>(c, s);
+  }
   if (s.K == 2048) {  // one frame as even/odd samples of a 1024-point complex FFT
     *handled = true;
     if (w == 12) return launch_wave<1024, kModeReal2x, 12>(c, s);
@@ -1401,8 +1408,8 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   return NXSIG_OK;
 }
 
-static int ensure_wave_tables_1024(Ctx* c) {
-  constexpr int C = 1024, R3 = 4;
+static int ensure_wave_tables(Ctx* c, const int C) {
+  const int R3 = C / 256;
   const double two_pi = 6.283185307179586476925286766559;
   Ctx::WaveTables& wt = c->wave_tables[C];
   if (wt.twB) return NXSIG_OK;
@@ -1427,7 +1434,7 @@ static int ensure_wave_tables_1024(Ctx* c) {
   if (rc) { wt.twB = nullptr; return rc; }
   rc = ctx_table(c, 0x7744ull ^ (uint64_t)C, twR.data(), twR.size() * sizeof(float2), &wt.twI);
   if (rc) { wt.twB = nullptr; return rc; }
-  for (int ji = 0; ji < 3; ++ji) {  // quad front-ends J = 2, 4, 8: [j-1][k0] = conj(w_C^(j k0)), k0 < C/J
+  for (int ji = 0; ji < 3 && C == 1024; ++ji) {  // quad front-ends J = 2, 4, 8: [j-1][k0] = conj(w_C^(j k0)), k0 < C/J
     const int Jv = 2 << ji, KO = C / Jv;
     std::vector<float2> twQ((size_t)(Jv - 1) * KO);
     for (int j = 1; j < Jv; ++j)
@@ -1446,6 +1453,8 @@ static int ensure_wave_tables_1024(Ctx* c) {
   if (rc) { wt.twB = nullptr; return rc; }
   return NXSIG_OK;
 }
+
+static int ensure_wave_tables_1024(Ctx* c) { return ensure_wave_tables(c, 1024); }
 
 int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   *handled = false;

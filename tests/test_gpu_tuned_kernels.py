@@ -42,6 +42,11 @@ def nerr(got, ref):
     (2048, 2048, 512, 2048 + 512 * 9, 3),        # real-2x front-end, odd M, 3 rows
     (2048, 2048, 511, 50000, 1),                 # odd hop: unaligned 4-byte loads
     (2048, 1024, 256, 30000, 2),                 # N < K on the real-2x front-end
+    (4096, 4096, 1024, 4096 + 1024 * 9, 3),      # 2048-point core (32 points per lane), real-2x front-end
+    (4096, 4096, 1023, 90000, 1),                # odd hop
+    (4096, 2048, 512, 60000, 2),                 # N < K
+    (4096, 4096, 4096, 4096 * 5, 2),             # no overlap
+    (4096, 4096, 512, 4096, 1),                  # a lone frame
 ])
 def test_stft_wave_variants(K, N, hop, L, batch):
     rng = np.random.default_rng(K + N + hop + L)
@@ -66,7 +71,7 @@ def test_stft_wave_chunk_seams_many_rows():
 
 
 @pytest.mark.parametrize("pad", ["reflect", "same", [(100, 900)], [(-3, 50)]])
-@pytest.mark.parametrize("K", [128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize("K", [128, 256, 512, 1024, 2048, 4096])
 def test_stft_wave_general_padding(pad, K):
     rng = np.random.default_rng(5 + K)
     if isinstance(pad, list) and K < 1024:

@@ -72,7 +72,7 @@ def main():
             n = int(name[3:])
             b = 16
             Lg = (1700 * 1024 * 1024 // (b * 8 * 4)) // n * n  # hop = n/4 -> 8n bytes out per hop samples
-            stft_case(ctx, n, n // 4, Lg, b, f"stft N={n} hop={n // 4}, {b} rows (generic kernels unless tuned)")
+            stft_case(ctx, n, n // 4, Lg, b, f"stft N={n} hop={n // 4}, {b} rows (tuned wave kernel if the size has one, else generic)")
     for name in which:
         if name.startswith("ist") and name != "istft":  # e.g. ist512: generic-path istft sizes
             n = int(name[3:]); hop = n // 4; b = 8

@@ -628,9 +628,9 @@ static int ensure_lds(KernelT kernel, size_t bytes) {
 static void host_fft_f64(std::vector<double>& re, std::vector<double>& im);
 
 // chirp / kernel-spectrum tables of the Bluestein path, cached per context by content
-static int blue_tables(Ctx* c, int K, BlueTables* t) {
+static int blue_tables(Ctx* c, int K, BlueTables* t, int forceP = 0) {
   int P = 1, logP = 0;
-  while (P < 2 * K - 1) { P <<= 1; ++logP; }
+  while (P < 2 * K - 1 || P < forceP) { P <<= 1; ++logP; }
   std::vector<float2> chirp((size_t)K), Bf((size_t)P);
   std::vector<double> cre((size_t)K), cim((size_t)K), bre((size_t)P, 0.0), bim((size_t)P, 0.0);
   for (int n = 0; n < K; ++n) {
@@ -646,12 +646,22 @@ static int blue_tables(Ctx* c, int K, BlueTables* t) {
   const void *dc = nullptr, *db = nullptr;
   int rc = ctx_table(c, 0xB10E0ull ^ (uint64_t)K, chirp.data(), chirp.size() * sizeof(float2), &dc);
   if (rc) return rc;
-  rc = ctx_table(c, 0xB10E1ull ^ (uint64_t)K, Bf.data(), Bf.size() * sizeof(float2), &db);
+  rc = ctx_table(c, 0xB10E1ull ^ (uint64_t)K ^ ((uint64_t)P << 20), Bf.data(), Bf.size() * sizeof(float2), &db);
   if (rc) return rc;
   t->K = K; t->P = P; t->logP = logP;
   t->chirp = reinterpret_cast<const float2*>(dc);
   t->Bf = reinterpret_cast<const float2*>(db);
+  if (forceP) { t->twP = nullptr; return NXSIG_OK; }
   return ctx_twiddles(c, P, &t->twP);
+}
+// tables for the wave-core Bluestein kernel: convolution length fixed to the core size P
+int blue_tables_dev(Ctx* c, int K, int P, const float2** chirp, const float2** Bf) {
+  BlueTables t;
+  int rc = blue_tables(c, K, &t, P);
+  if (rc) return rc;
+  if (t.P != P) return set_error(NXSIG_ERR_UNSUPPORTED, "bluestein: fft_length does not fit the core");
+  *chirp = t.chirp; *Bf = t.Bf;
+  return NXSIG_OK;
 }
 static bool use_bluestein(int K) { return !is_pow2(K) && K > 64 && K <= 4096; }
 

@@ -313,7 +313,8 @@ __device__ __forceinline__ float fetch_any(const float* __restrict__ x, const Wa
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_wave_smem[];
 
-typedef __attribute__((address_space(1))) v4f gv4f;  // explicit global address space: global_store, not flat_store
+typedef __attribute__((address_space(1))) v4f gv4f;
+typedef __attribute__((address_space(1))) v2f gv2f;  // explicit global address space: global_store, not flat_store
 
 // GENERAL = false: :valid framing with every existing frame fully inside the signal (the streaming case);
 // GENERAL = true : any padding mode / ragged tail, per-sample bounds and mirror math.  SCALE: :spectrum / :psd.
@@ -681,6 +682,111 @@ __global__ __launch_bounds__(64 * W) void k_stft_mel_wave(MelWaveArgs m) {
   if (lane == 0 && p_begin + wave < p_end) {
     const int i = __float_as_int(vmax);
     atomicMax(m.gmax, i >= 0 ? i : i ^ 0x7fffffff);
+  }
+}
+
+// ============================================================================================ Bluestein on the wave core
+// Non-power-of-two fft_length Kb <= C/2 (e.g. 400-point frames of 25 ms speech at 16 kHz): the chirp-z identity
+//   X[k] = c[k] * sum_n (u[n] c[n]) conj(c)[k - n],   c[n] = exp(-i pi n^2 / Kb)
+// turns the Kb-point DFT into one circular convolution of length C, which is exactly the overlap-save FIR chain of this
+// file: transposed core -> x Bf (spectrum of the conj-chirp kernel, / C) -> inverse core, with no transposition pass.
+// The DFT is linear over C, so TWO real frames ride through it as u = (frame A) + i (frame B) and are separated
+// afterwards with the Hermitian partner U[(Kb - k) mod Kb], fetched through the wave's own exchange buffer.
+struct BlueWaveArgs {
+  WaveArgs w;            // framing, window (f32[Kb], zero beyond N), forward tables, output
+  int32_t Kb;            // fft_length
+  const v2f* chirp;      // c64[Kb]
+  const v2f* Bf;         // c64[C], pre-scaled by 1/C
+  const v2f* twBi;
+  const v2f* twCi;
+};
+
+template <int C, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
+  const WaveArgs& a = b.w;
+  constexpr int P = C / 64;
+  constexpr int R3 = C / 256;
+  constexpr int NQ = C / 128;
+  constexpr int XCH = C + C / 16 + 16;
+  v2f* s_twB = reinterpret_cast<v2f*>(g_wave_smem);
+  v2f* s_twC = s_twB + 256;
+  v2f* s_twBi = s_twC + R3 * 256;
+  v2f* s_twCi = s_twBi + 256;
+  v2f* s_Bf = s_twCi + R3 * 256;
+  v2f* s_ch = s_Bf + C;                                   // [C/2]
+  float* s_w = reinterpret_cast<float*>(s_ch + C / 2);    // [C/2]
+  v2f* s_x = reinterpret_cast<v2f*>(s_w + C / 2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Kb = b.Kb;
+  for (int i = tid; i < 256; i += 64 * W) { s_twB[i] = a.twB[i]; s_twBi[i] = b.twBi[i]; }
+  for (int i = tid; i < R3 * 256; i += 64 * W) { s_twC[i] = a.twC[i]; s_twCi[i] = b.twCi[i]; }
+  for (int i = tid; i < C; i += 64 * W) s_Bf[i] = b.Bf[i];
+  for (int i = tid; i < Kb; i += 64 * W) { s_ch[i] = b.chirp[i]; s_w[i] = a.wtab[i]; }
+  __syncthreads();
+  v2f* xb = s_x + wave * XCH;
+
+  const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
+  int64_t p_end = p_begin + a.chunk;
+  if (p_end > a.total_pairs) p_end = a.total_pairs;
+  const int nuse = a.N < Kb ? a.N : Kb;
+  for (int64_t pr = p_begin + wave; pr < p_end; pr += W) {
+    const int64_t row = pr / a.pairs_per_row;
+    const int64_t pin = pr - row * a.pairs_per_row;
+    const int64_t mA = 2 * pin, mB = mA + 1;
+    const bool haveB = mB < a.M;
+    const float* xr = a.x + (size_t)row * a.batch_stride;
+    const int64_t qA = mA * a.hop, qB = qA + a.hop;
+    // every sample of both frames inside the signal: plain loads; otherwise per-sample padding / mirror math
+    const bool inside = a.reflect == 0 && qA - a.lo >= 0 && (haveB ? qB : qA) - a.lo + nuse <= a.L;
+    v2f zz[2][NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int n = 2 * lane + e + 128 * q;
+        v2f v = v2f{0.f, 0.f};
+        if (128 * q < nuse && n < nuse) {
+          float va, vb;
+          if (inside) { va = xr[qA - a.lo + n]; vb = haveB ? xr[qB - a.lo + n] : 0.0f; }
+          else { va = fetch_any(xr, a, qA + n); vb = haveB ? fetch_any(xr, a, qB + n) : 0.0f; }
+          const float w = s_w[n];
+          v = wcmul(v2f{va * w, vb * w}, s_ch[n]);   // windowed samples (exact f32 products, :101) times the chirp
+        }
+        zz[e][q] = v;
+      }
+    v2f d[P];
+    wave_fft_core_T<C>(zz, d, xb, s_twB, s_twC, lane);
+#pragma unroll
+    for (int s = 0; s < P; ++s) d[s] = wcmul(d[s], s_Bf[lane + 64 * s]);
+    v2f y[2][NQ];
+    wave_fft_core<C, true>(d, y, xb, s_twBi, s_twCi, lane);
+    // U[k] = y[k] c[k] = XA[k] + i XB[k], k < Kb: park it in the exchange buffer for the partner read
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = 2 * lane + e + 128 * q;
+        if (128 * q < Kb && k < Kb) { y[e][q] = wcmul(y[e][q], s_ch[k]); xb[k] = y[e][q]; }
+      }
+    wave_lds_fence();
+    v2f* zA = a.z + ((size_t)row * a.M + mA) * Kb;
+    v2f* zB = zA + Kb;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = 2 * lane + e + 128 * q;
+        if (128 * q < Kb && k < Kb) {
+          const v2f u = y[e][q];
+          const v2f p = xb[k == 0 ? 0 : Kb - k];
+          v2f xa = v2f{u.x + p.x, u.y - p.y} * 0.5f;
+          v2f xv = v2f{u.y + p.y, p.x - u.x} * 0.5f;
+          if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
+          __builtin_nontemporal_store(xa, (gv2f*)(zA + k));
+          if (haveB) __builtin_nontemporal_store(xv, (gv2f*)(zB + k));
+        }
+      }
+    wave_lds_fence();  // partner reads complete before the next unit's transposed pass writes the buffer
   }
 }
 
@@ -1285,6 +1391,46 @@ int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float*
   return launch_mel_finish(c, out, (int64_t)s.batch * s.fr.M * mel_bins, m.gmax);
 }
 
+int blue_tables_dev(Ctx* c, int K, int P, const float2** chirp, const float2** Bf);  // kernels_generic.hip
+
+template <int C>
+static int launch_blue_wave(Ctx* c, const StftLaunch& s) {
+  constexpr int W = 4, R3 = C / 256, XCH = C + C / 16 + 16;
+  BlueWaveArgs b;
+  WaveArgs& a = b.w;
+  a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
+  a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
+  a.pairs_per_row = (s.fr.M + 1) / 2;
+  a.total_pairs = a.pairs_per_row * s.batch;
+  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
+  a.twR = nullptr; a.dummy = nullptr;
+  { int rc = ensure_wave_tables(c, C); if (rc) return rc; }
+  Ctx::WaveTables& wt = c->wave_tables[C];
+  a.twB = reinterpret_cast<const v2f*>(wt.twB);
+  a.twC = reinterpret_cast<const v2f*>(wt.twC);
+  b.twBi = reinterpret_cast<const v2f*>(wt.twBi);
+  b.twCi = reinterpret_cast<const v2f*>(wt.twCi);
+  a.wtab = s.window_padK;
+  b.Kb = s.K;
+  const float2 *dc = nullptr, *db = nullptr;
+  { int rc = blue_tables_dev(c, s.K, C, &dc, &db); if (rc) return rc; }
+  b.chirp = reinterpret_cast<const v2f*>(dc);
+  b.Bf = reinterpret_cast<const v2f*>(db);
+  const size_t lds = (size_t)(2 * 256 + 2 * R3 * 256 + C + C / 2) * 8 + (size_t)(C / 2) * 4 + (size_t)W * XCH * 8;
+  const int units_per_wave = env_int("NXSIG_BLUE_UNITS_PER_WAVE", 4);
+  a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
+  const int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
+  if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
+  auto go = [&](auto kernel) -> int {
+    if (lds > 64 * 1024)
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, b);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  };
+  return s.has_scale ? go(k_stft_blue_wave<C, true, W>) : go(k_stft_blue_wave<C, false, W>);
+}
+
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   *handled = false;
   if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
@@ -1320,6 +1466,10 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
     if (w == 12) return launch_wave<1024, kModeReal2x, 12>(c, s);
     if (w == 8) return launch_wave<1024, kModeReal2x, 8>(c, s);
     return launch_wave<1024, kModeReal2x, 4>(c, s);
+  }
+  if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0)) {
+    *handled = true;  // non-power-of-two: Bluestein through the 1024- (Kb <= 512) or 2048-point core
+    return s.K <= 512 ? launch_blue_wave<1024>(c, s) : launch_blue_wave<2048>(c, s);
   }
   return NXSIG_OK;
 }

@@ -211,3 +211,42 @@ def test_concurrent_contexts_and_threads():
     for t in ts:
         t.join()
     assert len(errs) == 20 and max(errs) < 1e-5
+
+
+@pytest.mark.parametrize("K,N,hop,L,batch", [
+    (400, 400, 160, 16000, 2),        # 25 ms / 10 ms speech framing at 16 kHz
+    (400, 400, 160, 400 + 160 * 6, 3),  # odd frame count: phantom second frame of the last pair
+    (100, 100, 25, 3000, 2),
+    (500, 300, 100, 9000, 1),         # N < K: zero-padded frames
+    (511, 511, 128, 8000, 2),         # odd length: odd-aligned output rows
+    (512 - 1, 600, 200, 9000, 1),     # N > K: truncated frames
+    (513, 513, 171, 9000, 2),         # first length on the 2048-point core
+    (1000, 1000, 250, 30000, 2),
+    (1023, 1023, 512, 20000, 1),
+    (17, 17, 5, 400, 2),
+    (400, 400, 160, 400, 1),          # a lone frame
+])
+def test_stft_bluestein_wave(K, N, hop, L, batch):
+    """non-power-of-two fft_length <= 1024: chirp-z through the wave core, two frames per convolution"""
+    rng = np.random.default_rng(K * 3 + N + hop)
+    x = rng.standard_normal((batch, L)).astype(np.float32)
+    w = S.windows.hann(N)
+    for scaling in (None, "spectrum"):
+        opts = dict(overlap_length=N - hop, fft_length=K, sampling_rate=16000, scaling=scaling)
+        z, t, f = S.stft(x, w, **opts)
+        zo, to, fo = O.stft(x, w, **opts)
+        assert z.shape == zo.shape
+        assert nerr(z, zo) < 1e-5, (K, N, hop, scaling, nerr(z, zo))
+        assert np.array_equal(t, to, equal_nan=True) and np.array_equal(f, fo)  # M == 1: the reference's times are NaN
+
+
+@pytest.mark.parametrize("pad", ["reflect", "same", [(37, 211)]])
+@pytest.mark.parametrize("K", [400, 1000])
+def test_stft_bluestein_wave_padding(pad, K):
+    rng = np.random.default_rng(K)
+    x = rng.standard_normal((2, 7000)).astype(np.float32)
+    w = S.windows.hamming(K)
+    opts = dict(overlap_length=K - K // 4, fft_length=K, window_padding=pad, scaling="psd", sampling_rate=8000)
+    z, _, _ = S.stft(x, w, **opts)
+    zo, _, _ = O.stft(x, w, **opts)
+    assert z.shape == zo.shape and nerr(z, zo) < 1e-5

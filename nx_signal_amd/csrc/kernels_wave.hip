@@ -286,7 +286,9 @@ struct WaveArgs {
   int64_t batch_stride, L, lo, M;
   int32_t N, hop, reflect, batch;
   int64_t pairs_per_row;      // work units per row: ceil(M / 2) frame pairs (pair mode) or M frames (real-2x mode)
-  int64_t total_pairs;        // batch * pairs_per_row
+  int64_t total_pairs;        // units in this launch: batch * units_per_row (k_stft_wave), batch * pairs_per_row (others)
+  int64_t units_per_row;      // k_stft_wave: units of each row covered by this launch (interior or edge set)
+  int64_t u_split, u_add0, u_add1;  // unit u of the launch is unit-in-row u + (u < u_split ? u_add0 : u_add1)
   int64_t chunk;              // units per workgroup (contiguous)
   const float* wtab;          // device f32[fft_length]: window zero-padded / truncated to the fft length
   const v2f* twB;             // device c64[16][16]: w_256^(t k)
@@ -319,7 +321,7 @@ typedef __attribute__((address_space(1))) v2f gv2f;  // explicit global address 
 // GENERAL = false: :valid framing with every existing frame fully inside the signal (the streaming case);
 // GENERAL = true : any padding mode / ragged tail, per-sample bounds and mirror math.  SCALE: :spectrum / :psd.
 // W = waves per workgroup (tables in LDS are shared by the W waves; waves never synchronise with each other).
-template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2>
+template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2, bool NPRED = false>
 __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   constexpr int P = K / 64;     // complex points per lane
   constexpr int R3 = K / 256;   // last radix: 4 or 8
@@ -361,17 +363,17 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   auto issue_loads = [&](int64_t row, int64_t pin) {
     if (MODE == kModePair) {
       const int64_t mA = pin * 2;
-      const float* pa = a.x + (size_t)row * a.batch_stride + mA * a.hop + lane;
+      const float* pa = a.x + (size_t)row * a.batch_stride + (mA * a.hop - a.lo) + lane;
       const float* pb = pa + ((mA + 1 < a.M) ? a.hop : 0);  // phantom frame B of an odd tail: reload A, never stored
 #pragma unroll
       for (int s = 0; s < P; ++s) { ra[s] = pa[64 * s]; rb[s] = pb[64 * s]; }
     } else if (MODE == kModeReal2x) {  // complex point n = (x[2n], x[2n+1])
-      const float* pa = a.x + (size_t)row * a.batch_stride + pin * a.hop + 2 * lane;
+      const float* pa = a.x + (size_t)row * a.batch_stride + (pin * a.hop - a.lo) + 2 * lane;
 #pragma unroll
       for (int s = 0; s < P; ++s) { ra[s] = pa[128 * s]; rb[s] = pa[128 * s + 1]; }
     } else {  // quad: lane carries sequence j = lane % J = frames (m0 + 2j, m0 + 2j + 1); core point lane + 64 s = J n + j
       const int64_t fa = pin * (2 * J) + 2 * (lane % J), fb = fa + 1, last = a.M - 1;
-      const float* base = a.x + (size_t)row * a.batch_stride + (lane / J);
+      const float* base = a.x + (size_t)row * a.batch_stride - a.lo + (lane / J);
       const float* pa = base + (fa < last ? fa : last) * a.hop;  // phantom frames of a ragged tail: reload, never stored
       const float* pb = base + (fb < last ? fb : last) * a.hop;
 #pragma unroll
@@ -381,41 +383,51 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
   auto window_mul = [&](v2f* d) {
 #pragma unroll
     for (int s = 0; s < P; ++s) {
+      // NPRED (frame_length < fft_length): samples past the frame are loaded (the unit is interior) but must not
+      // reach the transform even as 0 * x, which would turn an Inf / NaN outside the frame into NaN
       if (MODE == kModePair) {
         const float w = s_w[lane + 64 * s];
         d[s] = v2f{ra[s] * w, rb[s] * w};
+        if (NPRED && lane + 64 * s >= a.N) d[s] = v2f{0.f, 0.f};
       } else if (MODE == kModeReal2x) {
         const v2f w = *reinterpret_cast<const v2f*>(&s_w[2 * (lane + 64 * s)]);
         d[s] = v2f{ra[s] * w.x, rb[s] * w.y};
+        if (NPRED && 2 * (lane + 64 * s) >= a.N) d[s].x = 0.f;
+        if (NPRED && 2 * (lane + 64 * s) + 1 >= a.N) d[s].y = 0.f;
       } else {
         const float w = s_w[(lane / J) + (64 / J) * s];
         d[s] = v2f{ra[s] * w, rb[s] * w};
+        if (NPRED && (lane / J) + (64 / J) * s >= a.N) d[s] = v2f{0.f, 0.f};
       }
     }
   };
   // (row, pair-in-row) of this wave's current and next pair, advanced incrementally (no division in the loop)
-  int64_t row = (p_begin + wave) / a.pairs_per_row;
-  int64_t pin = (p_begin + wave) - row * a.pairs_per_row;
-  int64_t nrow = row, npin = pin;
+  // A launch covers units_per_row of each row's pairs_per_row units: the interior ones (every sample of every frame
+  // inside the signal: the streaming kernels) or the few edge ones (GENERAL).  unit index u -> unit-in-row:
+  auto pinof = [&](int64_t u) { return u + (u < a.u_split ? a.u_add0 : a.u_add1); };
+  int64_t row = (p_begin + wave) / a.units_per_row;
+  int64_t uin = (p_begin + wave) - row * a.units_per_row;
+  int64_t nrow = row, nuin = uin;
   auto advance = [&](int64_t& r, int64_t& q) {
     q += kWavesPerBlock;
-    while (q >= a.pairs_per_row) { q -= a.pairs_per_row; ++r; }
+    while (q >= a.units_per_row) { q -= a.units_per_row; ++r; }
   };
-  advance(nrow, npin);
+  advance(nrow, nuin);
   v2f d[P];  // windowed samples of the current pair: re = frame A, im = frame B (exact f32 products, :101)
   if (!GENERAL && p_begin + wave < p_end) {
-    issue_loads(row, pin);
+    issue_loads(row, pinof(uin));
     window_mul(d);
   }
 
   for (int64_t pr = p_begin + wave; pr < p_end; pr += kWavesPerBlock) {
+    const int64_t pin = pinof(uin);
     const int64_t mA = MODE == kModePair ? pin * 2 : (MODE == kModeQuad ? pin * (2 * J) : pin), mB = mA + 1;
     const bool haveB = MODE == kModeReal2x ? true : (mB < a.M);
     const int64_t crow = row;
     if (!GENERAL) {
       // unconditional prefetch (the last iteration harmlessly re-reads its own unit) keeps the loop branch-free
       const bool more = pr + kWavesPerBlock < p_end;
-      issue_loads(more ? nrow : row, more ? npin : pin);
+      issue_loads(more ? nrow : row, more ? pinof(nuin) : pin);
       __builtin_amdgcn_sched_barrier(0);
     } else {
       const float* xr = a.x + (size_t)row * a.batch_stride;
@@ -498,8 +510,8 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
           __builtin_nontemporal_store(xbv, (gv4f*)(zfb + 128 * q));
         }
       }
-      row = nrow; pin = npin;
-      advance(nrow, npin);
+      row = nrow; uin = nuin;
+      advance(nrow, nuin);
       continue;
     }
     v2f* zA = a.z + ((size_t)crow * a.M + mA) * KOUT + 2 * lane;
@@ -530,8 +542,8 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
       __builtin_nontemporal_store(xa, (gv4f*)(zA + 128 * q));
       if (!GENERAL || haveB) __builtin_nontemporal_store(xbv, (gv4f*)(zB + 128 * q));
     }
-    row = nrow; pin = npin;
-    advance(nrow, npin);
+    row = nrow; uin = nuin;
+    advance(nrow, nuin);
   }
 }
 
@@ -1303,22 +1315,50 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
   // the kernel time), at the price of re-loading the 12 KB of tables per workgroup from L2.
   const int units_per_wave = env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : 8);  // measured optima
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
-  int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
-  if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
-  // streaming case: no padding and every existing frame reads its fft_length samples inside the signal
-  const bool streaming = s.fr.reflect == 0 && s.fr.lo == 0 && ((s.fr.M - 1) * (int64_t)s.fr.hop + KOUT <= s.fr.L);
+  // Interior frames [m_lo, m_hi): every one of the KOUT samples the streaming front-end reads lies inside the signal,
+  // whatever the padding mode (window_padding :reflect / :same / explicit only touch the first and last few frames).
+  // Interior units go to the branch-free software-pipelined kernel; the edge units to the bounds-checked one.
+  constexpr int F = MODE == kModePair ? 2 : (MODE == kModeQuad ? 2 * J : 1);  // frames per unit
+  const int64_t hop = s.fr.hop, lo = s.fr.lo, M = s.fr.M;
+  int64_t m_lo = lo > 0 ? (lo + hop - 1) / hop : 0;
+  int64_t m_hi = (s.fr.L + lo - KOUT >= 0) ? (s.fr.L + lo - KOUT) / hop + 1 : 0;
+  if (m_hi > M) m_hi = M;
+  if (m_lo > M) m_lo = M;
+  if (m_hi < m_lo) m_hi = m_lo;
+  int64_t u_lo = (m_lo + F - 1) / F;
+  int64_t u_hi = m_hi >= M ? a.pairs_per_row : m_hi / F;  // the last (possibly ragged) unit is interior iff frame M-1 is
+  if (u_lo > a.pairs_per_row) u_lo = a.pairs_per_row;
+  if (u_hi < u_lo) u_hi = u_lo;
+  if (env_int("NXSIG_WAVE_NO_SPLIT", 0) && !(u_lo == 0 && u_hi == a.pairs_per_row)) u_hi = u_lo = 0;
   const bool scale = s.has_scale != 0;
-  auto go = [&](auto kernel) -> int {
+  const bool npred = s.fr.N < KOUT;
+  auto go = [&](auto kernel, int64_t upr, int64_t split, int64_t add0, int64_t add1) -> int {
+    if (upr == 0) return NXSIG_OK;
+    a.units_per_row = upr; a.u_split = split; a.u_add0 = add0; a.u_add1 = add1;
+    a.total_pairs = upr * s.batch;
+    const int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
+    if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
-  if (streaming && !scale) return go(k_stft_wave<C, MODE, false, false, W, J>);
-  if (streaming && scale) return go(k_stft_wave<C, MODE, false, true, W, J>);
-  if (!scale) return go(k_stft_wave<C, MODE, true, false, W, J>);
-  return go(k_stft_wave<C, MODE, true, true, W, J>);
+  int rc;
+  {  // interior units u_lo .. u_hi-1
+    const int64_t upr = u_hi - u_lo, big = (int64_t)1 << 62;
+    if (!npred) rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false>, upr, big, u_lo, u_lo)
+                           : go(k_stft_wave<C, MODE, false, false, W, J, false>, upr, big, u_lo, u_lo);
+    else rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, true>, upr, big, u_lo, u_lo)
+                    : go(k_stft_wave<C, MODE, false, false, W, J, true>, upr, big, u_lo, u_lo);
+    if (rc) return rc;
+  }
+  {  // edge units 0 .. u_lo-1 and u_hi .. pairs_per_row-1
+    const int64_t upr = u_lo + (a.pairs_per_row - u_hi);
+    rc = scale ? go(k_stft_wave<C, MODE, true, true, W, J>, upr, u_lo, 0, u_hi - u_lo)
+               : go(k_stft_wave<C, MODE, true, false, W, J>, upr, u_lo, 0, u_hi - u_lo);
+  }
+  return rc;
 }
 
 int launch_mel_finish(Ctx* c, float* out, int64_t n, int* gmax);

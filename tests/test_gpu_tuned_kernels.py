@@ -250,3 +250,30 @@ def test_stft_bluestein_wave_padding(pad, K):
     z, _, _ = S.stft(x, w, **opts)
     zo, _, _ = O.stft(x, w, **opts)
     assert z.shape == zo.shape and nerr(z, zo) < 1e-5
+
+
+@pytest.mark.parametrize("K,N,hop", [(1024, 600, 200), (512, 400, 160), (2048, 1500, 500), (256, 200, 80)])
+def test_stft_interior_units_do_not_leak_samples_past_the_frame(K, N, hop):
+    """frame_length < fft_length on the streaming kernels: an Inf that lies past a frame's last sample (but inside the
+    fft_length samples the kernel loads) must not contaminate that frame.  Frames that share one complex transform
+    (2 at K=1024, 4 at 512, 8 at 256, 1 at 2048) do share non-finite values — a documented deviation —
+    so the expected finite/NaN pattern is the oracle's, widened to whole units."""
+    F = {1024: 2, 512: 4, 256: 8, 2048: 1}[K]
+    rng = np.random.default_rng(K + N)
+    x = rng.standard_normal((2, 20000)).astype(np.float32)
+    x[0, 7001] = np.inf
+    x[1, 12345] = np.nan
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=K)
+    z, _, _ = S.stft(x, w, **opts)
+    zo, _, _ = O.stft(x, w, **opts)
+    fin, fino = np.isfinite(z).all(axis=-1), np.isfinite(zo).all(axis=-1)
+    M = fin.shape[1]
+    expect = fino.copy()
+    for r in range(fin.shape[0]):
+        for u in range(0, M, F):
+            if not fino[r, u:u + F].all():
+                expect[r, u:u + F] = False
+    assert np.array_equal(fin, expect)
+    assert 0 < (~fin).sum() < fin.size // 4
+    assert nerr(z[fin], zo[fin]) < 1e-5

@@ -40,18 +40,21 @@ def fill_normal(ctx, buf, shape, seed):
     return chunk
 
 
-def stft_case(ctx, N, hop, L, batch, name):
+def stft_case(ctx, N, hop, L, batch, name, K=None, pad=None):
     lib = _lib.load()
     w = S.windows.hann(N)
-    M = (L - N) // hop + 1
+    K = K or N
+    pad = _lib.PAD_VALID if pad is None else pad
+    Lp = L + (N // 2) * 2 if pad == _lib.PAD_REFLECT else L   # :reflect pads N/2 on both sides
+    M = (Lp - N) // hop + 1
     xd = ctx.empty((batch, L), np.float32)
     fill_normal(ctx, xd, (batch, L), 7)
-    zd = ctx.empty((batch, M, N), np.complex64)
-    p = _lib.StftParams(N, hop, N, _lib.PAD_VALID, 0, 0, _lib.SCALE_NONE, 0, 48000.0)
+    zd = ctx.empty((batch, M, K), np.complex64)
+    p = _lib.StftParams(N, hop, K, pad, 0, 0, _lib.SCALE_NONE, 0, 48000.0)
     wp = w.ctypes.data_as(C.c_void_p)
     fn = lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
     ms = timeit(ctx, fn)
-    bpf = hop * 4 + N * 8
+    bpf = hop * 4 + K * 8
     gbs = batch * M * bpf / (ms * 1e-3) / 1e9
     print(json.dumps({"case": name, "N": N, "hop": hop, "batch": batch, "frames": batch * M, "ms": ms,
                       "frames_per_s": batch * M / (ms * 1e-3), "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / PEAK}), flush=True)
@@ -67,6 +70,12 @@ def main():
     if "stft2048" in which:
         # config 4 per-GPU shard: 8 channels x 10 min @ 48 kHz would be 7.4 GB of output; use 8 ch x 150 s (1.8 GB out)
         stft_case(ctx, 2048, 512, 7200000, 8, "stft N=2048 hop=512, 8 ch x 150 s (config 4 shard, shortened)")
+    if "reflect1024" in which:
+        stft_case(ctx, 1024, 256, 2880000, 32, "stft N=1024 hop=256 window_padding :reflect, 32 x 60 s", pad=_lib.PAD_REFLECT)
+    if "speech512" in which:
+        stft_case(ctx, 400, 160, 16000 * 600, 32, "stft N=400 hop=160 fft_length=512 (25 ms / 10 ms speech framing), 32 x 10 min @16 kHz", K=512)
+    if "speech512r" in which:
+        stft_case(ctx, 400, 160, 16000 * 600, 32, "stft N=400 hop=160 fft_length=512 :reflect, 32 x 10 min @16 kHz", K=512, pad=_lib.PAD_REFLECT)
     for name in which:
         if name.startswith("gen"):  # e.g. gen512: generic-kernel sizes, ~1.7 GB of output each
             n = int(name[3:])

@@ -23,6 +23,7 @@
 // The STFT path is HBM-bound (9 216 algorithmic B/frame at K=1024, 89 % stores), MFMA is deliberately unused.
 // Index math and LDS bank behaviour are modelled lane by lane in tools/emulate_wave_fft.py.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cmath>
 #include <cstdlib>
@@ -321,8 +322,26 @@ typedef __attribute__((address_space(1))) v2f gv2f;  // explicit global address 
 // GENERAL = false: :valid framing with every existing frame fully inside the signal (the streaming case);
 // GENERAL = true : any padding mode / ragged tail, per-sample bounds and mirror math.  SCALE: :spectrum / :psd.
 // W = waves per workgroup (tables in LDS are shared by the W waves; waves never synchronise with each other).
-template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2, bool NPRED = false>
-__global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
+// ---- fused STFT -> log-mel: NxSignal.stft (lib/nx_signal.ex:68-130) followed by stft_to_mel (:486-513) in
+// ONE kernel, so that mel_bins * 4 bytes per frame leave the chip instead of the 8 * fft_length byte spectrum.  The MEL
+// variants of k_stft_wave untangle only the bins below fft_length / 2, put |X|^2 of the unit's frames into the wave's
+// (then idle) exchange buffer, and every lane sums its mel bands over the sparse (triangular) filter rows held in LDS
+// as CSR; log10; per-wave running max -> one atomicMax.  A second tiny pass (k_mel_pass2) applies max(., gmax - 8) and
+// (. + 4) / 4 once the global maximum is known.  Every front-end (pair / real-2x / quad) and the interior / edge split
+// are shared with the plain STFT.
+struct MelWaveArgs {
+  WaveArgs w;                 // framing / tables of the STFT front half (z unused)
+  int32_t mel_bins, nnz;
+  const float* csr_w;         // [nnz] filter weights, band after band
+  const int* csr_off;         // [mel_bins + 1]
+  const int* csr_lo;          // [mel_bins] first bin of each band
+  float ln10;
+  float* out;                 // f32[batch][M][mel_bins] (log10 power, before the clamp pass)
+  int* gmax;
+};
+
+template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J, bool NPRED, bool MEL>
+__device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveArgs* mp) {
   constexpr int P = K / 64;     // complex points per lane
   constexpr int R3 = K / 256;   // last radix: 4 or 8
   constexpr int B12 = P / 16;   // radix-16 butterflies per lane in passes A and B
@@ -347,8 +366,46 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
     for (int i = tid; i < K; i += kWaveThreads) s_twR[i] = a.twR[i];
   if (MODE == kModeQuad)
     for (int i = tid; i < TWQ; i += kWaveThreads) s_twR[i] = a.twR[i];  // [j-1][k0] = conj(w_K^(j k0))
+  // MEL: [nnz] filter weights, [mel_bins + 1] offsets, [mel_bins] first bins after the exchange buffers
+  float* s_csr = reinterpret_cast<float*>(s_x + W * XCH);
+  int* s_off = reinterpret_cast<int*>(s_csr + (MEL ? mp->nnz : 0));
+  int* s_lo = s_off + (MEL ? mp->mel_bins + 1 : 0);
+  if (MEL) {
+    for (int i = tid; i < mp->nnz; i += kWaveThreads) s_csr[i] = mp->csr_w[i];
+    for (int i = tid; i <= mp->mel_bins; i += kWaveThreads) s_off[i] = mp->csr_off[i];
+    for (int i = tid; i < mp->mel_bins; i += kWaveThreads) s_lo[i] = mp->csr_lo[i];
+  }
   __syncthreads();  // the only workgroup barrier: tables are read-only afterwards
   v2f* xb = s_x + wave * XCH;
+  // MEL: after the core the exchange buffer is idle: |X|^2 of frame f of the unit at mags[f * KOUT/2 + k], k < KOUT/2
+  float* mags = reinterpret_cast<float*>(xb);
+  constexpr int FPU = MODE == kModePair ? 2 : (MODE == kModeQuad ? 2 * J : 1);  // frames per unit
+  constexpr int KH = KOUT / 2;
+  float vmax = -3.0e38f;
+  auto mel_tail = [&](int64_t crow, int64_t mA) {
+    wave_lds_fence();
+    // ---- sparse filterbank + log10
+    float* o0p = mp->out + ((size_t)crow * a.M + mA) * mp->mel_bins;
+    for (int b = lane; b < mp->mel_bins; b += 64) {
+      const int o0 = s_off[b], o1 = s_off[b + 1], k0 = s_lo[b];
+      float acc[FPU];
+#pragma unroll
+      for (int f = 0; f < FPU; ++f) acc[f] = 0.0f;
+      for (int j = o0; j < o1; ++j) {
+        const float wv = s_csr[j];
+#pragma unroll
+        for (int f = 0; f < FPU; ++f) acc[f] = fmaf(mags[f * KH + k0 + (j - o0)], wv, acc[f]);
+      }
+#pragma unroll
+      for (int f = 0; f < FPU; ++f) {
+        const float av = acc[f] > 1.0e-10f ? acc[f] : 1.0e-10f;
+        // hardware log2 (v_log_f32, ~1 ulp) * log10(2): |error| ~ 1e-7, far inside the 1e-4 the reference's tests use
+        const float v = __log2f(av) * 0.30102999566398120f;
+        if (mA + f < a.M) { o0p[(size_t)f * mp->mel_bins + b] = v; vmax = v > vmax ? v : vmax; }
+      }
+    }
+    wave_lds_fence();  // the power spectrum is consumed before the next pass A overwrites the buffer
+  };
 
   const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
   int64_t p_end = p_begin + a.chunk;
@@ -506,18 +563,29 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
           v4f xa = v4f{z0v.x + p0.x, z0v.y - p0.y, z1v.x + p1.x, z1v.y - p1.y} * 0.5f;
           v4f xbv = v4f{z0v.y + p0.y, p0.x - z0v.x, z1v.y + p1.y, p1.x - z1v.x} * 0.5f;
           if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }
-          __builtin_nontemporal_store(xa, (gv4f*)(zfa + 128 * q));
-          __builtin_nontemporal_store(xbv, (gv4f*)(zfb + 128 * q));
+          if (MEL) {
+            if (HQ >= 2 ? (q < HQ / 2) : (lane < 32)) {  // bins k0 = 2 lane + par + 128 q below fft_length / 2
+              const v2f pa2 = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};
+              const v2f pb2 = v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w};
+              *reinterpret_cast<v2f*>(&mags[(2 * j) * KH + 2 * lane + 128 * q]) = pa2;
+              *reinterpret_cast<v2f*>(&mags[(2 * j + 1) * KH + 2 * lane + 128 * q]) = pb2;
+            }
+          } else {
+            __builtin_nontemporal_store(xa, (gv4f*)(zfa + 128 * q));
+            __builtin_nontemporal_store(xbv, (gv4f*)(zfb + 128 * q));
+          }
         }
       }
+      if (MEL) mel_tail(crow, mA);
       row = nrow; uin = nuin;
       advance(nrow, nuin);
       continue;
     }
     v2f* zA = a.z + ((size_t)crow * a.M + mA) * KOUT + 2 * lane;
     v2f* zB = (GENERAL || haveB) ? zA + K : a.dummy + 2 * lane;  // pair: frame B; real-2x: bins K..2K-1
+    constexpr int QN = (MEL && MODE == kModePair) ? NQ / 2 : NQ;  // MEL: only the bins below fft_length / 2
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int q = 0; q < QN; ++q) {
       // partner of bin k = 2l+par+128q is K-k = 2l'+par+128(NQ-1-q) on lane l' (lane 0 / par 0: own (NQ-q) % NQ)
       const v2f own0 = zz[0][(NQ - q) % NQ];
       v2f p0, p1;
@@ -539,162 +607,39 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
         xa = xa + to;
       }
       if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }  // true division like the reference (:116/:119)
-      __builtin_nontemporal_store(xa, (gv4f*)(zA + 128 * q));
-      if (!GENERAL || haveB) __builtin_nontemporal_store(xbv, (gv4f*)(zB + 128 * q));
+      if (MEL) {
+        const v2f pa2 = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};      // |X[k]|^2, |X[k+1]|^2
+        *reinterpret_cast<v2f*>(&mags[2 * lane + 128 * q]) = pa2;
+        if (MODE == kModePair) {
+          const v2f pb2 = v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w};
+          *reinterpret_cast<v2f*>(&mags[KH + 2 * lane + 128 * q]) = pb2;
+        }
+      } else {
+        __builtin_nontemporal_store(xa, (gv4f*)(zA + 128 * q));
+        if (!GENERAL || haveB) __builtin_nontemporal_store(xbv, (gv4f*)(zB + 128 * q));
+      }
     }
+    if (MEL) mel_tail(crow, mA);
     row = nrow; uin = nuin;
     advance(nrow, nuin);
   }
+  if (MEL) {  // one atomic per wave: running maximum in ordered-int encoding
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(vmax, off); vmax = o > vmax ? o : vmax; }
+    if (lane == 0 && p_begin + wave < p_end) {
+      const int i = __float_as_int(vmax);
+      atomicMax(mp->gmax, i >= 0 ? i : i ^ 0x7fffffff);
+    }
+  }
 }
 
-// ============================================================================================ fused STFT -> mel
-// NxSignal.stft (lib/nx_signal.ex:68-130) followed by stft_to_mel (:486-513) in ONE kernel, so that
-// mel_bins * 4 bytes per frame leave the chip instead of the 8 KiB spectrum.  Pair mode of k_stft_wave (two frames per
-// 1024-point complex FFT); only bins < K/2 are untangled; |X|^2 goes to the wave's LDS buffer; every lane sums its
-// mel bands over the sparse (triangular) filter rows held in LDS as CSR; log10; per-wave running max -> one atomicMax.
-// A second tiny pass (k_mel_pass2) applies max(., gmax - 8) and (. + 4) / 4 once the global maximum is known.
-struct MelWaveArgs {
-  WaveArgs w;                 // framing / tables of the STFT front half (z unused)
-  int32_t mel_bins, nnz;
-  const float* csr_w;         // [nnz] filter weights, band after band
-  const int* csr_off;         // [mel_bins + 1]
-  const int* csr_lo;          // [mel_bins] first bin of each band
-  float ln10;
-  float* out;                 // f32[batch][M][mel_bins] (log10 power, before the clamp pass)
-  int* gmax;
-};
-
-template <int K, bool GENERAL, bool SCALE, int W>
+template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2, bool NPRED = false>
+__global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
+  stft_wave_body<K, MODE, GENERAL, SCALE, W, J, NPRED, false>(a, nullptr);
+}
+template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2, bool NPRED = false>
 __global__ __launch_bounds__(64 * W) void k_stft_mel_wave(MelWaveArgs m) {
-  const WaveArgs& a = m.w;
-  constexpr int P = K / 64;
-  constexpr int R3 = K / 256;
-  constexpr int NQ = K / 128;
-  constexpr int XCH = K + K / 16 + 16;
-  float* s_w = reinterpret_cast<float*>(g_wave_smem);
-  v2f* s_twB = reinterpret_cast<v2f*>(s_w + K);
-  v2f* s_twC = s_twB + 256;
-  v2f* s_x = s_twC + R3 * 256;
-  float* s_csr = reinterpret_cast<float*>(s_x + W * XCH);  // [nnz] weights, then [mel_bins+1] offsets, [mel_bins] lows
-  int* s_off = reinterpret_cast<int*>(s_csr + m.nnz);
-  int* s_lo = s_off + m.mel_bins + 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < K; i += 64 * W) s_w[i] = a.wtab[i];
-  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
-  for (int i = tid; i < R3 * 256; i += 64 * W) s_twC[i] = a.twC[i];
-  for (int i = tid; i < m.nnz; i += 64 * W) s_csr[i] = m.csr_w[i];
-  for (int i = tid; i <= m.mel_bins; i += 64 * W) s_off[i] = m.csr_off[i];
-  for (int i = tid; i < m.mel_bins; i += 64 * W) s_lo[i] = m.csr_lo[i];
-  __syncthreads();
-  v2f* xb = s_x + wave * XCH;
-  float* mags = reinterpret_cast<float*>(xb);  // after the core: |XA|^2 at [k], |XB|^2 at [K/2 + k], k < K/2
-
-  const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
-  int64_t p_end = p_begin + a.chunk;
-  if (p_end > a.total_pairs) p_end = a.total_pairs;
-
-  float ra[P], rb[P];
-  auto issue_loads = [&](int64_t row, int64_t pin) {
-    const int64_t mA = pin * 2;
-    const float* pa = a.x + (size_t)row * a.batch_stride + mA * a.hop + lane;
-    const float* pb = pa + ((mA + 1 < a.M) ? a.hop : 0);
-#pragma unroll
-    for (int s = 0; s < P; ++s) { ra[s] = pa[64 * s]; rb[s] = pb[64 * s]; }
-  };
-  auto window_mul = [&](v2f* d) {
-#pragma unroll
-    for (int s = 0; s < P; ++s) { const float w = s_w[lane + 64 * s]; d[s] = v2f{ra[s] * w, rb[s] * w}; }
-  };
-  int64_t row = (p_begin + wave) / a.pairs_per_row;
-  int64_t pin = (p_begin + wave) - row * a.pairs_per_row;
-  int64_t nrow = row, npin = pin;
-  auto advance = [&](int64_t& r, int64_t& q) {
-    q += W;
-    while (q >= a.pairs_per_row) { q -= a.pairs_per_row; ++r; }
-  };
-  advance(nrow, npin);
-  v2f d[P];
-  if (!GENERAL && p_begin + wave < p_end) { issue_loads(row, pin); window_mul(d); }
-  float vmax = -3.0e38f;
-
-  for (int64_t pr = p_begin + wave; pr < p_end; pr += W) {
-    const int64_t mA = pin * 2, mB = mA + 1;
-    const bool haveB = mB < a.M;
-    const int64_t crow = row;
-    if (!GENERAL) {
-      const bool more = pr + W < p_end;
-      issue_loads(more ? nrow : row, more ? npin : pin);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      const float* xr = a.x + (size_t)row * a.batch_stride;
-      const int64_t qA = mA * a.hop, qB = qA + a.hop;
-#pragma unroll
-      for (int s = 0; s < P; ++s) {
-        const int n = lane + 64 * s;
-        const float w = s_w[n];
-        const float va = (n < a.N) ? fetch_any(xr, a, qA + n) : 0.0f;
-        const float vb = (haveB && n < a.N) ? fetch_any(xr, a, qB + n) : 0.0f;
-        d[s] = v2f{va * w, vb * w};
-      }
-    }
-    v2f zz[2][NQ];
-    wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);
-    if (!GENERAL) {
-      __builtin_amdgcn_sched_barrier(0);
-      window_mul(d);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- untangle the bins below K/2 only, power spectrum into LDS (the exchange buffer is free until the next pass A)
-    const int src0 = ((64 - lane) & 63) << 2, src1 = (63 - lane) << 2;
-#pragma unroll
-    for (int q = 0; q < NQ / 2; ++q) {
-      const v2f own0 = zz[0][(NQ - q) % NQ];
-      v2f p0, p1;
-      p0.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(zz[0][NQ - 1 - q].x)));
-      p0.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(zz[0][NQ - 1 - q].y)));
-      p1.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(zz[1][NQ - 1 - q].x)));
-      p1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(zz[1][NQ - 1 - q].y)));
-      if (lane == 0) p0 = own0;
-      const v2f z0 = zz[0][q], z1 = zz[1][q];
-      v4f xa = v4f{z0.x + p0.x, z0.y - p0.y, z1.x + p1.x, z1.y - p1.y} * 0.5f;
-      v4f xbv = v4f{z0.y + p0.y, p0.x - z0.x, z1.y + p1.y, p1.x - z1.x} * 0.5f;
-      if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }
-      const v2f pa2 = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};      // |XA[k]|^2, |XA[k+1]|^2
-      const v2f pb2 = v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w};
-      *reinterpret_cast<v2f*>(&mags[2 * lane + 128 * q]) = pa2;
-      *reinterpret_cast<v2f*>(&mags[K / 2 + 2 * lane + 128 * q]) = pb2;
-    }
-    wave_lds_fence();
-    // ---- sparse filterbank + log10
-    float* oA = m.out + ((size_t)crow * a.M + mA) * m.mel_bins;
-    float* oB = oA + m.mel_bins;
-    for (int b = lane; b < m.mel_bins; b += 64) {
-      const int o0 = s_off[b], o1 = s_off[b + 1], k0 = s_lo[b];
-      float accA = 0.0f, accB = 0.0f;
-      for (int j = o0; j < o1; ++j) {
-        const float wv = s_csr[j];
-        accA = fmaf(mags[k0 + (j - o0)], wv, accA);
-        accB = fmaf(mags[K / 2 + k0 + (j - o0)], wv, accB);
-      }
-      accA = accA > 1.0e-10f ? accA : 1.0e-10f;
-      accB = accB > 1.0e-10f ? accB : 1.0e-10f;
-      // hardware log2 (v_log_f32, ~1 ulp) * log10(2): |error| ~ 1e-7, far inside the 1e-4 the reference's tests use
-      const float vA = __log2f(accA) * 0.30102999566398120f, vB = __log2f(accB) * 0.30102999566398120f;
-      oA[b] = vA;
-      vmax = vA > vmax ? vA : vmax;
-      if (haveB) { oB[b] = vB; vmax = vB > vmax ? vB : vmax; }
-    }
-    wave_lds_fence();  // the power spectrum is consumed before the next pass A overwrites the buffer
-    row = nrow; pin = npin;
-    advance(nrow, npin);
-  }
-  // one atomic per wave: running maximum in ordered-int encoding
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(vmax, off); vmax = o > vmax ? o : vmax; }
-  if (lane == 0 && p_begin + wave < p_end) {
-    const int i = __float_as_int(vmax);
-    atomicMax(m.gmax, i >= 0 ? i : i ^ 0x7fffffff);
-  }
+  stft_wave_body<K, MODE, GENERAL, SCALE, W, J, NPRED, true>(m.w, &m);
 }
 
 // ============================================================================================ Bluestein on the wave core
@@ -1282,8 +1227,18 @@ static int ensure_wave_tables_1024(Ctx* c);
 static int ensure_wave_tables(Ctx* c, int C);
 
 // C = complex core size (1024 here), MODE = front-end, W = waves per workgroup
+int launch_mel_finish(Ctx* c, float* out, int64_t n, int* gmax);
+int launch_mel_init(Ctx* c, int** gmax);
+
+struct MelLaunch {
+  int mel_bins;
+  const float* filters_host;  // [mel_bins][fft_length]
+  float* out;                 // device f32[batch][M][mel_bins]
+  bool* handled;              // set once the CSR fits LDS and the launch is committed
+};
+
 template <int C, int MODE, int W, int J = 2>
-static int launch_wave(Ctx* c, const StftLaunch& s) {
+static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullptr) {
   constexpr int R3 = C / 256;
   constexpr int XCH = C + C / 16 + 16;
   constexpr int KOUT = MODE == kModeReal2x ? 2 * C : (MODE == kModeQuad ? C / J : C);
@@ -1306,14 +1261,46 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);
 
-  const size_t lds = (size_t)KOUT * 4 + 256 * 8 + (size_t)R3 * 256 * 8 +
-                     (MODE == kModeReal2x ? (size_t)C * 8 : (MODE == kModeQuad ? (size_t)TWQ * 8 : 0)) +
-                     (size_t)W * XCH * 8;
+  size_t lds = (size_t)KOUT * 4 + 256 * 8 + (size_t)R3 * 256 * 8 +
+               (MODE == kModeReal2x ? (size_t)C * 8 : (MODE == kModeQuad ? (size_t)TWQ * 8 : 0)) +
+               (size_t)W * XCH * 8;
+  MelWaveArgs m;
+  if (mel) {  // CSR of the triangular filter rows restricted to bins < fft_length / 2
+    std::vector<float> cw;
+    std::vector<int> off(mel->mel_bins + 1, 0), lo(mel->mel_bins, 0);
+    const int half = KOUT / 2;
+    for (int b = 0; b < mel->mel_bins; ++b) {
+      const float* fr = mel->filters_host + (size_t)b * KOUT;
+      int l = half, h = 0;
+      for (int k = 0; k < half; ++k)
+        if (fr[k] != 0.0f) { if (k < l) l = k; h = k + 1; }
+      if (h <= l) { l = 0; h = 0; }
+      lo[b] = l;
+      for (int k = l; k < h; ++k) cw.push_back(fr[k]);
+      off[b + 1] = (int)cw.size();
+    }
+    if (cw.empty()) cw.push_back(0.0f);
+    if (cw.size() > 6144 || mel->mel_bins > 1024) return NXSIG_OK;  // keep the CSR in LDS; denser banks take the two-step path
+    *mel->handled = true;
+    const void *dw = nullptr, *doff = nullptr, *dlo = nullptr;
+    int rcm;
+    if ((rcm = ctx_table(c, 0xC5A1ull, cw.data(), cw.size() * sizeof(float), &dw))) return rcm;
+    if ((rcm = ctx_table(c, 0xC5A2ull, off.data(), off.size() * sizeof(int), &doff))) return rcm;
+    if ((rcm = ctx_table(c, 0xC5A3ull, lo.data(), lo.size() * sizeof(int), &dlo))) return rcm;
+    m.mel_bins = mel->mel_bins; m.nnz = (int)cw.size();
+    m.csr_w = reinterpret_cast<const float*>(dw); m.csr_off = reinterpret_cast<const int*>(doff); m.csr_lo = reinterpret_cast<const int*>(dlo);
+    m.ln10 = (float)std::log(10.0);
+    m.out = mel->out;
+    if ((rcm = launch_mel_init(c, &m.gmax))) return rcm;
+    lds += (size_t)m.nnz * 4 + (size_t)(2 * mel->mel_bins + 1) * 4;
+    a.z = nullptr;
+  }
   // Work distribution: each workgroup takes a SHORT contiguous chunk (a few units per wave) and the hardware
   // dispatcher hands chunks out in order.  Many short-lived workgroups balance the load across CUs / XCDs
   // dynamically: measured +12 % over a static equal partition with long-lived workgroups (the slowest CU set
   // the kernel time), at the price of re-loading the 12 KB of tables per workgroup from L2.
-  const int units_per_wave = env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : 8);  // measured optima
+  const int units_per_wave = mel ? env_int("NXSIG_MEL_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
+                                 : env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : 8);  // measured optima
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   // Interior frames [m_lo, m_hi): every one of the KOUT samples the streaming front-end reads lies inside the signal,
   // whatever the padding mode (window_padding :reflect / :same / explicit only touch the first and last few frames).
@@ -1340,11 +1327,34 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    if constexpr (std::is_invocable_v<decltype(kernel), MelWaveArgs>) {
+      m.w = a;
+      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, m);
+    } else {
+      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    }
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
   int rc;
+  if (mel) {
+    const int64_t big = (int64_t)1 << 62;
+    {
+      const int64_t upr = u_hi - u_lo;
+      if (!npred) rc = scale ? go(k_stft_mel_wave<C, MODE, false, true, W, J, false>, upr, big, u_lo, u_lo)
+                             : go(k_stft_mel_wave<C, MODE, false, false, W, J, false>, upr, big, u_lo, u_lo);
+      else rc = scale ? go(k_stft_mel_wave<C, MODE, false, true, W, J, true>, upr, big, u_lo, u_lo)
+                      : go(k_stft_mel_wave<C, MODE, false, false, W, J, true>, upr, big, u_lo, u_lo);
+      if (rc) return rc;
+    }
+    {
+      const int64_t upr = u_lo + (a.pairs_per_row - u_hi);
+      rc = scale ? go(k_stft_mel_wave<C, MODE, true, true, W, J>, upr, u_lo, 0, u_hi - u_lo)
+                 : go(k_stft_mel_wave<C, MODE, true, false, W, J>, upr, u_lo, 0, u_hi - u_lo);
+      if (rc) return rc;
+    }
+    return launch_mel_finish(c, mel->out, (int64_t)s.batch * s.fr.M * mel->mel_bins, m.gmax);
+  }
   {  // interior units u_lo .. u_hi-1
     const int64_t upr = u_hi - u_lo, big = (int64_t)1 << 62;
     if (!npred) rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false>, upr, big, u_lo, u_lo)
@@ -1359,76 +1369,6 @@ static int launch_wave(Ctx* c, const StftLaunch& s) {
                : go(k_stft_wave<C, MODE, true, false, W, J>, upr, u_lo, 0, u_hi - u_lo);
   }
   return rc;
-}
-
-int launch_mel_finish(Ctx* c, float* out, int64_t n, int* gmax);
-int launch_mel_init(Ctx* c, int** gmax);
-
-// fused stft -> mel; *handled = false when the shape is not covered (the caller falls back to stft + stft_to_mel)
-int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled) {
-  *handled = false;
-  constexpr int C = 1024, W = 4, R3 = 4, XCH = C + C / 16 + 16;
-  if (s.K != C || s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
-  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
-  // CSR of the triangular filter rows restricted to bins < K/2
-  std::vector<float> cw;
-  std::vector<int> off(mel_bins + 1, 0), lo(mel_bins, 0);
-  const int half = C / 2;
-  for (int b = 0; b < mel_bins; ++b) {
-    int l = half, h = 0;
-    for (int k = 0; k < half; ++k)
-      if (filters_host[(size_t)b * C + k] != 0.0f) { if (k < l) l = k; h = k + 1; }
-    if (h <= l) { l = 0; h = 0; }
-    lo[b] = l;
-    for (int k = l; k < h; ++k) cw.push_back(filters_host[(size_t)b * C + k]);
-    off[b + 1] = (int)cw.size();
-  }
-  if (cw.empty()) cw.push_back(0.0f);
-  if (cw.size() > 6144 || mel_bins > 1024) return NXSIG_OK;  // keep the CSR in LDS; denser banks take the two-step path
-  int rc = ensure_wave_tables_1024(c);
-  if (rc) return rc;
-  *handled = true;
-  MelWaveArgs m;
-  WaveArgs& a = m.w;
-  a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
-  a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
-  a.pairs_per_row = (s.fr.M + 1) / 2;
-  a.total_pairs = a.pairs_per_row * s.batch;
-  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = nullptr; a.dummy = nullptr; a.twR = nullptr;
-  Ctx::WaveTables& wt = c->wave_tables[C];
-  a.twB = reinterpret_cast<const v2f*>(wt.twB);
-  a.twC = reinterpret_cast<const v2f*>(wt.twC);
-  a.wtab = s.window_padK;
-  const void *dw = nullptr, *doff = nullptr, *dlo = nullptr;
-  if ((rc = ctx_table(c, 0xC5A1ull, cw.data(), cw.size() * sizeof(float), &dw))) return rc;
-  if ((rc = ctx_table(c, 0xC5A2ull, off.data(), off.size() * sizeof(int), &doff))) return rc;
-  if ((rc = ctx_table(c, 0xC5A3ull, lo.data(), lo.size() * sizeof(int), &dlo))) return rc;
-  m.mel_bins = mel_bins; m.nnz = (int)cw.size();
-  m.csr_w = reinterpret_cast<const float*>(dw); m.csr_off = reinterpret_cast<const int*>(doff); m.csr_lo = reinterpret_cast<const int*>(dlo);
-  m.ln10 = (float)std::log(10.0);
-  m.out = out;
-  if ((rc = launch_mel_init(c, &m.gmax))) return rc;
-  const int units_per_wave = env_int("NXSIG_MEL_UNITS_PER_WAVE", 16);
-  a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
-  const int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
-  if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft_mel: too many frames for one launch");
-  const size_t lds = (size_t)C * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8 +
-                     (size_t)m.nnz * 4 + (size_t)(2 * mel_bins + 1) * 4;
-  const bool streaming = s.fr.reflect == 0 && s.fr.lo == 0 && ((s.fr.M - 1) * (int64_t)s.fr.hop + C <= s.fr.L);
-  const bool scale = s.has_scale != 0;
-  auto go = [&](auto kernel) -> int {
-    if (lds > 64 * 1024)
-      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, m);
-    NXSIG_HIP_TRY(hipGetLastError());
-    return NXSIG_OK;
-  };
-  if (streaming && !scale) rc = go(k_stft_mel_wave<C, false, false, W>);
-  else if (streaming && scale) rc = go(k_stft_mel_wave<C, false, true, W>);
-  else if (!scale) rc = go(k_stft_mel_wave<C, true, false, W>);
-  else rc = go(k_stft_mel_wave<C, true, true, W>);
-  if (rc) return rc;
-  return launch_mel_finish(c, out, (int64_t)s.batch * s.fr.M * mel_bins, m.gmax);
 }
 
 int blue_tables_dev(Ctx* c, int K, int P, const float2** chirp, const float2** Bf);  // kernels_generic.hip
@@ -1476,42 +1416,38 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
   if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
   if (s.window_padK == nullptr) return NXSIG_OK;
-  const int w = env_int("NXSIG_WAVE_W", 0);
-  if (s.K == 1024) {  // two frames per 1024-point complex FFT
-    *handled = true;
-    if (w == 16) return launch_wave<1024, kModePair, 16>(c, s);
-    if (w == 8) return launch_wave<1024, kModePair, 8>(c, s);
-    return launch_wave<1024, kModePair, 4>(c, s);
-  }
-  if (s.K == 512) {  // 4 frames interleaved into one 1024-point complex FFT
-    *handled = true;
-    return launch_wave<1024, kModeQuad, 4, 2>(c, s);
-  }
-  if (s.K == 256) {  // 8 frames
-    *handled = true;
-    return launch_wave<1024, kModeQuad, 4, 4>(c, s);
-  }
-  if (s.K == 128) {  // 16 frames
-    *handled = true;
-    return launch_wave<1024, kModeQuad, 4, 8>(c, s);
-  }
-  if (s.K == 4096) {  // one frame as even/odd samples of a 2048-point complex FFT (32 points per lane)
-    *handled = true;
-    if (w == 2) return launch_wave<2048, kModeReal2x, 2>(c, s);
-    if (w == 6) return launch_wave<2048, kModeReal2x, 6>(c, s);
-    return launch_wave<2048, kModeReal2x, 4>(c, s);
-  }
-  if (s.K == 2048) {  // one frame as even/odd samples of a 1024-point complex FFT
-    *handled = true;
-    if (w == 12) return launch_wave<1024, kModeReal2x, 12>(c, s);
-    if (w == 8) return launch_wave<1024, kModeReal2x, 8>(c, s);
-    return launch_wave<1024, kModeReal2x, 4>(c, s);
+  // 4 waves per workgroup everywhere: 8 / 12 / 16 measured equal or slower (tables are re-read from L2 either way)
+  switch (s.K) {
+    case 1024: *handled = true; return launch_wave<1024, kModePair, 4>(c, s);      // two frames per 1024-point complex FFT
+    case 512: *handled = true; return launch_wave<1024, kModeQuad, 4, 2>(c, s);    // 4 frames interleaved into one transform
+    case 256: *handled = true; return launch_wave<1024, kModeQuad, 4, 4>(c, s);    // 8 frames
+    case 128: *handled = true; return launch_wave<1024, kModeQuad, 4, 8>(c, s);    // 16 frames
+    case 2048: *handled = true; return launch_wave<1024, kModeReal2x, 4>(c, s);    // one frame as even/odd samples
+    case 4096: *handled = true; return launch_wave<2048, kModeReal2x, 4>(c, s);    // same on the 2048-point core
+    default: break;
   }
   if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0)) {
     *handled = true;  // non-power-of-two: Bluestein through the 1024- (Kb <= 512) or 2048-point core
     return s.K <= 512 ? launch_blue_wave<1024>(c, s) : launch_blue_wave<2048>(c, s);
   }
   return NXSIG_OK;
+}
+
+// fused stft -> log-mel; *handled = false when the shape is not covered (the caller falls back to stft + stft_to_mel)
+int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled) {
+  *handled = false;
+  if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
+  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  MelLaunch mel{mel_bins, filters_host, out, handled};
+  switch (s.K) {
+    case 1024: return launch_wave<1024, kModePair, 4>(c, s, &mel);
+    case 512: return launch_wave<1024, kModeQuad, 4, 2>(c, s, &mel);
+    case 256: return launch_wave<1024, kModeQuad, 4, 4>(c, s, &mel);
+    case 128: return launch_wave<1024, kModeQuad, 4, 8>(c, s, &mel);
+    case 2048: return launch_wave<1024, kModeReal2x, 4>(c, s, &mel);
+    case 4096: return launch_wave<2048, kModeReal2x, 4>(c, s, &mel);
+    default: return NXSIG_OK;
+  }
 }
 
 template <int R, int W, bool HALF = false, bool DBL = false>
@@ -1795,8 +1731,6 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
 int launch_fir_wave(Ctx* c, const FirLaunch& s, bool* handled) {
   switch (env_int("NXSIG_FIR_W", 14)) {
     case 4: return launch_fir_wave_W<4>(c, s, handled);
-    case 6: return launch_fir_wave_W<6>(c, s, handled);
-    case 12: return launch_fir_wave_W<12>(c, s, handled);
     default: return launch_fir_wave_W<14>(c, s, handled);
   }
 }

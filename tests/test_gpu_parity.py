@@ -148,8 +148,15 @@ def test_stft_to_mel_doctest_and_oracle(golden):
     (1024, 1024, 256, "reflect", "psd", 80),    # fused, general loader + scaling
     (1024, 1000, 250, "valid", None, 64),       # fused, N < K
     (1024, 1024, 256, "valid", None, 7),        # fewer bands than lanes
-    (512, 512, 128, "valid", None, 80),         # not covered by the fused kernel: two-step path behind the same entry
-    (2048, 2048, 512, "valid", "spectrum", 128),
+    (512, 512, 128, "valid", None, 80),         # quad front-end (4 frames per transform) + fused mel
+    (512, 400, 160, "reflect", None, 80),       # speech front-end: 25 ms frames, 10 ms hop, 512-point FFT, centred
+    (512, 400, 160, "valid", "psd", 40),
+    (256, 256, 64, "same", None, 40),           # 8 frames per transform
+    (128, 128, 32, "valid", "spectrum", 20),    # 16 frames per transform
+    (2048, 2048, 512, "valid", "spectrum", 128),  # real-2x front-end
+    (2048, 1200, 300, "reflect", None, 64),
+    (4096, 4096, 1024, "valid", None, 128),     # 2048-point core
+    (400, 400, 160, "valid", None, 80),         # non-power-of-two: two-step path behind the same entry
 ])
 def test_mel_spectrogram_fused_matches_two_step_and_oracle(K, N, hop, pad, scaling, mb):
     rng = np.random.default_rng(K + mb)

@@ -19,4 +19,5 @@ defmodule NxSignalAMD.NIF do
   def from_device(_buf), do: :erlang.nif_error(:nif_not_loaded)
   def stft_dev(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft_dev(_ctx, _z, _frames, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def spectrum_mul_dev(_ctx, _z, _rows, _fft_length, _h), do: :erlang.nif_error(:nif_not_loaded)
 end

@@ -208,6 +208,15 @@ int nxsig_stft_mel_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t b
                        float* out, int64_t* num_frames_out, int32_t mem);
 
 /*
+ * STFT-domain filtering kept on the device: the `Nx.multiply(z, hfft)` step of the reference's documented
+ * workflow stft -> z * H -> istft (guides/filtering.livemd:137-159).  out[r][k] = z[r][k] * h[k], each component
+ * computed in double and rounded once like Nx.BinaryBackend's complex multiply.  z, out c64[rows][fft_length] (out may
+ * alias z); `h` c64[fft_length] is a HOST table (the DFT of the filter, e.g. from nxsig_fft).
+ */
+int nxsig_spectrum_mul_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int32_t fft_length, const nxsig_c64* h,
+                           nxsig_c64* out, int32_t mem);
+
+/*
  * 1-D complex case of Convolution.fftconvolve/3 — lib/nx_signal/convolution.ex:252-329 (tests: "FFT complex",
  * test/nx_signal/convolutions_test.exs:473-487): out = ifft(fft(a, P) * fft(b, P)) sliced per mode, with
  * P = next power of two >= n1 + n2 - 1 (same linear convolution as the reference's length n1 + n2 - 1).

@@ -257,6 +257,21 @@ static ERL_NIF_TERM nif_istft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM a
   return mk_ok(env, t);
 }
 
+/* spectrum_mul_dev(ctx, z_buf, rows, fft_length, h_bin) -> {:ok, z_buf}   (in place: Nx.multiply(z, hfft), guides/filtering.livemd:141) */
+static ERL_NIF_TERM nif_spectrum_mul_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  buf_res_t* z;
+  ErlNifBinary h;
+  ErlNifSInt64 rows;
+  int k;
+  if (argc != 5 || !get_ctx(env, argv[0], &c) || !enif_get_resource(env, argv[1], BUF_RES, (void**)&z) ||
+      !enif_get_int64(env, argv[2], &rows) || !enif_get_int(env, argv[3], &k) || !enif_inspect_binary(env, argv[4], &h))
+    return enif_make_badarg(env);
+  if (rows < 0 || k < 1 || h.size != (size_t)k * 8 || z->bytes < (size_t)rows * (size_t)k * 8) return enif_make_badarg(env);
+  int rc = nxsig_spectrum_mul_c64(c->ctx, (const nxsig_c64*)z->dptr, rows, k, (const nxsig_c64*)h.data, (nxsig_c64*)z->dptr, NXSIG_DEVICE);
+  return rc ? mk_error(env, rc) : mk_ok(env, argv[1]);
+}
+
 static int load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {
   (void)priv; (void)info;
   CTX_RES = enif_open_resource_type(env, NULL, "nxsig_ctx", ctx_dtor, ERL_NIF_RT_CREATE | ERL_NIF_RT_TAKEOVER, NULL);
@@ -276,6 +291,7 @@ static ErlNifFunc funcs[] = {
     {"from_device", 1, nif_from_device, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_dev", 6, nif_stft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_dev", 6, nif_istft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"spectrum_mul_dev", 5, nif_spectrum_mul_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 ERL_NIF_INIT(Elixir.NxSignalAMD.NIF, funcs, load, NULL, upgrade, NULL)

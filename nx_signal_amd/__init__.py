@@ -26,6 +26,7 @@ from .device import Context, DeviceBuffer, default_context, device_view, is_devi
 
 __all__ = [
     "stft", "istft", "as_windowed", "overlap_and_add", "fft_frequencies", "mel_filters", "stft_to_mel", "mel_spectrogram",
+    "spectrum_multiply",
     "Context", "DeviceBuffer", "default_context", "ArgumentError",
     "NxSignalDeviceError", "NxSignalLibraryError", "NxSignalUnsupported",
 ]
@@ -338,6 +339,34 @@ def stft_to_mel(z, sampling_rate, ctx: Context | None = None, **opts):
     rows = int(np.prod(zin.shape[:-1], dtype=np.int64))
     out = np.empty(zin.shape[:-1] + (mb,), dtype=np.float32)
     _lib.check(lib.nxsig_stft_to_mel(c.handle, _as_ptr(zin), rows, K, mb, _as_ptr(filt), _as_ptr(out), _lib.HOST))
+    return out
+
+
+def spectrum_multiply(z, h, ctx: Context | None = None):
+    """The `Nx.multiply(z, hfft)` step of the reference's STFT-domain filtering workflow (guides/filtering.livemd:137-159:
+    stft -> z * H -> istft), kept on the device.  z c64[..., frames, K] (numpy or DeviceBuffer), h c64[K]
+    (host) -> same kind and shape as z.  Components are computed in double and rounded once like Nx.BinaryBackend."""
+    hh = np.ascontiguousarray(np.asarray(h).astype(np.complex64))
+    if hh.ndim != 1:
+        raise ArgumentError("spectrum_multiply: h must be a rank-1 tensor of fft_length bins")
+    K = int(hh.shape[0])
+    lib = _lib.load()
+    if is_device(z):
+        ptr, shape, dt = device_view(z)
+        if dt != np.complex64 or shape[-1] != K:
+            raise ArgumentError("spectrum_multiply: z must be complex64 with fft_length bins on the last axis")
+        c = _ctx_of(z, ctx)
+        out = c.empty(tuple(shape), np.complex64)
+        rows = int(np.prod(shape[:-1], dtype=np.int64))
+        _lib.check(lib.nxsig_spectrum_mul_c64(c.handle, C.c_void_p(ptr), rows, K, _as_ptr(hh), C.c_void_p(out.ptr), _lib.DEVICE))
+        return out
+    zin = np.ascontiguousarray(np.asarray(z).astype(np.complex64))
+    if zin.shape[-1] != K:
+        raise ArgumentError("spectrum_multiply: z must have fft_length bins on the last axis")
+    c = _ctx_of(None, ctx)
+    out = np.empty_like(zin)
+    rows = int(np.prod(zin.shape[:-1], dtype=np.int64))
+    _lib.check(lib.nxsig_spectrum_mul_c64(c.handle, _as_ptr(zin), rows, K, _as_ptr(hh), _as_ptr(out), _lib.HOST))
     return out
 
 

@@ -89,6 +89,7 @@ SIGNATURES = {
     "nxsig_fftconvolve_c64": (C.c_int, [_p, _p, _i64, _p, _i64, _i32, _p, _i32]),
     "nxsig_mel_filters_f32": (C.c_int, [_i32, _i32, _f64, _f64, _f64, _p]),
     "nxsig_stft_to_mel": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _i32]),
+    "nxsig_spectrum_mul_c64": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _i32]),
     "nxsig_stft_mel_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _p, _p, C.POINTER(_i64), _i32]),
 }
 

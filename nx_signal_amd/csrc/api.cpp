@@ -692,6 +692,30 @@ int nxsig_stft_to_mel(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int32_t 
   NXSIG_API_END
 }
 
+int nxsig_spectrum_mul_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int32_t fft_length, const nxsig_c64* h,
+                           nxsig_c64* out, int32_t mem) {
+  NXSIG_API_BEGIN
+  if (!z || !h || !out) return set_error(NXSIG_ERR_INVALID_ARG, "spectrum_mul: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (rows < 0 || fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "spectrum_mul: rows >= 0 and fft_length >= 1 required");
+  NXSIG_CHECK_CTX(ctx)
+  if (rows == 0) return NXSIG_OK;
+  const void* hd = nullptr;
+  if ((rc = ctx_table(c, 0x5BEC0ull ^ (uint64_t)fft_length, h, (size_t)fft_length * sizeof(float2), &hd))) return rc;
+  const size_t bytes = (size_t)rows * fft_length * sizeof(float2);
+  if (mem == NXSIG_DEVICE)
+    return launch_spectrum_mul(c, reinterpret_cast<const float2*>(z), rows, fft_length, reinterpret_cast<const float2*>(hd),
+                               reinterpret_cast<float2*>(out));
+  Staged st(c);
+  const void* zd = nullptr;
+  if ((rc = st.in(1, z, bytes, &zd))) return rc;
+  float2* zw = reinterpret_cast<float2*>(const_cast<void*>(zd));
+  if ((rc = launch_spectrum_mul(c, zw, rows, fft_length, reinterpret_cast<const float2*>(hd), zw))) return rc;
+  return st.out_copy(out, zw, bytes);
+  NXSIG_API_END
+}
+
 int nxsig_stft_mel_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride,
                        const float* window, const nxsig_stft_params* p, int32_t mel_bins, const float* filters, float* out,
                        int64_t* num_frames_out, int32_t mem) {

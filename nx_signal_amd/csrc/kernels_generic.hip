@@ -539,6 +539,18 @@ __global__ __launch_bounds__(kThreads) void k_cmul_inplace(float2* __restrict__ 
   if (i < n) a[i] = cmul(a[i], b[i]);
 }
 
+// out[r][k] = z[r][k] * h[k] (guides/filtering.livemd:141: Nx.multiply(z, hfft)); BinaryBackend multiplies complex
+// numbers in double and rounds each component once, so do the same (the kernel is HBM-bound either way)
+__global__ __launch_bounds__(kThreads) void k_spectrum_mul(const float2* __restrict__ z, const float2* __restrict__ h,
+                                                           float2* __restrict__ out, int64_t total, int32_t K) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    const float2 a = z[i], b = h[i % K];
+    const double re = (double)a.x * (double)b.x - (double)a.y * (double)b.y;
+    const double im = (double)a.x * (double)b.y + (double)a.y * (double)b.x;
+    out[i] = make_float2((float)re, (float)im);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ stft_to_mel
 // lib/nx_signal.ex:486-513.  The Slaney filters are triangles: band b is non-zero on a short bin range, so the
 // `Nx.dot` over frequencies is a sparse band sum (per band a [lo, hi) range into the dense filter row).
@@ -949,6 +961,17 @@ int launch_fftconvolve_c64(Ctx* c, const float2* a, int64_t n1, const float2* b,
   NXSIG_HIP_TRY(hipGetLastError());
   if ((rc = launch_fft(c, A, false, 1, P, P, true, C))) return rc;
   NXSIG_HIP_TRY(hipMemcpyAsync(out, C + start, (size_t)len * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+  return NXSIG_OK;
+}
+
+int launch_spectrum_mul(Ctx* c, const float2* z, int64_t rows, int32_t K, const float2* h_dev, float2* out) {
+  const int64_t total = rows * K;
+  if (total == 0) return NXSIG_OK;
+  int64_t blocks = (total + kThreads - 1) / kThreads;
+  const int64_t cap = (int64_t)c->num_cus * 32;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_spectrum_mul, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, z, h_dev, out, total, K);
+  NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
 }
 

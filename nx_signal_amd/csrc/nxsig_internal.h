@@ -130,6 +130,7 @@ struct FirLaunch {
   float* y;                    // device f32[batch][out_len]
 };
 int launch_fir(Ctx* c, const FirLaunch& a);
+int launch_spectrum_mul(Ctx* c, const float2* z, int64_t rows, int32_t K, const float2* h_dev, float2* out);
 int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t mel_bins, const float* filters_host,
                        float* out);
 int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled);

@@ -455,3 +455,42 @@ def test_stft_config4_shard_full_size_beyond_4gb():
         assert_close(got, ref[0], f"channel {c} frame {m} (byte offset {off})")
     zd.free()
     xd.free()
+
+
+# ------------------------------------------------------------------------------- STFT-domain filtering chain (8f-3)
+def test_spectrum_multiply_bit_exact_and_shapes():
+    rng = np.random.default_rng(11)
+    z = (rng.standard_normal((3, 17, 256)) + 1j * rng.standard_normal((3, 17, 256))).astype(np.complex64)
+    h = (rng.standard_normal(256) + 1j * rng.standard_normal(256)).astype(np.complex64)
+    exp = (z.astype(np.complex128) * h.astype(np.complex128)).astype(np.complex64)  # double, one rounding (BinaryBackend)
+    got = S.spectrum_multiply(z, h)
+    assert got.shape == z.shape and np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    ctx = S.default_context()
+    gd = S.spectrum_multiply(ctx.to_device(z), h)
+    assert np.array_equal(gd.numpy().view(np.uint32), exp.view(np.uint32))
+    with pytest.raises(S.ArgumentError):
+        S.spectrum_multiply(z, h[:100])
+
+
+def test_stft_domain_filtering_chain_stays_on_device():
+    """guides/filtering.livemd:137-159: stft(scaling: :spectrum) -> z * hfft -> istft(scaling: :spectrum), every
+    intermediate device-resident; compared with the same chain through the oracle."""
+    fs, N, hop = 8000, 1024, 256
+    x = O.synth_signal(40000, seed=21)
+    w = S.windows.hann(N)
+    hcoef = S.filters.firwin(101, [1000], sampling_rate=fs)
+    hfft = O.fft(hcoef, length=N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=fs, scaling="spectrum")
+    ctx = S.default_context()
+    zd, _, _ = S.stft(ctx.to_device(x), w, **opts)
+    zf = S.spectrum_multiply(zd, hfft)
+    yd = S.istft(zf, w, **opts)
+    assert S.device.is_device(zd) and S.device.is_device(zf) and S.device.is_device(yd)
+    zo, _, _ = O.stft(x, w, **opts)
+    zfo = (zo.astype(np.complex128) * hfft.astype(np.complex128)).astype(np.complex64)
+    yo = O.istft(zfo, w, **opts)
+    y = yd.numpy()
+    assert y.shape == yo.shape
+    inner = slice(N, -N)  # well-conditioned interior (edges: see the conditioning note in the istft tests)
+    assert_close(y[inner], yo[inner], "filtered chain, interior")
+    assert nerr(y, yo)[0] < 2e-4

@@ -208,6 +208,20 @@ int nxsig_stft_mel_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t b
                        float* out, int64_t* num_frames_out, int32_t mem);
 
 /*
+ * Magnitude spectrogram fused with the STFT (opt-in, not in the reference API): what
+ * guides/spectrogram.livemd:76-92 computes from NxSignal.stft/3 — Nx.abs(s) of the bins below fft_length / 2, optionally
+ * as dBFS 20 * log(|s| / reduce_max|s|) / log(10) — without writing the complex spectrum to HBM: fft_length * 2 bytes per
+ * frame leave the chip instead of fft_length * 8.   x f32[batch][length] -> out f32[batch][M][fft_length / 2].
+ * kind: NXSIG_MAG_ABS |s|, NXSIG_MAG_POWER |s|^2, NXSIG_MAG_DBFS (the maximum runs over the whole output).
+ */
+#define NXSIG_MAG_ABS 0
+#define NXSIG_MAG_POWER 1
+#define NXSIG_MAG_DBFS 2
+int nxsig_stft_magnitude_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride,
+                             const float* window, const nxsig_stft_params* params, int32_t kind, float* out,
+                             int64_t* num_frames_out, int32_t mem);
+
+/*
  * STFT-domain filtering kept on the device: the `Nx.multiply(z, hfft)` step of the reference's documented
  * workflow stft -> z * H -> istft (guides/filtering.livemd:137-159).  out[r][k] = z[r][k] * h[k], each component
  * computed in double and rounded once like Nx.BinaryBackend's complex multiply.  z, out c64[rows][fft_length] (out may

@@ -26,7 +26,7 @@ from .device import Context, DeviceBuffer, default_context, device_view, is_devi
 
 __all__ = [
     "stft", "istft", "as_windowed", "overlap_and_add", "fft_frequencies", "mel_filters", "stft_to_mel", "mel_spectrogram",
-    "spectrum_multiply",
+    "spectrum_multiply", "spectrogram",
     "Context", "DeviceBuffer", "default_context", "ArgumentError",
     "NxSignalDeviceError", "NxSignalLibraryError", "NxSignalUnsupported",
 ]
@@ -418,6 +418,67 @@ def mel_spectrogram(data, window, ctx: Context | None = None, **opts):
     _lib.check(lib.nxsig_stft_mel_f32(c.handle, _as_ptr(x), L, batch, L, _as_ptr(w), C.byref(p), mb, _as_ptr(filt), _as_ptr(out),
                                       C.byref(M), _lib.HOST))
     return out
+
+
+def _stft_times(m: int, N: int, fs: float) -> np.ndarray:
+    times = np.empty(m, dtype=np.float32)
+    _lib.check(_lib.load().nxsig_stft_times_f32(N, fs, m, _as_ptr(times)))
+    return times
+
+
+_MAG_KINDS = {"magnitude": _lib.MAG_ABS, "power": _lib.MAG_POWER, "dbfs": _lib.MAG_DBFS}
+
+
+def spectrogram(data, window, ctx: Context | None = None, **opts):
+    """Extension (not in the reference API): the magnitude spectrogram guides/spectrogram.livemd:76-92
+    derives from `NxSignal.stft/3` — `Nx.abs(s)` of the bins below fft_length / 2, optionally in dBFS
+    (`20 * log(|s| / reduce_max(|s|)) / log(10)`) — fused with the STFT so the complex spectrum never goes to HBM.
+    Takes the stft options plus :kind ("magnitude" (default), "power", "dbfs").
+    Returns {spec f32[..., frames, fft_length/2], t, f[:fft_length/2]}."""
+    kind = opts.pop("kind", "magnitude")
+    if kind not in _MAG_KINDS:
+        raise ArgumentError(f"invalid :kind, expected one of {list(_MAG_KINDS)}, got: {kind!r}")
+    o = _validate(
+        opts,
+        {"overlap_length": None, "window": None, "scaling": None, "window_padding": "valid", "sampling_rate": 100,
+         "fft_length": "power_of_two"},
+        "spectrogram",
+    )
+    w = _window_host(window)
+    N = int(w.shape[0])
+    fs = float(o["sampling_rate"])
+    overlap = N // 2 if o["overlap_length"] is None else int(o["overlap_length"])
+    hop = N - overlap
+    if o["scaling"] not in _SCALING:
+        raise ArgumentError(f"invalid :scaling, expected one of :spectrum, :psd or nil, got: {o['scaling']!r}")
+    mode, lo, hi = _pad_args(o["window_padding"])
+    K = _resolve_fft_length(o["fft_length"], N)
+    half = K // 2
+    p = StftParams(N, hop, K, mode, lo, hi, _SCALING[o["scaling"]], 0, fs)
+    lib = _lib.load()
+    M = C.c_int64()
+    f = fft_frequencies(fs, fft_length=K)[:half]
+    if is_device(data):
+        ptr, shape, dt = device_view(data)
+        if dt != np.float32:
+            raise ArgumentError("spectrogram: device input must be float32")
+        c = _ctx_of(data, ctx)
+        L = shape[-1]
+        batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
+        m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
+        out = c.empty(tuple(shape[:-1]) + (m, half), np.float32)
+        _lib.check(lib.nxsig_stft_magnitude_f32(c.handle, C.c_void_p(ptr), L, batch, L, _as_ptr(w), C.byref(p), _MAG_KINDS[kind],
+                                                C.c_void_p(out.ptr), C.byref(M), _lib.DEVICE))
+        return out, _stft_times(m, N, fs), f
+    x = _host_f32(data, "spectrogram")
+    c = _ctx_of(None, ctx)
+    L = x.shape[-1]
+    batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
+    m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
+    out = np.empty(x.shape[:-1] + (m, half), dtype=np.float32)
+    _lib.check(lib.nxsig_stft_magnitude_f32(c.handle, _as_ptr(x), L, batch, L, _as_ptr(w), C.byref(p), _MAG_KINDS[kind], _as_ptr(out),
+                                            C.byref(M), _lib.HOST))
+    return out, _stft_times(m, N, fs), f
 
 
 from . import convolution, filters, transforms, waveforms, windows  # noqa: E402,F401

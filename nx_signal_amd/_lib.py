@@ -16,6 +16,7 @@ OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_OOM = 0, -1, -
 HOST, DEVICE = 0, 1
 PAD_VALID, PAD_REFLECT, PAD_SAME, PAD_EXPLICIT = 0, 1, 2, 3
 SCALE_NONE, SCALE_SPECTRUM, SCALE_PSD = 0, 1, 2
+MAG_ABS, MAG_POWER, MAG_DBFS = 0, 1, 2
 WIN_RECTANGULAR, WIN_BARTLETT, WIN_TRIANGULAR, WIN_BLACKMAN, WIN_HAMMING, WIN_HANN, WIN_KAISER = range(7)
 CONV_FULL, CONV_SAME, CONV_VALID = 0, 1, 2
 
@@ -90,6 +91,7 @@ SIGNATURES = {
     "nxsig_mel_filters_f32": (C.c_int, [_i32, _i32, _f64, _f64, _f64, _p]),
     "nxsig_stft_to_mel": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _i32]),
     "nxsig_spectrum_mul_c64": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _i32]),
+    "nxsig_stft_magnitude_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _p, C.POINTER(_i64), _i32]),
     "nxsig_stft_mel_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _p, _p, C.POINTER(_i64), _i32]),
 }
 

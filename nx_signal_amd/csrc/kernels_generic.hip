@@ -551,6 +551,35 @@ __global__ __launch_bounds__(kThreads) void k_spectrum_mul(const float2* __restr
   }
 }
 
+// |z| (kind 0 / 2) or |z|^2 (kind 1) of the bins below K/2: the two-step form of the fused magnitude sink
+__global__ __launch_bounds__(kThreads) void k_mag_from_spectrum(const float2* __restrict__ z, int64_t rows, int32_t K,
+                                                                int32_t kind, float* __restrict__ out, int* gmax) {
+  const int half = K / 2;
+  const int64_t total = rows * half;
+  float vmax = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t r = i / half;
+    const int k = (int)(i - r * half);
+    const float2 v = z[(size_t)r * K + k];
+    const float p2 = v.x * v.x + v.y * v.y;
+    const float o = kind == 1 ? p2 : sqrtf(p2);
+    out[i] = o;
+    vmax = o > vmax ? o : vmax;
+  }
+  if (kind == 2) {
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(vmax, off); vmax = o > vmax ? o : vmax; }
+    if ((threadIdx.x & 63) == 0) atomicMax(gmax, __float_as_int(vmax));  // magnitudes are >= 0: plain int order
+  }
+}
+__global__ __launch_bounds__(kThreads) void k_mag_db_pass2_g(float* __restrict__ out, int64_t n, const int* __restrict__ gmax) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const float mx = __int_as_float(*gmax);  // magnitudes are >= 0: stored in plain int order
+  const float r = out[i] / mx;
+  const float l = logf(r);  // <= 1 ulp from the correctly rounded double log the reference takes
+  out[i] = (20.0f * l) / 2.3025851f;
+}
+
 // ------------------------------------------------------------------------------------------ stft_to_mel
 // lib/nx_signal.ex:486-513.  The Slaney filters are triangles: band b is non-zero on a short bin range, so the
 // `Nx.dot` over frequencies is a sparse band sum (per band a [lo, hi) range into the dense filter row).
@@ -621,6 +650,7 @@ __global__ __launch_bounds__(kThreads) void k_mel_pass2(float* __restrict__ out,
 }
 
 // ========================================================================================== launchers
+int launch_mel_init(Ctx* c, int** gmax);
 static int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -1012,6 +1042,24 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
   hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, out, n,
                      reinterpret_cast<const int*>(gm));
   NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+int launch_mag_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, int kind, float* out) {
+  const int64_t total = rows * (K / 2);
+  if (total == 0) return NXSIG_OK;
+  int* gm = nullptr;
+  int rc = launch_mel_init(c, &gm);
+  if (rc) return rc;
+  int64_t blocks = (total + kThreads - 1) / kThreads;
+  const int64_t cap = (int64_t)c->num_cus * 32;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_mag_from_spectrum, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, z, rows, K, kind, out, gm);
+  NXSIG_HIP_TRY(hipGetLastError());
+  if (kind == 2) {
+    hipLaunchKernelGGL(k_mag_db_pass2_g, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, out, total, gm);
+    NXSIG_HIP_TRY(hipGetLastError());
+  }
   return NXSIG_OK;
 }
 

@@ -329,6 +329,8 @@ typedef __attribute__((address_space(1))) v2f gv2f;  // explicit global address 
 // as CSR; log10; per-wave running max -> one atomicMax.  A second tiny pass (k_mel_pass2) applies max(., gmax - 8) and
 // (. + 4) / 4 once the global maximum is known.  Every front-end (pair / real-2x / quad) and the interior / edge split
 // are shared with the plain STFT.
+enum { kSinkSpectrum = 0, kSinkMel = 1, kSinkMag = 2 };
+
 struct MelWaveArgs {
   WaveArgs w;                 // framing / tables of the STFT front half (z unused)
   int32_t mel_bins, nnz;
@@ -336,12 +338,15 @@ struct MelWaveArgs {
   const int* csr_off;         // [mel_bins + 1]
   const int* csr_lo;          // [mel_bins] first bin of each band
   float ln10;
-  float* out;                 // f32[batch][M][mel_bins] (log10 power, before the clamp pass)
+  float* out;                 // f32[batch][M][mel_bins] (log10 power, before the clamp pass) / f32[batch][M][fft_length/2] (MAG)
   int* gmax;
+  int32_t mag_kind;           // MAG sink: 0 = |X|, 1 = |X|^2, 2 = |X| with a running maximum (dBFS pass follows)
 };
 
-template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J, bool NPRED, bool MEL>
+template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J, bool NPRED, int SINK>
 __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveArgs* mp) {
+  constexpr bool MEL = SINK == kSinkMel;   // |X|^2 -> LDS -> sparse mel filterbank -> log10
+  constexpr bool MAG = SINK == kSinkMag;   // |X| or |X|^2 of the bins below fft_length / 2 straight to HBM as f32
   constexpr int P = K / 64;     // complex points per lane
   constexpr int R3 = K / 256;   // last radix: 4 or 8
   constexpr int B12 = P / 16;   // radix-16 butterflies per lane in passes A and B
@@ -405,6 +410,14 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
       }
     }
     wave_lds_fence();  // the power spectrum is consumed before the next pass A overwrites the buffer
+  };
+  // MAG sink: two adjacent bins of one frame (p2 = |X[k]|^2, |X[k+1]|^2) -> f32 row of fft_length / 2 values
+  auto mag_store = [&](float* rowp, v2f p2) {
+    v2f v = p2;
+    if (mp->mag_kind != 1) v = v2f{__builtin_sqrtf(p2.x), __builtin_sqrtf(p2.y)};
+    const float mx = v.x > v.y ? v.x : v.y;
+    vmax = mx > vmax ? mx : vmax;
+    __builtin_nontemporal_store(v, (gv2f*)rowp);
   };
 
   const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
@@ -563,12 +576,18 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
           v4f xa = v4f{z0v.x + p0.x, z0v.y - p0.y, z1v.x + p1.x, z1v.y - p1.y} * 0.5f;
           v4f xbv = v4f{z0v.y + p0.y, p0.x - z0v.x, z1v.y + p1.y, p1.x - z1v.x} * 0.5f;
           if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }
-          if (MEL) {
+          if (MEL || MAG) {
             if (HQ >= 2 ? (q < HQ / 2) : (lane < 32)) {  // bins k0 = 2 lane + par + 128 q below fft_length / 2
               const v2f pa2 = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};
               const v2f pb2 = v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w};
-              *reinterpret_cast<v2f*>(&mags[(2 * j) * KH + 2 * lane + 128 * q]) = pa2;
-              *reinterpret_cast<v2f*>(&mags[(2 * j + 1) * KH + 2 * lane + 128 * q]) = pb2;
+              if (MEL) {
+                *reinterpret_cast<v2f*>(&mags[(2 * j) * KH + 2 * lane + 128 * q]) = pa2;
+                *reinterpret_cast<v2f*>(&mags[(2 * j + 1) * KH + 2 * lane + 128 * q]) = pb2;
+              } else {
+                float* r0 = mp->out + ((size_t)crow * a.M + mA + 2 * j) * KH + 2 * lane + 128 * q;
+                if (mA + 2 * j < a.M) mag_store(r0, pa2);
+                if (mA + 2 * j + 1 < a.M) mag_store(r0 + KH, pb2);
+              }
             }
           } else {
             __builtin_nontemporal_store(xa, (gv4f*)(zfa + 128 * q));
@@ -583,7 +602,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
     }
     v2f* zA = a.z + ((size_t)crow * a.M + mA) * KOUT + 2 * lane;
     v2f* zB = (GENERAL || haveB) ? zA + K : a.dummy + 2 * lane;  // pair: frame B; real-2x: bins K..2K-1
-    constexpr int QN = (MEL && MODE == kModePair) ? NQ / 2 : NQ;  // MEL: only the bins below fft_length / 2
+    constexpr int QN = ((MEL || MAG) && MODE == kModePair) ? NQ / 2 : NQ;  // MEL / MAG: only the bins below fft_length / 2
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
       // partner of bin k = 2l+par+128q is K-k = 2l'+par+128(NQ-1-q) on lane l' (lane 0 / par 0: own (NQ-q) % NQ)
@@ -614,6 +633,10 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
           const v2f pb2 = v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w};
           *reinterpret_cast<v2f*>(&mags[KH + 2 * lane + 128 * q]) = pb2;
         }
+      } else if (MAG) {
+        float* r0 = mp->out + ((size_t)crow * a.M + mA) * KH + 2 * lane + 128 * q;
+        mag_store(r0, v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w});
+        if (MODE == kModePair && haveB) mag_store(r0 + KH, v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w});
       } else {
         __builtin_nontemporal_store(xa, (gv4f*)(zA + 128 * q));
         if (!GENERAL || haveB) __builtin_nontemporal_store(xbv, (gv4f*)(zB + 128 * q));
@@ -623,7 +646,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
     row = nrow; uin = nuin;
     advance(nrow, nuin);
   }
-  if (MEL) {  // one atomic per wave: running maximum in ordered-int encoding
+  if (MEL || (MAG && mp->mag_kind == 2)) {  // one atomic per wave: running maximum in ordered-int encoding
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(vmax, off); vmax = o > vmax ? o : vmax; }
     if (lane == 0 && p_begin + wave < p_end) {
@@ -635,11 +658,26 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
 
 template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2, bool NPRED = false>
 __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
-  stft_wave_body<K, MODE, GENERAL, SCALE, W, J, NPRED, false>(a, nullptr);
+  stft_wave_body<K, MODE, GENERAL, SCALE, W, J, NPRED, kSinkSpectrum>(a, nullptr);
 }
 template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2, bool NPRED = false>
 __global__ __launch_bounds__(64 * W) void k_stft_mel_wave(MelWaveArgs m) {
-  stft_wave_body<K, MODE, GENERAL, SCALE, W, J, NPRED, true>(m.w, &m);
+  stft_wave_body<K, MODE, GENERAL, SCALE, W, J, NPRED, kSinkMel>(m.w, &m);
+}
+template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2, bool NPRED = false>
+__global__ __launch_bounds__(64 * W) void k_stft_mag_wave(MelWaveArgs m) {
+  stft_wave_body<K, MODE, GENERAL, SCALE, W, J, NPRED, kSinkMag>(m.w, &m);
+}
+
+// dBFS of a magnitude spectrogram (guides/spectrogram.livemd:88-90): 20 * log(|s| / max|s|) / log(10), f32 steps
+__global__ __launch_bounds__(256) void k_mag_db_pass2(float* __restrict__ out, int64_t n, const int* __restrict__ gmax) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int g = *gmax;
+  const float mx = __int_as_float(g >= 0 ? g : g ^ 0x7fffffff);
+  const float r = out[i] / mx;
+  const float l = logf(r);  // <= 1 ulp from the correctly rounded double log the reference takes
+  out[i] = (20.0f * l) / 2.3025851f;
 }
 
 // ============================================================================================ Bluestein on the wave core
@@ -1233,8 +1271,9 @@ int launch_mel_init(Ctx* c, int** gmax);
 struct MelLaunch {
   int mel_bins;
   const float* filters_host;  // [mel_bins][fft_length]
-  float* out;                 // device f32[batch][M][mel_bins]
+  float* out;                 // device f32[batch][M][mel_bins]  (magnitude sink: f32[batch][M][fft_length / 2])
   bool* handled;              // set once the CSR fits LDS and the launch is committed
+  int mag_kind = -1;          // >= 0: magnitude sink (0 |X|, 1 |X|^2, 2 dBFS) instead of the mel filterbank
 };
 
 template <int C, int MODE, int W, int J = 2>
@@ -1265,7 +1304,15 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
                (MODE == kModeReal2x ? (size_t)C * 8 : (MODE == kModeQuad ? (size_t)TWQ * 8 : 0)) +
                (size_t)W * XCH * 8;
   MelWaveArgs m;
-  if (mel) {  // CSR of the triangular filter rows restricted to bins < fft_length / 2
+  if (mel && mel->mag_kind >= 0) {
+    *mel->handled = true;
+    m.mel_bins = 0; m.nnz = 0; m.csr_w = nullptr; m.csr_off = nullptr; m.csr_lo = nullptr; m.ln10 = 0.f;
+    m.out = mel->out; m.mag_kind = mel->mag_kind;
+    int rcm;
+    if ((rcm = launch_mel_init(c, &m.gmax))) return rcm;
+    a.z = nullptr;
+  } else if (mel) {  // CSR of the triangular filter rows restricted to bins < fft_length / 2
+    m.mag_kind = -1;
     std::vector<float> cw;
     std::vector<int> off(mel->mel_bins + 1, 0), lo(mel->mel_bins, 0);
     const int half = KOUT / 2;
@@ -1299,7 +1346,8 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
   // dispatcher hands chunks out in order.  Many short-lived workgroups balance the load across CUs / XCDs
   // dynamically: measured +12 % over a static equal partition with long-lived workgroups (the slowest CU set
   // the kernel time), at the price of re-loading the 12 KB of tables per workgroup from L2.
-  const int units_per_wave = mel ? env_int("NXSIG_MEL_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
+  const int units_per_wave = (mel && mel->mag_kind >= 0) ? env_int("NXSIG_MAG_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
+                             : mel ? env_int("NXSIG_MEL_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
                                  : env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : 8);  // measured optima
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   // Interior frames [m_lo, m_hi): every one of the KOUT samples the streaming front-end reads lies inside the signal,
@@ -1337,6 +1385,29 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     return NXSIG_OK;
   };
   int rc;
+  if (mel && mel->mag_kind >= 0) {
+    const int64_t big = (int64_t)1 << 62;
+    {
+      const int64_t upr = u_hi - u_lo;
+      if (!npred) rc = scale ? go(k_stft_mag_wave<C, MODE, false, true, W, J, false>, upr, big, u_lo, u_lo)
+                             : go(k_stft_mag_wave<C, MODE, false, false, W, J, false>, upr, big, u_lo, u_lo);
+      else rc = scale ? go(k_stft_mag_wave<C, MODE, false, true, W, J, true>, upr, big, u_lo, u_lo)
+                      : go(k_stft_mag_wave<C, MODE, false, false, W, J, true>, upr, big, u_lo, u_lo);
+      if (rc) return rc;
+    }
+    {
+      const int64_t upr = u_lo + (a.pairs_per_row - u_hi);
+      rc = scale ? go(k_stft_mag_wave<C, MODE, true, true, W, J>, upr, u_lo, 0, u_hi - u_lo)
+                 : go(k_stft_mag_wave<C, MODE, true, false, W, J>, upr, u_lo, 0, u_hi - u_lo);
+      if (rc) return rc;
+    }
+    if (mel->mag_kind == 2) {
+      const int64_t n = (int64_t)s.batch * s.fr.M * (KOUT / 2);
+      hipLaunchKernelGGL(k_mag_db_pass2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, mel->out, n, m.gmax);
+      NXSIG_HIP_TRY(hipGetLastError());
+    }
+    return NXSIG_OK;
+  }
   if (mel) {
     const int64_t big = (int64_t)1 << 62;
     {
@@ -1439,6 +1510,23 @@ int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float*
   if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
   if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
   MelLaunch mel{mel_bins, filters_host, out, handled};
+  switch (s.K) {
+    case 1024: return launch_wave<1024, kModePair, 4>(c, s, &mel);
+    case 512: return launch_wave<1024, kModeQuad, 4, 2>(c, s, &mel);
+    case 256: return launch_wave<1024, kModeQuad, 4, 4>(c, s, &mel);
+    case 128: return launch_wave<1024, kModeQuad, 4, 8>(c, s, &mel);
+    case 2048: return launch_wave<1024, kModeReal2x, 4>(c, s, &mel);
+    case 4096: return launch_wave<2048, kModeReal2x, 4>(c, s, &mel);
+    default: return NXSIG_OK;
+  }
+}
+
+// fused stft -> magnitude / power / dBFS spectrogram of the bins below fft_length / 2
+int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool* handled) {
+  *handled = false;
+  if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
+  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  MelLaunch mel{0, nullptr, out, handled, kind};
   switch (s.K) {
     case 1024: return launch_wave<1024, kModePair, 4>(c, s, &mel);
     case 512: return launch_wave<1024, kModeQuad, 4, 2>(c, s, &mel);

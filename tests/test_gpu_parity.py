@@ -494,3 +494,43 @@ def test_stft_domain_filtering_chain_stays_on_device():
     inner = slice(N, -N)  # well-conditioned interior (edges: see the conditioning note in the istft tests)
     assert_close(y[inner], yo[inner], "filtered chain, interior")
     assert nerr(y, yo)[0] < 2e-4
+
+
+# ------------------------------------------------------------------------------- magnitude spectrogram (8f-2)
+@pytest.mark.parametrize("K,N,hop,pad,scaling", [
+    (1024, 1024, 256, "valid", None),
+    (1024, 1024, 512, "reflect", "spectrum"),   # the guide's call: default 50 % overlap
+    (512, 400, 160, "reflect", None),
+    (256, 256, 64, "valid", "psd"),
+    (128, 128, 32, "same", None),
+    (2048, 2048, 512, "valid", None),
+    (4096, 3000, 1000, "valid", None),
+    (400, 400, 160, "valid", None),             # two-step path behind the same entry point
+    (64, 64, 16, "valid", None),
+])
+def test_spectrogram_magnitude_power_dbfs(K, N, hop, pad, scaling):
+    """guides/spectrogram.livemd:76-92: Nx.abs(s) of the first fft_length/2 bins, and 20*log(|s|/max|s|)/log(10)"""
+    rng = np.random.default_rng(K + N)
+    x = rng.standard_normal((2, 20000 + 5)).astype(np.float32)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=K, sampling_rate=16000, window_padding=pad, scaling=scaling)
+    zo, to, fo = O.stft(x, w, **opts)
+    half = K // 2
+    mag_ref = np.abs(zo[..., :half].astype(np.complex128)).astype(np.float32)
+    mag, t, f = S.spectrogram(x, w, **opts)
+    assert mag.shape == mag_ref.shape and mag.dtype == np.float32
+    assert np.array_equal(t, to) and np.array_equal(f, fo[:half])
+    scale = float(mag_ref.max())
+    assert np.max(np.abs(mag - mag_ref)) / scale < 1e-5
+    pw, _, _ = S.spectrogram(x, w, kind="power", **opts)
+    assert np.max(np.abs(pw - mag_ref.astype(np.float64) ** 2)) / scale ** 2 < 1e-5
+    db, _, _ = S.spectrogram(x, w, kind="dbfs", **opts)
+    db_ref = 20.0 * np.log10(mag_ref.astype(np.float64) / scale)
+    loud = db_ref > -80.0                      # below that the log amplifies fp32 round-off of near-zero bins
+    assert np.max(np.abs(db[loud] - db_ref[loud])) < 1e-2
+    assert float(db.max()) == 0.0
+    ctx = S.default_context()
+    md, _, _ = S.spectrogram(ctx.to_device(x), w, **opts)
+    assert np.array_equal(md.numpy().view(np.uint32), mag.view(np.uint32))
+    with pytest.raises(S.ArgumentError):
+        S.spectrogram(x, w, kind="decibels", **opts)

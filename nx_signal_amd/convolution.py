@@ -31,6 +31,18 @@ def convolve(in1, in2, ctx=None, **opts):
     return fftconvolve(in1, in2, ctx=ctx, mode=o["mode"])
 
 
+def correlate(in1, in2, ctx=None, **opts):
+    """NxSignal.Convolution.correlate/3 — lib/nx_signal/convolution.ex:87-93: convolve(in1, conj(reverse(in2)), opts)
+    (1-D; `method: :fft` is the path built here, like convolve)."""
+    k = np.asarray(in2)
+    if k.ndim != 1:
+        raise NxSignalUnsupported("correlate: n-D kernels are outside the hot path")
+    k = k[::-1]
+    if np.iscomplexobj(k):
+        k = np.conj(k)
+    return convolve(in1, np.ascontiguousarray(k), ctx=ctx, **opts)
+
+
 def fftconvolve(in1, in2, ctx=None, **opts):
     """1-D real case of fftconvolve: the longer operand streams through HBM, the shorter one is the FIR kernel.
     in1 may carry leading batch axes (independent channels) when it is the signal."""

@@ -587,3 +587,23 @@ def synth_signal(length, seed=1234, channels=None):
     rng = np.random.Generator(np.random.PCG64(seed))
     shape = (length,) if channels is None else (channels, length)
     return rng.standard_normal(shape, dtype=f32)
+
+
+def fft_nd(x, axes=(-1,), lengths=None, inverse=False):
+    """NxSignal.Transforms.fft_nd / ifft_nd — lib/nx_signal/transforms.ex:5-21: fold Nx.fft / Nx.ifft(axis:, length:)
+    over the axes list (each stage rounds to c64 like the BinaryBackend call it stands for)."""
+    acc = np.asarray(x)
+    lengths = list(lengths) if lengths is not None else [None] * len(axes)
+    for ax, ln in zip(axes, lengths):
+        moved = np.moveaxis(acc, ax, -1)
+        out = ifft(moved, length=ln) if inverse else fft(moved, length=ln)
+        acc = np.moveaxis(out, -1, ax)
+    return np.ascontiguousarray(acc)
+
+
+def correlate(a, b, mode="full"):
+    """NxSignal.Convolution.correlate/3 (method: :fft) — lib/nx_signal/convolution.ex:87-93"""
+    k = np.asarray(b)[::-1]
+    if np.iscomplexobj(k):
+        k = np.conj(k)
+    return fftconvolve(np.asarray(a), np.ascontiguousarray(k), mode=mode)

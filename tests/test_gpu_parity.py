@@ -534,3 +534,43 @@ def test_spectrogram_magnitude_power_dbfs(K, N, hop, pad, scaling):
     assert np.array_equal(md.numpy().view(np.uint32), mag.view(np.uint32))
     with pytest.raises(S.ArgumentError):
         S.spectrogram(x, w, kind="decibels", **opts)
+
+
+# ------------------------------------------------------------------------------- fft_nd over several axes, correlate (8f-4)
+def test_fft_nd_multi_axis_golden_and_oracle(golden):
+    for v in golden["fft_nd"]:
+        fn = S.transforms.ifft_nd if v["inverse"] else S.transforms.fft_nd
+        kw = {"axes": v["axes"]}
+        if v["lengths"] is not None:
+            kw["lengths"] = v["lengths"]
+        z = fn(np.array(v["x"]), **kw)
+        a = np.array(v["expect"], dtype=np.float64)
+        exp = (a[..., 0] + 1j * a[..., 1]).astype(np.complex64)
+        assert z.shape == exp.shape and z.dtype == np.complex64
+        assert nx_all_close(z, exp, max(v["atol"], 1e-6), max(v["rtol"], 1e-6)), (v["src"], z)
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((6, 20, 48)) + 1j * rng.standard_normal((6, 20, 48))).astype(np.complex64)
+    got = S.transforms.fft_nd(a, axes=[1, 2, 0], lengths=[32, 64, None])
+    assert_close(got, O.fft_nd(a, axes=[1, 2, 0], lengths=[32, 64, None]), "3-axis fold")
+    back = S.transforms.ifft_nd(got, axes=[0, 2, 1])
+    assert_close(back, O.fft_nd(got, axes=[0, 2, 1], inverse=True), "inverse fold")
+    with pytest.raises(S.ArgumentError):
+        S.transforms.fft_nd(a, axes=[3])
+
+
+def test_correlate_fft_method(golden):
+    for v in golden["correlate"]:
+        got = S.convolution.correlate(np.array(v["a"], dtype=np.float32), np.array(v["b"], dtype=np.float32), method="fft")
+        assert np.allclose(got, np.array(v["expect"], dtype=np.float32), rtol=1e-5, atol=1e-5), got
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(5000).astype(np.float32)
+    k = rng.standard_normal(129).astype(np.float32)
+    for mode in ("full", "same", "valid"):
+        got = S.convolution.correlate(x, k, method="fft", mode=mode)
+        full = O.direct_convolve_f64(x, k[::-1].copy())
+        n = {"full": 5000 + 128, "same": 5000, "valid": 5000 - 128}[mode]
+        start = (full.shape[0] - n) // 2 if mode != "full" else 0
+        assert_close(got, full[start:start + n].astype(np.float32), f"correlate {mode}")
+    a = (rng.standard_normal(40) + 1j * rng.standard_normal(40)).astype(np.complex64)
+    b = (rng.standard_normal(7) + 1j * rng.standard_normal(7)).astype(np.complex64)
+    assert_close(S.convolution.correlate(a, b, method="fft"), O.correlate(a, b), "complex correlate")

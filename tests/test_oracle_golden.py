@@ -157,6 +157,29 @@ def test_fft_rows(golden):
         assert nx_all_close(d, np.array([complex(*c) for c in v["expect_diff"]]), v["atol"], v["rtol"])
 
 
+def _cplx(nested):
+    a = np.array(nested, dtype=np.float64)
+    return (a[..., 0] + 1j * a[..., 1]).astype(np.complex64)
+
+
+def test_fft_nd_all_axes(golden):
+    """Transforms.fft_nd / ifft_nd over two axes: test/nx_signal/convolutions_test.exs:65-93, transforms_test.exs:12-41"""
+    for v in golden["fft_nd"]:
+        z = O.fft_nd(np.array(v["x"]), axes=v["axes"], lengths=v["lengths"], inverse=v["inverse"])
+        exp = _cplx(v["expect"])
+        assert z.shape == exp.shape and z.dtype == np.complex64, v["src"]
+        if v["atol"] == 0.0:
+            assert np.array_equal(z, exp), (v["src"], z)
+        else:
+            assert nx_all_close(z, exp, v["atol"], v["rtol"]), (v["src"], z)
+
+
+def test_correlate_doctest(golden):
+    for v in golden["correlate"]:
+        got = O.correlate(np.array(v["a"], dtype=np.float32), np.array(v["b"], dtype=np.float32))
+        assert np.allclose(got, np.array(v["expect"], dtype=np.float32), rtol=1e-6, atol=1e-6), got
+
+
 def test_firwin_scipy_vectors(golden):
     for v in golden["firwin"]:
         opts = dict(v["opts"])

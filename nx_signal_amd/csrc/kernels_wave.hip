@@ -1737,14 +1737,14 @@ static void host_fft1024_f64(std::vector<double>& re, std::vector<double>& im) {
   }
 }
 
-template <int W>
+template <int W, int K = 1024>
 static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
   *handled = false;
-  constexpr int K = 1024, R3 = 4, XCH = K + K / 16 + 16;
+  constexpr int R3 = K / 256, XCH = K + K / 16 + 16;
   if (s.out_len <= 0 || s.batch == 0) return NXSIG_OK;
   if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
-  if (s.taps > 513) return NXSIG_OK;  // block of 1024 would be < 50 % efficient: generic path uses bigger blocks
-  int rc = ensure_wave_tables_1024(c);
+  if (s.taps > K / 2 + 1) return NXSIG_OK;  // a block would be < 50 % efficient: the generic path uses bigger blocks
+  int rc = ensure_wave_tables(c, K);
   if (rc) return rc;
   *handled = true;
   std::vector<double> re(K, 0.0), im(K, 0.0);
@@ -1753,7 +1753,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
   std::vector<float2> H(K);
   for (int i = 0; i < K; ++i) H[i] = make_float2((float)(re[i] / K), (float)(im[i] / K));
   const void* Hd = nullptr;
-  rc = ctx_table(c, 0xF1A1ull, H.data(), H.size() * sizeof(float2), &Hd);
+  rc = ctx_table(c, 0xF1A1ull ^ (uint64_t)K, H.data(), H.size() * sizeof(float2), &Hd);
   if (rc) return rc;
   FirWaveArgs a;
   a.x = s.x; a.L = s.L; a.batch_stride = s.batch_stride; a.batch = s.batch; a.taps = s.taps;
@@ -1817,6 +1817,13 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
 }
 
 int launch_fir_wave(Ctx* c, const FirLaunch& s, bool* handled) {
+  // 2048-sample blocks (32 points per lane) for 514..1025 taps; NXSIG_FIR_K=2048 forces them for shorter filters
+  if (s.taps > 513 || env_int("NXSIG_FIR_K", 1024) == 2048) {
+    switch (env_int("NXSIG_FIR_W", 6)) {
+      case 4: return launch_fir_wave_W<4, 2048>(c, s, handled);
+      default: return launch_fir_wave_W<6, 2048>(c, s, handled);
+    }
+  }
   switch (env_int("NXSIG_FIR_W", 14)) {
     case 4: return launch_fir_wave_W<4>(c, s, handled);
     default: return launch_fir_wave_W<14>(c, s, handled);

@@ -140,11 +140,12 @@ def test_istft_rectangular_window_no_edge_fix_needed():
     assert nerr(y, O.istft(z, w, overlap_length=N - hop, fft_length=N)) < 1e-5
 
 
-@pytest.mark.parametrize("taps", [1, 2, 65, 129, 257, 385, 513, 300, 514, 1000])
+@pytest.mark.parametrize("taps", [1, 2, 65, 129, 257, 385, 513, 300, 514, 641, 769, 1000, 1025, 1026])
 @pytest.mark.parametrize("mode", ["full", "same", "valid"])
 def test_fir_wave_stream_edge_split(taps, mode):
     """taps-1 multiples of 128 take the vectorised streaming kernel for interior block pairs and the bounds-checked
-    kernel at the row ends; other tap counts take the bounds-checked kernel throughout; > 513 taps the generic one"""
+    kernel at the row ends; other tap counts take the bounds-checked kernel throughout; 514..1025 taps run on 2048-sample
+    blocks (the 2048-point core), longer filters on the generic kernel"""
     rng = np.random.default_rng(taps)
     L = 20000 + (taps % 7)
     x = rng.standard_normal((3, L)).astype(np.float32)

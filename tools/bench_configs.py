@@ -180,6 +180,21 @@ def main():
         gbs = batch * M * bpf / (ms * 1e-3) / 1e9
         print(json.dumps({"case": "istft N=1024 hop=256, 16 x 60 s (config 3 batched)", "ms": ms, "frames_per_s": batch * M / (ms * 1e-3),
                           "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / PEAK}), flush=True)
+    for name in which:
+        if name.startswith("fir") and name != "fir":  # e.g. fir1025: other filter lengths on the config 5 shard
+            taps = int(name[3:])
+            L, batch = 28800000, 8
+            h = S.filters.firwin(taps if taps % 2 else taps + 1, [4000], sampling_rate=48000)[:taps]
+            h = np.ascontiguousarray(h)
+            xd = ctx.empty((batch, L), np.float32)
+            fill_normal(ctx, xd, (batch, L), 11)
+            yd = ctx.empty((batch, L), np.float32)
+            hp = h.ctypes.data_as(C.c_void_p)
+            fn = lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, hp, taps, _lib.CONV_SAME, C.c_void_p(yd.ptr), _lib.DEVICE))
+            ms = timeit(ctx, fn, reps=10)
+            gbs = batch * L * 8 / (ms * 1e-3) / 1e9
+            print(json.dumps({"case": f"fir {taps} taps :same, 8 ch x 10 min @48k", "ms": ms, "samples_per_s": batch * L / (ms * 1e-3),
+                              "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / PEAK}), flush=True)
     if "fir" in which:
         L, batch = 28800000, 8  # config 5 per-GPU shard: 8 channels x 10 min
         h = S.filters.firwin(257, [4000], sampling_rate=48000)

@@ -163,7 +163,7 @@ def main():
     kernel_ms = kernel_ms_total / args.steps
     achieved = (B * M * BYTES_PER_FRAME) / (kernel_ms * 1e-3) / 1e9  # GB/s per GPU, algorithmic bytes
 
-    # config 2 exactly as written: ONE 60 s stream per launch, back-to-back launches (L3-resident, launch-bound)
+    # config 2 exactly as written: ONE 60 s stream per launch, back-to-back launches (L3-resident; bound by the fixed latency of a 703-workgroup kernel)
     for _ in range(20):
         step(1)
     ctx.sync()
@@ -173,7 +173,7 @@ def main():
         step(1)
     single_ms = ctx.timer_stop() / reps
     single = {
-        "workload": "1 x 60 s mono (config 2 as written, 103.7 MB: Infinity-Cache resident, launch-bound)",
+        "workload": "1 x 60 s mono (config 2 as written, 103.7 MB: Infinity-Cache resident; fixed kernel latency dominates, a HIP-graph replay is no faster)",
         "ms_per_launch": single_ms,
         "frames_per_s": M / (single_ms * 1e-3),
         "algorithmic_GBps": M * BYTES_PER_FRAME / (single_ms * 1e-3) / 1e9,

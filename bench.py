@@ -94,6 +94,12 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a banner ("Hostname : ...", "Librccl path : ...") to the
+    # process' stdout when the communicator comes up, so file descriptor 1 points at stderr until the result is ready.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,7 +261,10 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)  # whatever the teardown prints must not follow the JSON line
     if dist is not None:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()

@@ -579,11 +579,16 @@ def test_correlate_fft_method(golden):
 # ------------------------------------------------------------------------------- HIP graph capture of the hot path
 def test_stft_istft_are_capturable_into_a_hip_graph():
     """After the first (table-building) call the device entry points only launch kernels on the context's stream: no
-    allocation, no synchronisation, no host copies.  So a caller can capture them into a HIP graph (here through
-    torch.cuda.CUDAGraph on a stream handed over with nxsig_set_stream) and replay the launch-bound small-batch case."""
-    torch = pytest.importorskip("torch")
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
+    allocation, no synchronisation, no host copies.  So a caller can capture them into a HIP graph on a stream handed
+    over with nxsig_set_stream and replay the small-batch case (HIP runtime driven through ctypes: no torch needed)."""
+    import ctypes as C
+
+    from nx_signal_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+
+    def ok(rc, what):
+        assert rc == 0, f"{what} -> hip error {rc}"
+
     N, hop = 1024, 256
     x = O.synth_signal(48000, seed=3)
     w = S.windows.hann(N)
@@ -593,26 +598,30 @@ def test_stft_istft_are_capturable_into_a_hip_graph():
     z_ref, _, _ = S.stft(xd, w, ctx=ctx, **opts)       # warm-up: builds and caches every table
     y_ref = S.istft(z_ref, w, ctx=ctx, **opts)
     z_ref_h, y_ref_h = z_ref.numpy(), y_ref.numpy()
-    import ctypes as C
-
-    from nx_signal_amd import _lib
     lib = _lib.load()
     M = z_ref.shape[0]
     zd = ctx.empty((M, N), np.complex64)
     yd = ctx.empty(y_ref.shape, np.complex64)
     p = _lib.StftParams(N, hop, N, _lib.PAD_VALID, 0, 0, _lib.SCALE_NONE, 0, 48000.0)
     wp = w.ctypes.data_as(C.c_void_p)
-    side = torch.cuda.Stream()
-    g = torch.cuda.CUDAGraph()
-    ctx.set_stream(side.cuda_stream)
+    stream, graph, gexec = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    ok(hip.hipStreamCreate(C.byref(stream)), "hipStreamCreate")
+    ctx.set_stream(stream.value)
     try:
-        with torch.cuda.graph(g, stream=side):
-            _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), 48000, 1, 48000, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
-            _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(zd.ptr), M, 1, wp, C.byref(p), C.c_void_p(yd.ptr), _lib.DEVICE))
+        ok(hip.hipStreamBeginCapture(stream, 0), "hipStreamBeginCapture")  # hipStreamCaptureModeGlobal
+        _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), 48000, 1, 48000, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
+        _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(zd.ptr), M, 1, wp, C.byref(p), C.c_void_p(yd.ptr), _lib.DEVICE))
+        ok(hip.hipStreamEndCapture(stream, C.byref(graph)), "hipStreamEndCapture")
+        ok(hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
         for _ in range(3):
-            g.replay()
-        torch.cuda.synchronize()
+            ok(hip.hipGraphLaunch(gexec, stream), "hipGraphLaunch")
+        ok(hip.hipStreamSynchronize(stream), "hipStreamSynchronize")
     finally:
         ctx.set_stream(None)
+        if gexec.value:
+            hip.hipGraphExecDestroy(gexec)
+        if graph.value:
+            hip.hipGraphDestroy(graph)
+        hip.hipStreamDestroy(stream)
     assert np.array_equal(zd.numpy().view(np.uint32), z_ref_h.view(np.uint32))
     assert np.array_equal(yd.numpy().view(np.uint32), y_ref_h.view(np.uint32))

@@ -4,7 +4,7 @@
     python -m nx_signal_amd.build --force
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
-gpurun snapshot.  No torch, no cmake: three translation units and one link line.
+gpurun snapshot.  No torch, no cmake: four translation units (compiled concurrently) and one link line.
 """
 from __future__ import annotations
 
@@ -52,6 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     ]
     objs = []
     cc = hipcc()
+    running = []  # stale translation units compile concurrently (the wave kernels dominate: ~1 min)
     for src, extra in UNITS:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
@@ -60,7 +61,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
             cmd = [cc, f"--offload-arch={ARCH}", *COMMON, *extra, "-c", s, "-o", o]
             if verbose:
                 print("[nxsig build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            running.append((cmd, o, subprocess.Popen(cmd)))
+    failed = []
+    for cmd, o, proc in running:
+        if proc.wait() != 0:
+            failed.append(cmd)
+            if os.path.exists(o):
+                os.remove(o)
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     if force or _stale(OUT, objs):
         cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", OUT]
         if verbose:

@@ -317,7 +317,8 @@ __device__ __forceinline__ float fetch_any(const float* __restrict__ x, const Wa
 extern __shared__ __attribute__((aligned(16))) unsigned char g_wave_smem[];
 
 typedef __attribute__((address_space(1))) v4f gv4f;
-typedef __attribute__((address_space(1))) v2f gv2f;  // explicit global address space: global_store, not flat_store
+typedef __attribute__((address_space(1))) v2f gv2f;
+typedef __attribute__((address_space(3))) float lds_f32;  // explicit global address space: global_store, not flat_store
 
 // GENERAL = false: :valid framing with every existing frame fully inside the signal (the streaming case);
 // GENERAL = true : any padding mode / ragged tail, per-sample bounds and mirror math.  SCALE: :spectrum / :psd.
@@ -1021,6 +1022,156 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_half(IstftWaveArgs a) {
   }
 }
 
+// ---- iSTFT for N = K/J (J = 4: N = 256, J = 8: N = 128): J consecutive frames per 1024-point inverse FFT.
+// Y[k0 + N m] = 1/J sum_j (C_j[k0] w_K^(j k0)) w_J^(jm) is a lane-local forward radix-J butterfly in the core's input
+// layout (k0 = lane + 64 s', m = s / (16/J)); the UNSCALED inverse transform then returns c_j[n] at index J n + j, i.e.
+// zz[par][q] holds frame j = (2 lane + par) mod J, sample n = (2 lane + par + 128 q) / J.  Frames of one transform sit
+// on different lanes, so the overlap-add goes through the wave's exchange buffer (idle after the core): the J windowed
+// frames are parked there frame-major with plain writes, and every lane then gathers its output positions: carry of the
+// earlier units + the frames that cover the position, summed in ascending frame order (deterministic, run-to-run
+// bit-stable; 16-byte LDS reads, no read-modify-write chains).  The first J hop positions are normalised and stored
+// with 16-byte stores; the following N - hop positions become the carry of the next unit (a small LDS strip per wave).
+template <int K, int J, int R, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
+  constexpr int NJ = K / J;              // frame length (= fft_length)
+  constexpr int P = K / 64;
+  constexpr int PJ = P / J;              // bins per lane per frame: k0 = lane + 64 s', s' < PJ
+  constexpr int R3 = K / 256;
+  constexpr int NQ = K / 128;
+  constexpr int XCH = K + K / 16 + 16;
+  constexpr int HOP = NJ / R;
+  constexpr int CARRY = NJ - HOP;        // positions handed to the next unit
+  constexpr int OUTN = J * HOP;          // positions finished per unit
+  constexpr int CPAD = CARRY > 0 ? CARRY : 2;
+  static_assert(OUTN % 128 == 0, "J hop must be a multiple of 128");
+  static_assert(2 * HOP >= 128 / J, "lanes of one instruction would share an accumulator cell");
+  float* s_w = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_twB = reinterpret_cast<v2f*>(s_w + NJ);
+  v2f* s_twC = s_twB + 256;
+  v2f* s_twQ = s_twC + R3 * 256;          // [j-1][k0] = conj(w_K^(j k0)), k0 < NJ
+  v2f* s_x = s_twQ + (J - 1) * NJ;
+  v2f* s_carry = s_x + W * XCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < NJ; i += 64 * W) s_w[i] = a.wtab[i];
+  for (int i = tid; i < (J - 1) * NJ; i += 64 * W) s_twQ[i] = a.twH[i];
+  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
+  for (int i = tid; i < R3 * 256; i += 64 * W) s_twC[i] = a.twC[i];
+  __syncthreads();
+  v2f* xb = s_x + wave * XCH;
+  v2f* carry = s_carry + wave * CPAD;
+  const int64_t run = (int64_t)blockIdx.x * W + wave;
+  if (run >= a.total_runs) return;
+  const int64_t row = run / a.runs_per_row;
+  const int64_t u0 = (run - row * a.runs_per_row) * a.run_len;   // units of J frames / J output segments
+  const int64_t units_per_row = (a.segs_per_row + J - 1) / J;
+  int64_t u1 = u0 + a.run_len;
+  if (u1 > units_per_row) u1 = units_per_row;
+  constexpr int HALO = (R - 1 + J - 1) / J;                      // earlier units whose frames reach into this run
+  const int64_t us = u0 >= HALO ? u0 - HALO : 0;
+  for (int i = lane; i < CARRY; i += 64) carry[i] = v2f{0.f, 0.f};
+  const float invK = 1.0f / (float)K;
+  const int64_t out_len = a.segs_per_row * HOP;
+
+  const v2f* zrow = a.z + (size_t)row * a.M * NJ + lane;
+  v2f r[J][PJ];
+  auto issue_loads = [&](int64_t u) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int64_t m = u * J + j;
+      const v2f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * NJ;  // clamped: frames past the end contribute zero
+#pragma unroll
+      for (int s = 0; s < PJ; ++s) r[j][s] = pz[64 * s];
+    }
+  };
+  v2f d[P];
+  auto pack = [&]() {   // d[s' + PJ m] = sum_j (C_j[k0] w_K^(j k0)) w_J^(jm)   (the 1/J rides in invK)
+#pragma unroll
+    for (int s = 0; s < PJ; ++s) {
+      v2f t[J];
+      t[0] = r[0][s];
+#pragma unroll
+      for (int j = 1; j < J; ++j) {
+        const v2f w = s_twQ[(j - 1) * NJ + lane + 64 * s];
+        t[j] = wcmul(r[j][s], v2f{w.x, -w.y});
+      }
+      if (J == 4) dft4<false>(t[0], t[1], t[2], t[3]);
+      else dft8<false>(t);
+#pragma unroll
+      for (int m = 0; m < J; ++m) d[s + PJ * m] = t[m];
+    }
+  };
+  issue_loads(us);
+  pack();
+
+  for (int64_t u = us; u < u1; ++u) {
+    issue_loads(u + 1 < u1 ? u + 1 : u);  // unconditional prefetch keeps the loop branch-free
+    __builtin_amdgcn_sched_barrier(0);
+    v2f zz[2][NQ];
+    wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    pack();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- park the unit's J windowed frames in the (now idle) exchange buffer, frame-major: xb[j NJ + n]
+    //      ((IDFT / N) * scale) * window, lib/nx_signal.ex:609-628, same rounding order; plain writes, no ordering issue
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int i = 2 * lane + e + 128 * q;
+        const int j = i % J, n = i / J;
+        v2f v = zz[e][q] * invK;
+        if (SCALE) v = v * a.scale;
+        const float live = (u * J + j) < a.M ? 1.0f : 0.0f;
+        xb[j * NJ + n] = v * (s_w[n] * live);
+      }
+    wave_lds_fence();
+    // position t of the unit (t = 0 is sample u J hop of the row) = carry of earlier units + frames j with 0 <= t - j hop < NJ,
+    // summed in ascending frame order; every lane takes adjacent pairs (16-byte LDS reads: hop is even)
+    auto gather = [&](int t) -> v4f {
+      v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+      if (CARRY > 0 && t < CARRY) acc = *reinterpret_cast<const v4f*>(&carry[t]);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int off = t - j * HOP;
+        if (off >= 0 && off < NJ) acc += *reinterpret_cast<const v4f*>(&xb[j * NJ + off]);
+      }
+      return acc;
+    };
+    // ---- finished positions: x reciprocal of the guarded normaliser, 16-byte stores
+    const int64_t t_unit = u * OUTN;
+    v2f* yrow = a.y + (size_t)row * out_len;
+#pragma unroll
+    for (int i = 0; i < OUTN / 128; ++i) {
+      const int t = 2 * lane + 128 * i;
+      const v4f acc = gather(t);
+      const int64_t seg = u * J + t / HOP;           // absolute hop segment
+      const int pos = t % HOP;
+      const int64_t trow = seg < R - 1 ? seg : (seg >= a.M ? R + (seg - a.M) : R - 1);
+      const bool inside = u >= u0 && t_unit + t < out_len;
+      const v2f rd = inside ? *reinterpret_cast<const v2f*>(a.den + trow * HOP + pos) : v2f{0.f, 0.f};
+      const v4f o = v4f{acc.x * rd.x, acc.y * rd.x, acc.z * rd.y, acc.w * rd.y};
+      v2f* yp = inside ? yrow + t_unit + t : a.dummy + 2 * lane;
+      __builtin_nontemporal_store(o, (gv4f*)yp);
+    }
+    // ---- carry for the next unit: positions OUTN .. OUTN + CARRY - 1 (all reads first, then the writes)
+    constexpr int CI = (CARRY + 127) / 128;
+    v4f nc[CI > 0 ? CI : 1];
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+      const int t = 2 * lane + 128 * i;
+      nc[i] = t < CARRY ? gather(OUTN + t) : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+      const int t = 2 * lane + 128 * i;
+      if (t < CARRY) *reinterpret_cast<v4f*>(&carry[t]) = nc[i];
+    }
+    wave_lds_fence();  // all reads of the buffer are done before the next pass A overwrites it
+  }
+}
+
 // ---- iSTFT for N = 2K (2048): ONE frame per TWO 1024-point inverse FFTs (decimation in frequency).  A 16-byte load
 // yields Z[2k'] and Z[2k'+1] together; E = IDFT_K(even bins), O = IDFT_K(odd bins) come out of the inverse core in the
 // adjacent-pair layout, and x[n] = E[n] + t O[n], x[n + K] = E[n] - t O[n], t = exp(+2 pi i n / 2K), is lane-local,
@@ -1538,6 +1689,31 @@ int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool
   }
 }
 
+// guarded normaliser rows (lib/nx_signal.ex:630-635) as RECIPROCALS: f32[2R-1][hop] = head segments 0..R-2, the interior
+// segment, tail segments; double accumulation in ascending frame order, one rounding
+static int istft_den_table(Ctx* c, int R, int hop, const float* window_host, const float** out) {
+  std::vector<float> den((size_t)(2 * R - 1) * hop);
+  auto w2 = [&](int idx) { const float w = std::fabs(window_host[idx]); return (double)(w * w); };
+  for (int row = 0; row < 2 * R - 1; ++row)
+    for (int pos = 0; pos < hop; ++pos) {
+      double acc = 0.0;
+      for (int rr = R - 1; rr >= 0; --rr) {  // frame j - rr contributes w2[rr*hop + pos]
+        bool have;
+        if (row < R - 1) have = rr <= row;             // head segment j = row: frames j - rr >= 0
+        else if (row == R - 1) have = true;            // interior
+        else have = rr >= row - R + 1;                 // tail segment j = M + (row - R): frames j - rr <= M - 1
+        if (have) acc += w2(rr * hop + pos);
+      }
+      const float d = (float)acc;
+      den[(size_t)row * hop + pos] = (float)(1.0 / (double)(d > 1.0e-10f ? d : 1.0f));  // reciprocal of the guarded normaliser
+    }
+  const void* dd = nullptr;
+  int rc3 = ctx_table(c, 0xDE17ull ^ ((uint64_t)R << 32), den.data(), den.size() * sizeof(float), &dd);
+  if (rc3) return rc3;
+  *out = reinterpret_cast<const float*>(dd);
+  return NXSIG_OK;
+}
+
 template <int R, int W, bool HALF = false, bool DBL = false>
 static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window_padK, const float* window_host) {
   constexpr int K = 1024, R3 = K / 256, XCH = K + K / 16 + 16;
@@ -1550,28 +1726,7 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   a.twB = reinterpret_cast<const v2f*>(wt.twBi);  // conjugated tables: the kernel runs the core in inverse direction
   a.twC = reinterpret_cast<const v2f*>(wt.twCi);
   a.scale = s.scale_mul;
-  {  // guarded normaliser rows (lib/nx_signal.ex:630-635): double accumulation in ascending frame order, one rounding
-    const int hop = s.hop;
-    std::vector<float> den((size_t)(2 * R - 1) * hop);
-    auto w2 = [&](int idx) { const float w = std::fabs(window_host[idx]); return (double)(w * w); };
-    for (int row = 0; row < 2 * R - 1; ++row)
-      for (int pos = 0; pos < hop; ++pos) {
-        double acc = 0.0;
-        for (int rr = R - 1; rr >= 0; --rr) {  // frame j - rr contributes w2[rr*hop + pos]
-          bool have;
-          if (row < R - 1) have = rr <= row;             // head segment j = row: frames j - rr >= 0
-          else if (row == R - 1) have = true;            // interior
-          else have = rr >= row - R + 1;                 // tail segment j = M + (row - R): frames j - rr <= M - 1
-          if (have) acc += w2(rr * hop + pos);
-        }
-        const float d = (float)acc;
-        den[(size_t)row * hop + pos] = (float)(1.0 / (double)(d > 1.0e-10f ? d : 1.0f));  // reciprocal of the guarded normaliser
-      }
-    const void* dd = nullptr;
-    int rc3 = ctx_table(c, 0xDE17ull ^ ((uint64_t)R << 32), den.data(), den.size() * sizeof(float), &dd);
-    if (rc3) return rc3;
-    a.den = reinterpret_cast<const float*>(dd);
-  }
+  { int rc3 = istft_den_table(c, R, s.hop, window_host, &a.den); if (rc3) return rc3; }
   a.y = reinterpret_cast<v2f*>(s.y);
   void* dummy = nullptr;
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
@@ -1670,6 +1825,46 @@ static int ensure_wave_tables(Ctx* c, const int C) {
 
 static int ensure_wave_tables_1024(Ctx* c) { return ensure_wave_tables(c, 1024); }
 
+template <int J, int R>
+static int launch_istft_wave_quad(Ctx* c, const IstftLaunch& s, const float* window_host) {
+  constexpr int K = 1024, W = 6, R3 = K / 256, XCH = K + K / 16 + 16, NJ = K / J, HOP = NJ / R;
+  constexpr int CPAD = (NJ - HOP) > 0 ? (NJ - HOP) : 2;
+  IstftWaveArgs a;
+  a.z = reinterpret_cast<const v2f*>(s.z); a.M = s.M; a.batch = s.batch; a.hop = s.hop;
+  a.segs_per_row = s.M + R - 1;
+  a.wtab = s.window;
+  Ctx::WaveTables& wt = c->wave_tables[K];
+  if (!wt.twB) return NXSIG_ERR_UNSUPPORTED;
+  a.twB = reinterpret_cast<const v2f*>(wt.twBi);
+  a.twC = reinterpret_cast<const v2f*>(wt.twCi);
+  a.twH = reinterpret_cast<const v2f*>(wt.twQ[J == 4 ? 1 : 2]);  // conj(w_K^(j k0)); the kernel conjugates on load
+  a.scale = s.scale_mul;
+  { int rc3 = istft_den_table(c, R, s.hop, window_host, &a.den); if (rc3) return rc3; }
+  a.y = reinterpret_cast<v2f*>(s.y);
+  void* dummy = nullptr;
+  { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
+  a.dummy = reinterpret_cast<v2f*>(dummy);
+  const int64_t units_per_row = (a.segs_per_row + J - 1) / J;
+  const int64_t total_units = units_per_row * s.batch;
+  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", 24);  // two rounds of the 12 resident waves per CU
+  int64_t run_len = (total_units + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
+  const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", 8);
+  if (run_len < min_run) run_len = min_run;
+  a.run_len = run_len;
+  a.runs_per_row = (units_per_row + run_len - 1) / run_len;
+  a.total_runs = a.runs_per_row * s.batch;
+  const int64_t blocks = (a.total_runs + W - 1) / W;
+  const size_t lds = (size_t)NJ * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)(J - 1) * NJ * 8 + (size_t)W * XCH * 8 + (size_t)W * CPAD * 8;
+  auto go = [&](auto kernel) -> int {
+    if (lds > 64 * 1024)
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  };
+  return s.has_scale ? go(k_istft_wave_quad<K, J, R, true, W>) : go(k_istft_wave_quad<K, J, R, false, W>);
+}
+
 int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   *handled = false;
   if (s.M == 0 || s.batch == 0) return NXSIG_OK;
@@ -1686,6 +1881,28 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
       case 2: return launch_istft_wave_R<2, 4, true>(c, s, s.window, window_host);
       case 4: return launch_istft_wave_R<4, 4, true>(c, s, s.window, window_host);
       default: return launch_istft_wave_R<8, 4, true>(c, s, s.window, window_host);
+    }
+  }
+  if ((s.K == 256 && s.N == 256) || (s.K == 128 && s.N == 128)) {  // 4 / 8 frames per 1024-point inverse FFT
+    const int R = s.N / s.hop;
+    if (s.hop * R != s.N || (R != 1 && R != 2 && R != 4 && R != 8)) return NXSIG_OK;
+    if (s.M < 2 * R - 1) return NXSIG_OK;
+    int rc5 = ensure_wave_tables_1024(c);
+    if (rc5) return rc5;
+    *handled = true;
+    if (s.K == 256) {
+      switch (R) {
+        case 1: return launch_istft_wave_quad<4, 1>(c, s, window_host);
+        case 2: return launch_istft_wave_quad<4, 2>(c, s, window_host);
+        case 4: return launch_istft_wave_quad<4, 4>(c, s, window_host);
+        default: return launch_istft_wave_quad<4, 8>(c, s, window_host);
+      }
+    }
+    switch (R) {
+      case 1: return launch_istft_wave_quad<8, 1>(c, s, window_host);
+      case 2: return launch_istft_wave_quad<8, 2>(c, s, window_host);
+      case 4: return launch_istft_wave_quad<8, 4>(c, s, window_host);
+      default: return launch_istft_wave_quad<8, 8>(c, s, window_host);
     }
   }
   if (s.K == 2048 && s.N == 2048) {  // one frame per two 1024-point inverse FFTs

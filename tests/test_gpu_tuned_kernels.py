@@ -131,6 +131,21 @@ def test_istft_wave_dbl_n2048(hop, M):
         assert nerr(y, yo) < 1e-5, (hop, M, scaling, nerr(y, yo))
 
 
+@pytest.mark.parametrize("N,hop", [(256, 32), (256, 64), (256, 128), (256, 256), (128, 16), (128, 32), (128, 64), (128, 128)])
+@pytest.mark.parametrize("M", [3, 16, 17, 66, 301])
+def test_istft_wave_quad_n256_n128(N, hop, M):
+    """N = 256 / 128: 4 / 8 frames per 1024-point inverse FFT, overlap-add through the wave's LDS buffer; frame counts
+    that are not multiples of the unit, run seams, every supported hop (M < 2R-1 takes the generic path)"""
+    rng = np.random.default_rng(N + hop * 5 + M)
+    z = (rng.standard_normal((3, M, N)) + 1j * rng.standard_normal((3, M, N))).astype(np.complex64)
+    w = S.windows.hann(N)
+    for scaling in (None, "spectrum"):
+        y = S.istft(z, w, overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=16000)
+        yo = O.istft(z, w, overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=16000)
+        assert y.shape == yo.shape
+        assert nerr(y, yo) < 1e-5, (N, hop, M, scaling, nerr(y, yo))
+
+
 def test_istft_rectangular_window_no_edge_fix_needed():
     N, hop, M = 1024, 256, 40
     rng = np.random.default_rng(3)

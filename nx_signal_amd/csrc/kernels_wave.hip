@@ -350,7 +350,6 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   constexpr bool MAG = SINK == kSinkMag;   // |X| or |X|^2 of the bins below fft_length / 2 straight to HBM as f32
   constexpr int P = K / 64;     // complex points per lane
   constexpr int R3 = K / 256;   // last radix: 4 or 8
-  constexpr int B12 = P / 16;   // radix-16 butterflies per lane in passes A and B
   constexpr int NQ = K / 128;   // bins per lane per parity
   constexpr int XCH = K + K / 16 + 16;  // padded exchange buffer, complex elements (keeps 16-B alignment)
   constexpr int KOUT = MODE == kModeReal2x ? 2 * K : (MODE == kModeQuad ? K / J : K);  // fft_length = bins per frame

@@ -115,3 +115,56 @@ def test_fuzz_framing_and_ola(seed):
     ov = int(rng.integers(0, N))
     fr = rng.standard_normal((2, M, N)).astype(np.float32)
     assert np.array_equal(S.overlap_and_add(fr, overlap_length=ov).view(np.uint32), O.overlap_and_add(fr, ov).view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_stft_long_rows_interior_edge_split(seed):
+    """longer rows (hundreds to thousands of frames) on the tuned lengths: large interior for the streaming kernels,
+    edge units under every padding mode, frame_length above / below fft_length, odd hops, several rows"""
+    rng = np.random.default_rng(5000 + seed)
+    K = int(rng.choice([128, 256, 512, 1024, 2048, 4096, 400, 1000]))
+    N = int(rng.choice([K, K, max(2, int(K * 0.78)), max(2, K // 2 + 1), K + K // 3]))
+    hop = int(rng.choice([max(1, N // 4), max(1, N // 2), max(1, N // 3 + 1), max(1, int(rng.integers(1, N + 1)))]))
+    M_target = int(rng.integers(150, 1500)) if K <= 1024 else int(rng.integers(40, 300))
+    pad = ["valid", "reflect", "same", [(int(rng.integers(0, 2 * N)), int(rng.integers(0, 2 * N)))],
+           [(-int(rng.integers(0, N // 2 + 1)), int(rng.integers(0, N)))]][rng.integers(5)]
+    L = N + (M_target - 1) * hop + int(rng.integers(0, hop))
+    batch = int(rng.choice([1, 2, 5]))
+    scaling = [None, "spectrum", "psd"][rng.integers(3)]
+    x = rng.standard_normal((batch, L)).astype(np.float32)
+    w = make_window(rng, N)
+    opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=22050)
+    z, t, f = S.stft(x, w, **opts)
+    zo, to, fo = O.stft(x, w, **opts)
+    assert z.shape == zo.shape, (opts, L)
+    assert nerr(z, zo) < 1e-5, (K, N, hop, L, pad, scaling, batch, nerr(z, zo))
+    assert np.array_equal(t, to, equal_nan=True) and np.array_equal(f, fo)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_fused_sinks(seed):
+    """log-mel and magnitude sinks of the stft kernels against the two-step oracle chain"""
+    rng = np.random.default_rng(6000 + seed)
+    K = int(rng.choice([128, 256, 512, 1024, 2048, 4096, 400, 64]))
+    N = int(rng.choice([K, K, max(2, int(K * 0.78))]))
+    hop = int(rng.choice([max(1, N // 4), max(1, N // 2), max(1, int(rng.integers(1, N + 1)))]))
+    pad = ["valid", "reflect", "same"][rng.integers(3)]
+    L = N + int(rng.integers(5, 300)) * hop + int(rng.integers(0, hop))
+    batch = int(rng.choice([1, 3]))
+    scaling = [None, "spectrum"][rng.integers(2)]
+    fs = 16000
+    x = rng.standard_normal((batch, L)).astype(np.float32)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=fs)
+    zo, _, _ = O.stft(x, w, **opts)
+    half = K // 2
+    mag_ref = np.abs(zo[..., :half].astype(np.complex128)).astype(np.float32)
+    mag, _, _ = S.spectrogram(x, w, **opts)
+    assert mag.shape == mag_ref.shape
+    assert np.max(np.abs(mag - mag_ref)) / float(mag_ref.max()) < 1e-5, (K, N, hop, pad)
+    mb = int(rng.choice([8, 40, 80]))
+    if K >= 64:
+        got = S.mel_spectrogram(x, w, mel_bins=mb, **opts)
+        ref = O.stft_to_mel(zo.reshape(-1, K), fs, K, mel_bins=mb).reshape(zo.shape[:-1] + (mb,))
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) < 1e-4, (K, N, hop, pad, mb, float(np.max(np.abs(got - ref))))

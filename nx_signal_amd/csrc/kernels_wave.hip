@@ -694,11 +694,21 @@ struct BlueWaveArgs {
   const v2f* Bf;         // c64[C], pre-scaled by 1/C
   const v2f* twBi;
   const v2f* twCi;
+  // sinks other than the complex spectrum (same fields as MelWaveArgs)
+  int32_t mel_bins, nnz;
+  const float* csr_w;
+  const int* csr_off;
+  const int* csr_lo;
+  float* out;
+  int* gmax;
+  int32_t mag_kind;
 };
 
-template <int C, bool SCALE, int W>
+// SINK: kSinkSpectrum (c64 rows of Kb bins), kSinkMel (log-mel of the bins below Kb / 2), kSinkMag (|X| / |X|^2 of them)
+template <int C, bool SCALE, int W, int SINK = kSinkSpectrum>
 __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
   const WaveArgs& a = b.w;
+  constexpr bool MEL = SINK == kSinkMel, MAG = SINK == kSinkMag;
   constexpr int P = C / 64;
   constexpr int R3 = C / 256;
   constexpr int NQ = C / 128;
@@ -717,8 +727,19 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
   for (int i = tid; i < R3 * 256; i += 64 * W) { s_twC[i] = a.twC[i]; s_twCi[i] = b.twCi[i]; }
   for (int i = tid; i < C; i += 64 * W) s_Bf[i] = b.Bf[i];
   for (int i = tid; i < Kb; i += 64 * W) { s_ch[i] = b.chirp[i]; s_w[i] = a.wtab[i]; }
+  float* s_csr = reinterpret_cast<float*>(s_x + W * XCH);
+  int* s_off = reinterpret_cast<int*>(s_csr + (MEL ? b.nnz : 0));
+  int* s_lo = s_off + (MEL ? b.mel_bins + 1 : 0);
+  if (MEL) {
+    for (int i = tid; i < b.nnz; i += 64 * W) s_csr[i] = b.csr_w[i];
+    for (int i = tid; i <= b.mel_bins; i += 64 * W) s_off[i] = b.csr_off[i];
+    for (int i = tid; i < b.mel_bins; i += 64 * W) s_lo[i] = b.csr_lo[i];
+  }
   __syncthreads();
   v2f* xb = s_x + wave * XCH;
+  const int half = Kb / 2;
+  float* mags = reinterpret_cast<float*>(xb + C / 2);  // MEL: |XA|^2 at [k], |XB|^2 at [half + k]; U lives in xb[0 .. Kb)
+  float vmax = -3.0e38f;
 
   const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
   int64_t p_end = p_begin + a.chunk;
@@ -777,11 +798,50 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
           v2f xa = v2f{u.x + p.x, u.y - p.y} * 0.5f;
           v2f xv = v2f{u.y + p.y, p.x - u.x} * 0.5f;
           if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
-          __builtin_nontemporal_store(xa, (gv2f*)(zA + k));
-          if (haveB) __builtin_nontemporal_store(xv, (gv2f*)(zB + k));
+          if (SINK == kSinkSpectrum) {
+            __builtin_nontemporal_store(xa, (gv2f*)(zA + k));
+            if (haveB) __builtin_nontemporal_store(xv, (gv2f*)(zB + k));
+          } else if (k < half) {
+            const float pa = xa.x * xa.x + xa.y * xa.y, pb = xv.x * xv.x + xv.y * xv.y;
+            if (MEL) { mags[k] = pa; mags[half + k] = pb; }
+            else {
+              const float va = b.mag_kind == 1 ? pa : __builtin_sqrtf(pa), vb = b.mag_kind == 1 ? pb : __builtin_sqrtf(pb);
+              float* o = b.out + ((size_t)row * a.M + mA) * half + k;
+              o[0] = va;
+              vmax = va > vmax ? va : vmax;
+              if (haveB) { o[half] = vb; vmax = vb > vmax ? vb : vmax; }
+            }
+          }
         }
       }
+    if (MEL) {
+      wave_lds_fence();
+      float* o0p = b.out + ((size_t)row * a.M + mA) * b.mel_bins;
+      for (int mb = lane; mb < b.mel_bins; mb += 64) {
+        const int o0 = s_off[mb], o1 = s_off[mb + 1], k0 = s_lo[mb];
+        float accA = 0.0f, accB = 0.0f;
+        for (int j = o0; j < o1; ++j) {
+          const float wv = s_csr[j];
+          accA = fmaf(mags[k0 + (j - o0)], wv, accA);
+          accB = fmaf(mags[half + k0 + (j - o0)], wv, accB);
+        }
+        accA = accA > 1.0e-10f ? accA : 1.0e-10f;
+        accB = accB > 1.0e-10f ? accB : 1.0e-10f;
+        const float vA = __log2f(accA) * 0.30102999566398120f, vB = __log2f(accB) * 0.30102999566398120f;
+        o0p[mb] = vA;
+        vmax = vA > vmax ? vA : vmax;
+        if (haveB) { o0p[b.mel_bins + mb] = vB; vmax = vB > vmax ? vB : vmax; }
+      }
+    }
     wave_lds_fence();  // partner reads complete before the next unit's transposed pass writes the buffer
+  }
+  if (MEL || (MAG && b.mag_kind == 2)) {  // one atomic per wave: running maximum in ordered-int encoding
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(vmax, off); vmax = o > vmax ? o : vmax; }
+    if (lane == 0 && p_begin + wave < p_end) {
+      const int i = __float_as_int(vmax);
+      atomicMax(b.gmax, i >= 0 ? i : i ^ 0x7fffffff);
+    }
   }
 }
 
@@ -1595,9 +1655,11 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
 int blue_tables_dev(Ctx* c, int K, int P, const float2** chirp, const float2** Bf);  // kernels_generic.hip
 
 template <int C>
-static int launch_blue_wave(Ctx* c, const StftLaunch& s) {
+static int launch_blue_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullptr) {
   constexpr int W = 4, R3 = C / 256, XCH = C + C / 16 + 16;
   BlueWaveArgs b;
+  b.mel_bins = 0; b.nnz = 0; b.csr_w = nullptr; b.csr_off = nullptr; b.csr_lo = nullptr; b.out = nullptr; b.gmax = nullptr;
+  b.mag_kind = -1;
   WaveArgs& a = b.w;
   a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
   a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
@@ -1617,7 +1679,43 @@ static int launch_blue_wave(Ctx* c, const StftLaunch& s) {
   { int rc = blue_tables_dev(c, s.K, C, &dc, &db); if (rc) return rc; }
   b.chirp = reinterpret_cast<const v2f*>(dc);
   b.Bf = reinterpret_cast<const v2f*>(db);
-  const size_t lds = (size_t)(2 * 256 + 2 * R3 * 256 + C + C / 2) * 8 + (size_t)(C / 2) * 4 + (size_t)W * XCH * 8;
+  size_t lds = (size_t)(2 * 256 + 2 * R3 * 256 + C + C / 2) * 8 + (size_t)(C / 2) * 4 + (size_t)W * XCH * 8;
+  int sink = kSinkSpectrum;
+  if (mel && mel->mag_kind >= 0) {
+    sink = kSinkMag;
+    *mel->handled = true;
+    b.out = mel->out; b.mag_kind = mel->mag_kind;
+    int rcm = launch_mel_init(c, &b.gmax);
+    if (rcm) return rcm;
+  } else if (mel) {  // CSR of the triangular filter rows restricted to bins < fft_length / 2
+    sink = kSinkMel;
+    std::vector<float> cw;
+    std::vector<int> off(mel->mel_bins + 1, 0), lo(mel->mel_bins, 0);
+    const int half = s.K / 2;
+    for (int mb = 0; mb < mel->mel_bins; ++mb) {
+      const float* fr = mel->filters_host + (size_t)mb * s.K;
+      int l = half, h = 0;
+      for (int k = 0; k < half; ++k)
+        if (fr[k] != 0.0f) { if (k < l) l = k; h = k + 1; }
+      if (h <= l) { l = 0; h = 0; }
+      lo[mb] = l;
+      for (int k = l; k < h; ++k) cw.push_back(fr[k]);
+      off[mb + 1] = (int)cw.size();
+    }
+    if (cw.empty()) cw.push_back(0.0f);
+    if (cw.size() > 6144 || mel->mel_bins > 1024) return NXSIG_OK;  // two-step path
+    *mel->handled = true;
+    const void *dw = nullptr, *doff = nullptr, *dlo = nullptr;
+    int rcm;
+    if ((rcm = ctx_table(c, 0xC5A1ull, cw.data(), cw.size() * sizeof(float), &dw))) return rcm;
+    if ((rcm = ctx_table(c, 0xC5A2ull, off.data(), off.size() * sizeof(int), &doff))) return rcm;
+    if ((rcm = ctx_table(c, 0xC5A3ull, lo.data(), lo.size() * sizeof(int), &dlo))) return rcm;
+    b.mel_bins = mel->mel_bins; b.nnz = (int)cw.size();
+    b.csr_w = reinterpret_cast<const float*>(dw); b.csr_off = reinterpret_cast<const int*>(doff); b.csr_lo = reinterpret_cast<const int*>(dlo);
+    b.out = mel->out;
+    if ((rcm = launch_mel_init(c, &b.gmax))) return rcm;
+    lds += (size_t)b.nnz * 4 + (size_t)(2 * mel->mel_bins + 1) * 4;
+  }
   const int units_per_wave = env_int("NXSIG_BLUE_UNITS_PER_WAVE", 4);
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   const int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
@@ -1629,7 +1727,18 @@ static int launch_blue_wave(Ctx* c, const StftLaunch& s) {
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
-  return s.has_scale ? go(k_stft_blue_wave<C, true, W>) : go(k_stft_blue_wave<C, false, W>);
+  int rc;
+  if (sink == kSinkMel) rc = s.has_scale ? go(k_stft_blue_wave<C, true, W, kSinkMel>) : go(k_stft_blue_wave<C, false, W, kSinkMel>);
+  else if (sink == kSinkMag) rc = s.has_scale ? go(k_stft_blue_wave<C, true, W, kSinkMag>) : go(k_stft_blue_wave<C, false, W, kSinkMag>);
+  else return s.has_scale ? go(k_stft_blue_wave<C, true, W>) : go(k_stft_blue_wave<C, false, W>);
+  if (rc) return rc;
+  if (sink == kSinkMel) return launch_mel_finish(c, mel->out, (int64_t)s.batch * s.fr.M * mel->mel_bins, b.gmax);
+  if (mel->mag_kind == 2) {
+    const int64_t n = (int64_t)s.batch * s.fr.M * (s.K / 2);
+    hipLaunchKernelGGL(k_mag_db_pass2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, mel->out, n, b.gmax);
+    NXSIG_HIP_TRY(hipGetLastError());
+  }
+  return NXSIG_OK;
 }
 
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
@@ -1667,7 +1776,10 @@ int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float*
     case 128: return launch_wave<1024, kModeQuad, 4, 8>(c, s, &mel);
     case 2048: return launch_wave<1024, kModeReal2x, 4>(c, s, &mel);
     case 4096: return launch_wave<2048, kModeReal2x, 4>(c, s, &mel);
-    default: return NXSIG_OK;
+    default:
+      if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0))
+        return s.K <= 512 ? launch_blue_wave<1024>(c, s, &mel) : launch_blue_wave<2048>(c, s, &mel);
+      return NXSIG_OK;
   }
 }
 
@@ -1684,7 +1796,10 @@ int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool
     case 128: return launch_wave<1024, kModeQuad, 4, 8>(c, s, &mel);
     case 2048: return launch_wave<1024, kModeReal2x, 4>(c, s, &mel);
     case 4096: return launch_wave<2048, kModeReal2x, 4>(c, s, &mel);
-    default: return NXSIG_OK;
+    default:
+      if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0))
+        return s.K <= 512 ? launch_blue_wave<1024>(c, s, &mel) : launch_blue_wave<2048>(c, s, &mel);
+      return NXSIG_OK;
   }
 }
 

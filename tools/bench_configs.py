@@ -140,29 +140,30 @@ def main():
             print(json.dumps({"case": f"magnitude spectrogram {kname} fused with the stft, N=1024 hop=256, 32 x 60 s", "ms": ms,
                               "frames_per_s": batch * M / (ms * 1e-3), "bytes_per_frame": bpf,
                               "algorithmic_GBps": batch * M * bpf / (ms * 1e-3) / 1e9}), flush=True)
-    if "melspeech" in which:
-        # ASR front-end: 25 ms frames / 10 ms hop at 16 kHz, 512-point FFT, centred (:reflect), 80 mel bands
-        N, hop, K, L, batch, mb = 400, 160, 512, 16000 * 600, 32, 80
-        w = S.windows.hann(N)
-        M = (L + 2 * (N // 2) - N) // hop + 1
-        xd = ctx.empty((batch, L), np.float32)
-        fill_normal(ctx, xd, (batch, L), 13)
-        filt = S.mel_filters(K, mb, 16000.0)
-        od = ctx.empty((batch, M, mb), np.float32)
-        zd = ctx.empty((batch, M, K), np.complex64)
-        p = _lib.StftParams(N, hop, K, _lib.PAD_REFLECT, 0, 0, 0, 0, 16000.0)
-        wp, fp = w.ctypes.data_as(C.c_void_p), filt.ctypes.data_as(C.c_void_p)
-        fused = lambda: _lib.check(lib.nxsig_stft_mel_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), mb, fp, C.c_void_p(od.ptr), None, _lib.DEVICE))
+    for msname in ("melspeech", "melspeech400"):
+      if msname in which:
+          # ASR front-end: 25 ms frames / 10 ms hop at 16 kHz, 512-point (or n_fft = 400) FFT, centred (:reflect), 80 mel bands
+          N, hop, K, L, batch, mb = 400, 160, (512 if msname == "melspeech" else 400), 16000 * 600, 32, 80
+          w = S.windows.hann(N)
+          M = (L + 2 * (N // 2) - N) // hop + 1
+          xd = ctx.empty((batch, L), np.float32)
+          fill_normal(ctx, xd, (batch, L), 13)
+          filt = S.mel_filters(K, mb, 16000.0)
+          od = ctx.empty((batch, M, mb), np.float32)
+          zd = ctx.empty((batch, M, K), np.complex64)
+          p = _lib.StftParams(N, hop, K, _lib.PAD_REFLECT, 0, 0, 0, 0, 16000.0)
+          wp, fp = w.ctypes.data_as(C.c_void_p), filt.ctypes.data_as(C.c_void_p)
+          fused = lambda: _lib.check(lib.nxsig_stft_mel_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), mb, fp, C.c_void_p(od.ptr), None, _lib.DEVICE))
 
-        def two_step2():
-            _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
-            _lib.check(lib.nxsig_stft_to_mel(ctx.handle, C.c_void_p(zd.ptr), batch * M, K, mb, fp, C.c_void_p(od.ptr), _lib.DEVICE))
+          def two_step2():
+              _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
+              _lib.check(lib.nxsig_stft_to_mel(ctx.handle, C.c_void_p(zd.ptr), batch * M, K, mb, fp, C.c_void_p(od.ptr), _lib.DEVICE))
 
-        for name, fn in (("log-mel fused", fused), ("log-mel two-step", two_step2)):
-            ms = timeit(ctx, fn)
-            print(json.dumps({"case": f"{name}, N=400 hop=160 fft_length=512 :reflect, {mb} mel bins, 32 x 10 min @16 kHz", "ms": ms,
-                              "frames_per_s": batch * M / (ms * 1e-3), "audio_seconds_per_s": batch * 600 / (ms * 1e-3),
-                              "bytes_per_frame_fused": hop * 4 + mb * 4}), flush=True)
+          for name, fn in (("log-mel fused", fused), ("log-mel two-step", two_step2)):
+              ms = timeit(ctx, fn)
+              print(json.dumps({"case": f"{name}, N=400 hop=160 fft_length={K} :reflect, {mb} mel bins, 32 x 10 min @16 kHz", "ms": ms,
+                                "frames_per_s": batch * M / (ms * 1e-3), "audio_seconds_per_s": batch * 600 / (ms * 1e-3),
+                                "bytes_per_frame_fused": hop * 4 + mb * 4}), flush=True)
     if "istft" in which:
         N, hop, L, batch = 1024, 256, 2880000, 16
         w = S.windows.hann(N)

@@ -625,3 +625,38 @@ def test_stft_istft_are_capturable_into_a_hip_graph():
         hip.hipStreamDestroy(stream)
     assert np.array_equal(zd.numpy().view(np.uint32), z_ref_h.view(np.uint32))
     assert np.array_equal(yd.numpy().view(np.uint32), y_ref_h.view(np.uint32))
+
+
+# ------------------------------------------------------------------------------- concurrency (dirty-scheduler threads)
+def test_concurrent_calls_from_several_threads():
+    """NIF dirty schedulers are arbitrary OS threads: calls on one shared context (serialised by its mutex) and on
+    per-thread contexts must be re-entrant and give the single-threaded result (ctypes releases the GIL)."""
+    import threading
+
+    N, hop = 1024, 256
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+    shared = S.default_context()
+    sigs = [O.synth_signal(30000 + 1000 * i, seed=50 + i) for i in range(6)]
+    refs = [S.stft(x, w, ctx=shared, **opts)[0] for x in sigs]
+    errors = []
+
+    def worker(i, own_ctx):
+        try:
+            c = S.Context(0) if own_ctx else shared
+            for _ in range(10):
+                z, _, _ = S.stft(sigs[i], w, ctx=c, **opts)
+                if not np.array_equal(z.view(np.uint32), refs[i].view(np.uint32)):
+                    errors.append((i, own_ctx, "mismatch"))
+                y = S.istft(z, w, ctx=c, **opts)
+                if not np.all(np.isfinite(y.view(np.float32))):
+                    errors.append((i, own_ctx, "non-finite"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, own_ctx, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i, i % 2 == 0)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -4,7 +4,7 @@
     python -m nx_signal_amd.build --force
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
-gpurun snapshot.  No torch, no cmake: four translation units (compiled concurrently) and one link line.
+gpurun snapshot.  No torch, no cmake: six translation units (compiled concurrently) and one link line.
 """
 from __future__ import annotations
 
@@ -27,6 +27,8 @@ UNITS = [
     ("api.cpp", ["-x", "hip"]),
     ("kernels_generic.hip", []),
     ("kernels_wave.hip", []),
+    ("kernels_wave_mel.hip", []),
+    ("kernels_wave_mag.hip", []),
 ]
 
 
@@ -46,7 +48,7 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))] + [
         os.path.join(ROOT, "include", "nxsig.h"),
         os.path.abspath(__file__),
     ]

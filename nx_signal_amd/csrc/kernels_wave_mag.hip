@@ -1,0 +1,26 @@
+// Wave-private FFT kernels, part 3 of 3: the fused STFT -> magnitude / power / dBFS kernels and their launcher.
+#include "wave_stft.hpp"
+
+namespace nxsig {
+
+// fused stft -> magnitude / power / dBFS spectrogram of the bins below fft_length / 2
+int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool* handled) {
+  *handled = false;
+  if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
+  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  MelLaunch mel{0, nullptr, out, handled, kind};
+  switch (s.K) {
+    case 1024: return launch_wave<1024, kModePair, 4, 2, kSinkMag>(c, s, &mel);
+    case 512: return launch_wave<1024, kModeQuad, 4, 2, kSinkMag>(c, s, &mel);
+    case 256: return launch_wave<1024, kModeQuad, 4, 4, kSinkMag>(c, s, &mel);
+    case 128: return launch_wave<1024, kModeQuad, 4, 8, kSinkMag>(c, s, &mel);
+    case 2048: return launch_wave<1024, kModeReal2x, 4, 2, kSinkMag>(c, s, &mel);
+    case 4096: return launch_wave<2048, kModeReal2x, 4, 2, kSinkMag>(c, s, &mel);
+    default:
+      if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0))
+        return s.K <= 512 ? launch_blue_wave<1024, kSinkMag>(c, s, &mel) : launch_blue_wave<2048, kSinkMag>(c, s, &mel);
+      return NXSIG_OK;
+  }
+}
+
+}  // namespace nxsig

@@ -1,0 +1,26 @@
+// Wave-private FFT kernels, part 2 of 3: the fused STFT -> log-mel kernels and their launcher.
+#include "wave_stft.hpp"
+
+namespace nxsig {
+
+// fused stft -> log-mel; *handled = false when the shape is not covered (the caller falls back to stft + stft_to_mel)
+int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled) {
+  *handled = false;
+  if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
+  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  MelLaunch mel{mel_bins, filters_host, out, handled};
+  switch (s.K) {
+    case 1024: return launch_wave<1024, kModePair, 4, 2, kSinkMel>(c, s, &mel);
+    case 512: return launch_wave<1024, kModeQuad, 4, 2, kSinkMel>(c, s, &mel);
+    case 256: return launch_wave<1024, kModeQuad, 4, 4, kSinkMel>(c, s, &mel);
+    case 128: return launch_wave<1024, kModeQuad, 4, 8, kSinkMel>(c, s, &mel);
+    case 2048: return launch_wave<1024, kModeReal2x, 4, 2, kSinkMel>(c, s, &mel);
+    case 4096: return launch_wave<2048, kModeReal2x, 4, 2, kSinkMel>(c, s, &mel);
+    default:
+      if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0))
+        return s.K <= 512 ? launch_blue_wave<1024, kSinkMel>(c, s, &mel) : launch_blue_wave<2048, kSinkMel>(c, s, &mel);
+      return NXSIG_OK;
+  }
+}
+
+}  // namespace nxsig

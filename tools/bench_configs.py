@@ -53,6 +53,19 @@ def stft_case(ctx, N, hop, L, batch, name, K=None, pad=None):
     p = _lib.StftParams(N, hop, K, pad, 0, 0, _lib.SCALE_NONE, 0, 48000.0)
     wp = w.ctypes.data_as(C.c_void_p)
     fn = lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
+    nalt = int(os.environ.get("NXSIG_BENCH_ALT_INPUTS", "1"))
+    if nalt > 1:  # rotate over several input buffers so that no input stays resident in the Infinity Cache between launches
+        xs = [xd]
+        for i in range(nalt - 1):
+            xi = ctx.empty((batch, L), np.float32)
+            fill_normal(ctx, xi, (batch, L), 100 + i)
+            xs.append(xi)
+        state = {"i": 0}
+
+        def fn():
+            xi = xs[state["i"] % nalt]
+            state["i"] += 1
+            _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xi.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
     ms = timeit(ctx, fn)
     bpf = hop * 4 + K * 8
     gbs = batch * M * bpf / (ms * 1e-3) / 1e9
@@ -76,6 +89,13 @@ def main():
         stft_case(ctx, 400, 160, 16000 * 600, 32, "stft N=400 hop=160 fft_length=512 (25 ms / 10 ms speech framing), 32 x 10 min @16 kHz", K=512)
     if "speech512r" in which:
         stft_case(ctx, 400, 160, 16000 * 600, 32, "stft N=400 hop=160 fft_length=512 :reflect, 32 x 10 min @16 kHz", K=512, pad=_lib.PAD_REFLECT)
+    for name in which:
+        if name.startswith("case:"):  # case:N:hop:K[:rows[:samples]] — any stft shape, :valid
+            f = [int(v) for v in name.split(":")[1:]]
+            n, hp, k = f[0], f[1], f[2]
+            rows = f[3] if len(f) > 3 else 32
+            Lc = f[4] if len(f) > 4 else (1500 * 1024 * 1024 // (rows * 8 * k)) * hp + n
+            stft_case(ctx, n, hp, Lc, rows, f"stft N={n} hop={hp} fft_length={k}, {rows} rows x {Lc} samples", K=k)
     for name in which:
         if name.startswith("gen"):  # e.g. gen512: generic-kernel sizes, ~1.7 GB of output each
             n = int(name[3:])

@@ -1035,7 +1035,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
   // the kernel time), at the price of re-loading the 12 KB of tables per workgroup from L2.
   const int units_per_wave = (mel && mel->mag_kind >= 0) ? env_int("NXSIG_MAG_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
                              : mel ? env_int("NXSIG_MEL_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
-                                 : env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : 8);  // measured optima
+                                 : env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : (MODE == kModeQuad ? (J == 2 ? 2 : 3) : 8));  // measured optima (input from HBM)
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   // Interior frames [m_lo, m_hi): every one of the KOUT samples the streaming front-end reads lies inside the signal,
   // whatever the padding mode (window_padding :reflect / :same / explicit only touch the first and last few frames).

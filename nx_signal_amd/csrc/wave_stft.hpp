@@ -1,14 +1,19 @@
-// Tuned gfx950 kernels built around ONE wave-private 1024-point complex FFT core (wave_fft_core / wave_fft_core_T):
-// 64 lanes x 16 points, radix 16 x 16 x 4, two LDS exchanges in an 8.8 KB wave-private buffer, no workgroup barrier
-// after the table preload.  Every kernel below is a different way of feeding that core and draining it:
+// Tuned gfx950 kernels built around ONE wave-private complex FFT core (wave_fft_core / wave_fft_core_T, 1024 or 2048
+// points): 64 lanes x 16 (32) points, radix 16 x 16 x 4 (8), two LDS exchanges in an 8.8 (17.5) KB wave-private buffer,
+// no workgroup barrier after the table preload.  Every kernel is a different way of feeding that core and draining it.
+// This header holds what the three wave translation units share:
 //
-//   k_stft_wave       pair   : two adjacent real frames as re / im                        fft_length 1024
-//                     real-2x: one 2048-sample frame as even / odd samples                fft_length 2048
-//                     quad   : 2J frames, J complex sequences interleaved (J = 2, 4, 8)   fft_length 512 / 256 / 128
-//   k_stft_mel_wave   pair mode + |X|^2 -> sparse mel filterbank -> log10 (fused stft_to_mel)
-//   k_istft_wave      one complex frame per inverse FFT, run of frames per wave, pending overlap sums in registers (N = 1024)
-//   k_istft_wave_half two consecutive frames per inverse FFT (N = 512)
-//   k_fir_wave        overlap-save: transposed-pass forward FFT -> x H -> inverse core, two blocks as re / im
+//   wave_fft_core / _core_T   forward, transposed and inverse-direction cores, packed-FP32 butterflies
+//   stft_wave_body            pair   : two adjacent real frames as re / im                        fft_length 1024
+//                             real-2x: one frame as even / odd samples                            fft_length 2048, 4096
+//                             quad   : 2J frames, J complex sequences interleaved (J = 2, 4, 8)   fft_length 512 / 256 / 128
+//                             sinks  : complex spectrum (k_stft_wave), log-mel (k_stft_mel_wave), magnitude (k_stft_mag_wave)
+//   k_stft_blue_wave          non-power-of-two fft_length <= 1024: Bluestein chirp-z on the same cores, same sinks
+//   launch_wave / launch_blue_wave   launch templates (interior / edge split, staged quad input, chunk geometry);
+//                             the SINK template argument selects the kernel family a translation unit instantiates
+//
+//   kernels_wave.hip      iSTFT (k_istft_wave, _half, _quad, _dbl), overlap-save FIR (k_fir_wave), plain STFT launcher
+//   kernels_wave_mel.hip  log-mel launcher          kernels_wave_mag.hip  magnitude launcher
 //
 // The core in pair mode, step by step:
 //   global load (frame slice x window fused, lib/nx_signal.ex:94-101)          64 lanes x P = K/64 points
@@ -22,13 +27,13 @@
 //
 // The STFT path is HBM-bound (9 216 algorithmic B/frame at K=1024, 89 % stores), MFMA is deliberately unused.
 // Index math and LDS bank behaviour are modelled lane by lane in tools/emulate_wave_fft.py.
+#pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
 #include <cmath>
 #include <cstdlib>
 
-#pragma once
 #include "nxsig_internal.h"
 
 namespace nxsig {

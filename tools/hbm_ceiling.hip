@@ -67,6 +67,22 @@ __global__ __launch_bounds__(256) void k_istftmix(const float* __restrict__ in, 
   }
 }
 
+
+// NT fill: each wave writes CH consecutive KiB (CH x 64 lanes x 16 B), waves take consecutive chunks
+template <int CH>
+__global__ __launch_bounds__(256) void k_fill_nt(float4* __restrict__ out, size_t n16) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * 256) >> 6;
+  const size_t chunks = n16 / (64 * CH);
+  for (size_t c = wave; c < chunks; c += nw) {
+    v4f* o = reinterpret_cast<v4f*>(out) + c * 64 * CH + lane;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { v4f v = {1.f + j, 2.f, 3.f, (float)lane}; __builtin_nontemporal_store(v, o + 64 * j); }
+  }
+}
+
 int main(int argc, char** argv) {
   size_t mib = argc > 1 ? atol(argv[1]) : 2048;
   size_t bytes = mib << 20;
@@ -104,6 +120,14 @@ int main(int argc, char** argv) {
       ms = time([&] { hipLaunchKernelGGL(k_istftmix<8>, dim3(grid), dim3(256), 0, 0, (const float*)a, b, fr, chunk); }, 20);
       printf("istftmix  8B chunk %4zu: %8.3f ms  %7.1f GB/s\n", chunk, ms, fr * 10240.0 / ms / 1e6);
     }
+  }
+  for (int grid : {2048, 8192, 32768}) {
+    float ms = time([&] { hipLaunchKernelGGL(k_fill_nt<1>, dim3(grid), dim3(256), 0, 0, b, n); }, 20);
+    printf("fill nt 1KiB/wave grid %6d: %8.3f ms  %7.1f GB/s (w)\n", grid, ms, 1.0 * bytes / ms / 1e6);
+    ms = time([&] { hipLaunchKernelGGL(k_fill_nt<8>, dim3(grid), dim3(256), 0, 0, b, n); }, 20);
+    printf("fill nt 8KiB/wave grid %6d: %8.3f ms  %7.1f GB/s (w)\n", grid, ms, 1.0 * bytes / ms / 1e6);
+    ms = time([&] { hipLaunchKernelGGL(k_fill_nt<16>, dim3(grid), dim3(256), 0, 0, b, n); }, 20);
+    printf("fill nt 16KiB/wave grid %6d: %8.3f ms  %7.1f GB/s (w)\n", grid, ms, 1.0 * bytes / ms / 1e6);
   }
   return 0;
 }

@@ -201,7 +201,8 @@ struct Staged {
     unsigned T = hw >= 8 ? 4 : 1;  // more threads contend on the process' mmap lock: 8 / 16 / 32 measured slower
     if (const char* v = std::getenv("NXSIG_PREFAULT_THREADS")) { const int n = std::atoi(v); if (n >= 1 && n <= 64) T = (unsigned)n; }
     const size_t per = (((e - a) / T) + page - 1) & ~(size_t)(page - 1);
-    auto work = [page](uintptr_t s0, uintptr_t s1) {
+    auto work = [](uintptr_t s0, uintptr_t s1) {
+      const uintptr_t page = 4096;
       if (s1 <= s0) return;
 #ifdef __linux__
       if (madvise(reinterpret_cast<void*>(s0), s1 - s0, 23 /* MADV_POPULATE_WRITE */) == 0) return;

@@ -1089,7 +1089,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
-  int rc;
+  int rc = NXSIG_OK;
   if constexpr (SINK == kSinkMag) {
     const int64_t big = (int64_t)1 << 62;
     {

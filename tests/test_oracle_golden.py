@@ -196,3 +196,25 @@ def test_firwin_errors(golden):
             O.firwin(v["num_taps"], v["cutoff"], **v["opts"])
     with pytest.raises(ValueError, match="cutoff must be a list"):
         O.firwin(5, 0.3)
+
+
+def test_oracle_config1_regression_fixture():
+    """tests/golden/oracle_c1_fixture.npz (made by tests/golden/make_oracle_fixtures.py) pins the oracle itself on
+    BASELINE config 1: the reference cannot run here, so this guards the checker against silent drift."""
+    import os
+
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_c1_fixture.npz"))
+    x = O.synth_signal(48000, seed=1234)
+    assert np.array_equal(x[:2048], fx["x_head"])
+    w = O.hann(1024)
+    z, t, f = O.stft(x, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert tuple(fx["shape_z"]) == z.shape == (184, 1024)
+    assert np.array_equal(t, fx["times"]) and np.array_equal(f, fx["freqs"])
+    scale = float(np.max(np.abs(z)))
+    assert np.max(np.abs(z[fx["frames"]] - fx["z_frames"])) / scale < 1e-7
+    assert np.max(np.abs(z.sum(axis=0).astype(np.complex64) - fx["z_colsum"])) / scale < 1e-5
+    assert np.allclose(np.abs(z).sum(axis=1).astype(np.float32), fx["z_abs_rowsum"], rtol=1e-6)
+    y = O.istft(z, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert tuple(fx["shape_y"]) == y.shape
+    ys = float(np.max(np.abs(y)))
+    assert np.max(np.abs(y[:1536] - fx["y_head"])) / ys < 1e-6 and np.max(np.abs(y[-1536:] - fx["y_tail"])) / ys < 1e-6

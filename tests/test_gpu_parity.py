@@ -660,3 +660,26 @@ def test_concurrent_calls_from_several_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_stft_config1_against_committed_fixture():
+    """HIP stft / istft on BASELINE config 1 against tests/golden/oracle_c1_fixture.npz (committed data, no live oracle)"""
+    import os
+
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_c1_fixture.npz"))
+    x = O.synth_signal(48000, seed=1234)
+    assert np.array_equal(x[:2048], fx["x_head"])
+    w = S.windows.hann(1024)
+    opts = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)
+    z, t, f = S.stft(x, w, **opts)
+    assert z.shape == tuple(fx["shape_z"])
+    assert np.array_equal(t, fx["times"]) and np.array_equal(f, fx["freqs"])
+    scale = float(np.max(np.abs(fx["z_frames"])))
+    assert np.max(np.abs(z[fx["frames"]] - fx["z_frames"])) / scale < 1e-5
+    assert np.max(np.abs(z.sum(axis=0) - fx["z_colsum"])) / scale < 2e-4     # 184-term sums of values with 1e-7 error
+    y = S.istft(z, w, **opts)
+    ys = float(np.max(np.abs(fx["y_head"])))
+    # the first / last hop of an iSTFT under a Hann window divide by a vanishing normaliser: 1e-7 differences between the
+    # two spectra are amplified there (see the conditioning note in test_istft_config3_*), so compare past the first hop
+    assert np.max(np.abs(y[512:1536] - fx["y_head"][512:])) / ys < 1e-5
+    assert np.max(np.abs(y[-1536:-512] - fx["y_tail"][:-512])) / ys < 1e-5

@@ -169,6 +169,7 @@ struct DeviceGuard {
       c->tables.clear();
       c->wave_tables.clear();
       c->memo_dev = c->memo_devK = nullptr;
+      c->memo.clear();
     }
   }
   std::lock_guard<std::mutex> lock;

@@ -18,6 +18,8 @@
 // :609-637 (istft), :684-736 (overlap_and_add), lib/nx_signal/convolution.ex:252-329 (fftconvolve).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "nxsig_internal.h"
 
 namespace nxsig {
@@ -673,6 +675,17 @@ static void host_fft_f64(std::vector<double>& re, std::vector<double>& im);
 static int blue_tables(Ctx* c, int K, BlueTables* t, int forceP = 0) {
   int P = 1, logP = 0;
   while (P < 2 * K - 1 || P < forceP) { P <<= 1; ++logP; }
+  const uint64_t bkey = 0xB10E5000000000ull ^ ((uint64_t)K << 24) ^ (uint64_t)P ^ (forceP ? 0x800000000000ull : 0ull);
+  {
+    auto hit = c->memo.find(bkey);
+    if (hit != c->memo.end()) {  // the tables depend on (K, P) only
+      t->K = K; t->P = P; t->logP = logP;
+      t->chirp = reinterpret_cast<const float2*>(hit->second[0]);
+      t->Bf = reinterpret_cast<const float2*>(hit->second[1]);
+      t->twP = reinterpret_cast<const float2*>(hit->second[2]);
+      return NXSIG_OK;
+    }
+  }
   std::vector<float2> chirp((size_t)K), Bf((size_t)P);
   std::vector<double> cre((size_t)K), cim((size_t)K), bre((size_t)P, 0.0), bim((size_t)P, 0.0);
   for (int n = 0; n < K; ++n) {
@@ -693,8 +706,14 @@ static int blue_tables(Ctx* c, int K, BlueTables* t, int forceP = 0) {
   t->K = K; t->P = P; t->logP = logP;
   t->chirp = reinterpret_cast<const float2*>(dc);
   t->Bf = reinterpret_cast<const float2*>(db);
-  if (forceP) { t->twP = nullptr; return NXSIG_OK; }
-  return ctx_twiddles(c, P, &t->twP);
+  if (forceP) {
+    t->twP = nullptr;
+  } else {
+    rc = ctx_twiddles(c, P, &t->twP);
+    if (rc) return rc;
+  }
+  c->memo[bkey] = {reinterpret_cast<uint64_t>(t->chirp), reinterpret_cast<uint64_t>(t->Bf), reinterpret_cast<uint64_t>(t->twP)};
+  return NXSIG_OK;
 }
 // tables for the wave-core Bluestein kernel: convolution length fixed to the core size P
 int blue_tables_dev(Ctx* c, int K, int P, const float2** chirp, const float2** Bf) {
@@ -909,6 +928,29 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
   if (s.M == 0 || s.batch == 0) return NXSIG_OK;
   const int N = s.N, hop = s.hop;
   const int64_t out_len = s.M * hop + (N - hop);
+  // everything derived on the host below is a pure function of (window, hop, M): memoised per context
+  const uint64_t ekey = fnv1a(0xED6Full ^ ((uint64_t)hop << 24) ^ ((uint64_t)s.M << 40), window_host, (size_t)N * sizeof(float)) ^ (uint64_t)N;
+  {
+    auto hit = c->memo.find(ekey);
+    if (hit != c->memo.end()) {
+      const std::vector<uint64_t>& v = hit->second;  // {mode, tau bits, tw, idx, n_idx}
+      if (v[0] == 0) return NXSIG_OK;
+      EdgeFixArgs a;
+      uint32_t tb = (uint32_t)v[1];
+      std::memcpy(&a.tau, &tb, 4);
+      a.z = s.z; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
+      a.y = s.y; a.out_len = out_len;
+      a.tw = reinterpret_cast<const double2*>(v[2]);
+      a.idx = reinterpret_cast<const int64_t*>(v[3]);
+      a.n_idx = (int64_t)v[4];
+      const int64_t blocks = v[0] == 1 ? a.n_idx : out_len;
+      if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "istft: signal too long for the edge fix-up grid");
+      dim3 grid((unsigned)blocks, (unsigned)s.batch);
+      hipLaunchKernelGGL(k_istft_edge_fix, grid, dim3(kThreads), 0, c->stream, a);
+      NXSIG_HIP_TRY(hipGetLastError());
+      return NXSIG_OK;
+    }
+  }
   // interior normaliser is periodic in n with period hop: den_mid[r] = sum_{j = r (mod hop)} |w[j]|^2
   const int period = hop < N ? hop : N;
   double dmin = 1e300, dmax = 0.0;
@@ -918,7 +960,7 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
     dmin = d < dmin ? d : dmin;
     dmax = d > dmax ? d : dmax;
   }
-  if (!(dmax > 0.0)) return NXSIG_OK;
+  if (!(dmax > 0.0)) { c->memo[ekey] = {0, 0, 0, 0, 0}; return NXSIG_OK; }
   EdgeFixArgs a;
   a.tau = (float)(0.02 * dmax);
   a.z = s.z; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
@@ -954,7 +996,7 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
     };
     for (int64_t n = 0; n < head_cnt; ++n) consider(n);
     for (int64_t n = tail_start; n < out_len; ++n) consider(n);
-    if (idx.empty()) return NXSIG_OK;
+    if (idx.empty()) { c->memo[ekey] = {0, 0, 0, 0, 0}; return NXSIG_OK; }
     const void* d = nullptr;
     int rc = ctx_table(c, 0x1D8ull, idx.data(), idx.size() * sizeof(int64_t), &d);
     if (rc) return rc;
@@ -963,6 +1005,11 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
     blocks = a.n_idx;
   } else {
     blocks = out_len;  // ill-conditioned interior (e.g. hop == N under a tapered window): every sample is a candidate
+  }
+  {
+    uint32_t tb;
+    std::memcpy(&tb, &a.tau, 4);
+    c->memo[ekey] = {a.idx ? 1ull : 2ull, (uint64_t)tb, reinterpret_cast<uint64_t>(a.tw), reinterpret_cast<uint64_t>(a.idx), (uint64_t)a.n_idx};
   }
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "istft: signal too long for the edge fix-up grid");
   dim3 grid((unsigned)blocks, (unsigned)s.batch);

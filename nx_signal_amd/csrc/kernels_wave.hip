@@ -650,6 +650,9 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
 // guarded normaliser rows (lib/nx_signal.ex:630-635) as RECIPROCALS: f32[2R-1][hop] = head segments 0..R-2, the interior
 // segment, tail segments; double accumulation in ascending frame order, one rounding
 static int istft_den_table(Ctx* c, int R, int hop, const float* window_host, const float** out) {
+  const uint64_t dkey = fnv1a(0xDE18ull ^ ((uint64_t)R << 32) ^ ((uint64_t)hop << 8), window_host, (size_t)R * hop * sizeof(float));
+  auto hit = c->memo.find(dkey);
+  if (hit != c->memo.end()) { *out = reinterpret_cast<const float*>(hit->second[0]); return NXSIG_OK; }
   std::vector<float> den((size_t)(2 * R - 1) * hop);
   auto w2 = [&](int idx) { const float w = std::fabs(window_host[idx]); return (double)(w * w); };
   for (int row = 0; row < 2 * R - 1; ++row)
@@ -669,6 +672,7 @@ static int istft_den_table(Ctx* c, int R, int hop, const float* window_host, con
   int rc3 = ctx_table(c, 0xDE17ull ^ ((uint64_t)R << 32), den.data(), den.size() * sizeof(float), &dd);
   if (rc3) return rc3;
   *out = reinterpret_cast<const float*>(dd);
+  c->memo[dkey] = {reinterpret_cast<uint64_t>(dd)};
   return NXSIG_OK;
 }
 
@@ -875,14 +879,21 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
   int rc = ensure_wave_tables(c, K);
   if (rc) return rc;
   *handled = true;
-  std::vector<double> re(K, 0.0), im(K, 0.0);
-  for (int i = 0; i < s.taps; ++i) re[i] = (double)s.h_host[i];
-  host_fft1024_f64(re, im);
-  std::vector<float2> H(K);
-  for (int i = 0; i < K; ++i) H[i] = make_float2((float)(re[i] / K), (float)(im[i] / K));
   const void* Hd = nullptr;
-  rc = ctx_table(c, 0xF1A1ull ^ (uint64_t)K, H.data(), H.size() * sizeof(float2), &Hd);
-  if (rc) return rc;
+  const uint64_t hkey = fnv1a(0xF1B0ull ^ ((uint64_t)K << 32), s.h_host, (size_t)s.taps * sizeof(float)) ^ (uint64_t)s.taps;
+  auto hit = c->memo.find(hkey);
+  if (hit != c->memo.end()) {
+    Hd = reinterpret_cast<const void*>(hit->second[0]);  // same taps as an earlier call: no host FFT
+  } else {
+    std::vector<double> re(K, 0.0), im(K, 0.0);
+    for (int i = 0; i < s.taps; ++i) re[i] = (double)s.h_host[i];
+    host_fft1024_f64(re, im);
+    std::vector<float2> H(K);
+    for (int i = 0; i < K; ++i) H[i] = make_float2((float)(re[i] / K), (float)(im[i] / K));
+    rc = ctx_table(c, 0xF1A1ull ^ (uint64_t)K, H.data(), H.size() * sizeof(float2), &Hd);
+    if (rc) return rc;
+    c->memo[hkey] = {reinterpret_cast<uint64_t>(Hd)};
+  }
   FirWaveArgs a;
   a.x = s.x; a.L = s.L; a.batch_stride = s.batch_stride; a.batch = s.batch; a.taps = s.taps;
   a.V = K - (s.taps - 1);

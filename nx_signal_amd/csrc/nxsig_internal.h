@@ -79,6 +79,9 @@ struct Ctx {
   int memo_K = 0;
   const float* memo_dev = nullptr;   // f32[N]
   const float* memo_devK = nullptr;  // f32[K], zero-padded / truncated to the fft length
+  // memo of host-side derivations keyed by the content they derive from (filter spectrum of a tap vector, OLA normaliser
+  // rows and edge-fix sample list of a window): a few machine words each, dropped together with `tables`
+  std::map<uint64_t, std::vector<uint64_t>> memo;
 };
 
 int ctx_twiddles(Ctx* c, int K, const float2** out);

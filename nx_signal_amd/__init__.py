@@ -17,6 +17,7 @@ kernels behind the C ABI in include/nxsig.h; there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 
 import numpy as np
 
@@ -304,10 +305,22 @@ def mel_filters(fft_length, mel_bins, sampling_rate, **opts):
     o = _validate(opts, {"max_mel": 3016, "mel_frequency_spacing": 200 / 3, "type": "f32"}, "mel_filters")
     if o["type"] not in ("f32", np.float32):
         raise ArgumentError("mel_filters: only type f32 is built")
-    out = np.empty((int(mel_bins), int(fft_length)), dtype=np.float32)
-    _lib.check(_lib.load().nxsig_mel_filters_f32(int(fft_length), int(mel_bins), float(sampling_rate), float(o["max_mel"]),
-                                                 float(o["mel_frequency_spacing"]), _as_ptr(out)))
+    return _mel_filters_table(int(fft_length), int(mel_bins), float(sampling_rate), float(o["max_mel"]),
+                              float(o["mel_frequency_spacing"])).copy()
+
+
+@functools.lru_cache(maxsize=16)
+def _mel_filters_table(fft_length: int, mel_bins: int, sampling_rate: float, max_mel: float, spacing: float) -> np.ndarray:
+    """the filterbank is a pure function of its five parameters: generated once per combination (read-only copy)"""
+    out = np.empty((mel_bins, fft_length), dtype=np.float32)
+    _lib.check(_lib.load().nxsig_mel_filters_f32(fft_length, mel_bins, sampling_rate, max_mel, spacing, _as_ptr(out)))
+    out.setflags(write=False)
     return out
+
+
+def _mel_filters_for(K, mb, fs, fopts):
+    o = _validate(dict(fopts), {"max_mel": 3016, "mel_frequency_spacing": 200 / 3}, "mel_filters")
+    return _mel_filters_table(int(K), int(mb), float(fs), float(o["max_mel"]), float(o["mel_frequency_spacing"]))
 
 
 def stft_to_mel(z, sampling_rate, ctx: Context | None = None, **opts):
@@ -319,7 +332,7 @@ def stft_to_mel(z, sampling_rate, ctx: Context | None = None, **opts):
         raise ArgumentError("missing :fft_length option")
     K, mb = int(o["fft_length"]), int(o["mel_bins"])
     fopts = {k: o[k] for k in ("max_mel", "mel_frequency_spacing") if o[k] is not None}
-    filt = mel_filters(K, mb, sampling_rate, **fopts)
+    filt = _mel_filters_for(K, mb, sampling_rate, fopts)
     lib = _lib.load()
     if is_device(z):
         ptr, shape, dt = device_view(z)
@@ -393,7 +406,7 @@ def mel_spectrogram(data, window, ctx: Context | None = None, **opts):
     K = _resolve_fft_length(o["fft_length"], N)
     mb = int(mo.get("mel_bins", 128))
     fopts = {k: mo[k] for k in ("max_mel", "mel_frequency_spacing") if mo.get(k) is not None}
-    filt = mel_filters(K, mb, fs, **fopts)
+    filt = _mel_filters_for(K, mb, fs, fopts)
     p = StftParams(N, hop, K, mode, lo, hi, _SCALING[o["scaling"]], 0, fs)
     lib = _lib.load()
     M = C.c_int64()

@@ -4,7 +4,7 @@
     python -m nx_signal_amd.build --force
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
-gpurun snapshot.  No torch, no cmake: six translation units (compiled concurrently) and one link line.
+gpurun snapshot.  No torch, no cmake: seven translation units (compiled concurrently) and one link line.
 """
 from __future__ import annotations
 
@@ -29,6 +29,7 @@ UNITS = [
     ("kernels_wave.hip", []),
     ("kernels_wave_mel.hip", []),
     ("kernels_wave_mag.hip", []),
+    ("kernels_wave_r20.hip", []),
 ]
 
 

@@ -625,6 +625,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
   }
 }
 
+int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_r20.hip
+
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   *handled = false;
   if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
@@ -639,6 +641,10 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
     case 2048: *handled = true; return launch_wave<1024, kModeReal2x, 4>(c, s);    // one frame as even/odd samples
     case 4096: *handled = true; return launch_wave<2048, kModeReal2x, 4>(c, s);    // same on the 2048-point core
     default: break;
+  }
+  if (s.K == 400) {  // 20 x 20 native kernel (kernels_wave_r20.hip)
+    int rc20 = launch_stft_r20(c, s, handled, nullptr);
+    if (rc20 || *handled) return rc20;
   }
   if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0)) {
     *handled = true;  // non-power-of-two: Bluestein through the 1024- (Kb <= 512) or 2048-point core

@@ -3,6 +3,8 @@
 
 namespace nxsig {
 
+int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_r20.hip
+
 // fused stft -> magnitude / power / dBFS spectrogram of the bins below fft_length / 2
 int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool* handled) {
   *handled = false;
@@ -17,6 +19,11 @@ int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool
     case 2048: return launch_wave<1024, kModeReal2x, 4, 2, kSinkMag>(c, s, &mel);
     case 4096: return launch_wave<2048, kModeReal2x, 4, 2, kSinkMag>(c, s, &mel);
     default:
+      if (s.K == 400) {  // native 20 x 20 kernel
+        bool h20 = false;
+        int rc20 = launch_stft_r20(c, s, &h20, &mel);
+        if (rc20 || h20) return rc20;
+      }
       if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0))
         return s.K <= 512 ? launch_blue_wave<1024, kSinkMag>(c, s, &mel) : launch_blue_wave<2048, kSinkMag>(c, s, &mel);
       return NXSIG_OK;

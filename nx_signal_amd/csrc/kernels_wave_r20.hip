@@ -1,0 +1,318 @@
+// Wave kernels, part 4: fft_length 400 = 20 x 20 computed natively (25 ms speech frames at 16 kHz, n_fft = 400).
+//
+// The Bluestein kernel pays two 1024-point transforms (about 102 kflop) per frame pair for a 400-point DFT (about
+// 17 kflop) and is VALU-bound.  Here one 400-point complex FFT runs on 20 lanes x 20 points as two radix-20 passes
+// (Cooley-Tukey n = 20 n1 + n2, k = k1 + 20 k2; each 20-point DFT is a prime-factor 4 x 5 butterfly without internal
+// twiddles), three transforms per wave (lanes 60..63 idle).  As everywhere in this library two real frames ride as
+// re / im of one transform and are separated afterwards through the Hermitian partner U[(400 - k) mod 400].
+//
+//   raw samples of the unit's six frames (one contiguous span) -> LDS            16-byte loads when aligned and inside
+//   pass A   lane n2: DFT20 over n1 of u[20 n1 + n2] (frame slice x window fused, lib/nx_signal.ex:94-101), x W400^(n2 k1)
+//   20 x 20 transpose through LDS (row stride 21: conflict-free both ways)
+//   pass B   lane k1: DFT20 over n2 -> U[k1 + 20 k2]
+//   natural-order U in LDS -> untangle XA = (U + conj U')/2, XB = -i (U - conj U')/2 -> 16-byte stores (:129)
+#include "wave_stft.hpp"
+
+namespace nxsig {
+
+struct R20Args {
+  WaveArgs w;              // framing, window (f32[400], zero beyond N), div / has_scale, z; pairs_per_row = ceil(M / 2)
+  const v2f* tw;           // c64[20][20]: W_400^(n2 k1) at [n2 * 20 + k1]
+  int64_t units_per_row;   // ceil(pairs_per_row / 3): a unit = three frame pairs = six frames
+  int64_t total_units;
+  int32_t fast_ok;         // base pointer, row stride and padding offset allow 16-byte loads
+  // sinks other than the complex spectrum (same fields as MelWaveArgs)
+  int32_t mel_bins, nnz;
+  const float* csr_w;
+  const int* csr_off;
+  const int* csr_lo;
+  float* out;
+  int* gmax;
+  int32_t mag_kind;
+};
+
+// 5-point DFT, forward (e^{-2 pi i ..})
+__device__ __forceinline__ void dft5(v2f& x0, v2f& x1, v2f& x2, v2f& x3, v2f& x4) {
+  const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f, s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+  const v2f a1 = x1 + x4, a2 = x2 + x3, b1 = x1 - x4, b2 = x2 - x3;
+  const v2f t1 = x0 + a1 * c1 + a2 * c2, t2 = x0 + a1 * c2 + a2 * c1;
+  const v2f u1 = b1 * s1 + b2 * s2, u2 = b1 * s2 - b2 * s1;
+  x0 = x0 + a1 + a2;
+  x1 = add_mi(t1, u1); x4 = add_pi(t1, u1);
+  x2 = add_mi(t2, u2); x3 = add_pi(t2, u2);
+}
+
+// 20-point DFT in natural order, prime-factor 4 x 5: n = (5 n1 + 4 n2) mod 20, k = (5 k1 + 16 k2) mod 20, no twiddles
+__device__ __forceinline__ void dft20(v2f* v) {
+  v2f A[4][5];
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) {
+    v2f c0 = v[(4 * n2) % 20], c1 = v[(5 + 4 * n2) % 20], c2 = v[(10 + 4 * n2) % 20], c3 = v[(15 + 4 * n2) % 20];
+    dft4<false>(c0, c1, c2, c3);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2; A[3][n2] = c3;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    dft5(A[k1][0], A[k1][1], A[k1][2], A[k1][3], A[k1][4]);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) v[(5 * k1 + 16 * k2) % 20] = A[k1][k2];
+  }
+}
+
+// SINK: kSinkSpectrum (c64 rows of 400 bins), kSinkMel (log-mel of the bins below 200), kSinkMag (|X| / |X|^2 of them)
+template <bool SCALE, int W, int SINK>
+__global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
+  const WaveArgs& a = b.w;
+  constexpr bool MEL = SINK == kSinkMel, MAG = SINK == kSinkMag;
+  constexpr int KB = 400, HALF = 200;
+  constexpr int BUF = 1280;                      // complex cells per wave: staging (<= 2560 floats) / 3 x 20 x 21 / 3 x 400
+  float* s_w = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
+  v2f* s_x = s_tw + KB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = b.tw[i]; }
+  float* s_csr = reinterpret_cast<float*>(s_x + W * BUF);
+  int* s_off = reinterpret_cast<int*>(s_csr + (MEL ? b.nnz : 0));
+  int* s_lo = s_off + (MEL ? b.mel_bins + 1 : 0);
+  if (MEL) {
+    for (int i = tid; i < b.nnz; i += 64 * W) s_csr[i] = b.csr_w[i];
+    for (int i = tid; i <= b.mel_bins; i += 64 * W) s_off[i] = b.csr_off[i];
+    for (int i = tid; i < b.mel_bins; i += 64 * W) s_lo[i] = b.csr_lo[i];
+  }
+  __syncthreads();
+  float vmax = -3.0e38f;
+  v2f* buf = s_x + wave * BUF;
+  float* S = reinterpret_cast<float*>(buf);
+  const int g = lane / 20, l20 = lane % 20;       // transform of the unit (g == 3: idle lanes), lane inside it
+  const int nuse = a.N < KB ? a.N : KB;
+  const int span = 5 * a.hop + nuse;
+  const int span4 = (span + 3) & ~3;
+
+  const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
+  int64_t p_end = p_begin + a.chunk;
+  if (p_end > b.total_units) p_end = b.total_units;
+  for (int64_t ui = p_begin + wave; ui < p_end; ui += W) {
+    const int64_t row = ui / b.units_per_row;
+    const int64_t u = ui - row * b.units_per_row;
+    const float* xr = a.x + (size_t)row * a.batch_stride;
+    const int64_t q0 = 6 * u * (int64_t)a.hop;    // padded-signal index of the unit's first sample
+    const int64_t start = q0 - a.lo;              // the same in the stored row
+    // ---- the unit's raw samples -> LDS
+    const bool inside = b.fast_ok && a.reflect == 0 && start >= 0 && start + span4 <= a.L;
+    if (inside) {
+      const v4f* p4 = reinterpret_cast<const v4f*>(xr + start) + lane;
+#pragma unroll
+      for (int c = 0; c < 10; ++c)
+        if (256 * c + 4 * lane < span4) *reinterpret_cast<v4f*>(&S[256 * c + 4 * lane]) = p4[64 * c];
+    } else {
+      for (int i = lane; i < span; i += 64) S[i] = fetch_any(xr, a, q0 + i);
+    }
+    wave_lds_fence();
+    // ---- pass A: lane n2 = l20 of transform g: u[20 n1 + n2] = (frame A + i frame B) x window
+    const int64_t pair = 3 * u + g;
+    const bool active = g < 3 && pair < a.pairs_per_row;
+    const int64_t mA = 2 * pair;
+    const bool haveB = active && (mA + 1 < a.M);
+    v2f v[20];
+    {
+      const float* fa = S + (2 * (g < 3 ? g : 0)) * a.hop + l20;
+      const float* fb = fa + a.hop;
+#pragma unroll
+      for (int n1 = 0; n1 < 20; ++n1) {
+        const int n = 20 * n1 + l20;
+        v2f t = v2f{0.f, 0.f};
+        if (active && n < nuse) {
+          const float w = s_w[n];
+          t = v2f{fa[20 * n1] * w, haveB ? fb[20 * n1] * w : 0.0f};  // exact f32 products like the reference (:101)
+        }
+        v[n1] = t;
+      }
+    }
+    dft20(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 20; ++k1) v[k1] = wcmul(v[k1], s_tw[l20 * 20 + k1]);
+    wave_lds_fence();                               // every lane has read its samples: the buffer becomes the exchange
+    if (g < 3) {
+#pragma unroll
+      for (int k1 = 0; k1 < 20; ++k1) buf[g * 420 + k1 * 21 + l20] = v[k1];
+    }
+    wave_lds_fence();
+    // ---- pass B: lane k1 = l20: DFT20 over n2
+    if (g < 3) {
+#pragma unroll
+      for (int n2 = 0; n2 < 20; ++n2) v[n2] = buf[g * 420 + l20 * 21 + n2];
+    }
+    dft20(v);
+    wave_lds_fence();
+    if (g < 3) {
+#pragma unroll
+      for (int k2 = 0; k2 < 20; ++k2) buf[g * KB + l20 + 20 * k2] = v[k2];   // U[k1 + 20 k2] in natural order
+    }
+    wave_lds_fence();
+    // ---- untangle + sink: lane takes bins 2 l20 + 40 j, +1 (only the bins below 200 for the mel / magnitude sinks)
+    constexpr int NJ = SINK == kSinkSpectrum ? 10 : 5;
+    v2f pw[2][NJ];  // MEL: |XA|^2, |XB|^2 of the lane's bin pairs, parked in registers until every lane has read U
+    if (active) {
+      const v2f* U = buf + g * KB;
+      v2f* zA = a.z + ((size_t)row * a.M + mA) * KB;
+      v2f* zB = zA + KB;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int k = 2 * l20 + 40 * j;
+        const v4f uu = *reinterpret_cast<const v4f*>(&U[k]);
+        const v2f p0 = U[k == 0 ? 0 : KB - k], p1 = U[KB - 1 - k];
+        v4f xa = v4f{uu.x + p0.x, uu.y - p0.y, uu.z + p1.x, uu.w - p1.y} * 0.5f;
+        v4f xv = v4f{uu.y + p0.y, p0.x - uu.x, uu.w + p1.y, p1.x - uu.z} * 0.5f;
+        if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
+        if (SINK == kSinkSpectrum) {
+          __builtin_nontemporal_store(xa, (gv4f*)(zA + k));
+          if (haveB) __builtin_nontemporal_store(xv, (gv4f*)(zB + k));
+        } else {
+          const v2f pa = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};
+          const v2f pb = v2f{xv.x * xv.x + xv.y * xv.y, xv.z * xv.z + xv.w * xv.w};
+          if (MEL) { pw[0][j] = pa; pw[1][j] = pb; }
+          else {
+            const v2f va = b.mag_kind == 1 ? pa : v2f{__builtin_sqrtf(pa.x), __builtin_sqrtf(pa.y)};
+            const v2f vb = b.mag_kind == 1 ? pb : v2f{__builtin_sqrtf(pb.x), __builtin_sqrtf(pb.y)};
+            float* o = b.out + ((size_t)row * a.M + mA) * HALF + k;
+            __builtin_nontemporal_store(va, (gv2f*)o);
+            float mx = va.x > va.y ? va.x : va.y;
+            if (haveB) { __builtin_nontemporal_store(vb, (gv2f*)(o + HALF)); mx = vb.x > mx ? vb.x : mx; mx = vb.y > mx ? vb.y : mx; }
+            vmax = mx > vmax ? mx : vmax;
+          }
+        }
+      }
+    }
+    if (MEL) {
+      wave_lds_fence();                          // every partner read of U is done: the buffer becomes the power spectra
+      float* mags = reinterpret_cast<float*>(buf);  // frame f of the unit (f = 2 g + {0, 1}) at mags[f * 200 + k]
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          *reinterpret_cast<v2f*>(&mags[(2 * g) * HALF + 2 * l20 + 40 * j]) = pw[0][j];
+          *reinterpret_cast<v2f*>(&mags[(2 * g + 1) * HALF + 2 * l20 + 40 * j]) = pw[1][j];
+        }
+      }
+      wave_lds_fence();
+      // sparse filterbank + log10 over the unit's (frame, band) items, all 64 lanes
+      const int items = 6 * b.mel_bins;
+      for (int it = lane; it < items; it += 64) {
+        const int f = it / b.mel_bins, mb = it - f * b.mel_bins;
+        const int64_t m = 6 * u + f;
+        if (m >= a.M) continue;
+        const int o0 = s_off[mb], o1 = s_off[mb + 1], k0 = s_lo[mb];
+        float acc = 0.0f;
+        for (int jj = o0; jj < o1; ++jj) acc = fmaf(mags[f * HALF + k0 + (jj - o0)], s_csr[jj], acc);
+        acc = acc > 1.0e-10f ? acc : 1.0e-10f;
+        const float vv = __log2f(acc) * 0.30102999566398120f;
+        b.out[((size_t)row * a.M + m) * b.mel_bins + mb] = vv;
+        vmax = vv > vmax ? vv : vmax;
+      }
+    }
+    wave_lds_fence();  // all reads of the buffer are done before the next unit's samples overwrite it
+  }
+  if (MEL || (MAG && b.mag_kind == 2)) {  // one atomic per wave: running maximum in ordered-int encoding
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(vmax, off); vmax = o > vmax ? o : vmax; }
+    if (lane == 0 && p_begin + wave < p_end) {
+      const int i = __float_as_int(vmax);
+      atomicMax(b.gmax, i >= 0 ? i : i ^ 0x7fffffff);
+    }
+  }
+}
+
+int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel) {
+  *handled = false;
+  constexpr int W = 4, KB = 400, BUF = 1280;
+  if (s.K != KB || s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
+  if (env_int("NXSIG_DISABLE_R20", 0) || env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  const int nuse = s.fr.N < KB ? s.fr.N : KB;
+  if (5 * (int64_t)s.fr.hop + nuse > 2 * BUF) return NXSIG_OK;  // the unit's span must fit the wave's buffer
+  R20Args b;
+  b.mel_bins = 0; b.nnz = 0; b.csr_w = nullptr; b.csr_off = nullptr; b.csr_lo = nullptr; b.out = nullptr; b.gmax = nullptr;
+  b.mag_kind = -1;
+  int sink = kSinkSpectrum;
+  size_t lds_extra = 0;
+  if (mel && mel->mag_kind >= 0) {
+    sink = kSinkMag;
+    b.out = mel->out; b.mag_kind = mel->mag_kind;
+    int rcm = launch_mel_init(c, &b.gmax);
+    if (rcm) return rcm;
+  } else if (mel) {  // CSR of the triangular filter rows restricted to bins < 200
+    sink = kSinkMel;
+    std::vector<float> cw;
+    std::vector<int> off(mel->mel_bins + 1, 0), lo(mel->mel_bins, 0);
+    const int half = KB / 2;
+    for (int mb = 0; mb < mel->mel_bins; ++mb) {
+      const float* fr = mel->filters_host + (size_t)mb * KB;
+      int l = half, h = 0;
+      for (int k = 0; k < half; ++k)
+        if (fr[k] != 0.0f) { if (k < l) l = k; h = k + 1; }
+      if (h <= l) { l = 0; h = 0; }
+      lo[mb] = l;
+      for (int k = l; k < h; ++k) cw.push_back(fr[k]);
+      off[mb + 1] = (int)cw.size();
+    }
+    if (cw.empty()) cw.push_back(0.0f);
+    if (cw.size() > 6144 || mel->mel_bins > 1024) return NXSIG_OK;  // Bluestein / two-step path
+    const void *dw = nullptr, *doff = nullptr, *dlo = nullptr;
+    int rcm;
+    if ((rcm = ctx_table(c, 0xC5A1ull, cw.data(), cw.size() * sizeof(float), &dw))) return rcm;
+    if ((rcm = ctx_table(c, 0xC5A2ull, off.data(), off.size() * sizeof(int), &doff))) return rcm;
+    if ((rcm = ctx_table(c, 0xC5A3ull, lo.data(), lo.size() * sizeof(int), &dlo))) return rcm;
+    b.mel_bins = mel->mel_bins; b.nnz = (int)cw.size();
+    b.csr_w = reinterpret_cast<const float*>(dw); b.csr_off = reinterpret_cast<const int*>(doff); b.csr_lo = reinterpret_cast<const int*>(dlo);
+    b.out = mel->out;
+    if ((rcm = launch_mel_init(c, &b.gmax))) return rcm;
+    lds_extra = (size_t)b.nnz * 4 + (size_t)(2 * mel->mel_bins + 1) * 4;
+  }
+  *handled = true;
+  if (mel) *mel->handled = true;
+  WaveArgs& a = b.w;
+  a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
+  a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
+  a.pairs_per_row = (s.fr.M + 1) / 2;
+  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
+  a.twB = a.twC = a.twR = nullptr; a.dummy = nullptr; a.wtab = s.window_padK;
+  a.units_per_row = 0; a.u_split = 0; a.u_add0 = 0; a.u_add1 = 0;
+  b.units_per_row = (a.pairs_per_row + 2) / 3;
+  b.total_units = b.units_per_row * s.batch;
+  a.total_pairs = b.total_units;
+  b.fast_ok = ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0 && (s.batch_stride & 3) == 0 && (s.fr.lo & 3) == 0 &&
+               ((6 * (int64_t)s.fr.hop) & 3) == 0) ? 1 : 0;
+  std::vector<float2> tw((size_t)KB);
+  for (int n2 = 0; n2 < 20; ++n2)
+    for (int k1 = 0; k1 < 20; ++k1) {
+      const double ang = -6.283185307179586476925286766559 * (double)(n2 * k1) / (double)KB;
+      tw[(size_t)n2 * 20 + k1] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+  const void* dt = nullptr;
+  int rc = ctx_table(c, 0x20A20ull, tw.data(), tw.size() * sizeof(float2), &dt);
+  if (rc) return rc;
+  b.tw = reinterpret_cast<const v2f*>(dt);
+  const int units_per_wave = env_int("NXSIG_R20_UNITS_PER_WAVE", 2);
+  a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
+  const int64_t blocks = (b.total_units + a.chunk - 1) / a.chunk;
+  if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
+  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)W * BUF * 8 + lds_extra;
+  auto go = [&](auto kernel) -> int {
+    if (lds > 64 * 1024)
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, b);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  };
+  if (sink == kSinkMel) rc = s.has_scale ? go(k_stft_r20<true, W, kSinkMel>) : go(k_stft_r20<false, W, kSinkMel>);
+  else if (sink == kSinkMag) rc = s.has_scale ? go(k_stft_r20<true, W, kSinkMag>) : go(k_stft_r20<false, W, kSinkMag>);
+  else rc = s.has_scale ? go(k_stft_r20<true, W, kSinkSpectrum>) : go(k_stft_r20<false, W, kSinkSpectrum>);
+  if (rc) return rc;
+  if (sink == kSinkMel) return launch_mel_finish(c, mel->out, (int64_t)s.batch * s.fr.M * mel->mel_bins, b.gmax);
+  if (sink == kSinkMag && mel->mag_kind == 2) {
+    const int64_t n = (int64_t)s.batch * s.fr.M * (KB / 2);
+    hipLaunchKernelGGL(k_mag_db_pass2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, mel->out, n, b.gmax);
+    NXSIG_HIP_TRY(hipGetLastError());
+  }
+  return NXSIG_OK;
+}
+
+}  // namespace nxsig

@@ -91,23 +91,37 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
   const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
   int64_t p_end = p_begin + a.chunk;
   if (p_end > b.total_units) p_end = b.total_units;
+  // the span of a unit that lies inside the stored row (and is 16-byte aligned) is fetched one unit ahead into registers
+  v4f rs[10];
+  auto prefetch = [&](int64_t ui) -> bool {
+    const int64_t row = ui / b.units_per_row;
+    const int64_t u = ui - row * b.units_per_row;
+    const int64_t start = 6 * u * (int64_t)a.hop - a.lo;
+    const bool inside = b.fast_ok && a.reflect == 0 && start >= 0 && start + span4 <= a.L;
+    if (inside) {
+      const v4f* p4 = reinterpret_cast<const v4f*>(a.x + (size_t)row * a.batch_stride + start) + lane;
+#pragma unroll
+      for (int c = 0; c < 10; ++c)
+        if (256 * c + 4 * lane < span4) rs[c] = p4[64 * c];
+    }
+    return inside;
+  };
+  bool have = (p_begin + wave < p_end) ? prefetch(p_begin + wave) : false;
   for (int64_t ui = p_begin + wave; ui < p_end; ui += W) {
     const int64_t row = ui / b.units_per_row;
     const int64_t u = ui - row * b.units_per_row;
     const float* xr = a.x + (size_t)row * a.batch_stride;
     const int64_t q0 = 6 * u * (int64_t)a.hop;    // padded-signal index of the unit's first sample
-    const int64_t start = q0 - a.lo;              // the same in the stored row
     // ---- the unit's raw samples -> LDS
-    const bool inside = b.fast_ok && a.reflect == 0 && start >= 0 && start + span4 <= a.L;
-    if (inside) {
-      const v4f* p4 = reinterpret_cast<const v4f*>(xr + start) + lane;
+    if (have) {
 #pragma unroll
       for (int c = 0; c < 10; ++c)
-        if (256 * c + 4 * lane < span4) *reinterpret_cast<v4f*>(&S[256 * c + 4 * lane]) = p4[64 * c];
+        if (256 * c + 4 * lane < span4) *reinterpret_cast<v4f*>(&S[256 * c + 4 * lane]) = rs[c];
     } else {
       for (int i = lane; i < span; i += 64) S[i] = fetch_any(xr, a, q0 + i);
     }
     wave_lds_fence();
+    have = (ui + W < p_end) ? prefetch(ui + W) : false;   // next unit's samples travel during this unit's transforms
     // ---- pass A: lane n2 = l20 of transform g: u[20 n1 + n2] = (frame A + i frame B) x window
     const int64_t pair = 3 * u + g;
     const bool active = g < 3 && pair < a.pairs_per_row;
@@ -149,36 +163,48 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
       for (int k2 = 0; k2 < 20; ++k2) buf[g * KB + l20 + 20 * k2] = v[k2];   // U[k1 + 20 k2] in natural order
     }
     wave_lds_fence();
-    // ---- untangle + sink: lane takes bins 2 l20 + 40 j, +1 (only the bins below 200 for the mel / magnitude sinks)
-    constexpr int NJ = SINK == kSinkSpectrum ? 10 : 5;
-    v2f pw[2][NJ];  // MEL: |XA|^2, |XB|^2 of the lane's bin pairs, parked in registers until every lane has read U
-    if (active) {
-      const v2f* U = buf + g * KB;
-      v2f* zA = a.z + ((size_t)row * a.M + mA) * KB;
+    // ---- untangle + sink.  All 64 lanes walk the three transforms one after the other: lane takes the bin pairs
+    //      p = lane + 64 i (bins 2p, 2p + 1), so a wave instruction stores 1 KiB of one frame's row contiguously
+    //      (only the bins below 200 for the mel / magnitude sinks)
+    constexpr int NP = SINK == kSinkSpectrum ? 200 : 100;    // bin pairs per frame that reach the sink
+    constexpr int NI = (NP + 63) / 64;
+    v2f pw[3][2][NI];  // MEL: |XA|^2, |XB|^2 of the lane's bin pairs, parked in registers until every lane has read U
+#pragma unroll
+    for (int gg = 0; gg < 3; ++gg) {
+      const int64_t pr = 3 * u + gg;
+      const bool act = pr < a.pairs_per_row;                 // wave-uniform
+      const int64_t m0 = 2 * pr;
+      const bool hb = act && (m0 + 1 < a.M);
+      const v2f* U = buf + gg * KB;
+      v2f* zA = a.z + ((size_t)row * a.M + m0) * KB;
       v2f* zB = zA + KB;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int k = 2 * l20 + 40 * j;
-        const v4f uu = *reinterpret_cast<const v4f*>(&U[k]);
-        const v2f p0 = U[k == 0 ? 0 : KB - k], p1 = U[KB - 1 - k];
-        v4f xa = v4f{uu.x + p0.x, uu.y - p0.y, uu.z + p1.x, uu.w - p1.y} * 0.5f;
-        v4f xv = v4f{uu.y + p0.y, p0.x - uu.x, uu.w + p1.y, p1.x - uu.z} * 0.5f;
-        if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
-        if (SINK == kSinkSpectrum) {
-          __builtin_nontemporal_store(xa, (gv4f*)(zA + k));
-          if (haveB) __builtin_nontemporal_store(xv, (gv4f*)(zB + k));
-        } else {
-          const v2f pa = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};
-          const v2f pb = v2f{xv.x * xv.x + xv.y * xv.y, xv.z * xv.z + xv.w * xv.w};
-          if (MEL) { pw[0][j] = pa; pw[1][j] = pb; }
-          else {
-            const v2f va = b.mag_kind == 1 ? pa : v2f{__builtin_sqrtf(pa.x), __builtin_sqrtf(pa.y)};
-            const v2f vb = b.mag_kind == 1 ? pb : v2f{__builtin_sqrtf(pb.x), __builtin_sqrtf(pb.y)};
-            float* o = b.out + ((size_t)row * a.M + mA) * HALF + k;
-            __builtin_nontemporal_store(va, (gv2f*)o);
-            float mx = va.x > va.y ? va.x : va.y;
-            if (haveB) { __builtin_nontemporal_store(vb, (gv2f*)(o + HALF)); mx = vb.x > mx ? vb.x : mx; mx = vb.y > mx ? vb.y : mx; }
-            vmax = mx > vmax ? mx : vmax;
+      for (int i = 0; i < NI; ++i) {
+        const int pi = lane + 64 * i;
+        if (MEL) { pw[gg][0][i] = v2f{0.f, 0.f}; pw[gg][1][i] = v2f{0.f, 0.f}; }
+        if (act && pi < NP) {
+          const int k = 2 * pi;
+          const v4f uu = *reinterpret_cast<const v4f*>(&U[k]);
+          const v2f p0 = U[k == 0 ? 0 : KB - k], p1 = U[KB - 1 - k];
+          v4f xa = v4f{uu.x + p0.x, uu.y - p0.y, uu.z + p1.x, uu.w - p1.y} * 0.5f;
+          v4f xv = v4f{uu.y + p0.y, p0.x - uu.x, uu.w + p1.y, p1.x - uu.z} * 0.5f;
+          if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
+          if (SINK == kSinkSpectrum) {
+            __builtin_nontemporal_store(xa, (gv4f*)(zA + k));
+            if (hb) __builtin_nontemporal_store(xv, (gv4f*)(zB + k));
+          } else {
+            const v2f pa = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};
+            const v2f pb = v2f{xv.x * xv.x + xv.y * xv.y, xv.z * xv.z + xv.w * xv.w};
+            if (MEL) { pw[gg][0][i] = pa; pw[gg][1][i] = pb; }
+            else {
+              const v2f va = b.mag_kind == 1 ? pa : v2f{__builtin_sqrtf(pa.x), __builtin_sqrtf(pa.y)};
+              const v2f vb = b.mag_kind == 1 ? pb : v2f{__builtin_sqrtf(pb.x), __builtin_sqrtf(pb.y)};
+              float* o = b.out + ((size_t)row * a.M + m0) * HALF + k;
+              __builtin_nontemporal_store(va, (gv2f*)o);
+              float mx = va.x > va.y ? va.x : va.y;
+              if (hb) { __builtin_nontemporal_store(vb, (gv2f*)(o + HALF)); mx = vb.x > mx ? vb.x : mx; mx = vb.y > mx ? vb.y : mx; }
+              vmax = mx > vmax ? mx : vmax;
+            }
           }
         }
       }
@@ -186,13 +212,16 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
     if (MEL) {
       wave_lds_fence();                          // every partner read of U is done: the buffer becomes the power spectra
       float* mags = reinterpret_cast<float*>(buf);  // frame f of the unit (f = 2 g + {0, 1}) at mags[f * 200 + k]
-      if (active) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          *reinterpret_cast<v2f*>(&mags[(2 * g) * HALF + 2 * l20 + 40 * j]) = pw[0][j];
-          *reinterpret_cast<v2f*>(&mags[(2 * g + 1) * HALF + 2 * l20 + 40 * j]) = pw[1][j];
+      for (int gg = 0; gg < 3; ++gg)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int pi = lane + 64 * i;
+          if (pi < NP) {
+            *reinterpret_cast<v2f*>(&mags[(2 * gg) * HALF + 2 * pi]) = pw[gg][0][i];
+            *reinterpret_cast<v2f*>(&mags[(2 * gg + 1) * HALF + 2 * pi]) = pw[gg][1][i];
+          }
         }
-      }
       wave_lds_fence();
       // sparse filterbank + log10 over the unit's (frame, band) items, all 64 lanes
       const int items = 6 * b.mel_bins;

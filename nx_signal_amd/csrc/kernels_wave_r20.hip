@@ -223,19 +223,24 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
           }
         }
       wave_lds_fence();
-      // sparse filterbank + log10 over the unit's (frame, band) items, all 64 lanes
-      const int items = 6 * b.mel_bins;
-      for (int it = lane; it < items; it += 64) {
-        const int f = it / b.mel_bins, mb = it - f * b.mel_bins;
-        const int64_t m = 6 * u + f;
-        if (m >= a.M) continue;
+      // sparse filterbank + log10: one band per lane, the unit's six frames share every weight (six independent sums)
+      for (int mb = lane; mb < b.mel_bins; mb += 64) {
         const int o0 = s_off[mb], o1 = s_off[mb + 1], k0 = s_lo[mb];
-        float acc = 0.0f;
-        for (int jj = o0; jj < o1; ++jj) acc = fmaf(mags[f * HALF + k0 + (jj - o0)], s_csr[jj], acc);
-        acc = acc > 1.0e-10f ? acc : 1.0e-10f;
-        const float vv = __log2f(acc) * 0.30102999566398120f;
-        b.out[((size_t)row * a.M + m) * b.mel_bins + mb] = vv;
-        vmax = vv > vmax ? vv : vmax;
+        float acc[6];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) acc[f] = 0.0f;
+        for (int jj = o0; jj < o1; ++jj) {
+          const float wv = s_csr[jj];
+#pragma unroll
+          for (int f = 0; f < 6; ++f) acc[f] = fmaf(mags[f * HALF + k0 + (jj - o0)], wv, acc[f]);
+        }
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+          const int64_t m = 6 * u + f;
+          const float av = acc[f] > 1.0e-10f ? acc[f] : 1.0e-10f;
+          const float vv = __log2f(av) * 0.30102999566398120f;
+          if (m < a.M) { b.out[((size_t)row * a.M + m) * b.mel_bins + mb] = vv; vmax = vv > vmax ? vv : vmax; }
+        }
       }
     }
     wave_lds_fence();  // all reads of the buffer are done before the next unit's samples overwrite it
@@ -319,7 +324,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   int rc = ctx_table(c, 0x20A20ull, tw.data(), tw.size() * sizeof(float2), &dt);
   if (rc) return rc;
   b.tw = reinterpret_cast<const v2f*>(dt);
-  const int units_per_wave = env_int("NXSIG_R20_UNITS_PER_WAVE", 2);
+  const int units_per_wave = env_int("NXSIG_R20_UNITS_PER_WAVE", sink == kSinkMel ? 8 : 2);  // the mel sink amortises its CSR preload
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   const int64_t blocks = (b.total_units + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");

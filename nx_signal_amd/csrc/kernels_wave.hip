@@ -786,6 +786,8 @@ static int launch_istft_wave_quad(Ctx* c, const IstftLaunch& s, const float* win
   return s.has_scale ? go(k_istft_wave_quad<K, J, R, true, W>) : go(k_istft_wave_quad<K, J, R, false, W>);
 }
 
+int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);  // kernels_wave_r20.hip
+
 int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   *handled = false;
   if (s.M == 0 || s.batch == 0) return NXSIG_OK;
@@ -803,6 +805,10 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
       case 4: return launch_istft_wave_R<4, 4, true>(c, s, s.window, window_host);
       default: return launch_istft_wave_R<8, 4, true>(c, s, s.window, window_host);
     }
+  }
+  if (s.K == 400 && s.N == 400) {  // native 20 x 20 inverse (kernels_wave_r20.hip); declines odd hops / short inputs
+    int rc20 = launch_istft_r20(c, s, window_host, handled);
+    if (rc20 || *handled) return rc20;
   }
   if ((s.K == 256 && s.N == 256) || (s.K == 128 && s.N == 128)) {  // 4 / 8 frames per 1024-point inverse FFT
     const int R = s.N / s.hop;

@@ -146,6 +146,24 @@ def test_istft_wave_quad_n256_n128(N, hop, M):
         assert nerr(y, yo) < 1e-5, (N, hop, M, scaling, nerr(y, yo))
 
 
+@pytest.mark.parametrize("hop", [160, 100, 200, 400, 50, 80, 2, 398, 133])
+@pytest.mark.parametrize("M", [3, 16, 17, 66, 301])
+def test_istft_r20_n400(hop, M):
+    """N = 400 natively (20 x 20 inverse transform, three frames per wave iteration, gathered overlap-add): hops that do
+    and do not divide the frame length, unit / run seams, frame counts below 2R-1 and an odd hop (generic path)"""
+    N = 400
+    if hop <= 4 and M > 66:
+        pytest.skip("tiny hop: covered at smaller M")
+    rng = np.random.default_rng(hop * 11 + M)
+    z = (rng.standard_normal((2, M, N)) + 1j * rng.standard_normal((2, M, N))).astype(np.complex64)
+    w = S.windows.hann(N)
+    for scaling in (None, "spectrum"):
+        y = S.istft(z, w, overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=16000)
+        yo = O.istft(z, w, overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=16000)
+        assert y.shape == yo.shape
+        assert nerr(y, yo) < 1e-5, (hop, M, scaling, nerr(y, yo))
+
+
 def test_istft_rectangular_window_no_edge_fix_needed():
     N, hop, M = 1024, 256, 40
     rng = np.random.default_rng(3)

@@ -168,3 +168,21 @@ def test_fuzz_fused_sinks(seed):
         ref = O.stft_to_mel(zo.reshape(-1, K), fs, K, mel_bins=mb).reshape(zo.shape[:-1] + (mb,))
         assert got.shape == ref.shape
         assert np.max(np.abs(got - ref)) < 1e-4, (K, N, hop, pad, mb, float(np.max(np.abs(got - ref))))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_istft_n400(seed):
+    """N = 400 iSTFT: random hops (even: native 20 x 20 kernel; odd: generic path), frame counts, rows, scalings, windows"""
+    rng = np.random.default_rng(7000 + seed)
+    N = 400
+    hop = int(rng.choice([160, 100, 80, 200, int(rng.integers(1, N + 1)), 2 * int(rng.integers(1, N // 2 + 1))]))
+    M = int(rng.integers(1, 400))
+    bshape = [(), (2,), (3,)][rng.integers(3)]
+    scaling = [None, "spectrum", "psd"][rng.integers(3)]
+    z = (rng.standard_normal(bshape + (M, N)) + 1j * rng.standard_normal(bshape + (M, N))).astype(np.complex64)
+    w = make_window(rng, N)
+    opts = dict(overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=16000)
+    y = S.istft(z, w, **opts)
+    yo = O.istft(z, w, **opts)
+    assert y.shape == yo.shape
+    assert nerr(y, yo) < 1e-5, (hop, M, bshape, scaling, nerr(y, yo))

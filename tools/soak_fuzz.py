@@ -12,7 +12,7 @@ import test_gpu_fuzz as F  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
-    fams = [F.test_fuzz_stft, F.test_fuzz_istft, F.test_fuzz_fir, F.test_fuzz_stft_long_rows_interior_edge_split, F.test_fuzz_fused_sinks]
+    fams = [F.test_fuzz_stft, F.test_fuzz_istft, F.test_fuzz_fir, F.test_fuzz_stft_long_rows_interior_edge_split, F.test_fuzz_fused_sinks, F.test_fuzz_istft_n400]
     bad = 0
     t0 = time.time()
     for i in range(n):

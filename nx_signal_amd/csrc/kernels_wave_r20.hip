@@ -20,7 +20,7 @@ struct R20Args {
   const v2f* tw;           // c64[20][20]: W_400^(n2 k1) at [n2 * 20 + k1]
   int64_t units_per_row;   // ceil(pairs_per_row / 3): a unit = three frame pairs = six frames
   int64_t total_units;
-  int32_t fast_ok;         // base pointer, row stride and padding offset allow 16-byte loads
+  int32_t fast_ok;         // prefetch aligned, in-bounds spans with 16-byte loads one unit ahead
   // sinks other than the complex spectrum (same fields as MelWaveArgs)
   int32_t mel_bins, nnz;
   const float* csr_w;
@@ -97,9 +97,10 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
     const int64_t row = ui / b.units_per_row;
     const int64_t u = ui - row * b.units_per_row;
     const int64_t start = 6 * u * (int64_t)a.hop - a.lo;
-    const bool inside = b.fast_ok && a.reflect == 0 && start >= 0 && start + span4 <= a.L;
+    const float* p = a.x + (size_t)row * a.batch_stride + start;
+    const bool inside = b.fast_ok && a.reflect == 0 && start >= 0 && start + span4 <= a.L && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
     if (inside) {
-      const v4f* p4 = reinterpret_cast<const v4f*>(a.x + (size_t)row * a.batch_stride + start) + lane;
+      const v4f* p4 = reinterpret_cast<const v4f*>(p) + lane;
 #pragma unroll
       for (int c = 0; c < 10; ++c)
         if (256 * c + 4 * lane < span4) rs[c] = p4[64 * c];
@@ -118,7 +119,12 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
       for (int c = 0; c < 10; ++c)
         if (256 * c + 4 * lane < span4) *reinterpret_cast<v4f*>(&S[256 * c + 4 * lane]) = rs[c];
     } else {
-      for (int i = lane; i < span; i += 64) S[i] = fetch_any(xr, a, q0 + i);
+      const int64_t start = q0 - a.lo;
+      if (a.reflect == 0 && start >= 0 && start + span <= a.L) {   // inside the row but not 16-byte aligned: 4-byte loads
+        for (int i = lane; i < span; i += 64) S[i] = xr[start + i];
+      } else {                                                      // padding / mirror / row end: per-sample bounds
+        for (int i = lane; i < span; i += 64) S[i] = fetch_any(xr, a, q0 + i);
+      }
     }
     wave_lds_fence();
     have = (ui + W < p_end) ? prefetch(ui + W) : false;   // next unit's samples travel during this unit's transforms
@@ -312,8 +318,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   b.units_per_row = (a.pairs_per_row + 2) / 3;
   b.total_units = b.units_per_row * s.batch;
   a.total_pairs = b.total_units;
-  b.fast_ok = ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0 && (s.batch_stride & 3) == 0 && (s.fr.lo & 3) == 0 &&
-               ((6 * (int64_t)s.fr.hop) & 3) == 0) ? 1 : 0;
+  b.fast_ok = env_int("NXSIG_R20_NO_PREFETCH", 0) ? 0 : 1;  // 16-byte register prefetch of aligned spans (measured: 5.35 vs 4.1-4.9 TB/s for loads at the point of use)
   std::vector<float2> tw((size_t)KB);
   for (int n2 = 0; n2 < 20; ++n2)
     for (int k1 = 0; k1 < 20; ++k1) {

@@ -1072,8 +1072,11 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
   if (env_int("NXSIG_WAVE_NO_SPLIT", 0) && !(u_lo == 0 && u_hi == a.pairs_per_row)) u_hi = u_lo = 0;
   const bool scale = s.has_scale != 0;
   const bool npred = s.fr.N < KOUT;
+  const int64_t chunk_main = a.chunk;
   auto go = [&](auto kernel, int64_t upr, int64_t split, int64_t add0, int64_t add1) -> int {
     if (upr == 0) return NXSIG_OK;
+    // the edge launch has few, slow (bounds-checked) units: one per wave, so that they all run concurrently
+    a.chunk = (split < ((int64_t)1 << 61)) ? W : chunk_main;
     a.units_per_row = upr; a.u_split = split; a.u_add0 = add0; a.u_add1 = add1;
     a.total_pairs = upr * s.batch;
     const int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;

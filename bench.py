@@ -13,6 +13,16 @@ numbers.  The single-stream figure (config 2 exactly as written) is reported bes
 Inputs and outputs are device-resident (HBM) when the timed region starts; N GPUs each process their own
 batch (weak scaling, no data-path collective — frames are independent).
 
+No torch: under a launcher (RANK / WORLD_SIZE / LOCAL_RANK in the environment, e.g. torch.distributed.run) every
+rank joins an RCCL communicator created by libnxsig.so itself (nxsig_group_create_rank: ncclCommInitRank, the unique id
+travels through a file on the node); barrier, max-over-ranks and the optional assembly all-gather go through the C ABI.
+
+Clock pre-conditioning: a GPU that has been idle starts a run of launches at boost clocks, overshoots its power budget
+about 5 launches in and takes ~20 launches to settle (round-1 trace: 576 -> 725 -> 571 us).  Before the W warm-up steps
+the bench therefore launches the same step until 10 consecutive launches lie within 3 % of the running minimum (at most
+300 launches / ~0.2 s), untimed, so that a short timed window (--steps 20) measures the steady state.  The per-launch
+distribution of the TIMED steps (min / median / p90 / max) is printed so that a transient stays visible.
+
 Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch
 (hop*4 + K*8 = 9216 B/frame x frames) / mean kernel time measured with HIP events on the library's stream.
 `cpu_baseline` = the oracle's C restatement of the BinaryBackend path (oracle/bb_baseline.c) timed on this
@@ -62,9 +72,14 @@ def cpu_baseline(max_seconds: float):
     t0 = time.perf_counter()
     bb_baseline.stft(seg, w, HOP, N_FFT, threads=1)
     dt1 = time.perf_counter() - t0
+    # all-cores leg: >= 5 s of wall on every host core (OpenMP over frames, persistent per-thread scratch), sized from the
+    # 1-thread rate; a first short call brings the thread pool up and pre-faults the result buffer, untimed
     cores = os.cpu_count() or 1
+    zbuf = np.zeros((M, N_FFT), np.complex64)
+    bb_baseline.stft_repeat(x, w, HOP, N_FFT, 1, cores, out=zbuf)
+    reps = max(1, int(np.ceil(min(max_seconds * 0.3, 6.0) * cores * (frames / dt1) / M)))
     t0 = time.perf_counter()
-    bb_baseline.stft(seg, w, HOP, N_FFT, threads=cores)
+    done, _ = bb_baseline.stft_repeat(x, w, HOP, N_FFT, reps, cores, out=zbuf)
     dtn = time.perf_counter() - t0
     return {
         "value": frames / dt1,
@@ -74,7 +89,8 @@ def cpu_baseline(max_seconds: float):
         "sample": f"first {frames} frames of one 60 s mono 48 kHz stream (N=1024 hop=256 Hann), oracle/bb_baseline.c "
                   f"recursive radix-2 in f64, 1 thread; Nx.BinaryBackend itself cannot run here (no BEAM: "
                   f"elixir={'found' if _which('elixir') else 'not found'})",
-        "all_cores": {"value": frames / dtn, "cores": cores},
+        "all_cores": {"value": done / dtn, "cores": cores, "seconds": dtn,
+                      "sample": f"{reps} passes over the 60 s stream ({done} frames), OpenMP static over frames"},
     }
 
 
@@ -92,6 +108,8 @@ def main():
     ap.add_argument("--streams", type=int, default=32, help="independent 60 s streams per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--precondition", type=int, default=300,
+                    help="max untimed launches spent settling the clocks before the warm-up steps (0 = none)")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  RCCL prints a banner ("Hostname : ...", "Librccl path : ...") to the
@@ -106,20 +124,14 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
 
-    dist = None
-    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:  # launched by torch.distributed.run (any world size)
-        import torch
-        import torch.distributed as dist_mod
-
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)  # nccl == RCCL over xGMI
-        dist = dist_mod
-
     import nx_signal_amd as S
-    from nx_signal_amd import _lib
+    from nx_signal_amd import _lib, sharding
     import ctypes as C
 
-    ctx = S.Context(local_rank)
+    group = None
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:  # under a launcher (any world size): RCCL through the C ABI
+        group = sharding.Group.ranked(world, rank, local_rank)
+    ctx = group.contexts[0] if group is not None else S.Context(local_rank)
     lib = _lib.load()
     w = S.windows.hann(N_FFT)
     B = args.streams
@@ -139,29 +151,42 @@ def main():
         _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
 
     def barrier():
-        ctx.sync()
-        if dist is not None:
-            import torch
+        if group is not None:
+            group.barrier()  # waits for the stream, all-reduces one word over RCCL, waits again
+        else:
+            ctx.sync()
 
-            torch.cuda.synchronize()
-            dist.barrier(device_ids=[local_rank])
+    # ---- clock pre-conditioning (untimed, see the module docstring)
+    precondition = {"launches": 0, "settled": False}
+    if args.precondition > 0:
+        hist = []
+        while len(hist) < args.precondition:
+            ctx.timer_lap()
+            for _ in range(10):
+                step()
+                ctx.timer_lap()
+            hist += ctx.timer_laps()
+            lo = min(hist)
+            if len(hist) >= 30 and max(hist[-10:]) <= 1.03 * lo:
+                precondition["settled"] = True
+                break
+        precondition.update(launches=len(hist), first10_us=[round(v * 1e3, 1) for v in hist[:10]],
+                            last10_us=[round(v * 1e3, 1) for v in hist[-10:]], min_us=round(min(hist) * 1e3, 1))
 
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    ctx.timer_start()
+    ctx.timer_lap()
     for _ in range(args.steps):
         step()
-    kernel_ms_total = ctx.timer_stop()  # HIP events on the stream the kernels run on (synchronises)
+        ctx.timer_lap()
+    laps = ctx.timer_laps()  # HIP events on the stream the kernels run on, one interval per step (synchronises)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed, kernel_ms_total], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_total = float(t[0]), float(t[1])
+    kernel_ms_total = float(sum(laps))
+    if group is not None:
+        elapsed, kernel_ms_total = group.allreduce([elapsed, kernel_ms_total], "max")
 
     frames_per_step = B * M * world
     ms_per_step = elapsed * 1e3 / args.steps
@@ -188,30 +213,30 @@ def main():
     # optional final assembly, timed SEPARATELY from frames/s: RCCL all-gather of one 60 s stream's
     # spectrum per rank (92 MB each).  Outputs otherwise stay sharded and device-resident.
     assembly = None
-    if dist is not None:
+    if group is not None:
         try:  # the optional assembly must never take the measurement down with it
-            import torch
-
-            zt = torch.empty((M, N_FFT), dtype=torch.complex64, device="cuda")
-            _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, 1, L, wp, C.byref(p), C.c_void_p(zt.data_ptr()), None, _lib.DEVICE))
-            ctx.sync()
-            gathered = torch.empty((world, M, N_FFT), dtype=torch.complex64, device="cuda")
-            zr, gr = torch.view_as_real(zt), torch.view_as_real(gathered)
+            zt = ctx.empty((world, M, N_FFT), np.complex64)  # full-size buffer: the own shard is computed in place
+            own = zt.ptr + rank * M * N_FFT * 8
+            _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, 1, L, wp, C.byref(p), C.c_void_p(own), None, _lib.DEVICE))
+            counts = [M * N_FFT * 8] * world
             for _ in range(2):
-                dist.all_gather_into_tensor(gr, zr)
-            torch.cuda.synchronize()
-            dist.barrier(device_ids=[local_rank])
+                group.allgather([own], counts, [zt.ptr])
+            group.barrier()
             tg = time.perf_counter()
             reps_g = 5
             for _ in range(reps_g):
-                dist.all_gather_into_tensor(gr, zr)
-            torch.cuda.synchronize()
+                group.allgather([own], counts, [zt.ptr])
+            ctx.sync()
             tg = (time.perf_counter() - tg) / reps_g
-            ok = bool(torch.equal(gathered[rank], zt))
-            assembly = {"collective": "all_gather_into_tensor (RCCL)", "bytes_per_rank": int(zt.numel() * 8),
-                        "ms": tg * 1e3, "recv_GBps_per_rank": (world - 1) * zt.numel() * 8 / tg / 1e9 if world > 1 else 0.0,
-                        "own_shard_intact": ok}
-            del gathered, zt
+            chk = np.empty((64, N_FFT), np.complex64)
+            ref = np.empty((64, N_FFT), np.complex64)
+            _lib.check(lib.nxsig_download(ctx.handle, chk.ctypes.data_as(C.c_void_p), C.c_void_p(own), chk.nbytes))
+            _lib.check(lib.nxsig_download(ctx.handle, ref.ctypes.data_as(C.c_void_p), C.c_void_p(zd.ptr), ref.nbytes))
+            assembly = {"collective": "nxsig_group_allgather (RCCL ncclAllGather through the C ABI, in place)",
+                        "bytes_per_rank": int(M * N_FFT * 8), "ms": tg * 1e3,
+                        "recv_GBps_per_rank": (world - 1) * M * N_FFT * 8 / tg / 1e9 if world > 1 else 0.0,
+                        "own_shard_intact": bool(np.array_equal(chk.view(np.uint32), ref.view(np.uint32)))}
+            zt.free()
         except Exception as e:  # noqa: BLE001
             assembly = {"error": repr(e)[:200]}
 
@@ -256,7 +281,11 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel_ms": kernel_ms, "bytes_per_frame": BYTES_PER_FRAME, "frac_of_measured_copy_6290": achieved / 6290.0,
+                "kernel_us": {"min": round(min(laps) * 1e3, 1), "median": round(float(np.median(laps)) * 1e3, 1),
+                              "p90": round(float(np.percentile(laps, 90)) * 1e3, 1), "max": round(max(laps) * 1e3, 1)},
             },
+            "precondition": precondition,
+            "comm": None if group is None else {"backend": "RCCL via libnxsig.so (ncclCommInitRank)", "world": world, "torch": False},
             "single_stream": single,
             "assembly": assembly,
             "max_norm_err_vs_oracle": verify,
@@ -268,9 +297,9 @@ def main():
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)  # whatever the teardown prints must not follow the JSON line
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    if group is not None:
+        group.barrier()
+        group.close()
 
 
 if __name__ == "__main__":

@@ -181,6 +181,11 @@ int nxsig_fft(nxsig_ctx* ctx, const void* in, int32_t in_is_real, int64_t rows, 
 int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
                   int32_t num_taps, int32_t mode, float* y, int32_t mem);
 
+/* Any slice [out_start, out_start + out_len) of the FULL convolution of every row with h (the modes of nxsig_fir_f32 are
+ * three such slices; sharded filtering asks for the slice a rank owns): y f32[batch][out_len]. */
+int nxsig_fir_slice_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
+                        int32_t num_taps, int64_t out_start, int64_t out_len, float* y, int32_t mem);
+
 /*
  * NxSignal.mel_filters/4 — lib/nx_signal.ex:397-445 (Slaney-style filterbank, host-side with BinaryBackend rounding):
  * out f32[mel_bins][fft_length].  Defaults of the reference: max_mel 3016, mel_frequency_spacing 200/3.
@@ -238,6 +243,96 @@ int nxsig_spectrum_mul_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int
  */
 int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const nxsig_c64* b, int64_t n2, int32_t mode,
                           nxsig_c64* out, int32_t mem);
+
+/* ============================================================== multi-GPU groups ====
+ * The path shards with NO data-path exchange: channels (the reference's vectorized axes,
+ * lib/nx_signal.ex:358-363) are independent and frames are independent given their samples, so rank r owns a
+ * contiguous block of channels, or a contiguous frame range of one long stream plus an (N - hop)-sample input halo it
+ * reads redundantly.  The only collective is the OPTIONAL final assembly: an RCCL all-gather over xGMI of the output
+ * shards.  A group is either
+ *   - LOCAL: one process drives every GPU of the node (the Elixir / dirty-NIF host): one nxsig_ctx + stream per device,
+ *     communicators from ncclCommInitAll, collectives fused with ncclGroupStart / ncclGroupEnd; or
+ *   - RANKED: one process per GPU (bench.py under a process launcher): ncclCommInitRank, the 128-byte ncclUniqueId
+ *     travelling from rank 0 through a file on the node (nxsig_rendezvous_*).
+ * librccl is dlopen()ed when the first group is created; a process that never creates a group never loads it.
+ * Members that share one device (testing / replicas on a single GPU) get no communicator: their assembly runs as
+ * device-to-device copies (LOCAL groups only).
+ */
+typedef struct nxsig_group nxsig_group;
+
+typedef enum nxsig_shard_axis {
+  NXSIG_SHARD_CHANNELS = 0, /* batch rows split into contiguous blocks (BASELINE configs 4 / 5) */
+  NXSIG_SHARD_FRAMES = 1    /* frame ranges of each row, input halo read redundantly (one long stream) */
+} nxsig_shard_axis;
+
+/* contiguous near-equal split of range(total): the first total % parts members get one extra item (pure) */
+int nxsig_shard_range(int64_t total, int32_t parts, int32_t index, int64_t* begin, int64_t* end);
+/* frame range [m0, m1) of member `index` of a :valid-framed stream of `num_frames` frames and the sample span
+ * [s0, s1) it reads: s0 = m0 * hop, s1 = (m1 - 1) * hop + frame_length (pure) */
+int nxsig_shard_frames(int64_t num_frames, int32_t frame_length, int32_t hop, int32_t parts, int32_t index, int64_t* m0,
+                       int64_t* m1, int64_t* s0, int64_t* s1);
+/* output range [n0, n1) of member `index` of a FIR whose full-convolution slice starts at `out_start` (mode offset) and
+ * the input span [s0, s1), clamped to [0, length), it reads: num_taps - 1 samples of halo (pure) */
+int nxsig_shard_fir(int64_t length, int32_t num_taps, int32_t mode, int32_t parts, int32_t index, int64_t* n0, int64_t* n1,
+                    int64_t* s0, int64_t* s1);
+
+/* file rendezvous on one node (pure host code): publish writes `bytes` bytes atomically (tmp file + rename), fetch polls
+ * until the file exists, is complete and is younger than `max_age_s` seconds (stale files of earlier runs are ignored) */
+int nxsig_rendezvous_publish(const char* path, const void* data, size_t bytes);
+int nxsig_rendezvous_fetch(const char* path, void* data, size_t bytes, int32_t timeout_ms, int32_t max_age_s);
+
+/* LOCAL group over `n` devices of this process (device_ids NULL = 0 .. n-1) */
+int nxsig_group_create_local(int32_t n, const int32_t* device_ids, nxsig_group** out);
+/* RANKED group: this process is rank `rank` of `world` and drives `device`.  Rank 0 creates the ncclUniqueId and
+ * publishes it at `rendezvous_path`, the other ranks fetch it there (timeout_ms); world == 1 needs no path. */
+int nxsig_group_create_rank(int32_t world, int32_t rank, int32_t device, const char* rendezvous_path, int32_t timeout_ms,
+                            nxsig_group** out);
+void nxsig_group_destroy(nxsig_group* g);
+int32_t nxsig_group_world(const nxsig_group* g);        /* ranks in the group */
+int32_t nxsig_group_local_count(const nxsig_group* g);  /* members driven by this process */
+int32_t nxsig_group_rank(const nxsig_group* g, int32_t local_index);   /* global rank of a local member */
+nxsig_ctx* nxsig_group_ctx(nxsig_group* g, int32_t local_index);       /* its context (owned by the group) */
+int32_t nxsig_group_has_rccl(const nxsig_group* g);     /* 1 when the members hold RCCL communicators */
+/* waits for every local stream, then (RCCL) all-reduces one word across the group and waits again */
+int nxsig_group_barrier(nxsig_group* g);
+/* element-wise reduction of `n` (<= 64) host doubles over the PROCESSES of the group; op 0 = max, 1 = sum */
+int nxsig_group_allreduce_f64(nxsig_group* g, double* values, int32_t n, int32_t op);
+/*
+ * Final assembly of sharded device buffers: member r contributes `counts[r]` bytes (counts has nxsig_group_world
+ * entries and is the same on every member).  For each local member i: send[i] = its shard (device), recv[i] = a device
+ * buffer of sum(counts) bytes receiving the shards in rank order; send[i] may point into recv[i] at its own offset (in
+ * place).  RCCL: one ncclBroadcast per rank inside ncclGroupStart / End (ncclAllGather when all counts are equal), on the
+ * members' streams; asynchronous.  Members sharing a device: device-to-device copies.
+ */
+int nxsig_group_allgather(nxsig_group* g, const void* const* send, const int64_t* counts, void* const* recv);
+
+/*
+ * NxSignal.stft/3 sharded over the group (window_padding must be :valid — padding belongs to the stream ends).
+ *   mem == NXSIG_HOST  : x[0] is the whole host tensor f32[batch][length], z[0] the whole host result c64[batch][M][K];
+ *                        every local member uploads its part, computes it, and the result is assembled either by per-shard
+ *                        downloads (gather == 0) or by the RCCL all-gather followed by one download (gather == 1).
+ *                        LOCAL groups only.
+ *   mem == NXSIG_DEVICE: x[i] is local member i's INPUT SHARD on its own device — rows [c0, c1) of the tensor
+ *                        (channels axis: f32[c1 - c0][length], rows batch_stride apart) or the sample span [s0, s1) of
+ *                        every row (frames axis: f32[batch][s1 - s0], rows batch_stride apart).  gather == 0: z[i] receives
+ *                        the member's output shard (c64[c1 - c0][M][K] / c64[batch][m1 - m0][K]) and stays on its device.
+ *                        gather == 1: z[i] is a full c64[batch][M][K] buffer on every member's device; shards are
+ *                        computed in place and all-gathered (frames axis: batch must be 1).  Asynchronous.
+ * `length`, `batch` always describe the WHOLE tensor; ranges come from nxsig_shard_range / nxsig_shard_frames.
+ */
+int nxsig_stft_sharded_f32(nxsig_group* g, const float* const* x, int64_t length, int32_t batch, int64_t batch_stride,
+                           const float* window, const nxsig_stft_params* params, int32_t axis, int32_t gather,
+                           nxsig_c64* const* z, int32_t mem);
+/* FIR filtering (nxsig_fir_f32) sharded over the group; same conventions.  Channels axis: rows split.  Frames axis here
+ * means OUTPUT SAMPLE ranges of every row with a (num_taps - 1)-sample input halo (nxsig_shard_fir). */
+int nxsig_fir_sharded_f32(nxsig_group* g, const float* const* x, int64_t length, int32_t batch, int64_t batch_stride,
+                          const float* h, int32_t num_taps, int32_t mode, int32_t axis, int32_t gather, float* const* y,
+                          int32_t mem);
+
+/* per-launch stopwatch on the ctx stream: lap() records an event (at most 4096 per series), laps() synchronises and
+ * returns the n - 1 intervals in milliseconds and clears the series */
+int nxsig_timer_lap(nxsig_ctx* ctx);
+int nxsig_timer_laps(nxsig_ctx* ctx, float* intervals_ms, int32_t capacity, int32_t* count);
 
 #ifdef __cplusplus
 }

@@ -160,12 +160,8 @@ def as_windowed(tensor, ctx: Context | None = None, **opts):
     return out
 
 
-def stft(data, window, ctx: Context | None = None, **opts):
-    """NxSignal.stft/3 — lib/nx_signal.ex:68-130.  Returns (z c64[..., M, K], times f32[M], frequencies f32[K]).
-
-    Defaults follow the code, not the doc (SURVEY B1-B3): window_padding "valid", sampling_rate 100,
-    fft_length "power_of_two", overlap_length div(N, 2); the :window key is accepted and ignored.
-    """
+def _resolve_stft_opts(window, opts):
+    """option parsing / defaults of NxSignal.stft/3 (lib/nx_signal.ex:71-85) -> (StftParams, N, hop, K)"""
     o = _validate(
         opts,
         {"overlap_length": None, "window": None, "scaling": None, "window_padding": "valid", "sampling_rate": 100,
@@ -183,7 +179,19 @@ def stft(data, window, ctx: Context | None = None, **opts):
         raise ArgumentError(f"invalid :scaling, expected one of :spectrum, :psd or nil, got: {o['scaling']!r}")
     mode, lo, hi = _pad_args(o["window_padding"])
     K = _resolve_fft_length(o["fft_length"], N)
-    p = StftParams(N, hop, K, mode, lo, hi, _SCALING[o["scaling"]], 0, fs)
+    return StftParams(N, hop, K, mode, lo, hi, _SCALING[o["scaling"]], 0, fs), N, hop, K
+
+
+def stft(data, window, ctx: Context | None = None, **opts):
+    """NxSignal.stft/3 — lib/nx_signal.ex:68-130.  Returns (z c64[..., M, K], times f32[M], frequencies f32[K]).
+
+    Defaults follow the code, not the doc (SURVEY B1-B3): window_padding "valid", sampling_rate 100,
+    fft_length "power_of_two", overlap_length div(N, 2); the :window key is accepted and ignored.
+    """
+    p, N, hop, K = _resolve_stft_opts(window, opts)
+    w = _window_host(window)
+    fs = float(p.sampling_rate)
+    mode, lo, hi = p.pad_mode, p.pad_lo, p.pad_hi
     lib = _lib.load()
     M = C.c_int64()
     if is_device(data):

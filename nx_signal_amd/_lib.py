@@ -19,6 +19,7 @@ SCALE_NONE, SCALE_SPECTRUM, SCALE_PSD = 0, 1, 2
 MAG_ABS, MAG_POWER, MAG_DBFS = 0, 1, 2
 WIN_RECTANGULAR, WIN_BARTLETT, WIN_TRIANGULAR, WIN_BLACKMAN, WIN_HAMMING, WIN_HANN, WIN_KAISER = range(7)
 CONV_FULL, CONV_SAME, CONV_VALID = 0, 1, 2
+SHARD_CHANNELS, SHARD_FRAMES = 0, 1
 
 
 class ArgumentError(ValueError):
@@ -92,6 +93,28 @@ SIGNATURES = {
     "nxsig_stft_to_mel": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _i32]),
     "nxsig_spectrum_mul_c64": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _i32]),
     "nxsig_stft_magnitude_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _p, C.POINTER(_i64), _i32]),
+    "nxsig_fir_slice_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32]),
+    "nxsig_timer_lap": (C.c_int, [_p]),
+    "nxsig_timer_laps": (C.c_int, [_p, _pf, _i32, C.POINTER(_i32)]),
+    # multi-GPU groups
+    "nxsig_shard_range": (C.c_int, [_i64, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "nxsig_shard_frames": (C.c_int, [_i64, _i32, _i32, _i32, _i32] + [C.POINTER(_i64)] * 4),
+    "nxsig_shard_fir": (C.c_int, [_i64, _i32, _i32, _i32, _i32] + [C.POINTER(_i64)] * 4),
+    "nxsig_rendezvous_publish": (C.c_int, [C.c_char_p, _p, _sz]),
+    "nxsig_rendezvous_fetch": (C.c_int, [C.c_char_p, _p, _sz, _i32, _i32]),
+    "nxsig_group_create_local": (C.c_int, [_i32, C.POINTER(_i32), C.POINTER(_p)]),
+    "nxsig_group_create_rank": (C.c_int, [_i32, _i32, _i32, C.c_char_p, _i32, C.POINTER(_p)]),
+    "nxsig_group_destroy": (None, [_p]),
+    "nxsig_group_world": (_i32, [_p]),
+    "nxsig_group_local_count": (_i32, [_p]),
+    "nxsig_group_rank": (_i32, [_p, _i32]),
+    "nxsig_group_ctx": (_p, [_p, _i32]),
+    "nxsig_group_has_rccl": (_i32, [_p]),
+    "nxsig_group_barrier": (C.c_int, [_p]),
+    "nxsig_group_allreduce_f64": (C.c_int, [_p, C.POINTER(_f64), _i32, _i32]),
+    "nxsig_group_allgather": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_i64), C.POINTER(_p)]),
+    "nxsig_stft_sharded_f32": (C.c_int, [_p, C.POINTER(_p), _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _i32, C.POINTER(_p), _i32]),
+    "nxsig_fir_sharded_f32": (C.c_int, [_p, C.POINTER(_p), _i64, _i32, _i64, _p, _i32, _i32, _i32, _i32, C.POINTER(_p), _i32]),
     "nxsig_stft_mel_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _p, _p, C.POINTER(_i64), _i32]),
 }
 

@@ -25,6 +25,7 @@ UNITS = [
     # (source, extra flags)
     ("host_numerics.cpp", ["-x", "hip", "-ffp-contract=off"]),  # BinaryBackend rounding: no FMA contraction
     ("api.cpp", ["-x", "hip"]),
+    ("group.cpp", ["-x", "hip"]),  # multi-GPU groups: RCCL is dlopen()ed at run time, never linked
     ("kernels_generic.hip", []),
     ("kernels_wave.hip", []),
     ("kernels_wave_mel.hip", []),
@@ -74,7 +75,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
     if force or _stale(OUT, objs):
-        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", OUT]
+        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-ldl", "-lpthread", "-o", OUT]
         if verbose:
             print("[nxsig build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -321,6 +321,7 @@ void nxsig_ctx_destroy(nxsig_ctx* ctx) {
     for (auto& s : c->scratch) if (s) (void)hipFree(s);
     (void)hipEventDestroy(c->ev_start);
     (void)hipEventDestroy(c->ev_stop);
+    for (auto e : c->lap_events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
   } catch (...) {
   }
@@ -415,6 +416,38 @@ int nxsig_timer_stop(nxsig_ctx* ctx, float* elapsed_ms) {
   NXSIG_HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
   NXSIG_HIP_TRY(hipEventSynchronize(c->ev_stop));
   NXSIG_HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev_start, c->ev_stop));
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_timer_lap(nxsig_ctx* ctx) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (c->laps_used >= 4096) return set_error(NXSIG_ERR_INVALID_ARG, "timer_lap: at most 4096 laps per series");
+  if (c->laps_used == c->lap_events.size()) {
+    hipEvent_t e;
+    NXSIG_HIP_TRY(hipEventCreate(&e));
+    c->lap_events.push_back(e);
+  }
+  NXSIG_HIP_TRY(hipEventRecord(c->lap_events[c->laps_used], c->stream));
+  ++c->laps_used;
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_timer_laps(nxsig_ctx* ctx, float* intervals_ms, int32_t capacity, int32_t* count) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!count || (capacity > 0 && !intervals_ms)) return set_error(NXSIG_ERR_INVALID_ARG, "timer_laps: null output");
+  const size_t n = c->laps_used;
+  c->laps_used = 0;
+  *count = 0;
+  if (n == 0) return NXSIG_OK;
+  NXSIG_HIP_TRY(hipEventSynchronize(c->lap_events[n - 1]));
+  for (size_t i = 0; i + 1 < n && (int32_t)i < capacity; ++i) {
+    NXSIG_HIP_TRY(hipEventElapsedTime(&intervals_ms[i], c->lap_events[i], c->lap_events[i + 1]));
+    *count = (int32_t)i + 1;
+  }
   return NXSIG_OK;
   NXSIG_API_END
 }
@@ -650,8 +683,8 @@ int nxsig_fft(nxsig_ctx* ctx, const void* in, int32_t in_is_real, int64_t rows, 
   NXSIG_API_END
 }
 
-int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
-                  int32_t num_taps, int32_t mode, float* y, int32_t mem) {
+static int fir_common(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
+                      int32_t num_taps, int64_t start, int64_t out_len, float* y, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
   if (!x || !h || !y) return set_error(NXSIG_ERR_INVALID_ARG, "fir: null pointer argument");
@@ -660,18 +693,8 @@ int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch,
   if (batch < 1 || batch > 65535 || length < 1 || num_taps < 1)
     return set_error(NXSIG_ERR_INVALID_ARG, "fir: batch, length and num_taps must be >= 1");
   if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "fir: batch_stride < length");
-  const int64_t full = length + num_taps - 1;
-  int64_t out_len, start;
-  switch (mode) {  // lib/nx_signal/convolution.ex:300-329: centered(out, shape) starts at div(full - new, 2)
-    case NXSIG_CONV_FULL: out_len = full; start = 0; break;
-    case NXSIG_CONV_SAME: out_len = length; start = (full - out_len) / 2; break;
-    case NXSIG_CONV_VALID:
-      out_len = (length >= num_taps ? length - num_taps : num_taps - length) + 1;
-      start = (full - out_len) / 2;
-      break;
-    default:  // convolution.ex:41-44
-      return set_error(NXSIG_ERR_INVALID_ARG, "expected mode to be one of [:full, :same, :valid]");
-  }
+  if (start < 0 || out_len < 1 || start + out_len > length + num_taps - 1)
+    return set_error(NXSIG_ERR_INVALID_ARG, "fir: requested slice lies outside the full convolution");
   FirLaunch a;
   a.L = length; a.batch = batch; a.batch_stride = batch_stride; a.h_host = h; a.taps = num_taps;
   a.out_start = start; a.out_len = out_len;
@@ -689,6 +712,29 @@ int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch,
   if ((rc = launch_fir(c, a))) return rc;
   return st.out_copy(y, yd, ybytes);
   NXSIG_API_END
+}
+
+int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
+                  int32_t num_taps, int32_t mode, float* y, int32_t mem) {
+  if (length < 1 || num_taps < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fir: batch, length and num_taps must be >= 1");
+  const int64_t full = length + num_taps - 1;
+  int64_t out_len, start;
+  switch (mode) {  // lib/nx_signal/convolution.ex:300-329: centered(out, shape) starts at div(full - new, 2)
+    case NXSIG_CONV_FULL: out_len = full; start = 0; break;
+    case NXSIG_CONV_SAME: out_len = length; start = (full - out_len) / 2; break;
+    case NXSIG_CONV_VALID:
+      out_len = (length >= num_taps ? length - num_taps : num_taps - length) + 1;
+      start = (full - out_len) / 2;
+      break;
+    default:  // convolution.ex:41-44
+      return set_error(NXSIG_ERR_INVALID_ARG, "expected mode to be one of [:full, :same, :valid]");
+  }
+  return fir_common(ctx, x, length, batch, batch_stride, h, num_taps, start, out_len, y, mem);
+}
+
+int nxsig_fir_slice_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
+                        int32_t num_taps, int64_t out_start, int64_t out_len, float* y, int32_t mem) {
+  return fir_common(ctx, x, length, batch, batch_stride, h, num_taps, out_start, out_len, y, mem);
 }
 
 int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const nxsig_c64* b, int64_t n2, int32_t mode,

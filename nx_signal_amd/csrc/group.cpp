@@ -1,0 +1,614 @@
+// Multi-GPU groups behind the C ABI (include/nxsig.h, "multi-GPU groups").
+//
+// The STFT / FIR path shards with no data-path exchange (channels — the reference's vectorized axes,
+// lib/nx_signal.ex:358-363 — are independent; frames are independent given their samples), so a group is little more
+// than one context + stream per GPU and a shard plan.  The only collective is the optional final assembly: an RCCL
+// all-gather over xGMI.  Two ways to build a group:
+//   LOCAL   one process drives every GPU (the Elixir / dirty-NIF host): ncclCommInitAll, collectives of all members fused
+//           between ncclGroupStart / ncclGroupEnd, one stream per device so the per-device launches overlap;
+//   RANKED  one process per GPU (bench.py under a launcher): ncclCommInitRank, the ncclUniqueId published by rank 0 in a
+//           file on the node.
+// librccl.so (570 MB) is dlopen()ed on the first group creation only: processes that never shard never pay for it, and
+// libnxsig.so has no link-time dependency on it.  No torch anywhere.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <rccl/rccl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <mutex>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "nxsig_internal.h"
+
+namespace nxsig {
+
+// ---------------------------------------------------------------------------------------------- RCCL, loaded lazily
+struct Rccl {
+  void* handle = nullptr;
+  std::string error;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static Rccl& rccl_state() {
+  static Rccl r;
+  return r;
+}
+static Rccl* rccl() {
+  Rccl& r = rccl_state();
+  static std::once_flag once;
+  std::call_once(once, [&r] {
+    const char* names[] = {std::getenv("NXSIG_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.handle) break;
+      r.error = dlerror();
+    }
+    if (!r.handle) return;
+    bool ok = true;
+    auto sym = [&](const char* name) -> void* {
+      void* p = dlsym(r.handle, name);
+      if (!p) { ok = false; r.error = std::string("missing symbol ") + name; }
+      return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(r.handle); r.handle = nullptr; }
+  });
+  return r.handle ? &r : nullptr;
+}
+static std::string rccl_error() { return rccl_state().error; }
+
+#define NXSIG_NCCL_TRY(R, expr)                                                                              \
+  do {                                                                                                       \
+    ncclResult_t _r = (expr);                                                                                \
+    if (_r != ncclSuccess) return set_error(NXSIG_ERR_HIP, std::string(#expr) + ": " + (R)->GetErrorString(_r)); \
+  } while (0)
+
+struct Member {
+  int rank = 0;
+  int device = 0;
+  nxsig_ctx* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  double* cell = nullptr;  // device scratch: 2 x 64 doubles (barrier word, small reductions)
+};
+
+struct Group {
+  int world = 1;
+  bool ranked = false;   // one process per GPU
+  bool has_rccl = false;
+  std::vector<Member> m;
+  std::mutex mu;
+};
+
+static hipStream_t stream_of(const Member& mb) { return reinterpret_cast<hipStream_t>(nxsig_get_stream(mb.ctx)); }
+
+static void destroy_group(Group* g) {
+  if (!g) return;
+  Rccl* R = g->has_rccl ? rccl() : nullptr;
+  for (auto& mb : g->m) {
+    if (mb.ctx) (void)nxsig_sync(mb.ctx);
+    if (mb.comm && R) { (void)hipSetDevice(mb.device); (void)R->CommDestroy(mb.comm); }
+    if (mb.cell) { (void)hipSetDevice(mb.device); (void)hipFree(mb.cell); }
+    if (mb.ctx) nxsig_ctx_destroy(mb.ctx);
+  }
+  delete g;
+}
+
+static int split(int64_t total, int parts, int index, int64_t* b, int64_t* e) {
+  if (parts < 1 || index < 0 || index >= parts || total < 0)
+    return set_error(NXSIG_ERR_INVALID_ARG, "shard: need parts >= 1, 0 <= index < parts, total >= 0");
+  const int64_t base = total / parts, extra = total % parts;
+  *b = index * base + (index < extra ? index : extra);
+  *e = *b + base + (index < extra ? 1 : 0);
+  return NXSIG_OK;
+}
+
+static int fir_geometry(int64_t length, int32_t taps, int32_t mode, int64_t* out_len, int64_t* start) {
+  if (length < 1 || taps < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fir: length and num_taps must be >= 1");
+  const int64_t full = length + taps - 1;
+  switch (mode) {  // lib/nx_signal/convolution.ex:300-329
+    case NXSIG_CONV_FULL: *out_len = full; *start = 0; break;
+    case NXSIG_CONV_SAME: *out_len = length; *start = (full - length) / 2; break;
+    case NXSIG_CONV_VALID: *out_len = (length >= taps ? length - taps : taps - length) + 1; *start = (full - *out_len) / 2; break;
+    default: return set_error(NXSIG_ERR_INVALID_ARG, "expected mode to be one of [:full, :same, :valid]");
+  }
+  return NXSIG_OK;
+}
+
+// everything a member needs to know about its part of a sharded call
+struct Part {
+  int64_t row0 = 0, rows = 0;      // rows of the tensor it processes
+  int64_t in0 = 0, in_len = 0;     // sample span of every row it reads
+  int64_t out0 = 0, out_len = 0;   // output items (frames / samples) per row it produces, first item
+  int64_t out_start = 0;           // FIR: index of its first output inside the full convolution of ITS input span
+};
+
+}  // namespace nxsig
+
+using namespace nxsig;
+
+#define NXSIG_API_BEGIN try {
+#define NXSIG_API_END                                                                   \
+  }                                                                                     \
+  catch (const std::bad_alloc&) { return set_error(NXSIG_ERR_OOM, "host out of memory"); } \
+  catch (const std::exception& e) { return set_error(NXSIG_ERR_INVALID_ARG, std::string("internal error: ") + e.what()); } \
+  catch (...) { return set_error(NXSIG_ERR_INVALID_ARG, "internal error"); }
+
+extern "C" {
+
+/* ------------------------------------------------------------------------------------------------ shard plans (pure) */
+int nxsig_shard_range(int64_t total, int32_t parts, int32_t index, int64_t* begin, int64_t* end) {
+  NXSIG_API_BEGIN
+  if (!begin || !end) return set_error(NXSIG_ERR_INVALID_ARG, "shard_range: null output");
+  return split(total, parts, index, begin, end);
+  NXSIG_API_END
+}
+
+int nxsig_shard_frames(int64_t num_frames, int32_t frame_length, int32_t hop, int32_t parts, int32_t index, int64_t* m0,
+                       int64_t* m1, int64_t* s0, int64_t* s1) {
+  NXSIG_API_BEGIN
+  if (!m0 || !m1 || !s0 || !s1) return set_error(NXSIG_ERR_INVALID_ARG, "shard_frames: null output");
+  if (frame_length < 1 || hop < 1) return set_error(NXSIG_ERR_INVALID_ARG, "shard_frames: frame_length and hop must be >= 1");
+  int rc = split(num_frames, parts, index, m0, m1);
+  if (rc) return rc;
+  *s0 = *m0 * hop;
+  *s1 = *m1 > *m0 ? (*m1 - 1) * hop + frame_length : *s0;
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_shard_fir(int64_t length, int32_t num_taps, int32_t mode, int32_t parts, int32_t index, int64_t* n0, int64_t* n1,
+                    int64_t* s0, int64_t* s1) {
+  NXSIG_API_BEGIN
+  if (!n0 || !n1 || !s0 || !s1) return set_error(NXSIG_ERR_INVALID_ARG, "shard_fir: null output");
+  int64_t out_len, start;
+  int rc = fir_geometry(length, num_taps, mode, &out_len, &start);
+  if (rc) return rc;
+  if ((rc = split(out_len, parts, index, n0, n1))) return rc;
+  // output n of the mode's slice is full-convolution index n + start = sum_j h[j] x[n + start - j], j < taps
+  int64_t a = *n0 + start - (num_taps - 1), b = *n1 + start;
+  if (a < 0) a = 0;
+  if (b > length) b = length;
+  if (*n1 <= *n0 || b < a) b = a;
+  *s0 = a; *s1 = b;
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+/* ------------------------------------------------------------------------------------------------ file rendezvous */
+int nxsig_rendezvous_publish(const char* path, const void* data, size_t bytes) {
+  NXSIG_API_BEGIN
+  if (!path || !*path || (!data && bytes)) return set_error(NXSIG_ERR_INVALID_ARG, "rendezvous_publish: bad arguments");
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return set_error(NXSIG_ERR_INVALID_ARG, "rendezvous_publish: cannot create " + tmp);
+  const size_t n = bytes ? std::fwrite(data, 1, bytes, f) : 0;
+  const int ce = std::fclose(f);
+  if (n != bytes || ce != 0) { std::remove(tmp.c_str()); return set_error(NXSIG_ERR_INVALID_ARG, "rendezvous_publish: short write to " + tmp); }
+  if (std::rename(tmp.c_str(), path) != 0) { std::remove(tmp.c_str()); return set_error(NXSIG_ERR_INVALID_ARG, std::string("rendezvous_publish: cannot rename to ") + path); }
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_rendezvous_fetch(const char* path, void* data, size_t bytes, int32_t timeout_ms, int32_t max_age_s) {
+  NXSIG_API_BEGIN
+  if (!path || !*path || (!data && bytes)) return set_error(NXSIG_ERR_INVALID_ARG, "rendezvous_fetch: bad arguments");
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    struct stat st;
+    if (stat(path, &st) == 0 && (size_t)st.st_size == bytes &&
+        (max_age_s <= 0 || std::time(nullptr) - st.st_mtime <= (time_t)max_age_s)) {
+      FILE* f = std::fopen(path, "rb");
+      if (f) {
+        const size_t n = bytes ? std::fread(data, 1, bytes, f) : 0;
+        std::fclose(f);
+        if (n == bytes) return NXSIG_OK;
+      }
+    }
+    const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > timeout_ms) return set_error(NXSIG_ERR_INVALID_ARG, std::string("rendezvous_fetch: timed out waiting for ") + path);
+    std::this_thread::sleep_for(std::chrono::milliseconds(5));
+  }
+  NXSIG_API_END
+}
+
+/* ------------------------------------------------------------------------------------------------ groups */
+static int make_member(Group* g, int rank, int device) {
+  Member mb;
+  mb.rank = rank; mb.device = device;
+  int rc = nxsig_ctx_create(device, &mb.ctx);
+  if (rc) return rc;
+  g->m.push_back(mb);
+  Member& r = g->m.back();
+  NXSIG_HIP_TRY(hipSetDevice(device));
+  NXSIG_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&r.cell), 128 * sizeof(double)));
+  NXSIG_HIP_TRY(hipMemset(r.cell, 0, 128 * sizeof(double)));
+  return NXSIG_OK;
+}
+
+int nxsig_group_create_local(int32_t n, const int32_t* device_ids, nxsig_group** out) {
+  NXSIG_API_BEGIN
+  if (!out) return set_error(NXSIG_ERR_INVALID_ARG, "group_create_local: out is null");
+  if (n < 1 || n > 64) return set_error(NXSIG_ERR_INVALID_ARG, "group_create_local: need 1 <= n <= 64 members");
+  Group* g = new Group();
+  g->world = n; g->ranked = false;
+  std::vector<int> devs(n);
+  std::set<int> distinct;
+  for (int i = 0; i < n; ++i) { devs[i] = device_ids ? device_ids[i] : i; distinct.insert(devs[i]); }
+  for (int i = 0; i < n; ++i) {
+    int rc = make_member(g, i, devs[i]);
+    if (rc) { destroy_group(g); return rc; }
+  }
+  if ((int)distinct.size() == n) {  // one GPU per member: RCCL communicators (members sharing a device assemble by copies)
+    Rccl* R = rccl();
+    if (!R) { destroy_group(g); return set_error(NXSIG_ERR_HIP, "cannot load librccl: " + rccl_error()); }
+    std::vector<ncclComm_t> comms(n, nullptr);
+    ncclResult_t r = R->CommInitAll(comms.data(), n, devs.data());
+    if (r != ncclSuccess) { destroy_group(g); return set_error(NXSIG_ERR_HIP, std::string("ncclCommInitAll: ") + R->GetErrorString(r)); }
+    for (int i = 0; i < n; ++i) g->m[i].comm = comms[i];
+    g->has_rccl = true;
+  }
+  *out = reinterpret_cast<nxsig_group*>(g);
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_group_create_rank(int32_t world, int32_t rank, int32_t device, const char* rendezvous_path, int32_t timeout_ms,
+                            nxsig_group** out) {
+  NXSIG_API_BEGIN
+  if (!out) return set_error(NXSIG_ERR_INVALID_ARG, "group_create_rank: out is null");
+  if (world < 1 || rank < 0 || rank >= world) return set_error(NXSIG_ERR_INVALID_ARG, "group_create_rank: need 0 <= rank < world");
+  if (world > 1 && (!rendezvous_path || !*rendezvous_path))
+    return set_error(NXSIG_ERR_INVALID_ARG, "group_create_rank: world > 1 needs a rendezvous path");
+  Rccl* R = rccl();
+  if (!R) return set_error(NXSIG_ERR_HIP, "cannot load librccl: " + rccl_error());
+  Group* g = new Group();
+  g->world = world; g->ranked = true;
+  int rc = make_member(g, rank, device);
+  if (rc) { destroy_group(g); return rc; }
+  ncclUniqueId id;
+  std::memset(&id, 0, sizeof(id));
+  if (rank == 0) {
+    ncclResult_t r = R->GetUniqueId(&id);
+    if (r != ncclSuccess) { destroy_group(g); return set_error(NXSIG_ERR_HIP, std::string("ncclGetUniqueId: ") + R->GetErrorString(r)); }
+    if (world > 1 && (rc = nxsig_rendezvous_publish(rendezvous_path, &id, sizeof(id)))) { destroy_group(g); return rc; }
+  } else if ((rc = nxsig_rendezvous_fetch(rendezvous_path, &id, sizeof(id), timeout_ms > 0 ? timeout_ms : 120000, 600))) {
+    destroy_group(g);
+    return rc;
+  }
+  if (hipSetDevice(device) != hipSuccess) { destroy_group(g); return set_error(NXSIG_ERR_HIP, "hipSetDevice failed"); }
+  ncclResult_t r = R->CommInitRank(&g->m[0].comm, world, id, rank);
+  if (r != ncclSuccess) { destroy_group(g); return set_error(NXSIG_ERR_HIP, std::string("ncclCommInitRank: ") + R->GetErrorString(r)); }
+  g->has_rccl = true;
+  *out = reinterpret_cast<nxsig_group*>(g);
+  // every rank holds the id once the communicator is up (ncclCommInitRank synchronises): rank 0 removes the file
+  rc = nxsig_group_barrier(*out);
+  if (rc) { destroy_group(g); *out = nullptr; return rc; }
+  if (rank == 0 && world > 1) std::remove(rendezvous_path);
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+void nxsig_group_destroy(nxsig_group* g) {
+  try { destroy_group(reinterpret_cast<Group*>(g)); } catch (...) {}
+}
+
+int32_t nxsig_group_world(const nxsig_group* g) { return g ? reinterpret_cast<const Group*>(g)->world : 0; }
+int32_t nxsig_group_local_count(const nxsig_group* g) { return g ? (int32_t)reinterpret_cast<const Group*>(g)->m.size() : 0; }
+int32_t nxsig_group_rank(const nxsig_group* g, int32_t i) {
+  const Group* G = reinterpret_cast<const Group*>(g);
+  return (G && i >= 0 && i < (int)G->m.size()) ? G->m[i].rank : -1;
+}
+nxsig_ctx* nxsig_group_ctx(nxsig_group* g, int32_t i) {
+  Group* G = reinterpret_cast<Group*>(g);
+  return (G && i >= 0 && i < (int)G->m.size()) ? G->m[i].ctx : nullptr;
+}
+int32_t nxsig_group_has_rccl(const nxsig_group* g) { return g && reinterpret_cast<const Group*>(g)->has_rccl ? 1 : 0; }
+
+int nxsig_group_barrier(nxsig_group* grp) {
+  NXSIG_API_BEGIN
+  if (!grp) return set_error(NXSIG_ERR_INVALID_ARG, "null group");
+  Group* g = reinterpret_cast<Group*>(grp);
+  std::lock_guard<std::mutex> lock(g->mu);
+  int rc;
+  for (auto& mb : g->m)
+    if ((rc = nxsig_sync(mb.ctx))) return rc;
+  if (!g->has_rccl) return NXSIG_OK;
+  Rccl* R = rccl();
+  NXSIG_NCCL_TRY(R, R->GroupStart());
+  for (auto& mb : g->m) {
+    NXSIG_HIP_TRY(hipSetDevice(mb.device));
+    int* w = reinterpret_cast<int*>(mb.cell);
+    NXSIG_NCCL_TRY(R, R->AllReduce(w, w + 16, 1, ncclInt32, ncclSum, mb.comm, stream_of(mb)));
+  }
+  NXSIG_NCCL_TRY(R, R->GroupEnd());
+  for (auto& mb : g->m)
+    if ((rc = nxsig_sync(mb.ctx))) return rc;
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_group_allreduce_f64(nxsig_group* grp, double* values, int32_t n, int32_t op) {
+  NXSIG_API_BEGIN
+  if (!grp || !values) return set_error(NXSIG_ERR_INVALID_ARG, "group_allreduce: null argument");
+  if (n < 1 || n > 64) return set_error(NXSIG_ERR_INVALID_ARG, "group_allreduce: 1 <= n <= 64");
+  if (op != 0 && op != 1) return set_error(NXSIG_ERR_INVALID_ARG, "group_allreduce: op must be 0 (max) or 1 (sum)");
+  Group* g = reinterpret_cast<Group*>(grp);
+  std::lock_guard<std::mutex> lock(g->mu);
+  if (!g->has_rccl || !g->ranked) return NXSIG_OK;  // a single process: its values are the result
+  Rccl* R = rccl();
+  Member& mb = g->m[0];
+  NXSIG_HIP_TRY(hipSetDevice(mb.device));
+  hipStream_t s = stream_of(mb);
+  NXSIG_HIP_TRY(hipMemcpyAsync(mb.cell, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+  NXSIG_NCCL_TRY(R, R->AllReduce(mb.cell, mb.cell + 64, (size_t)n, ncclDouble, op == 0 ? ncclMax : ncclSum, mb.comm, s));
+  NXSIG_HIP_TRY(hipMemcpyAsync(values, mb.cell + 64, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+  NXSIG_HIP_TRY(hipStreamSynchronize(s));
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+static int allgather_locked(Group* g, const void* const* send, const int64_t* counts, void* const* recv) {
+  const int W = g->world;
+  std::vector<int64_t> off(W + 1, 0);
+  bool equal = true;
+  for (int r = 0; r < W; ++r) {
+    if (counts[r] < 0) return set_error(NXSIG_ERR_INVALID_ARG, "group_allgather: negative count");
+    off[r + 1] = off[r] + counts[r];
+    if (counts[r] != counts[0]) equal = false;
+  }
+  for (size_t i = 0; i < g->m.size(); ++i)
+    if (!recv[i] || (!send[i] && counts[g->m[i].rank] > 0)) return set_error(NXSIG_ERR_INVALID_ARG, "group_allgather: null buffer");
+  if (g->has_rccl) {
+    Rccl* R = rccl();
+    NXSIG_NCCL_TRY(R, R->GroupStart());
+    for (size_t i = 0; i < g->m.size(); ++i) {
+      Member& mb = g->m[i];
+      NXSIG_HIP_TRY(hipSetDevice(mb.device));
+      char* rb = static_cast<char*>(recv[i]);
+      if (equal) {
+        if (counts[0] > 0) NXSIG_NCCL_TRY(R, R->AllGather(send[i], rb, (size_t)counts[0], ncclChar, mb.comm, stream_of(mb)));
+      } else {
+        for (int r = 0; r < W; ++r) {  // unequal shards: one broadcast per rank, fused into a single group launch
+          if (counts[r] == 0) continue;
+          const void* sb = r == mb.rank ? send[i] : rb + off[r];
+          NXSIG_NCCL_TRY(R, R->Broadcast(sb, rb + off[r], (size_t)counts[r], ncclChar, r, mb.comm, stream_of(mb)));
+        }
+      }
+    }
+    NXSIG_NCCL_TRY(R, R->GroupEnd());
+    return NXSIG_OK;
+  }
+  if (g->ranked) return set_error(NXSIG_ERR_UNSUPPORTED, "group_allgather: a ranked group without RCCL cannot assemble");
+  // members share devices (single-GPU testing / replicas): device-to-device copies once every shard is complete
+  int rc;
+  for (auto& mb : g->m)
+    if ((rc = nxsig_sync(mb.ctx))) return rc;
+  for (size_t i = 0; i < g->m.size(); ++i) {
+    NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
+    char* rb = static_cast<char*>(recv[i]);
+    for (size_t j = 0; j < g->m.size(); ++j) {
+      const int r = g->m[j].rank;
+      if (counts[r] == 0 || rb + off[r] == send[j]) continue;
+      NXSIG_HIP_TRY(hipMemcpyAsync(rb + off[r], send[j], (size_t)counts[r], hipMemcpyDefault, stream_of(g->m[i])));
+    }
+  }
+  return NXSIG_OK;
+}
+
+int nxsig_group_allgather(nxsig_group* grp, const void* const* send, const int64_t* counts, void* const* recv) {
+  NXSIG_API_BEGIN
+  if (!grp || !send || !counts || !recv) return set_error(NXSIG_ERR_INVALID_ARG, "group_allgather: null argument");
+  Group* g = reinterpret_cast<Group*>(grp);
+  std::lock_guard<std::mutex> lock(g->mu);
+  return allgather_locked(g, send, counts, recv);
+  NXSIG_API_END
+}
+
+}  // extern "C"
+
+/* ------------------------------------------------------------------------------------------------ sharded hot path */
+namespace {
+
+// geometry of a sharded call: what every rank does
+struct Plan {
+  int64_t rows_total = 0, in_len_total = 0, out_items_total = 0;  // whole tensor: rows, samples per row, output items per row
+  int64_t item_bytes = 0;                                          // bytes of one output item (frame: K * 8; sample: 4)
+  std::vector<Part> part;                                          // per rank
+  std::vector<int64_t> count;                                      // output bytes per rank
+};
+
+// runs `compute(member, part, x_dev, out_dev)` for every local member; host mode stages through per-member device buffers
+template <class Compute>
+int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_stride, int32_t axis, int32_t gather,
+                void* const* out, int32_t mem, Compute compute) {
+  const size_t nl = g->m.size();
+  const bool by_rows = axis == NXSIG_SHARD_CHANNELS;
+  if (!by_rows && gather && pl.rows_total != 1 && mem == NXSIG_DEVICE)
+    return set_error(NXSIG_ERR_UNSUPPORTED, "sharded: in-place assembly of frame / sample shards needs batch == 1");
+  int rc;
+  if (mem == NXSIG_DEVICE) {
+    std::vector<const void*> send(nl);
+    for (size_t i = 0; i < nl; ++i) {
+      const Part& p = pl.part[g->m[i].rank];
+      if (!out[i] || (!x[i] && p.rows > 0 && p.out_len > 0)) return set_error(NXSIG_ERR_INVALID_ARG, "sharded: null shard pointer");
+      char* dst = static_cast<char*>(out[i]);
+      if (gather) dst += by_rows ? p.row0 * pl.out_items_total * pl.item_bytes : p.out0 * pl.item_bytes;
+      send[i] = dst;
+      if (p.rows > 0 && p.out_len > 0 && (rc = compute(g->m[i], p, static_cast<const float*>(x[i]), batch_stride, dst))) return rc;
+    }
+    if (!gather) return NXSIG_OK;
+    return allgather_locked(g, send.data(), pl.count.data(), out);
+  }
+  // ---- host tensors: LOCAL groups only (one process sees the whole tensor); one thread per member keeps every GPU busy
+  if (g->ranked && g->world > 1) return set_error(NXSIG_ERR_UNSUPPORTED, "sharded: host tensors need a LOCAL group (one process, all GPUs)");
+  if (!x[0] || !out[0]) return set_error(NXSIG_ERR_INVALID_ARG, "sharded: null tensor pointer");
+  const float* xh = static_cast<const float*>(x[0]);
+  char* oh = static_cast<char*>(out[0]);
+  const int64_t full_bytes = pl.rows_total * pl.out_items_total * pl.item_bytes;
+  std::vector<void*> din(nl, nullptr), dout(nl, nullptr);
+  std::vector<const void*> send(nl, nullptr);
+  std::vector<int> rcs(nl, 0);
+  std::vector<std::string> msgs(nl);
+  auto cleanup = [&]() {
+    for (size_t i = 0; i < nl; ++i) {
+      if (din[i]) (void)nxsig_free(g->m[i].ctx, din[i]);
+      if (dout[i]) (void)nxsig_free(g->m[i].ctx, dout[i]);
+    }
+  };
+  auto work = [&](size_t i) {
+    Member& mb = g->m[i];
+    const Part& p = pl.part[mb.rank];
+    auto fail = [&](int code) { rcs[i] = code; msgs[i] = nxsig_last_error(); };
+    int r;
+    const int64_t shard_bytes = pl.count[mb.rank];
+    if ((r = nxsig_alloc(mb.ctx, (size_t)(gather ? full_bytes : shard_bytes), &dout[i]))) return fail(r);
+    char* dst = static_cast<char*>(dout[i]);
+    if (gather) dst += by_rows ? p.row0 * pl.out_items_total * pl.item_bytes : p.out0 * pl.item_bytes;
+    send[i] = dst;
+    if (p.rows == 0 || p.out_len == 0) return;
+    if ((r = nxsig_alloc(mb.ctx, (size_t)(p.rows * p.in_len) * sizeof(float), &din[i]))) return fail(r);
+    for (int64_t row = 0; row < p.rows; ++row)  // the member's rows / spans, packed densely on its device
+      if ((r = nxsig_upload(mb.ctx, static_cast<float*>(din[i]) + row * p.in_len, xh + (p.row0 + row) * batch_stride + p.in0,
+                            (size_t)p.in_len * sizeof(float)))) return fail(r);
+    if ((r = compute(mb, p, static_cast<const float*>(din[i]), p.in_len, dst))) return fail(r);
+    if (gather) return;
+    // per-shard download straight into its place of the host result
+    if (by_rows) {
+      if ((r = nxsig_download(mb.ctx, oh + p.row0 * pl.out_items_total * pl.item_bytes, dst, (size_t)shard_bytes))) return fail(r);
+    } else {
+      for (int64_t row = 0; row < p.rows; ++row)
+        if ((r = nxsig_download(mb.ctx, oh + (row * pl.out_items_total + p.out0) * pl.item_bytes, dst + row * p.out_len * pl.item_bytes,
+                                (size_t)(p.out_len * pl.item_bytes)))) return fail(r);
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < nl; ++i) th.emplace_back(work, i);
+    work(0);
+    for (auto& t : th) t.join();
+  }
+  for (size_t i = 0; i < nl; ++i)
+    if (rcs[i]) { cleanup(); return set_error(rcs[i], msgs[i]); }
+  rc = NXSIG_OK;
+  if (gather) {
+    if (!by_rows && pl.rows_total != 1) { cleanup(); return set_error(NXSIG_ERR_UNSUPPORTED, "sharded: assembly of frame / sample shards needs batch == 1"); }
+    rc = allgather_locked(g, send.data(), pl.count.data(), dout.data());
+    if (!rc) rc = nxsig_download(g->m[0].ctx, oh, dout[0], (size_t)full_bytes);  // synchronises member 0's stream
+    for (size_t i = 1; i < nl && !rc; ++i) rc = nxsig_sync(g->m[i].ctx);
+  }
+  std::string keep = rc ? nxsig_last_error() : "";
+  cleanup();
+  return rc ? set_error(rc, keep) : NXSIG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nxsig_stft_sharded_f32(nxsig_group* grp, const float* const* x, int64_t length, int32_t batch, int64_t batch_stride,
+                           const float* window, const nxsig_stft_params* p, int32_t axis, int32_t gather,
+                           nxsig_c64* const* z, int32_t mem) {
+  NXSIG_API_BEGIN
+  if (!grp || !x || !window || !p || !z) return set_error(NXSIG_ERR_INVALID_ARG, "stft_sharded: null argument");
+  if (mem != NXSIG_HOST && mem != NXSIG_DEVICE) return set_error(NXSIG_ERR_INVALID_ARG, "mem must be NXSIG_HOST or NXSIG_DEVICE");
+  if (axis != NXSIG_SHARD_CHANNELS && axis != NXSIG_SHARD_FRAMES) return set_error(NXSIG_ERR_INVALID_ARG, "stft_sharded: bad axis");
+  if (p->pad_mode != NXSIG_PAD_VALID)
+    return set_error(NXSIG_ERR_INVALID_ARG, "stft_sharded: window_padding must be :valid (padding belongs to the stream ends)");
+  if (batch < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft_sharded: batch must be >= 1");
+  if (mem == NXSIG_HOST && batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "stft_sharded: batch_stride < length");
+  const int64_t M = nxsig_num_frames(length, p->frame_length, p->hop, NXSIG_PAD_VALID, 0, 0);
+  if (M < 0) return (int)M;
+  if (p->fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft: fft_length must be >= 1");
+  Group* g = reinterpret_cast<Group*>(grp);
+  std::lock_guard<std::mutex> lock(g->mu);
+  Plan pl;
+  pl.rows_total = batch; pl.in_len_total = length; pl.out_items_total = M; pl.item_bytes = (int64_t)p->fft_length * 8;
+  pl.part.resize(g->world); pl.count.resize(g->world);
+  for (int r = 0; r < g->world; ++r) {
+    Part& q = pl.part[r];
+    int rc;
+    if (axis == NXSIG_SHARD_CHANNELS) {
+      int64_t c0, c1;
+      if ((rc = split(batch, g->world, r, &c0, &c1))) return rc;
+      q.row0 = c0; q.rows = c1 - c0; q.in0 = 0; q.in_len = length; q.out0 = 0; q.out_len = M;
+    } else {
+      int64_t m0, m1, s0, s1;
+      if ((rc = nxsig_shard_frames(M, p->frame_length, p->hop, g->world, r, &m0, &m1, &s0, &s1))) return rc;
+      q.row0 = 0; q.rows = batch; q.in0 = s0; q.in_len = s1 - s0; q.out0 = m0; q.out_len = m1 - m0;
+    }
+    pl.count[r] = q.rows * q.out_len * pl.item_bytes;
+  }
+  auto compute = [&](Member& mb, const Part& q, const float* xd, int64_t stride, void* dst) -> int {
+    return nxsig_stft_f32(mb.ctx, xd, q.in_len, (int32_t)q.rows, stride, window, p, static_cast<nxsig_c64*>(dst), nullptr, NXSIG_DEVICE);
+  };
+  return run_sharded(g, pl, reinterpret_cast<const void* const*>(x), batch_stride, axis, gather, reinterpret_cast<void* const*>(z), mem, compute);
+  NXSIG_API_END
+}
+
+int nxsig_fir_sharded_f32(nxsig_group* grp, const float* const* x, int64_t length, int32_t batch, int64_t batch_stride,
+                          const float* h, int32_t num_taps, int32_t mode, int32_t axis, int32_t gather, float* const* y,
+                          int32_t mem) {
+  NXSIG_API_BEGIN
+  if (!grp || !x || !h || !y) return set_error(NXSIG_ERR_INVALID_ARG, "fir_sharded: null argument");
+  if (mem != NXSIG_HOST && mem != NXSIG_DEVICE) return set_error(NXSIG_ERR_INVALID_ARG, "mem must be NXSIG_HOST or NXSIG_DEVICE");
+  if (axis != NXSIG_SHARD_CHANNELS && axis != NXSIG_SHARD_FRAMES) return set_error(NXSIG_ERR_INVALID_ARG, "fir_sharded: bad axis");
+  if (batch < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fir_sharded: batch must be >= 1");
+  if (mem == NXSIG_HOST && batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "fir_sharded: batch_stride < length");
+  int64_t out_len, start;
+  int rc = fir_geometry(length, num_taps, mode, &out_len, &start);
+  if (rc) return rc;
+  Group* g = reinterpret_cast<Group*>(grp);
+  std::lock_guard<std::mutex> lock(g->mu);
+  Plan pl;
+  pl.rows_total = batch; pl.in_len_total = length; pl.out_items_total = out_len; pl.item_bytes = 4;
+  pl.part.resize(g->world); pl.count.resize(g->world);
+  for (int r = 0; r < g->world; ++r) {
+    Part& q = pl.part[r];
+    if (axis == NXSIG_SHARD_CHANNELS) {
+      int64_t c0, c1;
+      if ((rc = split(batch, g->world, r, &c0, &c1))) return rc;
+      q.row0 = c0; q.rows = c1 - c0; q.in0 = 0; q.in_len = length; q.out0 = 0; q.out_len = out_len; q.out_start = start;
+    } else {
+      int64_t n0, n1, s0, s1;
+      if ((rc = nxsig_shard_fir(length, num_taps, mode, g->world, r, &n0, &n1, &s0, &s1))) return rc;
+      q.row0 = 0; q.rows = batch; q.in0 = s0; q.in_len = s1 - s0; q.out0 = n0; q.out_len = n1 - n0;
+      q.out_start = n0 + start - s0;  // index of output n0 inside the full convolution of the span [s0, s1)
+      if (q.in_len == 0) q.out_len = 0;
+    }
+    pl.count[r] = q.rows * q.out_len * pl.item_bytes;
+  }
+  auto compute = [&](Member& mb, const Part& q, const float* xd, int64_t stride, void* dst) -> int {
+    return nxsig_fir_slice_f32(mb.ctx, xd, q.in_len, (int32_t)q.rows, stride, h, num_taps, q.out_start, q.out_len, static_cast<float*>(dst), NXSIG_DEVICE);
+  };
+  return run_sharded(g, pl, reinterpret_cast<const void* const*>(x), batch_stride, axis, gather, reinterpret_cast<void* const*>(y), mem, compute);
+  NXSIG_API_END
+}
+
+}  // extern "C"

@@ -58,6 +58,8 @@ struct Ctx {
   hipStream_t stream = nullptr;
   bool own_stream = true;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  std::vector<hipEvent_t> lap_events;  // nxsig_timer_lap series: events are created on demand and reused
+  size_t laps_used = 0;
   std::mutex mu;
   int num_cus = 0;
   std::string dev_name;

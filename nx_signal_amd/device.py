@@ -16,13 +16,17 @@ from . import _lib
 
 
 class Context:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _borrowed=None):
         lib = _lib.load()
+        self._lib = lib
+        self.device = int(device)
+        self._owned = _borrowed is None
+        if _borrowed is not None:  # a context owned by a Group (nxsig_group_ctx)
+            self._h = C.c_void_p(_borrowed)
+            return
         h = C.c_void_p()
         _lib.check(lib.nxsig_ctx_create(int(device), C.byref(h)))
         self._h = h
-        self._lib = lib
-        self.device = int(device)
 
     @property
     def handle(self):
@@ -46,6 +50,17 @@ class Context:
         _lib.check(self._lib.nxsig_timer_stop(self.handle, C.byref(ms)))
         return float(ms.value)
 
+    def timer_lap(self):
+        """records one event of a per-launch stopwatch series on the context's stream"""
+        _lib.check(self._lib.nxsig_timer_lap(self.handle))
+
+    def timer_laps(self):
+        """synchronises and returns the intervals (ms) between consecutive timer_lap() events; clears the series"""
+        buf = (C.c_float * 4096)()
+        n = C.c_int32()
+        _lib.check(self._lib.nxsig_timer_laps(self.handle, buf, 4096, C.byref(n)))
+        return [float(buf[i]) for i in range(n.value)]
+
     def set_stream(self, hip_stream_ptr):
         _lib.check(self._lib.nxsig_set_stream(self.handle, C.c_void_p(hip_stream_ptr)))
 
@@ -57,7 +72,8 @@ class Context:
 
     def close(self):
         if self._h is not None:
-            self._lib.nxsig_ctx_destroy(self._h)
+            if self._owned:
+                self._lib.nxsig_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):  # pragma: no cover

@@ -1,26 +1,47 @@
-"""Multi-GPU sharding of the STFT / FIR path: one process per GPU, no data-path collective.
+"""Multi-GPU sharding of the STFT / FIR path behind the C ABI — no torch, no Python-side collective.
 
-Frames of a stream are independent given their samples and channels are fully independent, so the path shards
-with NO exchange step: rank r owns a contiguous block of channels, or a contiguous range of frames of one long
-stream plus an (N - hop)-sample input halo that it reads redundantly.  The only collective is the OPTIONAL
-final assembly (`gather=True`): an all-gather of the output shards through torch.distributed — backend "nccl"
-is RCCL over xGMI on ROCm, "gloo" is used by the CPU tests.  Outputs stay sharded and device-resident by
-default (assembling config 4 would move 51.6 GB into every GPU: 30x the compute time).
+Frames of a stream are independent given their samples and channels (the reference's vectorized axes,
+lib/nx_signal.ex:358-363) are fully independent, so the path shards with NO exchange step: rank r owns a contiguous
+block of channels, or a contiguous range of frames of one long stream plus an (N - hop)-sample input halo that it
+reads redundantly.  The only collective is the OPTIONAL final assembly (`gather=True`): an RCCL all-gather over xGMI
+issued by libnxsig.so itself (csrc/group.cpp: ncclCommInitAll / ncclCommInitRank, ncclGroupStart/End, ncclAllGather or
+one ncclBroadcast per rank for unequal shards).  Outputs stay sharded and device-resident by default (assembling
+config 4 would move 51.6 GB into every GPU: 30x the compute time).
 
-The helpers below are pure index arithmetic (unit-tested without a GPU).
+`Group.local(n)`  — one process drives n GPUs (what the Elixir host does through the NIF);
+`Group.ranked()`  — one process per GPU under a launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (bench.py).
+
+The shard plans are pure index arithmetic computed by the C library (nxsig_shard_range / _frames / _fir) and are
+unit-tested without a GPU.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+
 import numpy as np
+
+from . import _lib
+from .device import Context, DeviceBuffer
+
+CHANNELS, FRAMES = _lib.SHARD_CHANNELS, _lib.SHARD_FRAMES
+_AXES = {"channels": CHANNELS, "frames": FRAMES, "samples": FRAMES}
+
+
+def _four(fn, *args):
+    out = [C.c_int64() for _ in range(4)]
+    _lib.check(fn(*args, *[C.byref(o) for o in out]))
+    return tuple(int(o.value) for o in out)
 
 
 def split_range(n: int, world: int, rank: int):
     """Contiguous near-equal split of range(n): the first n % world ranks get one extra item."""
-    if world < 1 or not (0 <= rank < world):
-        raise ValueError("bad world/rank")
-    base, extra = divmod(int(n), world)
-    start = rank * base + min(rank, extra)
-    return start, start + base + (1 if rank < extra else 0)
+    b, e = C.c_int64(), C.c_int64()
+    try:
+        _lib.check(_lib.load().nxsig_shard_range(int(n), int(world), int(rank), C.byref(b), C.byref(e)))
+    except _lib.ArgumentError as exc:
+        raise ValueError(str(exc)) from exc
+    return int(b.value), int(e.value)
 
 
 def shard_channels(n_channels: int, world: int, rank: int):
@@ -31,76 +52,167 @@ def shard_channels(n_channels: int, world: int, rank: int):
 def shard_frames(num_frames: int, frame_length: int, hop: int, world: int, rank: int):
     """Frame range [m0, m1) owned by `rank` of a :valid-framed stream and the input span [s0, s1) it needs:
     s0 = m0*hop, s1 = (m1-1)*hop + frame_length — neighbouring shards overlap by frame_length - hop samples (halo)."""
-    m0, m1 = split_range(num_frames, world, rank)
-    if m1 <= m0:
-        return m0, m1, m0 * hop, m0 * hop
-    return m0, m1, m0 * hop, (m1 - 1) * hop + frame_length
+    return _four(_lib.load().nxsig_shard_frames, int(num_frames), int(frame_length), int(hop), int(world), int(rank))
 
 
-def shard_fir(length: int, num_taps: int, world: int, rank: int):
-    """Output range [n0, n1) of a :same-mode FIR owned by `rank` and the input span [s0, s1) (clamped to the
-    signal) it needs: (taps-1)//2 samples of look-ahead and taps-1-(taps-1)//2 of history."""
-    n0, n1 = split_range(length, world, rank)
-    ahead = (num_taps - 1) // 2
-    behind = num_taps - 1 - ahead
-    return n0, n1, max(0, n0 - behind), min(length, n1 + ahead)
+def shard_fir(length: int, num_taps: int, world: int, rank: int, mode: str = "same"):
+    """Output range [n0, n1) of a FIR (convolution mode `mode`) owned by `rank` and the input span [s0, s1) (clamped to
+    the signal) it needs: num_taps - 1 samples of halo split between history and look-ahead by the mode's offset."""
+    m = {"full": _lib.CONV_FULL, "same": _lib.CONV_SAME, "valid": _lib.CONV_VALID}[mode]
+    return _four(_lib.load().nxsig_shard_fir, int(length), int(num_taps), m, int(world), int(rank))
 
 
-def stft_sharded(data, window, rank: int, world: int, axis: str = "channels", gather: bool = False, group=None,
-                 compute=None, **opts):
-    """Computes this rank's shard of NxSignal.stft(data, window, **opts) (window_padding must be "valid").
+def rendezvous_path(env=None) -> str:
+    """File through which rank 0 hands the ncclUniqueId to the other ranks of ONE node: unique per launch (the launcher's
+    pid and its rendezvous port), removed by rank 0 once the communicator is up."""
+    env = os.environ if env is None else env
+    d = env.get("NXSIG_RDZV_DIR", "/tmp")
+    return os.path.join(d, "nxsig_rdzv_%s_%s_%d" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
 
-    data: the FULL tensor [channels, L] (axis="channels") or [L] (axis="frames"); every rank slices its own part
-          (in production each rank loads only its slice; the slicing rules are shard_channels / shard_frames).
-    returns (z_local, (lo, hi)) or, with gather=True, the assembled full spectrum on every rank.
-    compute: the per-shard stft callable — defaults to the HIP path (nx_signal_amd.stft); the CPU gloo tests pass
-             a stand-in because no GPU exists there.
+
+class Group:
+    """nxsig_group: one context + stream per member GPU, RCCL communicators for the assembly."""
+
+    def __init__(self, handle):
+        self._lib = _lib.load()
+        self._h = handle
+        self.world = int(self._lib.nxsig_group_world(handle))
+        self.local_count = int(self._lib.nxsig_group_local_count(handle))
+        self.ranks = [int(self._lib.nxsig_group_rank(handle, i)) for i in range(self.local_count)]
+        self.contexts = [Context(_borrowed=self._lib.nxsig_group_ctx(handle, i)) for i in range(self.local_count)]
+        self.has_rccl = bool(self._lib.nxsig_group_has_rccl(handle))
+
+    @classmethod
+    def local(cls, n: int, devices=None) -> "Group":
+        lib = _lib.load()
+        h = C.c_void_p()
+        ids = None if devices is None else (C.c_int32 * n)(*[int(d) for d in devices])
+        _lib.check(lib.nxsig_group_create_local(int(n), ids, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def ranked(cls, world=None, rank=None, device=None, path=None, timeout_ms=120000) -> "Group":
+        world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else int(device)
+        path = rendezvous_path() if path is None else path
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.nxsig_group_create_rank(world, rank, device, path.encode(), int(timeout_ms), C.byref(h)))
+        return cls(h)
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise _lib.NxSignalDeviceError("group already destroyed")
+        return self._h
+
+    def barrier(self):
+        _lib.check(self._lib.nxsig_group_barrier(self.handle))
+
+    def allreduce(self, values, op="max"):
+        """element-wise max / sum of a few host doubles over the PROCESSES of the group"""
+        v = (C.c_double * len(values))(*[float(x) for x in values])
+        _lib.check(self._lib.nxsig_group_allreduce_f64(self.handle, v, len(values), 0 if op == "max" else 1))
+        return [float(x) for x in v]
+
+    def allgather(self, send_ptrs, counts_bytes, recv_ptrs):
+        n = self.local_count
+        s = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in send_ptrs])
+        r = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in recv_ptrs])
+        c = (C.c_int64 * self.world)(*[int(x) for x in counts_bytes])
+        _lib.check(self._lib.nxsig_group_allgather(self.handle, s, c, r))
+
+    def sync(self):
+        for c in self.contexts:
+            c.sync()
+
+    def close(self):
+        if self._h is not None:
+            for c in self.contexts:
+                c._h = None  # owned by the group
+            self._lib.nxsig_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _stft_params(window, opts):
+    from . import _resolve_stft_opts  # noqa: PLC0415
+
+    return _resolve_stft_opts(window, opts)
+
+
+def stft_sharded(group: Group, data, window, axis: str = "channels", gather: bool = False, **opts):
+    """NxSignal.stft(data, window, **opts) sharded over `group` (window_padding must be "valid").
+
+    data: host array [channels, L] / [L]  -> returns the assembled host spectrum c64[channels, M, K] / [M, K]
+          (per-shard downloads, or with gather=True the RCCL all-gather followed by one download; LOCAL groups), or
+          a list with one DeviceBuffer per LOCAL member holding that member's input shard (rows [c0, c1) or the sample
+          span [s0, s1) of every row; see shard_channels / shard_frames) together with `length=` and `batch=` of the
+          whole tensor -> returns the list of per-member output DeviceBuffers (shards, or full tensors with gather=True).
     """
-    if opts.get("window_padding", "valid") != "valid":
-        raise ValueError("sharded stft supports window_padding='valid' (padding belongs to the stream ends)")
-    if compute is None:
-        from . import stft as compute  # noqa: PLC0415
-    w = np.asarray(window)
-    N = int(w.shape[0])
-    overlap = opts.get("overlap_length")
-    hop = N - (N // 2 if overlap is None else int(overlap))
-    if axis == "channels":
-        c0, c1 = shard_channels(data.shape[0], world, rank)
-        z, _, _ = compute(data[c0:c1], window, **opts)
-        lo, hi = c0, c1
-    elif axis == "frames":
-        L = data.shape[-1]
-        M = (L - N) // hop + 1
-        m0, m1, s0, s1 = shard_frames(M, N, hop, world, rank)
-        z, _, _ = compute(data[..., s0:s1], window, **opts)
-        lo, hi = m0, m1
-    else:
-        raise ValueError("axis must be 'channels' or 'frames'")
-    if not gather:
-        return z, (lo, hi)
-    return all_gather_shards(z, lo, hi, rank, world, group=group), (lo, hi)
+    lib = _lib.load()
+    w = np.ascontiguousarray(window, dtype=np.float32)
+    length = opts.pop("length", None)
+    batch = opts.pop("batch", None)
+    p, N, hop, K = _stft_params(w, opts)
+    ax = _AXES[axis]
+    n = group.local_count
+    if isinstance(data, (list, tuple)) and data and isinstance(data[0], DeviceBuffer):
+        if length is None or batch is None:
+            raise _lib.ArgumentError("device shards need length= and batch= of the whole tensor")
+        M = int(_lib.check(lib.nxsig_num_frames(int(length), N, hop, _lib.PAD_VALID, 0, 0)))
+        outs = []
+        for i, r in enumerate(group.ranks):
+            if gather:
+                shape = (batch, M, K)
+            elif ax == CHANNELS:
+                c0, c1 = shard_channels(batch, group.world, r)
+                shape = (c1 - c0, M, K)
+            else:
+                m0, m1, _, _ = shard_frames(M, N, hop, group.world, r)
+                shape = (batch, m1 - m0, K)
+            outs.append(group.contexts[i].empty(shape, np.complex64))
+        stride = int(data[0].shape[-1])
+        xs = (C.c_void_p * n)(*[C.c_void_p(d.ptr) for d in data])
+        zs = (C.c_void_p * n)(*[C.c_void_p(o.ptr) for o in outs])
+        _lib.check(lib.nxsig_stft_sharded_f32(group.handle, xs, int(length), int(batch), stride, w.ctypes.data_as(C.c_void_p),
+                                              C.byref(p), ax, int(bool(gather)), zs, _lib.DEVICE))
+        return outs
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    squeeze = x.ndim == 1
+    x2 = x.reshape(1, -1) if squeeze else x.reshape(-1, x.shape[-1])
+    B, L = x2.shape
+    M = int(_lib.check(lib.nxsig_num_frames(L, N, hop, _lib.PAD_VALID, 0, 0)))
+    z = np.empty((B, M, K), np.complex64)
+    xs = (C.c_void_p * n)(*([x2.ctypes.data_as(C.c_void_p)] + [C.c_void_p(0)] * (n - 1)))
+    zs = (C.c_void_p * n)(*([z.ctypes.data_as(C.c_void_p)] + [C.c_void_p(0)] * (n - 1)))
+    _lib.check(lib.nxsig_stft_sharded_f32(group.handle, xs, L, B, L, w.ctypes.data_as(C.c_void_p), C.byref(p), ax,
+                                          int(bool(gather)), zs, _lib.HOST))
+    return z[0] if squeeze else z.reshape(x.shape[:-1] + (M, K))
 
 
-def all_gather_shards(z_local, lo: int, hi: int, rank: int, world: int, group=None):
-    """Final assembly: all-gather of unequal shards along axis 0 (RCCL when the tensors live on GPUs)."""
-    import torch
-    import torch.distributed as dist
-
-    t = z_local if isinstance(z_local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(z_local))
-    sizes = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device), group=group)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes)
-    if torch.is_complex(t):
-        tr = torch.view_as_real(t)
-    else:
-        tr = t
-    pad = torch.zeros((mx,) + tuple(tr.shape[1:]), dtype=tr.dtype, device=tr.device)
-    pad[: tr.shape[0]] = tr
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    parts = [b[:n] for b, n in zip(bufs, sizes)]
-    out = torch.cat(parts, dim=0)
-    if torch.is_complex(t):
-        out = torch.view_as_complex(out.contiguous())
-    return out if isinstance(z_local, torch.Tensor) else out.numpy()
+def fir_sharded(group: Group, data, taps, mode: str = "same", axis: str = "channels", gather: bool = False):
+    """Filters.fir (overlap-save FFT convolution, nxsig_fir_f32) of a host array [channels, L] / [L] sharded over `group`."""
+    lib = _lib.load()
+    h = np.ascontiguousarray(taps, dtype=np.float32)
+    m = {"full": _lib.CONV_FULL, "same": _lib.CONV_SAME, "valid": _lib.CONV_VALID}.get(mode)
+    if m is None:
+        raise _lib.ArgumentError("expected mode to be one of [:full, :same, :valid]")
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    squeeze = x.ndim == 1
+    x2 = x.reshape(1, -1) if squeeze else x.reshape(-1, x.shape[-1])
+    B, L = x2.shape
+    n_out = int(_lib.check(lib.nxsig_conv_length(L, h.shape[0], m)))
+    y = np.empty((B, n_out), np.float32)
+    n = group.local_count
+    xs = (C.c_void_p * n)(*([x2.ctypes.data_as(C.c_void_p)] + [C.c_void_p(0)] * (n - 1)))
+    ys = (C.c_void_p * n)(*([y.ctypes.data_as(C.c_void_p)] + [C.c_void_p(0)] * (n - 1)))
+    _lib.check(lib.nxsig_fir_sharded_f32(group.handle, xs, L, B, L, h.ctypes.data_as(C.c_void_p), int(h.shape[0]), m,
+                                         _AXES[axis], int(bool(gather)), ys, _lib.HOST))
+    return y[0] if squeeze else y.reshape(x.shape[:-1] + (n_out,))

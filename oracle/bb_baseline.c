@@ -95,6 +95,43 @@ int64_t bb_stft_f32(const float* x, int64_t L, const float* w, int32_t N, int32_
   return M;
 }
 
+/* Throughput leg for the all-cores baseline: the same per-frame work as bb_stft_f32 over `reps` passes of the stream
+ * (reps * M frames shared out statically over the threads), every thread with its own persistent scratch and, after the
+ * first pass, its own output row, so that thread start-up, first-touch page faults of a fresh result buffer and the
+ * serial framing pass do not dominate a short sample.  z c64[M][K] receives pass 0.  Returns reps * M. */
+int64_t bb_stft_f32_repeat(const float* x, int64_t L, const float* w, int32_t N, int32_t hop, int32_t K, double eps,
+                           float* z, int32_t reps, int32_t threads) {
+  if (L < N || N < 1 || hop < 1 || K < 1 || reps < 1) return -1;
+  const int64_t M = (L - N) / hop + 1;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#else
+  (void)threads;
+#endif
+  const int nuse = N < K ? N : K;
+  const int64_t total = (int64_t)reps * M;
+#pragma omp parallel
+  {
+    cplx* in = (cplx*)malloc((size_t)K * sizeof(cplx));
+    cplx* out = (cplx*)malloc((size_t)K * sizeof(cplx));
+    cplx* scratch = (cplx*)malloc((size_t)2 * K * sizeof(cplx) + 64);
+    float* frame = (float*)malloc((size_t)N * sizeof(float));
+    float* zt = (float*)malloc((size_t)K * 2 * sizeof(float));
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < total; ++i) {
+      const int64_t m = i % M;
+      for (int n = 0; n < N; ++n) frame[n] = x[m * hop + n] * w[n]; /* framing + f32 window product (:94-101) */
+      for (int n = 0; n < nuse; ++n) { in[n].re = (double)frame[n]; in[n].im = 0.0; }
+      for (int n = nuse; n < K; ++n) { in[n].re = 0.0; in[n].im = 0.0; }
+      bb_fft_rec(in, 1, K, out, scratch);
+      float* zr = i < M ? z + (size_t)m * K * 2 : zt;
+      for (int k = 0; k < K; ++k) { zr[2 * k] = bb_clean(out[k].re, eps); zr[2 * k + 1] = bb_clean(out[k].im, eps); }
+    }
+    free(in); free(out); free(scratch); free(frame); free(zt);
+  }
+  return total;
+}
+
 int bb_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

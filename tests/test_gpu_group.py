@@ -1,0 +1,175 @@
+"""Multi-GPU groups through the C ABI (include/nxsig.h "multi-GPU groups") on ONE GPU:
+
+  * a LOCAL group with two members on device 0 runs the HIP stft / fir under shard_channels / shard_frames and the result
+    equals the unsharded HIP result — bit for bit wherever the kernels see the same operands (channel shards; frame shards
+    that start on an even frame, because two adjacent frames share one complex transform), to 1e-6 otherwise;
+  * the assembly (nxsig_group_allgather) of unequal shards returns the full tensor on every member (device-to-device copies
+    when members share a device; RCCL when every member has its own GPU — exercised here with 1-member groups, which go
+    through ncclCommInitAll / ncclCommInitRank, ncclAllReduce, ncclAllGather for real);
+  * a RANKED group of world size 1 comes up without a rendezvous file.
+No torch anywhere in this path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import nx_oracle as O
+
+import nx_signal_amd as S
+from nx_signal_amd import _lib, sharding
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def pair():
+    g = sharding.Group.local(2, devices=[0, 0])
+    yield g
+    g.close()
+
+
+@pytest.fixture(scope="module")
+def solo():
+    g = sharding.Group.local(1)
+    yield g
+    g.close()
+
+
+def test_group_shapes(pair, solo):
+    assert pair.world == 2 and pair.local_count == 2 and pair.ranks == [0, 1] and not pair.has_rccl
+    assert solo.world == 1 and solo.local_count == 1 and solo.has_rccl  # ncclCommInitAll on one device
+    assert "gfx950" in pair.contexts[1].name()
+    pair.barrier()
+    solo.barrier()
+    assert solo.allreduce([1.5, -2.0], "max") == [1.5, -2.0]
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_stft_channel_shards_equal_unsharded_bit_for_bit(pair, gather):
+    x = np.stack([O.synth_signal(30000, seed=100 + c) for c in range(5)])  # 5 channels over 2 members: 3 + 2
+    w = S.windows.hann(1024)
+    opts = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)
+    full, _, _ = S.stft(x, w, **opts)
+    got = sharding.stft_sharded(pair, x, w, axis="channels", gather=gather, **opts)
+    assert got.shape == full.shape and np.array_equal(bits(got), bits(full))
+    zo, _, _ = O.stft(x[4], w, **opts)
+    assert float(np.max(np.abs(got[4] - zo)) / np.max(np.abs(zo))) < 1e-5
+
+
+@pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("L,N,hop", [(1024 + 256 * 199, 1024, 256), (1024 + 256 * 200, 1024, 256), (50000, 400, 160), (2048 + 512 * 37, 2048, 512)])
+def test_stft_frame_shards(pair, gather, L, N, hop):
+    x = O.synth_signal(L, seed=7)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N if N != 400 else 512, sampling_rate=16000)
+    full, _, _ = S.stft(x, w, **opts)
+    got = sharding.stft_sharded(pair, x, w, axis="frames", gather=gather, **opts)
+    assert got.shape == full.shape
+    M = full.shape[0]
+    m0, m1, s0, s1 = sharding.shard_frames(M, N, hop, 2, 1)
+    assert s1 == (M - 1) * hop + N and s0 == m0 * hop
+    if N == 1024 and m0 % 2 == 0:
+        assert np.array_equal(bits(got), bits(full))  # same frame pairs ride the same transforms
+    assert float(np.max(np.abs(got - full)) / np.max(np.abs(full))) < 1e-6
+    zo, _, _ = O.stft(x, w, **opts)
+    assert float(np.max(np.abs(got - zo)) / np.max(np.abs(zo))) < 1e-5
+
+
+def test_stft_device_shards_stay_on_their_device(pair):
+    """DEVICE mode: every member is handed its input shard in HBM and keeps its output shard there (no host round trip)"""
+    B, L, N, hop = 4, 20000, 512, 128
+    x = np.stack([O.synth_signal(L, seed=200 + c) for c in range(B)])
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=8000)
+    full, _, _ = S.stft(x, w, **opts)
+    shards = []
+    for i, r in enumerate(pair.ranks):
+        c0, c1 = sharding.shard_channels(B, pair.world, r)
+        shards.append(pair.contexts[i].to_device(x[c0:c1]))
+    outs = sharding.stft_sharded(pair, shards, w, axis="channels", length=L, batch=B, **opts)
+    pair.sync()
+    got = np.concatenate([o.numpy() for o in outs], axis=0)
+    assert np.array_equal(bits(got), bits(full))
+    # assembly in place: every member ends up with the whole tensor
+    outs = sharding.stft_sharded(pair, shards, w, axis="channels", gather=True, length=L, batch=B, **opts)
+    pair.sync()
+    for o in outs:
+        assert o.shape == full.shape and np.array_equal(bits(o.numpy()), bits(full))
+    # frame shards of one long stream, device-resident, assembled in place
+    x1 = x[0]
+    M = full.shape[1]
+    fsh = []
+    for i, r in enumerate(pair.ranks):
+        m0, m1, s0, s1 = sharding.shard_frames(M, N, hop, pair.world, r)
+        fsh.append(pair.contexts[i].to_device(x1[s0:s1].reshape(1, -1)))
+    outs = sharding.stft_sharded(pair, fsh, w, axis="frames", gather=True, length=L, batch=1, **opts)
+    pair.sync()
+    for o in outs:
+        assert float(np.max(np.abs(o.numpy()[0] - full[0])) / np.max(np.abs(full[0]))) < 1e-6
+
+
+def test_allgather_of_unequal_shards(pair, solo):
+    rng = np.random.default_rng(3)
+    parts = [rng.integers(0, 2 ** 31, size=n, dtype=np.int64).astype(np.uint32) for n in (1000, 37)]
+    want = np.concatenate(parts)
+    send = [pair.contexts[i].to_device(parts[i]) for i in range(2)]
+    recv = [pair.contexts[i].empty((want.size,), np.uint32) for i in range(2)]
+    pair.allgather([s.ptr for s in send], [p.nbytes for p in parts], [r.ptr for r in recv])
+    pair.sync()
+    for r in recv:
+        assert np.array_equal(r.numpy(), want)
+    # one member with a communicator: ncclAllGather of a single rank must reproduce the shard (out of place and in place)
+    s1 = solo.contexts[0].to_device(parts[0])
+    r1 = solo.contexts[0].empty((parts[0].size,), np.uint32)
+    solo.allgather([s1.ptr], [parts[0].nbytes], [r1.ptr])
+    solo.allgather([r1.ptr], [parts[0].nbytes], [r1.ptr])
+    solo.sync()
+    assert np.array_equal(r1.numpy(), parts[0])
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_solo_group_runs_the_rccl_assembly(solo, gather):
+    x = np.stack([O.synth_signal(9000, seed=300 + c) for c in range(3)])
+    w = S.windows.hann(256)
+    opts = dict(overlap_length=192, fft_length=256, sampling_rate=8000)
+    full, _, _ = S.stft(x, w, **opts)
+    got = sharding.stft_sharded(solo, x, w, axis="channels", gather=gather, **opts)
+    assert np.array_equal(bits(got), bits(full))
+    got = sharding.stft_sharded(solo, x[0], w, axis="frames", gather=gather, **opts)
+    assert np.array_equal(bits(got), bits(full[0]))
+
+
+@pytest.mark.parametrize("mode", ["same", "full", "valid"])
+def test_fir_shards(pair, mode):
+    x = np.stack([O.synth_signal(100000, seed=400 + c) for c in range(3)])
+    h = S.filters.firwin(257, [4000.0], sampling_rate=48000)
+    full = S.filters.fir(x, h, mode=mode)
+    got = sharding.fir_sharded(pair, x, h, mode=mode, axis="channels")
+    assert np.array_equal(bits(got), bits(full))
+    for gather in (False, True):
+        got1 = sharding.fir_sharded(pair, x[0], h, mode=mode, axis="samples", gather=gather)
+        assert got1.shape == full[0].shape
+        assert float(np.max(np.abs(got1 - full[0])) / np.max(np.abs(full[0]))) < 1e-6
+    ref = np.convolve(x[0].astype(np.float64), h.astype(np.float64), mode=mode)
+    assert float(np.max(np.abs(got1 - ref)) / np.max(np.abs(ref))) < 1e-5
+
+
+def test_ranked_group_of_one():
+    g = sharding.Group.ranked(world=1, rank=0, device=0, path="")
+    try:
+        assert g.world == 1 and g.has_rccl
+        g.barrier()
+        assert g.allreduce([3.0, 4.0], "max") == [3.0, 4.0]
+        assert g.allreduce([3.0], "sum") == [3.0]
+    finally:
+        g.close()
+
+
+def test_sharded_rejects_padding_modes(pair):
+    x = O.synth_signal(5000, seed=1)
+    with pytest.raises(_lib.ArgumentError, match="valid"):
+        sharding.stft_sharded(pair, x, S.windows.hann(64), axis="frames", window_padding="reflect")

@@ -98,6 +98,90 @@ def cpu_baseline(max_seconds: float):
     }
 
 
+def secondary_rooflines(ctx, lib, S, _lib, C):
+    """Rooflines of the other BASELINE configs at their FULL per-GPU shard, measured like the headline (HIP events on the
+    library's stream, one interval per launch, device-resident data; algorithmic bytes per SURVEY 8d):
+      config 3  istft N=1024 hop=256, 16 x 60 s            10 240 B/frame  (K*8 read + hop*8 written, c64 out)
+      config 4  stft  N=2048 hop=512, 8 ch x 600 s          18 432 B/frame  (one GPU's share of 64 channels)
+      config 5  fir   257 taps :same, 8 ch x 600 s          8 B/sample      (4 in + 4 out)"""
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(99))
+
+    def fill(buf, rows, n):
+        chunk = rng.standard_normal(n, dtype=np.float32)
+        for r in range(rows):  # one full-entropy stream, rolled per row
+            xr = np.roll(chunk, 977 * r)
+            _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(buf.ptr + r * n * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
+
+    def measure(fn, reps, warm):
+        for _ in range(warm):
+            fn()
+        ctx.sync()
+        ctx.timer_lap()
+        for _ in range(reps):
+            fn()
+            ctx.timer_lap()
+        return ctx.timer_laps()
+
+    def block(workload, kernel, nbytes, laps, extra):
+        ms = float(np.mean(laps))
+        ach = nbytes / (ms * 1e-3) / 1e9
+        d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+             "kernel_ms": ms, "kernel_us": {"min": round(min(laps) * 1e3, 1), "median": round(float(np.median(laps)) * 1e3, 1),
+                                            "max": round(max(laps) * 1e3, 1)}, "workload": workload, "kernel": kernel}
+        d.update(extra)
+        return d
+
+    # ---- config 3: istft of 16 x 60 s
+    try:
+        B3 = 16
+        w = S.windows.hann(N_FFT)
+        x3 = ctx.empty((B3, L), np.float32)
+        fill(x3, B3, L)
+        z3, _, _ = S.stft(x3, w, ctx=ctx, overlap_length=N_FFT - HOP, fft_length=N_FFT, sampling_rate=SR)
+        y3 = ctx.empty((B3, M * HOP + N_FFT - HOP), np.complex64)
+        p3 = _lib.StftParams(N_FFT, HOP, N_FFT, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
+        wp = w.ctypes.data_as(C.c_void_p)
+        laps = measure(lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(z3.ptr), M, B3, wp, C.byref(p3), C.c_void_p(y3.ptr), _lib.DEVICE)), 20, 30)
+        out["roofline_istft"] = block("config 3: istft N=1024 hop=256, 16 x 60 s mono 48 kHz, c64 out", "k_istft_wave<1024> (+ k_istft_edge_fix)",
+                                      B3 * M * (N_FFT * 8 + HOP * 8), laps, {"bytes_per_frame": N_FFT * 8 + HOP * 8, "frames_per_s": B3 * M / (float(np.mean(laps)) * 1e-3)})
+        # round trip of config 3 on interior samples (size-independent property): y ~ x
+        chk = np.empty(4096, np.complex64)
+        _lib.check(lib.nxsig_download(ctx.handle, chk.ctypes.data_as(C.c_void_p), C.c_void_p(y3.ptr + 8 * 100000), chk.nbytes))
+        ref = np.empty(4096, np.float32)
+        _lib.check(lib.nxsig_download(ctx.handle, ref.ctypes.data_as(C.c_void_p), C.c_void_p(x3.ptr + 4 * 100000), ref.nbytes))
+        out["roofline_istft"]["roundtrip_max_err"] = float(np.max(np.abs(chk.real - ref)) / np.max(np.abs(ref)))
+        for b in (x3, z3, y3):
+            b.free()
+    except Exception as e:  # noqa: BLE001
+        out["roofline_istft"] = {"error": repr(e)[:200]}
+    # ---- configs 4 / 5: one GPU's 8 channels x 10 min
+    try:
+        B4, L4, N4, H4 = 8, SR * 600, 2048, 512
+        M4 = (L4 - N4) // H4 + 1
+        x4 = ctx.empty((B4, L4), np.float32)
+        fill(x4, B4, L4)
+        w4 = S.windows.hann(N4)
+        z4 = ctx.empty((B4, M4, N4), np.complex64)
+        p4 = _lib.StftParams(N4, H4, N4, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
+        wp4 = w4.ctypes.data_as(C.c_void_p)
+        laps = measure(lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, wp4, C.byref(p4), C.c_void_p(z4.ptr), None, _lib.DEVICE)), 10, 15)
+        out["roofline_stft2048"] = block("config 4 (one GPU's shard of 64 channels): stft N=2048 hop=512, 8 ch x 600 s @48 kHz", "k_stft_wave<1024, real-2x>",
+                                         B4 * M4 * (H4 * 4 + N4 * 8), laps, {"bytes_per_frame": H4 * 4 + N4 * 8, "frames_per_s": B4 * M4 / (float(np.mean(laps)) * 1e-3)})
+        z4.free()
+        h = S.filters.firwin(257, [4000.0], sampling_rate=float(SR))
+        y5 = ctx.empty((B4, L4), np.float32)
+        hp = h.ctypes.data_as(C.c_void_p)
+        laps = measure(lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, hp, 257, _lib.CONV_SAME, C.c_void_p(y5.ptr), _lib.DEVICE)), 10, 15)
+        out["roofline_fir"] = block("config 5 (one GPU's shard): fir 257 taps :same (overlap-save), 8 ch x 600 s @48 kHz", "k_fir_wave<1024>",
+                                    B4 * L4 * 8, laps, {"bytes_per_sample": 8, "samples_per_s": B4 * L4 / (float(np.mean(laps)) * 1e-3)})
+        x4.free()
+        y5.free()
+    except Exception as e:  # noqa: BLE001
+        out["roofline_fir"] = out.get("roofline_fir") or {"error": repr(e)[:200]}
+    return out
+
+
 class FileControl:
     """Control plane of last resort for N > 1 when the RCCL communicator cannot be created: barrier and max-over-ranks
     through files on the node (nxsig_rendezvous_publish / _fetch).  No data moves through it; the measurement itself
@@ -171,6 +255,7 @@ def main():
     ap.add_argument("--streams", type=int, default=32, help="independent 60 s streams per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the roofline blocks of configs 3 / 4 / 5")
     ap.add_argument("--precondition", type=int, default=300,
                     help="max untimed launches spent settling the clocks before the warm-up steps (0 = none)")
     args = ap.parse_args()
@@ -368,6 +453,8 @@ def main():
             "max_norm_err_vs_oracle": verify,
             "device": ctx.name(),
         }
+        if world == 1 and not args.no_secondary:
+            out.update(secondary_rooflines(ctx, lib, S, _lib, C))
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         sys.stdout.flush()

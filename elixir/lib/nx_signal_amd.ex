@@ -1,15 +1,20 @@
 defmodule NxSignalAMD do
   @moduledoc """
-  Drop-in for the hot path of `NxSignal` on AMD Instinct MI355X: `stft/3`, `istft/3` (same option names,
-  defaults, return shapes and `ArgumentError`s as `NxSignal` v0.3.0 — lib/nx_signal.ex:68-130, :582-638),
-  plus `NxSignalAMD.Windows`, `NxSignalAMD.Filters.firwin/3` and the new `NxSignalAMD.Filters.fir/3`.
+  Drop-in for the hot path of `NxSignal` (v0.3.0) on AMD Instinct MI355X: `stft/3`, `istft/3`, `as_windowed/2`,
+  `overlap_and_add/2`, `fft_frequencies/2`, `mel_filters/4`, `stft_to_mel/3` — same names, option keys, defaults, return
+  shapes and `ArgumentError`s as the reference (lib/nx_signal.ex:68-130, :154-166, :249-364, :397-513, :582-736) —
+  plus `NxSignalAMD.Windows`, `NxSignalAMD.Filters`, `NxSignalAMD.Convolution`, device-resident tensors
+  (`NxSignalAMD.DeviceTensor`) and multi-GPU sharding (`NxSignalAMD.Sharded`).
 
-  The functions are ordinary `def`s over a dirty NIF (they cannot be traced inside someone else's `defn`);
-  tensors cross as `Nx.to_binary/1` payloads (f32 / c64, row-major, little-endian) or stay in HBM as
-  `NxSignalAMD.DeviceTensor` resources.  NOT compiled in the build image (no BEAM there) — INTEGRATION.md.
+  The functions are ordinary `def`s over a dirty NIF (they cannot be traced inside someone else's `defn`); tensors cross
+  as `Nx.to_binary/1` payloads (f32 / c64, row-major, little-endian) or stay in HBM as `NxSignalAMD.DeviceTensor`s.
+  Vectorized (multichannel) inputs keep their vectorized axes like the reference's (`lib/nx_signal.ex:358-363`).
+
+  The build image has no BEAM, so these modules are not compiled there; the NIF they call IS compiled and executed by
+  the test-suite against a stand-in term runtime (tests/test_nif_shim.py), with the term shapes used below.
   """
 
-  alias NxSignalAMD.NIF
+  alias NxSignalAMD.{DeviceTensor, NIF}
 
   @pad %{valid: 0, reflect: 1, same: 2}
   @scaling %{nil => 0, :spectrum => 1, :psd => 2}
@@ -29,8 +34,223 @@ defmodule NxSignalAMD do
     end
   end
 
-  @doc "See `NxSignal.stft/3`. Returns `{z, times, frequencies}` with `z :: c64[frames: M][frequencies: K]`."
-  def stft(data, window, opts \\ []) do
+  @doc """
+  See `NxSignal.stft/3`. Returns `{z, times, frequencies}` with `z :: c64[frames: M][frequencies: K]`.
+
+  `data` may be an `Nx.Tensor` (vectorized axes = channels, re-applied to `z`) or a `NxSignalAMD.DeviceTensor`
+  (then `z` is a `DeviceTensor` too and nothing leaves the GPU).
+  """
+  def stft(data, window, opts \\ [])
+
+  def stft(%DeviceTensor{type: {:f, 32}} = data, window, opts) do
+    {params, fft_length} = stft_params!(window, opts)
+    {batch_shape, length} = split_last(data.shape)
+    batch = Tuple.product(batch_shape)
+    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+    {:ok, zref, m} = NIF.stft_dev(data.ctx, data.ref, length, batch, w, params) |> unwrap!()
+    {t, f} = times_and_frequencies(params, m)
+
+    z = %DeviceTensor{
+      ref: zref,
+      ctx: data.ctx,
+      shape: append(batch_shape, [m, fft_length]),
+      type: {:c, 64},
+      names: List.duplicate(nil, tuple_size(batch_shape)) ++ [:frames, :frequencies]
+    }
+
+    {z, t, f}
+  end
+
+  def stft(%Nx.Tensor{} = data, window, opts) do
+    {params, fft_length} = stft_params!(window, opts)
+    {flat, vec_axes} = devectorize(data)
+    {batch_shape, length} = split_last(Nx.shape(flat))
+    batch = Tuple.product(batch_shape)
+    x = flat |> Nx.as_type(:f32) |> Nx.to_binary()
+    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+    {:ok, z, m, t, f} = NIF.stft(context(), x, length, batch, w, params) |> unwrap!()
+    names = List.duplicate(nil, tuple_size(batch_shape)) ++ [:frames, :frequencies]
+
+    z =
+      Nx.from_binary(z, :c64)
+      |> Nx.reshape(append(batch_shape, [m, fft_length]), names: names)
+      |> revectorize(vec_axes)
+
+    {z, Nx.from_binary(t, :f32) |> Nx.reshape({m}, names: [:frames]),
+     Nx.from_binary(f, :f32) |> Nx.reshape({fft_length}, names: [:frequencies])}
+  end
+
+  @doc "See `NxSignal.istft/3`. Returns a c64 tensor of length `M * hop + overlap_length` (complex, like the reference)."
+  def istft(data, window, opts)
+
+  def istft(%DeviceTensor{type: {:c, 64}} = data, window, opts) do
+    {params, _overlap, m, batch_shape} = istft_params!(data.shape, window, opts)
+    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+    {:ok, yref} = NIF.istft_dev(data.ctx, data.ref, m, Tuple.product(batch_shape), w, params) |> unwrap!()
+    out_len = m * elem(params, 1) + (elem(params, 0) - elem(params, 1))
+    %DeviceTensor{ref: yref, ctx: data.ctx, shape: append(batch_shape, [out_len]), type: {:c, 64}}
+  end
+
+  def istft(%Nx.Tensor{} = data, window, opts) do
+    {flat, vec_axes} = devectorize(data)
+    {params, _overlap, m, batch_shape} = istft_params!(Nx.shape(flat), window, opts)
+    z = flat |> Nx.as_type(:c64) |> Nx.to_binary()
+    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+    {:ok, y} = NIF.istft(context(), z, m, Tuple.product(batch_shape), w, params) |> unwrap!()
+    out_len = m * elem(params, 1) + (elem(params, 0) - elem(params, 1))
+    Nx.from_binary(y, :c64) |> Nx.reshape(append(batch_shape, [out_len])) |> revectorize(vec_axes)
+  end
+
+  @doc "See `NxSignal.as_windowed/2` (lib/nx_signal.ex:249-364): `{..., L}` -> `{..., M, window_length}`, bit-exact gather."
+  def as_windowed(%Nx.Tensor{} = tensor, opts \\ []) do
+    opts = Keyword.validate!(opts, [:window_length, padding: :valid, stride: 1])
+    window_length = opts[:window_length] || raise ArgumentError, "missing :window_length option"
+
+    stride =
+      case opts[:stride] do
+        [s] when is_integer(s) and s >= 1 -> s
+        s when is_integer(s) and s >= 1 -> s
+        s -> raise ArgumentError, "expected an integer >= 1 or a list of integers, got: #{inspect(s)}"
+      end
+
+    {pad_mode, lo, hi} = padding!(opts[:padding])
+    {flat, vec_axes} = devectorize(tensor)
+    {batch_shape, length} = split_last(Nx.shape(flat))
+    # a pure gather: 32-bit words travel untouched (bit-exact for f32 / s32 / u32); other integer types go through s32 when
+    # every value fits, so that no integer is ever rounded through f32
+    {words, word_type} = to_words32(flat)
+
+    {:ok, frames, m} =
+      NIF.as_windowed(context(), Nx.to_binary(words), length, Tuple.product(batch_shape), window_length, stride, pad_mode, lo, hi)
+      |> unwrap!()
+
+    Nx.from_binary(frames, word_type)
+    |> Nx.reshape(append(batch_shape, [m, window_length]))
+    |> Nx.as_type(Nx.type(tensor))
+    |> revectorize(vec_axes)
+  end
+
+  defp to_words32(t) do
+    case Nx.type(t) do
+      {:f, 32} -> {t, {:f, 32}}
+      {:s, 32} -> {t, {:s, 32}}
+      {:u, 32} -> {t, {:u, 32}}
+      {:f, 16} -> {Nx.as_type(t, :f32), {:f, 32}}
+      {:bf, 16} -> {Nx.as_type(t, :f32), {:f, 32}}
+      {kind, _} when kind in [:s, :u] ->
+        lo = t |> Nx.reduce_min() |> Nx.to_number()
+        hi = t |> Nx.reduce_max() |> Nx.to_number()
+
+        if lo < -2_147_483_648 or hi > 2_147_483_647 do
+          raise ArgumentError, "as_windowed: integer values beyond 32 bits are not supported by the MI355X path"
+        end
+
+        {Nx.as_type(t, :s32), {:s, 32}}
+
+      other ->
+        raise ArgumentError, "as_windowed: unsupported tensor type #{inspect(other)}"
+    end
+  end
+
+  @doc "See `NxSignal.overlap_and_add/2` (lib/nx_signal.ex:684-736): `{..., M, N}` -> `{..., M * hop + overlap_length}`."
+  def overlap_and_add(%Nx.Tensor{} = tensor, opts \\ []) do
+    opts = Keyword.validate!(opts, [:overlap_length, type: Nx.type(tensor)])
+    overlap_length = opts[:overlap_length] || raise ArgumentError, "missing :overlap_length option"
+    {flat, vec_axes} = devectorize(tensor)
+    shape = Nx.shape(flat)
+    rank = tuple_size(shape)
+    {m, n} = {elem(shape, rank - 2), elem(shape, rank - 1)}
+    batch_shape = shape |> Tuple.delete_at(rank - 1) |> Tuple.delete_at(rank - 2)
+
+    {bin_type, components} =
+      case Nx.Type.normalize!(opts[:type]) do
+        {:c, _} -> {:c64, 2}
+        _ -> {:f32, 1}
+      end
+
+    frames = flat |> Nx.as_type(bin_type) |> Nx.to_binary()
+
+    {:ok, out} =
+      NIF.overlap_and_add(context(), frames, m, Tuple.product(batch_shape), n, overlap_length, components) |> unwrap!()
+
+    out_len = m * (n - overlap_length) + overlap_length
+
+    Nx.from_binary(out, bin_type)
+    |> Nx.reshape(append(batch_shape, [out_len]))
+    |> Nx.as_type(opts[:type])
+    |> revectorize(vec_axes)
+  end
+
+  @doc "See `NxSignal.fft_frequencies/2` (lib/nx_signal.ex:154-166)."
+  def fft_frequencies(sampling_rate, opts \\ []) do
+    opts = Keyword.validate!(opts, [:fft_length, :name, type: {:f, 32}, endpoint: false])
+    fft_length = opts[:fft_length] || raise ArgumentError, "missing :fft_length option"
+    {:ok, bin} = NIF.fft_frequencies(sampling_rate * 1.0, fft_length, if(opts[:endpoint], do: 1, else: 0)) |> unwrap!()
+    Nx.from_binary(bin, :f32) |> Nx.reshape({fft_length}, names: [opts[:name]]) |> Nx.as_type(opts[:type])
+  end
+
+  @doc "See `NxSignal.mel_filters/4` (lib/nx_signal.ex:397-445): `f32[mels: mel_bins][frequencies: fft_length]`."
+  def mel_filters(fft_length, mel_bins, sampling_rate, opts \\ []) do
+    opts = Keyword.validate!(opts, max_mel: 3016, mel_frequency_spacing: 200 / 3, type: {:f, 32})
+
+    {:ok, bin} =
+      NIF.mel_filters(fft_length, mel_bins, sampling_rate * 1.0, opts[:max_mel] * 1.0, opts[:mel_frequency_spacing] * 1.0)
+      |> unwrap!()
+
+    Nx.from_binary(bin, :f32) |> Nx.reshape({mel_bins, fft_length}, names: [:mels, :frequencies]) |> Nx.as_type(opts[:type])
+  end
+
+  @doc "See `NxSignal.stft_to_mel/3` (lib/nx_signal.ex:486-513): `c64[frames][frequencies]` -> `f32[frames][mel]`."
+  def stft_to_mel(%Nx.Tensor{} = z, sampling_rate, opts \\ []) do
+    opts = Keyword.validate!(opts, [:fft_length, :mel_bins, :max_mel, :mel_frequency_spacing, type: {:f, 32}])
+    {flat, vec_axes} = devectorize(z)
+    shape = Nx.shape(flat)
+    rank = tuple_size(shape)
+    {m, k} = {elem(shape, rank - 2), elem(shape, rank - 1)}
+    fft_length = opts[:fft_length] || k
+    mel_bins = opts[:mel_bins] || raise ArgumentError, "missing :mel_bins option"
+    batch_shape = shape |> Tuple.delete_at(rank - 1) |> Tuple.delete_at(rank - 2)
+    mel_opts = Keyword.take(opts, [:max_mel, :mel_frequency_spacing]) |> Keyword.reject(fn {_, v} -> is_nil(v) end)
+    filters = mel_filters(fft_length, mel_bins, sampling_rate, mel_opts) |> Nx.to_binary()
+    rows = Tuple.product(batch_shape) * m
+    zb = flat |> Nx.as_type(:c64) |> Nx.to_binary()
+    {:ok, out} = NIF.stft_to_mel(context(), zb, rows, fft_length, mel_bins, filters) |> unwrap!()
+
+    Nx.from_binary(out, :f32)
+    |> Nx.reshape(append(batch_shape, [m, mel_bins]), names: List.duplicate(nil, tuple_size(batch_shape)) ++ [:frames, :mel])
+    |> Nx.as_type(opts[:type])
+    |> revectorize(vec_axes)
+  end
+
+  @doc """
+  Fused `stft/3 |> stft_to_mel/3`: the log-mel spectrogram without writing the complex spectrum to HBM
+  (`mel_bins * 4` bytes per frame leave the chip instead of `fft_length * 8`). Returns `f32[..., frames, mel]`.
+  """
+  def mel_spectrogram(%Nx.Tensor{} = data, window, opts \\ []) do
+    {mel_opts, stft_opts} = Keyword.split(opts, [:mel_bins, :max_mel, :mel_frequency_spacing])
+    mel_bins = mel_opts[:mel_bins] || raise ArgumentError, "missing :mel_bins option"
+    {params, fft_length} = stft_params!(window, stft_opts)
+    filters = mel_filters(fft_length, mel_bins, elem(params, 7), Keyword.delete(mel_opts, :mel_bins)) |> Nx.to_binary()
+    {flat, vec_axes} = devectorize(data)
+    {batch_shape, length} = split_last(Nx.shape(flat))
+    x = flat |> Nx.as_type(:f32) |> Nx.to_binary()
+    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+
+    {:ok, out, m} =
+      NIF.stft_mel(context(), x, length, Tuple.product(batch_shape), w, params, mel_bins, filters) |> unwrap!()
+
+    Nx.from_binary(out, :f32) |> Nx.reshape(append(batch_shape, [m, mel_bins])) |> revectorize(vec_axes)
+  end
+
+  # ------------------------------------------------------------------------------------------ shared helpers
+  @doc false
+  def unwrap!({:error, {-1, msg}}), do: raise(ArgumentError, msg)
+  def unwrap!({:error, {code, msg}}), do: raise(RuntimeError, "nxsig status #{code}: #{msg}")
+  def unwrap!(ok), do: ok
+
+  @doc false
+  # option parsing / defaults of NxSignal.stft/3 (lib/nx_signal.ex:71-85; quirks B1-B3 of SURVEY App. B)
+  def stft_params!(window, opts) do
     {frame_length} = Nx.shape(window)
 
     opts =
@@ -48,27 +268,10 @@ defmodule NxSignalAMD do
     fft_length = resolve_fft_length(opts[:fft_length], frame_length)
     {pad_mode, lo, hi} = padding!(opts[:window_padding])
     scaling = scaling!(opts[:scaling])
-    {batch_shape, length} = split_last(Nx.shape(data))
-    batch = Tuple.product(batch_shape)
-
-    params =
-      {frame_length, frame_length - overlap_length, fft_length, pad_mode, lo, hi, scaling, sampling_rate * 1.0}
-
-    x = data |> Nx.as_type(:f32) |> Nx.to_binary()
-    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
-
-    {:ok, z, m, t, f} = NIF.stft(context(), x, length, batch, w, params) |> unwrap!()
-
-    z_shape = batch_shape |> Tuple.insert_at(tuple_size(batch_shape), m) |> Tuple.insert_at(tuple_size(batch_shape) + 1, fft_length)
-    names = List.duplicate(nil, tuple_size(batch_shape)) ++ [:frames, :frequencies]
-
-    {Nx.from_binary(z, :c64) |> Nx.reshape(z_shape, names: names),
-     Nx.from_binary(t, :f32) |> Nx.reshape({m}, names: [:frames]),
-     Nx.from_binary(f, :f32) |> Nx.reshape({fft_length}, names: [:frequencies])}
+    {{frame_length, frame_length - overlap_length, fft_length, pad_mode, lo, hi, scaling, sampling_rate * 1.0}, fft_length}
   end
 
-  @doc "See `NxSignal.istft/3`. Returns a c64 tensor of length `M * hop + overlap_length`."
-  def istft(data, window, opts) do
+  defp istft_params!(shape, window, opts) do
     opts = Keyword.validate!(opts, [:fft_length, :overlap_length, :scaling, sampling_rate: 1000])
     {frame_length} = Nx.shape(window)
     overlap_length = opts[:overlap_length] || div(frame_length, 2)
@@ -83,24 +286,28 @@ defmodule NxSignalAMD do
             "overlap_length must be a number less than the window size #{frame_length}, got: #{inspect(frame_length)}"
     end
 
-    shape = Nx.shape(data)
     rank = tuple_size(shape)
     {m, k} = {elem(shape, rank - 2), elem(shape, rank - 1)}
     batch_shape = shape |> Tuple.delete_at(rank - 1) |> Tuple.delete_at(rank - 2)
-    batch = Tuple.product(batch_shape)
     fft_length = resolve_fft_length(opts[:fft_length] || :power_of_two, k)
     params = {frame_length, frame_length - overlap_length, fft_length, 0, 0, 0, scaling, (opts[:sampling_rate] || 0) * 1.0}
-    z = data |> Nx.as_type(:c64) |> Nx.to_binary()
-    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
-    {:ok, y} = NIF.istft(context(), z, m, batch, w, params) |> unwrap!()
-    out_len = m * (frame_length - overlap_length) + overlap_length
-    Nx.from_binary(y, :c64) |> Nx.reshape(Tuple.insert_at(batch_shape, tuple_size(batch_shape), out_len))
+    {params, overlap_length, m, batch_shape}
   end
 
-  @doc false
-  def unwrap!({:error, {-1, msg}}), do: raise(ArgumentError, msg)
-  def unwrap!({:error, {code, msg}}), do: raise(RuntimeError, "nxsig status #{code}: #{msg}")
-  def unwrap!(ok), do: ok
+  defp times_and_frequencies({frame_length, _hop, fft_length, _pad, _lo, _hi, _scaling, fs}, m) do
+    # times = linspace(N / (2 fs), M N / (2 fs), n: M) (lib/nx_signal.ex:108-111, quirk B4), f32 arithmetic like the reference
+    step = frame_length / (2 * fs)
+    times = Nx.linspace(step, step * m, n: m, name: :frames, type: :f32)
+    {times, fft_frequencies(fs, fft_length: fft_length, name: :frequencies)}
+  end
+
+  # vectorized axes = channels: flatten them into leading axes for the NIF, re-apply them to the result
+  defp devectorize(%Nx.Tensor{vectorized_axes: []} = t), do: {t, []}
+  defp devectorize(%Nx.Tensor{vectorized_axes: axes} = t), do: {Nx.devectorize(t, keep_names: false), axes}
+  defp revectorize(t, []), do: t
+  defp revectorize(t, axes), do: Nx.vectorize(t, axes)
+
+  defp append(shape, dims), do: Enum.reduce(dims, shape, fn d, acc -> Tuple.insert_at(acc, tuple_size(acc), d) end)
 
   defp resolve_fft_length(:power_of_two, n), do: next_pow2(n, 1)
   defp resolve_fft_length(k, _n) when is_integer(k) and k >= 1, do: k
@@ -111,13 +318,14 @@ defmodule NxSignalAMD do
   defp next_pow2(n, p) when p >= n, do: p
   defp next_pow2(n, p), do: next_pow2(n, p * 2)
 
-  defp padding!(mode) when is_map_key(@pad, mode), do: {@pad[mode], 0, 0}
-  defp padding!([{lo, hi}]) when is_integer(lo) and is_integer(hi), do: {3, lo, hi}
+  @doc false
+  def padding!(mode) when is_map_key(@pad, mode), do: {@pad[mode], 0, 0}
+  def padding!([{lo, hi}]) when is_integer(lo) and is_integer(hi), do: {3, lo, hi}
 
-  defp padding!(mode) when is_list(mode),
+  def padding!(mode) when is_list(mode),
     do: raise(ArgumentError, "padding must be a list of {high, low} tuples, where each element is an integer. Got: #{inspect(mode)}")
 
-  defp padding!(mode),
+  def padding!(mode),
     do:
       raise(
         ArgumentError,
@@ -129,7 +337,8 @@ defmodule NxSignalAMD do
   defp scaling!(s),
     do: raise(ArgumentError, "invalid :scaling, expected one of :spectrum, :psd or nil, got: #{inspect(s)}")
 
-  defp split_last(shape) do
+  @doc false
+  def split_last(shape) do
     r = tuple_size(shape)
     {Tuple.delete_at(shape, r - 1), elem(shape, r - 1)}
   end

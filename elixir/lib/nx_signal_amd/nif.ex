@@ -1,7 +1,8 @@
 defmodule NxSignalAMD.NIF do
   @moduledoc false
-  # Thin loader of nif/nxsig_nif.c.  Every function is replaced at load time; the bodies below only run when
-  # the shared object is missing.
+  # Thin loader of nif/nxsig_nif.c.  Every function is replaced at load time; the bodies below only run when the
+  # shared object is missing.  Names and arities must equal the `funcs[]` table of the shim
+  # (tests/test_nif_shim.py::test_nif_ex_matches_the_shim_table checks both directions).
   @on_load :load_nif
 
   def load_nif do
@@ -9,15 +10,44 @@ defmodule NxSignalAMD.NIF do
     :erlang.load_nif(path, 0)
   end
 
+  def device_count(), do: :erlang.nif_error(:nif_not_loaded)
   def ctx_create(_device), do: :erlang.nif_error(:nif_not_loaded)
+  def sync(_ctx), do: :erlang.nif_error(:nif_not_loaded)
   def window(_kind, _n, _periodic, _beta, _eps), do: :erlang.nif_error(:nif_not_loaded)
   def firwin(_taps, _cutoff, _kind, _beta, _pass_zero, _scale, _fs), do: :erlang.nif_error(:nif_not_loaded)
+  def fft_frequencies(_fs, _fft_length, _endpoint), do: :erlang.nif_error(:nif_not_loaded)
+  def mel_filters(_fft_length, _mel_bins, _fs, _max_mel, _spacing), do: :erlang.nif_error(:nif_not_loaded)
+  def sinc(_t), do: :erlang.nif_error(:nif_not_loaded)
   def stft(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft(_ctx, _z, _frames, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def fir(_ctx, _x, _length, _batch, _taps, _mode), do: :erlang.nif_error(:nif_not_loaded)
+
+  def as_windowed(_ctx, _x, _length, _batch, _window_length, _stride, _pad_mode, _lo, _hi),
+    do: :erlang.nif_error(:nif_not_loaded)
+
+  def overlap_and_add(_ctx, _frames, _num_frames, _batch, _frame_length, _overlap, _components),
+    do: :erlang.nif_error(:nif_not_loaded)
+
+  def fft(_ctx, _in, _is_real, _rows, _n_in, _fft_length, _inverse), do: :erlang.nif_error(:nif_not_loaded)
+  def fftconvolve_c64(_ctx, _a, _b, _mode), do: :erlang.nif_error(:nif_not_loaded)
+  def stft_to_mel(_ctx, _z, _rows, _fft_length, _mel_bins, _filters), do: :erlang.nif_error(:nif_not_loaded)
+
+  def stft_mel(_ctx, _x, _length, _batch, _window, _params, _mel_bins, _filters),
+    do: :erlang.nif_error(:nif_not_loaded)
+
   def to_device(_ctx, _bin), do: :erlang.nif_error(:nif_not_loaded)
   def from_device(_buf), do: :erlang.nif_error(:nif_not_loaded)
+  def buf_size(_buf), do: :erlang.nif_error(:nif_not_loaded)
   def stft_dev(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft_dev(_ctx, _z, _frames, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def fir_dev(_ctx, _x, _length, _batch, _taps, _mode), do: :erlang.nif_error(:nif_not_loaded)
   def spectrum_mul_dev(_ctx, _z, _rows, _fft_length, _h), do: :erlang.nif_error(:nif_not_loaded)
+  def group_create(_devices), do: :erlang.nif_error(:nif_not_loaded)
+  def group_info(_group), do: :erlang.nif_error(:nif_not_loaded)
+
+  def stft_sharded(_group, _x, _length, _batch, _window, _params, _axis, _gather),
+    do: :erlang.nif_error(:nif_not_loaded)
+
+  def fir_sharded(_group, _x, _length, _batch, _taps, _mode, _axis, _gather),
+    do: :erlang.nif_error(:nif_not_loaded)
 end

@@ -1,19 +1,25 @@
 /*
  * nxsig_nif.c — dirty-NIF shim between the BEAM and the C ABI in include/nxsig.h.
  *
- * NOT COMPILED IN THIS IMAGE: erl_nif.h (Erlang/OTP) is absent and there is no elixir/erl/mix toolchain, so this
- * file is the reference-side binding a maintainer adds; nif/Makefile builds it only when
- * `erl` is found.  It is deliberately mechanical: every function unpacks terms, calls ONE nxsig_* entry point and
- * packs the result; all logic lives behind the C ABI where it is tested (tests/ drive the same entry points
- * through ctypes).
+ * The build image has no Erlang/OTP (no erl, no erl_nif.h), so nif/Makefile builds this file only where `erl` is
+ * found.  It is nevertheless compiled and EXECUTED by the test-suite: tests/stub/erl_nif.h declares the subset of the NIF
+ * API used here and tests/stub/erl_nif_fake.c is a miniature term runtime, so tests/test_nif_shim.py (CPU: host generators,
+ * argument validation; GPU: stft / istft / fir / device chains / sharded calls) calls these functions exactly as the BEAM
+ * would (entry->funcs[i].fptr(env, argc, argv)) and compares with the ctypes path bit for bit.
+ *
+ * The shim is deliberately mechanical: every function unpacks terms, validates sizes BEFORE allocating, calls ONE
+ * nxsig_* entry point and packs the result; all logic lives behind the C ABI.
  *
  * Conventions:
  *   - every GPU call is a dirty job (ERL_NIF_DIRTY_JOB_IO_BOUND: the scheduler thread waits on the GPU);
- *   - inputs are borrowed binaries (enif_inspect_binary, read-only, valid for the call), host outputs are
- *     BEAM-owned binaries (enif_make_new_binary), device tensors are resource objects whose destructor frees HBM;
- *   - errors come back as {:error, {code, message}}; nothing throws, aborts or longjmps across the boundary;
- *   - the context resource owns one GPU + one HIP stream; libnxsig serialises calls per context internally, so
- *     dirty schedulers may call concurrently from any OS thread.
+ *   - inputs are borrowed binaries (enif_inspect_binary, read-only, valid for the call); host outputs are BEAM-owned
+ *     binaries (enif_alloc_binary, which can FAIL without taking the VM down, then enif_make_binary); device tensors are
+ *     resource objects whose destructor frees HBM;
+ *   - errors come back as {:error, {code, message}} (code -1 = ArgumentError on the Elixir side); malformed terms are
+ *     badarg; nothing throws, aborts or longjmps across the boundary;
+ *   - a context resource owns one GPU + one HIP stream; libnxsig serialises calls per context internally, so dirty
+ *     schedulers may call concurrently from any OS thread;
+ *   - a group resource owns one context per member GPU and the RCCL communicators (nxsig_group_create_local).
  */
 #include <erl_nif.h>
 #include <stdint.h>
@@ -23,9 +29,11 @@
 
 static ErlNifResourceType* CTX_RES;
 static ErlNifResourceType* BUF_RES;
+static ErlNifResourceType* GRP_RES;
 
 typedef struct { nxsig_ctx* ctx; } ctx_res_t;
 typedef struct { ctx_res_t* owner; void* dptr; size_t bytes; } buf_res_t;
+typedef struct { nxsig_group* grp; } grp_res_t;
 
 static void ctx_dtor(ErlNifEnv* env, void* obj) { (void)env; ctx_res_t* r = obj; if (r->ctx) nxsig_ctx_destroy(r->ctx); }
 static void buf_dtor(ErlNifEnv* env, void* obj) {
@@ -34,21 +42,51 @@ static void buf_dtor(ErlNifEnv* env, void* obj) {
   if (b->dptr && b->owner && b->owner->ctx) nxsig_free(b->owner->ctx, b->dptr);
   if (b->owner) enif_release_resource(b->owner);
 }
+static void grp_dtor(ErlNifEnv* env, void* obj) { (void)env; grp_res_t* g = obj; if (g->grp) nxsig_group_destroy(g->grp); }
 
 static ERL_NIF_TERM mk_atom(ErlNifEnv* env, const char* a) { return enif_make_atom(env, a); }
-static ERL_NIF_TERM mk_error(ErlNifEnv* env, int code) {
-  const char* msg = nxsig_last_error();
-  ERL_NIF_TERM m;
+static ERL_NIF_TERM mk_error_msg(ErlNifEnv* env, int code, const char* msg) {
+  ErlNifBinary b;
   size_t n = msg ? strlen(msg) : 0;
-  unsigned char* p = enif_make_new_binary(env, n, &m);
-  if (n) memcpy(p, msg, n);
+  ERL_NIF_TERM m;
+  if (enif_alloc_binary(n, &b)) { if (n) memcpy(b.data, msg, n); m = enif_make_binary(env, &b); }
+  else m = mk_atom(env, "enomem");
   return enif_make_tuple2(env, mk_atom(env, "error"), enif_make_tuple2(env, enif_make_int(env, code), m));
 }
+static ERL_NIF_TERM mk_error(ErlNifEnv* env, int code) { return mk_error_msg(env, code, nxsig_last_error()); }
+static ERL_NIF_TERM mk_oom(ErlNifEnv* env) { return mk_error_msg(env, NXSIG_ERR_OOM, "cannot allocate the result binary"); }
 static ERL_NIF_TERM mk_ok(ErlNifEnv* env, ERL_NIF_TERM v) { return enif_make_tuple2(env, mk_atom(env, "ok"), v); }
 
-static int get_ctx(ErlNifEnv* env, ERL_NIF_TERM t, ctx_res_t** out) { return enif_get_resource(env, t, CTX_RES, (void**)out); }
+/* result binaries: enif_alloc_binary reports failure instead of aborting the VM; sizes are overflow-checked */
+static int mul_size(size_t* acc, uint64_t f) {
+  if (f != 0 && *acc > (size_t)-1 / f) return 0;
+  *acc *= (size_t)f;
+  return 1;
+}
+static int out_bin(ErlNifBinary* b, uint64_t a, uint64_t c, uint64_t d, uint64_t elem) {
+  size_t n = 1;
+  if (!mul_size(&n, a) || !mul_size(&n, c) || !mul_size(&n, d) || !mul_size(&n, elem)) return 0;
+  if (n > ((size_t)1 << 46)) return 0; /* 64 TiB: far beyond any host; keeps a bad shape from reaching the allocator */
+  return enif_alloc_binary(n, b);
+}
 
-/* {n, hop, k, pad_mode, pad_lo, pad_hi, scaling, sampling_rate} -> nxsig_stft_params */
+static int get_ctx(ErlNifEnv* env, ERL_NIF_TERM t, ctx_res_t** out) {
+  return enif_get_resource(env, t, CTX_RES, (void**)out) && (*out)->ctx != NULL;
+}
+static int get_buf(ErlNifEnv* env, ERL_NIF_TERM t, buf_res_t** out) { return enif_get_resource(env, t, BUF_RES, (void**)out); }
+static int get_grp(ErlNifEnv* env, ERL_NIF_TERM t, grp_res_t** out) {
+  return enif_get_resource(env, t, GRP_RES, (void**)out) && (*out)->grp != NULL;
+}
+/* Elixir numbers arrive as floats or integers */
+static int get_number(ErlNifEnv* env, ERL_NIF_TERM t, double* d) {
+  ErlNifSInt64 i;
+  if (enif_get_double(env, t, d)) return 1;
+  if (enif_get_int64(env, t, &i)) { *d = (double)i; return 1; }
+  return 0;
+}
+
+/* {n, hop, k, pad_mode, pad_lo, pad_hi, scaling, sampling_rate} -> nxsig_stft_params; geometry is validated here so that
+ * no size below is computed from a non-positive length (a negative fft_length reached enif_make_new_binary) */
 static int get_params(ErlNifEnv* env, ERL_NIF_TERM t, nxsig_stft_params* p) {
   const ERL_NIF_TERM* e;
   int arity;
@@ -58,15 +96,32 @@ static int get_params(ErlNifEnv* env, ERL_NIF_TERM t, nxsig_stft_params* p) {
   if (!enif_get_tuple(env, t, &arity, &e) || arity != 8) return 0;
   if (!enif_get_int(env, e[0], &n) || !enif_get_int(env, e[1], &hop) || !enif_get_int(env, e[2], &k) ||
       !enif_get_int(env, e[3], &pad) || !enif_get_int64(env, e[4], &lo) || !enif_get_int64(env, e[5], &hi) ||
-      !enif_get_int(env, e[6], &scal) || !enif_get_double(env, e[7], &fs))
+      !enif_get_int(env, e[6], &scal) || !get_number(env, e[7], &fs))
     return 0;
+  if (n < 1 || k < 1) return 0;
   memset(p, 0, sizeof *p);
   p->frame_length = n; p->hop = hop; p->fft_length = k; p->pad_mode = pad; p->pad_lo = lo; p->pad_hi = hi;
   p->scaling = scal; p->sampling_rate = fs;
   return 1;
 }
 
-/* ctx_create(device) */
+static ERL_NIF_TERM make_buf(ErlNifEnv* env, ctx_res_t* c, void* d, size_t bytes) {
+  buf_res_t* r = enif_alloc_resource(BUF_RES, sizeof *r);
+  r->owner = c; enif_keep_resource(c); r->dptr = d; r->bytes = bytes;
+  ERL_NIF_TERM t = enif_make_resource(env, r);
+  enif_release_resource(r);
+  return t;
+}
+
+/* ------------------------------------------------------------------------------------------------ contexts */
+static ERL_NIF_TERM nif_device_count(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  (void)argv;
+  int n = 0;
+  if (argc != 0) return enif_make_badarg(env);
+  int rc = nxsig_device_count(&n);
+  return rc ? mk_error(env, rc) : mk_ok(env, enif_make_int(env, n));
+}
+
 static ERL_NIF_TERM nif_ctx_create(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   int dev;
   if (argc != 1 || !enif_get_int(env, argv[0], &dev)) return enif_make_badarg(env);
@@ -80,17 +135,26 @@ static ERL_NIF_TERM nif_ctx_create(ErlNifEnv* env, int argc, const ERL_NIF_TERM 
   return mk_ok(env, t);
 }
 
-/* window(kind, n, periodic, beta, eps) -> {:ok, f32 binary}   (host-side generator, BinaryBackend rounding) */
+static ERL_NIF_TERM nif_sync(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  if (argc != 1 || !get_ctx(env, argv[0], &c)) return enif_make_badarg(env);
+  int rc = nxsig_sync(c->ctx);
+  return rc ? mk_error(env, rc) : mk_atom(env, "ok");
+}
+
+/* ------------------------------------------------------------------------------------------------ host generators */
+/* window(kind, n, periodic, beta, eps) -> {:ok, f32 binary}   (NxSignal.Windows.*, BinaryBackend rounding) */
 static ERL_NIF_TERM nif_window(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   int kind, n, per;
   double beta, eps;
   if (argc != 5 || !enif_get_int(env, argv[0], &kind) || !enif_get_int(env, argv[1], &n) || !enif_get_int(env, argv[2], &per) ||
-      !enif_get_double(env, argv[3], &beta) || !enif_get_double(env, argv[4], &eps) || n < 0)
+      !get_number(env, argv[3], &beta) || !get_number(env, argv[4], &eps) || n < 0)
     return enif_make_badarg(env);
-  ERL_NIF_TERM out;
-  float* w = (float*)enif_make_new_binary(env, (size_t)n * 4, &out);
-  int rc = nxsig_window_f32(kind, n, per, beta, eps, w);
-  return rc ? mk_error(env, rc) : mk_ok(env, out);
+  ErlNifBinary b;
+  if (!out_bin(&b, (uint64_t)n, 1, 1, 4)) return mk_oom(env);
+  int rc = nxsig_window_f32(kind, n, per, beta, eps, (float*)b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &b));
 }
 
 /* firwin(num_taps, [cutoff], window_kind, beta, pass_zero, scale, sampling_rate) */
@@ -99,83 +163,247 @@ static ERL_NIF_TERM nif_firwin(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
   double beta, fs, cut[64];
   unsigned len;
   if (argc != 7 || !enif_get_int(env, argv[0], &taps) || !enif_get_list_length(env, argv[1], &len) || len > 64 ||
-      !enif_get_int(env, argv[2], &kind) || !enif_get_double(env, argv[3], &beta) || !enif_get_int(env, argv[4], &pz) ||
-      !enif_get_int(env, argv[5], &sc) || !enif_get_double(env, argv[6], &fs) || taps < 1)
+      !enif_get_int(env, argv[2], &kind) || !get_number(env, argv[3], &beta) || !enif_get_int(env, argv[4], &pz) ||
+      !enif_get_int(env, argv[5], &sc) || !get_number(env, argv[6], &fs) || taps < 1)
     return enif_make_badarg(env);
   ERL_NIF_TERM head, tail = argv[1];
-  for (unsigned i = 0; i < len; ++i) {
-    if (!enif_get_list_cell(env, tail, &head, &tail) || !enif_get_double(env, head, &cut[i])) return enif_make_badarg(env);
-  }
-  ERL_NIF_TERM out;
-  float* h = (float*)enif_make_new_binary(env, (size_t)taps * 4, &out);
-  int rc = nxsig_firwin_f32(taps, cut, (int)len, kind, beta, pz, sc, fs, h);
-  return rc ? mk_error(env, rc) : mk_ok(env, out);
+  for (unsigned i = 0; i < len; ++i)
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !get_number(env, head, &cut[i])) return enif_make_badarg(env);
+  ErlNifBinary b;
+  if (!out_bin(&b, (uint64_t)taps, 1, 1, 4)) return mk_oom(env);
+  int rc = nxsig_firwin_f32(taps, cut, (int)len, kind, beta, pz, sc, fs, (float*)b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &b));
 }
 
+/* fft_frequencies(sampling_rate, fft_length, endpoint) -> {:ok, f32 binary}   (lib/nx_signal.ex:154-166) */
+static ERL_NIF_TERM nif_fft_frequencies(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  double fs;
+  int k, endpoint;
+  if (argc != 3 || !get_number(env, argv[0], &fs) || !enif_get_int(env, argv[1], &k) || !enif_get_int(env, argv[2], &endpoint) || k < 1)
+    return enif_make_badarg(env);
+  ErlNifBinary b;
+  if (!out_bin(&b, (uint64_t)k, 1, 1, 4)) return mk_oom(env);
+  int rc = nxsig_fft_frequencies_f32(fs, k, endpoint, (float*)b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &b));
+}
+
+/* mel_filters(fft_length, mel_bins, sampling_rate, max_mel, mel_frequency_spacing) -> {:ok, f32[mel_bins][fft_length]} (:397-445) */
+static ERL_NIF_TERM nif_mel_filters(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  int k, bins;
+  double fs, max_mel, sp;
+  if (argc != 5 || !enif_get_int(env, argv[0], &k) || !enif_get_int(env, argv[1], &bins) || !get_number(env, argv[2], &fs) ||
+      !get_number(env, argv[3], &max_mel) || !get_number(env, argv[4], &sp) || k < 1 || bins < 1)
+    return enif_make_badarg(env);
+  ErlNifBinary b;
+  if (!out_bin(&b, (uint64_t)k, (uint64_t)bins, 1, 4)) return mk_oom(env);
+  int rc = nxsig_mel_filters_f32(k, bins, fs, max_mel, sp, (float*)b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &b));
+}
+
+/* sinc(t_bin) -> {:ok, f32 binary}   (lib/nx_signal/waveforms.ex:451-457) */
+static ERL_NIF_TERM nif_sinc(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ErlNifBinary t, b;
+  if (argc != 1 || !enif_inspect_binary(env, argv[0], &t) || t.size % 4) return enif_make_badarg(env);
+  if (!out_bin(&b, t.size / 4, 1, 1, 4)) return mk_oom(env);
+  int rc = nxsig_sinc_f32((const float*)t.data, (int64_t)(t.size / 4), (float*)b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &b));
+}
+
+/* ------------------------------------------------------------------------------------------------ hot path, host tensors */
 /* stft(ctx, x_bin, length, batch, window_bin, params) -> {:ok, z_bin, num_frames, times_bin, freqs_bin} */
 static ERL_NIF_TERM nif_stft(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
-  ErlNifBinary x, w;
+  ErlNifBinary x, w, zb, tb, fb;
   ErlNifSInt64 length;
   int batch;
   nxsig_stft_params p;
   if (argc != 6 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
       !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p))
     return enif_make_badarg(env);
-  if (batch < 1 || length < 1 || x.size != (size_t)batch * (size_t)length * 4 || w.size != (size_t)p.frame_length * 4)
+  if (batch < 1 || length < 1 || x.size / 4 / (size_t)batch != (size_t)length || x.size % 4 || w.size != (size_t)p.frame_length * 4)
     return enif_make_badarg(env);
   int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
   if (m < 0) return mk_error(env, (int)m);
-  ERL_NIF_TERM zt, tt, ft;
-  nxsig_c64* z = (nxsig_c64*)enif_make_new_binary(env, (size_t)batch * (size_t)m * (size_t)p.fft_length * 8, &zt);
-  int rc = nxsig_stft_f32(c->ctx, (const float*)x.data, length, batch, length, (const float*)w.data, &p, z, NULL, NXSIG_HOST);
-  if (rc) return mk_error(env, rc);
-  float* t = (float*)enif_make_new_binary(env, (size_t)m * 4, &tt);
-  float* f = (float*)enif_make_new_binary(env, (size_t)p.fft_length * 4, &ft);
-  if ((rc = nxsig_stft_times_f32(p.frame_length, p.sampling_rate, m, t))) return mk_error(env, rc);
-  if ((rc = nxsig_fft_frequencies_f32(p.sampling_rate, p.fft_length, 0, f))) return mk_error(env, rc);
-  return enif_make_tuple5(env, mk_atom(env, "ok"), zt, enif_make_int64(env, m), tt, ft);
+  if (!out_bin(&zb, (uint64_t)batch, (uint64_t)m, (uint64_t)p.fft_length, 8)) return mk_oom(env);
+  int rc = nxsig_stft_f32(c->ctx, (const float*)x.data, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)zb.data, NULL, NXSIG_HOST);
+  if (rc) { enif_release_binary(&zb); return mk_error(env, rc); }
+  if (!out_bin(&tb, (uint64_t)m, 1, 1, 4)) { enif_release_binary(&zb); return mk_oom(env); }
+  if (!out_bin(&fb, (uint64_t)p.fft_length, 1, 1, 4)) { enif_release_binary(&zb); enif_release_binary(&tb); return mk_oom(env); }
+  if ((rc = nxsig_stft_times_f32(p.frame_length, p.sampling_rate, m, (float*)tb.data)) ||
+      (rc = nxsig_fft_frequencies_f32(p.sampling_rate, p.fft_length, 0, (float*)fb.data))) {
+    enif_release_binary(&zb); enif_release_binary(&tb); enif_release_binary(&fb);
+    return mk_error(env, rc);
+  }
+  return enif_make_tuple5(env, mk_atom(env, "ok"), enif_make_binary(env, &zb), enif_make_int64(env, m), enif_make_binary(env, &tb),
+                          enif_make_binary(env, &fb));
 }
 
 /* istft(ctx, z_bin, num_frames, batch, window_bin, params) -> {:ok, y_bin} */
 static ERL_NIF_TERM nif_istft(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
-  ErlNifBinary z, w;
+  ErlNifBinary z, w, yb;
   ErlNifSInt64 m;
   int batch;
   nxsig_stft_params p;
   if (argc != 6 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &z) || !enif_get_int64(env, argv[2], &m) ||
       !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p))
     return enif_make_badarg(env);
-  if (batch < 1 || m < 1 || z.size != (size_t)batch * (size_t)m * (size_t)p.fft_length * 8 || w.size != (size_t)p.frame_length * 4)
+  if (batch < 1 || m < 1 || z.size % 8 || z.size / 8 / (size_t)batch / (size_t)m != (size_t)p.fft_length ||
+      z.size / 8 % ((size_t)batch * (size_t)m) || w.size != (size_t)p.frame_length * 4)
     return enif_make_badarg(env);
   int64_t n = nxsig_ola_length(m, p.frame_length, p.hop);
   if (n < 0) return mk_error(env, (int)n);
-  ERL_NIF_TERM yt;
-  nxsig_c64* y = (nxsig_c64*)enif_make_new_binary(env, (size_t)batch * (size_t)n * 8, &yt);
-  int rc = nxsig_istft_c64(c->ctx, (const nxsig_c64*)z.data, m, batch, (const float*)w.data, &p, y, NXSIG_HOST);
-  return rc ? mk_error(env, rc) : mk_ok(env, yt);
+  if (!out_bin(&yb, (uint64_t)batch, (uint64_t)n, 1, 8)) return mk_oom(env);
+  int rc = nxsig_istft_c64(c->ctx, (const nxsig_c64*)z.data, m, batch, (const float*)w.data, &p, (nxsig_c64*)yb.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&yb); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &yb));
 }
 
-/* fir(ctx, x_bin, length, batch, taps_bin, mode) -> {:ok, y_bin} */
+/* fir(ctx, x_bin, length, batch, taps_bin, mode) -> {:ok, y_bin}   (Convolution.convolve(method: :fft), real 1-D rows) */
 static ERL_NIF_TERM nif_fir(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
-  ErlNifBinary x, h;
+  ErlNifBinary x, h, yb;
   ErlNifSInt64 length;
   int batch, mode;
   if (argc != 6 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
       !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &h) || !enif_get_int(env, argv[5], &mode))
     return enif_make_badarg(env);
-  if (batch < 1 || length < 1 || x.size != (size_t)batch * (size_t)length * 4 || h.size < 4 || h.size % 4) return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || x.size % 4 || x.size / 4 / (size_t)batch != (size_t)length || h.size < 4 || h.size % 4 ||
+      h.size / 4 > 0x7fffffff)
+    return enif_make_badarg(env);
   int64_t n = nxsig_conv_length(length, (int64_t)(h.size / 4), mode);
   if (n < 0) return mk_error(env, (int)n);
-  ERL_NIF_TERM yt;
-  float* y = (float*)enif_make_new_binary(env, (size_t)batch * (size_t)n * 4, &yt);
-  int rc = nxsig_fir_f32(c->ctx, (const float*)x.data, length, batch, length, (const float*)h.data, (int)(h.size / 4), mode, y, NXSIG_HOST);
-  return rc ? mk_error(env, rc) : mk_ok(env, yt);
+  if (!out_bin(&yb, (uint64_t)batch, (uint64_t)n, 1, 4)) return mk_oom(env);
+  int rc = nxsig_fir_f32(c->ctx, (const float*)x.data, length, batch, length, (const float*)h.data, (int)(h.size / 4), mode,
+                         (float*)yb.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&yb); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &yb));
 }
 
-/* ---- device-resident tensors: keep stft -> edit -> istft chains in HBM ---- */
+/* as_windowed(ctx, x_bin, length, batch, window_length, stride, pad_mode, pad_lo, pad_hi) -> {:ok, frames_bin, num_frames} */
+static ERL_NIF_TERM nif_as_windowed(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary x, ob;
+  ErlNifSInt64 length, lo, hi;
+  int batch, wl, stride, pad;
+  if (argc != 9 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_get_int(env, argv[4], &wl) || !enif_get_int(env, argv[5], &stride) ||
+      !enif_get_int(env, argv[6], &pad) || !enif_get_int64(env, argv[7], &lo) || !enif_get_int64(env, argv[8], &hi))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || x.size % 4 || x.size / 4 / (size_t)batch != (size_t)length) return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, wl, stride, pad, lo, hi);
+  if (m < 0) return mk_error(env, (int)m);
+  if (!out_bin(&ob, (uint64_t)batch, (uint64_t)m, (uint64_t)wl, 4)) return mk_oom(env);
+  int rc = nxsig_as_windowed_f32(c->ctx, (const float*)x.data, length, batch, length, wl, stride, pad, lo, hi, (float*)ob.data, NULL, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), enif_make_binary(env, &ob), enif_make_int64(env, m));
+}
+
+/* overlap_and_add(ctx, frames_bin, num_frames, batch, frame_length, overlap_length, components) -> {:ok, out_bin} */
+static ERL_NIF_TERM nif_overlap_and_add(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary f, ob;
+  ErlNifSInt64 m;
+  int batch, n, overlap, comps;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &f) || !enif_get_int64(env, argv[2], &m) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_get_int(env, argv[4], &n) || !enif_get_int(env, argv[5], &overlap) ||
+      !enif_get_int(env, argv[6], &comps))
+    return enif_make_badarg(env);
+  if (batch < 1 || m < 1 || n < 1 || (comps != 1 && comps != 2) || f.size % ((size_t)4 * (size_t)comps) ||
+      f.size / 4 / (size_t)comps / (size_t)batch / (size_t)m != (size_t)n || f.size / 4 / (size_t)comps % ((size_t)batch * (size_t)m))
+    return enif_make_badarg(env);
+  /* the reference's own check (lib/nx_signal.ex:692-695) must surface as ArgumentError, not badarg: let the library say it */
+  int64_t out_len = (overlap >= 0 && overlap < n) ? m * (int64_t)(n - overlap) + overlap : 1;
+  if (!out_bin(&ob, (uint64_t)batch, (uint64_t)out_len, (uint64_t)comps, 4)) return mk_oom(env);
+  int rc = nxsig_overlap_and_add(c->ctx, (const float*)f.data, m, batch, n, overlap, comps, (float*)ob.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &ob));
+}
+
+/* fft(ctx, in_bin, in_is_real, rows, n_in, fft_length, inverse) -> {:ok, c64 binary}   (Nx.fft / Nx.ifft over the last axis) */
+static ERL_NIF_TERM nif_fft(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary in, ob;
+  ErlNifSInt64 rows;
+  int is_real, n_in, k, inv;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &in) || !enif_get_int(env, argv[2], &is_real) ||
+      !enif_get_int64(env, argv[3], &rows) || !enif_get_int(env, argv[4], &n_in) || !enif_get_int(env, argv[5], &k) ||
+      !enif_get_int(env, argv[6], &inv))
+    return enif_make_badarg(env);
+  const size_t es = is_real ? 4 : 8;
+  if (rows < 1 || n_in < 1 || k < 1 || in.size % es || in.size / es / (size_t)rows != (size_t)n_in || in.size / es % (size_t)rows)
+    return enif_make_badarg(env);
+  if (!out_bin(&ob, (uint64_t)rows, (uint64_t)k, 1, 8)) return mk_oom(env);
+  int rc = nxsig_fft(c->ctx, in.data, is_real, rows, n_in, k, inv, (nxsig_c64*)ob.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &ob));
+}
+
+/* fftconvolve_c64(ctx, a_bin, b_bin, mode) -> {:ok, c64 binary}   (1-D complex case of Convolution.fftconvolve/3) */
+static ERL_NIF_TERM nif_fftconvolve_c64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary a, b, ob;
+  int mode;
+  if (argc != 4 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &a) || !enif_inspect_binary(env, argv[2], &b) ||
+      !enif_get_int(env, argv[3], &mode) || a.size < 8 || b.size < 8 || a.size % 8 || b.size % 8)
+    return enif_make_badarg(env);
+  int64_t n = nxsig_conv_length((int64_t)(a.size / 8), (int64_t)(b.size / 8), mode);
+  if (n < 0) return mk_error(env, (int)n);
+  if (!out_bin(&ob, (uint64_t)n, 1, 1, 8)) return mk_oom(env);
+  int rc = nxsig_fftconvolve_c64(c->ctx, (const nxsig_c64*)a.data, (int64_t)(a.size / 8), (const nxsig_c64*)b.data, (int64_t)(b.size / 8), mode,
+                                 (nxsig_c64*)ob.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &ob));
+}
+
+/* stft_to_mel(ctx, z_bin, rows, fft_length, mel_bins, filters_bin) -> {:ok, f32[rows][mel_bins]}   (lib/nx_signal.ex:486-513) */
+static ERL_NIF_TERM nif_stft_to_mel(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary z, f, ob;
+  ErlNifSInt64 rows;
+  int k, bins;
+  if (argc != 6 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &z) || !enif_get_int64(env, argv[2], &rows) ||
+      !enif_get_int(env, argv[3], &k) || !enif_get_int(env, argv[4], &bins) || !enif_inspect_binary(env, argv[5], &f))
+    return enif_make_badarg(env);
+  if (rows < 1 || k < 1 || bins < 1 || z.size % 8 || z.size / 8 / (size_t)rows != (size_t)k || z.size / 8 % (size_t)rows ||
+      f.size % 4 || f.size / 4 / (size_t)bins != (size_t)k || f.size / 4 % (size_t)bins)
+    return enif_make_badarg(env);
+  if (!out_bin(&ob, (uint64_t)rows, (uint64_t)bins, 1, 4)) return mk_oom(env);
+  int rc = nxsig_stft_to_mel(c->ctx, (const nxsig_c64*)z.data, rows, k, bins, (const float*)f.data, (float*)ob.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &ob));
+}
+
+/* stft_mel(ctx, x_bin, length, batch, window_bin, params, mel_bins, filters_bin) -> {:ok, f32[batch][M][mel_bins], M}  (fused) */
+static ERL_NIF_TERM nif_stft_mel(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary x, w, f, ob;
+  ErlNifSInt64 length;
+  int batch, bins;
+  nxsig_stft_params p;
+  if (argc != 8 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p) ||
+      !enif_get_int(env, argv[6], &bins) || !enif_inspect_binary(env, argv[7], &f))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || bins < 1 || x.size % 4 || x.size / 4 / (size_t)batch != (size_t)length ||
+      w.size != (size_t)p.frame_length * 4 || f.size % 4 || f.size / 4 / (size_t)bins != (size_t)p.fft_length || f.size / 4 % (size_t)bins)
+    return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
+  if (m < 0) return mk_error(env, (int)m);
+  if (!out_bin(&ob, (uint64_t)batch, (uint64_t)m, (uint64_t)bins, 4)) return mk_oom(env);
+  int rc = nxsig_stft_mel_f32(c->ctx, (const float*)x.data, length, batch, length, (const float*)w.data, &p, bins, (const float*)f.data,
+                              (float*)ob.data, NULL, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), enif_make_binary(env, &ob), enif_make_int64(env, m));
+}
+
+/* ------------------------------------------------------------------------------------------------ device-resident tensors
+ * keep stft -> edit -> istft chains in HBM (guides/filtering.livemd:137-159).  Device calls are
+ * asynchronous on the context's stream; from_device synchronises. */
 static ERL_NIF_TERM nif_to_device(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
   ErlNifBinary b;
@@ -184,23 +412,26 @@ static ERL_NIF_TERM nif_to_device(ErlNifEnv* env, int argc, const ERL_NIF_TERM a
   int rc = nxsig_alloc(c->ctx, b.size, &d);
   if (rc) return mk_error(env, rc);
   if ((rc = nxsig_upload(c->ctx, d, b.data, b.size))) { nxsig_free(c->ctx, d); return mk_error(env, rc); }
-  buf_res_t* r = enif_alloc_resource(BUF_RES, sizeof *r);
-  r->owner = c; enif_keep_resource(c); r->dptr = d; r->bytes = b.size;
-  ERL_NIF_TERM t = enif_make_resource(env, r);
-  enif_release_resource(r);
-  return mk_ok(env, t);
+  return mk_ok(env, make_buf(env, c, d, b.size));
 }
 
 static ERL_NIF_TERM nif_from_device(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   buf_res_t* b;
-  if (argc != 1 || !enif_get_resource(env, argv[0], BUF_RES, (void**)&b)) return enif_make_badarg(env);
-  ERL_NIF_TERM out;
-  unsigned char* p = enif_make_new_binary(env, b->bytes, &out);
-  int rc = nxsig_download(b->owner->ctx, p, b->dptr, b->bytes);
-  return rc ? mk_error(env, rc) : mk_ok(env, out);
+  ErlNifBinary ob;
+  if (argc != 1 || !get_buf(env, argv[0], &b)) return enif_make_badarg(env);
+  if (!enif_alloc_binary(b->bytes, &ob)) return mk_oom(env);
+  int rc = nxsig_download(b->owner->ctx, ob.data, b->dptr, b->bytes);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &ob));
 }
 
-/* stft_dev(ctx, x_buf, length, batch, window_bin, params) -> {:ok, z_buf, num_frames}  (asynchronous on the ctx stream) */
+static ERL_NIF_TERM nif_buf_size(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  buf_res_t* b;
+  if (argc != 1 || !get_buf(env, argv[0], &b)) return enif_make_badarg(env);
+  return enif_make_int64(env, (ErlNifSInt64)b->bytes);
+}
+
+/* stft_dev(ctx, x_buf, length, batch, window_bin, params) -> {:ok, z_buf, num_frames} */
 static ERL_NIF_TERM nif_stft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
   buf_res_t* x;
@@ -208,25 +439,21 @@ static ERL_NIF_TERM nif_stft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
   ErlNifSInt64 length;
   int batch;
   nxsig_stft_params p;
-  if (argc != 6 || !get_ctx(env, argv[0], &c) || !enif_get_resource(env, argv[1], BUF_RES, (void**)&x) ||
-      !enif_get_int64(env, argv[2], &length) || !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) ||
-      !get_params(env, argv[5], &p))
+  if (argc != 6 || !get_ctx(env, argv[0], &c) || !get_buf(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p))
     return enif_make_badarg(env);
-  if (batch < 1 || length < 1 || x->bytes < (size_t)batch * (size_t)length * 4 || w.size != (size_t)p.frame_length * 4)
+  if (batch < 1 || length < 1 || x->owner != c || x->bytes / 4 / (size_t)batch < (size_t)length || w.size != (size_t)p.frame_length * 4)
     return enif_make_badarg(env);
   int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
   if (m < 0) return mk_error(env, (int)m);
-  size_t zbytes = (size_t)batch * (size_t)m * (size_t)p.fft_length * 8;
+  size_t zbytes = 8;
+  if (!mul_size(&zbytes, (uint64_t)batch) || !mul_size(&zbytes, (uint64_t)m) || !mul_size(&zbytes, (uint64_t)p.fft_length)) return mk_oom(env);
   void* z = NULL;
   int rc = nxsig_alloc(c->ctx, zbytes, &z);
   if (rc) return mk_error(env, rc);
   rc = nxsig_stft_f32(c->ctx, (const float*)x->dptr, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)z, NULL, NXSIG_DEVICE);
   if (rc) { nxsig_free(c->ctx, z); return mk_error(env, rc); }
-  buf_res_t* r = enif_alloc_resource(BUF_RES, sizeof *r);
-  r->owner = c; enif_keep_resource(c); r->dptr = z; r->bytes = zbytes;
-  ERL_NIF_TERM t = enif_make_resource(env, r);
-  enif_release_resource(r);
-  return enif_make_tuple3(env, mk_atom(env, "ok"), t, enif_make_int64(env, m));
+  return enif_make_tuple3(env, mk_atom(env, "ok"), make_buf(env, c, z, zbytes), enif_make_int64(env, m));
 }
 
 /* istft_dev(ctx, z_buf, num_frames, batch, window_bin, params) -> {:ok, y_buf} */
@@ -237,24 +464,48 @@ static ERL_NIF_TERM nif_istft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM a
   ErlNifSInt64 m;
   int batch;
   nxsig_stft_params p;
-  if (argc != 6 || !get_ctx(env, argv[0], &c) || !enif_get_resource(env, argv[1], BUF_RES, (void**)&z) ||
-      !enif_get_int64(env, argv[2], &m) || !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) ||
-      !get_params(env, argv[5], &p))
+  if (argc != 6 || !get_ctx(env, argv[0], &c) || !get_buf(env, argv[1], &z) || !enif_get_int64(env, argv[2], &m) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p))
     return enif_make_badarg(env);
-  if (batch < 1 || m < 1 || z->bytes < (size_t)batch * (size_t)m * (size_t)p.fft_length * 8) return enif_make_badarg(env);
+  /* the window binary is read by the library: its size must match (a short window was read out of bounds) */
+  if (batch < 1 || m < 1 || z->owner != c || w.size != (size_t)p.frame_length * 4 ||
+      z->bytes / 8 / (size_t)batch / (size_t)m < (size_t)p.fft_length)
+    return enif_make_badarg(env);
   int64_t n = nxsig_ola_length(m, p.frame_length, p.hop);
   if (n < 0) return mk_error(env, (int)n);
-  size_t ybytes = (size_t)batch * (size_t)n * 8;
+  size_t ybytes = 8;
+  if (!mul_size(&ybytes, (uint64_t)batch) || !mul_size(&ybytes, (uint64_t)n)) return mk_oom(env);
   void* y = NULL;
   int rc = nxsig_alloc(c->ctx, ybytes, &y);
   if (rc) return mk_error(env, rc);
   rc = nxsig_istft_c64(c->ctx, (const nxsig_c64*)z->dptr, m, batch, (const float*)w.data, &p, (nxsig_c64*)y, NXSIG_DEVICE);
   if (rc) { nxsig_free(c->ctx, y); return mk_error(env, rc); }
-  buf_res_t* r = enif_alloc_resource(BUF_RES, sizeof *r);
-  r->owner = c; enif_keep_resource(c); r->dptr = y; r->bytes = ybytes;
-  ERL_NIF_TERM t = enif_make_resource(env, r);
-  enif_release_resource(r);
-  return mk_ok(env, t);
+  return mk_ok(env, make_buf(env, c, y, ybytes));
+}
+
+/* fir_dev(ctx, x_buf, length, batch, taps_bin, mode) -> {:ok, y_buf, out_length} */
+static ERL_NIF_TERM nif_fir_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  buf_res_t* x;
+  ErlNifBinary h;
+  ErlNifSInt64 length;
+  int batch, mode;
+  if (argc != 6 || !get_ctx(env, argv[0], &c) || !get_buf(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &h) || !enif_get_int(env, argv[5], &mode))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || x->owner != c || x->bytes / 4 / (size_t)batch < (size_t)length || h.size < 4 || h.size % 4 ||
+      h.size / 4 > 0x7fffffff)
+    return enif_make_badarg(env);
+  int64_t n = nxsig_conv_length(length, (int64_t)(h.size / 4), mode);
+  if (n < 0) return mk_error(env, (int)n);
+  size_t ybytes = 4;
+  if (!mul_size(&ybytes, (uint64_t)batch) || !mul_size(&ybytes, (uint64_t)n)) return mk_oom(env);
+  void* y = NULL;
+  int rc = nxsig_alloc(c->ctx, ybytes, &y);
+  if (rc) return mk_error(env, rc);
+  rc = nxsig_fir_f32(c->ctx, (const float*)x->dptr, length, batch, length, (const float*)h.data, (int)(h.size / 4), mode, (float*)y, NXSIG_DEVICE);
+  if (rc) { nxsig_free(c->ctx, y); return mk_error(env, rc); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), make_buf(env, c, y, ybytes), enif_make_int64(env, n));
 }
 
 /* spectrum_mul_dev(ctx, z_buf, rows, fft_length, h_bin) -> {:ok, z_buf}   (in place: Nx.multiply(z, hfft), guides/filtering.livemd:141) */
@@ -264,34 +515,130 @@ static ERL_NIF_TERM nif_spectrum_mul_dev(ErlNifEnv* env, int argc, const ERL_NIF
   ErlNifBinary h;
   ErlNifSInt64 rows;
   int k;
-  if (argc != 5 || !get_ctx(env, argv[0], &c) || !enif_get_resource(env, argv[1], BUF_RES, (void**)&z) ||
-      !enif_get_int64(env, argv[2], &rows) || !enif_get_int(env, argv[3], &k) || !enif_inspect_binary(env, argv[4], &h))
+  if (argc != 5 || !get_ctx(env, argv[0], &c) || !get_buf(env, argv[1], &z) || !enif_get_int64(env, argv[2], &rows) ||
+      !enif_get_int(env, argv[3], &k) || !enif_inspect_binary(env, argv[4], &h))
     return enif_make_badarg(env);
-  if (rows < 0 || k < 1 || h.size != (size_t)k * 8 || z->bytes < (size_t)rows * (size_t)k * 8) return enif_make_badarg(env);
+  if (rows < 1 || k < 1 || z->owner != c || h.size != (size_t)k * 8 || z->bytes / 8 / (size_t)rows < (size_t)k) return enif_make_badarg(env);
   int rc = nxsig_spectrum_mul_c64(c->ctx, (const nxsig_c64*)z->dptr, rows, k, (const nxsig_c64*)h.data, (nxsig_c64*)z->dptr, NXSIG_DEVICE);
   return rc ? mk_error(env, rc) : mk_ok(env, argv[1]);
+}
+
+/* ------------------------------------------------------------------------------------------------ multi-GPU groups
+ * One BEAM process drives every GPU of the node: a LOCAL group (ncclCommInitAll).  The vectorized (multichannel) axis of the
+ * reference (lib/nx_signal.ex:358-363) is what `axis = 0` shards. */
+/* group_create([device_id]) -> {:ok, group} */
+static ERL_NIF_TERM nif_group_create(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  unsigned len;
+  int32_t devs[64];
+  if (argc != 1 || !enif_get_list_length(env, argv[0], &len) || len < 1 || len > 64) return enif_make_badarg(env);
+  ERL_NIF_TERM head, tail = argv[0];
+  for (unsigned i = 0; i < len; ++i) {
+    int d;
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !enif_get_int(env, head, &d)) return enif_make_badarg(env);
+    devs[i] = d;
+  }
+  nxsig_group* g = NULL;
+  int rc = nxsig_group_create_local((int32_t)len, devs, &g);
+  if (rc) return mk_error(env, rc);
+  grp_res_t* r = enif_alloc_resource(GRP_RES, sizeof *r);
+  r->grp = g;
+  ERL_NIF_TERM t = enif_make_resource(env, r);
+  enif_release_resource(r);
+  return mk_ok(env, t);
+}
+
+/* group_info(group) -> {world, local_count, has_rccl} */
+static ERL_NIF_TERM nif_group_info(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  if (argc != 1 || !get_grp(env, argv[0], &g)) return enif_make_badarg(env);
+  return enif_make_tuple3(env, enif_make_int(env, nxsig_group_world(g->grp)), enif_make_int(env, nxsig_group_local_count(g->grp)),
+                          enif_make_int(env, nxsig_group_has_rccl(g->grp)));
+}
+
+/* stft_sharded(group, x_bin, length, batch, window_bin, params, axis, gather) -> {:ok, z_bin, num_frames} */
+static ERL_NIF_TERM nif_stft_sharded(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  ErlNifBinary x, w, zb;
+  ErlNifSInt64 length;
+  int batch, axis, gather;
+  nxsig_stft_params p;
+  if (argc != 8 || !get_grp(env, argv[0], &g) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p) ||
+      !enif_get_int(env, argv[6], &axis) || !enif_get_int(env, argv[7], &gather))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || x.size % 4 || x.size / 4 / (size_t)batch != (size_t)length || w.size != (size_t)p.frame_length * 4)
+    return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
+  if (m < 0) return mk_error(env, (int)m);
+  if (!out_bin(&zb, (uint64_t)batch, (uint64_t)m, (uint64_t)p.fft_length, 8)) return mk_oom(env);
+  const float* xs[64] = {(const float*)x.data};
+  nxsig_c64* zs[64] = {(nxsig_c64*)zb.data};
+  int rc = nxsig_stft_sharded_f32(g->grp, xs, length, batch, length, (const float*)w.data, &p, axis, gather, zs, NXSIG_HOST);
+  if (rc) { enif_release_binary(&zb); return mk_error(env, rc); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), enif_make_binary(env, &zb), enif_make_int64(env, m));
+}
+
+/* fir_sharded(group, x_bin, length, batch, taps_bin, mode, axis, gather) -> {:ok, y_bin} */
+static ERL_NIF_TERM nif_fir_sharded(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  ErlNifBinary x, h, yb;
+  ErlNifSInt64 length;
+  int batch, mode, axis, gather;
+  if (argc != 8 || !get_grp(env, argv[0], &g) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &h) || !enif_get_int(env, argv[5], &mode) ||
+      !enif_get_int(env, argv[6], &axis) || !enif_get_int(env, argv[7], &gather))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || x.size % 4 || x.size / 4 / (size_t)batch != (size_t)length || h.size < 4 || h.size % 4 ||
+      h.size / 4 > 0x7fffffff)
+    return enif_make_badarg(env);
+  int64_t n = nxsig_conv_length(length, (int64_t)(h.size / 4), mode);
+  if (n < 0) return mk_error(env, (int)n);
+  if (!out_bin(&yb, (uint64_t)batch, (uint64_t)n, 1, 4)) return mk_oom(env);
+  const float* xs[64] = {(const float*)x.data};
+  float* ys[64] = {(float*)yb.data};
+  int rc = nxsig_fir_sharded_f32(g->grp, xs, length, batch, length, (const float*)h.data, (int)(h.size / 4), mode, axis, gather, ys, NXSIG_HOST);
+  if (rc) { enif_release_binary(&yb); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &yb));
 }
 
 static int load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {
   (void)priv; (void)info;
   CTX_RES = enif_open_resource_type(env, NULL, "nxsig_ctx", ctx_dtor, ERL_NIF_RT_CREATE | ERL_NIF_RT_TAKEOVER, NULL);
   BUF_RES = enif_open_resource_type(env, NULL, "nxsig_buf", buf_dtor, ERL_NIF_RT_CREATE | ERL_NIF_RT_TAKEOVER, NULL);
-  return (CTX_RES && BUF_RES) ? 0 : -1;
+  GRP_RES = enif_open_resource_type(env, NULL, "nxsig_group", grp_dtor, ERL_NIF_RT_CREATE | ERL_NIF_RT_TAKEOVER, NULL);
+  return (CTX_RES && BUF_RES && GRP_RES) ? 0 : -1;
 }
 static int upgrade(ErlNifEnv* env, void** priv, void** old, ERL_NIF_TERM info) { (void)old; return load(env, priv, info); }
 
 static ErlNifFunc funcs[] = {
+    {"device_count", 0, nif_device_count, 0},
     {"ctx_create", 1, nif_ctx_create, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"sync", 1, nif_sync, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"window", 5, nif_window, 0},
     {"firwin", 7, nif_firwin, 0},
+    {"fft_frequencies", 3, nif_fft_frequencies, 0},
+    {"mel_filters", 5, nif_mel_filters, ERL_NIF_DIRTY_JOB_CPU_BOUND},
+    {"sinc", 1, nif_sinc, 0},
     {"stft", 6, nif_stft, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft", 6, nif_istft, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir", 6, nif_fir, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"as_windowed", 9, nif_as_windowed, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"overlap_and_add", 7, nif_overlap_and_add, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"fft", 7, nif_fft, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"fftconvolve_c64", 4, nif_fftconvolve_c64, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_to_mel", 6, nif_stft_to_mel, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_mel", 8, nif_stft_mel, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"to_device", 2, nif_to_device, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"from_device", 1, nif_from_device, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"buf_size", 1, nif_buf_size, 0},
     {"stft_dev", 6, nif_stft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_dev", 6, nif_istft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"fir_dev", 6, nif_fir_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"spectrum_mul_dev", 5, nif_spectrum_mul_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"group_create", 1, nif_group_create, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"group_info", 1, nif_group_info, 0},
+    {"stft_sharded", 8, nif_stft_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"fir_sharded", 8, nif_fir_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 ERL_NIF_INIT(Elixir.NxSignalAMD.NIF, funcs, load, NULL, upgrade, NULL)

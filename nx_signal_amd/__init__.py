@@ -147,7 +147,14 @@ def as_windowed(tensor, ctx: Context | None = None, **opts):
                                              C.c_void_p(out.ptr), C.byref(M), _lib.DEVICE))
         return out
     src = np.asarray(tensor)
-    x = _host_f32(src, "as_windowed")
+    if src.dtype.kind in "iub":
+        # framing is a pure gather (doctests :182-246 keep s64): 32-bit words travel through the kernel untouched, so integer
+        # tensors stay EXACT (no rounding through f32); wider integers go through int32 when every value fits
+        if src.size and (int(src.min()) < -2 ** 31 or int(src.max()) > 2 ** 31 - 1):
+            raise ArgumentError("as_windowed: integer values beyond 32 bits are not supported by the MI355X path")
+        x = np.ascontiguousarray(src.astype(np.int32)).view(np.float32)
+    else:
+        x = _host_f32(src, "as_windowed")
     c = _ctx_of(None, ctx)
     L = x.shape[-1]
     batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
@@ -155,8 +162,8 @@ def as_windowed(tensor, ctx: Context | None = None, **opts):
     out = np.empty(x.shape[:-1] + (m, N), dtype=np.float32)
     _lib.check(lib.nxsig_as_windowed_f32(c.handle, _as_ptr(x), L, batch, L, N, int(stride), mode, lo, hi, _as_ptr(out),
                                          C.byref(M), _lib.HOST))
-    if src.dtype.kind in "iub":  # framing is a pure gather: integer tensors keep their type (doctests :182-246)
-        return out.astype(src.dtype)
+    if src.dtype.kind in "iub":
+        return out.view(np.int32).astype(src.dtype)
     return out
 
 
@@ -285,6 +292,13 @@ def overlap_and_add(tensor, ctx: Context | None = None, **opts):
         if src.dtype.kind == "c":
             arr = np.ascontiguousarray(src.astype(np.complex64))
         else:
+            if src.dtype.kind in "iu" and src.size and src.ndim >= 2:
+                # the reference adds integers exactly; here sums are formed in double and stored as f32, exact only below 2^24:
+                # refuse loudly instead of returning rounded integers
+                cover = -(-int(src.shape[-1]) // max(int(src.shape[-1]) - overlap, 1))
+                if int(np.abs(src).max()) * cover >= 2 ** 24:
+                    raise ArgumentError("overlap_and_add: integer sums beyond 2^24 cannot be represented exactly by the f32 "
+                                        "MI355X path; cast to a float type explicitly")
             arr = _host_f32(src, "overlap_and_add")
         shape, dt = arr.shape, arr.dtype
     if len(shape) < 2:

@@ -124,6 +124,8 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
           pend[R - 2][e][qq] = f[R - 1];
         }
       }
+    // plain non-temporal stores here: the "sc1 nt" policy that helps the write-dominated STFT (+5 %) and the FIR (+3 %) costs
+    // this read-dominated kernel 38 % (395 -> 546 us on config 3, measured)
     v2f* yp = (j >= j0) ? a.y + (size_t)row * a.segs_per_row * a.hop + j * a.hop + 2 * lane : a.dummy + 2 * lane;
 #pragma unroll
     for (int qq = 0; qq < QS; ++qq) {
@@ -570,12 +572,13 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       pack();  // next pair (its samples landed during the two transforms)
       __builtin_amdgcn_sched_barrier(0);
       const int64_t b1 = a.first_block + 2 * (a.pb_lo + pin);
-      float* p1 = a.y + (size_t)row * a.out_len + (b1 * a.V - a.out_start - tm1) + 2 * lane;
+      // the pair's two valid parts are one contiguous run of 2 V outputs: streaming stores (sc1 nt) through a row descriptor
+      const StreamRow ys(a.y + (size_t)row * a.out_len + (b1 * a.V - a.out_start), (uint32_t)(2 * a.V) * 4);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (128 * q >= tm1) {  // uniform: (taps-1) % 128 == 0
-          *reinterpret_cast<v2f*>(p1 + 128 * q) = v2f{u[0][q].x, u[1][q].x};
-          *reinterpret_cast<v2f*>(p1 + a.V + 128 * q) = v2f{u[0][q].y, u[1][q].y};
+          ys.st8(v2f{u[0][q].x, u[1][q].x}, lane * 8 + 512 * q - tm1 * 4);
+          ys.st8(v2f{u[0][q].y, u[1][q].y}, lane * 8 + 512 * q - tm1 * 4 + a.V * 4);
         }
       }
       row = nrow; pin = npin;

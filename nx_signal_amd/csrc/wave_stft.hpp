@@ -288,6 +288,27 @@ __device__ __forceinline__ void wave_fft_core_T(const v2f (*zz)[K / 128], v2f* d
   wave_lds_fence();
 }
 
+// Streaming stores of one wave into a contiguous output row: a wave-uniform buffer descriptor (base forced into SGPRs
+// with readfirstlane: it usually depends on the wave index) + per-lane byte offsets, cache policy "sc1 nt".  On the
+// headline STFT launch the sc1 bit is worth +5 % over a plain non-temporal global store (see ST above).
+struct StreamRow {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ StreamRow(const void* uniform_base, uint32_t bytes) {
+    const uint64_t v = reinterpret_cast<uint64_t>(uniform_base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, bytes, 0x00020000);
+  }
+  static constexpr int kAux = 18;  // gfx940+ cache policy bits: 1 = sc0, 2 = nt, 16 = sc1
+  __device__ __forceinline__ void st16(v4f v, int byte_off) const {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), r, byte_off, 0, kAux);
+  }
+  __device__ __forceinline__ void st8(v2f v, int byte_off) const {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, byte_off, 0, kAux);
+  }
+};
+
 struct WaveArgs {
   const float* x;
   int64_t batch_stride, L, lo, M;
@@ -350,7 +371,12 @@ struct MelWaveArgs {
   int32_t mag_kind;           // MAG sink: 0 = |X|, 1 = |X|^2, 2 = |X| with a running maximum (dBFS pass follows)
 };
 
-template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J, bool NPRED, int SINK, int STG = 0>
+// ST (pair / real-2x front-ends, complex-spectrum sink, streaming kernel): cache policy of the spectrum stores.
+// 1 (default) = buffer_store_dwordx4 ... sc1 nt through a wave-uniform buffer descriptor of the frame's row; 0 = global_store
+// ... nt (__builtin_nontemporal_store), 2 = buffer_store ... nt.  Measured on the headline launch, interleaved in one process
+// (tools/sweep_stft.py NXSIG_STORE_POLICY 0 1 2): 5.71 / 6.00 / 5.69 TB/s — the sc1 bit (system-scope write-through) is worth
+// +5 %, the buffer addressing itself nothing.
+template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J, bool NPRED, int SINK, int STG = 0, int ST = 1>
 __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveArgs* mp) {
   // STG > 0 (quad streaming kernels): the unit's contiguous input span travels as STG 16-byte loads per lane and is
   // re-distributed through the wave's exchange buffer instead of 32 strided 4-byte loads per lane (see issue_loads)
@@ -652,6 +678,17 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
     }
     v2f* zA = a.z + ((size_t)crow * a.M + mA) * KOUT + 2 * lane;
     v2f* zB = (GENERAL || haveB) ? zA + K : a.dummy + 2 * lane;  // pair: frame B; real-2x: bins K..2K-1
+    constexpr bool BUFST = ST > 0 && (MODE == kModePair || MODE == kModeReal2x) && !GENERAL && SINK == kSinkSpectrum;
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    if (BUFST) {  // wave-uniform row descriptors (the row base depends on the wave index: make it an SGPR pair explicitly)
+      auto uni = [](const v2f* p) -> void* {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+      };
+      rsA = __builtin_amdgcn_make_buffer_rsrc(uni(zA - 2 * lane), 0, K * 8, 0x00020000);
+      rsB = __builtin_amdgcn_make_buffer_rsrc(uni(zB - 2 * lane), 0, K * 8, 0x00020000);
+    }
     constexpr int QN = ((MEL || MAG) && MODE == kModePair) ? NQ / 2 : NQ;  // MEL / MAG: only the bins below fft_length / 2
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
@@ -687,6 +724,11 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
         float* r0 = mp->out + ((size_t)crow * a.M + mA) * KH + 2 * lane + 128 * q;
         mag_store(r0, v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w});
         if (MODE == kModePair && haveB) mag_store(r0 + KH, v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w});
+      } else if (BUFST) {
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        constexpr int AUX = ST == 1 ? 18 : 2;  // gfx940+ cache policy bits: 1 = sc0, 2 = nt, 16 = sc1
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, xa), rsA, lane * 16 + 1024 * q, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, xbv), rsB, lane * 16 + 1024 * q, 0, AUX);
       } else {
         __builtin_nontemporal_store(xa, (gv4f*)(zA + 128 * q));
         if (!GENERAL || haveB) __builtin_nontemporal_store(xbv, (gv4f*)(zB + 128 * q));
@@ -711,9 +753,9 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   }
 }
 
-template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2, bool NPRED = false, int STG = 0>
+template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2, bool NPRED = false, int STG = 0, int ST = 1>
 __global__ __launch_bounds__(64 * W) void k_stft_wave(WaveArgs a) {
-  stft_wave_body<K, MODE, GENERAL, SCALE, W, J, NPRED, kSinkSpectrum, STG>(a, nullptr);
+  stft_wave_body<K, MODE, GENERAL, SCALE, W, J, NPRED, kSinkSpectrum, STG, ST>(a, nullptr);
 }
 template <int K, int MODE, bool GENERAL, bool SCALE, int W, int J = 2, bool NPRED = false, int STG = 0>
 __global__ __launch_bounds__(64 * W) void k_stft_mel_wave(MelWaveArgs m) {
@@ -1187,6 +1229,16 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
                                : go(k_stft_wave<C, MODE, false, false, W, J, false, 8>, upr, big, u_lo, u_lo);
         else rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, true, 8>, upr, big, u_lo, u_lo)
                         : go(k_stft_wave<C, MODE, false, false, W, J, true, 8>, upr, big, u_lo, u_lo);
+      }
+    }
+    if constexpr (MODE == kModePair && C == 1024) {
+      const int stp = env_int("NXSIG_STORE_POLICY", 1);  // A/B switch of the headline kernel only (evidence in profiles/)
+      if (!done && !npred && (stp == 0 || stp == 2)) {
+        done = true;
+        if (stp == 0) rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 0, 0>, upr, big, u_lo, u_lo)
+                                 : go(k_stft_wave<C, MODE, false, false, W, J, false, 0, 0>, upr, big, u_lo, u_lo);
+        else rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 0, 2>, upr, big, u_lo, u_lo)
+                        : go(k_stft_wave<C, MODE, false, false, W, J, false, 0, 2>, upr, big, u_lo, u_lo);
       }
     }
     if (!done) {

@@ -1,0 +1,282 @@
+"""The dirty-NIF shim (nif/nxsig_nif.c) compiled against the stand-in erl_nif.h and EXECUTED through the miniature term
+runtime of tests/stub/ (tests/nif_harness.py): the calls are made by name / arity through the ErlNifEntry table with the
+term shapes the Elixir wrappers (elixir/lib/) build, and compared with the ctypes path bit for bit.
+
+CPU part (no GPU): the shim compiles with -Wall -Wextra -Werror; nif.ex and the shim's funcs[] table agree in both
+directions; host generators; validation happens BEFORE any allocation and a failing allocation is an error
+tuple, not an abort.  GPU part (-m gpu): stft / istft / fir / as_windowed / overlap_and_add / fft / mel / device-resident
+chain / sharded calls through the NIF equal the ctypes results; resources are released (HBM freed) when the last term goes."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nif_harness as H
+from conftest import ROOT, f32_list
+from oracle import nx_oracle as O
+
+import nx_signal_amd as S
+
+gpu = pytest.mark.gpu
+PARAMS = (1024, 256, 1024, 0, 0, 0, 0, 48000.0)  # {n, hop, k, pad_mode, pad_lo, pad_hi, scaling, sampling_rate}
+
+
+def f32(b):
+    return np.frombuffer(b, np.float32)
+
+
+def c64(b):
+    return np.frombuffer(b, np.complex64)
+
+
+def test_shim_compiles_warning_free_and_loads():
+    H.build(force=True)  # gcc -std=c11 -Wall -Wextra -Werror against tests/stub/erl_nif.h
+    assert H.lib().fake_module_name() == b"Elixir.NxSignalAMD.NIF"
+    assert len(H.funcs()) >= 28
+
+
+def test_nif_ex_matches_the_shim_table():
+    src = open(os.path.join(ROOT, "elixir", "lib", "nx_signal_amd", "nif.ex")).read()
+    stubs = {}
+    for m in re.finditer(r"^\s*def (\w+)\(([^)]*)\)", src, re.M):
+        name, args = m.group(1), m.group(2).strip()
+        if name == "load_nif":
+            continue
+        stubs[(name, 0 if not args else len(args.split(",")))] = True
+    table = H.funcs()
+    assert set(stubs) == set(table), set(stubs) ^ set(table)
+    # every NIF the Elixir modules call exists with that arity
+    called = set()
+    for root, _, files in os.walk(os.path.join(ROOT, "elixir", "lib")):
+        for f in files:
+            text = open(os.path.join(root, f)).read()
+            for m in re.finditer(r"NIF\.(\w+)\(", text):
+                start = m.end()
+                depth, i, commas, empty = 1, start, 0, True
+                while depth:
+                    ch = text[i]
+                    if ch in "([{":
+                        depth += 1
+                    elif ch in ")]}":
+                        depth -= 1
+                    elif ch == "," and depth == 1:
+                        commas += 1
+                    if depth and not ch.isspace():
+                        empty = False
+                    i += 1
+                called.add((m.group(1), 0 if empty else commas + 1))
+    assert called <= set(table), called - set(table)
+    # GPU entry points are dirty jobs (a scheduler thread must never block on the GPU)
+    for (name, ar), flags in table.items():
+        if name in ("window", "firwin", "fft_frequencies", "sinc", "buf_size", "group_info", "device_count"):
+            continue
+        assert flags in (1, 2), (name, ar, flags)
+
+
+def test_host_generators_through_the_nif(golden):
+    for v in golden["windows"]:
+        if v["fn"] == "rectangular":
+            continue
+        kind = {"bartlett": 1, "triangular": 2, "blackman": 3, "hamming": 4, "hann": 5, "kaiser": 6}[v["fn"]]
+        o = v["opts"]
+        ok, b = H.call("window", kind, v["n"], 1 if o.get("is_periodic", True) else 0, float(o.get("beta", 12.0)), float(o.get("eps", 1e-7)))
+        assert ok == "ok"
+        if v["exact"]:
+            assert np.array_equal(f32(b).view(np.uint32), f32_list(v["expect"]).view(np.uint32)), v["src"]
+    for v in golden["firwin"]:
+        o = dict(v["opts"])
+        win = o.get("window", "hamming")
+        kind, beta = (6, float(win[1])) if isinstance(win, list) else ({"hamming": 4, "hann": 5, "blackman": 3, "bartlett": 1, "rectangular": 0}[win], 0.0)
+        ok, b = H.call("firwin", v["num_taps"], [float(c) for c in v["cutoff"]], kind, beta, 1 if o.get("pass_zero", True) else 0,
+                       1 if o.get("scale", True) else 0, float(o.get("sampling_rate", 2.0)))
+        want = S.filters.firwin(v["num_taps"], v["cutoff"], **{k: (tuple(x) if isinstance(x, list) else x) for k, x in o.items()})
+        assert np.array_equal(f32(b).view(np.uint32), want.view(np.uint32)), v["src"]
+    for v in golden["firwin_errors"]:
+        with pytest.raises(H.NifError) as e:
+            o = v["opts"]
+            kind = 4 if "window" not in o else 99  # an unknown window name maps to no kind on the Elixir side; the library refuses too
+            H.call("firwin", v["num_taps"], [float(c) for c in v["cutoff"]], kind, 0.0, 1 if o.get("pass_zero", True) else 0, 1, float(o.get("sampling_rate", 2.0)))
+        assert e.value.code == -1  # -> ArgumentError on the Elixir side
+    v = golden["fft_frequencies"][0]
+    ok, b = H.call("fft_frequencies", float(v["sampling_rate"]), v["fft_length"], 0)
+    assert np.array_equal(f32(b), f32_list(v["expect"]))
+    v = golden["mel_filters"][0]
+    ok, b = H.call("mel_filters", v["fft_length"], v["mel_bins"], float(v["sampling_rate"]), 3016.0, 200.0 / 3.0)
+    assert np.array_equal(f32(b).view(np.uint32), S.mel_filters(v["fft_length"], v["mel_bins"], v["sampling_rate"]).reshape(-1).view(np.uint32))
+    ok, b = H.call("sinc", np.array([0.0, 0.25, 1.0], np.float32))
+    assert np.array_equal(f32(b), S.waveforms.sinc(np.array([0.0, 0.25, 1.0], np.float32)))
+    # integers are accepted where Elixir callers may pass them (sampling_rate: 48000)
+    assert H.call("fft_frequencies", 16000, 10, 0)[0] == "ok"
+
+
+def test_malformed_terms_are_badarg_not_crashes():
+    with pytest.raises(H.BadArg):
+        H.call("window", 5, -3, 1, 0.0, 1e-7)
+    with pytest.raises(H.BadArg):
+        H.call("window", "hann", 8, 1, 0.0, 1e-7)
+    with pytest.raises(H.BadArg):
+        H.call("firwin", 0, [0.5], 4, 0.0, 1, 1, 2.0)
+    with pytest.raises(H.BadArg):
+        H.call("stft", 1, b"", 0, 0, b"", PARAMS)  # not a context resource
+    with pytest.raises(H.UndefinedNif):
+        H.call("stft", 1, 2)
+    with pytest.raises(H.BadArg):
+        H.call("sinc", b"abc")
+    assert H.lib().fake_live_binaries() == 0
+
+
+def test_result_allocation_failure_is_an_error_tuple():
+    L = H.lib()
+    L.fake_set_alloc_limit(1024)
+    try:
+        with pytest.raises(H.NifError) as e:
+            H.call("window", 5, 4096, 1, 0.0, 1e-7)
+        assert e.value.code == -5 and L.fake_live_binaries() == 0
+    finally:
+        L.fake_set_alloc_limit(1 << 40)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def nctx():
+    ok, ctx = H.call("ctx_create", 0)
+    assert ok == "ok"
+    yield ctx
+    H.release_all()
+
+
+@gpu
+def test_stft_istft_fir_through_the_nif_equal_the_ctypes_path(nctx):
+    x = np.stack([O.synth_signal(48000, seed=s) for s in (1234, 1235)])
+    w = S.windows.hann(1024)
+    ok, zb, m, tb, fb = H.call("stft", nctx, x, 48000, 2, w, PARAMS)
+    z, t, f = S.stft(x, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert ok == "ok" and m == 184
+    assert np.array_equal(c64(zb).view(np.uint32), z.reshape(-1).view(np.uint32))
+    assert np.array_equal(f32(tb), t) and np.array_equal(f32(fb), f)
+    zo, _, _ = O.stft(x[0], w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert float(np.max(np.abs(c64(zb)[: zo.size].reshape(zo.shape) - zo)) / np.max(np.abs(zo))) < 1e-5
+    ok, yb = H.call("istft", nctx, z, 184, 2, w, PARAMS)
+    y = S.istft(z, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert np.array_equal(c64(yb).view(np.uint32), y.reshape(-1).view(np.uint32))
+    h = S.filters.firwin(257, [4000.0], sampling_rate=48000)
+    for mode, name in ((0, "full"), (1, "same"), (2, "valid")):
+        ok, yb = H.call("fir", nctx, x, 48000, 2, h, mode)
+        assert np.array_equal(f32(yb).view(np.uint32), S.filters.fir(x, h, mode=name).reshape(-1).view(np.uint32))
+    # the reference's ArgumentErrors travel as {:error, {-1, message}}
+    with pytest.raises(H.NifError) as e:
+        H.call("stft", nctx, x, 48000, 2, w, (1024, 256, 1024, 7, 0, 0, 0, 48000.0))
+    assert e.value.code == -1 and "invalid padding mode" in e.value.msg
+    with pytest.raises(H.NifError) as e:
+        H.call("fir", nctx, x, 48000, 2, h, 9)
+    assert e.value.code == -1 and "expected mode to be one of" in e.value.msg
+    # shapes that do not match the binaries are badarg before anything is allocated or read
+    for bad in ((nctx, x, 48001, 2, w, PARAMS), (nctx, x, 48000, 2, w[:1000], PARAMS), (nctx, x, 48000, 2, w, (1024, 256, 0, 0, 0, 0, 0, 48000.0)),
+                (nctx, x, 48000, 2, w, (1024, 256, -5, 0, 0, 0, 0, 48000.0)), (nctx, x, 48000, 0, w, PARAMS)):
+        with pytest.raises(H.BadArg):
+            H.call("stft", *bad)
+    with pytest.raises(H.BadArg):
+        H.call("istft", nctx, z, 184, 2, w[:100], PARAMS)
+    assert H.lib().fake_live_binaries() == 0
+
+
+@gpu
+def test_framing_ola_fft_mel_through_the_nif(nctx, golden):
+    for v in golden["as_windowed"]:
+        x = np.array(v["x"], np.float32)
+        pad = v["padding"]
+        mode, lo, hi = ({"valid": 0, "reflect": 1, "same": 2}[pad], 0, 0) if isinstance(pad, str) else (3, pad[0][0], pad[0][1])
+        ok, fb, m = H.call("as_windowed", nctx, x, x.size, 1, v["window_length"], v["stride"], mode, lo, hi)
+        assert np.array_equal(f32(fb).reshape(m, v["window_length"]), np.array(v["expect"], np.float32)), v["src"]
+    # int32 words travel bit-exactly (the gather never touches the payload): values far beyond 2^24
+    xi = (np.arange(40, dtype=np.int64) * 100_000_007 % (2 ** 31 - 1)).astype(np.int32)
+    ok, fb, m = H.call("as_windowed", nctx, xi.view(np.float32), 40, 1, 8, 4, 0, 0, 0)
+    assert np.array_equal(np.frombuffer(fb, np.int32).reshape(m, 8), np.stack([xi[4 * i:4 * i + 8] for i in range(m)]))
+    assert np.array_equal(S.as_windowed(xi, window_length=8, stride=4), np.stack([xi[4 * i:4 * i + 8] for i in range(m)]))
+    fr = np.arange(3 * 4, dtype=np.float32).reshape(3, 4)
+    ok, ob = H.call("overlap_and_add", nctx, fr, 3, 1, 4, 2, 1)
+    assert np.array_equal(f32(ob), S.overlap_and_add(fr, overlap_length=2))
+    with pytest.raises(H.NifError) as e:
+        H.call("overlap_and_add", nctx, fr, 3, 1, 4, 4, 1)
+    assert e.value.code == -1 and "overlap_length must be a number less than the window size 4, got: 4" in e.value.msg
+    xr = O.synth_signal(6 * 50, seed=5).reshape(6, 50)
+    ok, ob = H.call("fft", nctx, xr, 1, 6, 50, 64, 0)
+    want = S.transforms.fft_nd(xr, axes=[1], lengths=[64]) if hasattr(S.transforms, "fft_nd") else None
+    if want is not None:
+        assert np.array_equal(c64(ob).view(np.uint32), np.ascontiguousarray(want).reshape(-1).view(np.uint32))
+    a = (O.synth_signal(30, seed=1) + 1j * O.synth_signal(30, seed=2)).astype(np.complex64)
+    b = (O.synth_signal(9, seed=3) + 1j * O.synth_signal(9, seed=4)).astype(np.complex64)
+    ok, ob = H.call("fftconvolve_c64", nctx, a, b, 0)
+    ref = np.convolve(a.astype(np.complex128), b.astype(np.complex128))
+    assert float(np.max(np.abs(c64(ob) - ref)) / np.max(np.abs(ref))) < 1e-5
+    x = O.synth_signal(16000, seed=8)
+    w = S.windows.hann(400)
+    p = (400, 160, 512, 1, 0, 0, 0, 16000.0)
+    filt = S.mel_filters(512, 80, 16000.0)
+    ok, mb, m = H.call("stft_mel", nctx, x, 16000, 1, w, p, 80, filt)
+    want = S.mel_spectrogram(x, w, overlap_length=240, fft_length=512, sampling_rate=16000, window_padding="reflect", mel_bins=80)
+    assert np.array_equal(f32(mb).view(np.uint32), np.ascontiguousarray(want).reshape(-1).view(np.uint32))
+    z, _, _ = S.stft(x, w, overlap_length=240, fft_length=512, sampling_rate=16000, window_padding="reflect")
+    ok, mb2 = H.call("stft_to_mel", nctx, z, z.shape[0], 512, 80, filt)
+    assert np.allclose(f32(mb2).reshape(want.shape), want, atol=1e-4)
+
+
+@gpu
+def test_device_resident_chain_through_the_nif(nctx):
+    """guides/filtering.livemd:137-159 without leaving HBM: to_device -> stft_dev -> spectrum_mul_dev -> istft_dev -> from_device"""
+    x = O.synth_signal(48000, seed=77)
+    w = S.windows.hann(1024)
+    live0 = H.lib().fake_live_resources()
+    ok, xb = H.call("to_device", nctx, x)
+    assert H.call("buf_size", xb) == x.nbytes
+    ok, zb, m = H.call("stft_dev", nctx, xb, 48000, 1, w, PARAMS)
+    hfft = np.fft.fft(np.r_[S.filters.firwin(65, [3000.0], sampling_rate=48000), np.zeros(1024 - 65)]).astype(np.complex64)
+    ok, zb2 = H.call("spectrum_mul_dev", nctx, zb, m, 1024, hfft)
+    ok, yb = H.call("istft_dev", nctx, zb2, m, 1, w, PARAMS)
+    assert H.call("sync", nctx) == "ok"
+    ok, out = H.call("from_device", yb)
+    z, _, _ = S.stft(x, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    want = S.istft(S.spectrum_multiply(z, hfft), w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert np.array_equal(c64(out).view(np.uint32), want.view(np.uint32))
+    ok, fy, n = H.call("fir_dev", nctx, xb, 48000, 1, S.filters.firwin(257, [4000.0], sampling_rate=48000), 1)
+    ok, fo = H.call("from_device", fy)
+    assert n == 48000 and np.array_equal(f32(fo).view(np.uint32), S.filters.fir(x, S.filters.firwin(257, [4000.0], sampling_rate=48000)).view(np.uint32))
+    # a short window binary is refused before the library reads it
+    with pytest.raises(H.BadArg):
+        H.call("istft_dev", nctx, zb, m, 1, w[:512], PARAMS)
+    with pytest.raises(H.BadArg):
+        H.call("stft_dev", nctx, xb, 48000, 2, w, PARAMS)  # the buffer holds one row, not two
+    # dropping the last term of a device tensor runs its destructor (HBM freed), the context outlives its buffers
+    d0 = H.lib().fake_dtor_calls()
+    del xb, zb, zb2, yb, fy
+    H.release_all()
+    assert H.lib().fake_dtor_calls() - d0 >= 4
+    assert H.lib().fake_live_resources() <= live0 + 1
+
+
+@gpu
+def test_sharded_calls_through_the_nif():
+    ok, ctx = H.call("ctx_create", 0)
+    ok, g = H.call("group_create", [0, 0])
+    assert H.call("group_info", g) == (2, 2, 0)
+    x = np.stack([O.synth_signal(30000, seed=500 + c) for c in range(3)])
+    w = S.windows.hann(1024)
+    z, _, _ = S.stft(x, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    for axis, gather in ((0, 0), (0, 1)):
+        ok, zb, m = H.call("stft_sharded", g, x, 30000, 3, w, PARAMS, axis, gather)
+        assert m == z.shape[1] and np.array_equal(c64(zb).view(np.uint32), z.reshape(-1).view(np.uint32))
+    ok, zb, m = H.call("stft_sharded", g, x[0], 30000, 1, w, PARAMS, 1, 1)
+    assert float(np.max(np.abs(c64(zb).reshape(z[0].shape) - z[0])) / np.max(np.abs(z[0]))) < 1e-6
+    h = S.filters.firwin(257, [4000.0], sampling_rate=48000)
+    ok, yb = H.call("fir_sharded", g, x, 30000, 3, h, 1, 0, 0)
+    assert np.array_equal(f32(yb).view(np.uint32), S.filters.fir(x, h).reshape(-1).view(np.uint32))
+    ok, g1 = H.call("group_create", [0])
+    assert H.call("group_info", g1) == (1, 1, 1)  # one GPU per member: RCCL communicator (ncclCommInitAll)
+    ok, zb, m = H.call("stft_sharded", g1, x, 30000, 3, w, PARAMS, 0, 1)
+    assert np.array_equal(c64(zb).view(np.uint32), z.reshape(-1).view(np.uint32))
+    with pytest.raises(H.NifError) as e:
+        H.call("stft_sharded", g, x, 30000, 3, w, (1024, 256, 1024, 1, 0, 0, 0, 48000.0), 0, 0)
+    assert e.value.code == -1 and ":valid" in e.value.msg
+    del g, g1, ctx
+    H.release_all()

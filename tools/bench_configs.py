@@ -83,6 +83,8 @@ def main():
     if "stft2048" in which:
         # config 4 per-GPU shard: 8 channels x 10 min @ 48 kHz would be 7.4 GB of output; use 8 ch x 150 s (1.8 GB out)
         stft_case(ctx, 2048, 512, 7200000, 8, "stft N=2048 hop=512, 8 ch x 150 s (config 4 shard, shortened)")
+    if "stft2048full" in which:  # config 4, one GPU's FULL shard: 8 channels x 10 min -> 7.37 GB of spectrum
+        stft_case(ctx, 2048, 512, 28800000, 8, "stft N=2048 hop=512, 8 ch x 600 s (config 4: one GPU's full shard)")
     if "reflect1024" in which:
         stft_case(ctx, 1024, 256, 2880000, 32, "stft N=1024 hop=256 window_padding :reflect, 32 x 60 s", pad=_lib.PAD_REFLECT)
     if "speech512" in which:

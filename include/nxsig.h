@@ -172,6 +172,26 @@ int nxsig_fft(nxsig_ctx* ctx, const void* in, int32_t in_is_real, int64_t rows, 
               int32_t inverse, nxsig_c64* out, int32_t mem);
 
 /*
+ * NxSignal.Transforms.fft_nd / ifft_nd — lib/nx_signal/transforms.ex:5-21: Enum.zip_reduce(axes, lengths, t, &Nx.fft(&3, axis: &1,
+ * length: &2)) (or Nx.ifft), entirely in HBM: an axis other than the last is brought to the back by a tiled transpose kernel,
+ * transformed by the row kernels and moved back.  in: f32 (in_is_real) or c64 tensor of `rank` <= 8 dims, row-major; out: c64 tensor
+ * whose dims at `axes` are `lengths` (zero-pad / truncate like Nx.fft(length:)).  Row lengths: any power of two up to 2^26
+ * (four-step beyond 8192), any other length up to 2^22 (Bluestein).  `out` must not alias `in`.
+ */
+int nxsig_fft_nd(nxsig_ctx* ctx, const void* in, int32_t in_is_real, const int64_t* shape, int32_t rank, const int32_t* axes,
+                 const int64_t* lengths, int32_t n_axes, int32_t inverse, nxsig_c64* out, int32_t mem);
+
+/*
+ * n-D Convolution.fftconvolve/3 — lib/nx_signal/convolution.ex:252-347: fft_nd of both operands over the axes where neither
+ * dimension is 1 (lengths s1 + s2 - 1), broadcast product, ifft_nd, Nx.real for real operands, `centered` slice per mode
+ * (:valid needs one operand at least as large as the other in every dimension, :335-347).  a, b: tensors of equal rank <= 8
+ * (f32 when *_is_real, else c64).  out: f32 when both are real, else c64; its shape is written to out_shape[rank] (may be
+ * NULL): full s1 + s2 - 1, same s1, valid |s1 - s2| + 1.
+ */
+int nxsig_fftconvolve_nd(nxsig_ctx* ctx, const void* a, int32_t a_is_real, const int64_t* a_shape, const void* b, int32_t b_is_real,
+                         const int64_t* b_shape, int32_t rank, int32_t mode, void* out, int64_t* out_shape, int32_t mem);
+
+/*
  * FIR filtering: y = Convolution.convolve(x, h, method: :fft, mode:) for real 1-D x (per batch row) and
  * real taps h — lib/nx_signal/convolution.ex:252-329 as used by guides/filtering.livemd:126-128 —
  * computed by overlap-save block FFT convolution (the `Filters.fir` of BASELINE config 5; the reference
@@ -239,7 +259,7 @@ int nxsig_spectrum_mul_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int
  * 1-D complex case of Convolution.fftconvolve/3 — lib/nx_signal/convolution.ex:252-329 (tests: "FFT complex",
  * test/nx_signal/convolutions_test.exs:473-487): out = ifft(fft(a, P) * fft(b, P)) sliced per mode, with
  * P = next power of two >= n1 + n2 - 1 (same linear convolution as the reference's length n1 + n2 - 1).
- *   a c64[n1], b c64[n2], out c64[nxsig_conv_length(n1, n2, mode)]; n1 + n2 - 1 <= 8192 (one LDS-resident FFT).
+ *   a c64[n1], b c64[n2], out c64[nxsig_conv_length(n1, n2, mode)]; n1 + n2 - 1 <= 2^26 (four-step transforms beyond 8192 points).
  */
 int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const nxsig_c64* b, int64_t n2, int32_t mode,
                           nxsig_c64* out, int32_t mem);

@@ -93,6 +93,8 @@ SIGNATURES = {
     "nxsig_stft_to_mel": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _i32]),
     "nxsig_spectrum_mul_c64": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _i32]),
     "nxsig_stft_magnitude_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _p, C.POINTER(_i64), _i32]),
+    "nxsig_fft_nd": (C.c_int, [_p, _p, _i32, C.POINTER(_i64), _i32, C.POINTER(_i32), C.POINTER(_i64), _i32, _i32, _p, _i32]),
+    "nxsig_fftconvolve_nd": (C.c_int, [_p, _p, _i32, C.POINTER(_i64), _p, _i32, C.POINTER(_i64), _i32, _i32, _p, C.POINTER(_i64), _i32]),
     "nxsig_fir_slice_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32]),
     "nxsig_timer_lap": (C.c_int, [_p]),
     "nxsig_timer_laps": (C.c_int, [_p, _pf, _i32, C.POINTER(_i32)]),

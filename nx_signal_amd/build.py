@@ -27,6 +27,7 @@ UNITS = [
     ("api.cpp", ["-x", "hip"]),
     ("group.cpp", ["-x", "hip"]),  # multi-GPU groups: RCCL is dlopen()ed at run time, never linked
     ("kernels_generic.hip", []),
+    ("kernels_nd.hip", []),
     ("kernels_wave.hip", []),
     ("kernels_wave_mel.hip", []),
     ("kernels_wave_mag.hip", []),

@@ -1,7 +1,9 @@
-"""NxSignal.Convolution (FFT method, 1-D real) — lib/nx_signal/convolution.ex:38-58, :252-347.
+"""NxSignal.Convolution (FFT method) — lib/nx_signal/convolution.ex:38-58, :252-347.
 
-`method: :direct` (n-D Nx.conv) is out of scope for the hot path and raises
-NxSignalUnsupported; the FFT method is served by the overlap-save kernel."""
+`method: :direct` (n-D Nx.conv) is out of scope for the hot path and raises NxSignalUnsupported.
+The FFT method: a real stream against a real 1-D filter runs the overlap-save kernel (any length, batched over leading
+axes); complex 1-D operands one transform of up to 2^26 points; n-D operands of equal rank the device-side fft_nd fold
+(nxsig_fftconvolve_nd: transforms over the axes where neither dimension is 1, broadcast product, inverse, `centered` slice)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -32,15 +34,35 @@ def convolve(in1, in2, ctx=None, **opts):
 
 
 def correlate(in1, in2, ctx=None, **opts):
-    """NxSignal.Convolution.correlate/3 — lib/nx_signal/convolution.ex:87-93: convolve(in1, conj(reverse(in2)), opts)
-    (1-D; `method: :fft` is the path built here, like convolve)."""
+    """NxSignal.Convolution.correlate/3 — lib/nx_signal/convolution.ex:87-93: convolve(in1, conj(reverse(in2)), opts) with the
+    kernel reversed along every axis (`method: :fft` is the path built here, like convolve)."""
     k = np.asarray(in2)
-    if k.ndim != 1:
-        raise NxSignalUnsupported("correlate: n-D kernels are outside the hot path")
-    k = k[::-1]
+    k = k[tuple(slice(None, None, -1) for _ in range(k.ndim))]
     if np.iscomplexobj(k):
         k = np.conj(k)
     return convolve(in1, np.ascontiguousarray(k), ctx=ctx, **opts)
+
+
+def _fftconvolve_nd(a, b, mode, ctx):
+    """equal-rank n-D operands (host): nxsig_fftconvolve_nd"""
+    lib = _lib.load()
+    for t in (a, b):
+        if t.dtype in (np.float64, np.complex128):
+            raise ArgumentError("fftconvolve: f64 / c128 is outside this path (f32 / c64); cast explicitly")
+    a_real, b_real = not np.iscomplexobj(a), not np.iscomplexobj(b)
+    ac = np.ascontiguousarray(a.astype(np.float32 if a_real else np.complex64))
+    bc = np.ascontiguousarray(b.astype(np.float32 if b_real else np.complex64))
+    rank = ac.ndim
+    s1 = (C.c_int64 * rank)(*ac.shape)
+    s2 = (C.c_int64 * rank)(*bc.shape)
+    osh = (C.c_int64 * rank)()
+    full = [x + y - 1 for x, y in zip(ac.shape, bc.shape)]
+    out = np.empty(full, np.float32 if (a_real and b_real) else np.complex64)  # every mode's result fits
+    c = ctx or default_context()
+    _lib.check(lib.nxsig_fftconvolve_nd(c.handle, ac.ctypes.data_as(C.c_void_p), int(a_real), s1, bc.ctypes.data_as(C.c_void_p),
+                                        int(b_real), s2, rank, _MODES[mode], out.ctypes.data_as(C.c_void_p), osh, _lib.HOST))
+    shape = tuple(int(v) for v in osh)
+    return out.reshape(-1)[: int(np.prod(shape))].reshape(shape).copy()
 
 
 def fftconvolve(in1, in2, ctx=None, **opts):
@@ -65,7 +87,7 @@ def fftconvolve(in1, in2, ctx=None, **opts):
         if a.ndim != 1 or h.ndim != 1:
             if a.ndim != h.ndim:
                 raise ArgumentError("Rank of in1 and in2 must be equal.")
-            raise NxSignalUnsupported("fftconvolve: n-D complex convolution is outside the hot path")
+            return _fftconvolve_nd(a, h, mode, ctx)
         if a.dtype == np.complex128 or h.dtype == np.complex128:
             raise ArgumentError("fftconvolve: complex128 is outside this path (f32/c64); cast to complex64 explicitly")
         ac = np.ascontiguousarray(a.astype(np.complex64))
@@ -77,7 +99,12 @@ def fftconvolve(in1, in2, ctx=None, **opts):
                                              bc.size, _MODES[mode], out.ctypes.data_as(C.c_void_p), _lib.HOST))
         return out
     if h.ndim != 1:
-        raise NxSignalUnsupported("fftconvolve: n-D kernels are outside the hot path")
+        if dev:
+            raise NxSignalUnsupported("n-D fftconvolve takes host tensors")
+        a = np.asarray(in1)
+        if a.ndim != h.ndim:  # convolution.ex:295-296
+            raise ArgumentError("Rank of in1 and in2 must be equal.")
+        return _fftconvolve_nd(a, h, mode, ctx)
     h32 = np.ascontiguousarray(h.astype(np.float32))
     if dev:
         ptr, shape, dt = device_view(in1)

@@ -737,6 +737,66 @@ int nxsig_fir_slice_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t 
   return fir_common(ctx, x, length, batch, batch_stride, h, num_taps, out_start, out_len, y, mem);
 }
 
+int nxsig_fft_nd(nxsig_ctx* ctx, const void* in, int32_t in_is_real, const int64_t* shape, int32_t rank, const int32_t* axes,
+                 const int64_t* lengths, int32_t n_axes, int32_t inverse, nxsig_c64* out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!in || !out || !shape || (n_axes > 0 && (!axes || !lengths))) return set_error(NXSIG_ERR_INVALID_ARG, "fft_nd: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (rank < 1 || rank > 8 || n_axes < 0 || n_axes > 16) return set_error(NXSIG_ERR_INVALID_ARG, "fft_nd: rank must be in [1, 8]");
+  std::vector<int64_t> osh(shape, shape + rank);
+  int64_t n_in = 1, n_out = 1;
+  for (int d = 0; d < rank; ++d) { if (shape[d] < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fft_nd: empty dimension"); n_in *= shape[d]; }
+  for (int i = 0; i < n_axes; ++i) {
+    const int ax = axes[i] < 0 ? axes[i] + rank : axes[i];
+    if (ax < 0 || ax >= rank) return set_error(NXSIG_ERR_INVALID_ARG, "fft_nd: axis out of bounds");
+    if (lengths[i] < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fft_nd: lengths must be positive");
+    osh[ax] = lengths[i];
+  }
+  for (auto v : osh) n_out *= v;
+  if (mem == NXSIG_DEVICE) return launch_fft_nd(c, in, in_is_real != 0, shape, rank, axes, lengths, n_axes, inverse != 0, reinterpret_cast<float2*>(out));
+  void *di = nullptr, *dout = nullptr;
+  const size_t ibytes = (size_t)n_in * (in_is_real ? sizeof(float) : sizeof(float2)), obytes = (size_t)n_out * sizeof(float2);
+  if ((rc = ctx_scratch(c, 17, ibytes, &di))) return rc;
+  if ((rc = ctx_scratch(c, 18, obytes, &dout))) return rc;
+  NXSIG_HIP_TRY(hipMemcpyAsync(di, in, ibytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_fft_nd(c, di, in_is_real != 0, shape, rank, axes, lengths, n_axes, inverse != 0, reinterpret_cast<float2*>(dout)))) return rc;
+  Staged st(c);
+  return st.out_copy(out, dout, obytes);
+  NXSIG_API_END
+}
+
+int nxsig_fftconvolve_nd(nxsig_ctx* ctx, const void* a, int32_t a_is_real, const int64_t* a_shape, const void* b, int32_t b_is_real,
+                         const int64_t* b_shape, int32_t rank, int32_t mode, void* out, int64_t* out_shape, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!a || !b || !out || !a_shape || !b_shape) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (rank < 1 || rank > 8) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: rank must be in [1, 8]");
+  if (mem == NXSIG_DEVICE) return launch_fftconvolve_nd(c, a, a_is_real != 0, a_shape, b, b_is_real != 0, b_shape, rank, mode, out, out_shape);
+  int64_t na = 1, nb = 1, no = 1, osh[8];
+  for (int d = 0; d < rank; ++d) {
+    if (a_shape[d] < 1 || b_shape[d] < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: empty dimension");
+    na *= a_shape[d]; nb *= b_shape[d]; no *= a_shape[d] + b_shape[d] - 1;  // upper bound of every mode's result
+  }
+  const bool real_out = a_is_real && b_is_real;
+  void *da = nullptr, *db = nullptr, *dout = nullptr;
+  const size_t abytes = (size_t)na * (a_is_real ? 4 : 8), bbytes = (size_t)nb * (b_is_real ? 4 : 8);
+  if ((rc = ctx_scratch(c, 17, abytes, &da))) return rc;
+  if ((rc = ctx_scratch(c, 18, bbytes, &db))) return rc;
+  if ((rc = ctx_scratch(c, 19, (size_t)no * (real_out ? 4 : 8), &dout))) return rc;
+  NXSIG_HIP_TRY(hipMemcpyAsync(da, a, abytes, hipMemcpyHostToDevice, c->stream));
+  NXSIG_HIP_TRY(hipMemcpyAsync(db, b, bbytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_fftconvolve_nd(c, da, a_is_real != 0, a_shape, db, b_is_real != 0, b_shape, rank, mode, dout, osh))) return rc;
+  int64_t nres = 1;
+  for (int d = 0; d < rank; ++d) { nres *= osh[d]; if (out_shape) out_shape[d] = osh[d]; }
+  Staged st(c);
+  return st.out_copy(out, dout, (size_t)nres * (real_out ? 4 : 8));
+  NXSIG_API_END
+}
+
 int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const nxsig_c64* b, int64_t n2, int32_t mode,
                           nxsig_c64* out, int32_t mem) {
   NXSIG_API_BEGIN
@@ -761,7 +821,7 @@ int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const 
   void* od = nullptr;
   if ((rc = st.in(1, a, (size_t)n1 * sizeof(float2), &ad))) return rc;
   if ((rc = st.in(2, b, (size_t)n2 * sizeof(float2), &bd))) return rc;
-  if ((rc = ctx_scratch(c, 3, (size_t)(out_len > 8192 ? out_len : 8192) * sizeof(float2), &od))) return rc;
+  if ((rc = ctx_scratch(c, 4, (size_t)(out_len > 8192 ? out_len : 8192) * sizeof(float2), &od))) return rc;
   if ((rc = launch_fftconvolve_c64(c, reinterpret_cast<const float2*>(ad), n1, reinterpret_cast<const float2*>(bd), n2, start, out_len,
                                    reinterpret_cast<float2*>(od)))) return rc;
   return st.out_copy(out, od, (size_t)out_len * sizeof(float2));

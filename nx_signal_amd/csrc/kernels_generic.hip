@@ -737,6 +737,7 @@ int launch_stft_generic(Ctx* c, const StftLaunch& s) {
   a.x = s.x; a.batch_stride = s.batch_stride; a.g = to_geom(s.fr);
   a.K = s.K; a.window = s.window; a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = s.z;
   if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
+  if ((is_pow2(s.K) && s.K > kMaxLdsPow2) || (!is_pow2(s.K) && s.K > 4096)) return launch_stft_big(c, s);  // kernels_nd.hip
   int rc = ctx_twiddles(c, s.K, &a.tw);
   if (rc) return rc;
   if (is_pow2(s.K) && s.K <= kMaxLdsPow2) {
@@ -758,8 +759,6 @@ int launch_stft_generic(Ctx* c, const StftLaunch& s) {
     dim3 grid((unsigned)s.fr.M, (unsigned)s.batch);
     hipLaunchKernelGGL(k_stft_blue, grid, dim3(kThreads), lds, c->stream, b);
   } else {
-    if (s.K > 16384)
-      return set_error(NXSIG_ERR_UNSUPPORTED, "stft: non-power-of-two fft_length > 16384 is not supported yet");
     a.logK = 0; a.F = 1;
     const int nuse = s.fr.N < s.K ? s.fr.N : s.K;
     const size_t lds = (size_t)nuse * sizeof(float);
@@ -776,6 +775,12 @@ static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows
   FftRowsArgs a;
   a.in = in; a.in_is_real = in_is_real ? 1 : 0; a.rows = rows; a.n_in = n_in; a.K = K;
   a.post_window = post_window; a.post_scale = post_scale; a.has_post_scale = has_post_scale ? 1 : 0; a.out = out;
+  if ((is_pow2(K) && K > kMaxLdsPow2) || (!is_pow2(K) && K > 4096)) {
+    // beyond the LDS-resident kernels: four-step / Bluestein rows in HBM (kernels_nd.hip), then the istft epilogue if any
+    int rcb = launch_fft_big(c, in, in_is_real, rows, n_in, K, inverse, out);
+    if (rcb) return rcb;
+    return launch_rows_post(c, out, rows, K, post_window, post_scale, has_post_scale, 1.0f, false);
+  }
   int rc = ctx_twiddles(c, K, &a.tw);
   if (rc) return rc;
   if (is_pow2(K) && K <= kMaxLdsPow2) {
@@ -809,7 +814,6 @@ static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows
       hipLaunchKernelGGL(k_fft_rows_blue<false>, grid, dim3(kThreads), lds, c->stream, b);
     }
   } else {
-    if (K > 16384) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: length > 16384 that is not a power of two <= 8192 is not supported yet");
     a.logK = 0; a.F = 1;
     const int nuse = n_in < K ? n_in : K;
     const size_t lds = (size_t)nuse * sizeof(float2);
@@ -1024,19 +1028,18 @@ int launch_fftconvolve_c64(Ctx* c, const float2* a, int64_t n1, const float2* b,
   const int64_t full = n1 + n2 - 1;
   int P = 1;
   while (P < full) P <<= 1;
-  if (P > kMaxLdsPow2)
-    return set_error(NXSIG_ERR_UNSUPPORTED, "fftconvolve (complex): n1 + n2 - 1 > 8192 is not supported yet");
+  if (full > ((int64_t)1 << 26)) return set_error(NXSIG_ERR_UNSUPPORTED, "fftconvolve (complex): n1 + n2 - 1 > 2^26 is not supported");
   void* sc = nullptr;
   int rc = ctx_scratch(c, 0, (size_t)3 * P * sizeof(float2), &sc);
   if (rc) return rc;
   float2* A = reinterpret_cast<float2*>(sc);
   float2* B = A + P;
   float2* C = B + P;
-  if ((rc = launch_fft(c, a, false, 1, (int32_t)n1, P, false, A))) return rc;
-  if ((rc = launch_fft(c, b, false, 1, (int32_t)n2, P, false, B))) return rc;
+  if ((rc = launch_fft_big(c, a, false, 1, n1, P, false, A))) return rc;  // four-step rows beyond 8192 points
+  if ((rc = launch_fft_big(c, b, false, 1, n2, P, false, B))) return rc;
   hipLaunchKernelGGL(k_cmul_inplace, dim3((P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, A, B, P);
   NXSIG_HIP_TRY(hipGetLastError());
-  if ((rc = launch_fft(c, A, false, 1, P, P, true, C))) return rc;
+  if ((rc = launch_fft_big(c, A, false, 1, P, P, true, C))) return rc;
   NXSIG_HIP_TRY(hipMemcpyAsync(out, C + start, (size_t)len * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
   return NXSIG_OK;
 }

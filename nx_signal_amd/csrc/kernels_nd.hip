@@ -1,0 +1,508 @@
+// Device-resident multi-axis and large transforms:
+//
+//   k_transpose          [outer][R][C] -> [outer][C][R] of c64 through a padded 64 x 64 LDS tile (512-byte runs on both
+//                        sides), optionally reading f32 / zero-padding / truncating on the way in and multiplying by the
+//                        four-step twiddle w_K^(r c) on the way out
+//   launch_fft_big       rows of ANY length beyond the LDS-resident kernels of kernels_generic.hip:
+//                          power of two K > 8192: four-step K = K1 K2 — transpose, K1-point row FFTs, twiddle + transpose,
+//                          K2-point row FFTs, transpose (five streaming passes, no host round trip);
+//                          other K > 4096: Bluestein chirp-z through a power-of-two transform of P >= 2K - 1 points
+//   launch_fft_nd        NxSignal.Transforms.fft_nd / ifft_nd (lib/nx_signal/transforms.ex:5-21): Enum.zip_reduce over
+//                        (axes, lengths) of Nx.fft(axis:, length:) — an axis other than the last is brought to the back
+//                        by k_transpose, transformed by the row kernels and moved back, all in HBM
+//   launch_fftconvolve_nd  n-D Convolution.fftconvolve/3 (lib/nx_signal/convolution.ex:252-347): fft_nd of both operands
+//                        over the axes where neither is 1 (lengths s1 + s2 - 1), broadcast product, ifft_nd, real part for
+//                        real operands, `centered` slice per mode
+//   launch_stft_big      stft for fft_length beyond the fused kernels: framing x window into a scratch tensor, then
+//                        launch_fft_big over its rows, then the :spectrum / :psd division
+//
+// Twiddles come from host tables generated in double (two-level: w_K^j = hi[j >> 13] * lo[j & 8191]).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "nxsig_internal.h"
+
+namespace nxsig {
+
+static constexpr int kT = 256;
+static constexpr int kTile = 64;
+
+__device__ __forceinline__ float2 ndmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+struct TrArgs {
+  const void* in;
+  float2* out;
+  int64_t outer;
+  int32_t R, C;
+  int32_t in_is_real;
+  int64_t plane_stride;   // elements between consecutive [R][C] planes of the input
+  int64_t plane_valid;    // plane elements with linear index r * C + c >= plane_valid read as zero (zero-pad / truncate)
+  int32_t tw_mode;        // 0 none, 1 multiply by w_K^(r c), 2 by its conjugate
+  int64_t K;
+  const float2* tw_lo;    // [8192]  w_K^t
+  const float2* tw_hi;    // [K / 8192] w_K^(8192 s)
+};
+
+__global__ __launch_bounds__(kT) void k_transpose(TrArgs a) {
+  __shared__ float2 tile[kTile][kTile + 1];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const int64_t o = blockIdx.z;
+  const int r0 = blockIdx.y * kTile, c0 = blockIdx.x * kTile;
+  const int64_t pbase = o * a.plane_stride;
+#pragma unroll 4
+  for (int i = ty; i < kTile; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float2 v = make_float2(0.f, 0.f);
+    if (r < a.R && c < a.C) {
+      const int64_t lin = (int64_t)r * a.C + c;
+      if (lin < a.plane_valid) {
+        if (a.in_is_real) v.x = reinterpret_cast<const float*>(a.in)[pbase + lin];
+        else v = reinterpret_cast<const float2*>(a.in)[pbase + lin];
+      }
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  float2* op = a.out + o * (int64_t)a.R * a.C;
+#pragma unroll 4
+  for (int i = ty; i < kTile; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < a.R && c < a.C) {
+      float2 v = tile[tx][i];
+      if (a.tw_mode) {
+        const int64_t j = ((int64_t)r * c) % a.K;
+        float2 w = ndmul(a.tw_hi[j >> 13], a.tw_lo[j & 8191]);
+        if (a.tw_mode == 2) w.y = -w.y;
+        v = ndmul(v, w);
+      }
+      op[(int64_t)c * a.R + r] = v;
+    }
+  }
+}
+
+static int launch_transpose(Ctx* c, const void* in, bool in_is_real, int64_t outer, int R, int C, int64_t plane_stride,
+                            int64_t plane_valid, float2* out, int tw_mode = 0, int64_t K = 0, const float2* lo = nullptr,
+                            const float2* hi = nullptr) {
+  if (outer == 0 || R == 0 || C == 0) return NXSIG_OK;
+  TrArgs a;
+  a.in = in; a.out = out; a.R = R; a.C = C; a.in_is_real = in_is_real ? 1 : 0;
+  a.plane_stride = plane_stride; a.plane_valid = plane_valid; a.tw_mode = tw_mode; a.K = K; a.tw_lo = lo; a.tw_hi = hi;
+  for (int64_t o0 = 0; o0 < outer; o0 += 65535) {  // gridDim.z limit
+    const int64_t no = outer - o0 < 65535 ? outer - o0 : 65535;
+    a.outer = no;
+    a.in = in_is_real ? static_cast<const void*>(reinterpret_cast<const float*>(in) + o0 * plane_stride)
+                      : static_cast<const void*>(reinterpret_cast<const float2*>(in) + o0 * plane_stride);
+    a.out = out + o0 * (int64_t)R * C;
+    dim3 grid((unsigned)((C + kTile - 1) / kTile), (unsigned)((R + kTile - 1) / kTile), (unsigned)no);
+    if (grid.y > 65535) return set_error(NXSIG_ERR_UNSUPPORTED, "transpose: more than 4 M rows per plane");
+    hipLaunchKernelGGL(k_transpose, grid, dim3(kT), 0, c->stream, a);
+  }
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+// ---- element-wise helpers
+__global__ __launch_bounds__(kT) void k_copy_pad(const void* __restrict__ in, int in_is_real, int64_t rows, int64_t n_in, int64_t K,
+                                                 float2* __restrict__ out) {  // rows of n_in -> rows of K (zero-pad / truncate)
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= rows * K) return;
+  const int64_t r = i / K, k = i - r * K;
+  float2 v = make_float2(0.f, 0.f);
+  if (k < n_in) {
+    if (in_is_real) v.x = reinterpret_cast<const float*>(in)[r * n_in + k];
+    else v = reinterpret_cast<const float2*>(in)[r * n_in + k];
+  }
+  out[i] = v;
+}
+// Bluestein: A[r][p] = conj^INV(x[r][p]) * chirp[p] for p < min(n_in, K), zero up to P
+__global__ __launch_bounds__(kT) void k_blue_in(const void* __restrict__ in, int in_is_real, int64_t rows, int64_t n_in, int64_t K, int64_t P,
+                                                const float2* __restrict__ chirp, int inv, float2* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= rows * P) return;
+  const int64_t r = i / P, p = i - r * P;
+  float2 v = make_float2(0.f, 0.f);
+  if (p < n_in && p < K) {
+    if (in_is_real) v.x = reinterpret_cast<const float*>(in)[r * n_in + p];
+    else v = reinterpret_cast<const float2*>(in)[r * n_in + p];
+    if (inv) v.y = -v.y;
+    v = ndmul(v, chirp[p]);
+  }
+  out[i] = v;
+}
+__global__ __launch_bounds__(kT) void k_mul_rowtable(float2* __restrict__ a, const float2* __restrict__ t, int64_t rows, int64_t P) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= rows * P) return;
+  a[i] = ndmul(a[i], t[i % P]);
+}
+// out[r][k] = conj^INV(A[r][k] * chirp[k]) (/ K for the inverse), k < K
+__global__ __launch_bounds__(kT) void k_blue_out(const float2* __restrict__ A, int64_t rows, int64_t K, int64_t P,
+                                                 const float2* __restrict__ chirp, int inv, float2* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= rows * K) return;
+  const int64_t r = i / K, k = i - r * K;
+  float2 v = ndmul(A[r * P + k], chirp[k]);
+  if (inv) { v.y = -v.y; v.x = v.x / (float)K; v.y = v.y / (float)K; }
+  out[i] = v;
+}
+// istft epilogue / stft scaling on finished rows: v = (v * scale) * window[k]   or   v = v / div
+__global__ __launch_bounds__(kT) void k_rows_post(float2* __restrict__ a, int64_t total, int64_t K, const float* __restrict__ window,
+                                                  float scale, int has_scale, float div, int has_div) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= total) return;
+  float2 v = a[i];
+  if (has_scale) { v.x *= scale; v.y *= scale; }
+  if (window) { const float w = window[i % K]; v.x *= w; v.y *= w; }
+  if (has_div) { v.x = v.x / div; v.y = v.y / div; }
+  a[i] = v;
+}
+
+static unsigned blocks_for(int64_t n) { return (unsigned)((n + kT - 1) / kT); }
+
+// ---- host tables
+static int twolevel_tables(Ctx* c, int64_t K, const float2** lo, const float2** hi) {
+  const uint64_t key = 0x7B16000000000000ull ^ (uint64_t)K;
+  auto hit = c->memo.find(key);
+  if (hit != c->memo.end()) { *lo = reinterpret_cast<const float2*>(hit->second[0]); *hi = reinterpret_cast<const float2*>(hit->second[1]); return NXSIG_OK; }
+  const double two_pi = 6.283185307179586476925286766559;
+  const int64_t nhi = (K + 8191) / 8192;
+  std::vector<float2> l(8192), h((size_t)nhi);
+  for (int t = 0; t < 8192; ++t) { const double ang = -two_pi * (double)(t % K) / (double)K; l[t] = make_float2((float)std::cos(ang), (float)std::sin(ang)); }
+  for (int64_t s = 0; s < nhi; ++s) { const double ang = -two_pi * (double)((s * 8192) % K) / (double)K; h[(size_t)s] = make_float2((float)std::cos(ang), (float)std::sin(ang)); }
+  const void *dl = nullptr, *dh = nullptr;
+  int rc = ctx_table(c, 0x7B161ull ^ ((uint64_t)K << 8), l.data(), l.size() * sizeof(float2), &dl);
+  if (rc) return rc;
+  if ((rc = ctx_table(c, 0x7B162ull ^ ((uint64_t)K << 8), h.data(), h.size() * sizeof(float2), &dh))) return rc;
+  c->memo[key] = {reinterpret_cast<uint64_t>(dl), reinterpret_cast<uint64_t>(dh)};
+  *lo = reinterpret_cast<const float2*>(dl); *hi = reinterpret_cast<const float2*>(dh);
+  return NXSIG_OK;
+}
+
+// iterative radix-2 in double with one twiddle table (the per-butterfly cos/sin of the small-table helper would take seconds here)
+static void host_fft_big(std::vector<double>& re, std::vector<double>& im) {
+  const size_t n = re.size();
+  std::vector<double> wr(n / 2 ? n / 2 : 1), wi(n / 2 ? n / 2 : 1);
+  for (size_t k = 0; k < n / 2; ++k) { const double ang = -6.283185307179586476925286766559 * (double)k / (double)n; wr[k] = std::cos(ang); wi[k] = std::sin(ang); }
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const size_t step = n / len;
+    for (size_t i = 0; i < n; i += len)
+      for (size_t k = 0; k < len / 2; ++k) {
+        const double cr = wr[k * step], ci = wi[k * step];
+        const size_t u = i + k, v = u + len / 2;
+        const double tr = re[v] * cr - im[v] * ci, ti = re[v] * ci + im[v] * cr;
+        re[v] = re[u] - tr; im[v] = im[u] - ti;
+        re[u] += tr; im[u] += ti;
+      }
+  }
+}
+
+static bool nd_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out);
+
+// power-of-two K = K1 K2 > 8192 (both <= 8192): X[k1 + K1 k2] = sum_n2 [w_K^(n2 k1) sum_n1 x[K2 n1 + n2] w_K1^(n1 k1)] w_K2^(n2 k2)
+static int fft_fourstep(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
+  int lg = 0;
+  while (((int64_t)1 << lg) < K) ++lg;
+  const int K1 = 1 << ((lg + 1) / 2), K2 = (int)(K / K1);
+  if (K1 > 8192) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: power-of-two lengths beyond 2^26 are not supported");
+  const float2 *lo = nullptr, *hi = nullptr;
+  int rc = twolevel_tables(c, K, &lo, &hi);
+  if (rc) return rc;
+  void *s1 = nullptr, *s2 = nullptr;
+  const size_t bytes = (size_t)rows * K * sizeof(float2);
+  if ((rc = ctx_scratch(c, 6, bytes, &s1))) return rc;
+  if ((rc = ctx_scratch(c, 7, bytes, &s2))) return rc;
+  float2* A = reinterpret_cast<float2*>(s1);
+  float2* B = reinterpret_cast<float2*>(s2);
+  // (a) [K1][K2] -> [K2][K1]   (zero-pad / truncate / real -> complex on the way in)
+  if ((rc = launch_transpose(c, in, in_is_real, rows, K1, K2, n_in, n_in < K ? n_in : K, A))) return rc;
+  // (b) K1-point transforms over n1
+  if ((rc = launch_fft(c, A, false, rows * K2, K1, K1, inverse, B))) return rc;
+  // (c) twiddle w_K^(n2 k1) and back to [K1][K2]
+  if ((rc = launch_transpose(c, B, false, rows, K2, K1, (int64_t)K, (int64_t)K, A, inverse ? 2 : 1, K, lo, hi))) return rc;
+  // (d) K2-point transforms over n2
+  if ((rc = launch_fft(c, A, false, rows * K1, K2, K2, inverse, B))) return rc;
+  // (e) Z[k1][k2] -> natural order X[k1 + K1 k2]
+  return launch_transpose(c, B, false, rows, K1, K2, (int64_t)K, (int64_t)K, out);
+}
+
+// any other K: chirp-z through a power-of-two convolution of P >= 2K - 1 points
+static int fft_bluestein_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
+  if (K > ((int64_t)1 << 22)) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: non-power-of-two lengths beyond 2^22 are not supported");
+  int64_t P = 1;
+  while (P < 2 * K - 1) P <<= 1;
+  const uint64_t key = 0xB16B000000000000ull ^ (uint64_t)K;
+  const float2 *chirp = nullptr, *Bf = nullptr;
+  auto hit = c->memo.find(key);
+  if (hit != c->memo.end()) { chirp = reinterpret_cast<const float2*>(hit->second[0]); Bf = reinterpret_cast<const float2*>(hit->second[1]); }
+  else {
+    std::vector<float2> ch((size_t)K), bf((size_t)P);
+    std::vector<double> bre((size_t)P, 0.0), bim((size_t)P, 0.0);
+    for (int64_t n = 0; n < K; ++n) {
+      const int64_t q = (n * n) % (2 * K);  // exact phase index
+      const double ang = -3.14159265358979323846 * (double)q / (double)K;
+      const double cr = std::cos(ang), ci = std::sin(ang);
+      ch[(size_t)n] = make_float2((float)cr, (float)ci);
+      bre[(size_t)n] = cr; bim[(size_t)n] = -ci;
+      if (n) { bre[(size_t)(P - n)] = cr; bim[(size_t)(P - n)] = -ci; }
+    }
+    host_fft_big(bre, bim);
+    for (int64_t i = 0; i < P; ++i) bf[(size_t)i] = make_float2((float)bre[(size_t)i], (float)bim[(size_t)i]);  // unscaled: the inverse rows divide by P
+    const void *dc = nullptr, *db = nullptr;
+    int rc = ctx_table(c, 0xB16B1ull ^ ((uint64_t)K << 8), ch.data(), ch.size() * sizeof(float2), &dc);
+    if (rc) return rc;
+    if ((rc = ctx_table(c, 0xB16B2ull ^ ((uint64_t)K << 8), bf.data(), bf.size() * sizeof(float2), &db))) return rc;
+    c->memo[key] = {reinterpret_cast<uint64_t>(dc), reinterpret_cast<uint64_t>(db)};
+    chirp = reinterpret_cast<const float2*>(dc); Bf = reinterpret_cast<const float2*>(db);
+  }
+  void *s1 = nullptr, *s2 = nullptr;
+  const size_t bytes = (size_t)rows * P * sizeof(float2);
+  int rc;
+  if ((rc = ctx_scratch(c, 8, bytes, &s1))) return rc;
+  if ((rc = ctx_scratch(c, 9, bytes, &s2))) return rc;
+  float2* A = reinterpret_cast<float2*>(s1);
+  float2* B = reinterpret_cast<float2*>(s2);
+  hipLaunchKernelGGL(k_blue_in, dim3(blocks_for(rows * P)), dim3(kT), 0, c->stream, in, in_is_real ? 1 : 0, rows, n_in, K, P, chirp, inverse ? 1 : 0, A);
+  NXSIG_HIP_TRY(hipGetLastError());
+  if ((rc = launch_fft_big(c, A, false, rows, P, P, false, B))) return rc;
+  hipLaunchKernelGGL(k_mul_rowtable, dim3(blocks_for(rows * P)), dim3(kT), 0, c->stream, B, Bf, rows, P);
+  NXSIG_HIP_TRY(hipGetLastError());
+  if ((rc = launch_fft_big(c, B, false, rows, P, P, true, A))) return rc;  // the inverse rows include the 1 / P
+  hipLaunchKernelGGL(k_blue_out, dim3(blocks_for(rows * K)), dim3(kT), 0, c->stream, A, rows, K, P, chirp, inverse ? 1 : 0, out);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+// rows of any length.  Lengths the LDS-resident kernels cover go straight to launch_fft.
+int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
+  if (rows == 0) return NXSIG_OK;
+  if (K < 1 || n_in < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fft: lengths must be >= 1");
+  const bool small = (nd_is_pow2(K) && K <= 8192) || (!nd_is_pow2(K) && K <= 4096);
+  if (small) {
+    if (n_in > 0x7fffffff) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: rows longer than 2^31");
+    return launch_fft(c, in, in_is_real, rows, (int32_t)n_in, (int32_t)K, inverse, out);
+  }
+  if (nd_is_pow2(K)) return fft_fourstep(c, in, in_is_real, rows, n_in, K, inverse, out);
+  return fft_bluestein_big(c, in, in_is_real, rows, n_in, K, inverse, out);
+}
+
+int launch_rows_post(Ctx* c, float2* a, int64_t rows, int64_t K, const float* window, float scale, bool has_scale, float div, bool has_div) {
+  if (rows == 0 || (!window && !has_scale && !has_div)) return NXSIG_OK;
+  hipLaunchKernelGGL(k_rows_post, dim3(blocks_for(rows * K)), dim3(kT), 0, c->stream, a, rows * K, K, window, scale, has_scale ? 1 : 0, div, has_div ? 1 : 0);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
+// ================================================================================================ fft_nd
+// in: device f32 / c64 tensor of `rank` dims (row-major); out: c64 tensor whose dims at `axes` are `lengths`
+int launch_fft_nd(Ctx* c, const void* in, bool in_is_real, const int64_t* shape, int rank, const int32_t* axes, const int64_t* lengths,
+                  int n_axes, bool inverse, float2* out) {
+  if (rank < 1 || rank > 8) return set_error(NXSIG_ERR_INVALID_ARG, "fft_nd: rank must be in [1, 8]");
+  std::vector<int64_t> cur(shape, shape + rank);
+  int64_t total = 1, max_total = 1;
+  for (int d = 0; d < rank; ++d) { if (cur[d] < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fft_nd: empty dimension"); total *= cur[d]; }
+  // the largest intermediate decides the scratch size
+  {
+    std::vector<int64_t> s2 = cur;
+    max_total = total;
+    for (int i = 0; i < n_axes; ++i) {
+      int ax = axes[i] < 0 ? axes[i] + rank : axes[i];
+      if (ax < 0 || ax >= rank) return set_error(NXSIG_ERR_INVALID_ARG, "fft_nd: axis out of bounds");
+      if (lengths[i] < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fft_nd: lengths must be positive");
+      s2[ax] = lengths[i];
+      int64_t t = 1;
+      for (auto v : s2) t *= v;
+      if (t > max_total) max_total = t;
+    }
+  }
+  if (n_axes == 0) {  // Enum.zip_reduce over nothing: the tensor itself (as c64)
+    hipLaunchKernelGGL(k_copy_pad, dim3(blocks_for(total)), dim3(kT), 0, c->stream, in, in_is_real ? 1 : 0, (int64_t)1, total, total, out);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  }
+  void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+  int rc;
+  const size_t bytes = (size_t)max_total * sizeof(float2);
+  if ((rc = ctx_scratch(c, 10, bytes, &p0))) return rc;
+  if ((rc = ctx_scratch(c, 11, bytes, &p1))) return rc;
+  if ((rc = ctx_scratch(c, 12, bytes, &p2))) return rc;
+  float2* bufs[3] = {reinterpret_cast<float2*>(p0), reinterpret_cast<float2*>(p1), reinterpret_cast<float2*>(p2)};
+  const void* src = in;
+  bool src_real = in_is_real;
+  int next = 0;
+  auto take = [&]() { float2* b = bufs[next]; next = (next + 1) % 3; return b; };
+  for (int i = 0; i < n_axes; ++i) {
+    const int ax = axes[i] < 0 ? axes[i] + rank : axes[i];
+    const int64_t K = lengths[i], na = cur[ax];
+    int64_t outer = 1, inner = 1;
+    for (int d = 0; d < ax; ++d) outer *= cur[d];
+    for (int d = ax + 1; d < rank; ++d) inner *= cur[d];
+    const bool last = i == n_axes - 1;
+    if (inner == 1) {  // the axis is already the fastest one
+      float2* dst = last ? out : take();
+      if ((rc = launch_fft_big(c, src, src_real, outer, na, K, inverse, dst))) return rc;
+      src = dst;
+    } else {
+      if (na > 0x7fffffff || inner > 0x7fffffff || K > 0x7fffffff) return set_error(NXSIG_ERR_UNSUPPORTED, "fft_nd: dimension beyond 2^31");
+      float2* t1 = take();  // [outer][na][inner] -> [outer][inner][na]
+      if ((rc = launch_transpose(c, src, src_real, outer, (int)na, (int)inner, na * inner, na * inner, t1))) return rc;
+      float2* t2 = take();
+      if ((rc = launch_fft_big(c, t1, false, outer * inner, na, K, inverse, t2))) return rc;
+      float2* dst = last ? out : take();  // [outer][inner][K] -> [outer][K][inner]
+      if ((rc = launch_transpose(c, t2, false, outer, (int)inner, (int)K, inner * K, inner * K, dst))) return rc;
+      src = dst;
+    }
+    src_real = false;
+    cur[ax] = K;
+  }
+  return NXSIG_OK;
+}
+
+// ================================================================================================ n-D fftconvolve
+struct BcastArgs {
+  int32_t rank;
+  int64_t oshape[8], astride[8], bstride[8];  // stride 0 where the operand's dimension is 1 (broadcast)
+  int64_t total;
+};
+__global__ __launch_bounds__(kT) void k_bcast_mul(const float2* __restrict__ a, const float2* __restrict__ b, BcastArgs g, float2* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= g.total) return;
+  int64_t rem = i, ia = 0, ib = 0;
+  for (int d = g.rank - 1; d >= 0; --d) {
+    const int64_t q = rem / g.oshape[d], x = rem - q * g.oshape[d];
+    ia += x * g.astride[d]; ib += x * g.bstride[d];
+    rem = q;
+  }
+  out[i] = ndmul(a[ia], b[ib]);
+}
+struct SliceArgs {
+  int32_t rank, real_out;
+  int64_t oshape[8], istride[8], start[8];
+  int64_t total;
+};
+__global__ __launch_bounds__(kT) void k_slice_out(const float2* __restrict__ in, SliceArgs g, void* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i >= g.total) return;
+  int64_t rem = i, ii = 0;
+  for (int d = g.rank - 1; d >= 0; --d) {
+    const int64_t q = rem / g.oshape[d], x = rem - q * g.oshape[d];
+    ii += (x + g.start[d]) * g.istride[d];
+    rem = q;
+  }
+  const float2 v = in[ii];
+  if (g.real_out) reinterpret_cast<float*>(out)[i] = v.x;  // Nx.real of the ifft for real operands (convolution.ex:286-291)
+  else reinterpret_cast<float2*>(out)[i] = v;
+}
+
+// a, b: device tensors of equal rank (f32 when *_is_real, else c64); out: f32 when both are real, else c64, shape per mode
+int launch_fftconvolve_nd(Ctx* c, const void* a, bool a_is_real, const int64_t* s1, const void* b, bool b_is_real, const int64_t* s2,
+                          int rank, int mode, void* out, int64_t* out_shape) {
+  if (rank < 1 || rank > 8) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: rank must be in [1, 8]");
+  int64_t full[8], res[8], start[8];
+  std::vector<int32_t> axes;
+  std::vector<int64_t> lens;
+  for (int d = 0; d < rank; ++d) {
+    if (s1[d] < 1 || s2[d] < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: empty dimension");
+    full[d] = s1[d] + s2[d] - 1;
+    if (s1[d] != 1 && s2[d] != 1) { axes.push_back(d); lens.push_back(full[d]); }  // convolution.ex:266-276
+  }
+  switch (mode) {  // apply_mode / centered, convolution.ex:300-347
+    case NXSIG_CONV_FULL: for (int d = 0; d < rank; ++d) { res[d] = full[d]; start[d] = 0; } break;
+    case NXSIG_CONV_SAME: for (int d = 0; d < rank; ++d) { res[d] = s1[d]; start[d] = (full[d] - s1[d]) / 2; } break;
+    case NXSIG_CONV_VALID: {
+      bool ok1 = true, ok2 = true;
+      for (int d = 0; d < rank; ++d) { ok1 = ok1 && s1[d] >= s2[d]; ok2 = ok2 && s2[d] >= s1[d]; }
+      if (!ok1 && !ok2)
+        return set_error(NXSIG_ERR_INVALID_ARG, "For 'valid' mode, one must be at least as large as the other in every dimension.");
+      for (int d = 0; d < rank; ++d) { res[d] = (ok1 ? s1[d] - s2[d] : s2[d] - s1[d]) + 1; start[d] = (full[d] - res[d]) / 2; }
+    } break;
+    default: return set_error(NXSIG_ERR_INVALID_ARG, "expected mode to be one of [:full, :same, :valid]");
+  }
+  // spectra: dims at the transformed axes become full[d]; the other dims keep each operand's own size (one of them is 1)
+  int64_t sh1[8], sh2[8], osh[8], n1 = 1, n2 = 1, no = 1;
+  for (int d = 0; d < rank; ++d) {
+    const bool tr = s1[d] != 1 && s2[d] != 1;
+    sh1[d] = tr ? full[d] : s1[d]; sh2[d] = tr ? full[d] : s2[d];
+    osh[d] = full[d];  // = max of the two for a broadcast axis
+    n1 *= sh1[d]; n2 *= sh2[d]; no *= osh[d];
+  }
+  void *pa = nullptr, *pb = nullptr, *pc = nullptr;
+  int rc;
+  if ((rc = ctx_scratch(c, 13, (size_t)(n1 > no ? n1 : no) * sizeof(float2), &pa))) return rc;  // A, later the inverse transform's result
+  if ((rc = ctx_scratch(c, 14, (size_t)n2 * sizeof(float2), &pb))) return rc;
+  if ((rc = ctx_scratch(c, 15, (size_t)no * sizeof(float2), &pc))) return rc;
+  float2 *A = reinterpret_cast<float2*>(pa), *B = reinterpret_cast<float2*>(pb), *C = reinterpret_cast<float2*>(pc);
+  if ((rc = launch_fft_nd(c, a, a_is_real, s1, rank, axes.data(), lens.data(), (int)axes.size(), false, A))) return rc;
+  if ((rc = launch_fft_nd(c, b, b_is_real, s2, rank, axes.data(), lens.data(), (int)axes.size(), false, B))) return rc;
+  BcastArgs g;
+  g.rank = rank; g.total = no;
+  int64_t st1 = 1, st2 = 1;
+  for (int d = rank - 1; d >= 0; --d) {
+    g.oshape[d] = osh[d];
+    g.astride[d] = sh1[d] == 1 && osh[d] != 1 ? 0 : st1;
+    g.bstride[d] = sh2[d] == 1 && osh[d] != 1 ? 0 : st2;
+    st1 *= sh1[d]; st2 *= sh2[d];
+  }
+  hipLaunchKernelGGL(k_bcast_mul, dim3(blocks_for(no)), dim3(kT), 0, c->stream, A, B, g, C);
+  NXSIG_HIP_TRY(hipGetLastError());
+  // ifft_nd over the same axes (lengths = current sizes) into A's slot: A is dead once the product is queued (stream order)
+  float2* D = A;
+  if ((rc = launch_fft_nd(c, C, false, osh, rank, axes.data(), lens.data(), (int)axes.size(), true, D))) return rc;
+  SliceArgs sl;
+  sl.rank = rank; sl.real_out = (a_is_real && b_is_real) ? 1 : 0; sl.total = 1;
+  int64_t st = 1;
+  for (int d = rank - 1; d >= 0; --d) { sl.oshape[d] = res[d]; sl.start[d] = start[d]; sl.istride[d] = st; st *= osh[d]; sl.total *= res[d]; }
+  hipLaunchKernelGGL(k_slice_out, dim3(blocks_for(sl.total)), dim3(kT), 0, c->stream, D, sl, out);
+  NXSIG_HIP_TRY(hipGetLastError());
+  if (out_shape) for (int d = 0; d < rank; ++d) out_shape[d] = res[d];
+  return NXSIG_OK;
+}
+
+// ================================================================================================ stft for long transforms
+__global__ __launch_bounds__(kT) void k_frames_windowed(const float* __restrict__ x, int64_t batch_stride, int64_t L, int64_t lo, int32_t reflect,
+                                                        int64_t M, int32_t N, int32_t hop, const float* __restrict__ w, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;  // (m, n) of one row
+  if (i >= M * N) return;
+  const int64_t m = i / N;
+  const int n = (int)(i - m * N);
+  int64_t pos = m * hop + n - lo;
+  const float* xr = x + (size_t)blockIdx.y * batch_stride;
+  float v;
+  if (reflect) {
+    if (L == 1) v = xr[0];
+    else {
+      const int64_t period = 2 * (L - 1);
+      pos %= period;
+      if (pos < 0) pos += period;
+      if (pos >= L) pos = period - pos;
+      v = xr[pos];
+    }
+  } else v = (pos >= 0 && pos < L) ? xr[pos] : 0.0f;
+  out[(size_t)blockIdx.y * M * N + i] = v * w[n];  // exact f32 product like lib/nx_signal.ex:101
+}
+
+int launch_stft_big(Ctx* c, const StftLaunch& s) {
+  if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
+  void* fr = nullptr;
+  int rc = ctx_scratch(c, 16, (size_t)s.batch * s.fr.M * s.fr.N * sizeof(float), &fr);
+  if (rc) return rc;
+  const int64_t per_row = s.fr.M * s.fr.N;
+  if ((per_row + kT - 1) / kT > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
+  hipLaunchKernelGGL(k_frames_windowed, dim3(blocks_for(per_row), (unsigned)s.batch), dim3(kT), 0, c->stream, s.x, s.batch_stride, s.fr.L, s.fr.lo,
+                     s.fr.reflect, s.fr.M, s.fr.N, s.fr.hop, s.window, reinterpret_cast<float*>(fr));
+  NXSIG_HIP_TRY(hipGetLastError());
+  const int64_t rows = (int64_t)s.batch * s.fr.M;
+  if ((rc = launch_fft_big(c, fr, true, rows, s.fr.N, s.K, false, s.z))) return rc;
+  return launch_rows_post(c, s.z, rows, s.K, nullptr, 1.0f, false, s.inv_scale_div, s.has_scale != 0);
+}
+
+}  // namespace nxsig

@@ -68,9 +68,10 @@ struct Ctx {
   // content-addressed small tables (windows, filter spectra ...): key = fnv1a(tag, bytes)
   std::map<uint64_t, DeviceTable> tables;
   // scratch buffer reused by multi-stage paths (generic istft, host staging)
-  // slots: 0 multi-stage temporaries, 1/2 host staging in/out, 3 wave-kernel dummy sink, 4 fused-path spectrum, 5 reduction cells
-  void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+  // slots: 0 multi-stage temporaries, 1/2 host staging in/out, 3 wave-kernel dummy sink, 4 fused-path spectrum, 5 reduction cells,
+  // 6-9 four-step / Bluestein rows, 10-12 fft_nd ping-pong, 13-15 n-D fftconvolve, 16 long-transform stft frames, 17-19 host staging of n-D calls
+  void* scratch[20] = {};
+  size_t scratch_bytes[20] = {};
   // per-K tables of the tuned wave kernels (pass-B / pass-C twiddles), built once
   struct WaveTables { const void* twB = nullptr; const void* twC = nullptr; const void* twI = nullptr;
                       const void* twBi = nullptr; const void* twCi = nullptr;    // ...i = conjugated (inverse transform)
@@ -141,6 +142,14 @@ int launch_spectrum_mul(Ctx* c, const float2* z, int64_t rows, int32_t K, const 
 int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t mel_bins, const float* filters_host,
                        float* out);
 int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled);
+// kernels_nd.hip: rows of any length (four-step / Bluestein beyond the LDS-resident kernels), device-side fft_nd, n-D fftconvolve
+int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out);
+int launch_rows_post(Ctx* c, float2* a, int64_t rows, int64_t K, const float* window, float scale, bool has_scale, float div, bool has_div);
+int launch_fft_nd(Ctx* c, const void* in, bool in_is_real, const int64_t* shape, int rank, const int32_t* axes, const int64_t* lengths,
+                  int n_axes, bool inverse, float2* out);
+int launch_fftconvolve_nd(Ctx* c, const void* a, bool a_is_real, const int64_t* s1, const void* b, bool b_is_real, const int64_t* s2,
+                          int rank, int mode, void* out, int64_t* out_shape);
+int launch_stft_big(Ctx* c, const StftLaunch& s);
 int launch_fftconvolve_c64(Ctx* c, const float2* a, int64_t n1, const float2* b, int64_t n2, int64_t start, int64_t len,
                            float2* out);
 

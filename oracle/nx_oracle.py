@@ -494,44 +494,46 @@ def istft(z, window, overlap_length=None, fft_length=None, sampling_rate=1000, s
 
 
 # --------------------------------------------------------------------------------------
-# NxSignal.Convolution.fftconvolve (1-D)  (lib/nx_signal/convolution.ex:252-347)
+# NxSignal.Convolution.fftconvolve (n-D)  (lib/nx_signal/convolution.ex:252-347)
 # --------------------------------------------------------------------------------------
 def fftconvolve(in1, in2, mode="full", eps=FFT_EPS):
+    """n-D: fft_nd of both operands over the axes where neither dimension is 1 with lengths s1 + s2 - 1 (:258-278), broadcast
+    product (c64 x c64 in double, rounded once), ifft_nd over the same axes (:284), Nx.real for real operands (:286-291),
+    apply_mode / centered (:300-347)."""
     if mode not in ("full", "same", "valid"):
         raise ValueError(f"expected mode to be one of [:full, :same, :valid], got: {mode!r}")
     a = np.asarray(in1)
     b = np.asarray(in2)
     if a.ndim != b.ndim:
         raise ValueError("Rank of in1 and in2 must be equal.")
-    if a.ndim != 1:
-        raise ValueError("oracle covers the 1-D case of fftconvolve only")
-    s1, s2 = a.shape[0], b.shape[0]
-    n = s1 + s2 - 1
+    s1, s2 = list(a.shape), list(b.shape)
+    lengths_all = [x + y - 1 for x, y in zip(s1, s2)]
+    axes = [i for i, (x, y) in enumerate(zip(s1, s2)) if x != 1 and y != 1]  # :265-274
+    lengths = [lengths_all[i] for i in axes]
     is_c = np.iscomplexobj(a) or np.iscomplexobj(b)
-    if s1 != 1 and s2 != 1:  # :265-274 axes where both dims != 1
-        sp1 = fft(a, length=n, eps=eps)
-        sp2 = fft(b, length=n, eps=eps)
-        # c64 * c64 in double, rounded once per component
-        c = (sp1.astype(c128) * sp2.astype(c128)).astype(c64)
-        out = ifft(c, length=None, eps=eps)
+    if axes:
+        sp1 = fft_nd(a, axes=axes, lengths=lengths)
+        sp2 = fft_nd(b, axes=axes, lengths=lengths)
+        c = (sp1.astype(c128) * sp2.astype(c128)).astype(c64)  # c64 * c64 in double, rounded once per component
+        out = fft_nd(c, axes=axes, lengths=[None] * len(axes), inverse=True)
     else:
-        # no FFT axis: broadcasting product of the inputs (c64 after ifft_nd over zero axes -> stays input type)
+        # no FFT axis: broadcasting product of the inputs
         out = (a.astype(c128) * b.astype(c128)).astype(c64) if is_c else (a.astype(f32) * b.astype(f32)).astype(f32)
     if not is_c and np.iscomplexobj(out):
         out = out.real.astype(f32)  # :286-291
     if mode == "full":
-        return out
+        return np.ascontiguousarray(out)
     if mode == "same":
         new = s1
     else:
-        if s1 >= s2:
-            new = s1 - s2 + 1
-        elif s2 >= s1:
-            new = s2 - s1 + 1
-        else:  # pragma: no cover
+        ok1 = all(x >= y for x, y in zip(s1, s2))
+        ok2 = all(y >= x for x, y in zip(s1, s2))
+        if not (ok1 or ok2):
             raise ValueError("For 'valid' mode, one must be at least as large as the other in every dimension.")
-    start = (out.shape[0] - new) // 2  # :319-329
-    return out[start : start + new]
+        big, small = (s1, s2) if ok1 else (s2, s1)
+        new = [x - y + 1 for x, y in zip(big, small)]
+    sl = tuple(slice((cur - n) // 2, (cur - n) // 2 + n) for cur, n in zip(out.shape, new))  # centered, :319-329
+    return np.ascontiguousarray(out[sl])
 
 
 def direct_convolve_f64(x, h):
@@ -603,7 +605,8 @@ def fft_nd(x, axes=(-1,), lengths=None, inverse=False):
 
 def correlate(a, b, mode="full"):
     """NxSignal.Convolution.correlate/3 (method: :fft) — lib/nx_signal/convolution.ex:87-93"""
-    k = np.asarray(b)[::-1]
+    k = np.asarray(b)
+    k = k[tuple(slice(None, None, -1) for _ in range(k.ndim))]
     if np.iscomplexobj(k):
         k = np.conj(k)
     return fftconvolve(np.asarray(a), np.ascontiguousarray(k), mode=mode)

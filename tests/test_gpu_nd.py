@@ -1,0 +1,120 @@
+"""Device-side multi-axis transforms, n-D fftconvolve and row lengths beyond the LDS-resident kernels (SURVEY §8 a13 / a14,
+§8f-4; csrc/kernels_nd.hip): NxSignal.Transforms.fft_nd / ifft_nd over any axes (lib/nx_signal/transforms.ex:5-21) and
+NxSignal.Convolution.fftconvolve/3 for operands of equal rank (lib/nx_signal/convolution.ex:252-347) against the oracle
+and the reference's own test literals; four-step rows (powers of two > 8192) and Bluestein rows (other lengths > 4096)
+against an f64 FFT; stft / istft with such fft_lengths against the oracle.  Tolerance: normalised max error < 1e-5."""
+import numpy as np
+import pytest
+
+from oracle import nx_oracle as O
+
+import nx_signal_amd as S
+
+pytestmark = pytest.mark.gpu
+
+
+def nerr(got, ref):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.max(np.abs(got.astype(np.complex128) - ref.astype(np.complex128))) / max(float(np.max(np.abs(ref))), 1e-30))
+
+
+def crandn(rng, *shape):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+
+
+@pytest.mark.parametrize("shape,axes,lengths", [
+    ((5, 7, 16), [0], [None]), ((5, 7, 16), [1], [9]), ((5, 7, 16), [1, 2], [None, 32]), ((5, 7, 16), [0, 2], [8, 5]),
+    ((5, 7, 16), [2, 0, 1], [16, 5, 7]), ((3, 100, 65), [1], [128]), ((130, 70), [0], [130]), ((130, 70), [0, 1], [256, 100]),
+    ((2, 3, 4, 5), [1, 3], [3, 8]), ((64, 64), [-2, -1], [None, None]), ((1, 9), [0], [4]), ((300,), [0], [512]),
+])
+def test_fft_nd_any_axes_host_and_device(shape, axes, lengths):
+    rng = np.random.default_rng(11)
+    for x in (rng.standard_normal(shape).astype(np.float32), crandn(rng, *shape)):
+        for inverse in (False, True):
+            fn = S.transforms.ifft_nd if inverse else S.transforms.fft_nd
+            want = O.fft_nd(x, axes=axes, lengths=lengths, inverse=inverse)
+            got = fn(x, axes=axes, lengths=lengths)
+            assert got.dtype == np.complex64 and nerr(got, want) < 1e-5, (shape, axes, lengths, inverse)
+            dgot = fn(S.default_context().to_device(x), axes=axes, lengths=lengths)  # stays in HBM
+            assert isinstance(dgot, S.DeviceBuffer) and np.array_equal(dgot.numpy().view(np.uint32), got.view(np.uint32))
+
+
+@pytest.mark.parametrize("K", [16384, 65536, 1 << 20, 5000, 12000, 10007, 16385, 100003])
+def test_long_rows_four_step_and_bluestein(K):
+    rng = np.random.default_rng(K)
+    rows = 3 if K <= 70000 else 1
+    x = crandn(rng, rows, K - 5)  # zero-padded to K
+    r = rng.standard_normal((rows, K + 7)).astype(np.float32)  # truncated to K
+    for inverse in (False, True):
+        fn = S.transforms.ifft_nd if inverse else S.transforms.fft_nd
+        npf = np.fft.ifft if inverse else np.fft.fft
+        assert nerr(fn(x, lengths=[K]), npf(x.astype(np.complex128), n=K, axis=-1)) < 1e-5, (K, inverse)
+        assert nerr(fn(r, lengths=[K]), npf(r.astype(np.float64), n=K, axis=-1)) < 1e-5, (K, inverse, "real")
+
+
+@pytest.mark.parametrize("N,K,hop", [(16384, 16384, 4096), (12000, 12000, 3000), (9000, 16384, 4500), (5000, 5000, 1250)])
+def test_stft_istft_with_long_transforms(N, K, hop):
+    x = O.synth_signal(N + hop * 6 + 17, seed=N)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=K, sampling_rate=48000)
+    for scaling in (None, "spectrum"):
+        z, t, f = S.stft(x, w, scaling=scaling, **opts)
+        zo, to, fo = O.stft(x, w, scaling=scaling, **opts)
+        assert nerr(z, zo) < 1e-5 and np.array_equal(t, to) and np.array_equal(f, fo)
+    if N == K:
+        zo, _, _ = O.stft(x, w, **opts)
+        y = S.istft(zo, w, **opts)
+        yo = O.istft(zo, w, **opts)
+        assert nerr(y, yo) < 1e-5
+
+
+def test_fftconvolve_nd_reference_literals(golden):
+    for v in golden["fftconvolve_nd"]:
+        def arr(x):
+            x = np.array(x)
+            return (x[..., 0] + 1j * x[..., 1]).astype(np.complex64) if v.get("complex") else x
+        a, b, e = arr(v["a"]), arr(v["b"]), arr(v["expect"])
+        for aa, bb in ([(a, b), (b, a)] if v.get("swap_too") else [(a, b)]):
+            out = S.convolution.convolve(aa, bb, method="fft", mode=v["mode"])
+            assert out.shape == e.shape and out.dtype == (np.complex64 if v.get("complex") else np.float32), v["src"]
+            assert np.all(np.abs(out - e) <= 1e-4 + 1e-4 * np.abs(e)), v["src"]  # assert_all_close of the reference
+
+
+@pytest.mark.parametrize("s1,s2", [((12, 17), (5, 4)), ((5, 4), (12, 17)), ((6, 1, 9), (3, 7, 2)), ((4, 5, 6), (4, 5, 6)),
+                                   ((40, 300), (7, 31)), ((2, 3, 4, 5), (2, 1, 3, 2)), ((1, 50), (1, 8)), ((33,), (5,))])
+@pytest.mark.parametrize("mode", ["full", "same", "valid"])
+def test_fftconvolve_nd_matches_oracle(s1, s2, mode):
+    rng = np.random.default_rng(sum(s1) + 3 * sum(s2))
+    ok1 = all(x >= y for x, y in zip(s1, s2))
+    ok2 = all(y >= x for x, y in zip(s1, s2))
+    for cplx in (False, True):
+        a = crandn(rng, *s1) if cplx else rng.standard_normal(s1).astype(np.float32)
+        b = rng.standard_normal(s2).astype(np.float32)
+        if mode == "valid" and not (ok1 or ok2):
+            with pytest.raises(S.ArgumentError, match="valid"):
+                S.convolution.fftconvolve(a, b, mode=mode)
+            continue
+        if len(s1) == 1 and not cplx:
+            continue  # 1-D real runs the overlap-save kernel (covered elsewhere)
+        got = S.convolution.fftconvolve(a, b, mode=mode)
+        want = O.fftconvolve(a, b, mode=mode)
+        assert got.dtype == want.dtype and nerr(got, want) < 1e-5, (s1, s2, mode, cplx)
+
+
+def test_fftconvolve_rank_mismatch_and_long_complex():
+    with pytest.raises(S.ArgumentError, match="Rank of in1 and in2 must be equal"):
+        S.convolution.fftconvolve(np.ones((3, 3), np.float32), np.ones((2, 2, 2), np.float32))
+    rng = np.random.default_rng(5)
+    a, b = crandn(rng, 20000), crandn(rng, 3000)  # n1 + n2 - 1 = 22 999 > 8192: four-step transforms
+    for mode in ("full", "same", "valid"):
+        got = S.convolution.fftconvolve(a, b, mode=mode)
+        ref = np.convolve(a.astype(np.complex128), b.astype(np.complex128), mode=mode)
+        assert nerr(got, ref) < 1e-5
+
+
+def test_correlate_2d():
+    rng = np.random.default_rng(2)
+    a, k = rng.standard_normal((9, 11)).astype(np.float32), rng.standard_normal((3, 4)).astype(np.float32)
+    got = S.convolution.correlate(a, k, method="fft", mode="same")
+    assert nerr(got, O.correlate(a, k, mode="same")) < 1e-5

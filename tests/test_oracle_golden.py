@@ -218,3 +218,18 @@ def test_oracle_config1_regression_fixture():
     assert tuple(fx["shape_y"]) == y.shape
     ys = float(np.max(np.abs(y)))
     assert np.max(np.abs(y[:1536] - fx["y_head"])) / ys < 1e-6 and np.max(np.abs(y[-1536:] - fx["y_tail"])) / ys < 1e-6
+
+
+def test_fftconvolve_nd_golden(golden):
+    """n-D FFT-method convolution of the oracle against the reference's own test literals (convolutions_test.exs:95-142,
+    :152-162, :444-453, :489-530), compared like the reference's assert_all_close (atol = rtol = 1e-4)"""
+    for v in golden["fftconvolve_nd"]:
+        def arr(x):
+            x = np.array(x)
+            return (x[..., 0] + 1j * x[..., 1]).astype(np.complex64) if v.get("complex") else x
+        a, b, e = arr(v["a"]), arr(v["b"]), arr(v["expect"])
+        for aa, bb in ([(a, b), (b, a)] if v.get("swap_too") else [(a, b)]):
+            out = O.fftconvolve(aa, bb, mode=v["mode"])
+            assert out.shape == e.shape, v["src"]
+            assert out.dtype == (np.complex64 if v.get("complex") else np.float32)
+            assert np.all(np.abs(out - e) <= 1e-4 + 1e-4 * np.abs(e)), v["src"]

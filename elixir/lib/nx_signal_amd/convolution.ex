@@ -1,9 +1,9 @@
 defmodule NxSignalAMD.Convolution do
   @moduledoc """
-  The FFT leg of `NxSignal.Convolution` (lib/nx_signal/convolution.ex:38-58, :252-329) for 1-D operands:
-  `convolve(a, b, method: :fft)` / `fftconvolve/3`.  Real operands run the overlap-save kernel (any length, batched over
-  leading axes of `a`); complex operands one transform of up to 8192 points.  `method: :direct` and n-D operands are not
-  part of the accelerated path and raise.
+  The FFT leg of `NxSignal.Convolution` (lib/nx_signal/convolution.ex:38-58, :252-347): `convolve(a, b, method: :fft)` /
+  `fftconvolve/3`.  A real stream against a real 1-D filter runs the overlap-save kernel (any length, batched over leading
+  axes of `a`); every other pair of operands of equal rank (complex, 2-D, 3-D ...) runs the device-side `fft_nd` fold like
+  the reference.  `method: :direct` is not part of the accelerated path and raises.
   """
   alias NxSignalAMD.NIF
 
@@ -24,27 +24,42 @@ defmodule NxSignalAMD.Convolution do
     opts = Keyword.validate!(opts, [:method, mode: :full])
     mode = mode!(opts[:mode])
 
-    if Nx.rank(in2) != 1 or Nx.rank(in1) < 1 do
-      raise ArgumentError, "the accelerated fftconvolve takes a 1-D second operand (the filter); n-D convolution is not accelerated"
-    end
-
     complex? = match?({:c, _}, Nx.type(in1)) or match?({:c, _}, Nx.type(in2))
     ctx = NxSignalAMD.context()
 
-    if complex? do
-      if Nx.rank(in1) != 1, do: raise(ArgumentError, "complex fftconvolve takes 1-D operands")
-      a = in1 |> Nx.as_type(:c64) |> Nx.to_binary()
-      b = in2 |> Nx.as_type(:c64) |> Nx.to_binary()
-      {:ok, out} = NIF.fftconvolve_c64(ctx, a, b, mode) |> NxSignalAMD.unwrap!()
-      Nx.from_binary(out, :c64)
-    else
-      {batch_shape, length} = NxSignalAMD.split_last(Nx.shape(in1))
-      batch = Tuple.product(batch_shape)
-      x = in1 |> Nx.as_type(:f32) |> Nx.to_binary()
-      h = in2 |> Nx.as_type(:f32) |> Nx.to_binary()
-      {:ok, y} = NIF.fir(ctx, x, length, batch, h, mode) |> NxSignalAMD.unwrap!()
-      n_out = div(byte_size(y), 4 * max(batch, 1))
-      Nx.from_binary(y, :f32) |> Nx.reshape(Tuple.insert_at(batch_shape, tuple_size(batch_shape), n_out))
+    cond do
+      Nx.rank(in2) == 1 and Nx.rank(in1) >= 1 and not complex? ->
+        # the streaming case: overlap-save FIR, `in1` may carry leading batch axes
+        {batch_shape, length} = NxSignalAMD.split_last(Nx.shape(in1))
+        batch = Tuple.product(batch_shape)
+        x = in1 |> Nx.as_type(:f32) |> Nx.to_binary()
+        h = in2 |> Nx.as_type(:f32) |> Nx.to_binary()
+        {:ok, y} = NIF.fir(ctx, x, length, batch, h, mode) |> NxSignalAMD.unwrap!()
+        n_out = div(byte_size(y), 4 * max(batch, 1))
+        Nx.from_binary(y, :f32) |> Nx.reshape(Tuple.insert_at(batch_shape, tuple_size(batch_shape), n_out))
+
+      Nx.rank(in1) != Nx.rank(in2) ->
+        raise ArgumentError, "Rank of in1 and in2 must be equal."
+
+      true ->
+        {a, a_real} = operand(in1)
+        {b, b_real} = operand(in2)
+
+        {:ok, out, out_shape} =
+          NIF.fftconvolve_nd(ctx, a, a_real, Tuple.to_list(Nx.shape(in1)), b, b_real, Tuple.to_list(Nx.shape(in2)), mode)
+          |> NxSignalAMD.unwrap!()
+
+        type = if a_real == 1 and b_real == 1, do: :f32, else: :c64
+        Nx.from_binary(out, type) |> Nx.reshape(List.to_tuple(out_shape))
+    end
+  end
+
+  defp operand(t) do
+    case Nx.type(t) do
+      {:c, 64} -> {Nx.to_binary(t), 0}
+      {:c, _} -> raise ArgumentError, "only c64 complex tensors are supported"
+      {:f, 64} -> raise ArgumentError, "f64 tensors are not supported by the MI355X path"
+      _ -> {t |> Nx.as_type(:f32) |> Nx.to_binary(), 1}
     end
   end
 

@@ -30,6 +30,10 @@ defmodule NxSignalAMD.NIF do
 
   def fft(_ctx, _in, _is_real, _rows, _n_in, _fft_length, _inverse), do: :erlang.nif_error(:nif_not_loaded)
   def fftconvolve_c64(_ctx, _a, _b, _mode), do: :erlang.nif_error(:nif_not_loaded)
+  def fft_nd(_ctx, _in, _is_real, _shape, _axes, _lengths, _inverse), do: :erlang.nif_error(:nif_not_loaded)
+
+  def fftconvolve_nd(_ctx, _a, _a_is_real, _a_shape, _b, _b_is_real, _b_shape, _mode),
+    do: :erlang.nif_error(:nif_not_loaded)
   def stft_to_mel(_ctx, _z, _rows, _fft_length, _mel_bins, _filters), do: :erlang.nif_error(:nif_not_loaded)
 
   def stft_mel(_ctx, _x, _length, _batch, _window, _params, _mel_bins, _filters),

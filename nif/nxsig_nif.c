@@ -360,6 +360,76 @@ static ERL_NIF_TERM nif_fftconvolve_c64(ErlNifEnv* env, int argc, const ERL_NIF_
   return mk_ok(env, enif_make_binary(env, &ob));
 }
 
+static int get_i64_list(ErlNifEnv* env, ERL_NIF_TERM list, int64_t* out, unsigned cap, unsigned* n) {
+  ERL_NIF_TERM head, tail = list;
+  if (!enif_get_list_length(env, list, n) || *n > cap) return 0;
+  for (unsigned i = 0; i < *n; ++i) {
+    ErlNifSInt64 v;
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !enif_get_int64(env, head, &v)) return 0;
+    out[i] = v;
+  }
+  return 1;
+}
+
+/* fft_nd(ctx, in_bin, in_is_real, shape, axes, lengths, inverse) -> {:ok, c64 binary}   (Transforms.fft_nd / ifft_nd, any axes) */
+static ERL_NIF_TERM nif_fft_nd(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary in, ob;
+  int is_real, inv;
+  int64_t shape[8], axes64[16], lengths[16], osh[8];
+  int32_t axes[16];
+  unsigned rank, na, nl;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &in) || !enif_get_int(env, argv[2], &is_real) ||
+      !get_i64_list(env, argv[3], shape, 8, &rank) || !get_i64_list(env, argv[4], axes64, 16, &na) ||
+      !get_i64_list(env, argv[5], lengths, 16, &nl) || !enif_get_int(env, argv[6], &inv) || rank < 1 || na != nl)
+    return enif_make_badarg(env);
+  size_t n_in = 1, n_out = 1;
+  for (unsigned d = 0; d < rank; ++d) { if (shape[d] < 1 || !mul_size(&n_in, (uint64_t)shape[d])) return enif_make_badarg(env); osh[d] = shape[d]; }
+  if (in.size % (is_real ? 4 : 8) || in.size / (is_real ? 4 : 8) != n_in) return enif_make_badarg(env);
+  for (unsigned i = 0; i < na; ++i) {
+    int64_t ax = axes64[i] < 0 ? axes64[i] + (int64_t)rank : axes64[i];
+    if (ax < 0 || ax >= (int64_t)rank || lengths[i] < 1) return enif_make_badarg(env);
+    axes[i] = (int32_t)ax; osh[ax] = lengths[i];
+  }
+  for (unsigned d = 0; d < rank; ++d) if (!mul_size(&n_out, (uint64_t)osh[d])) return mk_oom(env);
+  if (!out_bin(&ob, n_out, 1, 1, 8)) return mk_oom(env);
+  int rc = nxsig_fft_nd(c->ctx, in.data, is_real, shape, (int32_t)rank, axes, lengths, (int32_t)na, inv, (nxsig_c64*)ob.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &ob));
+}
+
+/* fftconvolve_nd(ctx, a_bin, a_is_real, a_shape, b_bin, b_is_real, b_shape, mode) -> {:ok, out_bin, out_shape}
+ * (Convolution.fftconvolve/3 for operands of equal rank; out is f32 when both are real, else c64) */
+static ERL_NIF_TERM nif_fftconvolve_nd(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary a, b, ob;
+  int a_real, b_real, mode;
+  int64_t s1[8], s2[8], osh[8];
+  unsigned r1, r2;
+  if (argc != 8 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &a) || !enif_get_int(env, argv[2], &a_real) ||
+      !get_i64_list(env, argv[3], s1, 8, &r1) || !enif_inspect_binary(env, argv[4], &b) || !enif_get_int(env, argv[5], &b_real) ||
+      !get_i64_list(env, argv[6], s2, 8, &r2) || !enif_get_int(env, argv[7], &mode) || r1 < 1)
+    return enif_make_badarg(env);
+  if (r1 != r2) return mk_error_msg(env, NXSIG_ERR_INVALID_ARG, "Rank of in1 and in2 must be equal.");  /* convolution.ex:295-296 */
+  size_t na = 1, nb = 1, nfull = 1;
+  for (unsigned d = 0; d < r1; ++d) {
+    if (s1[d] < 1 || s2[d] < 1 || !mul_size(&na, (uint64_t)s1[d]) || !mul_size(&nb, (uint64_t)s2[d]) ||
+        !mul_size(&nfull, (uint64_t)(s1[d] + s2[d] - 1)))
+      return enif_make_badarg(env);
+  }
+  if (a.size % (a_real ? 4 : 8) || a.size / (a_real ? 4 : 8) != na || b.size % (b_real ? 4 : 8) || b.size / (b_real ? 4 : 8) != nb)
+    return enif_make_badarg(env);
+  const size_t es = (a_real && b_real) ? 4 : 8;
+  if (!out_bin(&ob, nfull, 1, 1, es)) return mk_oom(env);  /* every mode's result fits the full size */
+  int rc = nxsig_fftconvolve_nd(c->ctx, a.data, a_real, s1, b.data, b_real, s2, (int32_t)r1, mode, ob.data, osh, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  size_t nres = 1;
+  ERL_NIF_TERM dims[8];
+  for (unsigned d = 0; d < r1; ++d) { nres *= (size_t)osh[d]; dims[d] = enif_make_int64(env, osh[d]); }
+  if (!enif_realloc_binary(&ob, nres * es)) { enif_release_binary(&ob); return mk_oom(env); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), enif_make_binary(env, &ob), enif_make_list_from_array(env, dims, r1));
+}
+
 /* stft_to_mel(ctx, z_bin, rows, fft_length, mel_bins, filters_bin) -> {:ok, f32[rows][mel_bins]}   (lib/nx_signal.ex:486-513) */
 static ERL_NIF_TERM nif_stft_to_mel(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
@@ -626,6 +696,8 @@ static ErlNifFunc funcs[] = {
     {"overlap_and_add", 7, nif_overlap_and_add, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fft", 7, nif_fft, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fftconvolve_c64", 4, nif_fftconvolve_c64, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"fft_nd", 7, nif_fft_nd, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"fftconvolve_nd", 8, nif_fftconvolve_nd, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_to_mel", 6, nif_stft_to_mel, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_mel", 8, nif_stft_mel, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"to_device", 2, nif_to_device, ERL_NIF_DIRTY_JOB_IO_BOUND},

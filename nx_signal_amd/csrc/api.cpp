@@ -80,18 +80,29 @@ int ctx_twiddles(Ctx* c, int K, const float2** out) {
 }
 
 int ctx_table(Ctx* c, uint64_t tag, const void* host, size_t bytes, const void** out) {
-  const uint64_t key = fnv1a(tag, host, bytes) ^ (uint64_t)bytes;
-  auto it = c->tables.find(key);
-  if (it == c->tables.end()) {
-    DeviceTable t;
-    t.bytes = bytes;
-    NXSIG_HIP_TRY(hipMalloc(&t.ptr, bytes ? bytes : 4));
-    NXSIG_HIP_TRY(hipMemcpyAsync(t.ptr, host, bytes, hipMemcpyHostToDevice, c->stream));
-    NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
-    it = c->tables.emplace(key, t).first;
+  // content-addressed: key = fnv1a(tag, content) ^ size.  A hit is VERIFIED (size + content of the kept host copy): on a
+  // 64-bit collision the next key is probed instead of silently handing out another table (a wrong window / filter).
+  uint64_t key = fnv1a(tag, host, bytes) ^ (uint64_t)bytes;
+  for (int probe = 0; probe < 8; ++probe, key = key * 0x9E3779B97F4A7C15ull + 1) {
+    auto it = c->tables.find(key);
+    if (it == c->tables.end()) {
+      DeviceTable t;
+      t.bytes = bytes;
+      NXSIG_HIP_TRY(hipMalloc(&t.ptr, bytes ? bytes : 4));
+      NXSIG_HIP_TRY(hipMemcpyAsync(t.ptr, host, bytes, hipMemcpyHostToDevice, c->stream));
+      NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+      if (bytes <= ((size_t)1 << 20)) t.host.assign(static_cast<const unsigned char*>(host), static_cast<const unsigned char*>(host) + bytes);
+      it = c->tables.emplace(key, std::move(t)).first;
+      *out = it->second.ptr;
+      return NXSIG_OK;
+    }
+    const DeviceTable& t = it->second;
+    if (t.bytes == bytes && (t.host.empty() ? bytes > ((size_t)1 << 20) : std::memcmp(t.host.data(), host, bytes) == 0)) {
+      *out = t.ptr;
+      return NXSIG_OK;
+    }
   }
-  *out = it->second.ptr;
-  return NXSIG_OK;
+  return set_error(NXSIG_ERR_HIP, "table cache: repeated hash collisions");
 }
 
 int ctx_scratch(Ctx* c, int slot, size_t bytes, void** out) {
@@ -162,8 +173,11 @@ int launch_fir(Ctx* c, const FirLaunch& a) {
 struct DeviceGuard {
   explicit DeviceGuard(Ctx* c) : lock(c->mu) {
     ok = (hipSetDevice(c->device) == hipSuccess);
-    // bound the content-addressed table cache.  Done at API entry only, never while a call holds table pointers.
-    if (ok && c->tables.size() > 256) {
+    // bound the content-addressed table cache.  Done at API entry only, never while a call holds table pointers, and never
+    // while the stream is being captured (a captured graph bakes table pointers in).  A graph captured EARLIER stays valid as
+    // long as its context sees fewer than 1024 distinct tables afterwards; beyond that re-capture it (streams).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (ok && c->tables.size() > 1024 && hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
       (void)hipStreamSynchronize(c->stream);
       for (auto& kv : c->tables) (void)hipFree(kv.second.ptr);
       c->tables.clear();

@@ -933,7 +933,9 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
   const int N = s.N, hop = s.hop;
   const int64_t out_len = s.M * hop + (N - hop);
   // everything derived on the host below is a pure function of (window, hop, M): memoised per context
-  const uint64_t ekey = fnv1a(0xED6Full ^ ((uint64_t)hop << 24) ^ ((uint64_t)s.M << 40), window_host, (size_t)N * sizeof(float)) ^ (uint64_t)N;
+  // key = hash of (hop, M, N) AS DATA followed by the window's content (shifting them into the seed aliased for large M / hop)
+  const int64_t ekey_geom[3] = {(int64_t)hop, (int64_t)s.M, (int64_t)N};
+  const uint64_t ekey = fnv1a(fnv1a(0xED6Full, ekey_geom, sizeof(ekey_geom)), window_host, (size_t)N * sizeof(float));
   {
     auto hit = c->memo.find(ekey);
     if (hit != c->memo.end()) {

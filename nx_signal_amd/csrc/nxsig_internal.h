@@ -51,6 +51,7 @@ int make_framing(int64_t L, int32_t N, int32_t hop, int32_t pad_mode, int64_t pa
 struct DeviceTable {
   void* ptr = nullptr;
   size_t bytes = 0;
+  std::vector<unsigned char> host;  // copy of the content (tables <= 1 MiB): a hash hit is verified against it
 };
 
 struct Ctx {

@@ -66,7 +66,7 @@ def lib():
             ("fake_call", vp, [vp, C.c_char_p, C.c_int, C.POINTER(vp)]), ("fake_binary", vp, [vp, vp, sz]),
             ("fake_copy_resource", vp, [vp, vp]), ("fake_tag", C.c_int, [vp]), ("fake_atom_name", C.c_char_p, [vp]),
             ("fake_bin_data", vp, [vp]), ("fake_bin_size", sz, [vp]), ("fake_tuple_arity", C.c_int, [vp]),
-            ("fake_tuple_elem", vp, [vp, C.c_int]), ("fake_live_resources", C.c_long, []), ("fake_dtor_calls", C.c_long, []),
+            ("fake_tuple_elem", vp, [vp, C.c_int]), ("fake_cons_head", vp, [vp]), ("fake_cons_tail", vp, [vp]), ("fake_live_resources", C.c_long, []), ("fake_dtor_calls", C.c_long, []),
             ("fake_live_binaries", C.c_long, []), ("fake_set_alloc_limit", None, [sz]),
             ("enif_make_int64", vp, [vp, C.c_int64]), ("enif_make_double", vp, [vp, C.c_double]), ("enif_make_atom", vp, [vp, C.c_char_p]),
             ("enif_make_tuple_from_array", vp, [vp, C.POINTER(vp), C.c_uint]), ("enif_make_list_from_array", vp, [vp, C.POINTER(vp), C.c_uint]),
@@ -123,6 +123,14 @@ def _from_term(L, t):
         return C.string_at(L.fake_bin_data(t), L.fake_bin_size(t))
     if tag == T_TUPLE:
         return tuple(_from_term(L, L.fake_tuple_elem(t, i)) for i in range(L.fake_tuple_arity(t)))
+    if tag == T_NIL:
+        return []
+    if tag == T_CONS:
+        out = []
+        while L.fake_tag(t) == T_CONS:
+            out.append(_from_term(L, L.fake_cons_head(t)))
+            t = L.fake_cons_tail(t)
+        return out
     if tag == T_RES:
         return Res(L.fake_copy_resource(_keep, t))
     if tag == T_BADARG:

@@ -83,6 +83,7 @@ unsigned char* enif_make_new_binary(ErlNifEnv*, size_t size, ERL_NIF_TERM* termp
 int enif_alloc_binary(size_t size, ErlNifBinary* bin);
 ERL_NIF_TERM enif_make_binary(ErlNifEnv*, ErlNifBinary* bin);
 void enif_release_binary(ErlNifBinary* bin);
+int enif_realloc_binary(ErlNifBinary* bin, size_t size);
 ERL_NIF_TERM enif_make_badarg(ErlNifEnv*);
 ERL_NIF_TERM enif_make_tuple2(ErlNifEnv*, ERL_NIF_TERM, ERL_NIF_TERM);
 ERL_NIF_TERM enif_make_tuple3(ErlNifEnv*, ERL_NIF_TERM, ERL_NIF_TERM, ERL_NIF_TERM);

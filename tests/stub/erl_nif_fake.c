@@ -120,6 +120,12 @@ ERL_NIF_TERM enif_make_binary(ErlNifEnv* env, ErlNifBinary* bin) {
   return (ERL_NIF_TERM)t;
 }
 void enif_release_binary(ErlNifBinary* bin) { if (bin->ref_bin) { free(bin->ref_bin); --g_live_binaries; bin->data = NULL; bin->ref_bin = NULL; } }
+int enif_realloc_binary(ErlNifBinary* bin, size_t size) {
+  unsigned char* p = (unsigned char*)realloc(bin->data, size ? size : 1);
+  if (!p) return 0;
+  bin->data = p; bin->ref_bin = p; bin->size = size;
+  return 1;
+}
 long fake_live_binaries(void) { return g_live_binaries; }
 ERL_NIF_TERM enif_make_badarg(ErlNifEnv* env) { return (ERL_NIF_TERM)new_term(env, T_BADARG); }
 ERL_NIF_TERM enif_make_tuple2(ErlNifEnv* e, ERL_NIF_TERM a, ERL_NIF_TERM b) { ERL_NIF_TERM v[2] = {a, b}; return enif_make_tuple_from_array(e, v, 2); }
@@ -186,5 +192,7 @@ const unsigned char* fake_bin_data(ERL_NIF_TERM t) { return T(t)->u.bin.data; }
 size_t fake_bin_size(ERL_NIF_TERM t) { return T(t)->u.bin.size; }
 int fake_tuple_arity(ERL_NIF_TERM t) { return T(t)->u.tup.n; }
 ERL_NIF_TERM fake_tuple_elem(ERL_NIF_TERM t, int i) { return T(t)->u.tup.e[i]; }
+ERL_NIF_TERM fake_cons_head(ERL_NIF_TERM t) { return T(t)->u.cons.head; }
+ERL_NIF_TERM fake_cons_tail(ERL_NIF_TERM t) { return T(t)->u.cons.tail; }
 long fake_live_resources(void) { return g_live_resources; }
 long fake_dtor_calls(void) { return g_dtor_calls; }

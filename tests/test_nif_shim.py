@@ -280,3 +280,28 @@ def test_sharded_calls_through_the_nif():
     assert e.value.code == -1 and ":valid" in e.value.msg
     del g, g1, ctx
     H.release_all()
+
+
+@gpu
+def test_fft_nd_and_fftconvolve_nd_through_the_nif(nctx, golden):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((5, 7, 16)).astype(np.float32)
+    ok, ob = H.call("fft_nd", nctx, x, 1, [5, 7, 16], [1, -1], [9, 32], 0)
+    want = S.transforms.fft_nd(x, axes=[1, 2], lengths=[9, 32])
+    assert np.array_equal(c64(ob).view(np.uint32), want.reshape(-1).view(np.uint32))
+    with pytest.raises(H.BadArg):
+        H.call("fft_nd", nctx, x, 1, [5, 7, 16], [3], [9], 0)
+    for v in golden["fftconvolve_nd"]:
+        def arr(t):
+            t = np.array(t)
+            return (t[..., 0] + 1j * t[..., 1]).astype(np.complex64) if v.get("complex") else t.astype(np.float32)
+        a, b, e = arr(v["a"]), arr(v["b"]), arr(v["expect"])
+        mode = {"full": 0, "same": 1, "valid": 2}[v["mode"]]
+        real = 0 if v.get("complex") else 1
+        ok, ob, osh = H.call("fftconvolve_nd", nctx, a, real, list(a.shape), b, real, list(b.shape), mode)
+        out = (f32(ob) if real else c64(ob)).reshape(osh)
+        assert tuple(osh) == e.shape and np.all(np.abs(out - e) <= 1e-4 + 1e-4 * np.abs(e)), v["src"]
+    with pytest.raises(H.NifError) as ei:
+        H.call("fftconvolve_nd", nctx, x, 1, [5, 7, 16], x, 1, [5, 112], 0)
+    assert ei.value.code == -1 and "Rank of in1 and in2 must be equal" in ei.value.msg
+    assert H.lib().fake_live_binaries() == 0

@@ -33,10 +33,22 @@ class UndefinedNif(Exception):
 
 
 class Res:
-    """a resource term kept alive in the harness' long-lived environment"""
+    """a resource term that outlives the call that made it: it sits in an environment of its own (what the BEAM does when a
+    term is kept by a process); dropping the Python object frees that environment, i.e. releases the reference"""
 
-    def __init__(self, term):
-        self.term = term
+    def __init__(self, env, term):
+        self.env, self.term = env, term
+
+    def release(self):
+        if self.env is not None:
+            _lib.fake_env_free(self.env)
+            self.env = self.term = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 def build(force=False):
@@ -132,7 +144,8 @@ def _from_term(L, t):
             t = L.fake_cons_tail(t)
         return out
     if tag == T_RES:
-        return Res(L.fake_copy_resource(_keep, t))
+        env = L.fake_env_new()
+        return Res(env, L.fake_copy_resource(env, t))
     if tag == T_BADARG:
         raise BadArg()
     raise TypeError(f"term tag {tag}")
@@ -157,8 +170,7 @@ def call(name, *args):
 
 
 def release_all():
-    """drops every resource term Python still holds (runs the destructors whose last reference this was)"""
-    global _keep
-    L = lib()
-    L.fake_env_free(_keep)
-    _keep = L.fake_env_new()
+    """kept for symmetry with earlier tests: resources are released when their Res objects die"""
+    import gc
+
+    gc.collect()

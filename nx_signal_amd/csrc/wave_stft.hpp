@@ -33,6 +33,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "nxsig_internal.h"
 
@@ -618,8 +619,8 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
           v2f u[J];
 #pragma unroll
           for (int m = 0; m < J; ++m) u[m] = zz[e][q + HQ * m];
-          if (J == 2) { const v2f s0 = u[0] + u[1], s1 = u[0] - u[1]; u[0] = s0; u[1] = s1; }
-          else if (J == 4) dft4<true>(u[0], u[1], u[2], u[3]);
+          if constexpr (J == 2) { const v2f s0 = u[0] + u[1], s1 = u[0] - u[1]; u[0] = s0; u[1] = s1; }
+          else if constexpr (J == 4) dft4<true>(u[0], u[1], u[2], u[3]);
           else dft8<true>(u);
 #pragma unroll
           for (int j = 0; j < J; ++j) {
@@ -634,6 +635,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
       for (int j = 0; j < J; ++j) {
         v2f* zfa = (mA + 2 * j < a.M) ? z0 + (size_t)(2 * j) * KOUT : dm;      // frame m0 + 2j      (real part of c_j)
         v2f* zfb = (mA + 2 * j + 1 < a.M) ? z0 + (size_t)(2 * j + 1) * KOUT : dm;  // frame m0 + 2j + 1 (imaginary part)
+        const StreamRow ra(zfa - 2 * lane, KOUT * 8), rb2(zfb - 2 * lane, KOUT * 8);  // wave-uniform row descriptors (SALU only)
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
           const v2f own0 = cs[j][0][(HQ - q) % HQ];
@@ -660,6 +662,9 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
                 if (mA + 2 * j + 1 < a.M) mag_store(r0 + KH, pb2);
               }
             }
+          } else if (ST > 0 && !GENERAL) {  // streaming kernel: "sc1 nt" stores through the two frames' row descriptors
+            ra.st16(xa, lane * 16 + 1024 * q);
+            rb2.st16(xbv, lane * 16 + 1024 * q);
           } else {
             __builtin_nontemporal_store(xa, (gv4f*)(zfa + 128 * q));
             __builtin_nontemporal_store(xbv, (gv4f*)(zfb + 128 * q));

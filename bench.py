@@ -279,11 +279,28 @@ def main():
     group = None
     filectl = None
     comm_error = None
+    hung_thread = False
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:  # under a launcher (any world size): RCCL through the C ABI
-        try:
-            group = sharding.Group.ranked(world, rank, local_rank)
-        except Exception as e:  # noqa: BLE001  (never lose the measurement to the communicator)
-            comm_error = repr(e)[:300]
+        # the communicator comes up in a watchdog thread: a rendezvous that never completes (a rank that died, a launcher
+        # that does not give the ranks a common parent ...) must not hang the measurement
+        import threading
+
+        box = {}
+
+        def _init():
+            try:
+                box["group"] = sharding.Group.ranked(world, rank, local_rank, timeout_ms=90000)
+            except Exception as e:  # noqa: BLE001  (never lose the measurement to the communicator)
+                box["error"] = repr(e)[:300]
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(timeout=150.0 if world > 1 else 60.0)
+        if "group" in box:
+            group = box["group"]
+        else:
+            comm_error = box.get("error", "RCCL communicator creation did not finish in time")
+            hung_thread = th.is_alive()
             print(f"[bench rank {rank}] RCCL group creation failed: {comm_error}; control plane falls back to files", file=sys.stderr)
             if world > 1:
                 filectl = FileControl(_lib.load(), sharding.rendezvous_path() + ".ctl", world, rank)
@@ -466,6 +483,10 @@ def main():
         group.close()
     if filectl is not None:
         filectl.cleanup()
+    if hung_thread:  # a communicator call that never returned would block interpreter shutdown
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

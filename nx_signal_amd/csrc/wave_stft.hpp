@@ -484,8 +484,13 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
       for (int s = 0; s < P; ++s) { ra[s] = pa[64 * s]; rb[s] = pb[64 * s]; }
     } else if (MODE == kModeReal2x) {  // complex point n = (x[2n], x[2n+1])
       const float* pa = a.x + (size_t)row * a.batch_stride + (pin * a.hop - a.lo) + 2 * lane;
+      if (STG == 2) {  // every frame starts on an 8-byte boundary (checked by the launcher): one 8-byte load per point
 #pragma unroll
-      for (int s = 0; s < P; ++s) { ra[s] = pa[128 * s]; rb[s] = pa[128 * s + 1]; }
+        for (int s = 0; s < P; ++s) { const v2f t = *reinterpret_cast<const v2f*>(pa + 128 * s); ra[s] = t.x; rb[s] = t.y; }
+      } else {
+#pragma unroll
+        for (int s = 0; s < P; ++s) { ra[s] = pa[128 * s]; rb[s] = pa[128 * s + 1]; }
+      }
     } else {  // quad: lane carries sequence j = lane % J = frames (m0 + 2j, m0 + 2j + 1); core point lane + 64 s = J n + j
       const int64_t fa = pin * (2 * J) + 2 * (lane % J), fb = fa + 1, last = a.M - 1;
       const float* base = a.x + (size_t)row * a.batch_stride - a.lo + (lane / J);
@@ -1234,6 +1239,15 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
                                : go(k_stft_wave<C, MODE, false, false, W, J, false, 8>, upr, big, u_lo, u_lo);
         else rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, true, 8>, upr, big, u_lo, u_lo)
                         : go(k_stft_wave<C, MODE, false, false, W, J, true, 8>, upr, big, u_lo, u_lo);
+      }
+    }
+    if constexpr (MODE == kModeReal2x) {
+      // even hop / padding / row stride and an 8-byte aligned signal: the frame's samples travel as 8-byte loads
+      if (!done && !npred && !env_int("NXSIG_NO_AL8", 0) && (reinterpret_cast<uintptr_t>(s.x) & 7) == 0 && (s.batch_stride & 1) == 0 &&
+          (hop & 1) == 0 && (lo & 1) == 0) {
+        done = true;
+        rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 2>, upr, big, u_lo, u_lo)
+                   : go(k_stft_wave<C, MODE, false, false, W, J, false, 2>, upr, big, u_lo, u_lo);
       }
     }
     if constexpr (MODE == kModePair && C == 1024) {

@@ -36,6 +36,10 @@ for f in find("trace", "*kernel_trace.csv"):
         r0 = meta[key]
         print(f"  {short(key[0]):64s} grid={key[1]} wg={key[2]} n={len(v)} mean_us={sum(v)/len(v)/1e3:.2f} median_us={v2[len(v2)//2]/1e3:.2f} min_us={v2[0]/1e3:.2f}"
               f" | VGPR={r0.get('VGPR_Count')} accVGPR={r0.get('Accum_VGPR_Count')} SGPR={r0.get('SGPR_Count')} LDS={r0.get('LDS_Block_Size')} scratch={r0.get('Scratch_Size')}")
+        if len(v) > 40:  # bench.py: pre-conditioning + warm-up launches come first, the TIMED window is the last --steps launches
+            t = v[-20:]
+            print(f"      last 20 launches (bench.py's timed window at --steps 20): mean_us={sum(t)/len(t)/1e3:.2f} min_us={min(t)/1e3:.2f} max_us={max(t)/1e3:.2f}"
+                  f" | first 12 launches (us): {' '.join(str(round(x/1e3)) for x in v[:12])}")
 for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for f in find(sub, "*counter_collection.csv"):
         rows = list(csv.DictReader(open(f)))

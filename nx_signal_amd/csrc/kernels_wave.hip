@@ -954,6 +954,9 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
     a.total_units = units_per_row * s.batch;
     const int units_per_wave = env_int("NXSIG_FIR_UNITS_PER_WAVE", 16);  // short chunks, many workgroups (see launch_wave)
     a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
+    // the edge launch has few, slow (bounds-checked) units: one per wave so that they all run concurrently, unless every pair
+    // goes through it (filters whose taps - 1 is not a multiple of 128)
+    if (!stream && a.total_units <= (int64_t)c->num_cus * W) a.chunk = W;
     const int64_t blocks = (a.total_units + a.chunk - 1) / a.chunk;
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: signal too long for one launch");
     if (lds > 64 * 1024) {

@@ -173,3 +173,31 @@ def test_sharded_rejects_padding_modes(pair):
     x = O.synth_signal(5000, seed=1)
     with pytest.raises(_lib.ArgumentError, match="valid"):
         sharding.stft_sharded(pair, x, S.windows.hann(64), axis="frames", window_padding="reflect")
+
+
+def test_config4_and_config5_partitioning_with_eight_members():
+    """BASELINE configs 4 / 5 shard 64 channels over 8 GPUs (8 contiguous channels each, no halo, no exchange).  Eight members
+    on the one GPU of this box run exactly that plan (N=2048 hop=512 Hann; 257-tap low-pass) on a shortened stream and must
+    reproduce the unsharded HIP result bit for bit, with and without the assembly."""
+    g = sharding.Group.local(8, devices=[0] * 8)
+    try:
+        assert [sharding.shard_channels(64, 8, r) for r in (0, 3, 7)] == [(0, 8), (24, 32), (56, 64)]
+        x = np.stack([np.roll(O.synth_signal(40000, seed=900), 131 * c) * np.float32(1 + 0.01 * c) for c in range(64)])
+        w = S.windows.hann(2048)
+        opts = dict(overlap_length=2048 - 512, fft_length=2048, sampling_rate=48000)
+        full, _, _ = S.stft(x, w, **opts)
+        for gather in (False, True):
+            got = sharding.stft_sharded(g, x, w, axis="channels", gather=gather, **opts)
+            assert np.array_equal(bits(got), bits(full))
+        h = S.filters.firwin(257, [4000.0], sampling_rate=48000)
+        yfull = S.filters.fir(x, h, mode="same")
+        for gather in (False, True):
+            got = sharding.fir_sharded(g, x, h, mode="same", axis="channels", gather=gather)
+            assert np.array_equal(bits(got), bits(yfull))
+        # one long stream split into 8 frame ranges with a 1536-sample input halo each
+        long = O.synth_signal(2048 + 512 * 799, seed=901)
+        zl, _, _ = S.stft(long, w, **opts)
+        got = sharding.stft_sharded(g, long, w, axis="frames", gather=True, **opts)
+        assert got.shape == zl.shape and float(np.max(np.abs(got - zl)) / np.max(np.abs(zl))) < 1e-6
+    finally:
+        g.close()

@@ -32,6 +32,7 @@ UNITS = [
     ("kernels_wave_mel.hip", []),
     ("kernels_wave_mag.hip", []),
     ("kernels_wave_r20.hip", []),
+    ("kernels_wave_8k.hip", []),
 ]
 
 

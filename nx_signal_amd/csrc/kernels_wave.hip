@@ -629,6 +629,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
 }
 
 int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_r20.hip
+int launch_stft_wave_8k(Ctx* c, const StftLaunch& s, bool* handled);                      // kernels_wave_8k.hip
 
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   *handled = false;
@@ -643,6 +644,10 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
     case 128: *handled = true; return launch_wave<1024, kModeQuad, 4, 8>(c, s);    // 16 frames
     case 2048: *handled = true; return launch_wave<1024, kModeReal2x, 4>(c, s);    // one frame as even/odd samples
     case 4096: *handled = true; return launch_wave<2048, kModeReal2x, 4>(c, s);    // same on the 2048-point core
+    case 8192: {                                                                   // four passes through the 1024-point core
+      int rc8 = launch_stft_wave_8k(c, s, handled);
+      if (rc8 || *handled) return rc8;
+    } break;
     default: break;
   }
   if (s.K == 400) {  // 20 x 20 native kernel (kernels_wave_r20.hip)

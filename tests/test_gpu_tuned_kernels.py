@@ -311,3 +311,25 @@ def test_stft_interior_units_do_not_leak_samples_past_the_frame(K, N, hop):
     assert np.array_equal(fin, expect)
     assert 0 < (~fin).sum() < fin.size // 4
     assert nerr(z[fin], zo[fin]) < 1e-5
+
+
+@pytest.mark.parametrize("N,hop,pad,scaling,L", [
+    (8192, 2048, "valid", None, 8192 * 5 + 77), (8192, 1024, "reflect", "spectrum", 8192 * 3 + 1), (8192, 8192, "same", None, 8192 * 4),
+    (8192, 4096, [(100, 3000)], "psd", 8192 * 3), (6000, 1500, "valid", None, 50001), (6000, 2000, "reflect", None, 30000),
+    (8192, 2047, "valid", None, 8192 * 3 + 5),
+])
+def test_stft_8192_on_four_passes_of_the_1024_core(N, hop, pad, scaling, L):
+    """fft_length 8192 (kernels_wave_8k.hip): interior frames stream, edge frames / padding modes / short frames (N < 8192)
+    take the bounds-checked instantiation; odd hops exercise the unaligned loads; batch rows and > 1 frame per wave"""
+    x = np.stack([O.synth_signal(L, seed=70 + c) for c in range(3)])
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=8192, sampling_rate=48000, window_padding=pad, scaling=scaling)
+    z, t, f = S.stft(x, w, **opts)
+    for c in range(3):
+        zo, to, fo = O.stft(x[c], w, **opts)
+        d = float(np.max(np.abs(z[c] - zo)) / np.max(np.abs(zo)))
+        assert z[c].shape == zo.shape and d < 1e-5, (N, hop, pad, c, d)
+    assert np.array_equal(t, to) and np.array_equal(f, fo)
+    zd, _, _ = S.stft(S.default_context().to_device(x[:, 1:]), w, **opts)  # odd (4-byte aligned only) base address
+    zo, _, _ = O.stft(x[0, 1:], w, **opts)
+    assert float(np.max(np.abs(zd.numpy()[0] - zo)) / np.max(np.abs(zo))) < 1e-5

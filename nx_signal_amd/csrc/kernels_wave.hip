@@ -136,6 +136,125 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
   }
 }
 
+// ---- iSTFT for N = 4096 (hop 512 / 1024 / 2048 / 4096): FOUR passes through the 1024-point inverse core per frame.
+// x[n0 + 1024 m] = 1/4096 sum_r conj(w_4096^(r n0)) w_4^(-r m) Y_r[n0],  Y_r = IDFT_1024(Z[4 k' + r]) (unscaled): the lane reads
+// Z[4 (l + 64 s) .. + 3] as two 16-byte loads (all four decimated sub-spectra at once: every byte of the frame is loaded
+// exactly once), runs the core four times and combines lane-locally.  Sample n0 + 1024 m sits on the lane that owns n0 = 2 l +
+// par + 128 q, so a lane's positions inside every hop segment are the same and the overlap-add stays in registers like in
+// k_istft_wave.  The next frame's 32 loads are in flight during the four cores; the frame data (128), the prefetch (128) and the
+// pending sums (up to 112) exceed 256 registers, so the kernel runs one wave per SIMD (4 waves per workgroup) and the
+// compiler parks the surplus in the accumulation half of the unified register file.
+template <int R, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) void k_istft_wave_4k(IstftWaveArgs a) {
+  constexpr int K = 1024, NQ = 8, P = 16, NF = 4096, XCH = K + K / 16 + 16;
+  constexpr int HOPC = NF / R;           // hop (compile-time: 512 .. 4096)
+  constexpr int SL = HOPC / 128;         // 128-sample slots per hop segment (per parity)
+  v2f* s_wv = reinterpret_cast<v2f*>(g_wave_smem);   // window as adjacent pairs: s_wv[i] = (w[2 i], w[2 i + 1])
+  v2f* s_twB = s_wv + NF / 2;
+  v2f* s_twC = s_twB + 256;
+  v2f* s_t4 = s_twC + 4 * 256;           // conj(w_4096^k), k < 1024
+  v2f* s_x = s_t4 + K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < NF / 2; i += 64 * W) s_wv[i] = reinterpret_cast<const v2f*>(a.wtab)[i];
+  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
+  for (int i = tid; i < 4 * 256; i += 64 * W) s_twC[i] = a.twC[i];
+  for (int i = tid; i < K; i += 64 * W) s_t4[i] = a.twH[i];
+  __syncthreads();
+  v2f* xb = s_x + wave * XCH;
+  const int64_t run = (int64_t)blockIdx.x * W + wave;
+  if (run >= a.total_runs) return;
+  const int64_t row = run / a.runs_per_row;
+  const int64_t j0 = (run - row * a.runs_per_row) * a.run_len;
+  int64_t j1 = j0 + a.run_len;
+  if (j1 > a.segs_per_row) j1 = a.segs_per_row;
+  const int64_t m_start = j0 >= (R - 1) ? j0 - (R - 1) : 0;
+  const float invK = 1.0f / (float)NF;
+  v2f pend[R - 1 > 0 ? R - 1 : 1][2][SL];
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) pend[i][e][sl] = v2f{0.f, 0.f};
+
+  const v4f* zrow = reinterpret_cast<const v4f*>(a.z + (size_t)row * a.M * NF) + 2 * lane;
+  v4f ra[P], rb[P];   // Z[4 (l + 64 s) + 0, 1] and [+ 2, 3]
+  auto issue_loads = [&](int64_t m) {
+    const v4f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * (NF / 2);
+#pragma unroll
+    for (int s = 0; s < P; ++s) { ra[s] = pz[128 * s]; rb[s] = pz[128 * s + 1]; }
+  };
+  issue_loads(m_start);
+  v4f ca[P], cb[P];
+#pragma unroll
+  for (int s = 0; s < P; ++s) { ca[s] = ra[s]; cb[s] = rb[s]; }
+
+  for (int64_t m = m_start; m < j1; ++m) {
+    issue_loads(m + 1 < j1 ? m + 1 : m);  // unconditional prefetch keeps the loop branch-free
+    __builtin_amdgcn_sched_barrier(0);
+    v2f y[4][2][NQ];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v2f d[P];
+#pragma unroll
+      for (int s = 0; s < P; ++s) {
+        const v4f t = r < 2 ? ca[s] : cb[s];
+        d[s] = (r & 1) ? v2f{t.z, t.w} : v2f{t.x, t.y};
+      }
+      wave_fft_core<K, true>(d, y[r], xb, s_twB, s_twC, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s = 0; s < P; ++s) { ca[s] = ra[s]; cb[s] = rb[s]; }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- lane-local inverse radix-4: y[mm][par][q] <- 4096 x[n0 + 1024 mm]
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const v2f t1 = s_t4[2 * lane + e + 128 * q];
+        const v2f t2 = wcmul(t1, t1), t3 = wcmul(t2, t1);
+        v2f a0 = y[0][e][q], a1 = wcmul(y[1][e][q], t1), a2 = wcmul(y[2][e][q], t2), a3 = wcmul(y[3][e][q], t3);
+        dft4<true>(a0, a1, a2, a3);
+        y[0][e][q] = a0; y[1][e][q] = a1; y[2][e][q] = a2; y[3][e][q] = a3;
+      }
+    const float live = m < a.M ? 1.0f : 0.0f;  // tail flush: frames m >= M do not exist
+    const int64_t j = m;
+    const int64_t trow = j < R - 1 ? j : (j >= a.M ? R + (j - a.M) : R - 1);
+    const float* dp = a.den + trow * a.hop + 2 * lane;
+    v2f* yp = (j >= j0) ? a.y + (size_t)row * a.segs_per_row * a.hop + j * a.hop + 2 * lane : a.dummy + 2 * lane;
+    // frame samples ((IDFT / K) * scale) * window folded into the pending overlap sums in ascending frame order;
+    // sample n0 + 1024 mm lies in hop segment (128 q + 1024 mm) / HOPC at slot ((128 q + 1024 mm) % HOPC) / 128
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      v2f out[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        v2f f[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const int off = i * HOPC + 128 * sl;           // 128 q + 1024 mm of segment i, slot sl
+          const int mm = off / 1024, q = (off % 1024) / 128;
+          v2f v = y[mm][e][q] * invK;
+          if (SCALE) v = v * a.scale;
+          const v2f wp = s_wv[lane + 64 * q + 512 * mm];   // (w[n], w[n + 1]) for n = 2 lane + 128 q + 1024 mm
+          f[i] = v * ((e ? wp.y : wp.x) * live);
+        }
+        if (R == 1) { out[e] = f[0]; }
+        else {
+          out[e] = pend[0][e][sl] + f[0];
+#pragma unroll
+          for (int i = 0; i + 1 < R - 1; ++i) pend[i][e][sl] = pend[i + 1][e][sl] + f[i + 1];
+          pend[R - 2][e][sl] = f[R - 1];
+        }
+      }
+      const v2f den = *reinterpret_cast<const v2f*>(dp + 128 * sl);
+      const v4f o = v4f{out[0].x * den.x, out[0].y * den.x, out[1].x * den.y, out[1].y * den.y};
+      __builtin_nontemporal_store(o, (gv4f*)(yp + 128 * sl));
+    }
+  }
+}
+
 // ---- iSTFT for N = K/2 (512): TWO consecutive frames per 1024-point inverse FFT.  Z[k0] = C0 + w_K^k0 C1,
 // Z[k0 + K/2] = C0 - w_K^k0 C1 is built lane-locally in the core's input layout (k0 = lane + 64 s'), and the inverse
 // core returns sample n = lane + 64 q of frame 0 in zz[0][q] and of frame 1 in zz[1][q]: the overlap-add between the
@@ -794,6 +913,53 @@ static int launch_istft_wave_quad(Ctx* c, const IstftLaunch& s, const float* win
   return s.has_scale ? go(k_istft_wave_quad<K, J, R, true, W>) : go(k_istft_wave_quad<K, J, R, false, W>);
 }
 
+template <int R>
+static int launch_istft_wave_4k(Ctx* c, const IstftLaunch& s, const float* window_host) {
+  constexpr int K = 1024, W = 4, XCH = K + K / 16 + 16, NF = 4096;
+  IstftWaveArgs a;
+  a.z = reinterpret_cast<const v2f*>(s.z); a.M = s.M; a.batch = s.batch; a.hop = s.hop;
+  a.segs_per_row = s.M + R - 1;
+  a.wtab = s.window;  // raw window, N == K == 4096
+  Ctx::WaveTables& wt = c->wave_tables[K];
+  if (!wt.twB) return NXSIG_ERR_UNSUPPORTED;
+  a.twB = reinterpret_cast<const v2f*>(wt.twBi);
+  a.twC = reinterpret_cast<const v2f*>(wt.twCi);
+  a.scale = s.scale_mul;
+  { int rc3 = istft_den_table(c, R, s.hop, window_host, &a.den); if (rc3) return rc3; }
+  a.y = reinterpret_cast<v2f*>(s.y);
+  void* dummy = nullptr;
+  { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
+  a.dummy = reinterpret_cast<v2f*>(dummy);
+  {
+    std::vector<float2> t4(K);
+    for (int k = 0; k < K; ++k) {
+      const double ang = 6.283185307179586476925286766559 * (double)k / 4096.0;  // conj(w_4096^k)
+      t4[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    const void* d4 = nullptr;
+    int rc4 = ctx_table(c, 0x8B14ull, t4.data(), t4.size() * sizeof(float2), &d4);
+    if (rc4) return rc4;
+    a.twH = reinterpret_cast<const v2f*>(d4);
+  }
+  const int64_t total_segs = a.segs_per_row * s.batch;
+  const int waves_per_cu = env_int("NXSIG_ISTFT4K_RUNS_PER_CU", 4);  // one wave per SIMD
+  int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
+  const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", 8);
+  if (run_len < min_run) run_len = min_run;
+  a.run_len = run_len;
+  a.runs_per_row = (a.segs_per_row + run_len - 1) / run_len;
+  a.total_runs = a.runs_per_row * s.batch;
+  const int64_t blocks = (a.total_runs + W - 1) / W;
+  const size_t lds = (size_t)NF * 4 + 256 * 8 + (size_t)4 * 256 * 8 + (size_t)K * 8 + (size_t)W * XCH * 8;
+  auto go = [&](auto kernel) -> int {
+    NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  };
+  return s.has_scale ? go(k_istft_wave_4k<R, true, W>) : go(k_istft_wave_4k<R, false, W>);
+}
+
 int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);  // kernels_wave_r20.hip
 
 int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
@@ -851,6 +1017,19 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
       case 2: return launch_istft_wave_R<2, 4, false, true>(c, s, s.window, window_host);
       case 4: return launch_istft_wave_R<4, 4, false, true>(c, s, s.window, window_host);
       default: return launch_istft_wave_R<8, 4, false, true>(c, s, s.window, window_host);
+    }
+  }
+  if (s.K == 4096 && s.N == 4096 && !env_int("NXSIG_DISABLE_4K", 0)) {  // four passes through the 1024-point inverse core per frame
+    if (s.hop != 512 && s.hop != 1024 && s.hop != 2048 && s.hop != 4096) return NXSIG_OK;
+    if (s.M < 2 * (4096 / s.hop) - 1) return NXSIG_OK;
+    int rc5 = ensure_wave_tables_1024(c);
+    if (rc5) return rc5;
+    *handled = true;
+    switch (4096 / s.hop) {
+      case 1: return launch_istft_wave_4k<1>(c, s, window_host);
+      case 2: return launch_istft_wave_4k<2>(c, s, window_host);
+      case 4: return launch_istft_wave_4k<4>(c, s, window_host);
+      default: return launch_istft_wave_4k<8>(c, s, window_host);
     }
   }
   if (s.K != 1024 || s.N != 1024) return NXSIG_OK;       // other sizes: generic two-stage path

@@ -333,3 +333,27 @@ def test_stft_8192_on_four_passes_of_the_1024_core(N, hop, pad, scaling, L):
     zd, _, _ = S.stft(S.default_context().to_device(x[:, 1:]), w, **opts)  # odd (4-byte aligned only) base address
     zo, _, _ = O.stft(x[0, 1:], w, **opts)
     assert float(np.max(np.abs(zd.numpy()[0] - zo)) / np.max(np.abs(zo))) < 1e-5
+
+
+@pytest.mark.parametrize("hop,scaling,M,batch", [(1024, None, 40, 3), (512, "spectrum", 23, 2), (2048, "psd", 9, 2), (4096, None, 5, 1), (1024, None, 7, 1),
+                                                 (1024, None, 300, 8)])
+def test_istft_4096_on_four_passes_of_the_1024_core(hop, scaling, M, batch):
+    """istft N = 4096 (k_istft_wave_4k): non-Hermitian random spectra (the output is complex like the reference's), every hop
+    the kernel takes, scaling modes, runs that start mid-row (halo frames), short inputs just above the 2R - 1 frame minimum"""
+    N = 4096
+    rng = np.random.default_rng(hop + M)
+    z = (rng.standard_normal((batch, M, N)) + 1j * rng.standard_normal((batch, M, N))).astype(np.complex64)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000, scaling=scaling)
+    y = S.istft(z, w, **opts)
+    for b in range(min(batch, 2)):
+        yo = O.istft(z[b], w, **opts)
+        d = float(np.max(np.abs(y[b] - yo)) / np.max(np.abs(yo)))
+        assert y[b].shape == yo.shape and d < 1e-5, (hop, scaling, M, b, d)
+    if hop == N:
+        return  # no overlap under a tapered window: the reference itself does not round-trip (normaliser guard, quirk B9)
+    x = O.synth_signal(N + hop * (M - 1), seed=5)  # round trip of a real signal through stft (tuned fft_length-4096 kernel) and back
+    zs, _, _ = S.stft(x, w, **opts)
+    ys = S.istft(zs, w, **opts)
+    core = slice(N, x.size - N) if x.size > 3 * N else slice(N // 2, N // 2 + 16)
+    assert float(np.max(np.abs(ys.real[core] - x[core]))) < 1e-4 * max(1.0, float(np.max(np.abs(x))))

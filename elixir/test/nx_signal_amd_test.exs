@@ -1,0 +1,59 @@
+defmodule NxSignalAMDTest do
+  # Values come from the reference's own doctests (elixir-nx/nx_signal v0.3.0: lib/nx_signal.ex:46-65, :182-204, :545-554,
+  # :656-681; lib/nx_signal/windows.ex:266-275) — the same literals tests/golden/reference_vectors.json holds for the Python
+  # mirror and the NIF harness.  Not run in the build image (no BEAM); `cd elixir && mix test` on a machine with OTP + a GPU.
+  use ExUnit.Case, async: false
+
+  alias NxSignalAMD, as: Sig
+
+  test "stft doctest: rectangular window of 2, hop 1, fs 400" do
+    {z, t, f} = Sig.stft(Nx.iota({4}), Sig.Windows.rectangular(2), overlap_length: 1, fft_length: 2, sampling_rate: 400)
+    assert Nx.shape(z) == {3, 2}
+    assert Nx.names(z) == [:frames, :frequencies]
+    assert Nx.to_flat_list(Nx.real(z)) == [1.0, -1.0, 3.0, -1.0, 5.0, -1.0]
+    assert Nx.to_flat_list(t) == [0.0025, 0.005, 0.0075] |> Enum.map(&Nx.to_number(Nx.tensor(&1, type: :f32)))
+    assert Nx.to_flat_list(f) == [0.0, 200.0]
+  end
+
+  test "as_windowed keeps integer tensors exact" do
+    out = Sig.as_windowed(Nx.iota({10}), window_length: 4)
+    assert Nx.type(out) == {:s, 64}
+    assert Nx.to_list(out) == for(i <- 0..6, do: Enum.to_list(i..(i + 3)))
+  end
+
+  test "overlap_and_add doctest" do
+    assert Nx.to_flat_list(Sig.overlap_and_add(Nx.iota({3, 4}), overlap_length: 0)) == Enum.to_list(0..11)
+    assert Nx.to_flat_list(Sig.overlap_and_add(Nx.iota({3, 4}), overlap_length: 3)) == [0, 5, 15, 18, 17, 11]
+
+    assert_raise ArgumentError, ~r/overlap_length must be a number less than the window size 4, got: 4/, fn ->
+      Sig.overlap_and_add(Nx.iota({3, 4}), overlap_length: 4)
+    end
+  end
+
+  test "hann window is bit-identical to the reference's doctest" do
+    assert Nx.to_flat_list(Sig.Windows.hann(5, is_periodic: false)) == [0.0, 0.5, 1.0, 0.5, 0.0]
+  end
+
+  test "stft |> istft round trip stays on the device" do
+    x = Nx.iota({4096}, type: :f32) |> Nx.sin()
+    w = Sig.Windows.hann(1024)
+    opts = [overlap_length: 768, fft_length: 1024, sampling_rate: 48_000]
+    xd = Sig.DeviceTensor.to_device(x)
+    {zd, _t, _f} = Sig.stft(xd, w, opts)
+    assert %Sig.DeviceTensor{shape: {13, 1024}, type: {:c, 64}} = zd
+    y = zd |> Sig.istft(w, opts) |> Sig.DeviceTensor.from_device() |> Nx.real()
+    assert Nx.to_number(Nx.reduce_max(Nx.abs(Nx.subtract(y[1024..3071], x[1024..3071])))) < 1.0e-5
+  end
+
+  test "vectorized (multichannel) inputs keep their vectorized axes" do
+    x = Nx.iota({3, 2048}, type: :f32) |> Nx.vectorize(:channel)
+    {z, _t, _f} = Sig.stft(x, Sig.Windows.hann(256), overlap_length: 192, sampling_rate: 8_000)
+    assert z.vectorized_axes == [channel: 3]
+    assert Nx.shape(z) == {29, 256}
+  end
+
+  test "invalid options raise ArgumentError like the reference" do
+    assert_raise ArgumentError, ~r/invalid :scaling/, fn -> Sig.stft(Nx.iota({16}), Sig.Windows.hann(4), scaling: :eggs) end
+    assert_raise ArgumentError, ~r/invalid padding mode/, fn -> Sig.stft(Nx.iota({16}), Sig.Windows.hann(4), window_padding: :zeros) end
+  end
+end

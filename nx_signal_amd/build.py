@@ -33,6 +33,7 @@ UNITS = [
     ("kernels_wave_mag.hip", []),
     ("kernels_wave_r20.hip", []),
     ("kernels_wave_8k.hip", []),
+    ("kernels_wave_rows.hip", []),
 ]
 
 

@@ -769,12 +769,20 @@ int launch_stft_generic(Ctx* c, const StftLaunch& s) {
   return NXSIG_OK;
 }
 
+int launch_fft_rows_wave(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse,
+                         const float* post_window, float post_scale, bool has_post_scale, float2* out, bool* handled);
+
 static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse,
                            const float* post_window, float post_scale, bool has_post_scale, float2* out) {
   if (rows == 0) return NXSIG_OK;
   FftRowsArgs a;
   a.in = in; a.in_is_real = in_is_real ? 1 : 0; a.rows = rows; a.n_in = n_in; a.K = K;
   a.post_window = post_window; a.post_scale = post_scale; a.has_post_scale = has_post_scale ? 1 : 0; a.out = out;
+  {  // K = 1024 / 2048 / 4096: one wave per row on the wave-private cores (kernels_wave_rows.hip)
+    bool handled = false;
+    int rcw = launch_fft_rows_wave(c, in, in_is_real, rows, n_in, K, inverse, post_window, post_scale, has_post_scale, out, &handled);
+    if (rcw || handled) return rcw;
+  }
   if ((is_pow2(K) && K > kMaxLdsPow2) || (!is_pow2(K) && K > 4096)) {
     // beyond the LDS-resident kernels: four-step / Bluestein rows in HBM (kernels_nd.hip), then the istft epilogue if any
     int rcb = launch_fft_big(c, in, in_is_real, rows, n_in, K, inverse, out);

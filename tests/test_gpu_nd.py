@@ -118,3 +118,34 @@ def test_correlate_2d():
     a, k = rng.standard_normal((9, 11)).astype(np.float32), rng.standard_normal((3, 4)).astype(np.float32)
     got = S.convolution.correlate(a, k, method="fft", mode="same")
     assert nerr(got, O.correlate(a, k, mode="same")) < 1e-5
+
+
+@pytest.mark.parametrize("K", [1024, 2048, 4096])
+def test_wave_core_row_kernels(K):
+    """kernels_wave_rows.hip: K = 1024 / 2048 (one core pass) and 4096 (four passes + radix-4) rows, f32 and c64 inputs,
+    zero-padded (n_in < K), exact (the 16-byte fast path of the 4096 kernel) and truncated (n_in > K) rows, both directions,
+    odd row counts (partial workgroups)"""
+    rng = np.random.default_rng(K)
+    for n_in in (K - 5, K, K + 7, 3):
+        for rows in (1, 37):
+            xc = crandn(rng, rows, n_in)
+            xr = rng.standard_normal((rows, n_in)).astype(np.float32)
+            for inverse in (False, True):
+                fn = S.transforms.ifft_nd if inverse else S.transforms.fft_nd
+                npf = np.fft.ifft if inverse else np.fft.fft
+                assert nerr(fn(xc, lengths=[K]), npf(xc.astype(np.complex128), n=K, axis=-1)) < 1e-5, (K, n_in, rows, inverse)
+                assert nerr(fn(xr, lengths=[K]), npf(xr.astype(np.float64), n=K, axis=-1)) < 1e-5, (K, n_in, rows, inverse, "real")
+
+
+@pytest.mark.parametrize("N,hop", [(2048, 300), (4096, 1000), (1024, 100)])
+def test_generic_istft_rides_the_wave_rows(N, hop):
+    """hops the fused istft kernels do not take: rows IFFT (wave row kernels with the x scale x window epilogue) + deterministic OLA"""
+    rng = np.random.default_rng(N + hop)
+    M = 9
+    z = crandn(rng, 2, M, N)
+    w = S.windows.hann(N)
+    for scaling in (None, "spectrum"):
+        opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000, scaling=scaling)
+        y = S.istft(z, w, **opts)
+        for b in range(2):
+            assert nerr(y[b], O.istft(z[b], w, **opts)) < 1e-5, (N, hop, scaling, b)

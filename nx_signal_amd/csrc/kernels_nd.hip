@@ -49,8 +49,9 @@ struct TrArgs {
 __global__ __launch_bounds__(kT) void k_transpose(TrArgs a) {
   __shared__ float2 tile[kTile][kTile + 1];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
-  const int64_t o = blockIdx.z;
-  const int r0 = blockIdx.y * kTile, c0 = blockIdx.x * kTile;
+  const int64_t o = blockIdx.y;
+  const int tiles_c = (a.C + kTile - 1) / kTile;   // tiles are numbered along blockIdx.x (2^31 of them): no 65535-row limit
+  const int r0 = (int)(blockIdx.x / tiles_c) * kTile, c0 = (int)(blockIdx.x % tiles_c) * kTile;
   const int64_t pbase = o * a.plane_stride;
 #pragma unroll 4
   for (int i = ty; i < kTile; i += 4) {
@@ -90,14 +91,15 @@ static int launch_transpose(Ctx* c, const void* in, bool in_is_real, int64_t out
   TrArgs a;
   a.in = in; a.out = out; a.R = R; a.C = C; a.in_is_real = in_is_real ? 1 : 0;
   a.plane_stride = plane_stride; a.plane_valid = plane_valid; a.tw_mode = tw_mode; a.K = K; a.tw_lo = lo; a.tw_hi = hi;
-  for (int64_t o0 = 0; o0 < outer; o0 += 65535) {  // gridDim.z limit
+  const int64_t tiles = (int64_t)((C + kTile - 1) / kTile) * ((R + kTile - 1) / kTile);
+  if (tiles > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "transpose: plane too large for one launch");
+  for (int64_t o0 = 0; o0 < outer; o0 += 65535) {  // gridDim.y limit
     const int64_t no = outer - o0 < 65535 ? outer - o0 : 65535;
     a.outer = no;
     a.in = in_is_real ? static_cast<const void*>(reinterpret_cast<const float*>(in) + o0 * plane_stride)
                       : static_cast<const void*>(reinterpret_cast<const float2*>(in) + o0 * plane_stride);
     a.out = out + o0 * (int64_t)R * C;
-    dim3 grid((unsigned)((C + kTile - 1) / kTile), (unsigned)((R + kTile - 1) / kTile), (unsigned)no);
-    if (grid.y > 65535) return set_error(NXSIG_ERR_UNSUPPORTED, "transpose: more than 4 M rows per plane");
+    dim3 grid((unsigned)tiles, (unsigned)no);
     hipLaunchKernelGGL(k_transpose, grid, dim3(kT), 0, c->stream, a);
   }
   NXSIG_HIP_TRY(hipGetLastError());

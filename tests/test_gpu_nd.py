@@ -149,3 +149,14 @@ def test_generic_istft_rides_the_wave_rows(N, hop):
         y = S.istft(z, w, **opts)
         for b in range(2):
             assert nerr(y[b], O.istft(z[b], w, **opts)) < 1e-5, (N, hop, scaling, b)
+
+
+def test_fft_nd_long_inner_axis():
+    """an axis-0 transform of a short, very wide tensor: 70 000 tile columns (beyond any 65 535 grid-dimension limit)"""
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((4, 70000 * 64 // 64 * 1)).astype(np.float32)[:, : 64 * 1100]  # 4 x 70 400
+    got = S.transforms.fft_nd(x, axes=[0], lengths=[8])
+    assert nerr(got, np.fft.fft(x.astype(np.float64), n=8, axis=0)) < 1e-5
+    wide = rng.standard_normal((2, 4300000)).astype(np.float32)  # inner axis of 4.3 M elements: > 65 535 tiles of 64 rows
+    got = S.transforms.fft_nd(wide, axes=[0])
+    assert nerr(got, np.fft.fft(wide.astype(np.float64), axis=0)) < 1e-5

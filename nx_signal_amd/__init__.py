@@ -194,6 +194,11 @@ def stft(data, window, ctx: Context | None = None, **opts):
 
     Defaults follow the code, not the doc: window_padding "valid", sampling_rate 100,
     fft_length "power_of_two", overlap_length div(N, 2); the :window key is accepted and ignored.
+
+    Device-resident inputs (DeviceBuffer, torch tensors, __cuda_array_interface__ objects) return a DeviceBuffer and the call is
+    ASYNCHRONOUS on the context's own HIP stream: it is ordered after earlier calls on the same context only.  Data produced
+    on another stream (e.g. torch's current stream) must be complete before the call, and the result must not be consumed on
+    another stream before `ctx.sync()` — or hand the library that stream with `ctx.set_stream(ptr)`.
     """
     p, N, hop, K = _resolve_stft_opts(window, opts)
     w = _window_host(window)

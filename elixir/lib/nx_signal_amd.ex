@@ -242,6 +242,34 @@ defmodule NxSignalAMD do
     Nx.from_binary(out, :f32) |> Nx.reshape(append(batch_shape, [m, mel_bins])) |> revectorize(vec_axes)
   end
 
+  @doc """
+  Magnitude spectrogram fused with the STFT (what `guides/spectrogram.livemd:76-92` derives from `NxSignal.stft/3`): `Nx.abs(s)`
+  of the bins below `fft_length / 2` (`kind: :magnitude`), `|s|^2` (`:power`) or `20 * log10(|s| / max |s|)` (`:dbfs`), without
+  writing the complex spectrum to HBM. Returns `f32[..., frames, fft_length / 2]`. Opt-in: not a reference function.
+  """
+  def spectrogram(%Nx.Tensor{} = data, window, opts \\ []) do
+    {kind, stft_opts} = Keyword.pop(opts, :kind, :magnitude)
+
+    kind_code =
+      case kind do
+        :magnitude -> 0
+        :power -> 1
+        :dbfs -> 2
+        other -> raise ArgumentError, "expected :kind to be one of :magnitude, :power, :dbfs, got: #{inspect(other)}"
+      end
+
+    {params, fft_length} = stft_params!(window, stft_opts)
+    {flat, vec_axes} = devectorize(data)
+    {batch_shape, length} = split_last(Nx.shape(flat))
+    x = flat |> Nx.as_type(:f32) |> Nx.to_binary()
+    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+
+    {:ok, out, m} =
+      NIF.stft_magnitude(context(), x, length, Tuple.product(batch_shape), w, params, kind_code) |> unwrap!()
+
+    Nx.from_binary(out, :f32) |> Nx.reshape(append(batch_shape, [m, div(fft_length, 2)])) |> revectorize(vec_axes)
+  end
+
   # ------------------------------------------------------------------------------------------ shared helpers
   @doc false
   def unwrap!({:error, {-1, msg}}), do: raise(ArgumentError, msg)

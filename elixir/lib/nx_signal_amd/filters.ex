@@ -30,7 +30,28 @@ defmodule NxSignalAMD.Filters do
     Nx.from_binary(bin, :f32)
   end
 
-  def fir(x, taps, opts \\ []) do
+  def fir(x, taps, opts \\ [])
+
+  # device-resident stream: filtered in HBM, the result stays there
+  def fir(%NxSignalAMD.DeviceTensor{type: {:f, 32}} = x, taps, opts) do
+    opts = Keyword.validate!(opts, mode: :same)
+
+    if not is_map_key(@modes, opts[:mode]) do
+      raise ArgumentError, "expected mode to be one of [:full, :same, :valid], got: #{inspect(opts[:mode])}"
+    end
+
+    r = tuple_size(x.shape)
+    length = elem(x.shape, r - 1)
+    batch_shape = Tuple.delete_at(x.shape, r - 1)
+    hb = taps |> Nx.as_type(:f32) |> Nx.to_binary()
+
+    {:ok, yref, n_out} =
+      NIF.fir_dev(x.ctx, x.ref, length, Tuple.product(batch_shape), hb, @modes[opts[:mode]]) |> NxSignalAMD.unwrap!()
+
+    %NxSignalAMD.DeviceTensor{ref: yref, ctx: x.ctx, shape: Tuple.insert_at(batch_shape, r - 1, n_out), type: {:f, 32}}
+  end
+
+  def fir(x, taps, opts) do
     opts = Keyword.validate!(opts, mode: :same)
 
     if not is_map_key(@modes, opts[:mode]) do

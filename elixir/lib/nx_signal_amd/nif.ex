@@ -39,6 +39,7 @@ defmodule NxSignalAMD.NIF do
   def stft_mel(_ctx, _x, _length, _batch, _window, _params, _mel_bins, _filters),
     do: :erlang.nif_error(:nif_not_loaded)
 
+  def stft_magnitude(_ctx, _x, _length, _batch, _window, _params, _kind), do: :erlang.nif_error(:nif_not_loaded)
   def to_device(_ctx, _bin), do: :erlang.nif_error(:nif_not_loaded)
   def from_device(_buf), do: :erlang.nif_error(:nif_not_loaded)
   def buf_size(_buf), do: :erlang.nif_error(:nif_not_loaded)

@@ -471,6 +471,29 @@ static ERL_NIF_TERM nif_stft_mel(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
   return enif_make_tuple3(env, mk_atom(env, "ok"), enif_make_binary(env, &ob), enif_make_int64(env, m));
 }
 
+/* stft_magnitude(ctx, x_bin, length, batch, window_bin, params, kind) -> {:ok, f32[batch][M][fft_length / 2], M}
+ * (fused |s| / |s|^2 / dBFS spectrogram of guides/spectrogram.livemd:76-92; kind 0 abs, 1 power, 2 dbfs) */
+static ERL_NIF_TERM nif_stft_magnitude(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary x, w, ob;
+  ErlNifSInt64 length;
+  int batch, kind;
+  nxsig_stft_params p;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p) ||
+      !enif_get_int(env, argv[6], &kind))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || x.size % 4 || x.size / 4 / (size_t)batch != (size_t)length || w.size != (size_t)p.frame_length * 4 ||
+      p.fft_length < 2)
+    return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
+  if (m < 0) return mk_error(env, (int)m);
+  if (!out_bin(&ob, (uint64_t)batch, (uint64_t)m, (uint64_t)(p.fft_length / 2), 4)) return mk_oom(env);
+  int rc = nxsig_stft_magnitude_f32(c->ctx, (const float*)x.data, length, batch, length, (const float*)w.data, &p, kind, (float*)ob.data, NULL, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), enif_make_binary(env, &ob), enif_make_int64(env, m));
+}
+
 /* ------------------------------------------------------------------------------------------------ device-resident tensors
  * keep stft -> edit -> istft chains in HBM (guides/filtering.livemd:137-159).  Device calls are
  * asynchronous on the context's stream; from_device synchronises. */
@@ -700,6 +723,7 @@ static ErlNifFunc funcs[] = {
     {"fftconvolve_nd", 8, nif_fftconvolve_nd, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_to_mel", 6, nif_stft_to_mel, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_mel", 8, nif_stft_mel, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_magnitude", 7, nif_stft_magnitude, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"to_device", 2, nif_to_device, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"from_device", 1, nif_from_device, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"buf_size", 1, nif_buf_size, 0},

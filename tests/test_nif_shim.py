@@ -217,6 +217,10 @@ def test_framing_ola_fft_mel_through_the_nif(nctx, golden):
     ok, mb, m = H.call("stft_mel", nctx, x, 16000, 1, w, p, 80, filt)
     want = S.mel_spectrogram(x, w, overlap_length=240, fft_length=512, sampling_rate=16000, window_padding="reflect", mel_bins=80)
     assert np.array_equal(f32(mb).view(np.uint32), np.ascontiguousarray(want).reshape(-1).view(np.uint32))
+    for kind, name in ((0, "magnitude"), (1, "power"), (2, "dbfs")):
+        ok, gb, m2 = H.call("stft_magnitude", nctx, x, 16000, 1, w, p, kind)
+        wantm = S.spectrogram(x, w, overlap_length=240, fft_length=512, sampling_rate=16000, window_padding="reflect", kind=name)
+        assert m2 == wantm.shape[0] and np.array_equal(f32(gb).view(np.uint32), np.ascontiguousarray(wantm).reshape(-1).view(np.uint32))
     z, _, _ = S.stft(x, w, overlap_length=240, fft_length=512, sampling_rate=16000, window_padding="reflect")
     ok, mb2 = H.call("stft_to_mel", nctx, z, z.shape[0], 512, 80, filt)
     assert np.allclose(f32(mb2).reshape(want.shape), want, atol=1e-4)

@@ -134,6 +134,10 @@ def test_fuzz_stft_long_rows_interior_edge_split(seed):
     x = rng.standard_normal((batch, L)).astype(np.float32)
     w = make_window(rng, N)
     opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=22050)
+    if isinstance(pad, list) and L + pad[0][0] + pad[0][1] < N:  # a crop that leaves no room for one frame (1 in 90 000 fresh seeds)
+        with pytest.raises(S.ArgumentError, match="does not fit"):
+            S.stft(x, w, **opts)
+        return
     z, t, f = S.stft(x, w, **opts)
     zo, to, fo = O.stft(x, w, **opts)
     assert z.shape == zo.shape, (opts, L)

@@ -1,0 +1,68 @@
+"""Worker of tests/test_gpu_group_ranked.py: one RANKED member (one process per rank) of a two-rank group whose ranks share the
+single GPU of the test box.  RCCL refuses two ranks on one device of one host, so every rank claims its own host id
+(NCCL_HOSTID) and the pair talks through RCCL's socket transport over loopback: the whole multi-process path — file
+rendezvous of the ncclUniqueId, ncclCommInitRank, barrier, all-reduce, all-gather of EQUAL shards (ncclAllGather, in place)
+and of UNEQUAL shards (one ncclBroadcast per rank), sharded stft on device shards with the assembly — runs for real."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world, path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    os.dup2(2, 1)  # RCCL's banner goes to stdout: keep it away from the verdict line
+    import nx_signal_amd as S
+    from nx_signal_amd import sharding
+    from oracle import nx_oracle as O
+
+    g = sharding.Group.ranked(world=world, rank=rank, device=0, path=path, timeout_ms=60000)
+    ctx = g.contexts[0]
+    assert g.world == world and g.local_count == 1 and g.ranks == [rank] and g.has_rccl
+    g.barrier()
+    assert g.allreduce([float(rank + 1), 10.0 - rank], "max") == [float(world), 10.0]
+    assert g.allreduce([float(rank + 1)], "sum") == [world * (world + 1) / 2.0]
+    # unequal shards: one broadcast per rank
+    parts = [(np.arange(1000 + 37 * r, dtype=np.uint32) * 2654435761 % 1000003 + r).astype(np.uint32) for r in range(world)]
+    want = np.concatenate(parts)
+    send = ctx.to_device(parts[rank])
+    recv = ctx.empty((want.size,), np.uint32)
+    g.allgather([send.ptr], [p.nbytes for p in parts], [recv.ptr])
+    ctx.sync()
+    assert np.array_equal(recv.numpy(), want), "unequal all-gather"
+    # equal shards, in place
+    eq = ctx.empty((world, 4096), np.uint32)
+    mine = (np.arange(4096, dtype=np.uint32) + 100000 * (rank + 1)).astype(np.uint32)
+    S._lib.check(S._lib.load().nxsig_upload(ctx.handle, eq.ptr + rank * 4096 * 4, mine.ctypes.data, mine.nbytes))
+    g.allgather([eq.ptr + rank * 4096 * 4], [4096 * 4] * world, [eq.ptr])
+    ctx.sync()
+    assert np.array_equal(eq.numpy(), np.stack([np.arange(4096, dtype=np.uint32) + 100000 * (r + 1) for r in range(world)])), "in-place all-gather"
+    # sharded stft on device shards: channels (3 + 2 of 5) and frame ranges of one stream, assembled on every rank
+    B, L, N, hop = 5, 30000, 1024, 256
+    x = np.stack([O.synth_signal(L, seed=100 + c) for c in range(B)])
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+    full, _, _ = S.stft(x, w, ctx=ctx, **opts)
+    c0, c1 = sharding.shard_channels(B, world, rank)
+    outs = sharding.stft_sharded(g, [ctx.to_device(x[c0:c1])], w, axis="channels", gather=True, length=L, batch=B, **opts)
+    ctx.sync()
+    assert np.array_equal(outs[0].numpy().view(np.uint32), full.view(np.uint32)), "channel shards + RCCL assembly"
+    M = full.shape[1]
+    m0, m1, s0, s1 = sharding.shard_frames(M, N, hop, world, rank)
+    outs = sharding.stft_sharded(g, [ctx.to_device(x[0, s0:s1].reshape(1, -1))], w, axis="frames", gather=True, length=L, batch=1, **opts)
+    ctx.sync()
+    got = outs[0].numpy()[0]
+    assert float(np.max(np.abs(got - full[0])) / np.max(np.abs(full[0]))) < 1e-6, "frame shards + RCCL assembly"
+    if m0 % 2 == 0:
+        assert np.array_equal(got.view(np.uint32), full[0].view(np.uint32))
+    g.barrier()
+    g.close()
+    print(f"RANKED-OK rank {rank} of {world}", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

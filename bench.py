@@ -256,6 +256,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the roofline blocks of configs 3 / 4 / 5")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST MODE for one-GPU boxes: every rank uses device LOCAL_RANK %% device_count and claims its own "
+                         "NCCL_HOSTID, so several ranks can form an RCCL communicator on ONE GPU (socket transport over lo); "
+                         "exercises the launcher / rendezvous / collective path, the rate is NOT a scaling figure")
     ap.add_argument("--precondition", type=int, default=300,
                     help="max untimed launches spent settling the clocks before the warm-up steps (0 = none)")
     args = ap.parse_args()
@@ -275,6 +279,14 @@ def main():
     import nx_signal_amd as S
     from nx_signal_amd import _lib, sharding
     import ctypes as C
+
+    if args.share_gpu:
+        os.environ["NCCL_HOSTID"] = f"nxsig-bench-rank{rank}"
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+        ndev = C.c_int()
+        _lib.check(_lib.load().nxsig_device_count(C.byref(ndev)))
+        local_rank = local_rank % max(ndev.value, 1)
 
     group = None
     filectl = None
@@ -452,7 +464,8 @@ def main():
                 "workload": f"{B} x (60 s mono 48 kHz f32) per GPU per step, N=1024 hop=256 periodic Hann, :valid, "
                             f"c64 full spectrum out; inputs/outputs device-resident",
                 "streams_per_gpu": B, "frames_per_stream": M, "frame_length": N_FFT, "hop": HOP, "fft_length": N_FFT,
-                "parallelism": f"streams sharded over {world} GPU(s), no data-path collective",
+                "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"
+                               + (" [--share-gpu test mode: the ranks share one device, not a scaling figure]" if args.share_gpu else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -451,11 +451,15 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
     const int j = (int)(n - m * a.hop);
     const float2* zr = zb + (size_t)m * a.N;
     double sr = 0.0, si = 0.0;
+    int tix = (int)(((int64_t)j * tid) % a.N);                 // twiddle index j k mod N, advanced without a division per term
+    const int tstep = (int)(((int64_t)j * kThreads) % a.N);
     for (int k = tid; k < a.N; k += kThreads) {
-      const double2 t = a.tw[((int64_t)j * k) % a.N];
+      const double2 t = a.tw[tix];
       const float2 v = zr[k];
       sr += (double)v.x * t.x - (double)v.y * t.y;
       si += (double)v.x * t.y + (double)v.y * t.x;
+      tix += tstep;
+      if (tix >= a.N) tix -= a.N;
     }
     red[tid] = sr;
     red[kThreads + tid] = si;

@@ -20,6 +20,7 @@ defmodule NxSignalAMD.NIF do
   def sinc(_t), do: :erlang.nif_error(:nif_not_loaded)
   def stft(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft(_ctx, _z, _frames, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def istft_filtered(_ctx, _z, _frames, _batch, _window, _params, _h), do: :erlang.nif_error(:nif_not_loaded)
   def fir(_ctx, _x, _length, _batch, _taps, _mode), do: :erlang.nif_error(:nif_not_loaded)
 
   def as_windowed(_ctx, _x, _length, _batch, _window_length, _stride, _pad_mode, _lo, _hi),
@@ -45,6 +46,7 @@ defmodule NxSignalAMD.NIF do
   def buf_size(_buf), do: :erlang.nif_error(:nif_not_loaded)
   def stft_dev(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft_dev(_ctx, _z, _frames, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def istft_filtered_dev(_ctx, _z, _frames, _batch, _window, _params, _h), do: :erlang.nif_error(:nif_not_loaded)
   def fir_dev(_ctx, _x, _length, _batch, _taps, _mode), do: :erlang.nif_error(:nif_not_loaded)
   def spectrum_mul_dev(_ctx, _z, _rows, _fft_length, _h), do: :erlang.nif_error(:nif_not_loaded)
   def group_create(_devices), do: :erlang.nif_error(:nif_not_loaded)

@@ -256,6 +256,17 @@ int nxsig_spectrum_mul_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int
                            nxsig_c64* out, int32_t mem);
 
 /*
+ * The last two steps of that workflow in one call: NxSignal.istft(Nx.multiply(z, hfft), window, opts)
+ * (guides/filtering.livemd:141 + :150-157).  Same result, bit for bit, as nxsig_spectrum_mul_c64 followed by nxsig_istft_c64
+ * (the product is formed in double and rounded to c64 before the inverse transform sees it), but for N = 1024 the filter
+ * values ride in the registers of the inverse-STFT kernel and the filtered spectrogram is never written to or re-read from
+ * HBM (26 KB of traffic per frame -> 10 at hop 256).  Other sizes run the two steps behind this entry.  z is not modified.
+ *   z c64[batch][M][K], h c64[K] HOST  ->  y c64[batch][M*hop + N-hop]
+ */
+int nxsig_istft_filtered_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
+                             const nxsig_stft_params* params, const nxsig_c64* h, nxsig_c64* y, int32_t mem);
+
+/*
  * 1-D complex case of Convolution.fftconvolve/3 — lib/nx_signal/convolution.ex:252-329 (tests: "FFT complex",
  * test/nx_signal/convolutions_test.exs:473-487): out = ifft(fft(a, P) * fft(b, P)) sliced per mode, with
  * P = next power of two >= n1 + n2 - 1 (same linear convolution as the reference's length n1 + n2 - 1).

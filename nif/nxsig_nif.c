@@ -263,6 +263,30 @@ static ERL_NIF_TERM nif_istft(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[
   return mk_ok(env, enif_make_binary(env, &yb));
 }
 
+/* istft_filtered(ctx, z_bin, num_frames, batch, window_bin, params, h_bin) -> {:ok, y_bin}
+ * NxSignal.istft(Nx.multiply(z, hfft), window, opts) in one library call (guides/filtering.livemd:141 + :150-157) */
+static ERL_NIF_TERM nif_istft_filtered(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary z, w, h, yb;
+  ErlNifSInt64 m;
+  int batch;
+  nxsig_stft_params p;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &z) || !enif_get_int64(env, argv[2], &m) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p) ||
+      !enif_inspect_binary(env, argv[6], &h))
+    return enif_make_badarg(env);
+  if (batch < 1 || m < 1 || p.fft_length < 1 || z.size % 8 || z.size / 8 / (size_t)batch / (size_t)m != (size_t)p.fft_length ||
+      z.size / 8 % ((size_t)batch * (size_t)m) || w.size != (size_t)p.frame_length * 4 || h.size != (size_t)p.fft_length * 8)
+    return enif_make_badarg(env);
+  int64_t n = nxsig_ola_length(m, p.frame_length, p.hop);
+  if (n < 0) return mk_error(env, (int)n);
+  if (!out_bin(&yb, (uint64_t)batch, (uint64_t)n, 1, 8)) return mk_oom(env);
+  int rc = nxsig_istft_filtered_c64(c->ctx, (const nxsig_c64*)z.data, m, batch, (const float*)w.data, &p, (const nxsig_c64*)h.data,
+                                    (nxsig_c64*)yb.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&yb); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &yb));
+}
+
 /* fir(ctx, x_bin, length, batch, taps_bin, mode) -> {:ok, y_bin}   (Convolution.convolve(method: :fft), real 1-D rows) */
 static ERL_NIF_TERM nif_fir(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
@@ -576,6 +600,34 @@ static ERL_NIF_TERM nif_istft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM a
   return mk_ok(env, make_buf(env, c, y, ybytes));
 }
 
+/* istft_filtered_dev(ctx, z_buf, num_frames, batch, window_bin, params, h_bin) -> {:ok, y_buf}   (z_buf is left untouched) */
+static ERL_NIF_TERM nif_istft_filtered_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  buf_res_t* z;
+  ErlNifBinary w, h;
+  ErlNifSInt64 m;
+  int batch;
+  nxsig_stft_params p;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !get_buf(env, argv[1], &z) || !enif_get_int64(env, argv[2], &m) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p) ||
+      !enif_inspect_binary(env, argv[6], &h))
+    return enif_make_badarg(env);
+  if (batch < 1 || m < 1 || p.fft_length < 1 || z->owner != c || w.size != (size_t)p.frame_length * 4 ||
+      h.size != (size_t)p.fft_length * 8 || z->bytes / 8 / (size_t)batch / (size_t)m < (size_t)p.fft_length)
+    return enif_make_badarg(env);
+  int64_t n = nxsig_ola_length(m, p.frame_length, p.hop);
+  if (n < 0) return mk_error(env, (int)n);
+  size_t ybytes = 8;
+  if (!mul_size(&ybytes, (uint64_t)batch) || !mul_size(&ybytes, (uint64_t)n)) return mk_oom(env);
+  void* y = NULL;
+  int rc = nxsig_alloc(c->ctx, ybytes, &y);
+  if (rc) return mk_error(env, rc);
+  rc = nxsig_istft_filtered_c64(c->ctx, (const nxsig_c64*)z->dptr, m, batch, (const float*)w.data, &p, (const nxsig_c64*)h.data,
+                                (nxsig_c64*)y, NXSIG_DEVICE);
+  if (rc) { nxsig_free(c->ctx, y); return mk_error(env, rc); }
+  return mk_ok(env, make_buf(env, c, y, ybytes));
+}
+
 /* fir_dev(ctx, x_buf, length, batch, taps_bin, mode) -> {:ok, y_buf, out_length} */
 static ERL_NIF_TERM nif_fir_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
@@ -714,6 +766,7 @@ static ErlNifFunc funcs[] = {
     {"sinc", 1, nif_sinc, 0},
     {"stft", 6, nif_stft, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft", 6, nif_istft, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"istft_filtered", 7, nif_istft_filtered, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir", 6, nif_fir, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"as_windowed", 9, nif_as_windowed, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"overlap_and_add", 7, nif_overlap_and_add, ERL_NIF_DIRTY_JOB_IO_BOUND},
@@ -729,6 +782,7 @@ static ErlNifFunc funcs[] = {
     {"buf_size", 1, nif_buf_size, 0},
     {"stft_dev", 6, nif_stft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_dev", 6, nif_istft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"istft_filtered_dev", 7, nif_istft_filtered_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir_dev", 6, nif_fir_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"spectrum_mul_dev", 5, nif_spectrum_mul_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"group_create", 1, nif_group_create, ERL_NIF_DIRTY_JOB_IO_BOUND},

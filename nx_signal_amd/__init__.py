@@ -27,7 +27,7 @@ from .device import Context, DeviceBuffer, default_context, device_view, is_devi
 
 __all__ = [
     "stft", "istft", "as_windowed", "overlap_and_add", "fft_frequencies", "mel_filters", "stft_to_mel", "mel_spectrogram",
-    "spectrum_multiply", "spectrogram",
+    "spectrum_multiply", "istft_filtered", "spectrogram",
     "Context", "DeviceBuffer", "default_context", "ArgumentError",
     "NxSignalDeviceError", "NxSignalLibraryError", "NxSignalUnsupported",
 ]
@@ -236,6 +236,21 @@ def stft(data, window, ctx: Context | None = None, **opts):
 
 def istft(data, window, ctx: Context | None = None, **opts):
     """NxSignal.istft/3 — lib/nx_signal.ex:582-638.  c64[..., M, K] -> c64[..., M*hop + overlap] (complex, B8)."""
+    return _istft(data, window, ctx, opts, None)
+
+
+def istft_filtered(data, h, window, ctx: Context | None = None, **opts):
+    """Extension (not in the reference API): `istft(Nx.multiply(z, h), window, opts)` — the last two steps of the reference's
+    STFT-domain filtering workflow (guides/filtering.livemd:141, :150-157) in one call.  Bit-identical to
+    `istft(spectrum_multiply(z, h), window, **opts)`; for 1024-point frames the filter is applied inside the inverse-STFT
+    kernel and the filtered spectrogram never exists in HBM.  h: c64[fft_length] (host)."""
+    hh = np.ascontiguousarray(np.asarray(h).astype(np.complex64))
+    if hh.ndim != 1:
+        raise ArgumentError("istft_filtered: h must be a rank-1 tensor of fft_length bins")
+    return _istft(data, window, ctx, opts, hh)
+
+
+def _istft(data, window, ctx, opts, hh):
     o = _validate(opts, {"fft_length": None, "overlap_length": None, "scaling": None, "sampling_rate": 1000}, "istft")
     w = _window_host(window)
     N = int(w.shape[0])
@@ -267,15 +282,23 @@ def istft(data, window, ctx: Context | None = None, **opts):
     K = _resolve_fft_length(o["fft_length"], Kin)
     if K != Kin:
         raise NxSignalUnsupported("istft: fft_length different from the spectrum's last axis (ifft pad/truncate) is not built")
+    if hh is not None and int(hh.shape[0]) != K:
+        raise ArgumentError("istft_filtered: h must have fft_length bins")
     batch = int(np.prod(shape[:-2], dtype=np.int64)) if len(shape) > 2 else 1
     p = StftParams(N, hop, K, 0, 0, 0, _SCALING[o["scaling"]], 0, fs)
     out_len = _lib.check(lib.nxsig_ola_length(Mf, N, hop))
+
+    def call(zp, yp, mem):
+        if hh is None:
+            return lib.nxsig_istft_c64(c.handle, zp, Mf, batch, _as_ptr(w), C.byref(p), yp, mem)
+        return lib.nxsig_istft_filtered_c64(c.handle, zp, Mf, batch, _as_ptr(w), C.byref(p), _as_ptr(hh), yp, mem)
+
     if is_device(data):
         y = c.empty(tuple(shape[:-2]) + (out_len,), np.complex64)
-        _lib.check(lib.nxsig_istft_c64(c.handle, C.c_void_p(ptr), Mf, batch, _as_ptr(w), C.byref(p), C.c_void_p(y.ptr), _lib.DEVICE))
+        _lib.check(call(C.c_void_p(ptr), C.c_void_p(y.ptr), _lib.DEVICE))
         return y
     y = np.empty(tuple(shape[:-2]) + (out_len,), dtype=np.complex64)
-    _lib.check(lib.nxsig_istft_c64(c.handle, _as_ptr(zin), Mf, batch, _as_ptr(w), C.byref(p), _as_ptr(y), _lib.HOST))
+    _lib.check(call(_as_ptr(zin), _as_ptr(y), _lib.HOST))
     return y
 
 

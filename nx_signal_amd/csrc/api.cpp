@@ -160,6 +160,16 @@ int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
   bool handled = false;
   int rc = launch_istft_wave(c, a, window_host, &handled);
   if (rc) return rc;
+  if (!handled && a.filt) {
+    // no fused kernel for this geometry: the filter product is materialised once (the two-step chain), then the plain path runs
+    void* zf = nullptr;
+    if ((rc = ctx_scratch(c, 20, (size_t)a.batch * a.M * a.K * sizeof(float2), &zf))) return rc;
+    if ((rc = launch_spectrum_mul(c, a.z, (int64_t)a.batch * a.M, a.K, a.filt, reinterpret_cast<float2*>(zf)))) return rc;
+    IstftLaunch b = a;
+    b.z = reinterpret_cast<const float2*>(zf);
+    b.filt = nullptr;
+    return launch_istft(c, b, window_host);
+  }
   if (!handled && (rc = launch_istft_generic(c, a))) return rc;
   return launch_istft_edge_fix(c, a, window_host);  // ill-conditioned edge samples recomputed in double
 }
@@ -580,9 +590,8 @@ int nxsig_stft_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch
   NXSIG_API_END
 }
 
-int nxsig_istft_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
-                    const nxsig_stft_params* p, nxsig_c64* y, int32_t mem) {
-  NXSIG_API_BEGIN
+static int istft_common(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
+                        const nxsig_stft_params* p, const nxsig_c64* h, nxsig_c64* y, int32_t mem) {
   NXSIG_CHECK_CTX(ctx)
   if (!z || !window || !p || !y) return set_error(NXSIG_ERR_INVALID_ARG, "istft: null pointer argument");
   int rc = check_mem(mem);
@@ -606,6 +615,11 @@ int nxsig_istft_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int3
   rc = ctx_table(c, 0x57494Eull, window, (size_t)N * sizeof(float), &wdev);
   if (rc) return rc;
   a.window = reinterpret_cast<const float*>(wdev);
+  if (h) {  // same table key as spectrum_mul: the two-step and the fused form share the filter's device copy
+    const void* hd = nullptr;
+    if ((rc = ctx_table(c, 0x5BEC0ull ^ (uint64_t)K, h, (size_t)K * sizeof(float2), &hd))) return rc;
+    a.filt = reinterpret_cast<const float2*>(hd);
+  }
   const int64_t out_len = num_frames * hop + (N - hop);
   const size_t zbytes = (size_t)batch * num_frames * K * sizeof(float2), ybytes = (size_t)batch * out_len * sizeof(float2);
   if (mem == NXSIG_DEVICE) {
@@ -619,6 +633,20 @@ int nxsig_istft_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int3
   a.z = reinterpret_cast<const float2*>(zd); a.y = reinterpret_cast<float2*>(yd);
   if ((rc = launch_istft(c, a, window))) return rc;
   return st.out_copy(y, yd, ybytes);
+}
+
+int nxsig_istft_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
+                    const nxsig_stft_params* p, nxsig_c64* y, int32_t mem) {
+  NXSIG_API_BEGIN
+  return istft_common(ctx, z, num_frames, batch, window, p, nullptr, y, mem);
+  NXSIG_API_END
+}
+
+int nxsig_istft_filtered_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
+                             const nxsig_stft_params* p, const nxsig_c64* h, nxsig_c64* y, int32_t mem) {
+  NXSIG_API_BEGIN
+  if (!h) return set_error(NXSIG_ERR_INVALID_ARG, "istft_filtered: null filter spectrum");
+  return istft_common(ctx, z, num_frames, batch, window, p, h, y, mem);
   NXSIG_API_END
 }
 

@@ -428,6 +428,7 @@ struct EdgeFixArgs {
   int64_t n_idx;
   float tau;
   const double2* tw;        // w_N^j = exp(+2 pi i j / N) in double, j in [0, N)
+  const float2* filt;       // optional c64[N]: the frames are z * filt rounded to c64 (IstftLaunch::filt), or nullptr
 };
 
 __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
@@ -455,7 +456,12 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
     const int tstep = (int)(((int64_t)j * kThreads) % a.N);
     for (int k = tid; k < a.N; k += kThreads) {
       const double2 t = a.tw[tix];
-      const float2 v = zr[k];
+      float2 v = zr[k];
+      if (a.filt) {
+        const float2 h = a.filt[k];
+        v = make_float2((float)((double)v.x * (double)h.x - (double)v.y * (double)h.y),
+                        (float)((double)v.x * (double)h.y + (double)v.y * (double)h.x));
+      }
       sr += (double)v.x * t.x - (double)v.y * t.y;
       si += (double)v.x * t.y + (double)v.y * t.x;
       tix += tstep;
@@ -956,7 +962,7 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
       EdgeFixArgs a;
       uint32_t tb = (uint32_t)v[1];
       std::memcpy(&a.tau, &tb, 4);
-      a.z = s.z; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
+      a.z = s.z; a.filt = s.filt; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
       a.y = s.y; a.out_len = out_len;
       a.tw = reinterpret_cast<const double2*>(v[2]);
       a.idx = reinterpret_cast<const int64_t*>(v[3]);
@@ -981,7 +987,7 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
   if (!(dmax > 0.0)) { c->memo[ekey] = {0, 0, 0, 0, 0}; return NXSIG_OK; }
   EdgeFixArgs a;
   a.tau = (float)(0.02 * dmax);
-  a.z = s.z; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
+  a.z = s.z; a.filt = s.filt; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
   a.y = s.y; a.out_len = out_len;
   a.idx = nullptr; a.n_idx = 0;
   // inverse twiddles in double (host libm), cached per N

@@ -28,9 +28,22 @@ struct IstftWaveArgs {
   const float* den;           // f32[2R-1][hop]: RECIPROCAL of the guarded OLA normaliser: head segments 0..R-2, interior, tail segments
   v2f* y;                     // c64[batch][segs_per_row * hop]
   v2f* dummy;
+  const v2f* filt = nullptr;  // c64[K] spectrum filter (FILT variant of k_istft_wave only)
 };
 
-template <int K, int R, bool SCALE, int W>
+// c64 product the way Nx.multiply forms it on the BinaryBackend: in double, each component rounded once (same expression as
+// k_spectrum_mul, so the fused and the two-step chain agree bit for bit)
+__device__ __forceinline__ v2f cmul_c64_rounded(v2f a, v2f b) {
+  const double re = (double)a.x * (double)b.x - (double)a.y * (double)b.y;
+  const double im = (double)a.x * (double)b.y + (double)a.y * (double)b.x;
+  return v2f{(float)re, (float)im};
+}
+
+// FILT: every frame's spectrum is multiplied by a.filt as it arrives from HBM (the z * H step of STFT-domain filtering,
+// guides/filtering.livemd:141): a lane always loads the same 16 bins, so its 16 filter values sit in registers and the separate
+// read-modify-write pass over the spectrogram (16 KB of HBM traffic per frame on top of this kernel's 10) disappears.  (Keeping the
+// table in LDS to stay at 3 waves per SIMD was measured too: it spills 25 registers and runs 30 % slower than this form.)
+template <int K, int R, bool SCALE, int W, bool FILT = false>
 __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
   constexpr int P = K / 64;
   constexpr int R3 = K / 256;
@@ -79,10 +92,20 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
 #pragma unroll
     for (int s = 0; s < P; ++s) r[s] = pz[64 * s];
   };
-  issue_loads(m_start);
-  v2f d[P];
+  v2f hv[FILT ? P : 1];
+  if (FILT) {
 #pragma unroll
-  for (int s = 0; s < P; ++s) d[s] = r[s];
+    for (int s = 0; s < P; ++s) hv[FILT ? s : 0] = a.filt[lane + 64 * s];
+  }
+  v2f d[P];
+  auto take_frame = [&]() {   // the prefetched spectrum (times the filter) becomes the core's input
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+      d[s] = FILT ? cmul_c64_rounded(r[s], hv[FILT ? s : 0]) : r[s];
+    }
+  };
+  issue_loads(m_start);
+  take_frame();
 
   for (int64_t m = m_start; m < j1; ++m) {
     issue_loads(m + 1 < j1 ? m + 1 : m);  // unconditional prefetch keeps the loop branch-free
@@ -90,8 +113,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
     v2f zz[2][NQ];
     wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);  // inverse direction (tables are conjugated)
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < P; ++s) d[s] = r[s];
+    take_frame();
     __builtin_amdgcn_sched_barrier(0);
 
     const float live = m < a.M ? 1.0f : 0.0f;  // tail flush: frames m >= M do not exist
@@ -823,11 +845,13 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   a.scale = s.scale_mul;
   { int rc3 = istft_den_table(c, R, s.hop, window_host, &a.den); if (rc3) return rc3; }
   a.y = reinterpret_cast<v2f*>(s.y);
+  a.filt = reinterpret_cast<const v2f*>(s.filt);
   void* dummy = nullptr;
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t total_segs = a.segs_per_row * s.batch;
-  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", DBL ? 8 : 12);  // = resident waves per CU: one even round
+  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", (DBL || s.filt) ? 8 : 12);  // the filtered variant holds 16 more
+                                                                                         // complex values per lane: 2 waves per SIMD  // = resident waves per CU: one even round
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", 8);
   if (run_len < min_run) run_len = min_run;
@@ -865,7 +889,10 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   } else {
     a.twH = nullptr;
     const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8;
-    if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    if (s.filt) {
+      if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    } else if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     else hipLaunchKernelGGL((k_istft_wave<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
   }
   NXSIG_HIP_TRY(hipGetLastError());
@@ -967,6 +994,8 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
   if (s.M == 0 || s.batch == 0) return NXSIG_OK;
   if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
   if (window_host == nullptr) return NXSIG_OK;
+  // a spectrum filter is fused into the N = 1024 kernel only; elsewhere the caller multiplies first (launch_istft)
+  if (s.filt && (s.K != 1024 || env_int("NXSIG_DISABLE_FUSED_FILTER", 0))) return NXSIG_OK;
   if (s.K == 512 && s.N == 512) {  // two frames per 1024-point inverse FFT
     if (s.hop != 64 && s.hop != 128 && s.hop != 256 && s.hop != 512) return NXSIG_OK;
     if (s.M < 2 * (512 / s.hop) - 1) return NXSIG_OK;

@@ -71,7 +71,7 @@ struct Ctx {
   // scratch buffer reused by multi-stage paths (generic istft, host staging)
   // slots: 0 multi-stage temporaries, 1/2 host staging in/out, 3 wave-kernel dummy sink, 4 fused-path spectrum, 5 reduction cells,
   // 6-9 four-step / Bluestein rows, 10-12 fft_nd ping-pong, 13-15 n-D fftconvolve, 16 long-transform stft frames, 17-19 host staging of n-D calls
-  void* scratch[20] = {};
+  void* scratch[24] = {};
   size_t scratch_bytes[20] = {};
   // per-K tables of the tuned wave kernels (pass-B / pass-C twiddles), built once
   struct WaveTables { const void* twB = nullptr; const void* twC = nullptr; const void* twI = nullptr;
@@ -119,6 +119,8 @@ struct IstftLaunch {
   float scale_mul;       // frames are MULTIPLIED by this (istft :614/:617)
   int32_t has_scale;
   float2* y;             // device c64[batch][M*hop + N-hop]
+  const float2* filt = nullptr;  // optional device c64[K]: every frame's spectrum is multiplied by it first (z * H of the
+                                 // STFT-domain filtering chain, guides/filtering.livemd:141), rounded to c64 like Nx.multiply
 };
 int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host);
 

@@ -57,6 +57,22 @@ int main(void) {
       const double d = fabs((double)y[(size_t)c * out_len + i].re - (double)x[(size_t)c * L + i]);
       if (d > worst) worst = d;
     }
+  /* istft(z * h) in one call == spectrum_mul followed by istft, bit for bit (h = a one-pole low-pass response) */
+  {
+    nxsig_c64* h = (nxsig_c64*)malloc(N * sizeof(nxsig_c64));
+    nxsig_c64* zf = (nxsig_c64*)malloc((size_t)CH * M * N * sizeof(nxsig_c64));
+    nxsig_c64* ya = (nxsig_c64*)malloc((size_t)CH * out_len * sizeof(nxsig_c64));
+    for (int k = 0; k < N; ++k) {
+      const double wk = 2.0 * 3.14159265358979323846 * k / N, dre = 1.0 - 0.9 * cos(wk), dim = 0.9 * sin(wk), dd = dre * dre + dim * dim;
+      h[k].re = (float)(0.1 * dre / dd); h[k].im = (float)(-0.1 * dim / dd);
+    }
+    CHECK(nxsig_spectrum_mul_c64(ctx, z, (int64_t)CH * M, N, h, zf, NXSIG_HOST));
+    CHECK(nxsig_istft_c64(ctx, zf, M, CH, w, &p, ya, NXSIG_HOST));
+    CHECK(nxsig_istft_filtered_c64(ctx, (const nxsig_c64*)zd, M, CH, w, &p, h, (nxsig_c64*)yd, NXSIG_DEVICE));
+    CHECK(nxsig_download(ctx, y2, yd, (size_t)CH * out_len * sizeof(nxsig_c64)));
+    if (memcmp(ya, y2, (size_t)CH * out_len * sizeof(nxsig_c64)) != 0) { fprintf(stderr, "fused filter differs from multiply-then-istft\n"); return 8; }
+    free(h); free(zf); free(ya);
+  }
   /* invalid arguments come back as codes + messages, never as aborts */
   p.scaling = 7;
   if (nxsig_stft_f32(ctx, x, L, CH, L, w, &p, z, NULL, NXSIG_HOST) != NXSIG_ERR_INVALID_ARG || strstr(nxsig_last_error(), "invalid :scaling") == NULL) {

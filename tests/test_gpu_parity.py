@@ -496,6 +496,44 @@ def test_stft_domain_filtering_chain_stays_on_device():
     assert nerr(y, yo)[0] < 2e-4
 
 
+@pytest.mark.parametrize("N,hop,scaling,batch,frames", [
+    (1024, 256, None, 3, 41),          # fused: the filter rides in the inverse-STFT kernel
+    (1024, 128, "spectrum", 2, 30),
+    (1024, 512, "psd", 1, 9),
+    (1024, 1024, None, 2, 5),          # hop == N: every sample goes through the double-precision edge fix-up (filtered there too)
+    (1024, 256, None, 1, 6),           # fewer frames than the tuned kernel takes: two-step behind the same entry
+    (1024, 300, None, 2, 12),          # hop the tuned kernel does not take
+    (512, 128, "spectrum", 2, 25),     # other sizes: product materialised once, then the size's own kernel
+    (2048, 512, None, 1, 11),
+    (4096, 1024, None, 1, 9),
+    (400, 160, None, 2, 14),
+    (256, 64, None, 3, 33),
+    (96, 24, None, 2, 20),             # generic path
+])
+def test_istft_filtered_is_bit_identical_to_multiply_then_istft(N, hop, scaling, batch, frames):
+    """istft_filtered(z, h, w) == istft(spectrum_multiply(z, h), w) bit for bit, host and device inputs; z is left untouched"""
+    rng = np.random.default_rng(N + hop)
+    z = (rng.standard_normal((batch, frames, N)) + 1j * rng.standard_normal((batch, frames, N))).astype(np.complex64)
+    h = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=16000, scaling=scaling)
+    want = S.istft(S.spectrum_multiply(z, h), w, **opts)
+    got = S.istft_filtered(z, h, w, **opts)
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ctx = S.default_context()
+    zd = ctx.to_device(z)
+    gd = S.istft_filtered(zd, h, w, **opts)
+    assert S.device.is_device(gd) and np.array_equal(gd.numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(zd.numpy().view(np.uint32), z.view(np.uint32))
+    # and against the oracle's chain
+    zf = (z.astype(np.complex128) * h.astype(np.complex128)).astype(np.complex64)
+    yo = O.istft(zf, w, **opts)
+    inner = slice(N, -N) if yo.shape[-1] > 3 * N else slice(None)
+    assert nerr(got[..., inner], yo[..., inner])[0] < 2e-4
+    with pytest.raises(S.ArgumentError):
+        S.istft_filtered(z, h[: N // 2], w, **opts)
+
+
 # ------------------------------------------------------------------------------- magnitude spectrogram (8f-2)
 @pytest.mark.parametrize("K,N,hop,pad,scaling", [
     (1024, 1024, 256, "valid", None),

@@ -243,6 +243,18 @@ def test_device_resident_chain_through_the_nif(nctx):
     z, _, _ = S.stft(x, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
     want = S.istft(S.spectrum_multiply(z, hfft), w, overlap_length=768, fft_length=1024, sampling_rate=48000)
     assert np.array_equal(c64(out).view(np.uint32), want.view(np.uint32))
+    # the same two steps in one call (filter applied inside the inverse-STFT kernel); the spectrum buffer stays as it was
+    ok, zb3, m3 = H.call("stft_dev", nctx, xb, 48000, 1, w, PARAMS)
+    ok, yb2 = H.call("istft_filtered_dev", nctx, zb3, m3, 1, w, PARAMS, hfft)
+    ok, out2 = H.call("from_device", yb2)
+    assert np.array_equal(c64(out2).view(np.uint32), want.view(np.uint32))
+    ok, zkeep = H.call("from_device", zb3)
+    assert np.array_equal(c64(zkeep).view(np.uint32), z.reshape(-1).view(np.uint32))
+    ok, out3 = H.call("istft_filtered", nctx, z, m3, 1, w, PARAMS, hfft)
+    assert np.array_equal(c64(out3).view(np.uint32), want.view(np.uint32))
+    with pytest.raises(H.BadArg):
+        H.call("istft_filtered_dev", nctx, zb3, m3, 1, w, PARAMS, hfft[:512])  # filter binary of the wrong size
+    del zb3, yb2
     ok, fy, n = H.call("fir_dev", nctx, xb, 48000, 1, S.filters.firwin(257, [4000.0], sampling_rate=48000), 1)
     ok, fo = H.call("from_device", fy)
     assert n == 48000 and np.array_equal(f32(fo).view(np.uint32), S.filters.fir(x, S.filters.firwin(257, [4000.0], sampling_rate=48000)).view(np.uint32))

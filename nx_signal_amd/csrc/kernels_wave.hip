@@ -642,15 +642,13 @@ struct FirWaveArgs {
   const v2f* H;                        // c64[K] natural order, pre-scaled by 1/K
   const v2f* twB;
   const v2f* twC;
-  const v2f* twBi;
-  const v2f* twCi;
   float* y;                            // f32[batch][out_len]
 };
 
 // STREAM = true : interior pairs only, 8-byte vector access, branch-free and software-pipelined like k_stft_wave
 //                 (requires (taps-1) % 128 == 0 and even offsets — checked by the launcher)
 // STREAM = false: the few edge pairs of every row (and every pair when the fast conditions fail): bounds-checked
-template <int K, bool STREAM, int W>
+template <int K, bool STREAM, int W, bool HREG = false>
 __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
   constexpr int P = K / 64;
   constexpr int R3 = K / 256;
@@ -658,14 +656,18 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
   constexpr int XCH = K + K / 16 + 16;
   v2f* s_twB = reinterpret_cast<v2f*>(g_wave_smem);
   v2f* s_twC = s_twB + 256;
-  v2f* s_twBi = s_twC + R3 * 256;
-  v2f* s_twCi = s_twBi + 256;
-  v2f* s_H = s_twCi + R3 * 256;
-  v2f* s_x = s_H + K;
+  v2f* s_H = s_twC + R3 * 256;   // the inverse core reads the same tables and conjugates inside its multiplies
+  v2f* s_x = s_H + (HREG ? 0 : K);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < 256; i += 64 * W) { s_twB[i] = a.twB[i]; s_twBi[i] = a.twBi[i]; }
-  for (int i = tid; i < R3 * 256; i += 64 * W) { s_twC[i] = a.twC[i]; s_twCi[i] = a.twCi[i]; }
-  for (int i = tid; i < K; i += 64 * W) s_H[i] = a.H[i];
+  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
+  for (int i = tid; i < R3 * 256; i += 64 * W) s_twC[i] = a.twC[i];
+  if (!HREG)
+    for (int i = tid; i < K; i += 64 * W) s_H[i] = a.H[i];
+  v2f hv[HREG ? P : 1];   // HREG: the lane's P filter-spectrum values stay in registers
+  if (HREG) {
+#pragma unroll
+    for (int s = 0; s < P; ++s) hv[HREG ? s : 0] = a.H[lane + 64 * s];
+  }
   __syncthreads();
   v2f* xb = s_x + wave * XCH;
 
@@ -706,9 +708,9 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       v2f d[P];
       wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);
 #pragma unroll
-      for (int s = 0; s < P; ++s) d[s] = wcmul(d[s], s_H[lane + 64 * s]);  // Z H / K
+      for (int s = 0; s < P; ++s) d[s] = wcmul(d[s], HREG ? hv[HREG ? s : 0] : s_H[lane + 64 * s]);  // Z H / K
       v2f u[2][NQ];
-      wave_fft_core<K, true>(d, u, xb, s_twBi, s_twCi, lane);  // inverse: u = (y1[n], y2[n])
+      wave_fft_core<K, true, true>(d, u, xb, s_twB, s_twC, lane);  // inverse: u = (y1[n], y2[n])
       __builtin_amdgcn_sched_barrier(0);
       pack();  // next pair (its samples landed during the two transforms)
       __builtin_amdgcn_sched_barrier(0);
@@ -752,8 +754,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       v2f d[P];
       wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);
 #pragma unroll
-      for (int s = 0; s < P; ++s) d[s] = wcmul(d[s], s_H[lane + 64 * s]);
-      wave_fft_core<K, true>(d, zz, xb, s_twBi, s_twCi, lane);
+      for (int s = 0; s < P; ++s) d[s] = wcmul(d[s], HREG ? hv[HREG ? s : 0] : s_H[lane + 64 * s]);
+      wave_fft_core<K, true, true>(d, zz, xb, s_twB, s_twC, lane);
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -1134,8 +1136,6 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
   Ctx::WaveTables& wt = c->wave_tables[K];
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
-  a.twBi = reinterpret_cast<const v2f*>(wt.twBi);
-  a.twCi = reinterpret_cast<const v2f*>(wt.twCi);
   a.y = s.y;
   // 8-byte vector access needs every offset even: taps-1 multiple of 128 (=> V even), even strides, aligned bases
   const bool fast = ((s.taps - 1) % 128 == 0) && (s.batch_stride % 2 == 0) && (s.out_len % 2 == 0) && (s.out_start % 2 == 0) &&
@@ -1160,12 +1160,13 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
     }
     a.pb_lo = lo; a.pb_hi = hi;
   }
-  const size_t lds = 2 * (256 * 8 + (size_t)R3 * 256 * 8) + (size_t)K * 8 + (size_t)W * XCH * 8;
+  const bool hreg = K == 1024 && W <= 8 && env_int("NXSIG_FIR_HREG", 1);  // 156 VGPRs: three waves per SIMD
+  const size_t lds = 256 * 8 + (size_t)R3 * 256 * 8 + (hreg ? 0 : (size_t)K * 8) + (size_t)W * XCH * 8;
   auto launch = [&](bool stream, int64_t units_per_row) -> int {
     if (units_per_row <= 0) return NXSIG_OK;
     a.units_per_row = units_per_row;
     a.total_units = units_per_row * s.batch;
-    const int units_per_wave = env_int("NXSIG_FIR_UNITS_PER_WAVE", 16);  // short chunks, many workgroups (see launch_wave)
+    const int units_per_wave = env_int("NXSIG_FIR_UNITS_PER_WAVE", 8);  // short chunks, many workgroups (see launch_wave)
     a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
     // the edge launch has few, slow (bounds-checked) units: one per wave so that they all run concurrently, unless every pair
     // goes through it (filters whose taps - 1 is not a multiple of 128)
@@ -1176,7 +1177,10 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_wave<K, true, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_wave<K, false, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    if (hreg) {
+      if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W, K == 1024>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      else hipLaunchKernelGGL((k_fir_wave<K, false, W, K == 1024>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    } else if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     else hipLaunchKernelGGL((k_fir_wave<K, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
@@ -1194,9 +1198,11 @@ int launch_fir_wave(Ctx* c, const FirLaunch& s, bool* handled) {
       default: return launch_fir_wave_W<6, 2048>(c, s, handled);
     }
   }
-  switch (env_int("NXSIG_FIR_W", 14)) {
+  switch (env_int("NXSIG_FIR_W", 4)) {
     case 4: return launch_fir_wave_W<4>(c, s, handled);
-    default: return launch_fir_wave_W<14>(c, s, handled);
+    case 7: return launch_fir_wave_W<7>(c, s, handled);
+    case 14: return launch_fir_wave_W<14>(c, s, handled);
+    default: return launch_fir_wave_W<4>(c, s, handled);
   }
 }
 

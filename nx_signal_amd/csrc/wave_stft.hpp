@@ -62,6 +62,13 @@ __device__ __forceinline__ v2f wcmul(v2f a, v2f b) {
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (a.x b.x - t.x, a.x b.y + t.y)
   return r;
 }
+// a * conj(b): lets an inverse-direction core read the FORWARD twiddle tables (no second copy in LDS)
+__device__ __forceinline__ v2f wcmul_conj(v2f a, v2f b) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));             // (a.y b.y, a.y b.x)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (a.x b.x + t.x, -a.x b.y + t.y)
+  return r;
+}
 // x + (-i) y = (x.x + y.y, x.y - y.x)      and      x + (+i) y = (x.x - y.y, x.y + y.x)
 __device__ __forceinline__ v2f add_mi(v2f x, v2f y) {
   v2f r;
@@ -152,8 +159,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // The K-point complex forward FFT of one wave: in  d[s] = x[lane + 64 s]  (P = K/64 points per lane),
 // out zz[par][q] = X[2 lane + par + 128 q].  xb = this wave's private LDS exchange buffer (XCH complex).
-// INV = true computes the UNSCALED inverse DFT: pass the conjugated twiddle tables (twBi / twCi).
-template <int K, bool INV = false>
+// INV = true computes the UNSCALED inverse DFT: pass the conjugated twiddle tables (twBi / twCi), or the forward tables with
+// CT = true (the conjugation then happens inside the multiply, at the same instruction count).
+template <int K, bool INV = false, bool CT = false>
 __device__ __forceinline__ void wave_fft_core(const v2f* d, v2f (*zz)[K / 128], v2f* xb, const v2f* s_twB, const v2f* s_twC,
                                               const int lane) {
   constexpr int P = K / 64;
@@ -185,7 +193,7 @@ __device__ __forceinline__ void wave_fft_core(const v2f* d, v2f (*zz)[K / 128], 
 #pragma unroll
     for (int u = 0; u < B12; ++u) {
 #pragma unroll
-      for (int t = 1; t < 16; ++t) e[u][t] = wcmul(e[u][t], s_twB[t * 16 + k16]);
+      for (int t = 1; t < 16; ++t) e[u][t] = CT ? wcmul_conj(e[u][t], s_twB[t * 16 + k16]) : wcmul(e[u][t], s_twB[t * 16 + k16]);
       dft16<INV>(e[u]);
     }
     wave_lds_fence();  // every exchange-1 read is issued before exchange 2 overwrites the buffer
@@ -209,8 +217,8 @@ __device__ __forceinline__ void wave_fft_core(const v2f* d, v2f (*zz)[K / 128], 
         c1[t] = v2f{v.z, v.w};
         if (t > 0) {
           const v4f w = *reinterpret_cast<const v4f*>(&s_twC[t * 256 + i0]);
-          c0[t] = wcmul(c0[t], v2f{w.x, w.y});
-          c1[t] = wcmul(c1[t], v2f{w.z, w.w});
+          c0[t] = CT ? wcmul_conj(c0[t], v2f{w.x, w.y}) : wcmul(c0[t], v2f{w.x, w.y});
+          c1[t] = CT ? wcmul_conj(c1[t], v2f{w.z, w.w}) : wcmul(c1[t], v2f{w.z, w.w});
         }
       }
       if (R3 == 4) { dft4<INV>(c0[0], c0[1], c0[2], c0[3]); dft4<INV>(c1[0], c1[1], c1[2], c1[3]); }

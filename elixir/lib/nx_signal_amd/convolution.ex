@@ -1,9 +1,11 @@
 defmodule NxSignalAMD.Convolution do
   @moduledoc """
-  The FFT leg of `NxSignal.Convolution` (lib/nx_signal/convolution.ex:38-58, :252-347): `convolve(a, b, method: :fft)` /
-  `fftconvolve/3`.  A real stream against a real 1-D filter runs the overlap-save kernel (any length, batched over leading
+  `NxSignal.Convolution` (lib/nx_signal/convolution.ex:38-58, :87-93, :95-218, :252-347): `convolve/3`, `correlate/3`,
+  `fftconvolve/3`.  `method: :direct` (the default, as in the reference) runs time-domain sums on the device, products
+  accumulated in double in the BinaryBackend's window order (exact on integer-valued data, O(output x kernel) work).
+  `method: :fft`: a real stream against a real 1-D filter runs the overlap-save kernel (any length, batched over leading
   axes of `a`); every other pair of operands of equal rank (complex, 2-D, 3-D ...) runs the device-side `fft_nd` fold like
-  the reference.  `method: :direct` is not part of the accelerated path and raises.
+  the reference.
   """
   alias NxSignalAMD.NIF
 
@@ -15,9 +17,42 @@ defmodule NxSignalAMD.Convolution do
 
     case opts[:method] do
       :fft -> fftconvolve(in1, in2, mode: opts[:mode])
-      :direct -> raise ArgumentError, "method: :direct is not accelerated; use method: :fft or NxSignal.Convolution"
+      :direct -> direct_convolve(in1, in2, opts[:mode])
       other -> raise ArgumentError, "expected method to be one of [:direct, :fft], got: #{inspect(other)}"
     end
+  end
+
+  @doc "See `NxSignal.Convolution.correlate/3`: `convolve(in1, conjugate(reverse(in2)), opts)`."
+  def correlate(in1, in2, opts \\ []) do
+    k = Nx.reverse(in2)
+    k = if match?({:c, _}, Nx.type(k)), do: Nx.conjugate(k), else: k
+    convolve(in1, k, opts)
+  end
+
+  # direct_convolve (lib/nx_signal/convolution.ex:95-218): rank checks as there; scalars become one-element vectors
+  defp direct_convolve(in1, in2, mode) do
+    rank =
+      case {Nx.rank(in1), Nx.rank(in2)} do
+        {0, 0} -> 0
+        {0, r} -> raise ArgumentError, message: "Incompatible ranks: {0, #{r}}"
+        {r, 0} -> raise ArgumentError, message: "Incompatible ranks: {#{r}, 0}"
+        {r, r} -> r
+        {r1, r2} ->
+          raise ArgumentError,
+                "NxSignal.convolve/3 requires both inputs to have the same rank or one of them to be a scalar, got #{r1} and #{r2}"
+      end
+
+    {in1, in2} = if rank == 0, do: {Nx.reshape(in1, {1}), Nx.reshape(in2, {1})}, else: {in1, in2}
+    {a, a_real} = operand(in1)
+    {b, b_real} = operand(in2)
+
+    {:ok, out, out_shape} =
+      NIF.convolve_direct(NxSignalAMD.context(), a, a_real, Tuple.to_list(Nx.shape(in1)), b, b_real, Tuple.to_list(Nx.shape(in2)), mode!(mode))
+      |> NxSignalAMD.unwrap!()
+
+    type = if a_real == 1 and b_real == 1, do: :f32, else: :c64
+    res = Nx.from_binary(out, type) |> Nx.reshape(List.to_tuple(out_shape))
+    if rank == 0, do: Nx.reshape(res, {}), else: res
   end
 
   def fftconvolve(in1, in2, opts \\ []) do

@@ -34,6 +34,7 @@ defmodule NxSignalAMD.NIF do
   def fft_nd(_ctx, _in, _is_real, _shape, _axes, _lengths, _inverse), do: :erlang.nif_error(:nif_not_loaded)
 
   def fftconvolve_nd(_ctx, _a, _a_is_real, _a_shape, _b, _b_is_real, _b_shape, _mode),
+  def convolve_direct(_ctx, _a, _a_is_real, _a_shape, _b, _b_is_real, _b_shape, _mode),
     do: :erlang.nif_error(:nif_not_loaded)
   def stft_to_mel(_ctx, _z, _rows, _fft_length, _mel_bins, _filters), do: :erlang.nif_error(:nif_not_loaded)
 

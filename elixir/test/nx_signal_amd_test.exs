@@ -56,4 +56,22 @@ defmodule NxSignalAMDTest do
     assert_raise ArgumentError, ~r/invalid :scaling/, fn -> Sig.stft(Nx.iota({16}), Sig.Windows.hann(4), scaling: :eggs) end
     assert_raise ArgumentError, ~r/invalid padding mode/, fn -> Sig.stft(Nx.iota({16}), Sig.Windows.hann(4), window_padding: :zeros) end
   end
+
+  test "convolve/3 defaults to the direct method and is exact on integer data" do
+    assert Sig.Convolution.convolve(Nx.tensor([3, 4, 5, 6, 5, 4]), Nx.tensor([1, 2, 3])) ==
+             Nx.tensor([3, 10, 22, 28, 32, 32, 23, 12], type: :f32)
+
+    assert Sig.Convolution.convolve(Nx.tensor([3, 4, 5]), Nx.tensor([1, 2, 3, 4]), mode: :same) == Nx.tensor([10, 22, 34], type: :f32)
+    assert Sig.Convolution.correlate(Nx.tensor([1, 2, 3]), Nx.tensor([3, 4, 5])) == Nx.tensor([5.0, 14.0, 26.0, 18.0, 9.0])
+    assert Sig.Convolution.convolve(Nx.tensor(1289), Nx.tensor(4567)) == Nx.tensor(5_886_863.0)
+    assert_raise ArgumentError, fn -> Sig.Convolution.convolve(Nx.tensor([1]), Nx.tensor(2)) end
+  end
+
+  test "istft_filtered equals multiply-then-istft" do
+    z = Nx.iota({2, 9, 1024}, type: :f32) |> Nx.sin() |> Nx.as_type(:c64)
+    h = Nx.iota({1024}, type: :f32) |> Nx.cos() |> Nx.as_type(:c64)
+    w = Sig.Windows.hann(1024)
+    opts = [overlap_length: 768, sampling_rate: 48_000]
+    assert Sig.istft_filtered(z, h, w, opts) == Sig.istft(Nx.multiply(z, h), w, opts)
+  end
 end

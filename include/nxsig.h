@@ -192,6 +192,17 @@ int nxsig_fftconvolve_nd(nxsig_ctx* ctx, const void* a, int32_t a_is_real, const
                          const int64_t* b_shape, int32_t rank, int32_t mode, void* out, int64_t* out_shape, int32_t mem);
 
 /*
+ * Convolution.convolve/3 with `method: :direct` (the reference's DEFAULT method) — lib/nx_signal/convolution.ex:38-58, :95-218:
+ * Nx.conv of in1, zero-padded per mode (:full k-1 on both sides; :same (k-1) - div(k-1, 2) left, div(k-1, 2) right; :valid none,
+ * the larger operand becomes the volume, :120-135), with in2 reversed along every axis.  Time-domain sums, products accumulated
+ * in double in the BinaryBackend's window order and rounded once: integer-valued inputs come out exact (the reference's tests
+ * compare with ==).  O(output x kernel) work — meant for short kernels; long filters belong to nxsig_fir_f32 / the FFT method.
+ * Same argument convention as nxsig_fftconvolve_nd; out shape: full s1 + s2 - 1, same s1, valid |s1 - s2| + 1.
+ */
+int nxsig_convolve_direct(nxsig_ctx* ctx, const void* a, int32_t a_is_real, const int64_t* a_shape, const void* b, int32_t b_is_real,
+                          const int64_t* b_shape, int32_t rank, int32_t mode, void* out, int64_t* out_shape, int32_t mem);
+
+/*
  * FIR filtering: y = Convolution.convolve(x, h, method: :fft, mode:) for real 1-D x (per batch row) and
  * real taps h — lib/nx_signal/convolution.ex:252-329 as used by guides/filtering.livemd:126-128 —
  * computed by overlap-save block FFT convolution (the `Filters.fir` of BASELINE config 5; the reference

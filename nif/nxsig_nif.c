@@ -424,7 +424,9 @@ static ERL_NIF_TERM nif_fft_nd(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
 
 /* fftconvolve_nd(ctx, a_bin, a_is_real, a_shape, b_bin, b_is_real, b_shape, mode) -> {:ok, out_bin, out_shape}
  * (Convolution.fftconvolve/3 for operands of equal rank; out is f32 when both are real, else c64) */
-static ERL_NIF_TERM nif_fftconvolve_nd(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+typedef int (*conv_nd_fn)(nxsig_ctx*, const void*, int32_t, const int64_t*, const void*, int32_t, const int64_t*, int32_t, int32_t, void*,
+                          int64_t*, int32_t);
+static ERL_NIF_TERM conv_nd_common(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[], conv_nd_fn fn, const char* rank_msg) {
   ctx_res_t* c;
   ErlNifBinary a, b, ob;
   int a_real, b_real, mode;
@@ -434,7 +436,7 @@ static ERL_NIF_TERM nif_fftconvolve_nd(ErlNifEnv* env, int argc, const ERL_NIF_T
       !get_i64_list(env, argv[3], s1, 8, &r1) || !enif_inspect_binary(env, argv[4], &b) || !enif_get_int(env, argv[5], &b_real) ||
       !get_i64_list(env, argv[6], s2, 8, &r2) || !enif_get_int(env, argv[7], &mode) || r1 < 1)
     return enif_make_badarg(env);
-  if (r1 != r2) return mk_error_msg(env, NXSIG_ERR_INVALID_ARG, "Rank of in1 and in2 must be equal.");  /* convolution.ex:295-296 */
+  if (r1 != r2) return mk_error_msg(env, NXSIG_ERR_INVALID_ARG, rank_msg);
   size_t na = 1, nb = 1, nfull = 1;
   for (unsigned d = 0; d < r1; ++d) {
     if (s1[d] < 1 || s2[d] < 1 || !mul_size(&na, (uint64_t)s1[d]) || !mul_size(&nb, (uint64_t)s2[d]) ||
@@ -445,13 +447,22 @@ static ERL_NIF_TERM nif_fftconvolve_nd(ErlNifEnv* env, int argc, const ERL_NIF_T
     return enif_make_badarg(env);
   const size_t es = (a_real && b_real) ? 4 : 8;
   if (!out_bin(&ob, nfull, 1, 1, es)) return mk_oom(env);  /* every mode's result fits the full size */
-  int rc = nxsig_fftconvolve_nd(c->ctx, a.data, a_real, s1, b.data, b_real, s2, (int32_t)r1, mode, ob.data, osh, NXSIG_HOST);
+  int rc = fn(c->ctx, a.data, a_real, s1, b.data, b_real, s2, (int32_t)r1, mode, ob.data, osh, NXSIG_HOST);
   if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
   size_t nres = 1;
   ERL_NIF_TERM dims[8];
   for (unsigned d = 0; d < r1; ++d) { nres *= (size_t)osh[d]; dims[d] = enif_make_int64(env, osh[d]); }
   if (!enif_realloc_binary(&ob, nres * es)) { enif_release_binary(&ob); return mk_oom(env); }
   return enif_make_tuple3(env, mk_atom(env, "ok"), enif_make_binary(env, &ob), enif_make_list_from_array(env, dims, r1));
+}
+static ERL_NIF_TERM nif_fftconvolve_nd(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  return conv_nd_common(env, argc, argv, nxsig_fftconvolve_nd, "Rank of in1 and in2 must be equal.");  /* convolution.ex:295-296 */
+}
+/* convolve_direct(ctx, a_bin, a_is_real, a_shape, b_bin, b_is_real, b_shape, mode) -> {:ok, out_bin, out_shape}
+ * (Convolution.convolve/3 with its default method: time-domain sums, lib/nx_signal/convolution.ex:95-218) */
+static ERL_NIF_TERM nif_convolve_direct(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  return conv_nd_common(env, argc, argv, nxsig_convolve_direct,
+                        "NxSignal.convolve/3 requires both inputs to have the same rank or one of them to be a scalar");  /* :112-115 */
 }
 
 /* stft_to_mel(ctx, z_bin, rows, fft_length, mel_bins, filters_bin) -> {:ok, f32[rows][mel_bins]}   (lib/nx_signal.ex:486-513) */
@@ -774,6 +785,7 @@ static ErlNifFunc funcs[] = {
     {"fftconvolve_c64", 4, nif_fftconvolve_c64, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fft_nd", 7, nif_fft_nd, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fftconvolve_nd", 8, nif_fftconvolve_nd, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"convolve_direct", 8, nif_convolve_direct, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_to_mel", 6, nif_stft_to_mel, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_mel", 8, nif_stft_mel, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_magnitude", 7, nif_stft_magnitude, ERL_NIF_DIRTY_JOB_IO_BOUND},

@@ -96,6 +96,7 @@ SIGNATURES = {
     "nxsig_stft_magnitude_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _p, C.POINTER(_i64), _i32]),
     "nxsig_fft_nd": (C.c_int, [_p, _p, _i32, C.POINTER(_i64), _i32, C.POINTER(_i32), C.POINTER(_i64), _i32, _i32, _p, _i32]),
     "nxsig_fftconvolve_nd": (C.c_int, [_p, _p, _i32, C.POINTER(_i64), _p, _i32, C.POINTER(_i64), _i32, _i32, _p, C.POINTER(_i64), _i32]),
+    "nxsig_convolve_direct": (C.c_int, [_p, _p, _i32, C.POINTER(_i64), _p, _i32, C.POINTER(_i64), _i32, _i32, _p, C.POINTER(_i64), _i32]),
     "nxsig_fir_slice_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32]),
     "nxsig_timer_lap": (C.c_int, [_p]),
     "nxsig_timer_laps": (C.c_int, [_p, _pf, _i32, C.POINTER(_i32)]),

@@ -1,7 +1,8 @@
-"""NxSignal.Convolution (FFT method) — lib/nx_signal/convolution.ex:38-58, :252-347.
+"""NxSignal.Convolution — lib/nx_signal/convolution.ex:38-58, :87-93, :95-218, :252-347.
 
-`method: :direct` (n-D Nx.conv) is out of scope for the hot path and raises NxSignalUnsupported.
-The FFT method: a real stream against a real 1-D filter runs the overlap-save kernel (any length, batched over leading
+`method: :direct` (the reference's default): time-domain sums on the device (nxsig_convolve_direct: one thread per output,
+products accumulated in double in the BinaryBackend's window order) — exact on the integer-valued data of the reference's
+tests, O(output x kernel) work, meant for short kernels.  The FFT method: a real stream against a real 1-D filter runs the overlap-save kernel (any length, batched over leading
 axes); complex 1-D operands one transform of up to 2^26 points; n-D operands of equal rank the device-side fft_nd fold
 (nxsig_fftconvolve_nd: transforms over the axes where neither dimension is 1, broadcast product, inverse, `centered` slice)."""
 from __future__ import annotations
@@ -29,13 +30,47 @@ def convolve(in1, in2, ctx=None, **opts):
     if o["method"] not in ("direct", "fft"):  # :46-49
         raise ArgumentError(f"expected method to be one of [:direct, :fft], got: {o['method']!r}")
     if o["method"] == "direct":
-        raise NxSignalUnsupported("convolve(method: :direct) (n-D Nx.conv) is outside the FFT/FIR hot path; use method='fft'")
+        return _convolve_direct(in1, in2, o["mode"], ctx)
     return fftconvolve(in1, in2, ctx=ctx, mode=o["mode"])
+
+
+def _convolve_direct(in1, in2, mode, ctx):
+    """direct_convolve — lib/nx_signal/convolution.ex:95-218 (rank checks :97-115, :valid operand order :120-135)"""
+    if is_device(in1) or is_device(in2):
+        raise NxSignalUnsupported("convolve(method: :direct) takes host tensors; device-resident streams use method='fft'")
+    a, b = np.asarray(in1), np.asarray(in2)
+    if a.ndim != b.ndim:
+        if a.ndim == 0 or b.ndim == 0:
+            raise ArgumentError(f"Incompatible ranks: {{{a.ndim}, {b.ndim}}}")
+        raise ArgumentError("NxSignal.convolve/3 requires both inputs to have the same rank or one of them to be a scalar, "
+                            f"got {a.ndim} and {b.ndim}")
+    for t in (a, b):
+        if t.dtype in (np.float64, np.complex128):
+            raise ArgumentError("convolve: f64 / c128 is outside this path (f32 / c64); cast explicitly")
+    scalar = a.ndim == 0
+    if scalar:
+        a, b = a.reshape(1), b.reshape(1)
+    if a.ndim > 8:
+        raise NxSignalUnsupported("convolve: rank > 8")
+    a_real, b_real = not np.iscomplexobj(a), not np.iscomplexobj(b)
+    ac = np.ascontiguousarray(a.astype(np.float32 if a_real else np.complex64))
+    bc = np.ascontiguousarray(b.astype(np.float32 if b_real else np.complex64))
+    rank = ac.ndim
+    s1 = (C.c_int64 * rank)(*ac.shape)
+    s2 = (C.c_int64 * rank)(*bc.shape)
+    osh = (C.c_int64 * rank)()
+    out = np.empty([x + y - 1 for x, y in zip(ac.shape, bc.shape)], np.float32 if (a_real and b_real) else np.complex64)
+    c = ctx or default_context()
+    _lib.check(_lib.load().nxsig_convolve_direct(c.handle, ac.ctypes.data_as(C.c_void_p), int(a_real), s1, bc.ctypes.data_as(C.c_void_p),
+                                                 int(b_real), s2, rank, _MODES[mode], out.ctypes.data_as(C.c_void_p), osh, _lib.HOST))
+    shape = tuple(int(v) for v in osh)
+    res = out.reshape(-1)[: int(np.prod(shape))].reshape(shape).copy()
+    return res.reshape(()) if scalar else res
 
 
 def correlate(in1, in2, ctx=None, **opts):
     """NxSignal.Convolution.correlate/3 — lib/nx_signal/convolution.ex:87-93: convolve(in1, conj(reverse(in2)), opts) with the
-    kernel reversed along every axis (`method: :fft` is the path built here, like convolve)."""
+    kernel reversed along every axis; :method and :mode go to convolve (default method :direct, like the reference)."""
     k = np.asarray(in2)
     k = k[tuple(slice(None, None, -1) for _ in range(k.ndim))]
     if np.iscomplexobj(k):

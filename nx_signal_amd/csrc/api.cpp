@@ -839,6 +839,36 @@ int nxsig_fftconvolve_nd(nxsig_ctx* ctx, const void* a, int32_t a_is_real, const
   NXSIG_API_END
 }
 
+int nxsig_convolve_direct(nxsig_ctx* ctx, const void* a, int32_t a_is_real, const int64_t* a_shape, const void* b, int32_t b_is_real,
+                          const int64_t* b_shape, int32_t rank, int32_t mode, void* out, int64_t* out_shape, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!a || !b || !out || !a_shape || !b_shape) return set_error(NXSIG_ERR_INVALID_ARG, "convolve: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (rank < 1 || rank > 8) return set_error(NXSIG_ERR_INVALID_ARG, "convolve: rank must be in [1, 8]");
+  if (mem == NXSIG_DEVICE) return launch_convolve_direct(c, a, a_is_real != 0, a_shape, b, b_is_real != 0, b_shape, rank, mode, out, out_shape);
+  int64_t na = 1, nb = 1, no = 1, osh[8];
+  for (int d = 0; d < rank; ++d) {
+    if (a_shape[d] < 1 || b_shape[d] < 1) return set_error(NXSIG_ERR_INVALID_ARG, "convolve: empty dimension");
+    na *= a_shape[d]; nb *= b_shape[d]; no *= a_shape[d] + b_shape[d] - 1;  // upper bound of every mode's result
+  }
+  const bool real_out = a_is_real && b_is_real;
+  void *da = nullptr, *db = nullptr, *dout = nullptr;
+  const size_t abytes = (size_t)na * (a_is_real ? 4 : 8), bbytes = (size_t)nb * (b_is_real ? 4 : 8);
+  if ((rc = ctx_scratch(c, 17, abytes, &da))) return rc;
+  if ((rc = ctx_scratch(c, 18, bbytes, &db))) return rc;
+  if ((rc = ctx_scratch(c, 19, (size_t)no * (real_out ? 4 : 8), &dout))) return rc;
+  NXSIG_HIP_TRY(hipMemcpyAsync(da, a, abytes, hipMemcpyHostToDevice, c->stream));
+  NXSIG_HIP_TRY(hipMemcpyAsync(db, b, bbytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = launch_convolve_direct(c, da, a_is_real != 0, a_shape, db, b_is_real != 0, b_shape, rank, mode, dout, osh))) return rc;
+  int64_t nres = 1;
+  for (int d = 0; d < rank; ++d) { nres *= osh[d]; if (out_shape) out_shape[d] = osh[d]; }
+  Staged st(c);
+  return st.out_copy(out, dout, (size_t)nres * (real_out ? 4 : 8));
+  NXSIG_API_END
+}
+
 int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const nxsig_c64* b, int64_t n2, int32_t mode,
                           nxsig_c64* out, int32_t mem) {
   NXSIG_API_BEGIN

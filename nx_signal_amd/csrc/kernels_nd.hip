@@ -469,6 +469,99 @@ int launch_fftconvolve_nd(Ctx* c, const void* a, bool a_is_real, const int64_t* 
   return NXSIG_OK;
 }
 
+// ================================================================================================ direct convolution
+// Convolution.convolve(method: :direct) — lib/nx_signal/convolution.ex:95-218: Nx.conv of in1 (zero-padded per mode) with the
+// kernel reversed along every axis.  One thread per output element; the products are accumulated in double in the order the
+// BinaryBackend walks the kernel window (row-major, ascending in1 index) and rounded once, so integer-valued inputs come out
+// exact like in the reference's tests and random inputs match a sequential double restatement bit for bit.  O(out x kernel):
+// the time-domain form, for short kernels; long filters belong to the FFT method (k_fir_wave / fftconvolve).
+struct DirectArgs {
+  int32_t rank, a_real, b_real;
+  int64_t oshape[8], ashape[8], kshape[8], astride[8], kstride[8], shift[8];  // in1 index = out index + window index + shift
+  int64_t total, ktotal;
+};
+__global__ __launch_bounds__(kT) void k_conv_direct(const void* __restrict__ a, const void* __restrict__ k, DirectArgs g, void* __restrict__ out) {
+  const int64_t o = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (o >= g.total) return;
+  int64_t base[8], j[8];
+  int64_t rem = o;
+  for (int d = g.rank - 1; d >= 0; --d) {
+    const int64_t q = rem / g.oshape[d];
+    base[d] = rem - q * g.oshape[d] + g.shift[d];
+    rem = q;
+    j[d] = 0;
+  }
+  const float* af = reinterpret_cast<const float*>(a);
+  const float2* ac = reinterpret_cast<const float2*>(a);
+  const float* kf = reinterpret_cast<const float*>(k);
+  const float2* kc = reinterpret_cast<const float2*>(k);
+  double acc_re = 0.0, acc_im = 0.0;
+  for (int64_t t = 0; t < g.ktotal; ++t) {
+    bool inside = true;
+    int64_t ia = 0, ik = 0;
+    for (int d = 0; d < g.rank; ++d) {
+      const int64_t i = base[d] + j[d];
+      inside = inside && i >= 0 && i < g.ashape[d];
+      ia += i * g.astride[d];
+      ik += (g.kshape[d] - 1 - j[d]) * g.kstride[d];   // the window holds the REVERSED kernel
+    }
+    if (inside) {
+      double ar, ai = 0.0, br, bi = 0.0;
+      if (g.a_real) ar = (double)af[ia]; else { const float2 v = ac[ia]; ar = (double)v.x; ai = (double)v.y; }
+      if (g.b_real) br = (double)kf[ik]; else { const float2 v = kc[ik]; br = (double)v.x; bi = (double)v.y; }
+      // f32 x f32 products are exact in double: each component of the complex product is rounded once, like Complex.multiply
+      acc_re += ar * br - ai * bi;
+      acc_im += ar * bi + ai * br;
+    }
+    for (int d = g.rank - 1; d >= 0; --d) {  // row-major odometer over the window
+      if (++j[d] < g.kshape[d]) break;
+      j[d] = 0;
+    }
+  }
+  if (g.a_real && g.b_real) reinterpret_cast<float*>(out)[o] = (float)acc_re;
+  else reinterpret_cast<float2*>(out)[o] = make_float2((float)acc_re, (float)acc_im);
+}
+
+// a, b: device tensors of equal rank (f32 when *_is_real, else c64); out f32 when both are real, else c64
+int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t* s1, const void* b, bool b_is_real, const int64_t* s2,
+                           int rank, int mode, void* out, int64_t* out_shape) {
+  if (rank < 1 || rank > 8) return set_error(NXSIG_ERR_INVALID_ARG, "convolve: rank must be in [1, 8]");
+  for (int d = 0; d < rank; ++d)
+    if (s1[d] < 1 || s2[d] < 1) return set_error(NXSIG_ERR_INVALID_ARG, "convolve: empty dimension");
+  const void *vol = a, *ker = b;
+  bool vol_real = a_is_real, ker_real = b_is_real;
+  const int64_t *sv = s1, *sk = s2;
+  if (mode == NXSIG_CONV_VALID) {  // convolution.ex:120-135: the larger operand becomes the volume
+    bool ok1 = true, ok2 = true;
+    for (int d = 0; d < rank; ++d) { ok1 = ok1 && s1[d] >= s2[d]; ok2 = ok2 && s1[d] <= s2[d]; }
+    if (!ok1 && !ok2)
+      return set_error(NXSIG_ERR_INVALID_ARG, "For :valid mode, one must be at least as large as the other in every dimension");
+    if (!ok1) { vol = b; ker = a; vol_real = b_is_real; ker_real = a_is_real; sv = s2; sk = s1; }
+  } else if (mode != NXSIG_CONV_FULL && mode != NXSIG_CONV_SAME) {
+    return set_error(NXSIG_ERR_INVALID_ARG, "expected mode to be one of [:full, :same, :valid]");
+  }
+  DirectArgs g;
+  g.rank = rank; g.a_real = vol_real ? 1 : 0; g.b_real = ker_real ? 1 : 0; g.total = 1; g.ktotal = 1;
+  int64_t sa = 1, sb = 1;
+  for (int d = rank - 1; d >= 0; --d) {
+    const int64_t k = sk[d];
+    int64_t pad_left, res;
+    switch (mode) {  // padding of Nx.conv, convolution.ex:157-190
+      case NXSIG_CONV_FULL: pad_left = k - 1; res = sv[d] + k - 1; break;
+      case NXSIG_CONV_SAME: pad_left = (k - 1) - (k - 1) / 2; res = sv[d]; break;
+      default: pad_left = 0; res = sv[d] - k + 1; break;
+    }
+    g.oshape[d] = res; g.ashape[d] = sv[d]; g.kshape[d] = k; g.astride[d] = sa; g.kstride[d] = sb; g.shift[d] = -pad_left;
+    sa *= sv[d]; sb *= k;
+    g.total *= res; g.ktotal *= k;
+    if (out_shape) out_shape[d] = res;
+  }
+  if (g.total > (int64_t)0x7fffffff * kT) return set_error(NXSIG_ERR_UNSUPPORTED, "convolve: result too large for one launch");
+  hipLaunchKernelGGL(k_conv_direct, dim3(blocks_for(g.total)), dim3(kT), 0, c->stream, vol, ker, g, out);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
 // ================================================================================================ stft for long transforms
 __global__ __launch_bounds__(kT) void k_frames_windowed(const float* __restrict__ x, int64_t batch_stride, int64_t L, int64_t lo, int32_t reflect,
                                                         int64_t M, int32_t N, int32_t hop, const float* __restrict__ w, float* __restrict__ out) {

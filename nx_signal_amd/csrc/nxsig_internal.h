@@ -150,6 +150,8 @@ int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_
 int launch_rows_post(Ctx* c, float2* a, int64_t rows, int64_t K, const float* window, float scale, bool has_scale, float div, bool has_div);
 int launch_fft_nd(Ctx* c, const void* in, bool in_is_real, const int64_t* shape, int rank, const int32_t* axes, const int64_t* lengths,
                   int n_axes, bool inverse, float2* out);
+int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t* s1, const void* b, bool b_is_real, const int64_t* s2,
+                           int rank, int mode, void* out, int64_t* out_shape);
 int launch_fftconvolve_nd(Ctx* c, const void* a, bool a_is_real, const int64_t* s1, const void* b, bool b_is_real, const int64_t* s2,
                           int rank, int mode, void* out, int64_t* out_shape);
 int launch_stft_big(Ctx* c, const StftLaunch& s);

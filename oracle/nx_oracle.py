@@ -536,6 +536,58 @@ def fftconvolve(in1, in2, mode="full", eps=FFT_EPS):
     return np.ascontiguousarray(out[sl])
 
 
+def convolve_direct(in1, in2, mode="full"):
+    """NxSignal.Convolution.convolve(method: :direct) — lib/nx_signal/convolution.ex:95-218: Nx.conv of in1 (zero-padded per
+    mode, :157-190) with in2 reversed along every axis (:137); :valid makes the larger operand the volume (:120-135).  Each
+    output is the sum over the kernel window in row-major order of products formed and accumulated in double (Elixir floats /
+    Complex structs in the BinaryBackend), rounded once to f32 / c64.  Scalars (rank 0) multiply (:97-99, :147-150)."""
+    if mode not in ("full", "same", "valid"):
+        raise ValueError(f"expected mode to be one of [:full, :same, :valid], got: {mode!r}")
+    a = np.asarray(in1)
+    b = np.asarray(in2)
+    if a.ndim != b.ndim:
+        if a.ndim == 0 or b.ndim == 0:
+            raise ValueError(f"Incompatible ranks: {{{a.ndim}, {b.ndim}}}")
+        raise ValueError(f"NxSignal.convolve/3 requires both inputs to have the same rank or one of them to be a scalar, got {a.ndim} and {b.ndim}")
+    scalar = a.ndim == 0
+    if scalar:
+        a, b = a.reshape(1), b.reshape(1)
+    if mode == "valid":
+        ok1 = all(x >= y for x, y in zip(a.shape, b.shape))
+        ok2 = all(x <= y for x, y in zip(a.shape, b.shape))
+        if not (ok1 or ok2):
+            raise ValueError("For :valid mode, one must be at least as large as the other in every dimension")
+        if not ok1:
+            a, b = b, a
+    is_c = np.iscomplexobj(a) or np.iscomplexobj(b)
+    wide = c128 if is_c else f64
+    vol = a.astype(c64 if np.iscomplexobj(a) else f32).astype(wide)
+    ker = b.astype(c64 if np.iscomplexobj(b) else f32).astype(wide)
+    ker = ker[tuple(slice(None, None, -1) for _ in range(ker.ndim))]
+    pads = []
+    for k in ker.shape:
+        if mode == "full":
+            pads.append((k - 1, k - 1))
+        elif mode == "same":
+            pads.append(((k - 1) - (k - 1) // 2, (k - 1) // 2))
+        else:
+            pads.append((0, 0))
+    vp = np.pad(vol, pads)
+    oshape = tuple(v - k + 1 for v, k in zip(vp.shape, ker.shape))
+    acc = np.zeros(oshape, dtype=wide)
+    for j in np.ndindex(*ker.shape):  # row-major over the window, like the backend's weighted sum
+        win = vp[tuple(slice(jj, jj + o) for jj, o in zip(j, oshape))]
+        kv = ker[j]
+        if is_c:  # Complex.multiply then Complex.add: every real operation rounds once (the f32 x f32 products are exact)
+            pr = win.real * kv.real - win.imag * kv.imag
+            pi = win.real * kv.imag + win.imag * kv.real
+            acc = (acc.real + pr) + 1j * (acc.imag + pi)
+        else:
+            acc = acc + win * kv
+    out = acc.astype(c64 if is_c else f32)
+    return out.reshape(()) if scalar else np.ascontiguousarray(out)
+
+
 def direct_convolve_f64(x, h):
     """Independent check (SURVEY §4 direct-vs-FFT pattern): full linear convolution in double."""
     return np.convolve(np.asarray(x, dtype=f64), np.asarray(h, dtype=f64))
@@ -603,10 +655,12 @@ def fft_nd(x, axes=(-1,), lengths=None, inverse=False):
     return np.ascontiguousarray(acc)
 
 
-def correlate(a, b, mode="full"):
-    """NxSignal.Convolution.correlate/3 (method: :fft) — lib/nx_signal/convolution.ex:87-93"""
+def correlate(a, b, mode="full", method="fft"):
+    """NxSignal.Convolution.correlate/3 — lib/nx_signal/convolution.ex:87-93: convolve(in1, conj(reverse(in2)), opts)"""
     k = np.asarray(b)
     k = k[tuple(slice(None, None, -1) for _ in range(k.ndim))]
     if np.iscomplexobj(k):
         k = np.conj(k)
+    if method == "direct":
+        return convolve_direct(np.asarray(a), np.ascontiguousarray(k), mode=mode)
     return fftconvolve(np.asarray(a), np.ascontiguousarray(k), mode=mode)

@@ -160,3 +160,61 @@ def test_fft_nd_long_inner_axis():
     wide = rng.standard_normal((2, 4300000)).astype(np.float32)  # inner axis of 4.3 M elements: > 65 535 tiles of 64 rows
     got = S.transforms.fft_nd(wide, axes=[0])
     assert nerr(got, np.fft.fft(wide.astype(np.float64), axis=0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------- convolve(method: :direct), the reference's default
+def _gop(v, key):
+    cplx = v.get("complex") and (v.get(key + "_complex") or not (v.get("a_complex") or v.get("b_complex")))
+    x = np.array(v[key], dtype=np.float64)
+    return (x[..., 0] + 1j * x[..., 1]).astype(np.complex64) if cplx else x.astype(np.float32)
+
+
+def test_convolve_direct_reference_literals(golden):
+    """every convolve/3 literal of test/nx_signal/convolutions_test.exs through the HIP kernel, compared with == like there"""
+    for v in golden["convolve_direct"]:
+        e = np.array(v["expect"], dtype=np.float64)
+        exp = (e[..., 0] + 1j * e[..., 1]).astype(np.complex64) if v.get("complex") else e.astype(np.float32)
+        got = S.convolution.convolve(_gop(v, "a"), _gop(v, "b"), mode=v["mode"])  # default method
+        assert got.shape == exp.shape and got.dtype == exp.dtype and np.array_equal(got, exp), (v["src"], got)
+    for v in golden["convolve_direct_doctest"]:
+        assert S.convolution.convolve(np.array(v["a"]), np.array(v["b"])).tolist() == v["expect"]
+    for v in golden["correlate"] + golden["correlate_direct"]:
+        got = S.convolution.correlate(np.array(v["a"], np.float32), np.array(v["b"], np.float32), mode=v.get("mode", "full"))
+        assert np.array_equal(got, np.array(v["expect"], np.float32)), (v["src"], got)
+    e = golden["convolve_direct_errors"]
+    with pytest.raises(S.ArgumentError, match="For :valid mode"):
+        S.convolution.convolve(np.ones(e[0]["a_shape"], np.float32), np.ones(e[0]["b_shape"], np.float32), mode="valid")
+    for r1, r2 in e[1]["ranks"]:
+        with pytest.raises(S.ArgumentError):
+            S.convolution.convolve(np.ones((1,) * r1, np.float32), np.ones((1,) * r2, np.float32))
+
+
+@pytest.mark.parametrize("s1,s2,mode,cplx", [
+    ((5000,), (129,), "full", False), ((5000,), (129,), "same", False), ((5000,), (128,), "same", False), ((5000,), (129,), "valid", False),
+    ((129,), (5000,), "valid", False), ((40,), (300,), "same", False), ((64,), (64,), "full", True), ((257,), (31,), "same", True),
+    ((37, 53), (5, 7), "full", False), ((37, 53), (6, 4), "same", False), ((5, 7), (37, 53), "valid", True),
+    ((9, 10, 11), (3, 4, 2), "same", False), ((3, 4, 5, 6), (2, 2, 3, 1), "full", True), ((1, 200), (1, 17), "valid", False),
+])
+def test_convolve_direct_matches_oracle_bit_for_bit(s1, s2, mode, cplx):
+    """same accumulation order as the oracle's restatement of the BinaryBackend (double, row-major over the window): identical bits;
+    and the direct and FFT methods agree to FFT round-off (the reference's own cross-check, convolutions_test.exs:392-416)"""
+    rng = np.random.default_rng(sum(s1) + 7 * sum(s2))
+    a = rng.standard_normal(s1).astype(np.float32)
+    b = rng.standard_normal(s2).astype(np.float32)
+    if cplx:
+        a = (a + 1j * rng.standard_normal(s1)).astype(np.complex64)
+    got = S.convolution.convolve(a, b, mode=mode, method="direct")
+    exp = O.convolve_direct(a, b, mode=mode)
+    assert got.shape == exp.shape and got.dtype == exp.dtype
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    viaf = S.convolution.convolve(a, b, mode=mode, method="fft")
+    assert viaf.shape == got.shape and nerr(viaf, got) < 1e-5
+
+
+def test_convolve_direct_long_stream_config5_slice():
+    """the 257-tap low-pass of config 5 on a 200 000-sample slice: the time-domain method against direct f64 convolution"""
+    x = O.synth_signal(200000, seed=5)
+    h = S.filters.firwin(257, [4000.0], sampling_rate=48000)
+    got = S.convolution.convolve(x, h, mode="same")
+    full = O.direct_convolve_f64(x, h)
+    assert np.array_equal(got, full[128:128 + 200000].astype(np.float32)) or nerr(got, full[128:128 + 200000].astype(np.float32)) < 1e-6

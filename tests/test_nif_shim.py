@@ -219,7 +219,7 @@ def test_framing_ola_fft_mel_through_the_nif(nctx, golden):
     assert np.array_equal(f32(mb).view(np.uint32), np.ascontiguousarray(want).reshape(-1).view(np.uint32))
     for kind, name in ((0, "magnitude"), (1, "power"), (2, "dbfs")):
         ok, gb, m2 = H.call("stft_magnitude", nctx, x, 16000, 1, w, p, kind)
-        wantm = S.spectrogram(x, w, overlap_length=240, fft_length=512, sampling_rate=16000, window_padding="reflect", kind=name)
+        wantm = S.spectrogram(x, w, overlap_length=240, fft_length=512, sampling_rate=16000, window_padding="reflect", kind=name)[0]
         assert m2 == wantm.shape[0] and np.array_equal(f32(gb).view(np.uint32), np.ascontiguousarray(wantm).reshape(-1).view(np.uint32))
     z, _, _ = S.stft(x, w, overlap_length=240, fft_length=512, sampling_rate=16000, window_padding="reflect")
     ok, mb2 = H.call("stft_to_mel", nctx, z, z.shape[0], 512, 80, filt)
@@ -320,4 +320,19 @@ def test_fft_nd_and_fftconvolve_nd_through_the_nif(nctx, golden):
     with pytest.raises(H.NifError) as ei:
         H.call("fftconvolve_nd", nctx, x, 1, [5, 7, 16], x, 1, [5, 112], 0)
     assert ei.value.code == -1 and "Rank of in1 and in2 must be equal" in ei.value.msg
+    # convolve/3 with its default method (:direct): the reference's literals come back exact
+    for v in golden["convolve_direct"]:
+        def op(key):
+            cplx = v.get("complex") and (v.get(key + "_complex") or not (v.get("a_complex") or v.get("b_complex")))
+            t = np.atleast_1d(np.array(v[key], dtype=np.float64))
+            return ((t[..., 0] + 1j * t[..., 1]).astype(np.complex64), 0) if cplx else (t.astype(np.float32), 1)
+        (a, ar), (b, br) = op("a"), op("b")
+        e = np.atleast_1d(np.array(v["expect"], dtype=np.float64))
+        e = (e[..., 0] + 1j * e[..., 1]).astype(np.complex64) if v.get("complex") else e.astype(np.float32)
+        ok, ob, osh = H.call("convolve_direct", nctx, a, ar, list(a.shape), b, br, list(b.shape), {"full": 0, "same": 1, "valid": 2}[v["mode"]])
+        out = (f32(ob) if (ar and br) else c64(ob)).reshape(osh)
+        assert tuple(osh) == e.shape and np.array_equal(out, e), v["src"]
+    with pytest.raises(H.NifError) as ei:
+        H.call("convolve_direct", nctx, np.ones((2, 3), np.float32), 1, [2, 3], np.ones((3, 2), np.float32), 1, [3, 2], 2)
+    assert ei.value.code == -1 and "For :valid mode" in ei.value.msg
     assert H.lib().fake_live_binaries() == 0

@@ -174,6 +174,35 @@ def test_fft_nd_all_axes(golden):
             assert nx_all_close(z, exp, v["atol"], v["rtol"]), (v["src"], z)
 
 
+def _golden_operand(v, key):
+    cplx = v.get("complex") and (v.get(key + "_complex") or not (v.get("a_complex") or v.get("b_complex")))
+    x = np.array(v[key], dtype=np.float64)
+    return (x[..., 0] + 1j * x[..., 1]).astype(np.complex64) if cplx else x.astype(np.float32)
+
+
+def _golden_expect(v):
+    e = np.array(v["expect"], dtype=np.float64)
+    return (e[..., 0] + 1j * e[..., 1]).astype(np.complex64) if v.get("complex") else e.astype(np.float32)
+
+
+def test_convolve_direct_reference_literals(golden):
+    """convolve/3 with its default method (:direct): every literal of test/nx_signal/convolutions_test.exs, compared with ==
+    like the reference does (integer-valued data: the double accumulation is exact)"""
+    for v in golden["convolve_direct"]:
+        got = O.convolve_direct(_golden_operand(v, "a"), _golden_operand(v, "b"), mode=v["mode"])
+        exp = _golden_expect(v)
+        assert got.shape == exp.shape and got.dtype == exp.dtype and np.array_equal(got, exp), (v["src"], got)
+    e = golden["convolve_direct_errors"]
+    with pytest.raises(ValueError):
+        O.convolve_direct(np.ones(e[0]["a_shape"], np.float32), np.ones(e[0]["b_shape"], np.float32), mode="valid")
+    for r1, r2 in e[1]["ranks"]:
+        with pytest.raises(ValueError):
+            O.convolve_direct(np.ones((1,) * r1, np.float32), np.ones((1,) * r2, np.float32))
+    for v in golden["correlate_direct"]:
+        got = O.correlate(np.array(v["a"], np.float32), np.array(v["b"], np.float32), mode=v["mode"], method="direct")
+        assert np.array_equal(got, np.array(v["expect"], np.float32)), (v["src"], got)
+
+
 def test_correlate_doctest(golden):
     for v in golden["correlate"]:
         got = O.correlate(np.array(v["a"], dtype=np.float32), np.array(v["b"], dtype=np.float32))

@@ -631,8 +631,9 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_dbl(IstftWaveArgs a) {
 //   -> the K - (taps-1) valid samples of both blocks leave with 8-byte stores.
 // Block b covers full-convolution outputs [b V, (b+1) V), V = K - (taps-1), from x[b V - (taps-1) + n].
 struct FirWaveArgs {
-  const float* x;
+  const float* x;                      // row base shifted by the grid phase (see launch_fir_wave_W)
   int64_t L, batch_stride;
+  int64_t xlo, xhi;                    // valid sample indices relative to x: [xlo, xhi) = [-phase, L - phase)
   int32_t batch, taps;
   int64_t V, nblocks, first_block;     // blocks (per row) covering the requested output slice
   int64_t pairs_per_row;               // block pairs per row
@@ -644,6 +645,9 @@ struct FirWaveArgs {
   const v2f* twC;
   float* y;                            // f32[batch][out_len]
 };
+
+int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, int32_t taps, int64_t first_block, int64_t pb_lo,
+                      int64_t dp_per_row, int64_t out_start, int64_t out_len, const float2* H_dev, float* y);  // kernels_wave_fir32.hip
 
 // STREAM = true : interior pairs only, 8-byte vector access, branch-free and software-pipelined like k_stft_wave
 //                 (requires (taps-1) % 128 == 0 and even offsets — checked by the launcher)
@@ -747,8 +751,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
         for (int e2 = 0; e2 < 2; ++e2) {
           const int n = 2 * lane + e2 + 128 * q;
           const int64_t p1 = s1 + n, p2 = s2 + n;
-          const float v1 = (p1 >= 0 && p1 < a.L) ? xr[p1] : 0.0f;
-          const float v2 = (have2 && p2 >= 0 && p2 < a.L) ? xr[p2] : 0.0f;
+          const float v1 = (p1 >= a.xlo && p1 < a.xhi) ? xr[p1] : 0.0f;
+          const float v2 = (have2 && p2 >= a.xlo && p2 < a.xhi) ? xr[p2] : 0.0f;
           zz[e2][q] = v2f{v1, v2};
         }
       v2f d[P];
@@ -1100,23 +1104,33 @@ static void host_fft1024_f64(std::vector<double>& re, std::vector<double>& im) {
 }
 
 template <int W, int K = 1024>
-static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
+static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   *handled = false;
   constexpr int R3 = K / 256, XCH = K + K / 16 + 16;
-  if (s.out_len <= 0 || s.batch == 0) return NXSIG_OK;
+  if (s_in.out_len <= 0 || s_in.batch == 0) return NXSIG_OK;
   if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
-  if (s.taps > K / 2 + 1) return NXSIG_OK;  // a block would be < 50 % efficient: the generic path uses bigger blocks
+  if (s_in.taps > K / 2 + 1) return NXSIG_OK;  // a block would be < 50 % efficient: the generic path uses bigger blocks
+  // The block geometry may treat the filter as LONGER than it is: trailing zero taps change nothing (the spectrum H is that of
+  // the taps zero-padded to K either way), only the valid part of a block shrinks.  Rounding taps - 1 up to a multiple of 32
+  // (128 on the 2048-point blocks) gives EVERY filter length the streaming kernels instead of the bounds-checked edge path.
+  const int taps_h = s_in.taps;
+  FirLaunch s = s_in;
+  {
+    const int q = K == 1024 ? 32 : 128;
+    const int eff = ((s_in.taps - 1 + q - 1) / q) * q + 1;
+    if (eff <= K / 2 + 1 && env_int("NXSIG_FIR_PAD_TAPS", 1)) s.taps = eff;
+  }
   int rc = ensure_wave_tables(c, K);
   if (rc) return rc;
   *handled = true;
   const void* Hd = nullptr;
-  const uint64_t hkey = fnv1a(0xF1B0ull ^ ((uint64_t)K << 32), s.h_host, (size_t)s.taps * sizeof(float)) ^ (uint64_t)s.taps;
+  const uint64_t hkey = fnv1a(0xF1B0ull ^ ((uint64_t)K << 32), s.h_host, (size_t)taps_h * sizeof(float)) ^ (uint64_t)taps_h;
   auto hit = c->memo.find(hkey);
   if (hit != c->memo.end()) {
     Hd = reinterpret_cast<const void*>(hit->second[0]);  // same taps as an earlier call: no host FFT
   } else {
     std::vector<double> re(K, 0.0), im(K, 0.0);
-    for (int i = 0; i < s.taps; ++i) re[i] = (double)s.h_host[i];
+    for (int i = 0; i < taps_h; ++i) re[i] = (double)s.h_host[i];
     host_fft1024_f64(re, im);
     std::vector<float2> H(K);
     for (int i = 0; i < K; ++i) H[i] = make_float2((float)(re[i] / K), (float)(im[i] / K));
@@ -1125,37 +1139,50 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
     c->memo[hkey] = {reinterpret_cast<uint64_t>(Hd)};
   }
   FirWaveArgs a;
-  a.x = s.x; a.L = s.L; a.batch_stride = s.batch_stride; a.batch = s.batch; a.taps = s.taps;
   a.V = K - (s.taps - 1);
-  a.first_block = s.out_start / a.V;
-  const int64_t last_block = (s.out_start + s.out_len - 1) / a.V;
+  // Grid phase: block b covers full-convolution outputs [b V + phase, (b + 1) V + phase) with phase = out_start mod 32, so every
+  // block's first output is y[multiple of 32]: the streaming stores (128-byte runs per half wave / 512-byte runs per wave, "sc1 nt")
+  // hit whole cache lines when the rows of y are 128-byte aligned.  With mode :same, out_start = div(taps - 1, 2) is rarely
+  // aligned by itself, and partial-line streaming writes cost a factor 2 (measured: 255 taps :same 2.2 -> 4.4 TB/s).  The shift
+  // is applied by moving the signal's origin: x' = x + phase, valid indices [-phase, L - phase), out_start' = out_start - phase.
+  const int64_t phase = env_int("NXSIG_FIR_PHASE", 1) ? (s.out_start % 32) : 0;
+  const int64_t out_start = s.out_start - phase;
+  a.x = s.x + phase; a.xlo = -phase; a.xhi = s.L - phase;
+  a.L = s.L; a.batch_stride = s.batch_stride; a.batch = s.batch; a.taps = s.taps;
+  a.first_block = out_start / a.V;
+  const int64_t last_block = (out_start + s.out_len - 1) / a.V;
   a.nblocks = last_block - a.first_block + 1;
   a.pairs_per_row = (a.nblocks + 1) / 2;
-  a.out_start = s.out_start; a.out_len = s.out_len;
+  a.out_start = out_start; a.out_len = s.out_len;
   a.H = reinterpret_cast<const v2f*>(Hd);
   Ctx::WaveTables& wt = c->wave_tables[K];
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
   a.y = s.y;
   // 8-byte vector access needs every offset even: taps-1 multiple of 128 (=> V even), even strides, aligned bases
-  const bool fast = ((s.taps - 1) % 128 == 0) && (s.batch_stride % 2 == 0) && (s.out_len % 2 == 0) && (s.out_start % 2 == 0) &&
-                    ((reinterpret_cast<uintptr_t>(s.x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 7) == 0);
-  // interior pairs pb in [pb_lo, pb_hi): block pair (b1, b1+1), b1 = first_block + 2 pb, reads x[b1 V - (taps-1) .. +V+K)
-  // inside [0, L) and writes y[b1 V - out_start .. + 2V) inside [0, out_len)
+  const bool fast8 = ((s.taps - 1) % 128 == 0) && (s.batch_stride % 2 == 0) && (s.out_len % 2 == 0) && (out_start % 2 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 7) == 0);
+  // the 32 x 32 kernel (kernels_wave_fir32.hip, 4-byte accesses: no alignment conditions) takes what the 8-byte kernel cannot;
+  // where both apply the 8-byte kernel is ~4 % faster (NXSIG_FIR32: 0 never, 1 when needed, 2 always)
+  const int fir32_mode = env_int("NXSIG_FIR32", 1);
+  const bool use32 = K == 1024 && (s.taps - 1) % 32 == 0 && (fir32_mode == 2 || (fir32_mode == 1 && !fast8));
+  const bool fast = use32 || fast8;
+  // interior pairs pb in [pb_lo, pb_hi): block pair (b1, b1+1), b1 = first_block + 2 pb, reads x'[b1 V - (taps-1) .. +V+K)
+  // inside [xlo, xhi) and writes y[b1 V - out_start' .. + 2V) inside [0, out_len)
   a.pb_lo = 0; a.pb_hi = 0;
   if (fast) {
     const int64_t tm1 = s.taps - 1;
     int64_t lo = 0;
     while (lo < a.pairs_per_row) {
       const int64_t b1 = a.first_block + 2 * lo;
-      if (b1 * a.V - tm1 >= 0 && b1 * a.V - a.out_start >= 0) break;
+      if (b1 * a.V - tm1 >= a.xlo && b1 * a.V - a.out_start >= 0) break;
       ++lo;
     }
     int64_t hi = a.pairs_per_row;
     while (hi > lo) {
       const int64_t b1 = a.first_block + 2 * (hi - 1);
       const bool have2 = (b1 + 1 - a.first_block) < a.nblocks;
-      if (have2 && b1 * a.V - tm1 + a.V + K <= s.L && b1 * a.V - a.out_start + 2 * a.V <= s.out_len) break;
+      if (have2 && b1 * a.V - tm1 + a.V + K <= a.xhi && b1 * a.V - a.out_start + 2 * a.V <= s.out_len) break;
       --hi;
     }
     a.pb_lo = lo; a.pb_hi = hi;
@@ -1185,7 +1212,13 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s, bool* handled) {
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
-  rc = launch(true, a.pb_hi - a.pb_lo);
+  if (use32) {  // interior pairs two at a time on the 32 x 32 kernel (kernels_wave_fir32.hip); an odd leftover joins the edge pairs
+    a.pb_hi -= (a.pb_hi - a.pb_lo) & 1;
+    rc = launch_fir_wave32(c, a.x, s.batch_stride, s.batch, s.taps, a.first_block, a.pb_lo, (a.pb_hi - a.pb_lo) / 2, a.out_start, s.out_len,
+                           reinterpret_cast<const float2*>(Hd), s.y);
+  } else {
+    rc = launch(true, a.pb_hi - a.pb_lo);
+  }
   if (rc) return rc;
   return launch(false, a.pairs_per_row - (a.pb_hi - a.pb_lo));
 }

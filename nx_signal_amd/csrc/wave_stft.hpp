@@ -312,6 +312,9 @@ struct StreamRow {
     typedef int v4i __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), r, byte_off, 0, kAux);
   }
+  __device__ __forceinline__ void st4(float v, int byte_off) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, byte_off, 0, kAux);
+  }
   __device__ __forceinline__ void st8(v2f v, int byte_off) const {
     typedef int v2i __attribute__((ext_vector_type(2)));
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, byte_off, 0, kAux);

@@ -123,10 +123,17 @@ def secondary_rooflines(ctx, lib, S, _lib, C):
             ctx.timer_lap()
         return ctx.timer_laps()
 
-    def block(workload, kernel, nbytes, laps, extra):
+    try:
+        traffic_tab = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        traffic_tab = {}
+
+    def block(workload, kernel, nbytes, laps, extra, traffic_key=None):
         ms = float(np.mean(laps))
         ach = nbytes / (ms * 1e-3) / 1e9
-        d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        # HBM bytes per launch from the PMC passes of the same launch shape (profiles/traffic.json), checked against the shape
+        traffic = traffic_tab.get(traffic_key + "_bytes_per_launch") if traffic_key and traffic_tab.get(traffic_key + "_algorithmic_bytes") == nbytes else None
+        d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
              "kernel_ms": ms, "kernel_us": {"min": round(min(laps) * 1e3, 1), "median": round(float(np.median(laps)) * 1e3, 1),
                                             "max": round(max(laps) * 1e3, 1)}, "workload": workload, "kernel": kernel}
         d.update(extra)
@@ -144,7 +151,7 @@ def secondary_rooflines(ctx, lib, S, _lib, C):
         wp = w.ctypes.data_as(C.c_void_p)
         laps = measure(lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(z3.ptr), M, B3, wp, C.byref(p3), C.c_void_p(y3.ptr), _lib.DEVICE)), 20, 30)
         out["roofline_istft"] = block("config 3: istft N=1024 hop=256, 16 x 60 s mono 48 kHz, c64 out", "k_istft_wave<1024> (+ k_istft_edge_fix)",
-                                      B3 * M * (N_FFT * 8 + HOP * 8), laps, {"bytes_per_frame": N_FFT * 8 + HOP * 8, "frames_per_s": B3 * M / (float(np.mean(laps)) * 1e-3)})
+                                      B3 * M * (N_FFT * 8 + HOP * 8), laps, {"bytes_per_frame": N_FFT * 8 + HOP * 8, "frames_per_s": B3 * M / (float(np.mean(laps)) * 1e-3)}, "istft")
         # round trip of config 3 on interior samples (size-independent property): y ~ x
         chk = np.empty(4096, np.complex64)
         _lib.check(lib.nxsig_download(ctx.handle, chk.ctypes.data_as(C.c_void_p), C.c_void_p(y3.ptr + 8 * 100000), chk.nbytes))
@@ -167,14 +174,14 @@ def secondary_rooflines(ctx, lib, S, _lib, C):
         wp4 = w4.ctypes.data_as(C.c_void_p)
         laps = measure(lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, wp4, C.byref(p4), C.c_void_p(z4.ptr), None, _lib.DEVICE)), 10, 15)
         out["roofline_stft2048"] = block("config 4 (one GPU's shard of 64 channels): stft N=2048 hop=512, 8 ch x 600 s @48 kHz", "k_stft_wave<1024, real-2x>",
-                                         B4 * M4 * (H4 * 4 + N4 * 8), laps, {"bytes_per_frame": H4 * 4 + N4 * 8, "frames_per_s": B4 * M4 / (float(np.mean(laps)) * 1e-3)})
+                                         B4 * M4 * (H4 * 4 + N4 * 8), laps, {"bytes_per_frame": H4 * 4 + N4 * 8, "frames_per_s": B4 * M4 / (float(np.mean(laps)) * 1e-3)}, "stft2048")
         z4.free()
         h = S.filters.firwin(257, [4000.0], sampling_rate=float(SR))
         y5 = ctx.empty((B4, L4), np.float32)
         hp = h.ctypes.data_as(C.c_void_p)
         laps = measure(lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, hp, 257, _lib.CONV_SAME, C.c_void_p(y5.ptr), _lib.DEVICE)), 10, 15)
         out["roofline_fir"] = block("config 5 (one GPU's shard): fir 257 taps :same (overlap-save), 8 ch x 600 s @48 kHz", "k_fir_wave<1024>",
-                                    B4 * L4 * 8, laps, {"bytes_per_sample": 8, "samples_per_s": B4 * L4 / (float(np.mean(laps)) * 1e-3)})
+                                    B4 * L4 * 8, laps, {"bytes_per_sample": 8, "samples_per_s": B4 * L4 / (float(np.mean(laps)) * 1e-3)}, "fir")
         x4.free()
         y5.free()
     except Exception as e:  # noqa: BLE001

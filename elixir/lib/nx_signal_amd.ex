@@ -338,7 +338,8 @@ defmodule NxSignalAMD do
     {{frame_length, frame_length - overlap_length, fft_length, pad_mode, lo, hi, scaling, sampling_rate * 1.0}, fft_length}
   end
 
-  defp istft_params!(shape, window, opts) do
+  @doc false
+  def istft_params!(shape, window, opts) do
     opts = Keyword.validate!(opts, [:fft_length, :overlap_length, :scaling, sampling_rate: 1000])
     {frame_length} = Nx.shape(window)
     overlap_length = opts[:overlap_length] || div(frame_length, 2)

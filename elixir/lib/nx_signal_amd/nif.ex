@@ -56,6 +56,9 @@ defmodule NxSignalAMD.NIF do
   def stft_sharded(_group, _x, _length, _batch, _window, _params, _axis, _gather),
     do: :erlang.nif_error(:nif_not_loaded)
 
+  def istft_sharded(_group, _z, _frames, _batch, _window, _params, _axis, _gather),
+    do: :erlang.nif_error(:nif_not_loaded)
+
   def fir_sharded(_group, _x, _length, _batch, _taps, _mode, _axis, _gather),
     do: :erlang.nif_error(:nif_not_loaded)
 end

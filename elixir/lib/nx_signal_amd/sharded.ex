@@ -46,6 +46,29 @@ defmodule NxSignalAMD.Sharded do
     if vec_axes == [], do: z, else: Nx.vectorize(z, vec_axes)
   end
 
+  @doc """
+  `NxSignal.istft/3` sharded over `group` by channels or by frame ranges (`axis: :frames`: every GPU recomputes the
+  `ceil(N / hop) - 1` halo frames in front of its range instead of exchanging partial overlap-add sums). Bit-identical to
+  the unsharded call. Options: istft's plus `axis:` and `gather:`.
+  """
+  def istft(group, %Nx.Tensor{} = data, window, opts \\ []) do
+    {shard_opts, istft_opts} = Keyword.split(opts, [:axis, :gather])
+    axis = Map.fetch!(@axes, shard_opts[:axis] || :channels)
+    gather = if shard_opts[:gather], do: 1, else: 0
+    vec_axes = data.vectorized_axes
+    flat = if vec_axes == [], do: data, else: Nx.devectorize(data, keep_names: false)
+    {params, _overlap, m, batch_shape} = NxSignalAMD.istft_params!(Nx.shape(flat), window, istft_opts)
+    z = flat |> Nx.as_type(:c64) |> Nx.to_binary()
+    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+
+    {:ok, y} =
+      NIF.istft_sharded(group, z, m, Tuple.product(batch_shape), w, params, axis, gather) |> NxSignalAMD.unwrap!()
+
+    out_len = m * elem(params, 1) + (elem(params, 0) - elem(params, 1))
+    y = Nx.from_binary(y, :c64) |> Nx.reshape(Tuple.insert_at(batch_shape, tuple_size(batch_shape), out_len))
+    if vec_axes == [], do: y, else: Nx.vectorize(y, vec_axes)
+  end
+
   @doc "FIR filtering (`NxSignalAMD.Filters.fir/3`) sharded over `group` by channels or by output-sample ranges."
   def fir(group, %Nx.Tensor{} = x, taps, opts \\ []) do
     opts = Keyword.validate!(opts, mode: :same, axis: :channels, gather: false)

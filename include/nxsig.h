@@ -318,6 +318,12 @@ int nxsig_shard_frames(int64_t num_frames, int32_t frame_length, int32_t hop, in
 int nxsig_shard_fir(int64_t length, int32_t num_taps, int32_t mode, int32_t parts, int32_t index, int64_t* n0, int64_t* n1,
                     int64_t* s0, int64_t* s1);
 
+/* iSTFT over frame ranges: member `index` keeps output samples [n0, n1) = [m0 hop, m1 hop) of its frame share (the last member
+ * also the tail up to M hop + N - hop) and needs input frames [f0, f1) = [m0 - (ceil(N / hop) - 1), m1) widened to multiples of
+ * 8 frames (the kernels' frame groups): the halo FRAMES are recomputed instead of exchanging partial overlap-add sums (pure) */
+int nxsig_shard_istft(int64_t num_frames, int32_t frame_length, int32_t hop, int32_t parts, int32_t index, int64_t* f0, int64_t* f1,
+                      int64_t* n0, int64_t* n1);
+
 /* file rendezvous on one node (pure host code): publish writes `bytes` bytes atomically (tmp file + rename), fetch polls
  * until the file exists, is complete and is younger than `max_age_s` seconds (stale files of earlier runs are ignored) */
 int nxsig_rendezvous_publish(const char* path, const void* data, size_t bytes);
@@ -365,6 +371,12 @@ int nxsig_group_allgather(nxsig_group* g, const void* const* send, const int64_t
 int nxsig_stft_sharded_f32(nxsig_group* g, const float* const* x, int64_t length, int32_t batch, int64_t batch_stride,
                            const float* window, const nxsig_stft_params* params, int32_t axis, int32_t gather,
                            nxsig_c64* const* z, int32_t mem);
+/* NxSignal.istft/3 (nxsig_istft_c64) sharded over the group; same conventions.  Channels axis: rows of z c64[batch][M][K] split.
+ * Frames axis: output sample ranges with halo frames (nxsig_shard_istft); DEVICE shards are dense c64[batch][f1 - f0][K] and
+ * c64[batch][n1 - n0].  The result equals the unsharded call bit for bit: every frame that touches a kept sample is present on
+ * the member that keeps it, and is added in the same order. */
+int nxsig_istft_sharded_c64(nxsig_group* g, const nxsig_c64* const* z, int64_t num_frames, int32_t batch, const float* window,
+                            const nxsig_stft_params* params, int32_t axis, int32_t gather, nxsig_c64* const* y, int32_t mem);
 /* FIR filtering (nxsig_fir_f32) sharded over the group; same conventions.  Channels axis: rows split.  Frames axis here
  * means OUTPUT SAMPLE ranges of every row with a (num_taps - 1)-sample input halo (nxsig_shard_fir). */
 int nxsig_fir_sharded_f32(nxsig_group* g, const float* const* x, int64_t length, int32_t batch, int64_t batch_stride,

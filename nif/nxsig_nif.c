@@ -734,6 +734,30 @@ static ERL_NIF_TERM nif_stft_sharded(ErlNifEnv* env, int argc, const ERL_NIF_TER
   return enif_make_tuple3(env, mk_atom(env, "ok"), enif_make_binary(env, &zb), enif_make_int64(env, m));
 }
 
+/* istft_sharded(group, z_bin, num_frames, batch, window_bin, params, axis, gather) -> {:ok, y_bin} */
+static ERL_NIF_TERM nif_istft_sharded(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  ErlNifBinary z, w, yb;
+  ErlNifSInt64 m;
+  int batch, axis, gather;
+  nxsig_stft_params p;
+  if (argc != 8 || !get_grp(env, argv[0], &g) || !enif_inspect_binary(env, argv[1], &z) || !enif_get_int64(env, argv[2], &m) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p) ||
+      !enif_get_int(env, argv[6], &axis) || !enif_get_int(env, argv[7], &gather))
+    return enif_make_badarg(env);
+  if (batch < 1 || m < 1 || p.fft_length < 1 || z.size % 8 || z.size / 8 / (size_t)batch / (size_t)m != (size_t)p.fft_length ||
+      z.size / 8 % ((size_t)batch * (size_t)m) || w.size != (size_t)p.frame_length * 4)
+    return enif_make_badarg(env);
+  int64_t n = nxsig_ola_length(m, p.frame_length, p.hop);
+  if (n < 0) return mk_error(env, (int)n);
+  if (!out_bin(&yb, (uint64_t)batch, (uint64_t)n, 1, 8)) return mk_oom(env);
+  const nxsig_c64* zs[64] = {(const nxsig_c64*)z.data};
+  nxsig_c64* ys[64] = {(nxsig_c64*)yb.data};
+  int rc = nxsig_istft_sharded_c64(g->grp, zs, m, batch, (const float*)w.data, &p, axis, gather, ys, NXSIG_HOST);
+  if (rc) { enif_release_binary(&yb); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &yb));
+}
+
 /* fir_sharded(group, x_bin, length, batch, taps_bin, mode, axis, gather) -> {:ok, y_bin} */
 static ERL_NIF_TERM nif_fir_sharded(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   grp_res_t* g;
@@ -800,6 +824,7 @@ static ErlNifFunc funcs[] = {
     {"group_create", 1, nif_group_create, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"group_info", 1, nif_group_info, 0},
     {"stft_sharded", 8, nif_stft_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"istft_sharded", 8, nif_istft_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir_sharded", 8, nif_fir_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 

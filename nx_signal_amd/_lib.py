@@ -103,6 +103,7 @@ SIGNATURES = {
     # multi-GPU groups
     "nxsig_shard_range": (C.c_int, [_i64, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
     "nxsig_shard_frames": (C.c_int, [_i64, _i32, _i32, _i32, _i32] + [C.POINTER(_i64)] * 4),
+    "nxsig_shard_istft": (C.c_int, [_i64, _i32, _i32, _i32, _i32] + [C.POINTER(_i64)] * 4),
     "nxsig_shard_fir": (C.c_int, [_i64, _i32, _i32, _i32, _i32] + [C.POINTER(_i64)] * 4),
     "nxsig_rendezvous_publish": (C.c_int, [C.c_char_p, _p, _sz]),
     "nxsig_rendezvous_fetch": (C.c_int, [C.c_char_p, _p, _sz, _i32, _i32]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     "nxsig_group_allreduce_f64": (C.c_int, [_p, C.POINTER(_f64), _i32, _i32]),
     "nxsig_group_allgather": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_i64), C.POINTER(_p)]),
     "nxsig_stft_sharded_f32": (C.c_int, [_p, C.POINTER(_p), _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _i32, C.POINTER(_p), _i32]),
+    "nxsig_istft_sharded_c64": (C.c_int, [_p, C.POINTER(_p), _i64, _i32, _p, C.POINTER(StftParams), _i32, _i32, C.POINTER(_p), _i32]),
     "nxsig_fir_sharded_f32": (C.c_int, [_p, C.POINTER(_p), _i64, _i32, _i64, _p, _i32, _i32, _i32, _i32, C.POINTER(_p), _i32]),
     "nxsig_stft_mel_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _p, _p, C.POINTER(_i64), _i32]),
 }

@@ -201,6 +201,30 @@ int nxsig_shard_fir(int64_t length, int32_t num_taps, int32_t mode, int32_t part
   NXSIG_API_END
 }
 
+int nxsig_shard_istft(int64_t num_frames, int32_t frame_length, int32_t hop, int32_t parts, int32_t index, int64_t* f0, int64_t* f1,
+                      int64_t* n0, int64_t* n1) {
+  NXSIG_API_BEGIN
+  if (!f0 || !f1 || !n0 || !n1) return set_error(NXSIG_ERR_INVALID_ARG, "shard_istft: null output");
+  if (frame_length < 1 || hop < 1 || hop > frame_length) return set_error(NXSIG_ERR_INVALID_ARG, "shard_istft: 1 <= hop <= frame_length required");
+  if (num_frames < 1) return set_error(NXSIG_ERR_INVALID_ARG, "shard_istft: num_frames must be >= 1");
+  int64_t m0, m1;
+  int rc = split(num_frames, parts, index, &m0, &m1);
+  if (rc) return rc;
+  const int64_t R = (frame_length + hop - 1) / hop;  // frames covering one output sample
+  // output samples [m0 hop, m1 hop) (the last member also takes the tail); sample n is covered by frames (n / hop - R, n / hop]
+  *n0 = m0 * hop;
+  *n1 = index == parts - 1 ? num_frames * hop + (frame_length - hop) : m1 * hop;
+  if (m1 <= m0 && index != parts - 1) { *f0 = *f1 = m0; *n1 = *n0; return NXSIG_OK; }
+  // the tuned kernels transform 2 / 4 / 8 consecutive frames in one complex FFT, groups starting at multiples of the group size:
+  // ranges aligned to 8 frames see every frame in the same group position as the unsharded call (identical rounding)
+  *f0 = m0 - (R - 1) > 0 ? ((m0 - (R - 1)) / 8) * 8 : 0;
+  *f1 = index == parts - 1 ? num_frames : ((m1 + 7) / 8) * 8;
+  if (*f1 > num_frames) *f1 = num_frames;
+  if (*f1 <= *f0) { *f1 = *f0; *n1 = *n0; }
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
 /* ------------------------------------------------------------------------------------------------ file rendezvous */
 int nxsig_rendezvous_publish(const char* path, const void* data, size_t bytes) {
   NXSIG_API_BEGIN
@@ -569,6 +593,63 @@ int nxsig_stft_sharded_f32(nxsig_group* grp, const float* const* x, int64_t leng
     return nxsig_stft_f32(mb.ctx, xd, q.in_len, (int32_t)q.rows, stride, window, p, static_cast<nxsig_c64*>(dst), nullptr, NXSIG_DEVICE);
   };
   return run_sharded(g, pl, reinterpret_cast<const void* const*>(x), batch_stride, axis, gather, reinterpret_cast<void* const*>(z), mem, compute);
+  NXSIG_API_END
+}
+
+int nxsig_istft_sharded_c64(nxsig_group* grp, const nxsig_c64* const* z, int64_t num_frames, int32_t batch, const float* window,
+                             const nxsig_stft_params* p, int32_t axis, int32_t gather, nxsig_c64* const* y, int32_t mem) {
+  NXSIG_API_BEGIN
+  if (!grp || !z || !window || !p || !y) return set_error(NXSIG_ERR_INVALID_ARG, "istft_sharded: null argument");
+  if (mem != NXSIG_HOST && mem != NXSIG_DEVICE) return set_error(NXSIG_ERR_INVALID_ARG, "mem must be NXSIG_HOST or NXSIG_DEVICE");
+  if (axis != NXSIG_SHARD_CHANNELS && axis != NXSIG_SHARD_FRAMES) return set_error(NXSIG_ERR_INVALID_ARG, "istft_sharded: bad axis");
+  if (batch < 1 || num_frames < 1) return set_error(NXSIG_ERR_INVALID_ARG, "istft_sharded: batch and num_frames must be >= 1");
+  const int N = p->frame_length, hop = p->hop, K = p->fft_length;
+  if (N < 1 || hop < 1 || hop > N || K != N) return set_error(NXSIG_ERR_INVALID_ARG, "istft_sharded: 1 <= hop <= frame_length == fft_length required");
+  const int64_t out_len = nxsig_ola_length(num_frames, N, hop);
+  if (out_len < 0) return (int)out_len;
+  Group* g = reinterpret_cast<Group*>(grp);
+  std::lock_guard<std::mutex> lock(g->mu);
+  // the spectrogram rides through the generic plan as rows of 2 K floats per frame
+  const int64_t fpf = (int64_t)K * 2;
+  Plan pl;
+  pl.rows_total = batch; pl.in_len_total = num_frames * fpf; pl.out_items_total = out_len; pl.item_bytes = 8;
+  pl.part.resize(g->world); pl.count.resize(g->world);
+  for (int r = 0; r < g->world; ++r) {
+    Part& q = pl.part[r];
+    int rc;
+    if (axis == NXSIG_SHARD_CHANNELS) {
+      int64_t c0, c1;
+      if ((rc = split(batch, g->world, r, &c0, &c1))) return rc;
+      q.row0 = c0; q.rows = c1 - c0; q.in0 = 0; q.in_len = num_frames * fpf; q.out0 = 0; q.out_len = out_len; q.out_start = 0;
+    } else {
+      int64_t f0, f1, n0, n1;
+      if ((rc = nxsig_shard_istft(num_frames, N, hop, g->world, r, &f0, &f1, &n0, &n1))) return rc;
+      q.row0 = 0; q.rows = batch; q.in0 = f0 * fpf; q.in_len = (f1 - f0) * fpf; q.out0 = n0; q.out_len = n1 - n0;
+      q.out_start = n0 - f0 * hop;  // first kept sample inside the member's local overlap-add
+    }
+    pl.count[r] = q.rows * q.out_len * pl.item_bytes;
+  }
+  auto compute = [&](Member& mb, const Part& q, const float* zd, int64_t /*stride: shards are dense c64[rows][frames][K]*/, void* dst) -> int {
+    const int64_t frames = q.in_len / fpf;
+    if (axis == NXSIG_SHARD_CHANNELS)
+      return nxsig_istft_c64(mb.ctx, reinterpret_cast<const nxsig_c64*>(zd), frames, (int32_t)q.rows, window, p, static_cast<nxsig_c64*>(dst), NXSIG_DEVICE);
+    // frame range: the local overlap-add of frames [f0, f1) reproduces the global one on the kept samples (every frame that
+    // touches them is present, in the same order); head and tail of the local result are partial sums and are dropped
+    const int64_t local_len = nxsig_ola_length(frames, N, hop);
+    void* tmp = nullptr;
+    int rc = nxsig_alloc(mb.ctx, (size_t)(q.rows * local_len) * 8, &tmp);
+    if (rc) return rc;
+    rc = nxsig_istft_c64(mb.ctx, reinterpret_cast<const nxsig_c64*>(zd), frames, (int32_t)q.rows, window, p, static_cast<nxsig_c64*>(tmp), NXSIG_DEVICE);
+    if (!rc) {
+      hipError_t e = hipMemcpy2DAsync(dst, (size_t)q.out_len * 8, static_cast<const char*>(tmp) + q.out_start * 8, (size_t)local_len * 8,
+                                      (size_t)q.out_len * 8, (size_t)q.rows, hipMemcpyDeviceToDevice, stream_of(mb));
+      if (e != hipSuccess) rc = set_error(NXSIG_ERR_HIP, std::string("istft_sharded: ") + hipGetErrorString(e));
+    }
+    const int rs = nxsig_sync(mb.ctx);  // the scratch result must outlive the copy
+    (void)nxsig_free(mb.ctx, tmp);
+    return rc ? rc : rs;
+  };
+  return run_sharded(g, pl, reinterpret_cast<const void* const*>(z), num_frames * fpf, axis, gather, reinterpret_cast<void* const*>(y), mem, compute);
   NXSIG_API_END
 }
 

@@ -55,6 +55,12 @@ def shard_frames(num_frames: int, frame_length: int, hop: int, world: int, rank:
     return _four(_lib.load().nxsig_shard_frames, int(num_frames), int(frame_length), int(hop), int(world), int(rank))
 
 
+def shard_istft(num_frames: int, frame_length: int, hop: int, world: int, rank: int):
+    """iSTFT over frame ranges: `rank` needs input frames [f0, f1) (its share plus ceil(N / hop) - 1 halo frames in front,
+    recomputed instead of exchanged, widened to multiples of 8 frames) and keeps output samples [n0, n1); returns (f0, f1, n0, n1)."""
+    return _four(_lib.load().nxsig_shard_istft, int(num_frames), int(frame_length), int(hop), int(world), int(rank))
+
+
 def shard_fir(length: int, num_taps: int, world: int, rank: int, mode: str = "same"):
     """Output range [n0, n1) of a FIR (convolution mode `mode`) owned by `rank` and the input span [s0, s1) (clamped to
     the signal) it needs: num_taps - 1 samples of halo split between history and look-ahead by the mode's offset."""
@@ -195,6 +201,70 @@ def stft_sharded(group: Group, data, window, axis: str = "channels", gather: boo
     _lib.check(lib.nxsig_stft_sharded_f32(group.handle, xs, L, B, L, w.ctypes.data_as(C.c_void_p), C.byref(p), ax,
                                           int(bool(gather)), zs, _lib.HOST))
     return z[0] if squeeze else z.reshape(x.shape[:-1] + (M, K))
+
+
+def istft_sharded(group: Group, data, window, axis: str = "channels", gather: bool = False, **opts):
+    """NxSignal.istft(data, window, **opts) sharded over `group`; equals the unsharded call bit for bit.
+
+    data: host array c64[channels, M, K] / [M, K] -> the assembled host signal c64[channels, out_len] / [out_len], or a list
+          with one DeviceBuffer per LOCAL member holding that member's dense input shard (rows [c0, c1), or frames [f0, f1) of
+          every row; see shard_channels / shard_istft) together with `num_frames=` and `batch=` of the whole tensor -> the
+          list of per-member output DeviceBuffers (shards, or full tensors with gather=True).
+    """
+    lib = _lib.load()
+    w = np.ascontiguousarray(window, dtype=np.float32)
+    num_frames = opts.pop("num_frames", None)
+    batch = opts.pop("batch", None)
+    N = int(w.shape[0])
+    o = {"fft_length": None, "overlap_length": None, "scaling": None, "sampling_rate": 1000}
+    unknown = [k for k in opts if k not in o]
+    if unknown:
+        raise _lib.ArgumentError(f"unknown keys {unknown} in istft options, the allowed keys are: {list(o)}")
+    o.update(opts)
+    overlap = N // 2 if o["overlap_length"] is None else int(o["overlap_length"])
+    if overlap >= N:
+        raise _lib.ArgumentError(f"overlap_length must be a number less than the window size {N}, got: {N}")
+    scal = {None: _lib.SCALE_NONE, "spectrum": _lib.SCALE_SPECTRUM, "psd": _lib.SCALE_PSD}
+    if o["scaling"] not in scal:
+        raise _lib.ArgumentError(f"invalid :scaling, expected one of :spectrum, :psd or nil, got: {o['scaling']!r}")
+    hop = N - overlap
+    p = _lib.StftParams(N, hop, N, 0, 0, 0, scal[o["scaling"]], 0, float(o["sampling_rate"] or 0.0))
+    ax = _AXES[axis]
+    n = group.local_count
+    if isinstance(data, (list, tuple)) and data and isinstance(data[0], DeviceBuffer):
+        if num_frames is None or batch is None:
+            raise _lib.ArgumentError("device shards need num_frames= and batch= of the whole tensor")
+        M = int(num_frames)
+        out_len = int(_lib.check(lib.nxsig_ola_length(M, N, hop)))
+        outs = []
+        for i, r in enumerate(group.ranks):
+            if gather:
+                shape = (batch, out_len)
+            elif ax == CHANNELS:
+                c0, c1 = shard_channels(batch, group.world, r)
+                shape = (c1 - c0, out_len)
+            else:
+                _, _, n0, n1 = shard_istft(M, N, hop, group.world, r)
+                shape = (batch, n1 - n0)
+            outs.append(group.contexts[i].empty(shape, np.complex64))
+        zs = (C.c_void_p * n)(*[C.c_void_p(d.ptr) for d in data])
+        ys = (C.c_void_p * n)(*[C.c_void_p(o_.ptr) for o_ in outs])
+        _lib.check(lib.nxsig_istft_sharded_c64(group.handle, zs, M, int(batch), w.ctypes.data_as(C.c_void_p), C.byref(p), ax,
+                                               int(bool(gather)), ys, _lib.DEVICE))
+        return outs
+    z = np.ascontiguousarray(data, dtype=np.complex64)
+    if z.ndim < 2 or z.shape[-1] != N:
+        raise _lib.ArgumentError("istft expects a tensor of shape {..., frames, frequencies} with fft_length == window length")
+    squeeze = z.ndim == 2
+    z3 = z.reshape((-1,) + z.shape[-2:])
+    B, M, _ = z3.shape
+    out_len = int(_lib.check(lib.nxsig_ola_length(M, N, hop)))
+    y = np.empty((B, out_len), np.complex64)
+    zs = (C.c_void_p * n)(*([z3.ctypes.data_as(C.c_void_p)] + [C.c_void_p(0)] * (n - 1)))
+    ys = (C.c_void_p * n)(*([y.ctypes.data_as(C.c_void_p)] + [C.c_void_p(0)] * (n - 1)))
+    _lib.check(lib.nxsig_istft_sharded_c64(group.handle, zs, M, B, w.ctypes.data_as(C.c_void_p), C.byref(p), ax, int(bool(gather)), ys,
+                                           _lib.HOST))
+    return y[0] if squeeze else y.reshape(z.shape[:-2] + (out_len,))
 
 
 def fir_sharded(group: Group, data, taps, mode: str = "same", axis: str = "channels", gather: bool = False):

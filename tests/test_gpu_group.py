@@ -158,6 +158,59 @@ def test_fir_shards(pair, mode):
     assert float(np.max(np.abs(got1 - ref)) / np.max(np.abs(ref))) < 1e-5
 
 
+@pytest.mark.parametrize("N,hop,M,scaling", [
+    (1024, 256, 61, None), (1024, 512, 40, "spectrum"), (1024, 1024, 9, None), (512, 128, 77, None), (2048, 512, 23, "psd"),
+    (256, 64, 130, None), (400, 160, 51, None), (96, 24, 45, None), (1024, 256, 3, None),
+])
+def test_istft_shards_equal_unsharded_bit_for_bit(pair, solo, N, hop, M, scaling):
+    """channels axis and frame ranges (halo FRAMES recomputed, partial overlap sums dropped): identical bits, host tensors and
+    dense device shards, with and without the assembly; 3 members over 2... frames fewer than members included"""
+    rng = np.random.default_rng(N + hop + M)
+    z = (rng.standard_normal((3, M, N)) + 1j * rng.standard_normal((3, M, N))).astype(np.complex64)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=16000, scaling=scaling)
+    full = S.istft(z, w, **opts)
+    sopts = {k: v for k, v in opts.items() if k != "fft_length"}
+    for gather in (False, True):
+        got = sharding.istft_sharded(pair, z, w, axis="channels", gather=gather, **sopts)
+        assert got.shape == full.shape and np.array_equal(bits(got), bits(full))
+        got1 = sharding.istft_sharded(pair, z[1], w, axis="frames", gather=gather, **sopts)
+        assert got1.shape == full[1].shape and np.array_equal(bits(got1), bits(full[1]))
+        got1 = sharding.istft_sharded(solo, z[1], w, axis="frames", gather=gather, **sopts)
+        assert np.array_equal(bits(got1), bits(full[1]))
+    got = sharding.istft_sharded(pair, z, w, axis="frames", **sopts)  # several rows, per-shard downloads
+    assert np.array_equal(bits(got), bits(full))
+    # dense device shards stay on their members
+    shards = []
+    for i, r in enumerate(pair.ranks):
+        f0, f1, n0, n1 = sharding.shard_istft(M, N, hop, pair.world, r)
+        shards.append(pair.contexts[i].to_device(np.ascontiguousarray(z[:, f0:f1, :])))
+    outs = sharding.istft_sharded(pair, shards, w, axis="frames", num_frames=M, batch=3, **sopts)
+    pos = 0
+    for i, r in enumerate(pair.ranks):
+        f0, f1, n0, n1 = sharding.shard_istft(M, N, hop, pair.world, r)
+        assert n0 == pos and outs[i].shape == (3, n1 - n0)
+        assert np.array_equal(bits(outs[i].numpy()), bits(full[:, n0:n1]))
+        pos = n1
+    assert pos == full.shape[-1]
+
+
+def test_istft_eight_frame_shards_of_a_long_stream():
+    g = sharding.Group.local(8, devices=[0] * 8)
+    try:
+        x = O.synth_signal(1024 + 256 * 999, seed=77)
+        w = S.windows.hann(1024)
+        z, _, _ = S.stft(x, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+        full = S.istft(z, w, overlap_length=768, sampling_rate=48000)
+        for gather in (False, True):
+            got = sharding.istft_sharded(g, z, w, axis="frames", gather=gather, overlap_length=768, sampling_rate=48000)
+            assert np.array_equal(bits(got), bits(full))
+        spans = [sharding.shard_istft(1000, 1024, 256, 8, r) for r in range(8)]
+        assert spans[0] == (0, 128, 0, 125 * 256) and spans[1][:2] == (120, 256) and spans[7][3] == 999 * 256 + 1024
+    finally:
+        g.close()
+
+
 def test_ranked_group_of_one():
     g = sharding.Group.ranked(world=1, rank=0, device=0, path="")
     try:

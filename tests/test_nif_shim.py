@@ -287,6 +287,10 @@ def test_sharded_calls_through_the_nif():
     h = S.filters.firwin(257, [4000.0], sampling_rate=48000)
     ok, yb = H.call("fir_sharded", g, x, 30000, 3, h, 1, 0, 0)
     assert np.array_equal(f32(yb).view(np.uint32), S.filters.fir(x, h).reshape(-1).view(np.uint32))
+    yfull = S.istft(z, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    for axis, gather in ((0, 0), (0, 1), (1, 0)):
+        ok, yb = H.call("istft_sharded", g, z, z.shape[1], 3, w, PARAMS, axis, gather)
+        assert np.array_equal(c64(yb).view(np.uint32), yfull.reshape(-1).view(np.uint32))
     ok, g1 = H.call("group_create", [0])
     assert H.call("group_info", g1) == (1, 1, 1)  # one GPU per member: RCCL communicator (ncclCommInitAll)
     ok, zb, m = H.call("stft_sharded", g1, x, 30000, 3, w, PARAMS, 0, 1)

@@ -72,6 +72,27 @@ def test_fir_shards():
                 assert np.allclose(np.concatenate(got), want, rtol=0, atol=1e-12), (taps, mode, world)
 
 
+def test_istft_frame_shards_reproduce_the_overlap_add():
+    """nxsig_shard_istft: kept sample ranges tile the output; the local overlap-add (oracle) of the member's frames, halo frames
+    included, equals the global one on the kept samples exactly (same frames, same order)"""
+    rng = np.random.default_rng(9)
+    for N, hop, M in ((16, 4, 37), (16, 16, 9), (12, 5, 20), (8, 2, 3), (32, 8, 100)):
+        z = (rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))).astype(np.complex64)
+        w = np.hanning(N + 1)[:N].astype(np.float32) + np.float32(0.05)
+        full = O.istft(z, w, overlap_length=N - hop, fft_length=N)
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for r in range(world):
+                f0, f1, n0, n1 = sharding.shard_istft(M, N, hop, world, r)
+                assert n0 == prev and 0 <= f0 <= f1 <= M
+                prev = n1
+                if n1 > n0:
+                    local = O.istft(z[f0:f1], w, overlap_length=N - hop, fft_length=N)
+                    k0 = n0 - f0 * hop
+                    assert np.array_equal(local[k0:k0 + (n1 - n0)].view(np.uint32), full[n0:n1].view(np.uint32)), (N, hop, M, world, r)
+            assert prev == full.shape[0]
+
+
 def _rdzv_reader(path, q):
     import ctypes as C
 

@@ -98,6 +98,79 @@ def test_fuzz_fir(seed):
         assert nerr(yr, ref) < 1e-5, (taps, L, mode, nerr(yr, ref))
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_fir_any_taps_offsets_and_slices(seed):
+    """every tap count (the block grid pads it), every output offset (the grid is phased to it), rows of odd lengths and odd
+    strides, and arbitrary slices of the full convolution through nxsig_fir_slice_f32 — against direct f64 convolution"""
+    import ctypes as C
+
+    from nx_signal_amd import _lib
+    rng = np.random.default_rng(7000 + seed)
+    taps = int(rng.integers(1, 1100)) if seed % 4 else int(rng.choice([33, 65, 129, 193, 257, 385, 513, 1025]))
+    L = int(rng.integers(max(taps, 2000), 160000))
+    B = int(rng.choice([1, 2, 3]))
+    x = rng.standard_normal((B, L)).astype(np.float32)
+    h = (rng.standard_normal(taps) / np.sqrt(taps)).astype(np.float32)
+    full = [O.direct_convolve_f64(x[b], h) for b in range(B)]
+    mode = ["full", "same", "valid"][rng.integers(3)]
+    y = S.filters.fir(x, h, mode=mode)
+    n = {"full": L + taps - 1, "same": L, "valid": L - taps + 1}[mode]
+    start = {"full": 0, "same": (taps - 1) // 2, "valid": taps - 1}[mode]
+    assert y.shape == (B, n)
+    for b in range(B):
+        assert nerr(y[b], full[b][start:start + n]) < 1e-5, (taps, L, mode)
+    # an arbitrary slice of the full convolution, device buffers, row stride larger than the length
+    ctx = S.default_context()
+    lib = _lib.load()
+    stride = L + int(rng.integers(0, 7))
+    xs = np.zeros((B, stride), np.float32)
+    xs[:, :L] = x
+    xd = ctx.to_device(xs)
+    o0 = int(rng.integers(0, L + taps - 2))
+    olen = int(rng.integers(1, min(L + taps - 1 - o0, 70000) + 1))
+    yd = ctx.empty((B, olen), np.float32)
+    _lib.check(lib.nxsig_fir_slice_f32(ctx.handle, C.c_void_p(xd.ptr), L, B, stride, h.ctypes.data_as(C.c_void_p), taps, o0, olen,
+                                       C.c_void_p(yd.ptr), _lib.DEVICE))
+    ys = yd.numpy()
+    for b in range(B):
+        ref = full[b][o0:o0 + olen]
+        assert float(np.max(np.abs(ys[b] - ref))) <= 1e-5 * max(float(np.max(np.abs(full[b]))), 1e-30), (taps, L, o0, olen)
+    xd.free()
+    yd.free()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_istft_filtered_and_direct_convolution(seed):
+    """the round's new entry points on random geometry: istft_filtered == multiply-then-istft (bits); convolve(method: :direct)
+    == the oracle's restatement (bits)"""
+    rng = np.random.default_rng(8000 + seed)
+    N = int(rng.choice([1024, 1024, 512, 256, 2048, 400, 96, 300]))
+    R = int(rng.choice([1, 2, 4, 8])) if N in (1024, 512, 256, 2048) else int(rng.choice([2, 3, 4]))
+    hop = max(N // R, 1)
+    M = int(rng.integers(1, 70))
+    B = int(rng.choice([1, 2, 5]))
+    z = (rng.standard_normal((B, M, N)) + 1j * rng.standard_normal((B, M, N))).astype(np.complex64)
+    hf = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
+    w = [S.windows.hann, S.windows.hamming, S.windows.blackman][rng.integers(3)](N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=8000, scaling=[None, "spectrum", "psd"][rng.integers(3)])
+    want = S.istft(S.spectrum_multiply(z, hf), w, **opts)
+    got = S.istft_filtered(z, hf, w, **opts)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, hop, M, B)
+    rank = int(rng.integers(1, 4))
+    s1 = tuple(int(v) for v in rng.integers(1, [400, 24, 9][rank - 1] + 1, size=rank))
+    s2 = tuple(int(v) for v in rng.integers(1, [60, 8, 4][rank - 1] + 1, size=rank))
+    mode = ["full", "same", "valid"][rng.integers(3)]
+    if mode == "valid" and not (all(a >= b for a, b in zip(s1, s2)) or all(a <= b for a, b in zip(s1, s2))):
+        mode = "same"
+    a = rng.standard_normal(s1).astype(np.float32)
+    b = rng.standard_normal(s2).astype(np.float32)
+    if seed % 3 == 0:
+        b = (b + 1j * rng.standard_normal(s2)).astype(np.complex64)
+    d = S.convolution.convolve(a, b, mode=mode)
+    e = O.convolve_direct(a, b, mode=mode)
+    assert d.shape == e.shape and np.array_equal(np.ascontiguousarray(d).view(np.uint32), np.ascontiguousarray(e).view(np.uint32)), (s1, s2, mode)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_fuzz_framing_and_ola(seed):
     rng = np.random.default_rng(4000 + seed)

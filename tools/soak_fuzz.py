@@ -12,7 +12,11 @@ import test_gpu_fuzz as F  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
-    fams = [F.test_fuzz_stft, F.test_fuzz_istft, F.test_fuzz_fir, F.test_fuzz_stft_long_rows_interior_edge_split, F.test_fuzz_fused_sinks, F.test_fuzz_istft_n400]
+    fams = [F.test_fuzz_stft, F.test_fuzz_istft, F.test_fuzz_fir, F.test_fuzz_stft_long_rows_interior_edge_split, F.test_fuzz_fused_sinks, F.test_fuzz_istft_n400,
+            F.test_fuzz_fir_any_taps_offsets_and_slices, F.test_fuzz_istft_filtered_and_direct_convolution]
+    only = os.environ.get("SOAK_ONLY")
+    if only:
+        fams = [f for f in fams if only in f.__name__]
     bad = 0
     t0 = time.time()
     for i in range(n):

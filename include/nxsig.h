@@ -206,7 +206,9 @@ int nxsig_convolve_direct(nxsig_ctx* ctx, const void* a, int32_t a_is_real, cons
  * FIR filtering: y = Convolution.convolve(x, h, method: :fft, mode:) for real 1-D x (per batch row) and
  * real taps h — lib/nx_signal/convolution.ex:252-329 as used by guides/filtering.livemd:126-128 —
  * computed by overlap-save block FFT convolution (the `Filters.fir` of BASELINE config 5; the reference
- * does one length-(L+K-1) FFT, results agree to fp32 rounding).
+ * does one length-(L+K-1) FFT, results agree to fp32 rounding).  Filters of any length: up to 1025 taps the tuned wave kernels,
+ * up to 4096 taps the generic overlap-save kernel, beyond that (impulse responses of seconds) one transform of
+ * next_pow2(length + num_taps - 1) <= 2^26 points per row like the reference.
  *   x f32[batch][length], h f32[num_taps] HOST, y f32[batch][nxsig_conv_length(length, num_taps, mode)]
  */
 int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,

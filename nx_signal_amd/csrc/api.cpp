@@ -173,7 +173,29 @@ int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
   if (!handled && (rc = launch_istft_generic(c, a))) return rc;
   return launch_istft_edge_fix(c, a, window_host);  // ill-conditioned edge samples recomputed in double
 }
+// filters longer than the overlap-save kernels take (> 4096 taps: impulse responses of seconds): one transform of
+// next_pow2(L + taps - 1) points per row, the way the reference's fftconvolve does it (lib/nx_signal/convolution.ex:252-329),
+// through the device-side fft_nd fold (four-step rows up to 2^26 points); the requested slice is copied out of the full result
+static int launch_fir_long(Ctx* c, const FirLaunch& a) {
+  const int64_t full = a.L + a.taps - 1;
+  if (full > ((int64_t)1 << 26))
+    return set_error(NXSIG_ERR_UNSUPPORTED, "fir: more than 4096 taps with length + taps - 1 > 2^26 is not supported");
+  const void* hd = nullptr;
+  int rc = ctx_table(c, 0xF17A95ull ^ ((uint64_t)a.taps << 24), a.h_host, (size_t)a.taps * sizeof(float), &hd);
+  if (rc) return rc;
+  void* tmp = nullptr;
+  if ((rc = ctx_scratch(c, 21, (size_t)full * sizeof(float), &tmp))) return rc;
+  const int64_t s1 = a.L, s2 = a.taps;
+  for (int32_t row = 0; row < a.batch; ++row) {
+    if ((rc = launch_fftconvolve_nd(c, a.x + (size_t)row * a.batch_stride, true, &s1, hd, true, &s2, 1, NXSIG_CONV_FULL, tmp, nullptr))) return rc;
+    NXSIG_HIP_TRY(hipMemcpyAsync(a.y + (size_t)row * a.out_len, static_cast<const float*>(tmp) + a.out_start, (size_t)a.out_len * sizeof(float),
+                                 hipMemcpyDeviceToDevice, c->stream));
+  }
+  return NXSIG_OK;
+}
+
 int launch_fir(Ctx* c, const FirLaunch& a) {
+  if (a.taps > 4096) return launch_fir_long(c, a);
   bool handled = false;
   int rc = launch_fir_wave(c, a, &handled);
   if (rc || handled) return rc;

@@ -357,3 +357,19 @@ def test_istft_4096_on_four_passes_of_the_1024_core(hop, scaling, M, batch):
     ys = S.istft(zs, w, **opts)
     core = slice(N, x.size - N) if x.size > 3 * N else slice(N // 2, N // 2 + 16)
     assert float(np.max(np.abs(ys.real[core] - x[core]))) < 1e-4 * max(1.0, float(np.max(np.abs(x))))
+
+
+@pytest.mark.parametrize("taps,L,mode", [(5000, 60000, "same"), (20000, 100000, "full"), (48000, 48000 * 4, "valid"), (4097, 9000, "same")])
+def test_fir_with_very_long_filters(taps, L, mode):
+    """more than 4096 taps (reverb-length impulse responses): one big transform per row like the reference's fftconvolve"""
+    from scipy import signal as ss
+    rng = np.random.default_rng(taps)
+    x = rng.standard_normal((2, L)).astype(np.float32)
+    h = (rng.standard_normal(taps) * np.exp(-np.arange(taps) / (taps / 6.0)) / np.sqrt(taps / 12.0)).astype(np.float32)
+    y = S.filters.fir(x, h, mode=mode)
+    for r in range(2):
+        ref = ss.fftconvolve(x[r].astype(np.float64), h.astype(np.float64), mode=mode)
+        assert y[r].shape == ref.shape
+        assert float(np.max(np.abs(y[r] - ref)) / np.max(np.abs(ref))) < 1e-5
+    yd = S.filters.fir(S.default_context().to_device(x), h, mode=mode)
+    assert np.array_equal(yd.numpy().view(np.uint32), y.view(np.uint32))

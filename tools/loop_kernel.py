@@ -1,3 +1,5 @@
+"""Keeps one kernel (fir | stft) running back to back for N seconds so that rocm-smi can be sampled beside it (tools only;
+profiles/r02/power_clocks.txt).  usage: python tools/loop_kernel.py fir 12 & sleep 5; rocm-smi --showclocks --showpower"""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())

@@ -43,7 +43,7 @@ __device__ __forceinline__ v2f cmul_c64_rounded(v2f a, v2f b) {
 // guides/filtering.livemd:141): a lane always loads the same 16 bins, so its 16 filter values sit in registers and the separate
 // read-modify-write pass over the spectrogram (16 KB of HBM traffic per frame on top of this kernel's 10) disappears.  (Keeping the
 // table in LDS to stay at 3 waves per SIMD was measured too: it spills 25 registers and runs 30 % slower than this form.)
-template <int K, int R, bool SCALE, int W, bool FILT = false>
+template <int K, int R, bool SCALE, int W, bool FILT = false, bool NTL = false>   // NTL: non-temporal loads of the spectrogram
 __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
   constexpr int P = K / 64;
   constexpr int R3 = K / 256;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
   auto issue_loads = [&](int64_t m) {
     const v2f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * K;  // clamped: frames past the end contribute zero
 #pragma unroll
-    for (int s = 0; s < P; ++s) r[s] = pz[64 * s];
+    for (int s = 0; s < P; ++s) r[s] = NTL ? __builtin_nontemporal_load(pz + 64 * s) : pz[64 * s];
   };
   v2f hv[FILT ? P : 1];
   if (FILT) {
@@ -695,8 +695,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       const float* p1 = a.x + (size_t)rw * a.batch_stride + (b1 * a.V - tm1) + 2 * lane;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        r1[q] = *reinterpret_cast<const v2f*>(p1 + 128 * q);
-        r2[q] = *reinterpret_cast<const v2f*>(p1 + a.V + 128 * q);
+        r1[q] = *reinterpret_cast<const v2f*>(p1 + 128 * q);   // default cache policy: the pair's blocks overlap and neighbours re-read
+        r2[q] = *reinterpret_cast<const v2f*>(p1 + a.V + 128 * q);   // the halo (non-temporal loads measured 0…-3 %)
       }
     };
     v2f zz[2][NQ];  // zz[par][q] = (x1[n], x2[n]), n = 2 lane + par + 128 q
@@ -895,9 +895,13 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   } else {
     a.twH = nullptr;
     const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8;
+    // the spectrogram is read once (5 % run halos aside): non-temporal loads, +2…5 % in interleaved A/B runs (NXSIG_ISTFT_NT_LOADS=0: off)
     if (s.filt) {
-      if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-      else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    } else if (env_int("NXSIG_ISTFT_NT_LOADS", 1)) {
+      if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, false, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, false, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     } else if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     else hipLaunchKernelGGL((k_istft_wave<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
   }

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_4k(IstftWaveArgs a) {
   auto issue_loads = [&](int64_t m) {
     const v4f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * (NF / 2);
 #pragma unroll
-    for (int s = 0; s < P; ++s) { ra[s] = pz[128 * s]; rb[s] = pz[128 * s + 1]; }
+    for (int s = 0; s < P; ++s) { ra[s] = pz[128 * s]; rb[s] = pz[128 * s + 1]; }   // (non-temporal loads measured -3 % here)
   };
   issue_loads(m_start);
   v4f ca[P], cb[P];
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_half(IstftWaveArgs a) {
     const v2f* p0 = zrow + (size_t)(m < last ? m : last) * NH;
     const v2f* p1 = zrow + (size_t)(m + 1 < last ? m + 1 : last) * NH;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { r0[q] = p0[64 * q]; r1[q] = p1[64 * q]; }
+    for (int q = 0; q < NQ; ++q) { r0[q] = __builtin_nontemporal_load(p0 + 64 * q); r1[q] = __builtin_nontemporal_load(p1 + 64 * q); }
   };
   v2f d[2 * NQ];
   auto combine = [&]() {
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
       const int64_t m = u * J + j;
       const v2f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * NJ;  // clamped: frames past the end contribute zero
 #pragma unroll
-      for (int s = 0; s < PJ; ++s) r[j][s] = pz[64 * s];
+      for (int s = 0; s < PJ; ++s) r[j][s] = __builtin_nontemporal_load(pz + 64 * s);
     }
   };
   v2f d[P];
@@ -577,12 +577,26 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_dbl(IstftWaveArgs a) {
       for (int qq = 0; qq < QS; ++qq) pend[i][e][qq] = v2f{0.f, 0.f};
 
   const v4f* zrow = reinterpret_cast<const v4f*>(a.z + (size_t)row * a.M * N2) + lane;
-  for (int64_t m = m_start; m < j1; ++m) {
-    // ---- load even / odd bins (k' = lane + 64 s): one 16-byte load per point pair
+  // even / odd bins (k' = lane + 64 s): one 16-byte load per point pair (non-temporal: the spectrogram is read once).  For
+  // R <= 4 the next frame's loads are in flight during the two cores; R = 8 has no registers left for that (7 pending
+  // segments) and loads at the top of the iteration.
+  constexpr bool PF = R <= 4;
+  v4f nv[P];
+  auto issue_loads = [&](int64_t m) {
     const v4f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * K;
+#pragma unroll
+    for (int s = 0; s < P; ++s) nv[s] = __builtin_nontemporal_load(pz + 64 * s);
+  };
+  if (PF) issue_loads(m_start);
+  for (int64_t m = m_start; m < j1; ++m) {
+    if (!PF) issue_loads(m);
     v2f de[P], dq[P];
 #pragma unroll
-    for (int s = 0; s < P; ++s) { const v4f v = pz[64 * s]; de[s] = v2f{v.x, v.y}; dq[s] = v2f{v.z, v.w}; }
+    for (int s = 0; s < P; ++s) { de[s] = v2f{nv[s].x, nv[s].y}; dq[s] = v2f{nv[s].z, nv[s].w}; }
+    if (PF) {
+      issue_loads(m + 1 < j1 ? m + 1 : m);  // unconditional prefetch keeps the loop branch-free
+      __builtin_amdgcn_sched_barrier(0);
+    }
     v2f ze[2][NQ], zo[2][NQ];
     wave_fft_core<K, true>(de, ze, xb, s_twB, s_twC, lane);
     wave_fft_core<K, true>(dq, zo, xb, s_twB, s_twC, lane);

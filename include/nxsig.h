@@ -99,6 +99,12 @@ const char* nxsig_last_error(void); /* thread-local, valid until the next call o
 int nxsig_device_name(nxsig_ctx* ctx, char* buf, size_t buflen);
 
 /* ---------------------------------------------------------------- memory / stream ----- */
+/* Device memory of the context's GPU through a caching allocator: nxsig_free parks the block (no hipFree, no device
+ * synchronisation) and a later nxsig_alloc of a similar size gets it back — a fresh 3.3 GB hipMalloc costs ~100 ms here, two
+ * hundred times the stft that fills it.  Reuse is ordered by the context's stream; callers that touch a buffer on another
+ * stream synchronise before freeing it.  The cache holds at most NXSIG_POOL_MAX_MB (default: a quarter of the device memory,
+ * 0 = no caching) and is emptied when an allocation fails.  Blocks belong to their context and die with it.  nxsig_free also
+ * accepts pointers from other HIP allocators (plain hipFree after the stream has drained). */
 int nxsig_alloc(nxsig_ctx* ctx, size_t bytes, void** dptr);
 int nxsig_free(nxsig_ctx* ctx, void* dptr);
 int nxsig_upload(nxsig_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);   /* synchronous */

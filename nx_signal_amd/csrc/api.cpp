@@ -365,6 +365,8 @@ void nxsig_ctx_destroy(nxsig_ctx* ctx) {
     for (auto& kv : c->twiddles) (void)hipFree(kv.second.ptr);
     for (auto& kv : c->tables) (void)hipFree(kv.second.ptr);
     for (auto& s : c->scratch) if (s) (void)hipFree(s);
+    for (auto& kv : c->pool_free) (void)hipFree(kv.second);
+    for (auto& kv : c->pool_live) (void)hipFree(kv.first);   // blocks the caller never returned die with their context
     (void)hipEventDestroy(c->ev_start);
     (void)hipEventDestroy(c->ev_stop);
     for (auto e : c->lap_events) (void)hipEventDestroy(e);
@@ -384,11 +386,45 @@ int nxsig_device_name(nxsig_ctx* ctx, char* buf, size_t buflen) {
   NXSIG_API_END
 }
 
+// ---- caching allocator (see Ctx::pool_free).  Blocks are rounded up to 2 MiB (256 B below 1 MiB) so that results of nearly equal
+// sizes share blocks; a cached block serves a request when it is at most 12.5 % + 2 MiB larger.
+static size_t pool_round(size_t bytes) {
+  if (bytes < 4) bytes = 4;
+  const size_t g = bytes < ((size_t)1 << 20) ? 256 : ((size_t)2 << 20);
+  return (bytes + g - 1) / g * g;
+}
+static void pool_trim(Ctx* c, size_t keep) {   // releases cached blocks, largest first, until at most `keep` bytes stay cached
+  if (c->pool_cached <= keep) return;
+  (void)hipStreamSynchronize(c->stream);
+  while (c->pool_cached > keep && !c->pool_free.empty()) {
+    auto it = std::prev(c->pool_free.end());
+    (void)hipFree(it->second);
+    c->pool_cached -= it->first;
+    c->pool_free.erase(it);
+  }
+}
+
 int nxsig_alloc(nxsig_ctx* ctx, size_t bytes, void** dptr) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
   if (!dptr) return set_error(NXSIG_ERR_INVALID_ARG, "dptr is null");
-  NXSIG_HIP_TRY(hipMalloc(dptr, bytes ? bytes : 4));
+  const size_t need = pool_round(bytes);
+  auto it = c->pool_free.lower_bound(need);
+  if (it != c->pool_free.end() && it->first <= need + need / 8 + ((size_t)2 << 20)) {
+    *dptr = it->second;
+    c->pool_live[it->second] = it->first;
+    c->pool_cached -= it->first;
+    c->pool_free.erase(it);
+    return NXSIG_OK;
+  }
+  hipError_t e = hipMalloc(dptr, need);
+  if (e != hipSuccess && !c->pool_free.empty()) {  // out of memory with blocks parked in the cache: give them back and retry
+    (void)hipGetLastError();
+    pool_trim(c, 0);
+    e = hipMalloc(dptr, need);
+  }
+  NXSIG_HIP_TRY(e);
+  c->pool_live[*dptr] = need;
   return NXSIG_OK;
   NXSIG_API_END
 }
@@ -397,8 +433,28 @@ int nxsig_free(nxsig_ctx* ctx, void* dptr) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
   if (!dptr) return NXSIG_OK;
-  NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
-  NXSIG_HIP_TRY(hipFree(dptr));
+  auto it = c->pool_live.find(dptr);
+  if (it == c->pool_live.end()) {  // not one of ours (or already released): plain free, after the stream has drained
+    NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+    NXSIG_HIP_TRY(hipFree(dptr));
+    return NXSIG_OK;
+  }
+  if (c->pool_cap == 0) {  // NXSIG_POOL_MAX_MB (0 disables caching); default: a quarter of the device memory
+    size_t free_b = 0, total_b = 0;
+    c->pool_cap = 1;
+    if (const char* v = std::getenv("NXSIG_POOL_MAX_MB")) c->pool_cap = (size_t)std::strtoull(v, nullptr, 10) << 20 | 1;
+    else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) c->pool_cap = total_b / 4 | 1;
+  }
+  const size_t sz = it->second;
+  c->pool_live.erase(it);
+  if (sz > c->pool_cap) {  // never cacheable
+    NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
+    NXSIG_HIP_TRY(hipFree(dptr));
+    return NXSIG_OK;
+  }
+  c->pool_free.emplace(sz, dptr);
+  c->pool_cached += sz;
+  pool_trim(c, c->pool_cap);
   return NXSIG_OK;
   NXSIG_API_END
 }

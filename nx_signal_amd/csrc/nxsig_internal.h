@@ -72,7 +72,7 @@ struct Ctx {
   // slots: 0 multi-stage temporaries, 1/2 host staging in/out, 3 wave-kernel dummy sink, 4 fused-path spectrum, 5 reduction cells,
   // 6-9 four-step / Bluestein rows, 10-12 fft_nd ping-pong, 13-15 n-D fftconvolve, 16 long-transform stft frames, 17-19 host staging of n-D calls
   void* scratch[24] = {};
-  size_t scratch_bytes[20] = {};
+  size_t scratch_bytes[24] = {};
   // per-K tables of the tuned wave kernels (pass-B / pass-C twiddles), built once
   struct WaveTables { const void* twB = nullptr; const void* twC = nullptr; const void* twI = nullptr;
                       const void* twBi = nullptr; const void* twCi = nullptr;    // ...i = conjugated (inverse transform)
@@ -86,6 +86,13 @@ struct Ctx {
   // memo of host-side derivations keyed by the content they derive from (filter spectrum of a tap vector, OLA normaliser
   // rows and edge-fix sample list of a window): a few machine words each, dropped together with `tables`
   std::map<uint64_t, std::vector<uint64_t>> memo;
+  // caching allocator behind nxsig_alloc / nxsig_free: freed blocks are kept (no hipFree, no device synchronisation) and handed
+  // out again to requests of a similar size.  A 3.3 GB hipMalloc costs ~100 ms on this platform — two hundred times the
+  // stft that fills it — so a caller that allocates its result per call (the Python mirror, the NIF's *_dev functions) would
+  // otherwise spend all its time in the allocator.  Reuse is ordered by the context's stream.
+  std::multimap<size_t, void*> pool_free;   // size -> block
+  std::map<void*, size_t> pool_live;        // blocks handed out by nxsig_alloc
+  size_t pool_cached = 0, pool_cap = 0;     // bytes sitting in pool_free; cap (0 = not yet decided)
 };
 
 int ctx_twiddles(Ctx* c, int K, const float2** out);

@@ -46,6 +46,26 @@ def main():
         t_total = (time.perf_counter() - t0) / n
         out[name] = {"host_issue_us": t_issue * 1e6, "sustained_us_per_call": t_total * 1e6}
     print(json.dumps({"case": "1 s mono 48 kHz, N=1024 hop=256 (184 frames), device-resident, via ctypes", **out}))
+    # the same through the Python mirror (option parsing, result allocation from the context's caching allocator, times / frequencies)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+    mirror = {
+        "stft(DeviceBuffer)": lambda: S.stft(xd, w, ctx=ctx, **opts),
+        "istft(DeviceBuffer)": lambda: S.istft(zd, w, ctx=ctx, **opts),
+        "fir(DeviceBuffer)": lambda: S.filters.fir(xd, h, mode="same"),
+        "stft(numpy) incl. PCIe": lambda: S.stft(x, w, ctx=ctx, **opts),
+    }
+    out2 = {}
+    for name, fn in mirror.items():
+        for _ in range(20):
+            fn()
+        ctx.sync()
+        n = 500
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        ctx.sync()
+        out2[name] = {"us_per_call": (time.perf_counter() - t0) / n * 1e6}
+    print(json.dumps({"case": "the same calls through the Python mirror (result buffers allocated per call)", **out2}))
 
 
 if __name__ == "__main__":

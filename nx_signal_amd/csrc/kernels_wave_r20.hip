@@ -348,7 +348,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   if (sink == kSinkMel) return launch_mel_finish(c, mel->out, (int64_t)s.batch * s.fr.M * mel->mel_bins, b.gmax);
   if (sink == kSinkMag && mel->mag_kind == 2) {
     const int64_t n = (int64_t)s.batch * s.fr.M * (KB / 2);
-    hipLaunchKernelGGL(k_mag_db_pass2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, mel->out, n, b.gmax);
+    hipLaunchKernelGGL(k_mag_db_pass2, dim3(mag_db_blocks(c, n)), dim3(256), 0, c->stream, mel->out, n, b.gmax);
     NXSIG_HIP_TRY(hipGetLastError());
   }
   return NXSIG_OK;

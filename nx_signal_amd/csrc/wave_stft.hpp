@@ -788,14 +788,26 @@ __global__ __launch_bounds__(64 * W) void k_stft_mag_wave(MelWaveArgs m) {
 }
 
 // dBFS of a magnitude spectrogram (guides/spectrogram.livemd:88-90): 20 * log(|s| / max|s|) / log(10), f32 steps
+static unsigned mag_db_blocks(const Ctx* c, int64_t n) {
+  const int64_t want = ((n >> 2) + 255) / 256, cap = (int64_t)c->num_cus * 32;
+  return (unsigned)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+__device__ __forceinline__ float mag_to_db(float v, float mx) {
+  const float l = logf(v / mx);  // <= 1 ulp from the correctly rounded double log the reference takes
+  return (20.0f * l) / 2.3025851f;
+}
+// in place, 16 bytes per lane (the buffer is a whole number of rows of fft_length / 2 floats; n4 = n / 4, the tail is scalar)
 static __global__ __launch_bounds__(256) void k_mag_db_pass2(float* __restrict__ out, int64_t n, const int* __restrict__ gmax) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   const int g = *gmax;
   const float mx = __int_as_float(g >= 0 ? g : g ^ 0x7fffffff);
-  const float r = out[i] / mx;
-  const float l = logf(r);  // <= 1 ulp from the correctly rounded double log the reference takes
-  out[i] = (20.0f * l) / 2.3025851f;
+  const int64_t n4 = n >> 2;
+  v4f* o4 = reinterpret_cast<v4f*>(out);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    v4f v = o4[i];
+    v = v4f{mag_to_db(v.x, mx), mag_to_db(v.y, mx), mag_to_db(v.z, mx), mag_to_db(v.w, mx)};
+    __builtin_nontemporal_store(v, (gv4f*)(o4 + i));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const int64_t i = (n4 << 2) + threadIdx.x; out[i] = mag_to_db(out[i], mx); }
 }
 
 // ============================================================================================ Bluestein on the wave core
@@ -1192,7 +1204,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     }
     if (mel->mag_kind == 2) {
       const int64_t n = (int64_t)s.batch * s.fr.M * (KOUT / 2);
-      hipLaunchKernelGGL(k_mag_db_pass2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, mel->out, n, m.gmax);
+      hipLaunchKernelGGL(k_mag_db_pass2, dim3(mag_db_blocks(c, n)), dim3(256), 0, c->stream, mel->out, n, m.gmax);
       NXSIG_HIP_TRY(hipGetLastError());
     }
     return NXSIG_OK;
@@ -1370,7 +1382,7 @@ static int launch_blue_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = 
   if (sink == kSinkMel) return launch_mel_finish(c, mel->out, (int64_t)s.batch * s.fr.M * mel->mel_bins, b.gmax);
   if (mel->mag_kind == 2) {
     const int64_t n = (int64_t)s.batch * s.fr.M * (s.K / 2);
-    hipLaunchKernelGGL(k_mag_db_pass2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, mel->out, n, b.gmax);
+    hipLaunchKernelGGL(k_mag_db_pass2, dim3(mag_db_blocks(c, n)), dim3(256), 0, c->stream, mel->out, n, b.gmax);
     NXSIG_HIP_TRY(hipGetLastError());
   }
   return NXSIG_OK;

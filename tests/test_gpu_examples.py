@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("script,needles", [
     ("filtering_guide.py", ["istft_filtered == multiply-then-istft bit for bit: True", "times / frequencies identical: True"]),
     ("spectrogram_guide.py", ["peak bins at [431, 991] Hz", "mel_spectrogram 128 bands (fused)"]),
+    ("sharded_groups.py", ["identical to the unsharded call: True", "taps :same sharded by channels (64, 960000); identical: True",
+                           "sharded istft identical to unsharded: True"]),
 ])
 def test_guide_examples_run_and_check_themselves(script, needles):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)], capture_output=True, text=True, timeout=600, cwd=ROOT)

@@ -471,9 +471,9 @@ int nxsig_upload(nxsig_ctx* ctx, void* dst_device, const void* src_host, size_t 
 int nxsig_download(nxsig_ctx* ctx, void* dst_host, const void* src_device, size_t bytes) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
-  NXSIG_HIP_TRY(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, c->stream));
-  NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
-  return NXSIG_OK;
+  if (!dst_host || !src_device) return set_error(NXSIG_ERR_INVALID_ARG, "download: null pointer");
+  Staged st(c);  // large results: chunked copy with the next chunk's pages pre-faulted (freshly allocated destinations)
+  return st.out_copy(dst_host, src_device, bytes);
   NXSIG_API_END
 }
 

@@ -43,7 +43,7 @@ def main():
     zl = sharding.stft_sharded(g, long, w1, axis="frames", gather=True, **o1)
     yl = sharding.istft_sharded(g, zl, w1, axis="frames", gather=True, overlap_length=768, sampling_rate=48000)
     zf, _, _ = S.stft(long, w1, **o1)
-    print(f"120 s stream by frame ranges: stft {zl.shape} max diff vs unsharded {float(np.max(np.abs(zl - zf))):.1e}; istft round trip err on the interior "
+    print(f"120 s stream by frame ranges: stft {zl.shape} normalised err vs unsharded {float(np.max(np.abs(zl - zf)) / np.max(np.abs(zf))):.1e}; istft round trip err on the interior "
           f"{float(np.max(np.abs(yl.real[1024:-1024] - long[1024:len(yl) - 1024]))):.1e}; sharded istft identical to unsharded: "
           f"{np.array_equal(yl.view(np.uint32), S.istft(zl, w1, overlap_length=768, sampling_rate=48000).view(np.uint32))}")
     g.close()

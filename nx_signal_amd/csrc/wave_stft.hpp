@@ -330,6 +330,7 @@ struct WaveArgs {
   int64_t units_per_row;      // k_stft_wave: units of each row covered by this launch (interior or edge set)
   int64_t u_split, u_add0, u_add1;  // unit u of the launch is unit-in-row u + (u < u_split ? u_add0 : u_add1)
   int64_t chunk;              // units per workgroup (contiguous)
+  int64_t xcd_span = 0;       // > 0: workgroup b takes chunk (b % 8) * xcd_span + b / 8 (consecutive chunks on one XCD); 0: chunk b
   const float* wtab;          // device f32[fft_length]: window zero-padded / truncated to the fft length
   const v2f* twB;             // device c64[16][16]: w_256^(t k)
   const v2f* twC;             // device c64[R3][256]: w_C^(t i)
@@ -467,7 +468,10 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
     __builtin_nontemporal_store(v, (gv2f*)rowp);
   };
 
-  const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
+  // the dispatcher deals workgroups round-robin over the 8 XCDs (each with its own L2): with xcd_span set, an XCD walks ONE
+  // contiguous eighth of the chunks, so the input a chunk shares with its neighbour (frame overlap at the seam) is in its L2
+  const int64_t chunk_id = a.xcd_span > 0 ? (int64_t)(blockIdx.x & 7) * a.xcd_span + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+  const int64_t p_begin = chunk_id * a.chunk;
   int64_t p_end = p_begin + a.chunk;
   if (p_end > a.total_pairs) p_end = a.total_pairs;
 
@@ -1154,7 +1158,9 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     a.chunk = (split < ((int64_t)1 << 61)) ? W : chunk_main;
     a.units_per_row = upr; a.u_split = split; a.u_add0 = add0; a.u_add1 = add1;
     a.total_pairs = upr * s.batch;
-    const int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
+    int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
+    a.xcd_span = 0;
+    if (env_int("NXSIG_XCD_REMAP", 0) && blocks >= 64) { a.xcd_span = (blocks + 7) / 8; blocks = a.xcd_span * 8; }
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -80,6 +80,33 @@ defmodule NxSignalAMD do
      Nx.from_binary(f, :f32) |> Nx.reshape({fft_length}, names: [:frequencies])}
   end
 
+  @doc """
+  Extension (not in the reference API): `stft/3` on a device tensor restricted to the bins `0 .. fft_length/2 - 1` — the slice
+  the reference's own downstream code keeps for real signals (`stft_to_mel/3`, the spectrogram guide) — written straight from
+  the transform: half the output traffic, the same bits as the first half of `stft/3`'s rows.
+  """
+  def stft_onesided(%DeviceTensor{type: {:f, 32}} = data, window, opts) do
+    {params, fft_length} = stft_params!(window, opts)
+    {batch_shape, length} = split_last(data.shape)
+    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+
+    {:ok, zref, m} =
+      NIF.stft_onesided_dev(data.ctx, data.ref, length, Tuple.product(batch_shape), w, params) |> unwrap!()
+
+    {t, f} = times_and_frequencies(params, m)
+    half = div(fft_length, 2)
+
+    z = %DeviceTensor{
+      ref: zref,
+      ctx: data.ctx,
+      shape: append(batch_shape, [m, half]),
+      type: {:c, 64},
+      names: List.duplicate(nil, tuple_size(batch_shape)) ++ [:frames, :frequencies]
+    }
+
+    {z, t, Nx.slice(f, [0], [half])}
+  end
+
   @doc "See `NxSignal.istft/3`. Returns a c64 tensor of length `M * hop + overlap_length` (complex, like the reference)."
   def istft(data, window, opts)
 

@@ -252,6 +252,15 @@ int nxsig_stft_mel_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t b
                        float* out, int64_t* num_frames_out, int32_t mem);
 
 /*
+ * One-sided complex spectrum (opt-in; not in the reference API): the bins 0 .. fft_length/2 - 1 of NxSignal.stft/3 —
+ * the slice the reference's own downstream code keeps for real signals (stft_to_mel: lib/nx_signal.ex:493-496; the spectrogram
+ * guide: guides/spectrogram.livemd:80-82) — written straight from the transform: 4 KB per frame instead of 8 at fft_length 1024,
+ * identical bits to the first half of nxsig_stft_f32's rows.  out c64[batch][M][fft_length / 2].
+ */
+int nxsig_stft_onesided_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* window,
+                            const nxsig_stft_params* params, nxsig_c64* out, int64_t* num_frames_out, int32_t mem);
+
+/*
  * Magnitude spectrogram fused with the STFT (opt-in, not in the reference API): what
  * guides/spectrogram.livemd:76-92 computes from NxSignal.stft/3 — Nx.abs(s) of the bins below fft_length / 2, optionally
  * as dBFS 20 * log(|s| / reduce_max|s|) / log(10) — without writing the complex spectrum to HBM: fft_length * 2 bytes per

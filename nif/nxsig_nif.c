@@ -584,6 +584,31 @@ static ERL_NIF_TERM nif_stft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
   return enif_make_tuple3(env, mk_atom(env, "ok"), make_buf(env, c, z, zbytes), enif_make_int64(env, m));
 }
 
+/* stft_onesided_dev(ctx, x_buf, length, batch, window_bin, params) -> {:ok, z_buf, num_frames}   (bins 0 .. fft_length/2 - 1 only: c64[batch][M][fft_length / 2]) */
+static ERL_NIF_TERM nif_stft_onesided_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  buf_res_t* x;
+  ErlNifBinary w;
+  ErlNifSInt64 length;
+  int batch;
+  nxsig_stft_params p;
+  if (argc != 6 || !get_ctx(env, argv[0], &c) || !get_buf(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p))
+    return enif_make_badarg(env);
+  if (p.fft_length < 2 || batch < 1 || length < 1 || x->owner != c || x->bytes / 4 / (size_t)batch < (size_t)length || w.size != (size_t)p.frame_length * 4)
+    return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
+  if (m < 0) return mk_error(env, (int)m);
+  size_t zbytes = 8;
+  if (!mul_size(&zbytes, (uint64_t)batch) || !mul_size(&zbytes, (uint64_t)m) || !mul_size(&zbytes, (uint64_t)(p.fft_length / 2))) return mk_oom(env);
+  void* z = NULL;
+  int rc = nxsig_alloc(c->ctx, zbytes, &z);
+  if (rc) return mk_error(env, rc);
+  rc = nxsig_stft_onesided_f32(c->ctx, (const float*)x->dptr, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)z, NULL, NXSIG_DEVICE);
+  if (rc) { nxsig_free(c->ctx, z); return mk_error(env, rc); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), make_buf(env, c, z, zbytes), enif_make_int64(env, m));
+}
+
 /* istft_dev(ctx, z_buf, num_frames, batch, window_bin, params) -> {:ok, y_buf} */
 static ERL_NIF_TERM nif_istft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
@@ -817,6 +842,7 @@ static ErlNifFunc funcs[] = {
     {"from_device", 1, nif_from_device, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"buf_size", 1, nif_buf_size, 0},
     {"stft_dev", 6, nif_stft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_onesided_dev", 6, nif_stft_onesided_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_dev", 6, nif_istft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_filtered_dev", 7, nif_istft_filtered_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir_dev", 6, nif_fir_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},

@@ -27,7 +27,7 @@ from .device import Context, DeviceBuffer, default_context, device_view, is_devi
 
 __all__ = [
     "stft", "istft", "as_windowed", "overlap_and_add", "fft_frequencies", "mel_filters", "stft_to_mel", "mel_spectrogram",
-    "spectrum_multiply", "istft_filtered", "spectrogram",
+    "spectrum_multiply", "istft_filtered", "stft_onesided", "spectrogram",
     "Context", "DeviceBuffer", "default_context", "ArgumentError",
     "NxSignalDeviceError", "NxSignalLibraryError", "NxSignalUnsupported",
 ]
@@ -200,12 +200,28 @@ def stft(data, window, ctx: Context | None = None, **opts):
     on another stream (e.g. torch's current stream) must be complete before the call, and the result must not be consumed on
     another stream before `ctx.sync()` — or hand the library that stream with `ctx.set_stream(ptr)`.
     """
+    return _stft(data, window, ctx, opts, False)
+
+
+def stft_onesided(data, window, ctx: Context | None = None, **opts):
+    """Extension (not in the reference API): `stft(data, window, **opts)` restricted to the bins 0 .. fft_length/2 - 1 — the slice
+    the reference's own downstream code keeps for real signals (stft_to_mel, lib/nx_signal.ex:493-496; the spectrogram guide) —
+    written straight from the transform (half the output traffic; the same bits as `stft(...)[0][..., :K // 2]`).
+    Returns (z c64[..., M, K // 2], times f32[M], frequencies f32[K // 2])."""
+    return _stft(data, window, ctx, opts, True)
+
+
+def _stft(data, window, ctx, opts, onesided):
     p, N, hop, K = _resolve_stft_opts(window, opts)
     w = _window_host(window)
     fs = float(p.sampling_rate)
     mode, lo, hi = p.pad_mode, p.pad_lo, p.pad_hi
     lib = _lib.load()
     M = C.c_int64()
+    Kout = K // 2 if onesided else K
+    if onesided and K < 2:
+        raise ArgumentError("stft_onesided: fft_length >= 2 required")
+    entry = lib.nxsig_stft_onesided_f32 if onesided else lib.nxsig_stft_f32
     if is_device(data):
         ptr, shape, dt = device_view(data)
         if dt != np.float32:
@@ -214,8 +230,8 @@ def stft(data, window, ctx: Context | None = None, **opts):
         L = shape[-1]
         batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
         m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
-        z = c.empty(shape[:-1] + (m, K), np.complex64)
-        _lib.check(lib.nxsig_stft_f32(c.handle, C.c_void_p(ptr), L, batch, L, _as_ptr(w), C.byref(p), C.c_void_p(z.ptr),
+        z = c.empty(shape[:-1] + (m, Kout), np.complex64)
+        _lib.check(entry(c.handle, C.c_void_p(ptr), L, batch, L, _as_ptr(w), C.byref(p), C.c_void_p(z.ptr),
                                       C.byref(M), _lib.DEVICE))
     else:
         x = _host_f32(data, "stft")
@@ -225,13 +241,13 @@ def stft(data, window, ctx: Context | None = None, **opts):
         L = x.shape[-1]
         batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
         m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
-        z = np.empty(x.shape[:-1] + (m, K), dtype=np.complex64)
-        _lib.check(lib.nxsig_stft_f32(c.handle, _as_ptr(x), L, batch, L, _as_ptr(w), C.byref(p), _as_ptr(z), C.byref(M),
+        z = np.empty(x.shape[:-1] + (m, Kout), dtype=np.complex64)
+        _lib.check(entry(c.handle, _as_ptr(x), L, batch, L, _as_ptr(w), C.byref(p), _as_ptr(z), C.byref(M),
                                       _lib.HOST))
     times = np.empty(m, dtype=np.float32)
     _lib.check(lib.nxsig_stft_times_f32(N, fs, m, _as_ptr(times)))
     freqs = fft_frequencies(fs, fft_length=K)
-    return z, times, freqs
+    return z, times, (freqs[:Kout] if onesided else freqs)
 
 
 def istft(data, window, ctx: Context | None = None, **opts):

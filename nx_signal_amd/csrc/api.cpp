@@ -1083,6 +1083,57 @@ int nxsig_stft_mel_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t b
   NXSIG_API_END
 }
 
+int nxsig_stft_onesided_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* window,
+                            const nxsig_stft_params* p, nxsig_c64* out, int64_t* num_frames_out, int32_t mem) {
+  NXSIG_API_BEGIN
+  if (!x || !window || !p || !out) return set_error(NXSIG_ERR_INVALID_ARG, "stft_onesided: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "stft_onesided: batch must be in [1, 65535]");
+  if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "stft_onesided: batch_stride < length");
+  if (p->fft_length < 2) return set_error(NXSIG_ERR_INVALID_ARG, "stft_onesided: fft_length >= 2 required");
+  rc = check_scaling(p->scaling);
+  if (rc) return rc;
+  Framing fr;
+  rc = make_framing(length, p->frame_length, p->hop, p->pad_mode, p->pad_lo, p->pad_hi, &fr);
+  if (rc) return rc;
+  if (num_frames_out) *num_frames_out = fr.M;
+  NXSIG_CHECK_CTX(ctx)
+  StftLaunch a;
+  a.fr = fr; a.batch = batch; a.batch_stride = batch_stride; a.K = p->fft_length;
+  a.has_scale = p->scaling != NXSIG_SCALE_NONE;
+  a.inv_scale_div = a.has_scale ? scaling_factor(window, p->frame_length, p->scaling, p->sampling_rate) : 1.0f;
+  rc = ctx_window(c, window, p->frame_length, p->fft_length, &a.window, &a.window_padK);
+  if (rc) return rc;
+  a.z = nullptr;
+  const int half = p->fft_length / 2;
+  const size_t obytes = (size_t)batch * fr.M * half * sizeof(float2);
+  Staged st(c);
+  float2* od = reinterpret_cast<float2*>(out);
+  if (mem == NXSIG_DEVICE) {
+    a.x = x;
+  } else {
+    const void* xd = nullptr; void* o2 = nullptr;
+    const size_t xbytes = ((size_t)(batch - 1) * batch_stride + length) * sizeof(float);
+    if ((rc = st.in(1, x, xbytes, &xd))) return rc;
+    if ((rc = st.out_alloc(2, obytes, &o2))) return rc;
+    a.x = reinterpret_cast<const float*>(xd); od = reinterpret_cast<float2*>(o2);
+  }
+  bool handled = false;
+  rc = launch_stft_mag_wave(c, a, 3 /* complex bins */, reinterpret_cast<float*>(od), &handled);
+  if (rc) return rc;
+  if (!handled) {  // two-step path: full spectrum in a scratch buffer, then the slice
+    void* zs = nullptr;
+    if ((rc = ctx_scratch(c, 4, (size_t)batch * fr.M * p->fft_length * sizeof(float2), &zs))) return rc;
+    a.z = reinterpret_cast<float2*>(zs);
+    if ((rc = launch_stft(c, a))) return rc;
+    if ((rc = launch_half_from_spectrum(c, a.z, (int64_t)batch * fr.M, p->fft_length, od))) return rc;
+  }
+  if (mem == NXSIG_DEVICE) return NXSIG_OK;
+  return st.out_copy(out, od, obytes);
+  NXSIG_API_END
+}
+
 int nxsig_stft_magnitude_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride,
                              const float* window, const nxsig_stft_params* p, int32_t kind, float* out,
                              int64_t* num_frames_out, int32_t mem) {

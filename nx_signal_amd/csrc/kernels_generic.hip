@@ -1115,6 +1115,26 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
   return NXSIG_OK;
 }
 
+// bins below K / 2 of every row (two-step form of the one-sided spectrum sink)
+__global__ __launch_bounds__(kThreads) void k_half_from_spectrum(const float2* __restrict__ z, int64_t rows, int32_t K, float2* __restrict__ out) {
+  const int half = K / 2;
+  const int64_t total = rows * half;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t r = i / half;
+    out[i] = z[(size_t)r * K + (i - r * half)];
+  }
+}
+int launch_half_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, float2* out) {
+  const int64_t total = rows * (K / 2);
+  if (total == 0) return NXSIG_OK;
+  int64_t blocks = (total + kThreads - 1) / kThreads;
+  const int64_t cap = (int64_t)c->num_cus * 32;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_half_from_spectrum, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, z, rows, K, out);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
 int launch_mag_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, int kind, float* out) {
   const int64_t total = rows * (K / 2);
   if (total == 0) return NXSIG_OK;

@@ -17,8 +17,12 @@ int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool
     case 256: return launch_wave<1024, kModeQuad, 4, 4, kSinkMag>(c, s, &mel);
     case 128: return launch_wave<1024, kModeQuad, 4, 8, kSinkMag>(c, s, &mel);
     case 2048: return launch_wave<1024, kModeReal2x, 4, 2, kSinkMag>(c, s, &mel);
-    case 4096: return launch_wave<2048, kModeReal2x, 4, 2, kSinkMag>(c, s, &mel);
+    case 4096:
+      if (kind == 3) return NXSIG_OK;  // the 2048-point core rounds a few bins differently when half its outputs are dead code:
+                                       // the one-sided form keeps its "same bits as stft" promise through the two-step path
+      return launch_wave<2048, kModeReal2x, 4, 2, kSinkMag>(c, s, &mel);
     default:
+      if (kind == 3) return NXSIG_OK;  // one-sided complex output: only the power-of-two front-ends above store it; the rest slice
       if (s.K == 400) {  // native 20 x 20 kernel
         bool h20 = false;
         int rc20 = launch_stft_r20(c, s, &h20, &mel);

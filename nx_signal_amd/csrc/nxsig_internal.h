@@ -146,6 +146,7 @@ struct FirLaunch {
   float* y;                    // device f32[batch][out_len]
 };
 int launch_fir(Ctx* c, const FirLaunch& a);
+int launch_half_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, float2* out);
 int launch_mag_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, int kind, float* out);
 int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool* handled);
 int launch_spectrum_mul(Ctx* c, const float2* z, int64_t rows, int32_t K, const float2* h_dev, float2* out);

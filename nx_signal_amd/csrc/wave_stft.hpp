@@ -381,7 +381,8 @@ struct MelWaveArgs {
   float ln10;
   float* out;                 // f32[batch][M][mel_bins] (log10 power, before the clamp pass) / f32[batch][M][fft_length/2] (MAG)
   int* gmax;
-  int32_t mag_kind;           // MAG sink: 0 = |X|, 1 = |X|^2, 2 = |X| with a running maximum (dBFS pass follows)
+  int32_t mag_kind;           // MAG sink: 0 = |X|, 1 = |X|^2, 2 = |X| with a running maximum (dBFS pass follows),
+                              // 3 = the complex bins themselves (one-sided spectrum: out is c64[...][fft_length / 2])
 };
 
 // ST (pair / real-2x front-ends, complex-spectrum sink, streaming kernel): cache policy of the spectrum stores.
@@ -677,9 +678,15 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
                 *reinterpret_cast<v2f*>(&mags[(2 * j) * KH + 2 * lane + 128 * q]) = pa2;
                 *reinterpret_cast<v2f*>(&mags[(2 * j + 1) * KH + 2 * lane + 128 * q]) = pb2;
               } else {
-                float* r0 = mp->out + ((size_t)crow * a.M + mA + 2 * j) * KH + 2 * lane + 128 * q;
-                if (mA + 2 * j < a.M) mag_store(r0, pa2);
-                if (mA + 2 * j + 1 < a.M) mag_store(r0 + KH, pb2);
+                if (mp->mag_kind == 3) {  // one-sided complex spectrum: two adjacent bins per 16-byte store
+                  v2f* c0 = reinterpret_cast<v2f*>(mp->out) + ((size_t)crow * a.M + mA + 2 * j) * KH + 2 * lane + 128 * q;
+                  if (mA + 2 * j < a.M) __builtin_nontemporal_store(xa, (gv4f*)c0);
+                  if (mA + 2 * j + 1 < a.M) __builtin_nontemporal_store(xbv, (gv4f*)(c0 + KH));
+                } else {
+                  float* r0 = mp->out + ((size_t)crow * a.M + mA + 2 * j) * KH + 2 * lane + 128 * q;
+                  if (mA + 2 * j < a.M) mag_store(r0, pa2);
+                  if (mA + 2 * j + 1 < a.M) mag_store(r0 + KH, pb2);
+                }
               }
             }
           } else if (ST > 0 && !GENERAL) {  // streaming kernel: "sc1 nt" stores through the two frames' row descriptors
@@ -746,9 +753,15 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
           *reinterpret_cast<v2f*>(&mags[KH + 2 * lane + 128 * q]) = pb2;
         }
       } else if (MAG) {
-        float* r0 = mp->out + ((size_t)crow * a.M + mA) * KH + 2 * lane + 128 * q;
-        mag_store(r0, v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w});
-        if (MODE == kModePair && haveB) mag_store(r0 + KH, v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w});
+        if (mp->mag_kind == 3) {  // one-sided complex spectrum: two adjacent bins per 16-byte store
+          v2f* c0 = reinterpret_cast<v2f*>(mp->out) + ((size_t)crow * a.M + mA) * KH + 2 * lane + 128 * q;
+          __builtin_nontemporal_store(xa, (gv4f*)c0);
+          if (MODE == kModePair && haveB) __builtin_nontemporal_store(xbv, (gv4f*)(c0 + KH));
+        } else {
+          float* r0 = mp->out + ((size_t)crow * a.M + mA) * KH + 2 * lane + 128 * q;
+          mag_store(r0, v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w});
+          if (MODE == kModePair && haveB) mag_store(r0 + KH, v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w});
+        }
       } else if (BUFST) {
         typedef int v4i __attribute__((ext_vector_type(4)));
         constexpr int AUX = ST == 1 ? 18 : 2;  // gfx940+ cache policy bits: 1 = sc0, 2 = nt, 16 = sc1

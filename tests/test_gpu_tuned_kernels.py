@@ -407,3 +407,23 @@ def test_freed_device_buffers_are_reused_not_reallocated():
         assert np.array_equal(z.numpy()[3, 1000].view(np.uint32), ref.view(np.uint32))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("K,N,hop,pad,scaling", [
+    (1024, 1024, 256, "valid", None), (1024, 1024, 512, "reflect", "spectrum"), (1024, 600, 200, "valid", None),
+    (512, 400, 160, "reflect", None), (512, 512, 128, "valid", "psd"), (256, 256, 64, "same", None), (128, 128, 32, "valid", None),
+    (2048, 2048, 512, "valid", None), (4096, 3000, 1000, "valid", "spectrum"),
+    (400, 400, 160, "valid", None), (1000, 1000, 250, "valid", None), (64, 64, 16, "valid", None), (8192, 8192, 2048, "valid", None),
+])
+def test_stft_onesided_equals_the_first_half_of_stft_bit_for_bit(K, N, hop, pad, scaling):
+    """the one-sided sink (tuned front-ends) and its two-step form (every other length): same bits as stft()[..., :K // 2]"""
+    rng = np.random.default_rng(K + N + hop)
+    x = rng.standard_normal((3, 30000 + 7)).astype(np.float32)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=K, sampling_rate=16000, window_padding=pad, scaling=scaling)
+    z, t, f = S.stft(x, w, **opts)
+    h, th, fh = S.stft_onesided(x, w, **opts)
+    assert h.shape == z.shape[:-1] + (K // 2,) and np.array_equal(th, t) and np.array_equal(fh, f[: K // 2])
+    assert np.array_equal(h.view(np.uint32), np.ascontiguousarray(z[..., : K // 2]).view(np.uint32))
+    hd, _, _ = S.stft_onesided(S.default_context().to_device(x), w, **opts)
+    assert np.array_equal(hd.numpy().view(np.uint32), h.view(np.uint32))

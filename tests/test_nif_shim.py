@@ -255,6 +255,10 @@ def test_device_resident_chain_through_the_nif(nctx):
     with pytest.raises(H.BadArg):
         H.call("istft_filtered_dev", nctx, zb3, m3, 1, w, PARAMS, hfft[:512])  # filter binary of the wrong size
     del zb3, yb2
+    ok, zh, mh = H.call("stft_onesided_dev", nctx, xb, 48000, 1, w, PARAMS)
+    ok, zhb = H.call("from_device", zh)
+    assert mh == m and np.array_equal(c64(zhb).reshape(m, 512).view(np.uint32), np.ascontiguousarray(z[:, :512]).view(np.uint32))
+    del zh
     ok, fy, n = H.call("fir_dev", nctx, xb, 48000, 1, S.filters.firwin(257, [4000.0], sampling_rate=48000), 1)
     ok, fo = H.call("from_device", fy)
     assert n == 48000 and np.array_equal(f32(fo).view(np.uint32), S.filters.fir(x, S.filters.firwin(257, [4000.0], sampling_rate=48000)).view(np.uint32))

@@ -162,6 +162,21 @@ def main():
             print(json.dumps({"case": f"magnitude spectrogram {kname} fused with the stft, N=1024 hop=256, 32 x 60 s", "ms": ms,
                               "frames_per_s": batch * M / (ms * 1e-3), "bytes_per_frame": bpf,
                               "algorithmic_GBps": batch * M * bpf / (ms * 1e-3) / 1e9}), flush=True)
+    if "onesided" in which:
+        N, hop, L, batch = 1024, 256, 2880000, 32
+        w = S.windows.hann(N)
+        M = (L - N) // hop + 1
+        xd = ctx.empty((batch, L), np.float32)
+        fill_normal(ctx, xd, (batch, L), 13)
+        od = ctx.empty((batch, M, N // 2), np.complex64)
+        p = _lib.StftParams(N, hop, N, 0, 0, 0, 0, 0, 48000.0)
+        wp = w.ctypes.data_as(C.c_void_p)
+        fn = lambda: _lib.check(lib.nxsig_stft_onesided_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(od.ptr), None, _lib.DEVICE))
+        ms = timeit(ctx, fn)
+        bpf = hop * 4 + (N // 2) * 8
+        print(json.dumps({"case": "one-sided complex spectrum (bins 0..K/2-1) fused with the stft, N=1024 hop=256, 32 x 60 s", "ms": ms,
+                          "frames_per_s": batch * M / (ms * 1e-3), "bytes_per_frame": bpf,
+                          "algorithmic_GBps": batch * M * bpf / (ms * 1e-3) / 1e9}), flush=True)
     for msname in ("melspeech", "melspeech400"):
       if msname in which:
           # ASR front-end: 25 ms frames / 10 ms hop at 16 kHz, 512-point (or n_fft = 400) FFT, centred (:reflect), 80 mel bands

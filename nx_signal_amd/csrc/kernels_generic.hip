@@ -865,8 +865,43 @@ int launch_istft_generic(Ctx* c, const IstftLaunch& s) {
   return NXSIG_OK;
 }
 
+// window lengths that are multiples of 4: a wave writes one frame at a time with 16-byte streaming stores (no index division:
+// lanes walk the frame in steps of 64 quads); frames whose samples all lie inside the signal read them directly
+__global__ __launch_bounds__(kThreads) void k_as_windowed_v4(const float* __restrict__ x, int64_t batch_stride, FrameGeom g, float* __restrict__ out) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) f4 gf4;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kThreads / 64);
+  const float* xr = x + (size_t)blockIdx.y * batch_stride;
+  float* orow = out + (size_t)blockIdx.y * g.M * g.N;
+  const int n4 = g.N / 4;
+  for (int64_t m = wave; m < g.M; m += nwaves) {
+    const int64_t q0 = m * g.hop - g.lo;                       // signal index of the frame's first sample
+    const bool inside = q0 >= 0 && q0 + g.N <= g.L;            // uniform per wave
+    f4* dst = reinterpret_cast<f4*>(orow + (size_t)m * g.N);
+    for (int j = lane; j < n4; j += 64) {
+      f4 v;
+      if (inside) { const float* p = xr + q0 + 4 * j; v = f4{p[0], p[1], p[2], p[3]}; }
+      else {
+        const int64_t q = m * g.hop + 4 * j;
+        v = f4{fetch_padded(xr, g, q), fetch_padded(xr, g, q + 1), fetch_padded(xr, g, q + 2), fetch_padded(xr, g, q + 3)};
+      }
+      __builtin_nontemporal_store(v, (gf4*)(dst + j));
+    }
+  }
+}
+
 int launch_as_windowed(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, const Framing& fr, float* out) {
   if (fr.M == 0 || batch == 0) return NXSIG_OK;
+  if (fr.N % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    int64_t blocks = (fr.M + kThreads / 64 - 1) / (kThreads / 64);
+    const int64_t cap = (int64_t)c->num_cus * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_as_windowed_v4, dim3((unsigned)blocks, (unsigned)batch), dim3(kThreads), 0, c->stream, x, batch_stride, to_geom(fr), out);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  }
   const int64_t total = fr.M * fr.N;
   dim3 grid((unsigned)((total + kThreads - 1) / kThreads), (unsigned)batch);
   hipLaunchKernelGGL(k_as_windowed, grid, dim3(kThreads), 0, c->stream, x, batch_stride, to_geom(fr), out);
@@ -874,10 +909,38 @@ int launch_as_windowed(Ctx* c, const float* x, int64_t batch_stride, int32_t bat
   return NXSIG_OK;
 }
 
+// real frames, hop and N multiples of 4: four consecutive outputs per thread (they share their covering frames), 16-byte loads
+// and stores, the same double accumulation in ascending frame order
+__global__ __launch_bounds__(kThreads) void k_ola_v4(const float* __restrict__ frames, int64_t M, int32_t N, int32_t hop,
+                                                    float* __restrict__ out, int64_t out_len) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) f4 gf4;
+  const int64_t n = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+  if (n >= out_len) return;   // out_len = M hop + N - hop is a multiple of 4
+  const float* fr = frames + (size_t)blockIdx.y * M * N;
+  int64_t m_hi = n / hop;
+  if (m_hi > M - 1) m_hi = M - 1;
+  int64_t m_lo = (n - N + hop) / hop;
+  if (n - N + 1 <= 0) m_lo = 0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (int64_t m = m_lo; m <= m_hi; ++m) {
+    const f4 v = *reinterpret_cast<const f4*>(fr + (size_t)m * N + (n - m * hop));
+    a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+  }
+  __builtin_nontemporal_store(f4{(float)a0, (float)a1, (float)a2, (float)a3}, (gf4*)(out + (size_t)blockIdx.y * out_len + n));
+}
+
 int launch_overlap_and_add(Ctx* c, const float* frames, int64_t M, int32_t batch, int32_t N, int32_t hop, int32_t comps,
                            float* out) {
   const int64_t out_len = M * hop + (N - hop);
   if (out_len == 0 || batch == 0) return NXSIG_OK;
+  if (comps == 1 && N % 4 == 0 && hop % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    // (a thread's 4 outputs n .. n+3 lie in the same hop segment and below the same frame ends, so they share m_lo .. m_hi)
+    dim3 grid((unsigned)((out_len / 4 + kThreads - 1) / kThreads), (unsigned)batch);
+    hipLaunchKernelGGL(k_ola_v4, grid, dim3(kThreads), 0, c->stream, frames, M, N, hop, out, out_len);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  }
   dim3 grid((unsigned)((out_len + kThreads - 1) / kThreads), (unsigned)batch);
   if (comps == 1)
     hipLaunchKernelGGL((k_ola<1, false>), grid, dim3(kThreads), 0, c->stream, frames, M, N, hop, nullptr, out, out_len);

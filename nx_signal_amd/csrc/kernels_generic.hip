@@ -612,19 +612,29 @@ struct MelArgs {
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-static constexpr int kMelFramesPerBlock = 4;
+static constexpr int kMelFramesPerBlock = 16;
 
+// 16 frames per workgroup: |z|^2 of the bins below K / 2 into LDS, then every thread owns one mel band for a subset of the frames
+// and walks the band ONCE, each filter weight loaded once and applied to all its frames (the first version re-read the weights
+// from L2 for every frame: 1.2 ms on 32 x 60 s, now 0.4).  Rounding as before: Nx.abs in double -> f32 -> squared in f32; the band
+// sum in double in ascending bin order, rounded once.
 __global__ __launch_bounds__(kThreads) void k_mel_pass1(MelArgs a) {
-  float* mags = reinterpret_cast<float*>(g_smem);  // [frames per block][half]
+  constexpr int FB = kMelFramesPerBlock;
+  float* mags = reinterpret_cast<float*>(g_smem);  // [FB][half]
   __shared__ int s_max;
   const int tid = threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * kMelFramesPerBlock;
+  const int64_t r0 = (int64_t)blockIdx.x * FB;
   if (tid == 0) s_max = f2ord(-3.0e38f);
-  for (int idx = tid; idx < kMelFramesPerBlock * a.half; idx += kThreads) {
+  // half is a multiple of kThreads for every power-of-two K >= 512 and the loop is uniform otherwise too: eight independent
+  // 8-byte loads in flight per thread
+  const int total = FB * a.half;
+#pragma unroll 8
+  for (int idx = tid; idx < total; idx += kThreads) {
     const int f = idx / a.half, k = idx - f * a.half;
     float m = 0.0f;
     if (r0 + f < a.rows) {
-      const float2 v = a.z[(size_t)(r0 + f) * a.K + k];
+      typedef float v2f_t __attribute__((ext_vector_type(2)));
+      const v2f_t v = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(a.z + (size_t)(r0 + f) * a.K + k));
       const float ab = (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);  // Nx.abs(c64) -> f32
       m = ab * ab;                                                                          // ** 2
     }
@@ -632,20 +642,32 @@ __global__ __launch_bounds__(kThreads) void k_mel_pass1(MelArgs a) {
   }
   __syncthreads();
   int lmax = f2ord(-3.0e38f);
-  for (int idx = tid; idx < kMelFramesPerBlock * a.mel_bins; idx += kThreads) {
-    const int f = idx / a.mel_bins, b = idx - f * a.mel_bins;
-    if (r0 + f >= a.rows) continue;
+  const int G = a.mel_bins >= kThreads ? 1 : kThreads / a.mel_bins;   // frame groups sharing the workgroup's threads
+  const int per = (FB + G - 1) / G;                                    // frames per thread (<= 16)
+  for (int t = tid; t < a.mel_bins * G; t += kThreads) {
+    const int b = t % a.mel_bins, g = t / a.mel_bins;
     const int2 rg = a.band[b];
     const float* fr = a.filt + (size_t)b * a.K;
-    const float* mg = mags + f * a.half;
-    double acc = 0.0;
-    for (int k = rg.x; k < rg.y; ++k) acc += (double)mg[k] * (double)fr[k];
-    float v = (float)acc;
-    v = v > 1.0e-10f ? v : 1.0e-10f;                       // Nx.clip(mel_spec, 1.0e-10, :infinity)
-    v = (float)log((double)v) / a.ln10;                    // Nx.log(.) / Nx.log(10)
-    a.out[(size_t)(r0 + f) * a.mel_bins + b] = v;
-    const int o = f2ord(v);
-    lmax = o > lmax ? o : lmax;
+    double acc[FB];
+#pragma unroll
+    for (int i = 0; i < FB; ++i) acc[i] = 0.0;
+    for (int k = rg.x; k < rg.y; ++k) {
+      const double w = (double)fr[k];
+#pragma unroll
+      for (int i = 0; i < FB; ++i)
+        if (i < per) acc[i] += (double)mags[(g + i * G) % FB * a.half + k] * w;   // frames g, g + G, ...: (index wraps only when unused)
+    }
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int f = g + i * G;
+      if (i >= per || f >= FB || r0 + f >= a.rows) continue;
+      float v = (float)acc[i];
+      v = v > 1.0e-10f ? v : 1.0e-10f;                       // Nx.clip(mel_spec, 1.0e-10, :infinity)
+      v = (float)log((double)v) / a.ln10;                    // Nx.log(.) / Nx.log(10)
+      a.out[(size_t)(r0 + f) * a.mel_bins + b] = v;
+      const int o = f2ord(v);
+      lmax = o > lmax ? o : lmax;
+    }
   }
   atomicMax(&s_max, lmax);
   __syncthreads();

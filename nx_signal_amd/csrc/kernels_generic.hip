@@ -616,7 +616,8 @@ static constexpr int kMelFramesPerBlock = 16;
 
 // 16 frames per workgroup: |z|^2 of the bins below K / 2 into LDS, then every thread owns one mel band for a subset of the frames
 // and walks the band ONCE, each filter weight loaded once and applied to all its frames (the first version re-read the weights
-// from L2 for every frame: 1.2 ms on 32 x 60 s, now 0.4).  Rounding as before: Nx.abs in double -> f32 -> squared in f32; the band
+// from L2 for every frame: 1.2 ms on 32 x 60 s, now 0.87; what remains is double-precision arithmetic — the band sums and one
+// libm-grade log per output — which the reference's rounding rule asks for; the fused sink of wave_stft.hpp is the fast path).  Rounding as before: Nx.abs in double -> f32 -> squared in f32; the band
 // sum in double in ascending bin order, rounded once.
 __global__ __launch_bounds__(kThreads) void k_mel_pass1(MelArgs a) {
   constexpr int FB = kMelFramesPerBlock;

@@ -453,7 +453,55 @@ def test_stft_config4_shard_full_size_beyond_4gb():
         _lib.check(lib.nxsig_download(ctx.handle, got.ctypes.data_as(C.c_void_p), C.c_void_p(zd.ptr + off), got.nbytes))
         ref, _, _ = O.stft(rows[c][m * hop: m * hop + N], w, **opts)
         assert_close(got, ref[0], f"channel {c} frame {m} (byte offset {off})")
+    # config 3's direction on the same 7.37 GB spectrum: the inverse reads byte offsets > 4 GiB; round-trip property
+    # (Hann, 75 % overlap: x is recovered wherever OLA(w^2) is fully covered) on spans sampled across every channel
+    yd = S.istft(zd, w, **opts)
+    Ly = (M - 1) * hop + N
+    assert yd.shape == (ch, Ly)
+    ctx.sync()
+    for c, s in [(0, N), (0, Ly - 2 * N - 4096), (3, 9_000_000), (4, 17_000_001), (6, 28_000_000), (7, Ly - 2 * N - 4096),
+                 (7, 5 * hop + 3)]:
+        got = np.empty(4096, np.complex64)
+        off = (c * Ly + s) * 8
+        _lib.check(lib.nxsig_download(ctx.handle, got.ctypes.data_as(C.c_void_p), C.c_void_p(yd.ptr + off), got.nbytes))
+        assert_close(got, rows[c][s: s + 4096].astype(np.complex64), f"round trip channel {c} sample {s}")
+    yd.free()
     zd.free()
+    xd.free()
+
+
+def test_fir_stream_beyond_4gb():
+    """FIR over more than 4 GiB of samples in one call (40 channels x 10 min @ 48 kHz = 4.6 GB in, 4.6 GB out; config 5's
+    filter): spans sampled across the whole output, including the last channel's end, vs direct convolution in double."""
+    import ctypes as C
+
+    from nx_signal_amd import _lib
+
+    ch, L, taps = 40, 28_800_000, 257
+    ctx = S.default_context()
+    lib = _lib.load()
+    base = O.synth_signal(L, seed=99)
+    h = S.filters.firwin(taps, [4000], sampling_rate=48000)
+    xd = ctx.empty((ch, L), np.float32)
+    assert xd.nbytes > 4 * 2**30
+    shifts = [(7_919 * c) % L for c in range(ch)]
+    for c in range(ch):
+        xr = np.roll(base, shifts[c])
+        _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(xd.ptr + c * L * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
+    yd = S.filters.fir(xd, h, mode="same")
+    assert yd.shape == (ch, L)
+    ctx.sync()
+    n = 8192
+    for c, s in [(0, 0), (0, L - n), (17, 1_234_567), (37, 14_400_001), (38, 31), (39, L - n), (39, 20_000_000)]:
+        got = np.empty(n, np.float32)
+        off = (c * L + s) * 4
+        _lib.check(lib.nxsig_download(ctx.handle, got.ctypes.data_as(C.c_void_p), C.c_void_p(yd.ptr + off), got.nbytes))
+        xr = np.roll(base, shifts[c])
+        lo, hi = max(0, s - 128), min(L, s + n + 128)
+        full = O.direct_convolve_f64(xr[lo:hi], h)  # full[j] = sum_k h[k] x[lo + j - k]; y[i] = full_of_row[i + 128]
+        j0 = s + 128 - lo
+        assert_close(got, full[j0: j0 + n].astype(np.float32), f"channel {c} sample {s} (byte offset {off})")
+    yd.free()
     xd.free()
 
 

@@ -638,6 +638,7 @@ __global__ __launch_bounds__(kThreads) void k_mel_pass1(MelArgs a) {
       const v2f_t v = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(a.z + (size_t)(r0 + f) * a.K + k));
       const float ab = (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);  // Nx.abs(c64) -> f32
       m = ab * ab;                                                                          // ** 2
+      if (!(m < INFINITY)) atomicOr(a.gmax + 1, 1);                                         // see k_mel_pass2
     }
     mags[idx] = m;
   }
@@ -675,13 +676,206 @@ __global__ __launch_bounds__(kThreads) void k_mel_pass1(MelArgs a) {
   if (tid == 0) atomicMax(a.gmax, s_max);
 }
 
+// The tiled form of pass 1 (every fft_length whose |z|^2 tile fits the LDS): FB = 64 / 32 / 16 / 8 frames per workgroup.
+//   phase 1  waves stream whole rows: lanes along the bins (512 B per load instruction), four rows in flight per wave;
+//            |z|^2 goes to LDS with an odd row stride
+//   phase 2  lane = frame: a wave walks one band (64 / FB bands when the tile has fewer than 64 frames) with the loop bounds
+//            uniform over the frames — no divergence between narrow and wide bands, the weight read once per 64 frames from a
+//            compact LDS copy of the non-zero filter entries, conflict-free |z|^2 reads (odd stride)
+//   phase 3  the [FB][mel_bins] result tile leaves as one contiguous, coalesced block
+// Same arithmetic and rounding as k_mel_pass1 (Nx.abs in double -> f32 -> squared in f32; band sum in double in ascending bin
+// order, rounded once; log in double) with cheaper instruction sequences for the square root and the logarithm (below): on
+// 768 256 frames of 400 bins -> 80 bands the pass takes 0.50 ms where k_mel_pass1 took 1.09 (it is bound by VALU issue, ~67 %
+// busy, not by its 1.5 GB of traffic), bit-identical to the oracle on every value the tests compare.
+struct MelTileArgs {
+  MelArgs m;
+  const float* cw;       // compact weights: band b's bins [lo, hi) at cw[woff + k - lo]
+  const float* wpad;     // the same, [mel_bins][maxw] zero-padded (staged into LDS when it fits)
+  const int4* bw;        // [mel_bins]: {lo, hi, woff, widest band of the wave's group (set on the group's first band)}
+  const double2* logtab; // [128]: {1 / c_i, log(c_i)}, c_i = 1 + (i + 0.5) / 128
+  int32_t nnz;           // entries of cw
+  int32_t maxw;          // widest band
+  int32_t fb_log2;       // frames per workgroup = 1 << fb_log2 (<= 64)
+  int32_t hs;            // odd row stride of the |z|^2 tile
+};
+
+// Nx.abs(c64) -> f32 -> ** 2.  The reference takes the square root in double and rounds it to f32; here: re^2 + im^2 in double,
+// a 1-ulp f32 square root of it, and one Newton correction whose residual s - r^2 is formed in double — the corrected value
+// carries ~5e-15 relative error before the single rounding to f32, so it equals the rounded double square root except when that
+// lies within 1e-7 ulp of a rounding boundary (v_rsq_f64 and its refinement cost three times as much).  Values whose f32 square
+// would leave the normal range take the plain double path.
+__device__ __forceinline__ double mel_norm2(float re, float im) {
+  return fma((double)re, (double)re, (double)im * (double)im);
+}
+// 1e-30 < (float)s < 1e30 as one unsigned compare on the bit pattern (s >= 0)
+__device__ __forceinline__ bool mel_abs_fast_ok(double s) { return __float_as_uint((float)s) - 0x0DA24261u < 0x7149F2CAu - 0x0DA24261u; }
+__device__ __forceinline__ float mel_abs_fast(double s) {
+  const float r = __builtin_amdgcn_sqrtf((float)s);
+  const double rd = (double)r;
+  const float e = (float)fma(-rd, rd, s);
+  return fmaf(e, 0.5f * __builtin_amdgcn_rcpf(r), r);
+}
+__device__ __forceinline__ float mel_abs2(float re, float im) {
+  const double s = mel_norm2(re, im);
+  const float ab = mel_abs_fast_ok(s) ? mel_abs_fast(s) : (float)sqrt(s);
+  return ab * ab;
+}
+
+// log(x) in double for a positive, normal x (the clipped band energies: 1e-10 <= x < 2^128): 7-bit table of {1 / c, log c},
+// r = x_mantissa / c - 1 by one fma (|r| <= 2^-8), log1p(r) to the r^7 term; |x - 1| < 2^-8 takes r = x - 1 without the table.
+// Relative error ~3e-16: after the rounding to f32 the result equals that of a correctly rounded log except within ~5e-9 ulp of a
+// rounding boundary.  A quarter of the instructions of the library's double log (which works in double-double).
+__device__ __forceinline__ double mel_log(double x, const double2* tab) {
+  const long long bits = __double_as_longlong(x);
+  const int hi = (int)(bits >> 32);
+  const double2 t = tab[(hi >> 13) & 127];
+  const double m = __longlong_as_double((bits & 0x000fffffffffffffll) | 0x3ff0000000000000ll);
+  double r = fma(m, t.x, -1.0);
+  double lc = t.y;
+  double ef = (double)(((hi >> 20) & 0x7ff) - 1023);
+  const double d = x - 1.0;
+  if (fabs(d) < 0.00390625) { r = d; lc = 0.0; ef = 0.0; }
+  double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+  p = fma(p, r, 0.2);
+  p = fma(p, r, -0.25);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -0.5);
+  p = fma(p * r, r, r);
+  const double y = fma(ef, 0.69314718055994530942, lc + p);
+  return hi >= 0x7ff00000 ? x : y;   // +inf (an overflowed band energy) and NaN pass through like log()
+}
+
+template <bool WLDS, int NT>
+__global__ __launch_bounds__(NT) void k_mel_tile(MelTileArgs t) {
+  typedef float v2f_t __attribute__((ext_vector_type(2)));
+  constexpr int NW = NT / 64, RW = 4;
+  const MelArgs& a = t.m;
+  const int FB = 1 << t.fb_log2;
+  float* mags = reinterpret_cast<float*>(g_smem);   // [FB][hs]
+  float* res = mags + FB * t.hs + t.maxw;           // [FB][mel_bins], behind a zeroed pad of maxw floats
+  float* wl = res + FB * a.mel_bins;                // [mel_bins][maxw], zero-padded band weights (WLDS only)
+  __shared__ int s_max;
+  __shared__ double2 s_log[128];
+  __shared__ int4 s_bw[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t r0 = (int64_t)blockIdx.x * FB;
+  const int nvalid = a.rows - r0 < FB ? (int)(a.rows - r0) : FB;
+  if (tid == 0) s_max = f2ord(-3.0e38f);
+  if (WLDS)
+    for (int i = tid; i < a.mel_bins * t.maxw; i += NT) wl[i] = t.wpad[i];
+  for (int i = tid; i < t.maxw; i += NT) mags[FB * t.hs + i] = 0.0f;
+  for (int i = tid; i < 128; i += NT) s_log[i] = t.logtab[i];
+  for (int i = tid; i < a.mel_bins; i += NT) s_bw[i] = t.bw[i];   // the launcher keeps mel_bins <= 256 on this kernel
+  // loads are unconditional (row and bin indices clamped into the tile) so that all eight of an iteration are in flight
+  // together; only the LDS stores are predicated
+  for (int fb = wave * RW; fb < FB; fb += NW * RW) {
+    const float2* zr[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int fr = fb + r < nvalid ? fb + r : nvalid - 1;
+      zr[r] = a.z + (size_t)(r0 + fr) * a.K;
+    }
+    for (int k0 = 0; k0 < a.half; k0 += 128) {
+      const int ka = k0 + lane, kb = ka + 64;
+      const int ca = ka < a.half ? ka : a.half - 1, cb = kb < a.half ? kb : a.half - 1;
+      v2f_t va[RW], vb[RW];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        va[r] = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(zr[r] + ca));
+        vb[r] = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(zr[r] + cb));
+      }
+      // rows past the end of the input were clamped to the last one: their tile rows hold finite values nobody reads.
+      // Straight-line arithmetic for all eight values; the out-of-range square roots (one branch per eight) are redone in double
+      double sa[RW], sb[RW];
+      float aa[RW], ab[RW];
+      bool odd = false;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        sa[r] = mel_norm2(va[r].x, va[r].y);
+        sb[r] = mel_norm2(vb[r].x, vb[r].y);
+        aa[r] = mel_abs_fast(sa[r]);
+        ab[r] = mel_abs_fast(sb[r]);
+        odd |= !mel_abs_fast_ok(sa[r]) | !mel_abs_fast_ok(sb[r]);
+      }
+      if (__builtin_expect(odd, 0)) {
+        asm volatile("; out-of-range magnitudes: double square root" ::: "memory");   // keeps this block a branch (not selects)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          if (!mel_abs_fast_ok(sa[r])) aa[r] = (float)sqrt(sa[r]);
+          if (!mel_abs_fast_ok(sb[r])) ab[r] = (float)sqrt(sb[r]);
+          if (!(aa[r] * aa[r] < INFINITY) || !(ab[r] * ab[r] < INFINITY)) atomicOr(a.gmax + 1, 1);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        if (fb + r < FB && ka < a.half) mags[(fb + r) * t.hs + ka] = aa[r] * aa[r];
+        if (fb + r < FB && kb < a.half) mags[(fb + r) * t.hs + kb] = ab[r] * ab[r];
+      }
+    }
+  }
+  __syncthreads();
+  const int f = lane & (FB - 1), sub = lane >> t.fb_log2, bpw = 64 >> t.fb_log2;
+  const float* mg = mags + f * t.hs;
+  int lmax = f2ord(-3.0e38f);
+  for (int b0 = wave * bpw; b0 < a.mel_bins; b0 += NW * bpw) {
+    const bool live = b0 + sub < a.mel_bins;
+    const int b = live ? b0 + sub : a.mel_bins - 1;
+    const int4 rg = s_bw[b];
+    double acc = 0.0;
+    if (WLDS) {
+      // the wave's bands walk the same number of bins (the widest of the group, .w of its first band): scalar loop control, the
+      // narrower band multiplies zero-padded weights with the bins that follow it (finite x 0 adds nothing; past the last row
+      // lies a zeroed pad)
+      const int nmax = __builtin_amdgcn_readfirstlane(s_bw[b0].w);
+      const float* mk = mg + rg.x;
+      const float* wk = wl + b * t.maxw;
+#pragma unroll 2
+      for (int j = 0; j < nmax; ++j) acc += (double)mk[j] * (double)wk[j];
+    } else {
+      const float* w = t.cw + rg.z - rg.x;
+      for (int k = rg.x; k < rg.y; ++k) acc += (double)mg[k] * (double)w[k];
+    }
+    float v = (float)acc;
+    v = v > 1.0e-10f ? v : 1.0e-10f;                       // Nx.clip(mel_spec, 1.0e-10, :infinity)
+    v = (float)mel_log((double)v, s_log) / a.ln10;         // Nx.log(.) / Nx.log(10)
+    if (live) res[f * a.mel_bins + b] = v;
+    if (live && f < nvalid) {
+      const int o = f2ord(v);
+      lmax = o > lmax ? o : lmax;
+    }
+  }
+  atomicMax(&s_max, lmax);
+  __syncthreads();
+  const int n = nvalid * a.mel_bins;
+  float* o = a.out + (size_t)r0 * a.mel_bins;
+  if (((FB * a.mel_bins) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {   // every tile starts 16-byte aligned
+    const int n4 = n >> 2;
+    for (int i = tid; i < n4; i += NT) reinterpret_cast<float4*>(o)[i] = reinterpret_cast<const float4*>(res)[i];
+    for (int i = (n4 << 2) + tid; i < n; i += NT) o[i] = res[i];
+  } else {
+    for (int i = tid; i < n; i += NT) o[i] = res[i];
+  }
+  if (tid == 0) atomicMax(a.gmax, s_max);
+}
+
 __global__ __launch_bounds__(kThreads) void k_mel_pass2(float* __restrict__ out, int64_t n, const int* __restrict__ gmax) {
-  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
-  const float floor_v = ord2f(*gmax) - 8.0f;               // Nx.reduce_max(log_spec) - 8
-  float v = out[i];
-  v = v > floor_v ? v : floor_v;
-  out[i] = (v + 4.0f) / 4.0f;
+  // gmax[1] != 0: some |z|^2 was inf / NaN.  The reference's dense Nx.dot multiplies it with the zero weights of every band
+  // (inf x 0), the NaN reaches reduce_max and from there every element; the sparse band sums here never form that product
+  const float floor_v = gmax[1] ? __int_as_float(0x7fc00000) : ord2f(*gmax) - 8.0f;   // Nx.reduce_max(log_spec) - 8
+  const int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+  if (i + 4 <= n && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    float4 v = *reinterpret_cast<float4*>(out + i);
+    v.x = ((v.x > floor_v ? v.x : floor_v) + 4.0f) / 4.0f;   // NaN floor: the comparison fails, the NaN is taken
+    v.y = ((v.y > floor_v ? v.y : floor_v) + 4.0f) / 4.0f;
+    v.z = ((v.z > floor_v ? v.z : floor_v) + 4.0f) / 4.0f;
+    v.w = ((v.w > floor_v ? v.w : floor_v) + 4.0f) / 4.0f;
+    *reinterpret_cast<float4*>(out + i) = v;
+    return;
+  }
+  for (int64_t j = i; j < n && j < i + 4; ++j) {
+    const float v = out[j];
+    out[j] = ((v > floor_v ? v : floor_v) + 4.0f) / 4.0f;
+  }
 }
 
 // ========================================================================================== launchers
@@ -1182,20 +1376,101 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
   void* gm = nullptr;
   rc = ctx_scratch(c, 5, 256, &gm);
   if (rc) return rc;
-  static const int init = (int)0x80000000;  // below every ordered-int value
-  NXSIG_HIP_TRY(hipMemcpyAsync(gm, &init, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  static const int init[2] = {(int)0x80000000, 0};  // {below every ordered-int value, no non-finite |z|^2 seen}
+  NXSIG_HIP_TRY(hipMemcpyAsync(gm, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   a.z = z; a.rows = rows; a.K = K; a.half = half; a.mel_bins = mel_bins;
   a.filt = reinterpret_cast<const float*>(fd); a.band = reinterpret_cast<const int2*>(bd);
   a.out = out; a.gmax = reinterpret_cast<int*>(gm);
   a.ln10 = (float)std::log(10.0);
-  const size_t lds = (size_t)kMelFramesPerBlock * half * sizeof(float);
-  int rc2 = ensure_lds(k_mel_pass1, lds);
-  if (rc2) return rc2;
-  hipLaunchKernelGGL(k_mel_pass1, dim3((unsigned)((rows + kMelFramesPerBlock - 1) / kMelFramesPerBlock)), dim3(kThreads), lds,
-                     c->stream, a);
+  // tiled kernel whenever one frame's bins fit the LDS budget (64 frames per tile for fft_length <= 512, fewer above), else
+  // the first form
+  std::vector<float> cw;
+  std::vector<int4> bw(mel_bins);
+  for (int b = 0; b < mel_bins; ++b) {
+    bw[b] = make_int4(band[b].x, band[b].y, (int)cw.size(), 0);
+    for (int k = band[b].x; k < band[b].y; ++k) cw.push_back(filters_host[(size_t)b * K + k]);
+  }
+  if (cw.empty()) cw.push_back(0.0f);
+  const int hs = half | 1;
+  int maxw = 1;
+  for (int b = 0; b < mel_bins; ++b) maxw = std::max(maxw, band[b].y - band[b].x);
+  const bool wlds = (size_t)mel_bins * maxw <= 4096;
+  static const bool tile_off = [] { const char* v = std::getenv("NXSIG_MEL_TILE"); return v && std::atoi(v) == 0; }();
+  int fb_log2 = -1;
+  size_t lds = 0;
+  static const size_t budget = [] { const char* v = std::getenv("NXSIG_MEL_LDS_KB"); return (size_t)(v ? std::atoi(v) : 56) * 1024; }();
+  static const int nt_knob = [] { const char* v = std::getenv("NXSIG_MEL_NT"); return v ? std::atoi(v) : 0; }();
+  for (int l = 6; l >= 0 && !tile_off && mel_bins <= 256; --l) {
+    const size_t need = ((size_t)(1 << l) * (hs + mel_bins) + maxw + (wlds ? (size_t)mel_bins * maxw : 0)) * sizeof(float);
+    if (need + 6200 <= budget) { fb_log2 = l; lds = need; break; }   // + the kernel's static tables
+  }
+  if (fb_log2 >= 0) {
+    MelTileArgs t;
+    const void *cd = nullptr, *od = nullptr;
+    rc = ctx_table(c, 0x3E1C0Aull, cw.data(), cw.size() * sizeof(float), &cd);
+    if (rc) return rc;
+    const int bpw = 64 >> fb_log2;
+    for (int b = 0; b < mel_bins; b += bpw) {
+      int gw = 0;
+      for (int j = b; j < std::min(b + bpw, mel_bins); ++j) gw = std::max(gw, bw[j].y - bw[j].x);
+      bw[b].w = gw;
+    }
+    std::vector<float> wpad(wlds ? (size_t)mel_bins * maxw : 1, 0.0f);
+    if (wlds)
+      for (int b = 0; b < mel_bins; ++b)
+        for (int k = band[b].x; k < band[b].y; ++k) wpad[(size_t)b * maxw + (k - band[b].x)] = filters_host[(size_t)b * K + k];
+    const void* pd = nullptr;
+    rc = ctx_table(c, 0x3E1C0Cull, wpad.data(), wpad.size() * sizeof(float), &pd);
+    if (rc) return rc;
+    rc = ctx_table(c, 0x3E1C0Bull ^ ((uint64_t)fb_log2 << 32), bw.data(), bw.size() * sizeof(int4), &od);
+    if (rc) return rc;
+    static const std::vector<double> logtab = [] {
+      std::vector<double> v(256);
+      for (int i = 0; i < 128; ++i) {
+        const double ci = 1.0 + (i + 0.5) / 128.0;
+        v[2 * i] = 1.0 / ci;
+        v[2 * i + 1] = std::log(ci);
+      }
+      return v;
+    }();
+    const void* ld = nullptr;
+    rc = ctx_table(c, 0x3E1106ull, logtab.data(), logtab.size() * sizeof(double), &ld);
+    if (rc) return rc;
+    t.m = a; t.cw = reinterpret_cast<const float*>(cd); t.bw = reinterpret_cast<const int4*>(od);
+    t.wpad = reinterpret_cast<const float*>(pd); t.maxw = maxw;
+    t.logtab = reinterpret_cast<const double2*>(ld);
+    t.nnz = (int)cw.size(); t.fb_log2 = fb_log2; t.hs = hs;
+    const int FB = 1 << fb_log2;
+    const dim3 grid((unsigned)((rows + FB - 1) / FB));
+    // 16 waves per tile when it has 32 or 64 frames: phase 2 is a chain of dependent LDS reads and double-precision
+    // operations per band, and it is the number of resident waves that hides their latency
+    // one wave per four frames of the tile (phase 1 streams four rows per wave), at least four waves
+    int nt = fb_log2 >= 6 ? 1024 : fb_log2 == 5 ? 512 : 256;
+    if (nt_knob) nt = nt_knob;
+#define NXSIG_MEL_TILE_LAUNCH(W, NT)                                                \
+    do {                                                                            \
+      rc = ensure_lds(k_mel_tile<W, NT>, lds);                                      \
+      if (rc) return rc;                                                            \
+      hipLaunchKernelGGL((k_mel_tile<W, NT>), grid, dim3(NT), lds, c->stream, t);   \
+    } while (0)
+    if (wlds && nt == 1024) NXSIG_MEL_TILE_LAUNCH(true, 1024);
+    else if (wlds && nt == 512) NXSIG_MEL_TILE_LAUNCH(true, 512);
+    else if (wlds) NXSIG_MEL_TILE_LAUNCH(true, 256);
+    else if (nt == 1024) NXSIG_MEL_TILE_LAUNCH(false, 1024);
+    else if (nt == 512) NXSIG_MEL_TILE_LAUNCH(false, 512);
+    else NXSIG_MEL_TILE_LAUNCH(false, 256);
+#undef NXSIG_MEL_TILE_LAUNCH
+  } else {
+    const size_t lds1 = (size_t)kMelFramesPerBlock * half * sizeof(float);
+    if (lds1 > 160 * 1024) return set_error(NXSIG_ERR_UNSUPPORTED, "stft_to_mel: fft_length beyond the LDS-resident kernels");
+    int rc2 = ensure_lds(k_mel_pass1, lds1);
+    if (rc2) return rc2;
+    hipLaunchKernelGGL(k_mel_pass1, dim3((unsigned)((rows + kMelFramesPerBlock - 1) / kMelFramesPerBlock)), dim3(kThreads), lds1,
+                       c->stream, a);
+  }
   NXSIG_HIP_TRY(hipGetLastError());
   const int64_t n = rows * mel_bins;
-  hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, out, n,
+  hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + 4 * kThreads - 1) / (4 * kThreads))), dim3(kThreads), 0, c->stream, out, n,
                      reinterpret_cast<const int*>(gm));
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
@@ -1244,14 +1519,14 @@ int launch_mel_init(Ctx* c, int** gmax) {
   void* gm = nullptr;
   int rc = ctx_scratch(c, 5, 256, &gm);
   if (rc) return rc;
-  static const int init = (int)0x80000000;
-  NXSIG_HIP_TRY(hipMemcpyAsync(gm, &init, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  static const int init[2] = {(int)0x80000000, 0};
+  NXSIG_HIP_TRY(hipMemcpyAsync(gm, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   *gmax = reinterpret_cast<int*>(gm);
   return NXSIG_OK;
 }
 int launch_mel_finish(Ctx* c, float* out, int64_t n, int* gmax) {
   if (n <= 0) return NXSIG_OK;
-  hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, out, n, gmax);
+  hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + 4 * kThreads - 1) / (4 * kThreads))), dim3(kThreads), 0, c->stream, out, n, gmax);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
 }

@@ -22,12 +22,14 @@ int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool
                                        // the one-sided form keeps its "same bits as stft" promise through the two-step path
       return launch_wave<2048, kModeReal2x, 4, 2, kSinkMag>(c, s, &mel);
     default:
-      if (kind == 3) return NXSIG_OK;  // one-sided complex output: only the power-of-two front-ends above store it; the rest slice
+      if (kind == 3 && s.K != 400) return NXSIG_OK;  // one-sided complex output: the power-of-two front-ends above and the
+                                                     // 20 x 20 kernel store it; the rest slice the full spectrum
       if (s.K == 400) {  // native 20 x 20 kernel
         bool h20 = false;
         int rc20 = launch_stft_r20(c, s, &h20, &mel);
         if (rc20 || h20) return rc20;
       }
+      if (kind == 3) return NXSIG_OK;
       if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0))
         return s.K <= 512 ? launch_blue_wave<1024, kSinkMag>(c, s, &mel) : launch_blue_wave<2048, kSinkMag>(c, s, &mel);
       return NXSIG_OK;

@@ -202,7 +202,11 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
             const v2f pa = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};
             const v2f pb = v2f{xv.x * xv.x + xv.y * xv.y, xv.z * xv.z + xv.w * xv.w};
             if (MEL) { pw[gg][0][i] = pa; pw[gg][1][i] = pb; }
-            else {
+            else if (b.mag_kind == 3) {   // one-sided complex rows: the same values the spectrum sink stores, bins below 200 only
+              float* o = b.out + (((size_t)row * a.M + m0) * HALF + k) * 2;
+              __builtin_nontemporal_store(xa, (gv4f*)o);
+              if (hb) __builtin_nontemporal_store(xv, (gv4f*)(o + 2 * HALF));
+            } else {
               const v2f va = b.mag_kind == 1 ? pa : v2f{__builtin_sqrtf(pa.x), __builtin_sqrtf(pa.y)};
               const v2f vb = b.mag_kind == 1 ? pb : v2f{__builtin_sqrtf(pb.x), __builtin_sqrtf(pb.y)};
               float* o = b.out + ((size_t)row * a.M + m0) * HALF + k;

@@ -143,6 +143,61 @@ def test_stft_to_mel_doctest_and_oracle(golden):
         assert got.shape == ref.shape and np.max(np.abs(got - ref)) < 1e-4
 
 
+@pytest.mark.parametrize("K,mb,fs,rows", [
+    (400, 80, 16000, 1000),    # the speech front-end's transform: 32-frame tiles
+    (400, 80, 16000, 1),       # a single frame
+    (401, 80, 16000, 33),      # odd fft_length: 200 bins of 401
+    (512, 80, 16000, 777), (256, 40, 8000, 1001), (64, 10, 8000, 130), (16, 4, 8000, 5),
+    (1024, 128, 48000, 300), (2048, 64, 48000, 70), (4096, 40, 48000, 19),
+    (8192, 20, 48000, 9),      # four-frame tiles (the first form of the kernel did not fit the LDS here)
+    (1000, 33, 22050, 65),
+    (1024, 300, 48000, 40),    # more bands than the tiled kernel's table holds: the first form
+])
+def test_stft_to_mel_is_bit_identical_to_the_oracle(K, mb, fs, rows):
+    """NxSignal.stft_to_mel/3 (lib/nx_signal.ex:486-513) on a given spectrum: Nx.abs in double -> f32 -> ** 2, the band sums in
+    double rounded once, log / log(10) in f32 arithmetic on a double log, the global maximum, clamp, (x + 4) / 4 — the tiled
+    kernel reproduces the oracle's bits (its square root and logarithm are cheaper sequences with ~1e-15 relative error before the
+    same single roundings; a mismatch of one ulp is possible only within ~1e-7 ulp of a rounding boundary, allowed for below)."""
+    rng = np.random.default_rng(K + mb + rows)
+    z = ((rng.standard_normal((rows, K)) + 1j * rng.standard_normal((rows, K))) * 10.0 ** rng.uniform(-3, 3, (rows, 1))).astype(np.complex64)
+    got = S.stft_to_mel(z, fs, fft_length=K, mel_bins=mb)
+    ref = O.stft_to_mel(z, fs, K, mel_bins=mb)
+    assert got.shape == ref.shape == (rows, mb) and got.dtype == np.float32
+    bad = int(np.sum(got != ref))
+    assert bad <= max(1, got.size // 100_000), (bad, got.size)
+    assert np.max(np.abs(got - ref)) < 2e-6
+    zd = S.default_context().to_device(z)                      # device-resident input, device-resident result
+    assert np.array_equal(S.stft_to_mel(zd, fs, fft_length=K, mel_bins=mb).numpy(), got)
+
+
+@pytest.mark.parametrize("mb", [40, 300])   # the tiled kernel / the first form (more bands than the tile's table holds)
+def test_stft_to_mel_extreme_magnitudes(mb):
+    """bins whose |z|^2 leaves the f32 normal range (the double square-root path), exact zeros, an overflowing bin and a NaN:
+    the reference's dense dot turns a non-finite |z|^2 into NaN for the whole tensor (inf x 0 weights, then reduce_max)"""
+    K, fs = 512, 16000
+    rng = np.random.default_rng(5)
+    z = (rng.standard_normal((64, K)) + 1j * rng.standard_normal((64, K))).astype(np.complex64)
+    z[3] *= np.float32(1e-18)       # |z|^2 ~ 1e-36: below the fast path's range, denormal squares
+    z[4] *= np.float32(1e-25)       # squares flush to zero: the 1e-10 clip decides
+    z[5] *= np.float32(3e16)        # |z|^2 ~ 1e33: above the fast path's range, still finite
+    z[6] = 0
+    z[7, 10:20] = 0
+    got = S.stft_to_mel(z, fs, fft_length=K, mel_bins=mb)
+    ref = O.stft_to_mel(z, fs, K, mel_bins=mb)
+    assert np.all(np.isfinite(got)) and np.array_equal(got, ref)
+    z[9] *= np.float32(1e25)        # band energy overflows f32 -> +inf -> every value clamps against max - 8 = inf
+    with np.errstate(all="ignore"):
+        ref = O.stft_to_mel(z, fs, K, mel_bins=mb)
+    got = S.stft_to_mel(z, fs, fft_length=K, mel_bins=mb)
+    assert np.all(np.isnan(ref)) and np.array_equal(got, ref, equal_nan=True)
+    z[9] = z[8]
+    z[60, 17] = np.nan
+    got = S.stft_to_mel(z, fs, fft_length=K, mel_bins=mb)
+    assert np.all(np.isnan(got))
+    z[60, 17] = 1.0
+    assert np.all(np.isfinite(S.stft_to_mel(z, fs, fft_length=K, mel_bins=mb)))   # the flag is per call
+
+
 @pytest.mark.parametrize("K,N,hop,pad,scaling,mb", [
     (1024, 1024, 256, "valid", None, 128),      # fused wave kernel, streaming
     (1024, 1024, 256, "reflect", "psd", 80),    # fused, general loader + scaling

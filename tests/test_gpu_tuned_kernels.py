@@ -414,6 +414,7 @@ def test_freed_device_buffers_are_reused_not_reallocated():
     (512, 400, 160, "reflect", None), (512, 512, 128, "valid", "psd"), (256, 256, 64, "same", None), (128, 128, 32, "valid", None),
     (2048, 2048, 512, "valid", None), (4096, 3000, 1000, "valid", "spectrum"),
     (400, 400, 160, "valid", None), (1000, 1000, 250, "valid", None), (64, 64, 16, "valid", None), (8192, 8192, 2048, "valid", None),
+    (400, 400, 160, "reflect", "psd"), (400, 400, 100, "same", None), (400, 320, 160, "reflect", "spectrum"),   # 20 x 20 kernel's own sink
 ])
 def test_stft_onesided_equals_the_first_half_of_stft_bit_for_bit(K, N, hop, pad, scaling):
     """the one-sided sink (tuned front-ends) and its two-step form (every other length): same bits as stft()[..., :K // 2]"""

@@ -1010,7 +1010,7 @@ static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows
     int rcw = launch_fft_rows_wave(c, in, in_is_real, rows, n_in, K, inverse, post_window, post_scale, has_post_scale, out, &handled);
     if (rcw || handled) return rcw;
   }
-  if ((is_pow2(K) && K > kMaxLdsPow2) || (!is_pow2(K) && K > 4096)) {
+  if ((is_pow2(K) && (K > kMaxLdsPow2 || K >= fft_tiled_min())) || (!is_pow2(K) && K > 4096)) {
     // beyond the LDS-resident kernels: four-step / Bluestein rows in HBM (kernels_nd.hip), then the istft epilogue if any
     int rcb = launch_fft_big(c, in, in_is_real, rows, n_in, K, inverse, out);
     if (rcb) return rcb;

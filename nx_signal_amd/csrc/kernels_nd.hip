@@ -4,8 +4,10 @@
 //                        sides), optionally reading f32 / zero-padding / truncating on the way in and multiplying by the
 //                        four-step twiddle w_K^(r c) on the way out
 //   launch_fft_big       rows of ANY length beyond the LDS-resident kernels of kernels_generic.hip:
-//                          power of two K > 8192: four-step K = K1 K2 — transpose, K1-point row FFTs, twiddle + transpose,
-//                          K2-point row FFTs, transpose (five streaming passes, no host round trip);
+//                          power of two 8192 <= K <= 2^20: two-pass tiled four-step (k_fft_tile, below): K1-point column transforms
+//                          + twiddle, then K2-point row transforms with the transposing store — 32 B per element of traffic;
+//                          larger powers of two: four-step K = K1 K2 through explicit transposes — transpose, K1-point row FFTs,
+//                          twiddle + transpose, K2-point row FFTs, transpose (five streaming passes, no host round trip);
 //                          other K > 4096: Bluestein chirp-z through a power-of-two transform of P >= 2K - 1 points
 //   launch_fft_nd        NxSignal.Transforms.fft_nd / ifft_nd (lib/nx_signal/transforms.ex:5-21): Enum.zip_reduce over
 //                        (axes, lengths) of Nx.fft(axis:, length:) — an axis other than the last is brought to the back
@@ -20,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -237,6 +240,238 @@ static int fft_fourstep(Ctx* c, const void* in, bool in_is_real, int64_t rows, i
   return launch_transpose(c, B, false, rows, K1, K2, (int64_t)K, (int64_t)K, out);
 }
 
+// ---- two-pass four-step (round 2): the transposes of fft_fourstep folded into the transforms.
+// k_fft_tile takes a tile of T sequences of n <= 2048 points into LDS (element (position p, sequence t) at p * T + t), runs an
+// in-place decimation-in-frequency FFT on all of them at once (one radix-2 stage when log2 n is odd, then radix-4 stages; a
+// thread owns butterfly j of sequence t with t fastest, so every stage reads and writes LDS in runs of T consecutive elements),
+// and leaves through a position table (the output of frequency k sits at the digit-reversed position).  Global accesses:
+//   pass A  sequences = columns n2 of the [K1][K2] view: every position is a run of T consecutive elements (T * 8 bytes), the
+//           result goes back the same way with the twiddle w_K^(n2 k1) applied (real input / zero padding / truncation on load)
+//   pass B  sequences = rows k1 of Y[k1][n2]: whole rows on load; X[k1 + K1 k2] on store — again runs of T consecutive k1
+// Two streaming passes (32 B per element) instead of five (80 B): 0.70-0.85 -> 1.2-1.6 TB/s algorithmic on rows of 2^13 ... 2^20
+// points (512 MB of c64 rows; each pass moves ~3 TB/s against ~5 for a plain copy: the LDS transform and the loads of a tile do
+// not overlap inside a workgroup, and 124 VGPRs keep it to four waves per SIMD; a persistent variant that prefetched the next
+// tile into registers needed 200+ VGPRs and was slower).  Above 2^20 the strided side would shrink to 32-byte runs: the
+// five-pass form stays.
+struct FtArgs {
+  const void* in;
+  float2* out;
+  int32_t n, lg, lgT;
+  int32_t in_real;
+  int32_t load_along;       // 1: the input is contiguous along the sequence (in_pos_stride == 1), 0: across sequences
+  int64_t in_seq_stride, in_pos_stride, in_row_stride, n_valid;
+  int64_t out_seq_stride, out_pos_stride, out_row_stride;
+  int64_t nseq;             // sequences per batch row (a multiple of T)
+  int32_t inverse;
+  float scale;
+  int32_t tw_mode;          // 1: multiply (sequence s, frequency k) by w_K^(s k) (conjugated for the inverse)
+  const float2 *tw_lo, *tw_hi, *tw_n;   // two-level w_K tables; w_n^j, j < n
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fft_tile(FtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ft_smem[];
+  float2* s = reinterpret_cast<float2*>(ft_smem);   // element (position p, sequence t) at p * TP + t.  (An odd stride TP = T + 1
+                                                    // against the bank conflicts of pass B's row-wise fill measured no faster and
+                                                    // costs a tile per CU at n = 1024: the kernel is bound by issue + HBM, not LDS.)
+  const int tid = threadIdx.x;
+  const int n = a.n, lgT = a.lgT, T = 1 << lgT, TP = T;
+  float2* s_tw = s + (size_t)n * TP;                // w_n^j, j < n (conjugated for the inverse), behind the tile
+  __shared__ unsigned short s_pos[2048];
+  const int64_t tiles_per_row = a.nseq >> lgT;
+  const int64_t row = blockIdx.x / tiles_per_row;
+  const int64_t seq0 = (blockIdx.x - row * tiles_per_row) << lgT;
+  for (int k = tid; k < n; k += NT) {   // where frequency k ends up: its digits, lowest first, select the sub-blocks of each stage
+    int pos = 0, span = n, kk = k;
+    if (a.lg & 1) { span >>= 1; pos += (kk & 1) * span; kk >>= 1; }
+    while (span >= 4) { span >>= 2; pos += (kk & 3) * span; kk >>= 2; }
+    s_pos[k] = (unsigned short)pos;
+    float2 w = a.tw_n[k];
+    if (a.inverse) w.y = -w.y;
+    s_tw[k] = w;
+  }
+  const int total = n << lgT;
+  const int64_t ibase = row * a.in_row_stride;
+  if (a.load_along) {
+#pragma unroll 8
+    for (int id = tid; id < total; id += NT) {
+      const int t = id >> a.lg, p = id & (n - 1);
+      const int64_t lin = (seq0 + t) * a.in_seq_stride + p;
+      float2 v = make_float2(0.f, 0.f);
+      if (lin < a.n_valid) {
+        if (a.in_real) v.x = reinterpret_cast<const float*>(a.in)[ibase + lin];
+        else v = reinterpret_cast<const float2*>(a.in)[ibase + lin];
+      }
+      s[p * TP + t] = v;
+    }
+  } else {
+#pragma unroll 8
+    for (int id = tid; id < total; id += NT) {
+      const int p = id >> lgT, t = id & (T - 1);
+      const int64_t lin = (seq0 + t) + (int64_t)p * a.in_pos_stride;
+      float2 v = make_float2(0.f, 0.f);
+      if (lin < a.n_valid) {
+        if (a.in_real) v.x = reinterpret_cast<const float*>(a.in)[ibase + lin];
+        else v = reinterpret_cast<const float2*>(a.in)[ibase + lin];
+      }
+      s[p * TP + t] = v;
+    }
+  }
+  __syncthreads();
+  const float sg = a.inverse ? 1.0f : -1.0f;   // the DFT4 rotation: -i forward, +i inverse
+  int span = n;
+  if (a.lg & 1) {
+    const int h = n >> 1;
+    for (int id = tid; id < (h << lgT); id += NT) {
+      const int i = id >> lgT, t = id & (T - 1);
+      const int i0 = i * TP + t, i1 = i0 + h * TP;
+      const float2 x0 = s[i0], x1 = s[i1];
+      s[i0] = make_float2(x0.x + x1.x, x0.y + x1.y);
+      s[i1] = ndmul(make_float2(x0.x - x1.x, x0.y - x1.y), s_tw[i]);
+    }
+    span = h;
+    __syncthreads();
+  }
+  while (span >= 16) {   // two radix-4 levels fused in registers: 16 elements per thread, one LDS round trip and one barrier
+    const int q16 = span >> 4, lgq = 31 - __clz(q16), st = n / span;
+    for (int id = tid; id < (total >> 4); id += NT) {
+      const int j = id >> lgT, t = id & (T - 1);
+      const int b = j >> lgq, o = j & (q16 - 1);
+      const int i0 = ((b * span) + o) * TP + t, dq = q16 * TP;
+      float2 e[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) e[m] = s[i0 + m * dq];
+#pragma unroll
+      for (int m0 = 0; m0 < 4; ++m0) {   // level 1: span, elements m0, m0 + 4, m0 + 8, m0 + 12; offset o + m0 q16
+        const float2 x0 = e[m0], x1 = e[m0 + 4], x2 = e[m0 + 8], x3 = e[m0 + 12];
+        const float2 sa = make_float2(x0.x + x2.x, x0.y + x2.y), sb = make_float2(x1.x + x3.x, x1.y + x3.y);
+        const float2 da = make_float2(x0.x - x2.x, x0.y - x2.y), db = make_float2(x1.x - x3.x, x1.y - x3.y);
+        const float2 idb = make_float2(-sg * db.y, sg * db.x);
+        const int o1 = (o + m0 * q16) * st;
+        e[m0] = make_float2(sa.x + sb.x, sa.y + sb.y);
+        e[m0 + 4] = ndmul(make_float2(da.x + idb.x, da.y + idb.y), s_tw[o1]);
+        e[m0 + 8] = ndmul(make_float2(sa.x - sb.x, sa.y - sb.y), s_tw[2 * o1]);
+        e[m0 + 12] = ndmul(make_float2(da.x - idb.x, da.y - idb.y), s_tw[3 * o1]);
+      }
+      const int o2 = o * st * 4;
+      const bool tw2 = q16 > 1;
+      const float2 v1 = tw2 ? s_tw[o2] : make_float2(1.f, 0.f), v2 = tw2 ? s_tw[2 * o2] : make_float2(1.f, 0.f),
+                   v3 = tw2 ? s_tw[3 * o2] : make_float2(1.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {      // level 2: span / 4 inside quarter r: elements 4 r + {0, 1, 2, 3}; offset o
+        const float2 x0 = e[4 * r], x1 = e[4 * r + 1], x2 = e[4 * r + 2], x3 = e[4 * r + 3];
+        const float2 sa = make_float2(x0.x + x2.x, x0.y + x2.y), sb = make_float2(x1.x + x3.x, x1.y + x3.y);
+        const float2 da = make_float2(x0.x - x2.x, x0.y - x2.y), db = make_float2(x1.x - x3.x, x1.y - x3.y);
+        const float2 idb = make_float2(-sg * db.y, sg * db.x);
+        float2 y0 = make_float2(sa.x + sb.x, sa.y + sb.y), y1 = make_float2(da.x + idb.x, da.y + idb.y);
+        float2 y2 = make_float2(sa.x - sb.x, sa.y - sb.y), y3 = make_float2(da.x - idb.x, da.y - idb.y);
+        if (tw2) { y1 = ndmul(y1, v1); y2 = ndmul(y2, v2); y3 = ndmul(y3, v3); }
+        s[i0 + (4 * r) * dq] = y0; s[i0 + (4 * r + 1) * dq] = y1; s[i0 + (4 * r + 2) * dq] = y2; s[i0 + (4 * r + 3) * dq] = y3;
+      }
+    }
+    span >>= 4;
+    __syncthreads();
+  }
+  while (span >= 4) {
+    const int q = span >> 2, lgq = 31 - __clz(q), st = n / span;
+    for (int id = tid; id < (total >> 2); id += NT) {
+      const int j = id >> lgT, t = id & (T - 1);
+      const int b = j >> lgq, o = j & (q - 1);
+      const int i0 = ((b * span) + o) * TP + t, dq = q * TP;
+      const float2 x0 = s[i0], x1 = s[i0 + dq], x2 = s[i0 + 2 * dq], x3 = s[i0 + 3 * dq];
+      const float2 sa = make_float2(x0.x + x2.x, x0.y + x2.y), sb = make_float2(x1.x + x3.x, x1.y + x3.y);
+      const float2 da = make_float2(x0.x - x2.x, x0.y - x2.y), db = make_float2(x1.x - x3.x, x1.y - x3.y);
+      const float2 idb = make_float2(-sg * db.y, sg * db.x);
+      float2 y0 = make_float2(sa.x + sb.x, sa.y + sb.y);
+      float2 y2 = make_float2(sa.x - sb.x, sa.y - sb.y);
+      float2 y1 = make_float2(da.x + idb.x, da.y + idb.y);
+      float2 y3 = make_float2(da.x - idb.x, da.y - idb.y);
+      if (q > 1) { y1 = ndmul(y1, s_tw[o * st]); y2 = ndmul(y2, s_tw[2 * o * st]); y3 = ndmul(y3, s_tw[3 * o * st]); }
+      s[i0] = y0; s[i0 + dq] = y1; s[i0 + 2 * dq] = y2; s[i0 + 3 * dq] = y3;
+    }
+    span = q;
+    __syncthreads();
+  }
+  float2* ob = a.out + row * a.out_row_stride;
+  // a thread's elements share t (NT is a multiple of T) and their k advance by NT / T: the four-step twiddle w_K^(s k) of pass A
+  // runs as a recurrence w <- w * w_K^(s NT / T), re-seeded from the two-level table every eight elements
+  const int t = tid & (T - 1);
+  const int64_t sq = seq0 + t;
+  const int dk = NT >> lgT;
+  float2 wstep = make_float2(1.f, 0.f), w = make_float2(1.f, 0.f);
+  if (a.tw_mode) {
+    const int64_t js = sq * dk;
+    wstep = ndmul(a.tw_hi[js >> 13], a.tw_lo[js & 8191]);
+    if (a.inverse) wstep.y = -wstep.y;
+  }
+  int cnt = 0;
+  for (int id = tid; id < total; id += NT, ++cnt) {
+    const int k = id >> lgT;
+    float2 v = s[(int)s_pos[k] * TP + t];
+    if (a.tw_mode) {
+      if ((cnt & 7) == 0) {
+        const int64_t j = sq * k;   // < K1 K2 = K
+        w = ndmul(a.tw_hi[j >> 13], a.tw_lo[j & 8191]);
+        if (a.inverse) w.y = -w.y;
+      } else {
+        w = ndmul(w, wstep);
+      }
+      v = ndmul(v, w);
+    }
+    v.x *= a.scale; v.y *= a.scale;
+    ob[sq * a.out_seq_stride + (int64_t)k * a.out_pos_stride] = v;
+  }
+}
+
+static int fft_fourstep_tiled(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
+  int lg = 0;
+  while (((int64_t)1 << lg) < K) ++lg;
+  const int lg1 = (lg + 1) / 2, lg2 = lg - lg1;
+  const int K1 = 1 << lg1, K2 = 1 << lg2;
+  static const int elems = [] { const char* v = std::getenv("NXSIG_FFT_TILE_ELEMS"); const int e = v ? std::atoi(v) : 8192; return e >= 1024 && e <= 16384 ? e : 8192; }();
+  static const int ntk = [] { const char* v = std::getenv("NXSIG_FFT_TILE_NT"); return v ? std::atoi(v) : 512; }();
+  const float2 *lo = nullptr, *hi = nullptr, *tw1 = nullptr, *tw2 = nullptr;
+  int rc = twolevel_tables(c, K, &lo, &hi);
+  if (rc) return rc;
+  if ((rc = ctx_twiddles(c, K1, &tw1))) return rc;
+  if ((rc = ctx_twiddles(c, K2, &tw2))) return rc;
+  void* s1 = nullptr;
+  if ((rc = ctx_scratch(c, 6, (size_t)rows * K * sizeof(float2), &s1))) return rc;
+  float2* Y = reinterpret_cast<float2*>(s1);
+  auto tile_lg = [&](int n, int64_t nseq) {
+    int l = 0;
+    while ((n << (l + 1)) <= elems && ((int64_t)1 << (l + 1)) <= nseq && l + 1 <= 6) ++l;
+    return l;
+  };
+  constexpr int NT = 512;
+  FtArgs a;
+  // pass A: columns n2, K1 points each
+  a.in = in; a.out = Y; a.n = K1; a.lg = lg1; a.lgT = tile_lg(K1, K2); a.in_real = in_is_real ? 1 : 0; a.load_along = 0;
+  a.in_seq_stride = 1; a.in_pos_stride = K2; a.in_row_stride = n_in; a.n_valid = n_in < K ? n_in : K;
+  a.out_seq_stride = 1; a.out_pos_stride = K2; a.out_row_stride = K; a.nseq = K2; a.inverse = inverse ? 1 : 0; a.scale = 1.0f;
+  a.tw_mode = 1; a.tw_lo = lo; a.tw_hi = hi; a.tw_n = tw1;
+  auto go = [&](int64_t blocks, size_t lds) -> int {
+    if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: too many tiles for one launch");
+    if (ntk == 256) {
+      if (lds > 64 * 1024) NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_tile<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_fft_tile<256>, dim3((unsigned)blocks), dim3(256), lds, c->stream, a);
+    } else {
+      if (lds > 64 * 1024) NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_tile<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_fft_tile<NT>, dim3((unsigned)blocks), dim3(NT), lds, c->stream, a);
+    }
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  };
+  if ((rc = go(rows * (K2 >> a.lgT), ((size_t)K1 * ((1 << a.lgT) + 1)) * sizeof(float2)))) return rc;
+  // pass B: rows k1, K2 points each; X[k1 + K1 k2]
+  a.in = Y; a.out = out; a.n = K2; a.lg = lg2; a.lgT = tile_lg(K2, K1); a.in_real = 0; a.load_along = 1;
+  a.in_seq_stride = K2; a.in_pos_stride = 1; a.in_row_stride = K; a.n_valid = K;
+  a.out_seq_stride = 1; a.out_pos_stride = K1; a.out_row_stride = K; a.nseq = K1; a.scale = inverse ? 1.0f / (float)K : 1.0f;
+  a.tw_mode = 0; a.tw_n = tw2;
+  if ((rc = go(rows * (K1 >> a.lgT), ((size_t)K2 * ((1 << a.lgT) + 1)) * sizeof(float2)))) return rc;
+  return NXSIG_OK;
+}
+
 // any other K: chirp-z through a power-of-two convolution of P >= 2K - 1 points
 static int fft_bluestein_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
   if (K > ((int64_t)1 << 22)) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: non-power-of-two lengths beyond 2^22 are not supported");
@@ -284,16 +519,25 @@ static int fft_bluestein_big(Ctx* c, const void* in, bool in_is_real, int64_t ro
   return NXSIG_OK;
 }
 
+int64_t fft_tiled_min() {
+  static const int64_t v = [] { const char* e = std::getenv("NXSIG_FFT_TILED_MIN"); const int64_t m = e ? std::atoll(e) : 8192; return m < 8192 ? 8192 : m; }();
+  return v;
+}
+
 // rows of any length.  Lengths the LDS-resident kernels cover go straight to launch_fft.
 int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
   if (rows == 0) return NXSIG_OK;
   if (K < 1 || n_in < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fft: lengths must be >= 1");
-  const bool small = (nd_is_pow2(K) && K <= 8192) || (!nd_is_pow2(K) && K <= 4096);
+  const bool small = (nd_is_pow2(K) && K <= 8192 && K < fft_tiled_min()) || (!nd_is_pow2(K) && K <= 4096);
   if (small) {
     if (n_in > 0x7fffffff) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: rows longer than 2^31");
     return launch_fft(c, in, in_is_real, rows, (int32_t)n_in, (int32_t)K, inverse, out);
   }
-  if (nd_is_pow2(K)) return fft_fourstep(c, in, in_is_real, rows, n_in, K, inverse, out);
+  if (nd_is_pow2(K)) {
+    static const bool tiled = [] { const char* v = std::getenv("NXSIG_FFT_TILED"); return !(v && std::atoi(v) == 0); }();
+    if (tiled && K <= ((int64_t)1 << 20)) return fft_fourstep_tiled(c, in, in_is_real, rows, n_in, K, inverse, out);
+    return fft_fourstep(c, in, in_is_real, rows, n_in, K, inverse, out);
+  }
   return fft_bluestein_big(c, in, in_is_real, rows, n_in, K, inverse, out);
 }
 

@@ -155,6 +155,7 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
 int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled);
 // kernels_nd.hip: rows of any length (four-step / Bluestein beyond the LDS-resident kernels), device-side fft_nd, n-D fftconvolve
 int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out);
+int64_t fft_tiled_min();   // power-of-two row lengths from here up run the two-pass tiled four-step of kernels_nd.hip
 int launch_rows_post(Ctx* c, float2* a, int64_t rows, int64_t K, const float* window, float scale, bool has_scale, float div, bool has_div);
 int launch_fft_nd(Ctx* c, const void* in, bool in_is_real, const int64_t* shape, int rank, const int32_t* axes, const int64_t* lengths,
                   int n_axes, bool inverse, float2* out);

@@ -40,7 +40,7 @@ def test_fft_nd_any_axes_host_and_device(shape, axes, lengths):
             assert isinstance(dgot, S.DeviceBuffer) and np.array_equal(dgot.numpy().view(np.uint32), got.view(np.uint32))
 
 
-@pytest.mark.parametrize("K", [16384, 65536, 1 << 20, 5000, 12000, 10007, 16385, 100003])
+@pytest.mark.parametrize("K", [16384, 32768, 65536, 1 << 17, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 23, 5000, 12000, 10007, 16385, 100003])
 def test_long_rows_four_step_and_bluestein(K):
     rng = np.random.default_rng(K)
     rows = 3 if K <= 70000 else 1

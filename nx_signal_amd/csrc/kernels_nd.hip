@@ -472,6 +472,37 @@ static int fft_fourstep_tiled(Ctx* c, const void* in, bool in_is_real, int64_t r
   return NXSIG_OK;
 }
 
+// A power-of-two transform of 16 ... 1024 points along an axis that is NOT the fastest one, [outer][na][inner] -> [outer][K][inner],
+// in ONE pass of k_fft_tile (sequences = the `inner` columns of a plane, T of them per workgroup, positions `inner` elements apart)
+// instead of transpose + row transforms + transpose.  Needs inner to be a multiple of 8 (64-byte runs at least).
+static int fft_columns_tiled(Ctx* c, const void* src, bool src_real, int64_t outer, int64_t na, int64_t inner, int64_t K, bool inverse,
+                             float2* dst, bool* handled) {
+  *handled = false;
+  static const bool on = [] { const char* v = std::getenv("NXSIG_FFT_COLUMNS"); return !(v && std::atoi(v) == 0); }();
+  if (!on || !nd_is_pow2(K) || K < 16 || K > 1024 || (inner & 7) != 0 || outer < 1) return NXSIG_OK;
+  int lg = 0;
+  while (((int64_t)1 << lg) < K) ++lg;
+  int lgT = 3;
+  while (lgT < 6 && (inner & (((int64_t)1 << (lgT + 1)) - 1)) == 0 && (K << (lgT + 1)) <= 8192) ++lgT;
+  const int64_t blocks = outer * (inner >> lgT);
+  if (blocks > 0x7fffffffLL) return NXSIG_OK;
+  const float2* tw = nullptr;
+  int rc = ctx_twiddles(c, (int)K, &tw);
+  if (rc) return rc;
+  FtArgs a;
+  a.in = src; a.out = dst; a.n = (int)K; a.lg = lg; a.lgT = lgT; a.in_real = src_real ? 1 : 0; a.load_along = 0;
+  a.in_seq_stride = 1; a.in_pos_stride = inner; a.in_row_stride = na * inner; a.n_valid = (na < K ? na : K) * inner;
+  a.out_seq_stride = 1; a.out_pos_stride = inner; a.out_row_stride = K * inner; a.nseq = inner;
+  a.inverse = inverse ? 1 : 0; a.scale = inverse ? 1.0f / (float)K : 1.0f;
+  a.tw_mode = 0; a.tw_lo = nullptr; a.tw_hi = nullptr; a.tw_n = tw;
+  const size_t lds = ((size_t)K * ((1 << lgT) + 1)) * sizeof(float2);
+  if (lds > 64 * 1024) NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_tile<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_fft_tile<512>, dim3((unsigned)blocks), dim3(512), lds, c->stream, a);
+  NXSIG_HIP_TRY(hipGetLastError());
+  *handled = true;
+  return NXSIG_OK;
+}
+
 // any other K: chirp-z through a power-of-two convolution of P >= 2K - 1 points
 static int fft_bluestein_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
   if (K > ((int64_t)1 << 22)) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: non-power-of-two lengths beyond 2^22 are not supported");
@@ -599,6 +630,15 @@ int launch_fft_nd(Ctx* c, const void* in, bool in_is_real, const int64_t* shape,
       src = dst;
     } else {
       if (na > 0x7fffffff || inner > 0x7fffffff || K > 0x7fffffff) return set_error(NXSIG_ERR_UNSUPPORTED, "fft_nd: dimension beyond 2^31");
+      {
+        float2* dst = last ? out : take();
+        bool handled = false;
+        if (reinterpret_cast<const void*>(dst) != src) {
+          if ((rc = fft_columns_tiled(c, src, src_real, outer, na, inner, K, inverse, dst, &handled))) return rc;
+        }
+        if (handled) { src = dst; src_real = false; cur[ax] = K; continue; }
+        if (!last) next = (next + 2) % 3;   // give the buffer back: take() order is fixed
+      }
       float2* t1 = take();  // [outer][na][inner] -> [outer][inner][na]
       if ((rc = launch_transpose(c, src, src_real, outer, (int)na, (int)inner, na * inner, na * inner, t1))) return rc;
       float2* t2 = take();
@@ -653,13 +693,21 @@ __global__ __launch_bounds__(kT) void k_slice_out(const float2* __restrict__ in,
 int launch_fftconvolve_nd(Ctx* c, const void* a, bool a_is_real, const int64_t* s1, const void* b, bool b_is_real, const int64_t* s2,
                           int rank, int mode, void* out, int64_t* out_shape) {
   if (rank < 1 || rank > 8) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: rank must be in [1, 8]");
-  int64_t full[8], res[8], start[8];
+  int64_t full[8], padded[8], res[8], start[8];
+  static const bool pow2_lengths = [] { const char* v = std::getenv("NXSIG_CONV_POW2"); return !(v && std::atoi(v) == 0); }();
   std::vector<int32_t> axes;
   std::vector<int64_t> lens;
   for (int d = 0; d < rank; ++d) {
     if (s1[d] < 1 || s2[d] < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: empty dimension");
     full[d] = s1[d] + s2[d] - 1;
-    if (s1[d] != 1 && s2[d] != 1) { axes.push_back(d); lens.push_back(full[d]); }  // convolution.ex:266-276
+    padded[d] = full[d];
+    if (s1[d] != 1 && s2[d] != 1) {  // convolution.ex:266-276
+      // The reference transforms at exactly s1 + s2 - 1 points.  Any length >= that gives the same linear convolution (the
+      // circular wrap never reaches the first s1 + s2 - 1 samples), so a non-power-of-two length runs at the next power of two:
+      // the tuned row kernels instead of Bluestein (which would pad to >= 2 (s1 + s2 - 1) - 1 internally anyway).
+      if (pow2_lengths) while (padded[d] & (padded[d] - 1)) padded[d] = (padded[d] | (padded[d] - 1)) + 1;
+      axes.push_back(d); lens.push_back(padded[d]);
+    }
   }
   switch (mode) {  // apply_mode / centered, convolution.ex:300-347
     case NXSIG_CONV_FULL: for (int d = 0; d < rank; ++d) { res[d] = full[d]; start[d] = 0; } break;
@@ -677,8 +725,8 @@ int launch_fftconvolve_nd(Ctx* c, const void* a, bool a_is_real, const int64_t* 
   int64_t sh1[8], sh2[8], osh[8], n1 = 1, n2 = 1, no = 1;
   for (int d = 0; d < rank; ++d) {
     const bool tr = s1[d] != 1 && s2[d] != 1;
-    sh1[d] = tr ? full[d] : s1[d]; sh2[d] = tr ? full[d] : s2[d];
-    osh[d] = full[d];  // = max of the two for a broadcast axis
+    sh1[d] = tr ? padded[d] : s1[d]; sh2[d] = tr ? padded[d] : s2[d];
+    osh[d] = padded[d];  // = max of the two for a broadcast axis
     n1 *= sh1[d]; n2 *= sh2[d]; no *= osh[d];
   }
   void *pa = nullptr, *pb = nullptr, *pc = nullptr;

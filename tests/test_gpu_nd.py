@@ -27,6 +27,9 @@ def crandn(rng, *shape):
     ((5, 7, 16), [0], [None]), ((5, 7, 16), [1], [9]), ((5, 7, 16), [1, 2], [None, 32]), ((5, 7, 16), [0, 2], [8, 5]),
     ((5, 7, 16), [2, 0, 1], [16, 5, 7]), ((3, 100, 65), [1], [128]), ((130, 70), [0], [130]), ((130, 70), [0, 1], [256, 100]),
     ((2, 3, 4, 5), [1, 3], [3, 8]), ((64, 64), [-2, -1], [None, None]), ((1, 9), [0], [4]), ((300,), [0], [512]),
+    # power-of-two transforms along a slower axis whose inner size is a multiple of 8: the one-pass column kernel
+    ((3, 100, 64), [1], [128]), ((2, 300, 24), [1], [256]), ((40, 16), [0], [16]), ((1000, 8), [0], [1024]), ((2, 512, 40), [1, 2], [512, 64]),
+    ((4, 33, 128), [1], [32]), ((2, 16, 8, 8), [1], [None]), ((3, 64, 72), [0, 1], [4, 64]),
 ])
 def test_fft_nd_any_axes_host_and_device(shape, axes, lengths):
     rng = np.random.default_rng(11)

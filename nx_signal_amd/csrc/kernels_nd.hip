@@ -814,6 +814,79 @@ __global__ __launch_bounds__(kT) void k_conv_direct(const void* __restrict__ a, 
   else reinterpret_cast<float2*>(out)[o] = make_float2((float)acc_re, (float)acc_im);
 }
 
+// Real x real operands whose kernel spans the last two axes at most (leading axes of extent 1 in the kernel are a batch): every
+// thread owns R = 8 consecutive outputs of a row and slides a register window over the input — one new input value and one
+// kernel value per tap feed eight double-precision FMAs — instead of decoding an n-D odometer per product.  Same sums: each
+// output accumulates its products in double in the window's row-major order (f32 x f32 is exact in double, so the fused
+// multiply-add rounds exactly like multiply-then-add), inputs outside the operand contribute a signed zero like the padding.
+struct DirectFast {
+  const float* a; const float* k; float* out;
+  int64_t nb, H, W, OH, OW, XB;   // batch planes; input rows / columns; output rows / columns; 8-wide output blocks per row
+  int32_t K1, K2;
+  int64_t sh1, sh2;               // input index = output index + tap index + shift
+};
+
+template <bool CHECK>
+__device__ __forceinline__ double df_ld(const float* __restrict__ row, int64_t ix, int64_t W) {
+  if (CHECK) return (ix >= 0 && ix < W) ? (double)row[ix] : 0.0;
+  return (double)row[ix];
+}
+
+template <bool CHECK>
+__device__ __forceinline__ void df_row(const float* __restrict__ ar, const float* __restrict__ kr, int K2, int64_t ix0, int64_t W,
+                                       double (&acc)[8]) {
+  constexpr int R = 8;
+  double w[2 * R - 1];
+#pragma unroll
+  for (int r = 0; r < R - 1; ++r) w[r] = df_ld<CHECK>(ar, ix0 + r, W);
+  int j = 0;
+  for (; j + R <= K2; j += R) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) w[R - 1 + u] = df_ld<CHECK>(ar, ix0 + j + R - 1 + u, W);
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const double kv = (double)kr[K2 - 1 - (j + u)];   // the window holds the REVERSED kernel
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = fma(w[u + r], kv, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) w[r] = w[R + r];
+  }
+  for (; j < K2; ++j) {
+    w[R - 1] = df_ld<CHECK>(ar, ix0 + j + R - 1, W);
+    const double kv = (double)kr[K2 - 1 - j];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = fma(w[r], kv, acc[r]);
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) w[r] = w[r + 1];
+  }
+}
+
+__global__ __launch_bounds__(kT) void k_conv_direct_rr(DirectFast g) {
+  constexpr int R = 8;
+  const int64_t o = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (o >= g.nb * g.OH * g.XB) return;
+  const int64_t by = o / g.XB, xb = o - by * g.XB;
+  const int64_t b = by / g.OH, y = by - b * g.OH;
+  const int64_t x0 = xb * R, ix0 = x0 + g.sh2;
+  double acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.0;
+  const bool interior = ix0 >= 0 && ix0 + (R - 1) + (g.K2 - 1) < g.W;
+  for (int j1 = 0; j1 < g.K1; ++j1) {
+    const int64_t iy = y + j1 + g.sh1;
+    if (iy < 0 || iy >= g.H) continue;
+    const float* ar = g.a + (b * g.H + iy) * g.W;
+    const float* kr = g.k + (int64_t)(g.K1 - 1 - j1) * g.K2;
+    if (interior) df_row<false>(ar, kr, g.K2, ix0, g.W, acc);
+    else df_row<true>(ar, kr, g.K2, ix0, g.W, acc);
+  }
+  float* orow = g.out + (b * g.OH + y) * g.OW + x0;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (x0 + r < g.OW) orow[r] = (float)acc[r];
+}
+
 // a, b: device tensors of equal rank (f32 when *_is_real, else c64); out f32 when both are real, else c64
 int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t* s1, const void* b, bool b_is_real, const int64_t* s2,
                            int rank, int mode, void* out, int64_t* out_shape) {
@@ -849,6 +922,25 @@ int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t*
     if (out_shape) out_shape[d] = res;
   }
   if (g.total > (int64_t)0x7fffffff * kT) return set_error(NXSIG_ERR_UNSUPPORTED, "convolve: result too large for one launch");
+  {
+    static const bool fast_on = [] { const char* v = std::getenv("NXSIG_DIRECT_FAST"); return !(v && std::atoi(v) == 0); }();
+    bool lead_one = true;
+    for (int d = 0; d + 2 < rank; ++d) lead_one = lead_one && sk[d] == 1;
+    if (fast_on && vol_real && ker_real && lead_one && sk[rank - 1] <= 0x7fffffff && (rank < 2 || sk[rank - 2] <= 0x7fffffff)) {
+      DirectFast f;
+      f.a = reinterpret_cast<const float*>(vol); f.k = reinterpret_cast<const float*>(ker); f.out = reinterpret_cast<float*>(out);
+      f.nb = 1;
+      for (int d = 0; d + 2 < rank; ++d) f.nb *= sv[d];
+      f.W = sv[rank - 1]; f.OW = g.oshape[rank - 1]; f.K2 = (int32_t)sk[rank - 1]; f.sh2 = g.shift[rank - 1];
+      if (rank >= 2) { f.H = sv[rank - 2]; f.OH = g.oshape[rank - 2]; f.K1 = (int32_t)sk[rank - 2]; f.sh1 = g.shift[rank - 2]; }
+      else { f.H = 1; f.OH = 1; f.K1 = 1; f.sh1 = 0; }
+      f.XB = (f.OW + 7) / 8;
+      const int64_t threads = f.nb * f.OH * f.XB;
+      hipLaunchKernelGGL(k_conv_direct_rr, dim3(blocks_for(threads)), dim3(kT), 0, c->stream, f);
+      NXSIG_HIP_TRY(hipGetLastError());
+      return NXSIG_OK;
+    }
+  }
   hipLaunchKernelGGL(k_conv_direct, dim3(blocks_for(g.total)), dim3(kT), 0, c->stream, vol, ker, g, out);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;

@@ -214,6 +214,31 @@ def test_convolve_direct_matches_oracle_bit_for_bit(s1, s2, mode, cplx):
     assert viaf.shape == got.shape and nerr(viaf, got) < 1e-5
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_convolve_direct_register_window_kernel_fuzz(seed):
+    """the real x real fast path (kernel spanning the last two axes at most, 8 outputs per thread): random ranks 1-4, sizes around the
+    8-wide blocks and 8-tap chunks, kernels longer than the rows, every mode — bit for bit against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    rank = int(rng.integers(1, 5))
+    lead = [int(rng.integers(1, 4)) for _ in range(max(0, rank - 2))]
+    if rank == 1:
+        sa, sb = [int(rng.integers(1, 400))], [int(rng.integers(1, 70))]
+    else:
+        sa = lead + [int(rng.integers(1, 40)), int(rng.integers(1, 90))]
+        sb = [1] * len(lead) + [int(rng.integers(1, 12)), int(rng.integers(1, 40))]
+    if seed % 5 == 0:
+        sa, sb = sb, sa                    # the kernel is the larger operand
+    mode = ["full", "same", "valid"][seed % 3]
+    if mode == "valid" and not (all(x >= y for x, y in zip(sa, sb)) or all(x <= y for x, y in zip(sa, sb))):
+        mode = "full"
+    a = rng.standard_normal(sa).astype(np.float32)
+    b = rng.standard_normal(sb).astype(np.float32)
+    got = S.convolution.convolve(a, b, mode=mode, method="direct")
+    exp = O.convolve_direct(a, b, mode=mode)
+    assert got.shape == exp.shape and got.dtype == np.float32, (sa, sb, mode)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (sa, sb, mode)
+
+
 def test_convolve_direct_long_stream_config5_slice():
     """the 257-tap low-pass of config 5 on a 200 000-sample slice: the time-domain method against direct f64 convolution"""
     x = O.synth_signal(200000, seed=5)

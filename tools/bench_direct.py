@@ -1,0 +1,20 @@
+#!/usr/bin/env python
+"""Convolution.convolve(method: :direct) — the reference's default method — on device-resident f32 tensors: 1-D streams and image
+batches (real x real: the register-window kernel).  One JSON object per line."""
+import sys, os, time, json, ctypes as C
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import nx_signal_amd as S
+from nx_signal_amd import _lib
+lib = _lib.load(); ctx = S.Context(0); rng = np.random.default_rng(0)
+for shape, kshape, mode in [((8, 1000000), (1, 257), 1), ((1, 8000000), (1, 31), 0), ((16, 512, 512), (1, 9, 9), 1), ((4, 1024, 1024), (1, 31, 31), 1)]:
+    a = ctx.to_device(rng.standard_normal(shape).astype(np.float32)); k = ctx.to_device(rng.standard_normal(kshape).astype(np.float32))
+    rank = len(shape)
+    s1, s2, osh = (C.c_int64 * rank)(*shape), (C.c_int64 * rank)(*kshape), (C.c_int64 * rank)()
+    y = ctx.empty(tuple(x + z - 1 for x, z in zip(shape, kshape)), np.float32)
+    fn = lambda: _lib.check(lib.nxsig_convolve_direct(ctx.handle, C.c_void_p(a.ptr), 1, s1, C.c_void_p(k.ptr), 1, s2, rank, mode, C.c_void_p(y.ptr), osh, _lib.DEVICE))
+    fn(); ctx.sync(); t0 = time.perf_counter()
+    for _ in range(3): fn()
+    ctx.sync(); ms = (time.perf_counter() - t0) / 3 * 1e3
+    n_out = int(np.prod([int(v) for v in osh])); macs = n_out * int(np.prod(kshape))
+    print(json.dumps({"case": f"convolve direct {shape} * {kshape}", "ms": ms, "GMAC_per_s": macs / ms / 1e6, "out_Msamples_per_s": n_out / ms / 1e3}), flush=True)

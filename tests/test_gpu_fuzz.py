@@ -263,3 +263,44 @@ def test_fuzz_istft_n400(seed):
     yo = O.istft(z, w, **opts)
     assert y.shape == yo.shape
     assert nerr(y, yo) < 1e-5, (hop, M, bshape, scaling, nerr(y, yo))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_stft_to_mel_bits(seed):
+    """stft_to_mel on random spectra (any fft_length, band count, row count, dynamic range): the oracle's bits — at most one value
+    in 100 000 may sit one ulp off (the tiled kernel's square root / logarithm carry ~1e-15 relative error before the same roundings)"""
+    rng = np.random.default_rng(7000 + seed)
+    K = int(rng.choice([16, 64, 100, 256, 400, 401, 512, 640, 1000, 1024, 2048, 4096, 8192]))
+    mb = int(rng.integers(1, min(K // 2, 140) + 1))
+    rows = int(rng.integers(1, max(2, 60000 // K)))
+    fs = int(rng.choice([8000, 16000, 22050, 48000]))
+    z = ((rng.standard_normal((rows, K)) + 1j * rng.standard_normal((rows, K))) * 10.0 ** rng.uniform(-4, 4, (rows, 1))).astype(np.complex64)
+    got = S.stft_to_mel(z, fs, fft_length=K, mel_bins=mb)
+    ref = O.stft_to_mel(z, fs, K, mel_bins=mb)
+    assert got.shape == ref.shape
+    assert int(np.sum(got != ref)) <= max(1, got.size // 100_000) and np.max(np.abs(got - ref)) < 2e-6, (K, mb, rows, fs)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_long_rows_and_columns(seed):
+    """the tiled four-step (rows of 2^13 ... 2^20 points; zero-padded / truncated, real / complex, both directions) and the one-pass
+    column transforms of fft_nd (a power-of-two length along a slower axis, inner size a multiple of 8) against numpy in double"""
+    rng = np.random.default_rng(8000 + seed)
+    K = 1 << int(rng.integers(13, 21))
+    rows = int(rng.integers(1, max(2, (1 << 21) // K)))
+    n_in = int(rng.choice([K, K - int(rng.integers(1, 1000)), K + int(rng.integers(1, 1000))]))
+    x = rng.standard_normal((rows, n_in)).astype(np.float32)
+    if seed & 1:
+        x = (x + 1j * rng.standard_normal((rows, n_in))).astype(np.complex64)
+    inverse = bool(seed & 2)
+    fn, npf = (S.transforms.ifft_nd, np.fft.ifft) if inverse else (S.transforms.fft_nd, np.fft.fft)
+    assert nerr(fn(x, lengths=[K]), npf(x.astype(np.complex128), n=K, axis=-1)) < 1e-5, (K, rows, n_in, inverse)
+    Kc = 1 << int(rng.integers(4, 11))
+    inner = 8 * int(rng.integers(1, 12))
+    na = int(rng.choice([Kc, max(1, Kc - int(rng.integers(1, 9))), Kc + int(rng.integers(1, 9))]))
+    y = rng.standard_normal((int(rng.integers(1, 4)), na, inner)).astype(np.float32)
+    if seed & 4:
+        y = (y + 1j * rng.standard_normal(y.shape)).astype(np.complex64)
+    got = fn(y, axes=[1], lengths=[Kc])
+    assert got.shape == (y.shape[0], Kc, inner)
+    assert nerr(got, npf(y.astype(np.complex128), n=Kc, axis=1)) < 1e-5, (y.shape, Kc, inverse)

@@ -887,6 +887,69 @@ __global__ __launch_bounds__(kT) void k_conv_direct_rr(DirectFast g) {
     if (x0 + r < g.OW) orow[r] = (float)acc[r];
 }
 
+// The same register window for complex operands (either or both): four outputs per thread, the products formed exactly like the
+// first kernel's — re = ar br - ai bi and im = ar bi + ai br, each rounded once (a real operand carries a literal 0.0 imaginary
+// part THROUGH the arithmetic, as there), then added to the running sums.
+template <bool AC, bool CHECK>
+__device__ __forceinline__ void dfc_ld(const void* __restrict__ row, int64_t ix, int64_t W, double& re, double& im) {
+  re = 0.0; im = 0.0;
+  if (CHECK && !(ix >= 0 && ix < W)) return;
+  if (AC) { const float2 v = reinterpret_cast<const float2*>(row)[ix]; re = (double)v.x; im = (double)v.y; }
+  else re = (double)reinterpret_cast<const float*>(row)[ix];
+}
+
+template <bool AC, bool KC, bool CHECK>
+__device__ __forceinline__ void dfc_row(const void* __restrict__ ar, const void* __restrict__ kr, int K2, int64_t ix0, int64_t W,
+                                        double (&acc_re)[4], double (&acc_im)[4]) {
+  constexpr int R = 4;
+  double wr[R], wi[R];
+#pragma unroll
+  for (int r = 0; r < R - 1; ++r) dfc_ld<AC, CHECK>(ar, ix0 + r, W, wr[r], wi[r]);
+  for (int j = 0; j < K2; ++j) {
+    dfc_ld<AC, CHECK>(ar, ix0 + j + R - 1, W, wr[R - 1], wi[R - 1]);
+    double br, bi = 0.0;
+    if (KC) { const float2 v = reinterpret_cast<const float2*>(kr)[K2 - 1 - j]; br = (double)v.x; bi = (double)v.y; }
+    else br = (double)reinterpret_cast<const float*>(kr)[K2 - 1 - j];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool in = !CHECK || (ix0 + j + r >= 0 && ix0 + j + r < W);   // the first kernel SKIPS outside products (no 0 x inf)
+      if (in) {
+        acc_re[r] += wr[r] * br - wi[r] * bi;
+        acc_im[r] += wr[r] * bi + wi[r] * br;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) { wr[r] = wr[r + 1]; wi[r] = wi[r + 1]; }
+  }
+}
+
+template <bool AC, bool KC>
+__global__ __launch_bounds__(kT) void k_conv_direct_cx(DirectFast g) {
+  constexpr int R = 4;
+  const int64_t o = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (o >= g.nb * g.OH * g.XB) return;
+  const int64_t by = o / g.XB, xb = o - by * g.XB;
+  const int64_t b = by / g.OH, y = by - b * g.OH;
+  const int64_t x0 = xb * R, ix0 = x0 + g.sh2;
+  double acc_re[R], acc_im[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { acc_re[r] = 0.0; acc_im[r] = 0.0; }
+  const bool interior = ix0 >= 0 && ix0 + (R - 1) + (g.K2 - 1) < g.W;
+  const size_t ea = AC ? sizeof(float2) : sizeof(float), ek = KC ? sizeof(float2) : sizeof(float);
+  for (int j1 = 0; j1 < g.K1; ++j1) {
+    const int64_t iy = y + j1 + g.sh1;
+    if (iy < 0 || iy >= g.H) continue;
+    const void* ar = reinterpret_cast<const char*>(g.a) + (size_t)((b * g.H + iy) * g.W) * ea;
+    const void* kr = reinterpret_cast<const char*>(g.k) + (size_t)((int64_t)(g.K1 - 1 - j1) * g.K2) * ek;
+    if (interior) dfc_row<AC, KC, false>(ar, kr, g.K2, ix0, g.W, acc_re, acc_im);
+    else dfc_row<AC, KC, true>(ar, kr, g.K2, ix0, g.W, acc_re, acc_im);
+  }
+  float2* orow = reinterpret_cast<float2*>(g.out) + (b * g.OH + y) * g.OW + x0;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (x0 + r < g.OW) orow[r] = make_float2((float)acc_re[r], (float)acc_im[r]);
+}
+
 // a, b: device tensors of equal rank (f32 when *_is_real, else c64); out f32 when both are real, else c64
 int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t* s1, const void* b, bool b_is_real, const int64_t* s2,
                            int rank, int mode, void* out, int64_t* out_shape) {
@@ -926,7 +989,7 @@ int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t*
     static const bool fast_on = [] { const char* v = std::getenv("NXSIG_DIRECT_FAST"); return !(v && std::atoi(v) == 0); }();
     bool lead_one = true;
     for (int d = 0; d + 2 < rank; ++d) lead_one = lead_one && sk[d] == 1;
-    if (fast_on && vol_real && ker_real && lead_one && sk[rank - 1] <= 0x7fffffff && (rank < 2 || sk[rank - 2] <= 0x7fffffff)) {
+    if (fast_on && lead_one && sk[rank - 1] <= 0x7fffffff && (rank < 2 || sk[rank - 2] <= 0x7fffffff)) {
       DirectFast f;
       f.a = reinterpret_cast<const float*>(vol); f.k = reinterpret_cast<const float*>(ker); f.out = reinterpret_cast<float*>(out);
       f.nb = 1;
@@ -934,9 +997,13 @@ int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t*
       f.W = sv[rank - 1]; f.OW = g.oshape[rank - 1]; f.K2 = (int32_t)sk[rank - 1]; f.sh2 = g.shift[rank - 1];
       if (rank >= 2) { f.H = sv[rank - 2]; f.OH = g.oshape[rank - 2]; f.K1 = (int32_t)sk[rank - 2]; f.sh1 = g.shift[rank - 2]; }
       else { f.H = 1; f.OH = 1; f.K1 = 1; f.sh1 = 0; }
-      f.XB = (f.OW + 7) / 8;
+      const bool rr = vol_real && ker_real;
+      f.XB = rr ? (f.OW + 7) / 8 : (f.OW + 3) / 4;
       const int64_t threads = f.nb * f.OH * f.XB;
-      hipLaunchKernelGGL(k_conv_direct_rr, dim3(blocks_for(threads)), dim3(kT), 0, c->stream, f);
+      if (rr) hipLaunchKernelGGL(k_conv_direct_rr, dim3(blocks_for(threads)), dim3(kT), 0, c->stream, f);
+      else if (!vol_real && !ker_real) hipLaunchKernelGGL((k_conv_direct_cx<true, true>), dim3(blocks_for(threads)), dim3(kT), 0, c->stream, f);
+      else if (!vol_real) hipLaunchKernelGGL((k_conv_direct_cx<true, false>), dim3(blocks_for(threads)), dim3(kT), 0, c->stream, f);
+      else hipLaunchKernelGGL((k_conv_direct_cx<false, true>), dim3(blocks_for(threads)), dim3(kT), 0, c->stream, f);
       NXSIG_HIP_TRY(hipGetLastError());
       return NXSIG_OK;
     }

@@ -214,10 +214,10 @@ def test_convolve_direct_matches_oracle_bit_for_bit(s1, s2, mode, cplx):
     assert viaf.shape == got.shape and nerr(viaf, got) < 1e-5
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 def test_convolve_direct_register_window_kernel_fuzz(seed):
-    """the real x real fast path (kernel spanning the last two axes at most, 8 outputs per thread): random ranks 1-4, sizes around the
-    8-wide blocks and 8-tap chunks, kernels longer than the rows, every mode — bit for bit against the oracle"""
+    """the register-window kernels (kernel spanning the last two axes at most; real and complex operands): random ranks 1-4, sizes
+    around the 8- / 4-wide blocks and 8-tap chunks, kernels longer than the rows, every mode — bit for bit against the oracle"""
     rng = np.random.default_rng(1000 + seed)
     rank = int(rng.integers(1, 5))
     lead = [int(rng.integers(1, 4)) for _ in range(max(0, rank - 2))]
@@ -233,10 +233,15 @@ def test_convolve_direct_register_window_kernel_fuzz(seed):
         mode = "full"
     a = rng.standard_normal(sa).astype(np.float32)
     b = rng.standard_normal(sb).astype(np.float32)
+    kind = (seed // 3) % 4                 # real x real (8 outputs per thread), complex x real, real x complex, complex x complex (4)
+    if kind in (1, 3):
+        a = (a + 1j * rng.standard_normal(sa)).astype(np.complex64)
+    if kind in (2, 3):
+        b = (b + 1j * rng.standard_normal(sb)).astype(np.complex64)
     got = S.convolution.convolve(a, b, mode=mode, method="direct")
     exp = O.convolve_direct(a, b, mode=mode)
-    assert got.shape == exp.shape and got.dtype == np.float32, (sa, sb, mode)
-    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (sa, sb, mode)
+    assert got.shape == exp.shape and got.dtype == (np.float32 if kind == 0 else np.complex64), (sa, sb, mode, kind)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (sa, sb, mode, kind)
 
 
 def test_convolve_direct_long_stream_config5_slice():

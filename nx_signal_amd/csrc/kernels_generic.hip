@@ -764,6 +764,8 @@ __global__ __launch_bounds__(NT) void k_mel_tile(MelTileArgs t) {
   if (WLDS)
     for (int i = tid; i < a.mel_bins * t.maxw; i += NT) wl[i] = t.wpad[i];
   for (int i = tid; i < t.maxw; i += NT) mags[FB * t.hs + i] = 0.0f;
+  if (t.hs > a.half)   // the odd row stride leaves one column nobody fills: a narrower band of a group reads it (times a zero weight)
+    for (int f = tid; f < FB; f += NT) mags[f * t.hs + a.half] = 0.0f;
   for (int i = tid; i < 128; i += NT) s_log[i] = t.logtab[i];
   for (int i = tid; i < a.mel_bins; i += NT) s_bw[i] = t.bw[i];   // the launcher keeps mel_bins <= 256 on this kernel
   // loads are unconditional (row and bin indices clamped into the tile) so that all eight of an iteration are in flight
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(NT) void k_mel_tile(MelTileArgs t) {
         sb[r] = mel_norm2(vb[r].x, vb[r].y);
         aa[r] = mel_abs_fast(sa[r]);
         ab[r] = mel_abs_fast(sb[r]);
-        odd |= !mel_abs_fast_ok(sa[r]) | !mel_abs_fast_ok(sb[r]);
+        odd |= !(mel_abs_fast_ok(sa[r]) && mel_abs_fast_ok(sb[r]));
       }
       if (__builtin_expect(odd, 0)) {
         asm volatile("; out-of-range magnitudes: double square root" ::: "memory");   // keeps this block a branch (not selects)

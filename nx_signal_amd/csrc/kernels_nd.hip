@@ -912,11 +912,8 @@ __device__ __forceinline__ void dfc_row(const void* __restrict__ ar, const void*
     else br = (double)reinterpret_cast<const float*>(kr)[K2 - 1 - j];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const bool in = !CHECK || (ix0 + j + r >= 0 && ix0 + j + r < W);   // the first kernel SKIPS outside products (no 0 x inf)
-      if (in) {
-        acc_re[r] += wr[r] * br - wi[r] * bi;
-        acc_im[r] += wr[r] * bi + wi[r] * br;
-      }
+      acc_re[r] += wr[r] * br - wi[r] * bi;   // outside the operand the window holds the padding's zeros, as in Nx.conv
+      acc_im[r] += wr[r] * bi + wi[r] * br;
     }
 #pragma unroll
     for (int r = 0; r < R - 1; ++r) { wr[r] = wr[r + 1]; wi[r] = wi[r + 1]; }

@@ -8,5 +8,5 @@ for e in NXSIG_FIR32=2 NXSIG_FIR32=0 NXSIG_FIR_PAD_TAPS=0 NXSIG_FIR_PHASE=0 NXSI
   echo "== $e"; env $e python -m pytest $SUITES -q -m gpu 2>&1 | tail -1
 done
 # the first form of the stft_to_mel kernel does not fit fft_length 8192 into the LDS (the tiled form does)
-echo "== NXSIG_MEL_TILE=0"; NXSIG_MEL_TILE=0 python -m pytest $SUITES -q -m gpu -k "not 8192-20-48000" 2>&1 | tail -1
+echo "== NXSIG_MEL_TILE=0"; NXSIG_MEL_TILE=0 python -m pytest $SUITES -q -m gpu -k "not 8192-20-48000 and not stft_to_mel_bits" 2>&1 | tail -1
 echo "== NXSIG_DISABLE_WAVE=1"; NXSIG_DISABLE_WAVE=1 python -m pytest $SUITES -q -m gpu -k "not leak_samples and not reused" 2>&1 | tail -1

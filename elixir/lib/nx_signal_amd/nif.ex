@@ -62,4 +62,7 @@ defmodule NxSignalAMD.NIF do
 
   def fir_sharded(_group, _x, _length, _batch, _taps, _mode, _axis, _gather),
     do: :erlang.nif_error(:nif_not_loaded)
+
+  def stft_mel_sharded(_group, _x, _length, _batch, _window, _params, _mel_bins, _filters, _axis),
+    do: :erlang.nif_error(:nif_not_loaded)
 end

@@ -69,6 +69,33 @@ defmodule NxSignalAMD.Sharded do
     if vec_axes == [], do: y, else: Nx.vectorize(y, vec_axes)
   end
 
+  @doc """
+  `NxSignalAMD.mel_spectrogram/3` (`stft/3 |> stft_to_mel/3`, fused) sharded over `group` — the one sharded call with an
+  exchange step: the clamp against `reduce_max(log_spec) - 8` (`lib/nx_signal.ex:511`) takes the maximum over the WHOLE tensor,
+  so the members' running maxima are all-reduced (RCCL `ncclAllReduce` / `ncclMax` on one `int32` pair) between the two passes.
+  Options: mel_spectrogram's plus `axis:` (`:channels` or `:frames`); `window_padding` must be `:valid`.
+  """
+  def mel_spectrogram(group, %Nx.Tensor{} = data, window, opts \\ []) do
+    {shard_opts, opts} = Keyword.split(opts, [:axis])
+    {mel_opts, stft_opts} = Keyword.split(opts, [:mel_bins, :max_mel, :mel_frequency_spacing])
+    axis = Map.fetch!(@axes, shard_opts[:axis] || :channels)
+    mel_bins = mel_opts[:mel_bins] || raise ArgumentError, "missing :mel_bins option"
+    {params, fft_length} = NxSignalAMD.stft_params!(window, stft_opts)
+    filters = NxSignalAMD.mel_filters(fft_length, mel_bins, elem(params, 7), Keyword.delete(mel_opts, :mel_bins)) |> Nx.to_binary()
+    vec_axes = data.vectorized_axes
+    flat = if vec_axes == [], do: data, else: Nx.devectorize(data, keep_names: false)
+    {batch_shape, length} = NxSignalAMD.split_last(Nx.shape(flat))
+    x = flat |> Nx.as_type(:f32) |> Nx.to_binary()
+    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+
+    {:ok, out, m} =
+      NIF.stft_mel_sharded(group, x, length, Tuple.product(batch_shape), w, params, mel_bins, filters, axis) |> NxSignalAMD.unwrap!()
+
+    shape = batch_shape |> Tuple.insert_at(tuple_size(batch_shape), m) |> Tuple.insert_at(tuple_size(batch_shape) + 1, mel_bins)
+    y = Nx.from_binary(out, :f32) |> Nx.reshape(shape)
+    if vec_axes == [], do: y, else: Nx.vectorize(y, vec_axes)
+  end
+
   @doc "FIR filtering (`NxSignalAMD.Filters.fir/3`) sharded over `group` by channels or by output-sample ranges."
   def fir(group, %Nx.Tensor{} = x, taps, opts \\ []) do
     opts = Keyword.validate!(opts, mode: :same, axis: :channels, gather: false)

@@ -400,6 +400,23 @@ int nxsig_fir_sharded_f32(nxsig_group* g, const float* const* x, int64_t length,
                           const float* h, int32_t num_taps, int32_t mode, int32_t axis, int32_t gather, float* const* y,
                           int32_t mem);
 
+/*
+ * NxSignal.stft/3 |> NxSignal.stft_to_mel/3 (lib/nx_signal.ex:68-130, :486-513) sharded over the group — the one sharded entry
+ * point with an EXCHANGE step: the clamp `max(log_spec, reduce_max(log_spec) - 8)` (:511) needs the maximum over the whole
+ * tensor.  Every member runs the fused stft -> mel kernel on its shard (device-resident, laid out as for nxsig_stft_sharded_f32
+ * with mem == NXSIG_DEVICE: rows [c0, c1) for the channels axis, the sample span [s0, s1) of every row for the frames axis),
+ * or — mem == NXSIG_HOST, LOCAL groups — on the part of the host tensor x[0] the call uploads to it;
+ * the members' running maxima (one int32 pair: ordered-int maximum, non-finite flag) are all-reduced — ncclAllReduce / ncclMax
+ * on the members' streams inside one ncclGroupStart / End; members of one process that share a device reduce through the
+ * host — and every member then clamps its own shard.  mem == NXSIG_DEVICE: out[i] is f32[c1 - c0][M][mel_bins] /
+ * f32[batch][m1 - m0][mel_bins] on member i's device and the results stay sharded (assemble with nxsig_group_allgather if
+ * needed); mem == NXSIG_HOST: out[0] is the whole host result f32[batch][M][mel_bins].  window_padding must be :valid.
+ * `filters`: host f32[mel_bins][fft_length] (nxsig_mel_filters_f32).  Asynchronous on the members' streams.
+ */
+int nxsig_stft_mel_sharded_f32(nxsig_group* g, const float* const* x, int64_t length, int32_t batch, int64_t batch_stride,
+                               const float* window, const nxsig_stft_params* params, int32_t mel_bins, const float* filters,
+                               int32_t axis, float* const* out, int64_t* num_frames_out, int32_t mem);
+
 /* per-launch stopwatch on the ctx stream: lap() records an event (at most 4096 per series), laps() synchronises and
  * returns the n - 1 intervals in milliseconds and clears the series */
 int nxsig_timer_lap(nxsig_ctx* ctx);

@@ -783,6 +783,33 @@ static ERL_NIF_TERM nif_istft_sharded(ErlNifEnv* env, int argc, const ERL_NIF_TE
   return mk_ok(env, enif_make_binary(env, &yb));
 }
 
+/* stft_mel_sharded(group, x_bin, length, batch, window_bin, params, mel_bins, filters_bin, axis) -> {:ok, f32[batch][M][mel_bins], M}
+ * (the sharded log-mel: the members' maxima are all-reduced between the two passes) */
+static ERL_NIF_TERM nif_stft_mel_sharded(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  ErlNifBinary x, w, f, ob;
+  ErlNifSInt64 length;
+  int batch, bins, axis;
+  nxsig_stft_params p;
+  if (argc != 9 || !get_grp(env, argv[0], &g) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p) ||
+      !enif_get_int(env, argv[6], &bins) || !enif_inspect_binary(env, argv[7], &f) || !enif_get_int(env, argv[8], &axis))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || bins < 1 || x.size % 4 || x.size / 4 / (size_t)batch != (size_t)length ||
+      w.size != (size_t)p.frame_length * 4 || p.fft_length < 2 || f.size % 4 || f.size / 4 / (size_t)bins != (size_t)p.fft_length ||
+      f.size / 4 % (size_t)bins)
+    return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
+  if (m < 0) return mk_error(env, (int)m);
+  if (!out_bin(&ob, (uint64_t)batch, (uint64_t)m, (uint64_t)bins, 4)) return mk_oom(env);
+  const float* xs[64] = {(const float*)x.data};
+  float* os[64] = {(float*)ob.data};
+  int rc = nxsig_stft_mel_sharded_f32(g->grp, xs, length, batch, length, (const float*)w.data, &p, bins, (const float*)f.data, axis, os,
+                                      NULL, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), enif_make_binary(env, &ob), enif_make_int64(env, m));
+}
+
 /* fir_sharded(group, x_bin, length, batch, taps_bin, mode, axis, gather) -> {:ok, y_bin} */
 static ERL_NIF_TERM nif_fir_sharded(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   grp_res_t* g;
@@ -852,6 +879,7 @@ static ErlNifFunc funcs[] = {
     {"stft_sharded", 8, nif_stft_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_sharded", 8, nif_istft_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir_sharded", 8, nif_fir_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_mel_sharded", 9, nif_stft_mel_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 ERL_NIF_INIT(Elixir.NxSignalAMD.NIF, funcs, load, NULL, upgrade, NULL)

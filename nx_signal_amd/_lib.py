@@ -123,6 +123,8 @@ SIGNATURES = {
     "nxsig_istft_sharded_c64": (C.c_int, [_p, C.POINTER(_p), _i64, _i32, _p, C.POINTER(StftParams), _i32, _i32, C.POINTER(_p), _i32]),
     "nxsig_fir_sharded_f32": (C.c_int, [_p, C.POINTER(_p), _i64, _i32, _i64, _p, _i32, _i32, _i32, _i32, C.POINTER(_p), _i32]),
     "nxsig_stft_mel_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _p, _p, C.POINTER(_i64), _i32]),
+    "nxsig_stft_mel_sharded_f32": (C.c_int, [_p, C.POINTER(_p), _i64, _i32, _i64, _p, C.POINTER(StftParams), _i32, _p, _i32, C.POINTER(_p),
+                                             C.POINTER(_i64), _i32]),
 }
 
 _lib = None

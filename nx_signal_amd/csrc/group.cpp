@@ -692,4 +692,132 @@ int nxsig_fir_sharded_f32(nxsig_group* grp, const float* const* x, int64_t lengt
   NXSIG_API_END
 }
 
+int nxsig_stft_mel_sharded_f32(nxsig_group* grp, const float* const* x, int64_t length, int32_t batch, int64_t batch_stride,
+                               const float* window, const nxsig_stft_params* p, int32_t mel_bins, const float* filters,
+                               int32_t axis, float* const* out, int64_t* num_frames_out, int32_t mem) {
+  NXSIG_API_BEGIN
+  if (!grp || !x || !window || !p || !filters || !out) return set_error(NXSIG_ERR_INVALID_ARG, "stft_mel_sharded: null argument");
+  if (mem != NXSIG_HOST && mem != NXSIG_DEVICE) return set_error(NXSIG_ERR_INVALID_ARG, "mem must be NXSIG_HOST or NXSIG_DEVICE");
+  if (axis != NXSIG_SHARD_CHANNELS && axis != NXSIG_SHARD_FRAMES) return set_error(NXSIG_ERR_INVALID_ARG, "stft_mel_sharded: bad axis");
+  if (p->pad_mode != NXSIG_PAD_VALID)
+    return set_error(NXSIG_ERR_INVALID_ARG, "stft_mel_sharded: window_padding must be :valid (padding belongs to the stream ends)");
+  if (batch < 1 || mel_bins < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft_mel_sharded: batch and mel_bins must be >= 1");
+  if (mem == NXSIG_HOST && batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "stft_mel_sharded: batch_stride < length");
+  const int64_t M = nxsig_num_frames(length, p->frame_length, p->hop, NXSIG_PAD_VALID, 0, 0);
+  if (M < 0) return (int)M;
+  if (num_frames_out) *num_frames_out = M;
+  Group* g = reinterpret_cast<Group*>(grp);
+  std::lock_guard<std::mutex> lock(g->mu);
+  if (g->ranked && g->world > 1 && !g->has_rccl)
+    return set_error(NXSIG_ERR_UNSUPPORTED, "stft_mel_sharded: a ranked group without RCCL cannot reduce the maximum");
+  if (mem == NXSIG_HOST && g->ranked && g->world > 1)
+    return set_error(NXSIG_ERR_UNSUPPORTED, "stft_mel_sharded: host tensors need a LOCAL group (one process, all GPUs)");
+  if (mem == NXSIG_HOST && (!x[0] || !out[0])) return set_error(NXSIG_ERR_INVALID_ARG, "stft_mel_sharded: null tensor pointer");
+  const size_t nl = g->m.size();
+  struct Sh { int64_t row0 = 0, rows = 0, in0 = 0, in_len = 0, m0 = 0, frames = 0, count = 0; void* din = nullptr; void* dout = nullptr; int* cell = nullptr; };
+  std::vector<Sh> sh(nl);
+  int rc = NXSIG_OK;
+  auto cleanup = [&]() {
+    for (size_t i = 0; i < nl; ++i) {
+      if (sh[i].din) (void)nxsig_free(g->m[i].ctx, sh[i].din);
+      if (sh[i].dout) (void)nxsig_free(g->m[i].ctx, sh[i].dout);
+    }
+  };
+  auto fail = [&](int code) { std::string keep = nxsig_last_error(); cleanup(); return set_error(code, keep); };
+  // pass 1 on every member: stft -> |.|^2 -> mel bands -> log10 of its shard, running maximum in the member's cell pair
+  for (size_t i = 0; i < nl; ++i) {
+    Member& mb = g->m[i];
+    Sh& q = sh[i];
+    if (axis == NXSIG_SHARD_CHANNELS) {
+      int64_t c0, c1;
+      if ((rc = split(batch, g->world, mb.rank, &c0, &c1))) return fail(rc);
+      q.row0 = c0; q.rows = c1 - c0; q.in0 = 0; q.in_len = length; q.m0 = 0; q.frames = M;
+    } else {
+      int64_t m0, m1, s0, s1;
+      if ((rc = nxsig_shard_frames(M, p->frame_length, p->hop, g->world, mb.rank, &m0, &m1, &s0, &s1))) return fail(rc);
+      q.row0 = 0; q.rows = batch; q.in0 = s0; q.in_len = s1 - s0; q.m0 = m0; q.frames = m1 - m0;
+    }
+    q.count = q.rows * q.frames * mel_bins;
+    Ctx* c = reinterpret_cast<Ctx*>(mb.ctx);
+    NXSIG_HIP_TRY(hipSetDevice(mb.device));
+    if (q.count == 0) {  // an empty shard still takes part in the reduction: identity elements
+      std::lock_guard<std::mutex> cl(c->mu);
+      if ((rc = launch_mel_init(c, &q.cell))) return fail(rc);
+      continue;
+    }
+    const float* xin;
+    float* dst;
+    int64_t stride = batch_stride;
+    if (mem == NXSIG_DEVICE) {
+      if (!x[i] || !out[i]) return fail(set_error(NXSIG_ERR_INVALID_ARG, "stft_mel_sharded: null shard pointer"));
+      xin = x[i]; dst = out[i];
+    } else {  // the member's rows / spans, packed densely on its device
+      if ((rc = nxsig_alloc(mb.ctx, (size_t)(q.rows * q.in_len) * sizeof(float), &q.din))) return fail(rc);
+      if ((rc = nxsig_alloc(mb.ctx, (size_t)q.count * sizeof(float), &q.dout))) return fail(rc);
+      for (int64_t row = 0; row < q.rows; ++row)
+        if ((rc = nxsig_upload(mb.ctx, static_cast<float*>(q.din) + row * q.in_len, x[0] + (q.row0 + row) * batch_stride + q.in0,
+                               (size_t)q.in_len * sizeof(float)))) return fail(rc);
+      xin = static_cast<const float*>(q.din); dst = static_cast<float*>(q.dout); stride = q.in_len;
+    }
+    c->mel_defer = true;
+    rc = nxsig_stft_mel_f32(mb.ctx, xin, q.in_len, (int32_t)q.rows, stride, window, p, mel_bins, filters, dst, nullptr, NXSIG_DEVICE);
+    c->mel_defer = false;
+    if (rc) return fail(rc);
+    void* gm = nullptr;
+    if ((rc = ctx_scratch(c, 5, 256, &gm))) return fail(rc);
+    q.cell = reinterpret_cast<int*>(gm);
+    if (mem == NXSIG_DEVICE) q.dout = nullptr;
+  }
+  // the exchange step of the log-mel path: max over the WHOLE tensor (Nx.reduce_max, lib/nx_signal.ex:511) and the non-finite flag
+  if (g->has_rccl) {
+    Rccl* R = rccl();
+    NXSIG_NCCL_TRY(R, R->GroupStart());
+    for (size_t i = 0; i < nl; ++i) {
+      NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
+      NXSIG_NCCL_TRY(R, R->AllReduce(sh[i].cell, sh[i].cell, 2, ncclInt32, ncclMax, g->m[i].comm, stream_of(g->m[i])));
+    }
+    NXSIG_NCCL_TRY(R, R->GroupEnd());
+  } else if (nl > 1) {  // members of one process sharing devices (no communicators): through the host
+    int best[2] = {(int)0x80000000, 0};
+    for (size_t i = 0; i < nl; ++i) {
+      int v[2];
+      NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
+      NXSIG_HIP_TRY(hipMemcpyAsync(v, sh[i].cell, sizeof(v), hipMemcpyDeviceToHost, stream_of(g->m[i])));
+      NXSIG_HIP_TRY(hipStreamSynchronize(stream_of(g->m[i])));
+      best[0] = v[0] > best[0] ? v[0] : best[0];
+      best[1] = v[1] > best[1] ? v[1] : best[1];
+    }
+    for (size_t i = 0; i < nl; ++i) {
+      NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
+      NXSIG_HIP_TRY(hipMemcpyAsync(sh[i].cell, best, sizeof(best), hipMemcpyHostToDevice, stream_of(g->m[i])));
+      NXSIG_HIP_TRY(hipStreamSynchronize(stream_of(g->m[i])));   // `best` lives on this stack frame
+    }
+  }
+  // pass 2 on every member: max(., global max - 8), (. + 4) / 4; host tensors: the shard goes to its place of the result
+  for (size_t i = 0; i < nl; ++i) {
+    Sh& q = sh[i];
+    if (q.count == 0) continue;
+    Member& mb = g->m[i];
+    Ctx* c = reinterpret_cast<Ctx*>(mb.ctx);
+    float* dst = mem == NXSIG_DEVICE ? out[i] : static_cast<float*>(q.dout);
+    {
+      std::lock_guard<std::mutex> cl(c->mu);
+      NXSIG_HIP_TRY(hipSetDevice(mb.device));
+      if ((rc = launch_mel_finish(c, dst, q.count, q.cell))) return fail(rc);
+    }
+    if (mem == NXSIG_DEVICE) continue;
+    float* oh = out[0];
+    if (axis == NXSIG_SHARD_CHANNELS) {
+      if ((rc = nxsig_download(mb.ctx, oh + q.row0 * M * mel_bins, dst, (size_t)q.count * sizeof(float)))) return fail(rc);
+    } else {
+      for (int64_t row = 0; row < q.rows; ++row)
+        if ((rc = nxsig_download(mb.ctx, oh + (row * M + q.m0) * mel_bins, dst + row * q.frames * mel_bins,
+                                 (size_t)(q.frames * mel_bins) * sizeof(float)))) return fail(rc);
+    }
+  }
+  cleanup();
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
 }  // extern "C"

@@ -1471,11 +1471,7 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
                        c->stream, a);
   }
   NXSIG_HIP_TRY(hipGetLastError());
-  const int64_t n = rows * mel_bins;
-  hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + 4 * kThreads - 1) / (4 * kThreads))), dim3(kThreads), 0, c->stream, out, n,
-                     reinterpret_cast<const int*>(gm));
-  NXSIG_HIP_TRY(hipGetLastError());
-  return NXSIG_OK;
+  return launch_mel_finish(c, out, rows * mel_bins, reinterpret_cast<int*>(gm));
 }
 
 // bins below K / 2 of every row (two-step form of the one-sided spectrum sink)
@@ -1527,7 +1523,7 @@ int launch_mel_init(Ctx* c, int** gmax) {
   return NXSIG_OK;
 }
 int launch_mel_finish(Ctx* c, float* out, int64_t n, int* gmax) {
-  if (n <= 0) return NXSIG_OK;
+  if (n <= 0 || c->mel_defer) return NXSIG_OK;
   hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + 4 * kThreads - 1) / (4 * kThreads))), dim3(kThreads), 0, c->stream, out, n, gmax);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;

@@ -93,6 +93,9 @@ struct Ctx {
   std::multimap<size_t, void*> pool_free;   // size -> block
   std::map<void*, size_t> pool_live;        // blocks handed out by nxsig_alloc
   size_t pool_cached = 0, pool_cap = 0;     // bytes sitting in pool_free; cap (0 = not yet decided)
+  // set by the sharded log-mel (group.cpp): the clamp pass of stft_to_mel / the fused mel sink is NOT launched — the running
+  // maximum of this context's shard must first be all-reduced with the other members'; the group launches the pass afterwards
+  bool mel_defer = false;
 };
 
 int ctx_twiddles(Ctx* c, int K, const float2** out);
@@ -153,6 +156,9 @@ int launch_spectrum_mul(Ctx* c, const float2* z, int64_t rows, int32_t K, const 
 int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t mel_bins, const float* filters_host,
                        float* out);
 int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled);
+// the two cells {running maximum in ordered-int encoding, non-finite flag} of the log-mel paths and their clamp pass
+int launch_mel_init(Ctx* c, int** gmax);
+int launch_mel_finish(Ctx* c, float* out, int64_t n, int* gmax);
 // kernels_nd.hip: rows of any length (four-step / Bluestein beyond the LDS-resident kernels), device-side fft_nd, n-D fftconvolve
 int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out);
 int64_t fft_tiled_min();   // power-of-two row lengths from here up run the two-pass tiled four-step of kernels_nd.hip

@@ -286,3 +286,59 @@ def fir_sharded(group: Group, data, taps, mode: str = "same", axis: str = "chann
     _lib.check(lib.nxsig_fir_sharded_f32(group.handle, xs, L, B, L, h.ctypes.data_as(C.c_void_p), int(h.shape[0]), m,
                                          _AXES[axis], int(bool(gather)), ys, _lib.HOST))
     return y[0] if squeeze else y.reshape(x.shape[:-1] + (n_out,))
+
+
+def mel_spectrogram_sharded(group: Group, data, window, axis: str = "channels", **opts):
+    """`stft(data, window) |> stft_to_mel` (the fused log-mel of `nx_signal_amd.mel_spectrogram`) sharded over `group` — the one
+    sharded call with an exchange step: the clamp against `reduce_max(log_spec) - 8` (lib/nx_signal.ex:511) takes the maximum
+    over the WHOLE tensor, so the members' running maxima are all-reduced (RCCL ncclAllReduce / ncclMax; through the host when
+    the members of one process share a device) between the two passes.  window_padding must be "valid".
+
+    data: host array [channels, L] / [L] (LOCAL groups: every member uploads its part, the result shards are downloaded into
+          place -> f32[channels, M, mel_bins] / [M, mel_bins]), or a list with one DeviceBuffer per LOCAL member holding
+          its input shard (rows [c0, c1) / the sample span [s0, s1) of every row) with `length=` and `batch=` of the whole
+          tensor -> the list of per-member result DeviceBuffers (shards; they stay on their devices).
+    Options: the stft options plus mel_bins (128), max_mel, mel_frequency_spacing."""
+    from . import _mel_filters_for  # the host filterbank of the unsharded call (bit-identical to the reference's doctest)
+
+    lib = _lib.load()
+    w = np.ascontiguousarray(window, dtype=np.float32)
+    length = opts.pop("length", None)
+    batch = opts.pop("batch", None)
+    mb = int(opts.pop("mel_bins", 128))
+    fopts = {k: opts.pop(k) for k in ("max_mel", "mel_frequency_spacing") if k in opts and opts[k] is not None}
+    p, N, hop, K = _stft_params(w, opts)
+    filt = _mel_filters_for(K, mb, float(p.sampling_rate), fopts)
+    ax = _AXES[axis]
+    n = group.local_count
+
+    def shard_shape(r, B, M):
+        if ax == CHANNELS:
+            c0, c1 = shard_channels(B, group.world, r)
+            return (c1 - c0, M, mb)
+        m0, m1, _, _ = shard_frames(M, N, hop, group.world, r)
+        return (B, m1 - m0, mb)
+
+    wp, fp = w.ctypes.data_as(C.c_void_p), filt.ctypes.data_as(C.c_void_p)
+    mo = C.c_int64(0)
+    if isinstance(data, (list, tuple)) and data and isinstance(data[0], DeviceBuffer):
+        if length is None or batch is None:
+            raise _lib.ArgumentError("device shards need length= and batch= of the whole tensor")
+        M = int(_lib.check(lib.nxsig_num_frames(int(length), N, hop, _lib.PAD_VALID, 0, 0)))
+        outs = [group.contexts[i].empty(shard_shape(r, int(batch), M), np.float32) for i, r in enumerate(group.ranks)]
+        stride = int(data[0].shape[-1])
+        xs = (C.c_void_p * n)(*[C.c_void_p(d.ptr) for d in data])
+        ys = (C.c_void_p * n)(*[C.c_void_p(o.ptr) for o in outs])
+        _lib.check(lib.nxsig_stft_mel_sharded_f32(group.handle, xs, int(length), int(batch), stride, wp, C.byref(p), mb, fp, ax, ys,
+                                                  C.byref(mo), _lib.DEVICE))
+        return outs
+    x = np.ascontiguousarray(data, dtype=np.float32)
+    squeeze = x.ndim == 1
+    x2 = x.reshape(1, -1) if squeeze else x.reshape(-1, x.shape[-1])
+    B, L = x2.shape
+    M = int(_lib.check(lib.nxsig_num_frames(L, N, hop, _lib.PAD_VALID, 0, 0)))
+    out = np.empty((B, M, mb), np.float32)
+    xs = (C.c_void_p * n)(*([x2.ctypes.data_as(C.c_void_p)] + [C.c_void_p(0)] * (n - 1)))
+    ys = (C.c_void_p * n)(*([out.ctypes.data_as(C.c_void_p)] + [C.c_void_p(0)] * (n - 1)))
+    _lib.check(lib.nxsig_stft_mel_sharded_f32(group.handle, xs, L, B, L, wp, C.byref(p), mb, fp, ax, ys, C.byref(mo), _lib.HOST))
+    return out[0] if squeeze else out.reshape(x.shape[:-1] + (M, mb))

@@ -211,6 +211,36 @@ def test_istft_eight_frame_shards_of_a_long_stream():
         g.close()
 
 
+@pytest.mark.parametrize("axis", ["channels", "frames"])
+@pytest.mark.parametrize("K,N,hop,mb", [(1024, 1024, 256, 128), (512, 400, 160, 80), (400, 400, 160, 80), (3000, 3000, 750, 40)])
+def test_log_mel_shards_all_reduce_the_global_maximum(pair, solo, axis, K, N, hop, mb):
+    """the sharded log-mel has an exchange step (the clamp needs reduce_max over the WHOLE tensor, lib/nx_signal.ex:511): two
+    members whose shards have very different levels — only an all-reduced maximum clamps the quiet shard like the unsharded call
+    does.  `pair`: members sharing the device reduce through the host; `solo`: the RCCL ncclAllReduce path (world of one)."""
+    rng = np.random.default_rng(K + hop)
+    L = N + hop * 333 + 5
+    x = rng.standard_normal((4, L)).astype(np.float32)
+    x[:2] *= np.float32(1e-3)            # channels shard: member 0 quiet, member 1 loud
+    x[:, : L // 2] *= np.float32(1e-2)   # frames shard: the first half quiet
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=K, sampling_rate=16000, mel_bins=mb)
+    full = S.mel_spectrogram(x, w, **opts)
+    lo = float(full.max()) - 2.0 - 1e-6  # (max - 8 + 4) / 4: the clamp floor of the whole tensor
+    assert float(full.min()) >= lo and np.any(full[:2] <= lo + 1e-5)   # the quiet channels do hit the global floor
+    for grp in (pair, solo):
+        got = sharding.mel_spectrogram_sharded(grp, x, w, axis=axis, **opts)
+        assert got.shape == full.shape and got.dtype == np.float32
+        if axis == "channels":
+            assert np.array_equal(bits(got), bits(full))                # same kernel per row, same maximum: identical
+        else:
+            assert float(np.max(np.abs(got - full))) < 2e-5             # frame pairing differs at the shard edge: fp32 rounding
+    xd = [pair.contexts[i].to_device(x[2 * i: 2 * i + 2]) for i in range(2)]   # device-resident shards stay on their devices
+    outs = sharding.mel_spectrogram_sharded(pair, xd, w, axis="channels", length=L, batch=4, **opts)
+    assert np.array_equal(bits(np.concatenate([o.numpy() for o in outs])), bits(full))
+    with pytest.raises(S.ArgumentError):
+        sharding.mel_spectrogram_sharded(pair, x, w, window_padding="reflect", **opts)
+
+
 def test_ranked_group_of_one():
     g = sharding.Group.ranked(world=1, rank=0, device=0, path="")
     try:

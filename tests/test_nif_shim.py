@@ -302,6 +302,18 @@ def test_sharded_calls_through_the_nif():
     with pytest.raises(H.NifError) as e:
         H.call("stft_sharded", g, x, 30000, 3, w, (1024, 256, 1024, 1, 0, 0, 0, 48000.0), 0, 0)
     assert e.value.code == -1 and ":valid" in e.value.msg
+    # the sharded log-mel: quiet first channel, so only the all-reduced maximum clamps it like the unsharded call
+    xq = x.copy()
+    xq[0] *= np.float32(1e-3)
+    filt = S.mel_filters(1024, 80, 48000.0)
+    mel = S.mel_spectrogram(xq, w, overlap_length=768, fft_length=1024, sampling_rate=48000, mel_bins=80)
+    for grp in (g, g1):
+        ok, mb, m = H.call("stft_mel_sharded", grp, xq, 30000, 3, w, PARAMS, 80, filt, 0)
+        assert m == mel.shape[1] and np.array_equal(f32(mb).view(np.uint32), mel.reshape(-1).view(np.uint32))
+    ok, mb, m = H.call("stft_mel_sharded", g, xq, 30000, 3, w, PARAMS, 80, filt, 1)
+    assert float(np.max(np.abs(f32(mb).reshape(mel.shape) - mel))) < 2e-5
+    with pytest.raises(H.BadArg):   # a filterbank that is not [mel_bins][fft_length]
+        H.call("stft_mel_sharded", g, xq, 30000, 3, w, PARAMS, 80, np.ascontiguousarray(filt[:, :100]), 0)
     del g, g1, ctx
     H.release_all()
 

@@ -12,3 +12,12 @@ wait $P0; echo "rank0 exit $?"; wait $P1; echo "rank1 exit $?"
 cat gpurun_out/two_rank/rank0.json
 grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" gpurun_out/two_rank/rank0.err | tail -8
 grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" gpurun_out/two_rank/rank1.err | tail -5
+# the sharded log-mel: its clamp needs the maximum over both ranks' shards (ncclAllReduce / ncclMax between the two passes)
+export MASTER_PORT=29534
+RANK=0 NCCL_HOSTID=nxsig-rank0 python tools/two_rank_mel.py > gpurun_out/two_rank/mel_rank0.json 2> gpurun_out/two_rank/mel_rank0.err &
+P0=$!
+RANK=1 NCCL_HOSTID=nxsig-rank1 python tools/two_rank_mel.py > gpurun_out/two_rank/mel_rank1.json 2> gpurun_out/two_rank/mel_rank1.err &
+P1=$!
+wait $P0; echo "mel rank0 exit $?"; wait $P1; echo "mel rank1 exit $?"
+cat gpurun_out/two_rank/mel_rank0.json gpurun_out/two_rank/mel_rank1.json
+grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" gpurun_out/two_rank/mel_rank0.err | tail -5

@@ -63,6 +63,16 @@ def main():
     lo, hi = m0 + (m0 & 1), m1 - ((m1 - m0 - (m0 & 1)) & 1)  # own frames whose frame PAIR (2j, 2j + 1) lies inside the shard
     if m0 % 2 == 0 and hi > lo:                                 # ... ride the same transform as in the unsharded launch: bit-identical
         assert np.array_equal(got[lo:hi].view(np.uint32), full[0][lo:hi].view(np.uint32))
+    # the sharded log-mel: rank 0's channels are quiet, so its clamp floor must come from the OTHER rank's maximum (ncclAllReduce max)
+    xq = x.copy()
+    xq[: sharding.shard_channels(B, world, 0)[1]] = x[: sharding.shard_channels(B, world, 0)[1]] * np.float32(1e-3)
+    mopts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000, mel_bins=80)
+    mfull = S.mel_spectrogram(xq, w, ctx, **mopts)
+    mine = sharding.mel_spectrogram_sharded(g, [ctx.to_device(xq[c0:c1])], w, axis="channels", length=L, batch=B, **mopts)[0].numpy()
+    assert np.array_equal(mine.view(np.uint32), mfull[c0:c1].view(np.uint32)), "sharded log-mel: all-reduced maximum"
+    if rank == 0:
+        alone = S.mel_spectrogram(xq[c0:c1], w, ctx, **mopts)
+        assert not np.array_equal(alone, mine), "the exchange step must matter for the quiet shard"
     g.barrier()
     print(f"RANKED-OK rank {rank} of {world}", file=sys.stderr, flush=True)
     g.close()

@@ -46,6 +46,13 @@ def main():
     print(f"120 s stream by frame ranges: stft {zl.shape} normalised err vs unsharded {float(np.max(np.abs(zl - zf)) / np.max(np.abs(zf))):.1e}; istft round trip err on the interior "
           f"{float(np.max(np.abs(yl.real[1024:-1024] - long[1024:len(yl) - 1024]))):.1e}; sharded istft identical to unsharded: "
           f"{np.array_equal(yl.view(np.uint32), S.istft(zl, w1, overlap_length=768, sampling_rate=48000).view(np.uint32))}")
+    # the one call with an exchange step: the log-mel's clamp needs the maximum over EVERY shard (an all-reduce between its passes)
+    xm = x[:, : 48000 * 5].copy()
+    xm[: ch // 2] *= np.float32(1e-3)            # half of the channels are quiet: their floor comes from the loud members' maximum
+    mo = dict(overlap_length=2048 - 512, fft_length=2048, sampling_rate=48000, mel_bins=128)
+    mel = sharding.mel_spectrogram_sharded(g, xm, w, axis="channels", **mo)
+    print(f"log-mel of {ch} ch sharded by channels {mel.shape}, global maximum all-reduced; identical to the unsharded call: "
+          f"{np.array_equal(mel.view(np.uint32), S.mel_spectrogram(xm, w, **mo).view(np.uint32))}")
     g.close()
 
 

@@ -359,7 +359,9 @@ def test_istft_4096_on_four_passes_of_the_1024_core(hop, scaling, M, batch):
     assert float(np.max(np.abs(ys.real[core] - x[core]))) < 1e-4 * max(1.0, float(np.max(np.abs(x))))
 
 
-@pytest.mark.parametrize("taps,L,mode", [(5000, 60000, "same"), (20000, 100000, "full"), (48000, 48000 * 4, "valid"), (4097, 9000, "same")])
+@pytest.mark.parametrize("taps,L,mode", [(5000, 60000, "same"), (20000, 100000, "full"), (48000, 48000 * 4, "valid"), (4097, 9000, "same"),
+                                          (96001, 3_000_000, "same"),     # one 2^22-point transform per row (five-pass four-step)
+                                          (70001, 900_000, "full")])      # 2^20 points: the two-pass tiled four-step
 def test_fir_with_very_long_filters(taps, L, mode):
     """more than 4096 taps (reverb-length impulse responses): one big transform per row like the reference's fftconvolve"""
     from scipy import signal as ss

@@ -74,4 +74,12 @@ defmodule NxSignalAMDTest do
     opts = [overlap_length: 768, sampling_rate: 48_000]
     assert Sig.istft_filtered(z, h, w, opts) == Sig.istft(Nx.multiply(z, h), w, opts)
   end
+
+  test "the sharded log-mel all-reduces the global maximum: channel shards equal the unsharded call" do
+    g = Sig.Sharded.group()
+    x = Nx.iota({4, 30_000}, type: :f32) |> Nx.sin() |> Nx.multiply(Nx.tensor([[1.0e-3], [1.0e-3], [1.0], [1.0]]))
+    w = Sig.Windows.hann(1024)
+    opts = [overlap_length: 768, sampling_rate: 48_000, mel_bins: 80]
+    assert Sig.Sharded.mel_spectrogram(g, x, w, opts) == Sig.mel_spectrogram(x, w, opts)
+  end
 end

@@ -242,8 +242,9 @@ static int fft_fourstep(Ctx* c, const void* in, bool in_is_real, int64_t rows, i
 
 // ---- two-pass four-step (round 2): the transposes of fft_fourstep folded into the transforms.
 // k_fft_tile takes a tile of T sequences of n <= 2048 points into LDS (element (position p, sequence t) at p * T + t), runs an
-// in-place decimation-in-frequency FFT on all of them at once (one radix-2 stage when log2 n is odd, then radix-4 stages; a
-// thread owns butterfly j of sequence t with t fastest, so every stage reads and writes LDS in runs of T consecutive elements),
+// in-place decimation-in-frequency FFT on all of them at once (one radix-2 stage when log2 n is odd, then radix-16 stages — two
+// radix-4 levels fused in registers — and a closing radix-4 stage when four points are left; a thread owns butterfly j of
+// sequence t with t fastest, so every stage reads and writes LDS in runs of T consecutive elements),
 // and leaves through a position table (the output of frequency k sits at the digit-reversed position).  Global accesses:
 //   pass A  sequences = columns n2 of the [K1][K2] view: every position is a run of T consecutive elements (T * 8 bytes), the
 //           result goes back the same way with the twiddle w_K^(n2 k1) applied (real input / zero padding / truncation on load)

@@ -717,13 +717,19 @@ int nxsig_stft_mel_sharded_f32(nxsig_group* grp, const float* const* x, int64_t 
   struct Sh { int64_t row0 = 0, rows = 0, in0 = 0, in_len = 0, m0 = 0, frames = 0, count = 0; void* din = nullptr; void* dout = nullptr; int* cell = nullptr; };
   std::vector<Sh> sh(nl);
   int rc = NXSIG_OK;
-  auto cleanup = [&]() {
-    for (size_t i = 0; i < nl; ++i) {
-      if (sh[i].din) (void)nxsig_free(g->m[i].ctx, sh[i].din);
-      if (sh[i].dout) (void)nxsig_free(g->m[i].ctx, sh[i].dout);
+  // host mode's per-member staging buffers go back to their allocators on EVERY exit (the HIP / RCCL error macros return early)
+  struct Staging {
+    Group* g; std::vector<Sh>* sh;
+    ~Staging() {
+      std::string keep = nxsig_last_error();   // nxsig_free resets the thread's message
+      for (size_t i = 0; i < sh->size(); ++i) {
+        if ((*sh)[i].din) (void)nxsig_free(g->m[i].ctx, (*sh)[i].din);
+        if ((*sh)[i].dout) (void)nxsig_free(g->m[i].ctx, (*sh)[i].dout);
+      }
+      (void)set_error(NXSIG_OK, keep);
     }
-  };
-  auto fail = [&](int code) { std::string keep = nxsig_last_error(); cleanup(); return set_error(code, keep); };
+  } staging{g, &sh};
+  auto fail = [&](int code) { return code; };
   // pass 1 on every member: stft -> |.|^2 -> mel bands -> log10 of its shard, running maximum in the member's cell pair
   for (size_t i = 0; i < nl; ++i) {
     Member& mb = g->m[i];
@@ -815,7 +821,6 @@ int nxsig_stft_mel_sharded_f32(nxsig_group* grp, const float* const* x, int64_t 
                                  (size_t)(q.frames * mel_bins) * sizeof(float)))) return fail(rc);
     }
   }
-  cleanup();
   return NXSIG_OK;
   NXSIG_API_END
 }

@@ -212,12 +212,19 @@ static int launch_fir_long(Ctx* c, const FirLaunch& a) {
   return NXSIG_OK;
 }
 
-int launch_fir(Ctx* c, const FirLaunch& a) {
-  if (a.taps > 4096) return launch_fir_long(c, a);
+int fir_row_flags(Ctx* c, int32_t batch, int** out);
+int launch_fir_poison(Ctx* c, const FirLaunch& a);
+int launch_fir(Ctx* c, const FirLaunch& a_in) {
+  if (a_in.taps > 4096) return launch_fir_long(c, a_in);   // one transform per row, like the reference: non-finite rows come out NaN
+  if (a_in.out_len <= 0 || a_in.batch == 0) return NXSIG_OK;
+  FirLaunch a = a_in;
+  int rc = fir_row_flags(c, a.batch, &a.row_flags);
+  if (rc) return rc;
   bool handled = false;
-  int rc = launch_fir_wave(c, a, &handled);
-  if (rc || handled) return rc;
-  return launch_fir_generic(c, a);
+  rc = launch_fir_wave(c, a, &handled);
+  if (rc) return rc;
+  if (!handled && (rc = launch_fir_generic(c, a))) return rc;
+  return launch_fir_poison(c, a);   // rows that held an Inf / NaN sample: NaN from end to end (FirLaunch::row_flags)
 }
 
 struct DeviceGuard {

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_pow2(StftArgs a) {
   for (int idx = tid; idx < total; idx += kThreads) {
     const int f = idx >> a.logK;
     if (m0 + f >= a.g.M) break;
-    float2 v = R[idx];
+    float2 v = fft_eps0(R[idx]);  // Nx.fft's clean-up comes before the scaling (:102, :113)
     if (a.has_scale) { v.x = v.x / a.div; v.y = v.y / a.div; }  // :116/:119 true division, like the reference
     z[idx] = v;
   }
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_dft(StftArgs a) {
       idx += k;
       if (idx >= a.K) idx -= a.K;
     }
-    float re = (float)dre, im = (float)dim;
+    float re = fft_eps0((float)dre), im = fft_eps0((float)dim);
     if (a.has_scale) { re = re / a.div; im = im / a.div; }
     z[k] = make_float2(re, im);
   }
@@ -199,6 +199,7 @@ struct FftRowsArgs {
   const float* post_window;
   float post_scale;
   int32_t has_post_scale;
+  int32_t clean;            // 1: Nx.fft / Nx.ifft eps clean-up of the finished transform (0: sub-step of a longer transform)
   float2* out;              // c64[rows][K]
 };
 
@@ -208,6 +209,7 @@ __device__ __forceinline__ float2 fft_epilogue(const FftRowsArgs& a, float2 v, i
     const float invK = 1.0f / (float)a.K;  // exact for powers of two; the DFT path divides instead
     v.x *= invK; v.y *= invK;
   }
+  if (a.clean) v = fft_eps0(v);  // Nx.fft / Nx.ifft clean-up, before whatever the caller multiplies in
   if (a.has_post_scale) { v.x *= a.post_scale; v.y *= a.post_scale; }
   if (a.post_window) { const float w = a.post_window[k]; v.x *= w; v.y *= w; }
   return v;
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_rows_dft(FftRowsArgs a) {
     }
     float2 v = make_float2((float)dre, (float)dim);
     if (INV) { v.x = v.x / (float)a.K; v.y = v.y / (float)a.K; }
+    if (a.clean) v = fft_eps0(v);
     if (a.has_post_scale) { v.x *= a.post_scale; v.y *= a.post_scale; }
     if (a.post_window) { const float w = a.post_window[k]; v.x *= w; v.y *= w; }
     out[k] = v;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_blue(StftBlueArgs b) {
   float2* Y = bluestein_lds<false>(A, Bb, b.t, nuse);
   float2* z = a.z + ((size_t)blockIdx.y * a.g.M + m) * a.K;
   for (int k = tid; k < a.K; k += kThreads) {
-    float2 v = Y[k];
+    float2 v = fft_eps0(Y[k]);
     if (a.has_scale) { v.x = v.x / a.div; v.y = v.y / a.div; }
     z[k] = v;
   }
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_rows_blue(FftBlueArgs b) {
   float2* Y = bluestein_lds<INV>(A, Bb, b.t, nuse);
   float2* out = a.out + (size_t)r * a.K;
   for (int k = tid; k < a.K; k += kThreads) {
-    float2 v = Y[k];
+    float2 v = a.clean ? fft_eps0(Y[k]) : Y[k];
     if (a.has_post_scale) { v.x *= a.post_scale; v.y *= a.post_scale; }
     if (a.post_window) { const float w = a.post_window[k]; v.x *= w; v.y *= w; }
     out[k] = v;
@@ -475,7 +478,10 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
       __syncthreads();
     }
     if (tid == 0) {
-      float fr = (float)(red[0] / (double)a.N), fi = (float)(red[kThreads] / (double)a.N);  // Nx.ifft rounds to c64
+      double dr = red[0] / (double)a.N, di = red[kThreads] / (double)a.N;
+      if (fabs(dr) <= 1.0e-10) dr = 0.0;   // Nx.ifft's eps clean-up, on the double result like the reference (App. A rule 7)
+      if (fabs(di) <= 1.0e-10) di = 0.0;
+      float fr = (float)dr, fi = (float)di;  // Nx.ifft rounds to c64
       if (a.has_scale) { fr *= a.scale; fi *= a.scale; }
       const float w = a.window[j];
       fr *= w; fi *= w;
@@ -511,7 +517,41 @@ struct FirArgs {
   const float2* H;          // device c64[B] = FFT_B(h zero-padded), computed on the host in double
   const float2* tw;
   float* y;
+  int* row_flags;           // FirLaunch::row_flags
 };
+
+// Last pass of every overlap-save FIR call (see FirLaunch::row_flags): one workgroup per row; a flagged row becomes NaN from
+// end to end, as the reference's single whole-row transform leaves it, and its flag is cleared for the next call.  Unflagged
+// rows cost one load.  (A poisoned row is written by one workgroup: the cold path favours simplicity.)
+__global__ __launch_bounds__(kThreads) void k_fir_poison(int* __restrict__ flags, float* __restrict__ y, int64_t out_len) {
+  const int64_t row = blockIdx.x;
+  if (flags[row] == 0) return;   // uniform across the workgroup
+  float* yr = y + (size_t)row * out_len;
+  const float qnan = __int_as_float(0x7fc00000);
+  for (int64_t i = threadIdx.x; i < out_len; i += kThreads) yr[i] = qnan;
+  __syncthreads();
+  if (threadIdx.x == 0) flags[row] = 0;
+}
+
+int fir_row_flags(Ctx* c, int32_t batch, int** out) {
+  const size_t need = (size_t)batch * sizeof(int);
+  if (c->scratch_bytes[22] < need) {
+    void* p = nullptr;
+    const size_t bytes = need < 4096 ? 4096 : need * 2;
+    int rc = ctx_scratch(c, 22, bytes, &p);
+    if (rc) return rc;
+    NXSIG_HIP_TRY(hipMemsetAsync(p, 0, bytes, c->stream));   // zero between calls: k_fir_poison clears what it consumes
+  }
+  *out = reinterpret_cast<int*>(c->scratch[22]);
+  return NXSIG_OK;
+}
+
+int launch_fir_poison(Ctx* c, const FirLaunch& s) {
+  if (!s.row_flags || s.batch == 0 || s.out_len <= 0) return NXSIG_OK;
+  hipLaunchKernelGGL(k_fir_poison, dim3((unsigned)s.batch), dim3(kThreads), 0, c->stream, s.row_flags, s.y, s.out_len);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
 
 __global__ __launch_bounds__(kThreads) void k_fir_os(FirArgs a) {
   float2* A = reinterpret_cast<float2*>(g_smem);
@@ -522,12 +562,15 @@ __global__ __launch_bounds__(kThreads) void k_fir_os(FirArgs a) {
   const bool have2 = (b2 - a.first_block) < a.nblocks;
   const float* x = a.x + (size_t)blockIdx.y * a.batch_stride;
   const int64_t s1 = b1 * V - (a.taps - 1), s2 = b2 * V - (a.taps - 1);
+  float nfsum = 0.0f;
   for (int t = tid; t < a.B; t += kThreads) {
     const int64_t p1 = s1 + t, p2 = s2 + t;
     const float v1 = (p1 >= 0 && p1 < a.L) ? x[p1] : 0.0f;
     const float v2 = (have2 && p2 >= 0 && p2 < a.L) ? x[p2] : 0.0f;
     A[t] = make_float2(v1, v2);
+    nfsum += v1 * 0.0f + v2 * 0.0f;   // 0 for finite samples, NaN otherwise
   }
+  if (nfsum != nfsum) atomicOr(a.row_flags + blockIdx.y, 1);   // see FirLaunch::row_flags
   __syncthreads();
   float2* R = lds_fft_pow2<false>(A, Bf, a.B, a.logB, 1, a.tw);
   float2* O = (R == A) ? Bf : A;
@@ -539,9 +582,9 @@ __global__ __launch_bounds__(kThreads) void k_fir_os(FirArgs a) {
   for (int t = a.taps - 1 + tid; t < a.B; t += kThreads) {
     const float2 v = Y[t];
     const int64_t n1 = b1 * V + (t - (a.taps - 1)) - a.out_start;
-    if (n1 >= 0 && n1 < a.out_len) y[n1] = v.x * invB;
+    if (n1 >= 0 && n1 < a.out_len) y[n1] = fft_eps0(v.x * invB);  // the Nx.ifft clean-up of fftconvolve (convolution.ex:282)
     const int64_t n2 = n1 + V;
-    if (have2 && n2 >= 0 && n2 < a.out_len) y[n2] = v.y * invB;
+    if (have2 && n2 >= 0 && n2 < a.out_len) y[n2] = fft_eps0(v.y * invB);
   }
 }
 
@@ -999,22 +1042,23 @@ int launch_stft_generic(Ctx* c, const StftLaunch& s) {
 }
 
 int launch_fft_rows_wave(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse,
-                         const float* post_window, float post_scale, bool has_post_scale, float2* out, bool* handled);
+                         const float* post_window, float post_scale, bool has_post_scale, float2* out, bool* handled, bool clean);
 
 static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse,
-                           const float* post_window, float post_scale, bool has_post_scale, float2* out) {
+                           const float* post_window, float post_scale, bool has_post_scale, float2* out, bool clean = true) {
   if (rows == 0) return NXSIG_OK;
   FftRowsArgs a;
   a.in = in; a.in_is_real = in_is_real ? 1 : 0; a.rows = rows; a.n_in = n_in; a.K = K;
   a.post_window = post_window; a.post_scale = post_scale; a.has_post_scale = has_post_scale ? 1 : 0; a.out = out;
+  a.clean = clean ? 1 : 0;
   {  // K = 1024 / 2048 / 4096: one wave per row on the wave-private cores (kernels_wave_rows.hip)
     bool handled = false;
-    int rcw = launch_fft_rows_wave(c, in, in_is_real, rows, n_in, K, inverse, post_window, post_scale, has_post_scale, out, &handled);
+    int rcw = launch_fft_rows_wave(c, in, in_is_real, rows, n_in, K, inverse, post_window, post_scale, has_post_scale, out, &handled, clean);
     if (rcw || handled) return rcw;
   }
   if ((is_pow2(K) && (K > kMaxLdsPow2 || K >= fft_tiled_min())) || (!is_pow2(K) && K > 4096)) {
     // beyond the LDS-resident kernels: four-step / Bluestein rows in HBM (kernels_nd.hip), then the istft epilogue if any
-    int rcb = launch_fft_big(c, in, in_is_real, rows, n_in, K, inverse, out);
+    int rcb = launch_fft_big(c, in, in_is_real, rows, n_in, K, inverse, out, clean);
     if (rcb) return rcb;
     return launch_rows_post(c, out, rows, K, post_window, post_scale, has_post_scale, 1.0f, false);
   }
@@ -1062,8 +1106,8 @@ static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows
   return NXSIG_OK;
 }
 
-int launch_fft(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse, float2* out) {
-  return launch_fft_rows(c, in, in_is_real, rows, n_in, K, inverse, nullptr, 1.0f, false, out);
+int launch_fft(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse, float2* out, bool clean) {
+  return launch_fft_rows(c, in, in_is_real, rows, n_in, K, inverse, nullptr, 1.0f, false, out, clean);
 }
 
 // generic istft: rows IFFT (x scale x window) into a scratch frames tensor, then the deterministic OLA + normaliser
@@ -1217,7 +1261,7 @@ int launch_fir_generic(Ctx* c, const FirLaunch& s) {
   a.first_block = s.out_start / V;
   const int64_t last_block = (s.out_start + s.out_len - 1) / V;
   a.nblocks = last_block - a.first_block + 1;
-  a.out_start = s.out_start; a.out_len = s.out_len; a.y = s.y;
+  a.out_start = s.out_start; a.out_len = s.out_len; a.y = s.y; a.row_flags = s.row_flags;
   const size_t lds = (size_t)2 * B * sizeof(float2);
   rc = ensure_lds(k_fir_os, lds);
   if (rc) return rc;

@@ -44,6 +44,7 @@ struct TrArgs {
   int64_t plane_stride;   // elements between consecutive [R][C] planes of the input
   int64_t plane_valid;    // plane elements with linear index r * C + c >= plane_valid read as zero (zero-pad / truncate)
   int32_t tw_mode;        // 0 none, 1 multiply by w_K^(r c), 2 by its conjugate
+  int32_t clean;          // 1: this transposition delivers a finished transform: Nx.fft / Nx.ifft eps clean-up on the way out
   int64_t K;
   const float2* tw_lo;    // [8192]  w_K^t
   const float2* tw_hi;    // [K / 8192] w_K^(8192 s)
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(kT) void k_transpose(TrArgs a) {
         if (a.tw_mode == 2) w.y = -w.y;
         v = ndmul(v, w);
       }
+      if (a.clean) v = fft_eps0(v);
       op[(int64_t)c * a.R + r] = v;
     }
   }
@@ -89,11 +91,12 @@ __global__ __launch_bounds__(kT) void k_transpose(TrArgs a) {
 
 static int launch_transpose(Ctx* c, const void* in, bool in_is_real, int64_t outer, int R, int C, int64_t plane_stride,
                             int64_t plane_valid, float2* out, int tw_mode = 0, int64_t K = 0, const float2* lo = nullptr,
-                            const float2* hi = nullptr) {
+                            const float2* hi = nullptr, bool clean = false) {
   if (outer == 0 || R == 0 || C == 0) return NXSIG_OK;
   TrArgs a;
   a.in = in; a.out = out; a.R = R; a.C = C; a.in_is_real = in_is_real ? 1 : 0;
   a.plane_stride = plane_stride; a.plane_valid = plane_valid; a.tw_mode = tw_mode; a.K = K; a.tw_lo = lo; a.tw_hi = hi;
+  a.clean = clean ? 1 : 0;
   const int64_t tiles = (int64_t)((C + kTile - 1) / kTile) * ((R + kTile - 1) / kTile);
   if (tiles > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "transpose: plane too large for one launch");
   for (int64_t o0 = 0; o0 < outer; o0 += 65535) {  // gridDim.y limit
@@ -144,13 +147,13 @@ __global__ __launch_bounds__(kT) void k_mul_rowtable(float2* __restrict__ a, con
 }
 // out[r][k] = conj^INV(A[r][k] * chirp[k]) (/ K for the inverse), k < K
 __global__ __launch_bounds__(kT) void k_blue_out(const float2* __restrict__ A, int64_t rows, int64_t K, int64_t P,
-                                                 const float2* __restrict__ chirp, int inv, float2* __restrict__ out) {
+                                                 const float2* __restrict__ chirp, int inv, int clean, float2* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (i >= rows * K) return;
   const int64_t r = i / K, k = i - r * K;
   float2 v = ndmul(A[r * P + k], chirp[k]);
   if (inv) { v.y = -v.y; v.x = v.x / (float)K; v.y = v.y / (float)K; }
-  out[i] = v;
+  out[i] = clean ? fft_eps0(v) : v;
 }
 // istft epilogue / stft scaling on finished rows: v = (v * scale) * window[k]   or   v = v / div
 __global__ __launch_bounds__(kT) void k_rows_post(float2* __restrict__ a, int64_t total, int64_t K, const float* __restrict__ window,
@@ -211,10 +214,10 @@ static void host_fft_big(std::vector<double>& re, std::vector<double>& im) {
 
 static bool nd_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
-int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out);
+int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out, bool clean);
 
 // power-of-two K = K1 K2 > 8192 (both <= 8192): X[k1 + K1 k2] = sum_n2 [w_K^(n2 k1) sum_n1 x[K2 n1 + n2] w_K1^(n1 k1)] w_K2^(n2 k2)
-static int fft_fourstep(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
+static int fft_fourstep(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out, bool clean) {
   int lg = 0;
   while (((int64_t)1 << lg) < K) ++lg;
   const int K1 = 1 << ((lg + 1) / 2), K2 = (int)(K / K1);
@@ -231,13 +234,13 @@ static int fft_fourstep(Ctx* c, const void* in, bool in_is_real, int64_t rows, i
   // (a) [K1][K2] -> [K2][K1]   (zero-pad / truncate / real -> complex on the way in)
   if ((rc = launch_transpose(c, in, in_is_real, rows, K1, K2, n_in, n_in < K ? n_in : K, A))) return rc;
   // (b) K1-point transforms over n1
-  if ((rc = launch_fft(c, A, false, rows * K2, K1, K1, inverse, B))) return rc;
+  if ((rc = launch_fft(c, A, false, rows * K2, K1, K1, inverse, B, false))) return rc;
   // (c) twiddle w_K^(n2 k1) and back to [K1][K2]
   if ((rc = launch_transpose(c, B, false, rows, K2, K1, (int64_t)K, (int64_t)K, A, inverse ? 2 : 1, K, lo, hi))) return rc;
   // (d) K2-point transforms over n2
-  if ((rc = launch_fft(c, A, false, rows * K1, K2, K2, inverse, B))) return rc;
-  // (e) Z[k1][k2] -> natural order X[k1 + K1 k2]
-  return launch_transpose(c, B, false, rows, K1, K2, (int64_t)K, (int64_t)K, out);
+  if ((rc = launch_fft(c, A, false, rows * K1, K2, K2, inverse, B, false))) return rc;
+  // (e) Z[k1][k2] -> natural order X[k1 + K1 k2]  (+ the eps clean-up of the finished transform)
+  return launch_transpose(c, B, false, rows, K1, K2, (int64_t)K, (int64_t)K, out, 0, 0, nullptr, nullptr, clean);
 }
 
 // ---- two-pass four-step (round 2): the transposes of fft_fourstep folded into the transforms.
@@ -265,6 +268,7 @@ struct FtArgs {
   int64_t nseq;             // sequences per batch row (a multiple of T)
   int32_t inverse;
   float scale;
+  int32_t clean;            // 1: this pass delivers the finished transform: Nx.fft / Nx.ifft eps clean-up after the scale
   int32_t tw_mode;          // 1: multiply (sequence s, frequency k) by w_K^(s k) (conjugated for the inverse)
   const float2 *tw_lo, *tw_hi, *tw_n;   // two-level w_K tables; w_n^j, j < n
 };
@@ -420,11 +424,12 @@ __global__ __launch_bounds__(NT) void k_fft_tile(FtArgs a) {
       v = ndmul(v, w);
     }
     v.x *= a.scale; v.y *= a.scale;
+    if (a.clean) v = fft_eps0(v);
     ob[sq * a.out_seq_stride + (int64_t)k * a.out_pos_stride] = v;
   }
 }
 
-static int fft_fourstep_tiled(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
+static int fft_fourstep_tiled(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out, bool clean) {
   int lg = 0;
   while (((int64_t)1 << lg) < K) ++lg;
   const int lg1 = (lg + 1) / 2, lg2 = lg - lg1;
@@ -449,7 +454,7 @@ static int fft_fourstep_tiled(Ctx* c, const void* in, bool in_is_real, int64_t r
   // pass A: columns n2, K1 points each
   a.in = in; a.out = Y; a.n = K1; a.lg = lg1; a.lgT = tile_lg(K1, K2); a.in_real = in_is_real ? 1 : 0; a.load_along = 0;
   a.in_seq_stride = 1; a.in_pos_stride = K2; a.in_row_stride = n_in; a.n_valid = n_in < K ? n_in : K;
-  a.out_seq_stride = 1; a.out_pos_stride = K2; a.out_row_stride = K; a.nseq = K2; a.inverse = inverse ? 1 : 0; a.scale = 1.0f;
+  a.out_seq_stride = 1; a.out_pos_stride = K2; a.out_row_stride = K; a.nseq = K2; a.inverse = inverse ? 1 : 0; a.scale = 1.0f; a.clean = 0;
   a.tw_mode = 1; a.tw_lo = lo; a.tw_hi = hi; a.tw_n = tw1;
   auto go = [&](int64_t blocks, size_t lds) -> int {
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: too many tiles for one launch");
@@ -467,7 +472,7 @@ static int fft_fourstep_tiled(Ctx* c, const void* in, bool in_is_real, int64_t r
   // pass B: rows k1, K2 points each; X[k1 + K1 k2]
   a.in = Y; a.out = out; a.n = K2; a.lg = lg2; a.lgT = tile_lg(K2, K1); a.in_real = 0; a.load_along = 1;
   a.in_seq_stride = K2; a.in_pos_stride = 1; a.in_row_stride = K; a.n_valid = K;
-  a.out_seq_stride = 1; a.out_pos_stride = K1; a.out_row_stride = K; a.nseq = K1; a.scale = inverse ? 1.0f / (float)K : 1.0f;
+  a.out_seq_stride = 1; a.out_pos_stride = K1; a.out_row_stride = K; a.nseq = K1; a.scale = inverse ? 1.0f / (float)K : 1.0f; a.clean = clean ? 1 : 0;
   a.tw_mode = 0; a.tw_n = tw2;
   if ((rc = go(rows * (K1 >> a.lgT), ((size_t)K2 * ((1 << a.lgT) + 1)) * sizeof(float2)))) return rc;
   return NXSIG_OK;
@@ -494,7 +499,7 @@ static int fft_columns_tiled(Ctx* c, const void* src, bool src_real, int64_t out
   a.in = src; a.out = dst; a.n = (int)K; a.lg = lg; a.lgT = lgT; a.in_real = src_real ? 1 : 0; a.load_along = 0;
   a.in_seq_stride = 1; a.in_pos_stride = inner; a.in_row_stride = na * inner; a.n_valid = (na < K ? na : K) * inner;
   a.out_seq_stride = 1; a.out_pos_stride = inner; a.out_row_stride = K * inner; a.nseq = inner;
-  a.inverse = inverse ? 1 : 0; a.scale = inverse ? 1.0f / (float)K : 1.0f;
+  a.inverse = inverse ? 1 : 0; a.scale = inverse ? 1.0f / (float)K : 1.0f; a.clean = 1;
   a.tw_mode = 0; a.tw_lo = nullptr; a.tw_hi = nullptr; a.tw_n = tw;
   const size_t lds = ((size_t)K * ((1 << lgT) + 1)) * sizeof(float2);
   if (lds > 64 * 1024) NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_tile<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -505,7 +510,7 @@ static int fft_columns_tiled(Ctx* c, const void* src, bool src_real, int64_t out
 }
 
 // any other K: chirp-z through a power-of-two convolution of P >= 2K - 1 points
-static int fft_bluestein_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
+static int fft_bluestein_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out, bool clean) {
   if (K > ((int64_t)1 << 22)) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: non-power-of-two lengths beyond 2^22 are not supported");
   int64_t P = 1;
   while (P < 2 * K - 1) P <<= 1;
@@ -542,11 +547,11 @@ static int fft_bluestein_big(Ctx* c, const void* in, bool in_is_real, int64_t ro
   float2* B = reinterpret_cast<float2*>(s2);
   hipLaunchKernelGGL(k_blue_in, dim3(blocks_for(rows * P)), dim3(kT), 0, c->stream, in, in_is_real ? 1 : 0, rows, n_in, K, P, chirp, inverse ? 1 : 0, A);
   NXSIG_HIP_TRY(hipGetLastError());
-  if ((rc = launch_fft_big(c, A, false, rows, P, P, false, B))) return rc;
+  if ((rc = launch_fft_big(c, A, false, rows, P, P, false, B, false))) return rc;
   hipLaunchKernelGGL(k_mul_rowtable, dim3(blocks_for(rows * P)), dim3(kT), 0, c->stream, B, Bf, rows, P);
   NXSIG_HIP_TRY(hipGetLastError());
-  if ((rc = launch_fft_big(c, B, false, rows, P, P, true, A))) return rc;  // the inverse rows include the 1 / P
-  hipLaunchKernelGGL(k_blue_out, dim3(blocks_for(rows * K)), dim3(kT), 0, c->stream, A, rows, K, P, chirp, inverse ? 1 : 0, out);
+  if ((rc = launch_fft_big(c, B, false, rows, P, P, true, A, false))) return rc;  // the inverse rows include the 1 / P
+  hipLaunchKernelGGL(k_blue_out, dim3(blocks_for(rows * K)), dim3(kT), 0, c->stream, A, rows, K, P, chirp, inverse ? 1 : 0, clean ? 1 : 0, out);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
 }
@@ -557,20 +562,20 @@ int64_t fft_tiled_min() {
 }
 
 // rows of any length.  Lengths the LDS-resident kernels cover go straight to launch_fft.
-int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out) {
+int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out, bool clean) {
   if (rows == 0) return NXSIG_OK;
   if (K < 1 || n_in < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fft: lengths must be >= 1");
   const bool small = (nd_is_pow2(K) && K <= 8192 && K < fft_tiled_min()) || (!nd_is_pow2(K) && K <= 4096);
   if (small) {
     if (n_in > 0x7fffffff) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: rows longer than 2^31");
-    return launch_fft(c, in, in_is_real, rows, (int32_t)n_in, (int32_t)K, inverse, out);
+    return launch_fft(c, in, in_is_real, rows, (int32_t)n_in, (int32_t)K, inverse, out, clean);
   }
   if (nd_is_pow2(K)) {
     static const bool tiled = [] { const char* v = std::getenv("NXSIG_FFT_TILED"); return !(v && std::atoi(v) == 0); }();
-    if (tiled && K <= ((int64_t)1 << 20)) return fft_fourstep_tiled(c, in, in_is_real, rows, n_in, K, inverse, out);
-    return fft_fourstep(c, in, in_is_real, rows, n_in, K, inverse, out);
+    if (tiled && K <= ((int64_t)1 << 20)) return fft_fourstep_tiled(c, in, in_is_real, rows, n_in, K, inverse, out, clean);
+    return fft_fourstep(c, in, in_is_real, rows, n_in, K, inverse, out, clean);
   }
-  return fft_bluestein_big(c, in, in_is_real, rows, n_in, K, inverse, out);
+  return fft_bluestein_big(c, in, in_is_real, rows, n_in, K, inverse, out, clean);
 }
 
 int launch_rows_post(Ctx* c, float2* a, int64_t rows, int64_t K, const float* window, float scale, bool has_scale, float div, bool has_div) {

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
         v2f f[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          v2f v = zz[e][i * QS + qq] * invK;
+          v2f v = fft_eps0(zz[e][i * QS + qq] * invK);  // Nx.ifft's clean-up (:609) precedes scale and window
           if (SCALE) v = v * a.scale;
           f[i] = v * (wv[e][i * QS + qq] * live);
         }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_4k(IstftWaveArgs a) {
         for (int i = 0; i < R; ++i) {
           const int off = i * HOPC + 128 * sl;           // 128 q + 1024 mm of segment i, slot sl
           const int mm = off / 1024, q = (off % 1024) / 128;
-          v2f v = y[mm][e][q] * invK;
+          v2f v = fft_eps0(y[mm][e][q] * invK);
           if (SCALE) v = v * a.scale;
           const v2f wp = s_wv[lane + 64 * q + 512 * mm];   // (w[n], w[n + 1]) for n = 2 lane + 128 q + 1024 mm
           f[i] = v * ((e ? wp.y : wp.x) * live);
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_4k(IstftWaveArgs a) {
 // core returns sample n = lane + 64 q of frame 0 in zz[0][q] and of frame 1 in zz[1][q]: the overlap-add between the
 // two frames and with the pending sums stays in registers for every hop that is a multiple of 64.
 template <int K, int R, bool SCALE, int W>
-__global__ __launch_bounds__(64 * W) void k_istft_wave_half(IstftWaveArgs a) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_istft_wave_half(IstftWaveArgs a) {
   constexpr int NH = K / 2;              // frame length (= fft_length)
   constexpr int R3 = K / 256;
   constexpr int NQ = K / 128;            // samples per lane per frame (n = lane + 64 q, q < NQ)
@@ -333,22 +333,54 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_half(IstftWaveArgs a) {
     for (int q = 0; q < NQ; ++q) { r0[q] = __builtin_nontemporal_load(p0 + 64 * q); r1[q] = __builtin_nontemporal_load(p1 + 64 * q); }
   };
   v2f d[2 * NQ];
+  // combine() also tells whether the pair holds a non-finite bin (the sum of the bins is finite iff they all are; an overflowing
+  // sum merely sends a finite pair down the solo route, which computes the same frames)
+  bool nf_next = false;
   auto combine = [&]() {
+    v2f sum = v2f{0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
+      sum += r0[q] + r1[q];
       const v2f t = wcmul(r1[q], v2f{tw_re[q], tw_im[q]});
       d[q] = r0[q] + t;
       d[q + NQ] = r0[q] - t;
     }
+    nf_next = wave_any_nonfinite(sum.x, sum.y);
   };
   issue_loads(m_start);
   combine();
 
   for (int64_t m = m_start; m < j1; m += 2) {
-    issue_loads(m + 2 < j1 ? m + 2 : m);
-    __builtin_amdgcn_sched_barrier(0);
+    const bool nf = nf_next;
     v2f zz[2][NQ];
-    wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
+    if (__builtin_expect(nf, 0)) {
+      // The reference inverts every frame on its own (Nx.ifft row by row, lib/nx_signal.ex:609): a non-finite bin reaches only
+      // the samples of ITS frame.  The pair leaves the shared transform: frame 1 alone (C0 = 0) gives zz[1], frame 0 alone
+      // (C1 = 0) gives zz[0].  Cold path, arranged so that it needs no more registers than the streaming path (or the whole
+      // kernel drops from 3 to 2 waves per SIMD: measured -12 %): the pair's spectra are read again from memory, d[] is reused,
+      // and the next pair's loads are issued only afterwards (the prefetch registers are free during the two transforms).
+      const int64_t last = a.M - 1;
+      const v2f* p0 = zrow + (size_t)(m < last ? m : last) * NH;
+      const v2f* p1 = zrow + (size_t)(m + 1 < last ? m + 1 : last) * NH;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { const v2f t = wcmul(p1[64 * q], v2f{tw_re[q], tw_im[q]}); d[q] = t; d[q + NQ] = v2f{0.f, 0.f} - t; }
+      wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
+      v2f keep[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) keep[q] = zz[1][q];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { d[q] = p0[64 * q]; d[q + NQ] = d[q]; }
+      wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) zz[1][q] = keep[q];
+      __builtin_amdgcn_sched_barrier(0);
+      issue_loads(m + 2 < j1 ? m + 2 : m);
+    } else {
+      issue_loads(m + 2 < j1 ? m + 2 : m);
+      __builtin_amdgcn_sched_barrier(0);
+      wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
     combine();
     __builtin_amdgcn_sched_barrier(0);
@@ -365,7 +397,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_half(IstftWaveArgs a) {
         v2f f[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          v2f v = zz[e][i * QS + qq] * invK;
+          v2f v = fft_eps0(zz[e][i * QS + qq] * invK);
           if (SCALE) v = v * a.scale;
           f[i] = v * (wv[i * QS + qq] * live);
         }
@@ -394,7 +426,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_half(IstftWaveArgs a) {
 // bit-stable; 16-byte LDS reads, no read-modify-write chains).  The first J hop positions are normalised and stored
 // with 16-byte stores; the following N - hop positions become the carry of the next unit (a small LDS strip per wave).
 template <int K, int J, int R, bool SCALE, int W>
-__global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_istft_wave_quad(IstftWaveArgs a) {
   constexpr int NJ = K / J;              // frame length (= fft_length)
   constexpr int P = K / 64;
   constexpr int PJ = P / J;              // bins per lane per frame: k0 = lane + 64 s', s' < PJ
@@ -446,14 +478,18 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
     }
   };
   v2f d[P];
+  bool nf_next = false;   // the unit just packed holds a non-finite bin (see k_istft_wave_half)
   auto pack = [&]() {   // d[s' + PJ m] = sum_j (C_j[k0] w_K^(j k0)) w_J^(jm)   (the 1/J rides in invK)
+    v2f sum = v2f{0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < PJ; ++s) {
       v2f t[J];
       t[0] = r[0][s];
+      sum += t[0];
 #pragma unroll
       for (int j = 1; j < J; ++j) {
         const v2f w = s_twQ[(j - 1) * NJ + lane + 64 * s];
+        sum += r[j][s];
         t[j] = wcmul(r[j][s], v2f{w.x, -w.y});
       }
       if (J == 4) dft4<false>(t[0], t[1], t[2], t[3]);
@@ -461,15 +497,48 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
 #pragma unroll
       for (int m = 0; m < J; ++m) d[s + PJ * m] = t[m];
     }
+    nf_next = wave_any_nonfinite(sum.x, sum.y);
   };
   issue_loads(us);
   pack();
 
   for (int64_t u = us; u < u1; ++u) {
-    issue_loads(u + 1 < u1 ? u + 1 : u);  // unconditional prefetch keeps the loop branch-free
-    __builtin_amdgcn_sched_barrier(0);
+    const bool nf = nf_next;
     v2f zz[2][NQ];
-    wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
+    if (__builtin_expect(nf, 0)) {
+      // solo route (see k_istft_wave_half): every frame of the unit alone through the transform, the other J - 1 sequences zero;
+      // element (par, q) of the result belongs to frame (2 lane + par) mod J and is taken from that frame's pass
+#pragma nounroll
+      for (int js = 0; js < J; ++js) {
+        const int64_t m = u * J + js;
+        const v2f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * NJ;
+        v2f zs[2][NQ];   // (d[] is free: pack() below rebuilds it for the next unit)
+#pragma unroll
+        for (int s = 0; s < PJ; ++s) {
+          v2f c = pz[64 * s];
+          if (js > 0) { const v2f w = s_twQ[(js - 1) * NJ + lane + 64 * s]; c = wcmul(c, v2f{w.x, -w.y}); }
+          // forward radix-J butterfly of a sequence that is zero except at j = js: t[mm] = c w_J^(js mm)
+#pragma unroll
+          for (int mm = 0; mm < J; ++mm) {
+            const int ph = (js * mm) % J;                         // w_J^ph = exp(-2 pi i ph / J)
+            const float ang = -6.283185307179586f * (float)ph / (float)J;
+            d[s + PJ * mm] = wcmul(c, v2f{__builtin_cosf(ang), __builtin_sinf(ang)});
+          }
+        }
+        wave_fft_core<K, true>(d, zs, xb, s_twB, s_twC, lane);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (js == 0 || (2 * lane + e) % J == js) zz[e][q] = zs[e][q];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      issue_loads(u + 1 < u1 ? u + 1 : u);   // only now: the prefetch registers were free during the J transforms (see _half)
+    } else {
+      issue_loads(u + 1 < u1 ? u + 1 : u);  // unconditional prefetch keeps the loop branch-free
+      __builtin_amdgcn_sched_barrier(0);
+      wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
     pack();
     __builtin_amdgcn_sched_barrier(0);
@@ -482,7 +551,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
       for (int q = 0; q < NQ; ++q) {
         const int i = 2 * lane + e + 128 * q;
         const int j = i % J, n = i / J;
-        v2f v = zz[e][q] * invK;
+        v2f v = fft_eps0(zz[e][q] * invK);
         if (SCALE) v = v * a.scale;
         const float live = (u * J + j) < a.M ? 1.0f : 0.0f;
         xb[j * NJ + n] = v * (s_w[n] * live);
@@ -610,7 +679,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_dbl(IstftWaveArgs a) {
       const int q = qp % NQ;
       const v2f t = s_twH[2 * lane + e + 128 * q];
       const v2f to = wcmul(zo[e][q], t);
-      v2f v = (qp < NQ ? ze[e][q] + to : ze[e][q] - to) * invN;
+      v2f v = fft_eps0((qp < NQ ? ze[e][q] + to : ze[e][q] - to) * invN);
       if (SCALE) v = v * a.scale;
       return v * (s_w[2 * lane + e + 128 * qp] * live);
     };
@@ -658,10 +727,11 @@ struct FirWaveArgs {
   const v2f* twB;
   const v2f* twC;
   float* y;                            // f32[batch][out_len]
+  int* row_flags;                      // FirLaunch::row_flags: a non-finite sample poisons its whole row, like the reference's one transform
 };
 
 int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, int32_t taps, int64_t first_block, int64_t pb_lo,
-                      int64_t dp_per_row, int64_t out_start, int64_t out_len, const float2* H_dev, float* y);  // kernels_wave_fir32.hip
+                      int64_t dp_per_row, int64_t out_start, int64_t out_len, const float2* H_dev, float* y, int* row_flags);  // kernels_wave_fir32.hip
 
 // STREAM = true : interior pairs only, 8-byte vector access, branch-free and software-pipelined like k_stft_wave
 //                 (requires (taps-1) % 128 == 0 and even offsets — checked by the launcher)
@@ -714,7 +784,14 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       }
     };
     v2f zz[2][NQ];  // zz[par][q] = (x1[n], x2[n]), n = 2 lane + par + 128 q
+    // pack() also sums the pair's samples: the sum is finite iff they all are (an overflowing sum of finite samples merely
+    // poisons a row whose outputs overflow anyway) -> FirLaunch::row_flags
+    v2f nfs = v2f{0.f, 0.f};
     auto pack = [&]() {
+      v2f t = r1[0] + r2[0];
+#pragma unroll
+      for (int q = 1; q < NQ; ++q) t += r1[q] + r2[q];
+      nfs = t;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) { zz[0][q] = v2f{r1[q].x, r2[q].x}; zz[1][q] = v2f{r1[q].y, r2[q].y}; }
     };
@@ -723,6 +800,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       const bool more = pr + W < p_end;
       issue_loads(more ? nrow : row, more ? npin : pin);  // unconditional prefetch: branch-free loop
       __builtin_amdgcn_sched_barrier(0);
+      if (wave_any_nonfinite(nfs.x, nfs.y) && lane == 0) atomicOr(a.row_flags + row, 1);
       v2f d[P];
       wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);
 #pragma unroll
@@ -738,8 +816,9 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (128 * q >= tm1) {  // uniform: (taps-1) % 128 == 0
-          ys.st8(v2f{u[0][q].x, u[1][q].x}, lane * 8 + 512 * q - tm1 * 4);
-          ys.st8(v2f{u[0][q].y, u[1][q].y}, lane * 8 + 512 * q - tm1 * 4 + a.V * 4);
+          // fft_eps0: the clean-up Nx.ifft applies to fftconvolve's result (convolution.ex:282)
+          ys.st8(fft_eps0(v2f{u[0][q].x, u[1][q].x}), lane * 8 + 512 * q - tm1 * 4);
+          ys.st8(fft_eps0(v2f{u[0][q].y, u[1][q].y}), lane * 8 + 512 * q - tm1 * 4 + a.V * 4);
         }
       }
       row = nrow; pin = npin;
@@ -759,6 +838,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       const int64_t s1 = b1 * a.V - tm1, s2 = s1 + a.V;
       const int64_t o1 = b1 * a.V - a.out_start - tm1;  // y index of block-1 sample n is o1 + n (n >= taps-1)
       v2f zz[2][NQ];
+      v2f nfs = v2f{0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -768,7 +848,9 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
           const float v1 = (p1 >= a.xlo && p1 < a.xhi) ? xr[p1] : 0.0f;
           const float v2 = (have2 && p2 >= a.xlo && p2 < a.xhi) ? xr[p2] : 0.0f;
           zz[e2][q] = v2f{v1, v2};
+          nfs += zz[e2][q];
         }
+      if (wave_any_nonfinite(nfs.x, nfs.y) && lane == 0) atomicOr(a.row_flags + row, 1);
       v2f d[P];
       wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);
 #pragma unroll
@@ -781,8 +863,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
           const int n = 2 * lane + e2 + 128 * q;
           if (n >= tm1) {
             const int64_t y1 = o1 + n, y2 = y1 + a.V;
-            if (y1 >= 0 && y1 < a.out_len) yr[y1] = zz[e2][q].x;
-            if (have2 && y2 >= 0 && y2 < a.out_len) yr[y2] = zz[e2][q].y;
+            if (y1 >= 0 && y1 < a.out_len) yr[y1] = fft_eps0(zz[e2][q].x);
+            if (have2 && y2 >= 0 && y2 < a.out_len) yr[y2] = fft_eps0(zz[e2][q].y);
           }
         }
     }
@@ -1176,7 +1258,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   Ctx::WaveTables& wt = c->wave_tables[K];
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
-  a.y = s.y;
+  a.y = s.y; a.row_flags = s.row_flags;
   // 8-byte vector access needs every offset even: taps-1 multiple of 128 (=> V even), even strides, aligned bases
   const bool fast8 = ((s.taps - 1) % 128 == 0) && (s.batch_stride % 2 == 0) && (s.out_len % 2 == 0) && (out_start % 2 == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 7) == 0);
@@ -1233,7 +1315,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   if (use32) {  // interior pairs two at a time on the 32 x 32 kernel (kernels_wave_fir32.hip); an odd leftover joins the edge pairs
     a.pb_hi -= (a.pb_hi - a.pb_lo) & 1;
     rc = launch_fir_wave32(c, a.x, s.batch_stride, s.batch, s.taps, a.first_block, a.pb_lo, (a.pb_hi - a.pb_lo) / 2, a.out_start, s.out_len,
-                           reinterpret_cast<const float2*>(Hd), s.y);
+                           reinterpret_cast<const float2*>(Hd), s.y, s.row_flags);
   } else {
     rc = launch(true, a.pb_hi - a.pb_lo);
   }

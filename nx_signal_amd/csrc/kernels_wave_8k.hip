@@ -126,6 +126,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave_8k(Wave8kArgs a) {
         if (m == 3) { o0 = rot135<false>(o0); o1 = rot135<false>(o1); }
         const v4f to = v4f{o0.x, o0.y, o1.x, o1.y};
         v4f lo4 = E + to, hi4 = E - to;
+        lo4 = fft_eps0(lo4); hi4 = fft_eps0(hi4);  // Nx.fft's clean-up (:102) precedes the scaling
         if (SCALE) { lo4 = lo4 / a.div; hi4 = hi4 / a.div; }
         zs.st16(lo4, lane * 16 + 1024 * q + 8192 * m);
         zs.st16(hi4, lane * 16 + 1024 * q + 8192 * m + 32768);

@@ -120,6 +120,7 @@ struct Fir32Args {
   const v2f* H;                        // c64[1024] natural order, pre-scaled by 1/1024
   const v2f* tw;                       // c64[32][32]: w_1024^(k1 n2)
   float* y;
+  int* row_flags;                      // FirLaunch::row_flags
 };
 
 // RLO = (taps - 1) / 32 as a compile-time constant for the common filter lengths (the stores of registers below it vanish at
@@ -162,6 +163,12 @@ __global__ __launch_bounds__(64 * W, 2) void k_fir_wave32(Fir32Args a) {
     v2f d[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) d[r] = nd[r];
+    {  // a non-finite sample poisons its whole row, like the reference's single transform (FirLaunch::row_flags)
+      v2f t = d[0];
+#pragma unroll
+      for (int r = 1; r < 32; ++r) t += d[r];
+      if (wave_any_nonfinite(t.x, t.y) && lane == 0) atomicOr(a.row_flags + row, 1);
+    }
     const bool more = p + W < p_end;
     issue_loads(src_of(more ? nrow : row, more ? nq : q));  // unconditional prefetch keeps the loop branch-free
     __builtin_amdgcn_sched_barrier(0);
@@ -180,11 +187,11 @@ __global__ __launch_bounds__(64 * W, 2) void k_fir_wave32(Fir32Args a) {
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
       if (RLO >= 0) {
-        if (r >= RLO) { ys.st4(d[r].x, base + 128 * r); ys.st4(d[r].y, base2 + 128 * r); }
+        if (r >= RLO) { ys.st4(fft_eps0(d[r].x), base + 128 * r); ys.st4(fft_eps0(d[r].y), base2 + 128 * r); }
       } else {
         const int poison = r >= a.r_lo ? 0 : 0x40000000;   // beyond num_records: the hardware drops the store
-        ys.st4(d[r].x, base + poison + 128 * r);
-        ys.st4(d[r].y, base2 + poison + 128 * r);
+        ys.st4(fft_eps0(d[r].x), base + poison + 128 * r);  // fft_eps0: the Nx.ifft clean-up of fftconvolve (convolution.ex:282)
+        ys.st4(fft_eps0(d[r].y), base2 + poison + 128 * r);
       }
     }
     row = nrow; q = nq;
@@ -194,13 +201,13 @@ __global__ __launch_bounds__(64 * W, 2) void k_fir_wave32(Fir32Args a) {
 
 // stream part of launch_fir_wave_W (kernels_wave.hip): interior pairs [pb_lo, pb_lo + 2 dp_per_row) of every row
 int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, int32_t taps, int64_t first_block, int64_t pb_lo,
-                      int64_t dp_per_row, int64_t out_start, int64_t out_len, const float2* H_dev, float* y) {
+                      int64_t dp_per_row, int64_t out_start, int64_t out_len, const float2* H_dev, float* y, int* row_flags) {
   if (dp_per_row <= 0 || batch <= 0) return NXSIG_OK;
   constexpr int W = 4;
   Fir32Args a;
   a.x = x; a.batch_stride = batch_stride; a.V = 1024 - (taps - 1); a.tm1 = taps - 1; a.r_lo = (taps - 1) / 32; a.first_block = first_block; a.pb_lo = pb_lo;
   a.dp_per_row = dp_per_row; a.total_dp = dp_per_row * batch;
-  a.out_start = out_start; a.out_len = out_len; a.H = reinterpret_cast<const v2f*>(H_dev); a.y = y;
+  a.out_start = out_start; a.out_len = out_len; a.H = reinterpret_cast<const v2f*>(H_dev); a.y = y; a.row_flags = row_flags;
   {
     const uint64_t key = 0xF1320000ull;
     auto hit = c->memo.find(key);

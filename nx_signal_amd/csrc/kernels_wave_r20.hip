@@ -107,6 +107,14 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
     }
     return inside;
   };
+  auto stage_slow = [&](const float* xr, int64_t q0) {
+    const int64_t start = q0 - a.lo;
+    if (a.reflect == 0 && start >= 0 && start + span <= a.L) {   // inside the row but not 16-byte aligned: 4-byte loads
+      for (int i = lane; i < span; i += 64) S[i] = xr[start + i];
+    } else {                                                      // padding / mirror / row end: per-sample bounds
+      for (int i = lane; i < span; i += 64) S[i] = fetch_any(xr, a, q0 + i);
+    }
+  };
   bool have = (p_begin + wave < p_end) ? prefetch(p_begin + wave) : false;
   for (int64_t ui = p_begin + wave; ui < p_end; ui += W) {
     const int64_t row = ui / b.units_per_row;
@@ -119,12 +127,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
       for (int c = 0; c < 10; ++c)
         if (256 * c + 4 * lane < span4) *reinterpret_cast<v4f*>(&S[256 * c + 4 * lane]) = rs[c];
     } else {
-      const int64_t start = q0 - a.lo;
-      if (a.reflect == 0 && start >= 0 && start + span <= a.L) {   // inside the row but not 16-byte aligned: 4-byte loads
-        for (int i = lane; i < span; i += 64) S[i] = xr[start + i];
-      } else {                                                      // padding / mirror / row end: per-sample bounds
-        for (int i = lane; i < span; i += 64) S[i] = fetch_any(xr, a, q0 + i);
-      }
+      stage_slow(xr, q0);
     }
     wave_lds_fence();
     have = (ui + W < p_end) ? prefetch(ui + W) : false;   // next unit's samples travel during this unit's transforms
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
     const int64_t mA = 2 * pair;
     const bool haveB = active && (mA + 1 < a.M);
     v2f v[20];
-    {
+    // sel < 0: the pair rides as frame A + i frame B; sel = 0 / 1: frame A / frame B ALONE as the real part (solo route)
+    auto build = [&](int sel) {
       const float* fa = S + (2 * (g < 3 ? g : 0)) * a.hop + l20;
       const float* fb = fa + a.hop;
 #pragma unroll
@@ -143,11 +147,17 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
         v2f t = v2f{0.f, 0.f};
         if (active && n < nuse) {
           const float w = s_w[n];
-          t = v2f{fa[20 * n1] * w, haveB ? fb[20 * n1] * w : 0.0f};  // exact f32 products like the reference (:101)
+          const float pa = fa[20 * n1] * w, pb = haveB ? fb[20 * n1] * w : 0.0f;  // exact f32 products like the reference (:101)
+          t = sel < 0 ? v2f{pa, pb} : v2f{sel == 0 ? pa : pb, 0.0f};
         }
         v[n1] = t;
       }
-    }
+    };
+    constexpr int NP = SINK == kSinkSpectrum ? 200 : 100;    // bin pairs per frame that reach the sink
+    constexpr int NI = (NP + 63) / 64;
+    v2f pw[3][2][NI];  // MEL: |XA|^2, |XB|^2 of the lane's bin pairs, parked in registers until every lane has read U
+    // transforms + untangle + sink of the unit; sel as above (sel >= 0: only that frame of every pair is stored)
+    auto xform_sink = [&](const int sel) {
     dft20(v);
 #pragma unroll
     for (int k1 = 1; k1 < 20; ++k1) v[k1] = wcmul(v[k1], s_tw[l20 * 20 + k1]);
@@ -172,9 +182,6 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
     // ---- untangle + sink.  All 64 lanes walk the three transforms one after the other: lane takes the bin pairs
     //      p = lane + 64 i (bins 2p, 2p + 1), so a wave instruction stores 1 KiB of one frame's row contiguously
     //      (only the bins below 200 for the mel / magnitude sinks)
-    constexpr int NP = SINK == kSinkSpectrum ? 200 : 100;    // bin pairs per frame that reach the sink
-    constexpr int NI = (NP + 63) / 64;
-    v2f pw[3][2][NI];  // MEL: |XA|^2, |XB|^2 of the lane's bin pairs, parked in registers until every lane has read U
 #pragma unroll
     for (int gg = 0; gg < 3; ++gg) {
       const int64_t pr = 3 * u + gg;
@@ -192,33 +199,64 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
           const int k = 2 * pi;
           const v4f uu = *reinterpret_cast<const v4f*>(&U[k]);
           const v2f p0 = U[k == 0 ? 0 : KB - k], p1 = U[KB - 1 - k];
-          v4f xa = v4f{uu.x + p0.x, uu.y - p0.y, uu.z + p1.x, uu.w - p1.y} * 0.5f;
-          v4f xv = v4f{uu.y + p0.y, p0.x - uu.x, uu.w + p1.y, p1.x - uu.z} * 0.5f;
+          v4f xa = fft_eps0(v4f{uu.x + p0.x, uu.y - p0.y, uu.z + p1.x, uu.w - p1.y} * 0.5f);  // Nx.fft's clean-up (:102)
+          v4f xv = fft_eps0(v4f{uu.y + p0.y, p0.x - uu.x, uu.w + p1.y, p1.x - uu.z} * 0.5f);
           if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
+          const bool stA = sel <= 0, stB = hb && sel != 0;      // solo rounds: the transform's real part is frame A (sel 0) / B (sel 1)
+          if (sel == 1) xv = xa;
           if (SINK == kSinkSpectrum) {
-            __builtin_nontemporal_store(xa, (gv4f*)(zA + k));
-            if (hb) __builtin_nontemporal_store(xv, (gv4f*)(zB + k));
+            if (stA) __builtin_nontemporal_store(xa, (gv4f*)(zA + k));
+            if (stB) __builtin_nontemporal_store(xv, (gv4f*)(zB + k));
           } else {
             const v2f pa = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};
             const v2f pb = v2f{xv.x * xv.x + xv.y * xv.y, xv.z * xv.z + xv.w * xv.w};
             if (MEL) { pw[gg][0][i] = pa; pw[gg][1][i] = pb; }
             else if (b.mag_kind == 3) {   // one-sided complex rows: the same values the spectrum sink stores, bins below 200 only
               float* o = b.out + (((size_t)row * a.M + m0) * HALF + k) * 2;
-              __builtin_nontemporal_store(xa, (gv4f*)o);
-              if (hb) __builtin_nontemporal_store(xv, (gv4f*)(o + 2 * HALF));
+              if (stA) __builtin_nontemporal_store(xa, (gv4f*)o);
+              if (stB) __builtin_nontemporal_store(xv, (gv4f*)(o + 2 * HALF));
             } else {
               const v2f va = b.mag_kind == 1 ? pa : v2f{__builtin_sqrtf(pa.x), __builtin_sqrtf(pa.y)};
               const v2f vb = b.mag_kind == 1 ? pb : v2f{__builtin_sqrtf(pb.x), __builtin_sqrtf(pb.y)};
               float* o = b.out + ((size_t)row * a.M + m0) * HALF + k;
-              __builtin_nontemporal_store(va, (gv2f*)o);
-              float mx = va.x > va.y ? va.x : va.y;
-              if (hb) { __builtin_nontemporal_store(vb, (gv2f*)(o + HALF)); mx = vb.x > mx ? vb.x : mx; mx = vb.y > mx ? vb.y : mx; }
+              float mx = -3.0e38f;
+              if (stA) { __builtin_nontemporal_store(va, (gv2f*)o); mx = va.x > va.y ? va.x : va.y; }
+              if (stB) { __builtin_nontemporal_store(vb, (gv2f*)(o + HALF)); mx = vb.x > mx ? vb.x : mx; mx = vb.y > mx ? vb.y : mx; }
               vmax = mx > vmax ? mx : vmax;
             }
           }
         }
       }
     }
+    };  // xform_sink
+    // ---- non-finite samples: the reference transforms every frame alone (lib/nx_signal.ex:94-102), so an Inf / NaN reaches only
+    // the frames that contain it.  A unit whose windowed samples are not all finite leaves the paired route: its frames A, then
+    // (samples re-staged) its frames B, ride alone as real parts.  The log-mel sink needs none of this: there a non-finite
+    // |z|^2 poisons the whole tensor through reduce_max (:511).
+    build(-1);
+    bool solo = false;
+    if (!MEL) {
+      v2f t = v[0];
+#pragma unroll
+      for (int n1 = 1; n1 < 20; ++n1) t += v[n1];
+      const bool nf = ((__float_as_uint(t.x) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(t.y) & 0x7f800000u) == 0x7f800000u);
+      solo = __builtin_amdgcn_ballot_w64(nf) != 0;
+    }
+    if (solo) {
+#pragma nounroll
+      for (int sel = 0; sel < 2; ++sel) {
+        if (sel == 1) {
+          wave_lds_fence();      // round A's partner reads are done
+          stage_slow(xr, q0);    // the exchange overwrote the samples
+          wave_lds_fence();
+        }
+        build(sel);
+        xform_sink(sel);
+      }
+    } else {
+      xform_sink(-1);
+    }
+    // (MEL: pw[][][] is filled by xform_sink(-1))
     if (MEL) {
       wave_lds_fence();                          // every partner read of U is done: the buffer becomes the power spectra
       float* mags = reinterpret_cast<float*>(buf);  // frame f of the unit (f = 2 g + {0, 1}) at mags[f * 200 + k]
@@ -459,7 +497,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_r20(IstftR20Args a) {
 #pragma unroll
       for (int k2 = 0; k2 < 20; ++k2) {
         const int n = l20 + 20 * k2;
-        v2f x = v2f{v[k2].x, -v[k2].y} * invK;
+        v2f x = fft_eps0(v2f{v[k2].x, -v[k2].y} * invK);  // Nx.ifft's clean-up (:609) precedes scale and window
         if (SCALE) x = x * a.scale;
         buf[g * KB + n] = x * (s_w[n] * live);
       }

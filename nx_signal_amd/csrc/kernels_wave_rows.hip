@@ -21,6 +21,7 @@ struct RowsWaveArgs {
   const float* post_window;  // f32[K] or nullptr
   float post_scale;
   int32_t has_post_scale;
+  int32_t clean;             // 1: eps clean-up of the finished transform (0 when the rows are a sub-step of a longer transform)
   int64_t chunk;            // rows per workgroup
   v2f* out;
 };
@@ -29,6 +30,7 @@ template <bool INV>
 __device__ __forceinline__ v4f rows_epilogue(const RowsWaveArgs& a, v2f z0, v2f z1, int k, float invK) {
   v4f o = v4f{z0.x, z0.y, z1.x, z1.y};
   if (INV) o = o * invK;  // exact for powers of two
+  if (a.clean) o = fft_eps0(o);  // Nx.fft / Nx.ifft clean-up, ahead of the istft epilogue
   if (a.has_post_scale) o = o * a.post_scale;
   if (a.post_window) {
     const v2f w = *reinterpret_cast<const v2f*>(a.post_window + k);
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(64 * W) void k_fft_rows_wave_4k(RowsWaveArgs a) {
 
 // returns handled = false for lengths / shapes the wave kernels do not take
 int launch_fft_rows_wave(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse,
-                         const float* post_window, float post_scale, bool has_post_scale, float2* out, bool* handled) {
+                         const float* post_window, float post_scale, bool has_post_scale, float2* out, bool* handled, bool clean) {
   *handled = false;
   if ((K != 1024 && K != 2048 && K != 4096) || rows < 1 || env_int("NXSIG_DISABLE_WAVE_ROWS", 0)) return NXSIG_OK;
   if (post_window && (reinterpret_cast<uintptr_t>(post_window) & 7) != 0) return NXSIG_OK;
@@ -160,7 +162,7 @@ int launch_fft_rows_wave(Ctx* c, const void* in, bool in_is_real, int64_t rows, 
   a.twB = reinterpret_cast<const v2f*>(inverse ? wt.twBi : wt.twB);
   a.twC = reinterpret_cast<const v2f*>(inverse ? wt.twCi : wt.twC);
   a.tw4k = nullptr;
-  a.post_window = post_window; a.post_scale = post_scale; a.has_post_scale = has_post_scale ? 1 : 0;
+  a.post_window = post_window; a.post_scale = post_scale; a.has_post_scale = has_post_scale ? 1 : 0; a.clean = clean ? 1 : 0;
   a.out = reinterpret_cast<v2f*>(out);
   constexpr int W = 4;
   const int rpw = env_int("NXSIG_ROWS_PER_WAVE", K == 4096 ? 2 : 4);

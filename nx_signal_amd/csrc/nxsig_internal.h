@@ -26,6 +26,14 @@ const char* last_error_cstr();
                                 std::string(#expr) + ": " + hipGetErrorString(_e));                  \
   } while (0)
 
+// ---- Nx.fft / Nx.ifft clean-up (SURVEY App. A rule 7; call sites lib/nx_signal.ex:102, :609, convolution.ex:282): the
+// BinaryBackend zeroes every component of a transform's result whose magnitude is <= eps (1e-10, the default of the :eps
+// option) before rounding to c64.  Every forward / inverse kernel applies it to the finished transform, ahead of any scaling
+// or window product the reference applies afterwards.  NaN compares false and passes through.
+constexpr float kFftEps = 1.0e-10f;
+__host__ __device__ __forceinline__ float fft_eps0(float x) { return __builtin_fabsf(x) <= kFftEps ? 0.0f : x; }
+__host__ __device__ __forceinline__ float2 fft_eps0(float2 v) { return make_float2(fft_eps0(v.x), fft_eps0(v.y)); }
+
 // ---- host numerics (host_numerics.cpp) ----
 int window_f32(int kind, int n, bool periodic, double beta, double eps, float* out);
 void sinc_f32(const float* t, int64_t n, float* out);
@@ -137,7 +145,8 @@ int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host);
 int launch_as_windowed(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, const Framing& fr, float* out);
 int launch_overlap_and_add(Ctx* c, const float* frames, int64_t M, int32_t batch, int32_t N, int32_t hop, int32_t comps,
                            float* out);
-int launch_fft(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse, float2* out);
+// clean: apply the Nx.fft / Nx.ifft eps clean-up to the result (false for transforms that are sub-steps of a longer one)
+int launch_fft(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse, float2* out, bool clean = true);
 
 struct FirLaunch {
   const float* x;
@@ -147,6 +156,11 @@ struct FirLaunch {
   int32_t taps;
   int64_t out_start, out_len;  // requested slice of the full convolution
   float* y;                    // device f32[batch][out_len]
+  // device int[batch], zero on entry: a kernel that loads a non-finite sample of row r sets row_flags[r]; launch_fir's last
+  // pass (k_fir_poison) then makes the whole row NaN and clears the flag.  The reference filters by ONE transform of the whole
+  // row (Convolution.fftconvolve, lib/nx_signal/convolution.ex:276-284), so an Inf / NaN sample anywhere leaves no finite
+  // output in that row; block-wise overlap-save would otherwise confine it to the blocks (and block pairs) that hold it.
+  int* row_flags = nullptr;
 };
 int launch_fir(Ctx* c, const FirLaunch& a);
 int launch_half_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, float2* out);
@@ -160,7 +174,7 @@ int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float*
 int launch_mel_init(Ctx* c, int** gmax);
 int launch_mel_finish(Ctx* c, float* out, int64_t n, int* gmax);
 // kernels_nd.hip: rows of any length (four-step / Bluestein beyond the LDS-resident kernels), device-side fft_nd, n-D fftconvolve
-int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out);
+int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out, bool clean = true);
 int64_t fft_tiled_min();   // power-of-two row lengths from here up run the two-pass tiled four-step of kernels_nd.hip
 int launch_rows_post(Ctx* c, float2* a, int64_t rows, int64_t K, const float* window, float scale, bool has_scale, float div, bool has_div);
 int launch_fft_nd(Ctx* c, const void* in, bool in_is_real, const int64_t* shape, int rank, const int32_t* axes, const int64_t* lengths,

@@ -41,6 +41,13 @@ namespace nxsig {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+// wave-uniform: true when one of the two packed values is Inf / NaN on some lane
+__device__ __forceinline__ bool wave_any_nonfinite(float sx, float sy) {
+  const bool nf = ((__float_as_uint(sx) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(sy) & 0x7f800000u) == 0x7f800000u);
+  return __builtin_amdgcn_ballot_w64(nf) != 0;
+}
+__device__ __forceinline__ v2f fft_eps0(v2f v) { return v2f{fft_eps0(v.x), fft_eps0(v.y)}; }
+__device__ __forceinline__ v4f fft_eps0(v4f v) { return v4f{fft_eps0(v.x), fft_eps0(v.y), fft_eps0(v.z), fft_eps0(v.w)}; }
 
 // front-ends of the C-point complex core
 enum : int {
@@ -578,61 +585,75 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
     window_mul(d);
   }
 
-  for (int64_t pr = p_begin + wave; pr < p_end; pr += kWavesPerBlock) {
-    const int64_t pin = pinof(uin);
-    const int64_t mA = MODE == kModePair ? pin * 2 : (MODE == kModeQuad ? pin * (2 * J) : pin), mB = mA + 1;
-    const bool haveB = MODE == kModeReal2x ? true : (mB < a.M);
-    const int64_t crow = row;
-    if (!GENERAL) {
-      // unconditional prefetch (the last iteration harmlessly re-reads its own unit) keeps the loop branch-free
-      const bool more = pr + kWavesPerBlock < p_end;
-      issue_loads(more ? nrow : row, more ? pinof(nuin) : pin);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      const float* xr = a.x + (size_t)row * a.batch_stride;
-      const int64_t qA = mA * a.hop, qB = qA + a.hop;
+  // ---- Nx.fft's clean-up (SURVEY App. A rule 7; call site lib/nx_signal.ex:102): every component of the finished spectrum
+  // with |x| <= eps = 1e-10 becomes +0, BEFORE the :spectrum / :psd division (:113-127).  NaN compares false and stays.
+  auto eps_clean = [](v4f v) { return fft_eps0(v); };
+  // ---- non-finite samples.  The reference transforms every frame on its own (one Nx.fft row per frame, lib/nx_signal.ex:94-102),
+  // so an Inf / NaN sample reaches only the frames that contain it.  Frames that share one complex transform here (2 in pair mode,
+  // 2J in quad mode) would share it: a unit whose windowed samples are not all finite therefore leaves the paired route and runs
+  // each of its frames ALONE through the core (real part of sequence 0, everything else zero).  The test is one packed add per
+  // point on values the loop holds anyway: the sum of the unit's windowed samples is finite iff they all are (an overflowing sum
+  // only sends a finite unit down the solo route, which computes the same spectra).  Wave-uniform branch, cold path.
+  constexpr bool CAN_SOLO = FPU > 1 && !MEL;  // log-mel: any non-finite |z|^2 poisons the whole tensor in the reference (reduce_max)
+  auto unit_nonfinite = [&](const v2f* dd) -> bool {
+    v2f t = dd[0];
 #pragma unroll
-      for (int s = 0; s < P; ++s) {
-        const int n = lane + 64 * s;
-        if (MODE == kModePair) {
-          const float w = s_w[n];
-          const float va = (n < a.N) ? fetch_any(xr, a, qA + n) : 0.0f;
-          const float vb = (haveB && n < a.N) ? fetch_any(xr, a, qB + n) : 0.0f;
-          d[s] = v2f{va * w, vb * w};
-        } else if (MODE == kModeReal2x) {
-          const float va = (2 * n < a.N) ? fetch_any(xr, a, qA + 2 * n) : 0.0f;
-          const float vb = (2 * n + 1 < a.N) ? fetch_any(xr, a, qA + 2 * n + 1) : 0.0f;
-          d[s] = v2f{va * s_w[2 * n], vb * s_w[2 * n + 1]};
-        } else {
-          const int nn = (lane / J) + (64 / J) * s;               // sample index inside the K/J-sample frames
-          const int64_t fa = mA + 2 * (lane % J), fb = fa + 1;   // lane % J selects the frame pair
-          const float w = s_w[nn];
-          const float va = (fa < a.M && nn < a.N) ? fetch_any(xr, a, fa * a.hop + nn) : 0.0f;
-          const float vb = (fb < a.M && nn < a.N) ? fetch_any(xr, a, fb * a.hop + nn) : 0.0f;
-          d[s] = v2f{va * w, vb * w};
-        }
+    for (int s = 1; s < P; ++s) t += dd[s];
+    const bool nf = ((__float_as_uint(t.x) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(t.y) & 0x7f800000u) == 0x7f800000u);
+    return __builtin_amdgcn_ballot_w64(nf) != 0;
+  };
+  // GENERAL kernels: bounds-checked, padded / mirrored samples of the unit's frames (solo < 0), or frame mA + solo alone
+  auto load_general = [&](v2f* dd, int64_t lrow, int64_t mA, int solo) {
+    const float* xr = a.x + (size_t)lrow * a.batch_stride;
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+      const int n = lane + 64 * s;
+      if (MODE == kModePair) {
+        const int64_t fa = solo < 0 ? mA : mA + solo;
+        const bool useB = solo < 0 && mA + 1 < a.M;
+        const float w = s_w[n];
+        const float va = (n < a.N) ? fetch_any(xr, a, fa * a.hop + n) : 0.0f;
+        const float vb = (useB && n < a.N) ? fetch_any(xr, a, (fa + 1) * a.hop + n) : 0.0f;
+        dd[s] = v2f{va * w, vb * w};
+      } else if (MODE == kModeReal2x) {
+        const int64_t qA = mA * a.hop;
+        const float va = (2 * n < a.N) ? fetch_any(xr, a, qA + 2 * n) : 0.0f;
+        const float vb = (2 * n + 1 < a.N) ? fetch_any(xr, a, qA + 2 * n + 1) : 0.0f;
+        dd[s] = v2f{va * s_w[2 * n], vb * s_w[2 * n + 1]};
+      } else {
+        const int nn = (lane / J) + (64 / J) * s;               // sample index inside the K/J-sample frames
+        const int jj = lane % J;                                 // lane % J selects the frame pair
+        const int64_t fa = solo < 0 ? mA + 2 * jj : mA + solo, fb = fa + 1;
+        const bool okA = solo < 0 ? fa < a.M : jj == 0, okB = solo < 0 && fb < a.M;
+        const float w = s_w[nn];
+        const float va = (okA && nn < a.N) ? fetch_any(xr, a, fa * a.hop + nn) : 0.0f;
+        const float vb = (okB && nn < a.N) ? fetch_any(xr, a, fb * a.hop + nn) : 0.0f;
+        dd[s] = v2f{va * w, vb * w};
       }
     }
-
-    v2f zz[2][NQ];  // zz[par][q] = Z[2 lane + par + 128 q]
-    wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);
-
-    // next unit's raw samples -> windowed d[].  Pair / real-2x: right after the butterflies (the loads had the whole core
-    // to land and their registers are free for the untangle).  Quad: at the very end of the iteration (LATE): with its
-    // input in HBM rather than in the Infinity Cache the quad kernels were waiting here (4.0 instead of 6.0 TB/s).
-    constexpr bool LATE = MODE == kModeQuad || STAGED;
-    if (!GENERAL && !LATE) {
-      __builtin_amdgcn_sched_barrier(0);
-      window_mul(d);
-      __builtin_amdgcn_sched_barrier(0);
+  };
+  // streaming kernels, solo route: frame m alone, straight from memory (the unit is interior: every sample exists)
+  auto load_solo = [&](v2f* dd, int64_t lrow, int64_t m) {
+    const float* xf = a.x + (size_t)lrow * a.batch_stride + (m * a.hop - a.lo);
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+      const int nn = MODE == kModeQuad ? (lane / J) + (64 / J) * s : lane + 64 * s;
+      const bool use = (MODE != kModeQuad || (lane % J) == 0) && (!NPRED || nn < a.N);
+      const float v = xf[nn] * s_w[nn];
+      dd[s] = v2f{use ? v : 0.0f, 0.0f};
     }
+  };
 
-    // ---- Hermitian untangle through partner lanes + store
+  // ---- Hermitian untangle through partner lanes + eps clean-up + scaling + store.  SOLO: only slot 0 of the unit (real part of
+  // sequence 0) is meaningful; it is frame mS of the row and leaves through plain non-temporal stores.
+  auto drain = [&](auto solo_c, v2f (*zz)[NQ], const int64_t crow, const int64_t mA, const bool haveB, const int64_t mS) {
+    constexpr bool SOLO = decltype(solo_c)::value;
     const int src0 = ((64 - lane) & 63) << 2, src1 = (63 - lane) << 2;
-    if (MODE == kModeQuad) {
+    if constexpr (MODE == kModeQuad) {
       constexpr int HQ = NQ / J;  // bins per lane per parity of the short spectra
+      constexpr int JN = SOLO ? 1 : J;
       // C_j[k0] = conj(w_K^(j k0)) / J * sum_m Z[k0 + (K/J) m] conj(w_J^(jm)),  k0 = 2 lane + par + 128 q, q < HQ
-      v2f cs[J][2][HQ];
+      v2f cs[JN][2][HQ];
 #pragma unroll
       for (int q = 0; q < HQ; ++q)
 #pragma unroll
@@ -644,18 +665,19 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
           else if constexpr (J == 4) dft4<true>(u[0], u[1], u[2], u[3]);
           else dft8<true>(u);
 #pragma unroll
-          for (int j = 0; j < J; ++j) {
+          for (int j = 0; j < JN; ++j) {
             v2f v = u[j] * (1.0f / (float)J);
             if (j > 0) v = wcmul(v, s_twR[(j - 1) * (K / J) + 2 * lane + e + 128 * q]);
             cs[j][e][q] = v;
           }
         }
-      v2f* z0 = a.z + ((size_t)crow * a.M + mA) * KOUT + 2 * lane;
+      const int64_t m0 = SOLO ? mS : mA;
+      v2f* z0 = a.z + ((size_t)crow * a.M + m0) * KOUT + 2 * lane;
       v2f* dm = a.dummy + 2 * lane;
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        v2f* zfa = (mA + 2 * j < a.M) ? z0 + (size_t)(2 * j) * KOUT : dm;      // frame m0 + 2j      (real part of c_j)
-        v2f* zfb = (mA + 2 * j + 1 < a.M) ? z0 + (size_t)(2 * j + 1) * KOUT : dm;  // frame m0 + 2j + 1 (imaginary part)
+      for (int j = 0; j < JN; ++j) {
+        v2f* zfa = (m0 + 2 * j < a.M) ? z0 + (size_t)(2 * j) * KOUT : dm;      // frame m0 + 2j      (real part of c_j)
+        v2f* zfb = (m0 + 2 * j + 1 < a.M) ? z0 + (size_t)(2 * j + 1) * KOUT : dm;  // frame m0 + 2j + 1 (imaginary part)
         const StreamRow ra(zfa - 2 * lane, KOUT * 8), rb2(zfb - 2 * lane, KOUT * 8);  // wave-uniform row descriptors (SALU only)
 #pragma unroll
         for (int q = 0; q < HQ; ++q) {
@@ -667,9 +689,10 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
           p1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(cs[j][1][HQ - 1 - q].y)));
           if (lane == 0) p0 = own0;
           const v2f z0v = cs[j][0][q], z1v = cs[j][1][q];
-          v4f xa = v4f{z0v.x + p0.x, z0v.y - p0.y, z1v.x + p1.x, z1v.y - p1.y} * 0.5f;
-          v4f xbv = v4f{z0v.y + p0.y, p0.x - z0v.x, z1v.y + p1.y, p1.x - z1v.x} * 0.5f;
+          v4f xa = eps_clean(v4f{z0v.x + p0.x, z0v.y - p0.y, z1v.x + p1.x, z1v.y - p1.y} * 0.5f);
+          v4f xbv = eps_clean(v4f{z0v.y + p0.y, p0.x - z0v.x, z1v.y + p1.y, p1.x - z1v.x} * 0.5f);
           if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }
+          const bool stA = SOLO || m0 + 2 * j < a.M, stB = !SOLO && m0 + 2 * j + 1 < a.M;
           if (MEL || MAG) {
             if (HQ >= 2 ? (q < HQ / 2) : (lane < 32)) {  // bins k0 = 2 lane + par + 128 q below fft_length / 2
               const v2f pa2 = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};
@@ -679,16 +702,18 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
                 *reinterpret_cast<v2f*>(&mags[(2 * j + 1) * KH + 2 * lane + 128 * q]) = pb2;
               } else {
                 if (mp->mag_kind == 3) {  // one-sided complex spectrum: two adjacent bins per 16-byte store
-                  v2f* c0 = reinterpret_cast<v2f*>(mp->out) + ((size_t)crow * a.M + mA + 2 * j) * KH + 2 * lane + 128 * q;
-                  if (mA + 2 * j < a.M) __builtin_nontemporal_store(xa, (gv4f*)c0);
-                  if (mA + 2 * j + 1 < a.M) __builtin_nontemporal_store(xbv, (gv4f*)(c0 + KH));
+                  v2f* c0 = reinterpret_cast<v2f*>(mp->out) + ((size_t)crow * a.M + m0 + 2 * j) * KH + 2 * lane + 128 * q;
+                  if (stA) __builtin_nontemporal_store(xa, (gv4f*)c0);
+                  if (stB) __builtin_nontemporal_store(xbv, (gv4f*)(c0 + KH));
                 } else {
-                  float* r0 = mp->out + ((size_t)crow * a.M + mA + 2 * j) * KH + 2 * lane + 128 * q;
-                  if (mA + 2 * j < a.M) mag_store(r0, pa2);
-                  if (mA + 2 * j + 1 < a.M) mag_store(r0 + KH, pb2);
+                  float* r0 = mp->out + ((size_t)crow * a.M + m0 + 2 * j) * KH + 2 * lane + 128 * q;
+                  if (stA) mag_store(r0, pa2);
+                  if (stB) mag_store(r0 + KH, pb2);
                 }
               }
             }
+          } else if (SOLO) {
+            __builtin_nontemporal_store(xa, (gv4f*)(zfa + 128 * q));
           } else if (ST > 0 && !GENERAL) {  // streaming kernel: "sc1 nt" stores through the two frames' row descriptors
             ra.st16(xa, lane * 16 + 1024 * q);
             rb2.st16(xbv, lane * 16 + 1024 * q);
@@ -698,85 +723,124 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
           }
         }
       }
+    } else {
+      const int64_t m0 = SOLO ? mS : mA;
+      v2f* zA = a.z + ((size_t)crow * a.M + m0) * KOUT + 2 * lane;
+      v2f* zB = (GENERAL || haveB) ? zA + K : a.dummy + 2 * lane;  // pair: frame B; real-2x: bins K..2K-1
+      constexpr bool BUFST = ST > 0 && (MODE == kModePair || MODE == kModeReal2x) && !GENERAL && SINK == kSinkSpectrum && !SOLO;
+      __amdgpu_buffer_rsrc_t rsA, rsB;
+      if (BUFST) {  // wave-uniform row descriptors (the row base depends on the wave index: make it an SGPR pair explicitly)
+        auto uni = [](const v2f* p) -> void* {
+          const uint64_t v = reinterpret_cast<uint64_t>(p);
+          const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+          return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+        };
+        rsA = __builtin_amdgcn_make_buffer_rsrc(uni(zA - 2 * lane), 0, K * 8, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc(uni(zB - 2 * lane), 0, K * 8, 0x00020000);
+      }
+      const bool stB = !SOLO && (MODE == kModePair ? haveB : true);
+      constexpr int QN = ((MEL || MAG) && MODE == kModePair) ? NQ / 2 : NQ;  // MEL / MAG: only the bins below fft_length / 2
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        // partner of bin k = 2l+par+128q is K-k = 2l'+par+128(NQ-1-q) on lane l' (lane 0 / par 0: own (NQ-q) % NQ)
+        const v2f own0 = zz[0][(NQ - q) % NQ];
+        v2f p0, p1;
+        p0.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(zz[0][NQ - 1 - q].x)));
+        p0.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(zz[0][NQ - 1 - q].y)));
+        p1.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(zz[1][NQ - 1 - q].x)));
+        p1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(zz[1][NQ - 1 - q].y)));
+        if (lane == 0) p0 = own0;
+        const v2f z0 = zz[0][q], z1 = zz[1][q];
+        // XA = ((a + c), (b - d)) / 2 ; XB = ((b + d), (c - a)) / 2   with Z = a + ib, Z[K-k] = c + id
+        v4f xa = v4f{z0.x + p0.x, z0.y - p0.y, z1.x + p1.x, z1.y - p1.y} * 0.5f;
+        v4f xbv = v4f{z0.y + p0.y, p0.x - z0.x, z1.y + p1.y, p1.x - z1.x} * 0.5f;
+        if (MODE == kModeReal2x) {
+          // xa = E[k], xbv = O[k] (spectra of the even / odd samples): X[k] = E + w_2K^k O, X[k+K] = E - w_2K^k O
+          const v4f t = *reinterpret_cast<const v4f*>(&s_twR[2 * lane + 128 * q]);
+          const v2f o0 = wcmul(v2f{xbv.x, xbv.y}, v2f{t.x, t.y}), o1 = wcmul(v2f{xbv.z, xbv.w}, v2f{t.z, t.w});
+          const v4f to = v4f{o0.x, o0.y, o1.x, o1.y};
+          xbv = xa - to;
+          xa = xa + to;
+        }
+        xa = eps_clean(xa);
+        if (!SOLO) xbv = eps_clean(xbv);
+        if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }  // true division like the reference (:116/:119)
+        if (MEL) {
+          const v2f pa2 = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};      // |X[k]|^2, |X[k+1]|^2
+          *reinterpret_cast<v2f*>(&mags[2 * lane + 128 * q]) = pa2;
+          if (MODE == kModePair) {
+            const v2f pb2 = v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w};
+            *reinterpret_cast<v2f*>(&mags[KH + 2 * lane + 128 * q]) = pb2;
+          }
+        } else if (MAG) {
+          if (mp->mag_kind == 3) {  // one-sided complex spectrum: two adjacent bins per 16-byte store
+            v2f* c0 = reinterpret_cast<v2f*>(mp->out) + ((size_t)crow * a.M + m0) * KH + 2 * lane + 128 * q;
+            __builtin_nontemporal_store(xa, (gv4f*)c0);
+            if (MODE == kModePair && stB) __builtin_nontemporal_store(xbv, (gv4f*)(c0 + KH));
+          } else {
+            float* r0 = mp->out + ((size_t)crow * a.M + m0) * KH + 2 * lane + 128 * q;
+            mag_store(r0, v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w});
+            if (MODE == kModePair && stB) mag_store(r0 + KH, v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w});
+          }
+        } else if (BUFST) {
+          typedef int v4i __attribute__((ext_vector_type(4)));
+          constexpr int AUX = ST == 1 ? 18 : 2;  // gfx940+ cache policy bits: 1 = sc0, 2 = nt, 16 = sc1
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, xa), rsA, lane * 16 + 1024 * q, 0, AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, xbv), rsB, lane * 16 + 1024 * q, 0, AUX);
+        } else {
+          __builtin_nontemporal_store(xa, (gv4f*)(zA + 128 * q));
+          if (!SOLO && (!GENERAL || haveB)) __builtin_nontemporal_store(xbv, (gv4f*)(zB + 128 * q));
+        }
+      }
+    }
+  };
+
+  for (int64_t pr = p_begin + wave; pr < p_end; pr += kWavesPerBlock) {
+    const int64_t pin = pinof(uin);
+    const int64_t mA = MODE == kModePair ? pin * 2 : (MODE == kModeQuad ? pin * (2 * J) : pin), mB = mA + 1;
+    const bool haveB = MODE == kModeReal2x ? true : (mB < a.M);
+    const int64_t crow = row;
+    if (!GENERAL) {
+      // unconditional prefetch (the last iteration harmlessly re-reads its own unit) keeps the loop branch-free
+      const bool more = pr + kWavesPerBlock < p_end;
+      issue_loads(more ? nrow : row, more ? pinof(nuin) : pin);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      load_general(d, row, mA, -1);
+    }
+
+    // next unit's raw samples -> windowed d[].  Pair / real-2x: right after the butterflies (the loads had the whole core
+    // to land and their registers are free for the untangle).  Quad: at the very end of the iteration (LATE): with its
+    // input in HBM rather than in the Infinity Cache the quad kernels were waiting here (4.0 instead of 6.0 TB/s).
+    constexpr bool LATE = MODE == kModeQuad || STAGED;
+    v2f zz[2][NQ];  // zz[par][q] = Z[2 lane + par + 128 q]
+    if (CAN_SOLO && unit_nonfinite(d)) {
+#pragma nounroll
+      for (int f = 0; f < FPU && mA + f < a.M; ++f) {
+        v2f ds[P];
+        if (GENERAL) load_general(ds, crow, mA, f); else load_solo(ds, crow, mA + f);
+        wave_fft_core<K>(ds, zz, xb, s_twB, s_twC, lane);
+        drain(std::true_type{}, zz, crow, mA, haveB, mA + f);
+      }
+      if (!GENERAL) {
+        __builtin_amdgcn_sched_barrier(0);
+        window_mul(d);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);
+      if (!GENERAL && !LATE) {
+        __builtin_amdgcn_sched_barrier(0);
+        window_mul(d);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      drain(std::false_type{}, zz, crow, mA, haveB, mA);
       if (MEL) mel_tail(crow, mA);
       if (!GENERAL && LATE) {
         __builtin_amdgcn_sched_barrier(0);
         window_mul(d);
         __builtin_amdgcn_sched_barrier(0);
       }
-      row = nrow; uin = nuin;
-      advance(nrow, nuin);
-      continue;
-    }
-    v2f* zA = a.z + ((size_t)crow * a.M + mA) * KOUT + 2 * lane;
-    v2f* zB = (GENERAL || haveB) ? zA + K : a.dummy + 2 * lane;  // pair: frame B; real-2x: bins K..2K-1
-    constexpr bool BUFST = ST > 0 && (MODE == kModePair || MODE == kModeReal2x) && !GENERAL && SINK == kSinkSpectrum;
-    __amdgpu_buffer_rsrc_t rsA, rsB;
-    if (BUFST) {  // wave-uniform row descriptors (the row base depends on the wave index: make it an SGPR pair explicitly)
-      auto uni = [](const v2f* p) -> void* {
-        const uint64_t v = reinterpret_cast<uint64_t>(p);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-        return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
-      };
-      rsA = __builtin_amdgcn_make_buffer_rsrc(uni(zA - 2 * lane), 0, K * 8, 0x00020000);
-      rsB = __builtin_amdgcn_make_buffer_rsrc(uni(zB - 2 * lane), 0, K * 8, 0x00020000);
-    }
-    constexpr int QN = ((MEL || MAG) && MODE == kModePair) ? NQ / 2 : NQ;  // MEL / MAG: only the bins below fft_length / 2
-#pragma unroll
-    for (int q = 0; q < QN; ++q) {
-      // partner of bin k = 2l+par+128q is K-k = 2l'+par+128(NQ-1-q) on lane l' (lane 0 / par 0: own (NQ-q) % NQ)
-      const v2f own0 = zz[0][(NQ - q) % NQ];
-      v2f p0, p1;
-      p0.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(zz[0][NQ - 1 - q].x)));
-      p0.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(zz[0][NQ - 1 - q].y)));
-      p1.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(zz[1][NQ - 1 - q].x)));
-      p1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(zz[1][NQ - 1 - q].y)));
-      if (lane == 0) p0 = own0;
-      const v2f z0 = zz[0][q], z1 = zz[1][q];
-      // XA = ((a + c), (b - d)) / 2 ; XB = ((b + d), (c - a)) / 2   with Z = a + ib, Z[K-k] = c + id
-      v4f xa = v4f{z0.x + p0.x, z0.y - p0.y, z1.x + p1.x, z1.y - p1.y} * 0.5f;
-      v4f xbv = v4f{z0.y + p0.y, p0.x - z0.x, z1.y + p1.y, p1.x - z1.x} * 0.5f;
-      if (MODE == kModeReal2x) {
-        // xa = E[k], xbv = O[k] (spectra of the even / odd samples): X[k] = E + w_2K^k O, X[k+K] = E - w_2K^k O
-        const v4f t = *reinterpret_cast<const v4f*>(&s_twR[2 * lane + 128 * q]);
-        const v2f o0 = wcmul(v2f{xbv.x, xbv.y}, v2f{t.x, t.y}), o1 = wcmul(v2f{xbv.z, xbv.w}, v2f{t.z, t.w});
-        const v4f to = v4f{o0.x, o0.y, o1.x, o1.y};
-        xbv = xa - to;
-        xa = xa + to;
-      }
-      if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }  // true division like the reference (:116/:119)
-      if (MEL) {
-        const v2f pa2 = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};      // |X[k]|^2, |X[k+1]|^2
-        *reinterpret_cast<v2f*>(&mags[2 * lane + 128 * q]) = pa2;
-        if (MODE == kModePair) {
-          const v2f pb2 = v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w};
-          *reinterpret_cast<v2f*>(&mags[KH + 2 * lane + 128 * q]) = pb2;
-        }
-      } else if (MAG) {
-        if (mp->mag_kind == 3) {  // one-sided complex spectrum: two adjacent bins per 16-byte store
-          v2f* c0 = reinterpret_cast<v2f*>(mp->out) + ((size_t)crow * a.M + mA) * KH + 2 * lane + 128 * q;
-          __builtin_nontemporal_store(xa, (gv4f*)c0);
-          if (MODE == kModePair && haveB) __builtin_nontemporal_store(xbv, (gv4f*)(c0 + KH));
-        } else {
-          float* r0 = mp->out + ((size_t)crow * a.M + mA) * KH + 2 * lane + 128 * q;
-          mag_store(r0, v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w});
-          if (MODE == kModePair && haveB) mag_store(r0 + KH, v2f{xbv.x * xbv.x + xbv.y * xbv.y, xbv.z * xbv.z + xbv.w * xbv.w});
-        }
-      } else if (BUFST) {
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        constexpr int AUX = ST == 1 ? 18 : 2;  // gfx940+ cache policy bits: 1 = sc0, 2 = nt, 16 = sc1
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, xa), rsA, lane * 16 + 1024 * q, 0, AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, xbv), rsB, lane * 16 + 1024 * q, 0, AUX);
-      } else {
-        __builtin_nontemporal_store(xa, (gv4f*)(zA + 128 * q));
-        if (!GENERAL || haveB) __builtin_nontemporal_store(xbv, (gv4f*)(zB + 128 * q));
-      }
-    }
-    if (MEL) mel_tail(crow, mA);
-    if (!GENERAL && LATE) {
-      __builtin_amdgcn_sched_barrier(0);
-      window_mul(d);
-      __builtin_amdgcn_sched_barrier(0);
     }
     row = nrow; uin = nuin;
     advance(nrow, nuin);
@@ -902,21 +966,31 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
     // every sample of both frames inside the signal: plain loads; otherwise per-sample padding / mirror math
     const bool inside = a.reflect == 0 && qA - a.lo >= 0 && (haveB ? qB : qA) - a.lo + nuse <= a.L;
     v2f zz[2][NQ];
+    // sel < 0: the pair rides as frame A + i frame B; sel = 0 / 1: frame A / B ALONE as the real part (solo route, below).
+    // Returns whether a windowed sample of the unit is not finite (wave-uniform).
+    auto load_unit = [&](const int sel) -> bool {
+      v2f sum = v2f{0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+      for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int n = 2 * lane + e + 128 * q;
-        v2f v = v2f{0.f, 0.f};
-        if (128 * q < nuse && n < nuse) {
-          float va, vb;
-          if (inside) { va = xr[qA - a.lo + n]; vb = haveB ? xr[qB - a.lo + n] : 0.0f; }
-          else { va = fetch_any(xr, a, qA + n); vb = haveB ? fetch_any(xr, a, qB + n) : 0.0f; }
-          const float w = s_w[n];
-          v = wcmul(v2f{va * w, vb * w}, s_ch[n]);   // windowed samples (exact f32 products, :101) times the chirp
+        for (int e = 0; e < 2; ++e) {
+          const int n = 2 * lane + e + 128 * q;
+          v2f v = v2f{0.f, 0.f};
+          if (128 * q < nuse && n < nuse) {
+            float va, vb;
+            if (inside) { va = xr[qA - a.lo + n]; vb = haveB ? xr[qB - a.lo + n] : 0.0f; }
+            else { va = fetch_any(xr, a, qA + n); vb = haveB ? fetch_any(xr, a, qB + n) : 0.0f; }
+            const float w = s_w[n];
+            const v2f u = sel < 0 ? v2f{va * w, vb * w} : v2f{(sel == 0 ? va : vb) * w, 0.0f};
+            sum += u;
+            v = wcmul(u, s_ch[n]);   // windowed samples (exact f32 products, :101) times the chirp
+          }
+          zz[e][q] = v;
         }
-        zz[e][q] = v;
-      }
+      const bool nf = ((__float_as_uint(sum.x) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(sum.y) & 0x7f800000u) == 0x7f800000u);
+      return __builtin_amdgcn_ballot_w64(nf) != 0;
+    };
+    auto xform_sink = [&](const int sel) {
     v2f d[P];
     wave_fft_core_T<C>(zz, d, xb, s_twB, s_twC, lane);
 #pragma unroll
@@ -942,25 +1016,39 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
         if (128 * q < Kb && k < Kb) {
           const v2f u = y[e][q];
           const v2f p = xb[k == 0 ? 0 : Kb - k];
-          v2f xa = v2f{u.x + p.x, u.y - p.y} * 0.5f;
-          v2f xv = v2f{u.y + p.y, p.x - u.x} * 0.5f;
+          v2f xa = fft_eps0(v2f{u.x + p.x, u.y - p.y} * 0.5f);
+          v2f xv = fft_eps0(v2f{u.y + p.y, p.x - u.x} * 0.5f);
           if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
+          const bool stA = sel <= 0, stB = haveB && sel != 0;   // solo rounds: the real part is frame A (sel 0) / frame B (sel 1)
+          if (sel == 1) xv = xa;
           if (SINK == kSinkSpectrum) {
-            __builtin_nontemporal_store(xa, (gv2f*)(zA + k));
-            if (haveB) __builtin_nontemporal_store(xv, (gv2f*)(zB + k));
+            if (stA) __builtin_nontemporal_store(xa, (gv2f*)(zA + k));
+            if (stB) __builtin_nontemporal_store(xv, (gv2f*)(zB + k));
           } else if (k < half) {
             const float pa = xa.x * xa.x + xa.y * xa.y, pb = xv.x * xv.x + xv.y * xv.y;
             if (MEL) { mags[k] = pa; mags[half + k] = pb; }
             else {
               const float va = b.mag_kind == 1 ? pa : __builtin_sqrtf(pa), vb = b.mag_kind == 1 ? pb : __builtin_sqrtf(pb);
               float* o = b.out + ((size_t)row * a.M + mA) * half + k;
-              o[0] = va;
-              vmax = va > vmax ? va : vmax;
-              if (haveB) { o[half] = vb; vmax = vb > vmax ? vb : vmax; }
+              if (stA) { o[0] = va; vmax = va > vmax ? va : vmax; }
+              if (stB) { o[half] = vb; vmax = vb > vmax ? vb : vmax; }
             }
           }
         }
       }
+    };  // xform_sink
+    // non-finite samples: the reference transforms every frame alone (lib/nx_signal.ex:94-102); a pair whose windowed samples
+    // are not all finite leaves the paired route and its frames ride alone, one after the other (same scheme as stft_wave_body)
+    if (load_unit(-1) && !MEL && haveB) {
+#pragma nounroll
+      for (int sel = 0; sel < 2; ++sel) {
+        load_unit(sel);
+        xform_sink(sel);
+        wave_lds_fence();
+      }
+    } else {
+      xform_sink(-1);
+    }
     if (MEL) {
       wave_lds_fence();
       float* o0p = b.out + ((size_t)row * a.M + mA) * b.mel_bins;

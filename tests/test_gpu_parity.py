@@ -826,24 +826,23 @@ def test_stft_config1_against_committed_fixture():
     assert np.max(np.abs(y[-1536:-512] - fx["y_tail"][:-512])) / ys < 1e-5
 
 
-def test_eps_clean_deviation_is_bounded():
-    """Nx.fft zeroes every component with |x| <= 1e-10 (SURVEY App. A rule 7); the GPU path skips that clean-up (DESIGN.md,
-    documented deviation).  Pin what the deviation can be: wherever the reference returns an exact zero the HIP result is
-    at most 1e-10 away in absolute terms, and everywhere else the usual normalised tolerance holds — on a tiny-amplitude
-    signal where most components sit around the threshold, and on a full-scale signal with exact zeros in its spectrum."""
+def test_eps_clean_up_is_applied():
+    """Nx.fft zeroes every component with |x| <= 1e-10 (SURVEY App. A rule 7) and so do the kernels (round 3; the detailed
+    tests live in tests/test_gpu_reference_numerics.py): on a tiny-amplitude signal whose components sit around the threshold
+    the zero / non-zero decision matches the oracle except within fp32 round-off of the threshold, and on a full-scale signal
+    with mathematically zero bins (where fp32 round-off ~1e-7 of the spectrum's scale keeps them non-zero) the usual
+    normalised tolerance holds."""
     w = S.windows.hann(1024)
     opts = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)
     n = np.arange(1024 * 6, dtype=np.float64)
-    for x in ((O.synth_signal(1024 * 6, seed=3) * np.float32(2e-12)).astype(np.float32),
-              np.cos(2 * np.pi * 8 * n / 1024).astype(np.float32)):  # bin-centred tone: most bins are ~0 in the reference
-        z, _, _ = S.stft(x, w, **opts)
-        zo, _, _ = O.stft(x, w, **opts)
-        cleaned = (zo.real == 0) | (zo.imag == 0)
-        d = np.maximum(np.abs(z.real.astype(np.float64) - zo.real), np.abs(z.imag.astype(np.float64) - zo.imag))  # per component, like the clean-up
-        scale = max(float(np.max(np.abs(zo))), 1e-30)
-        # components the reference cleaned to zero: the HIP value is fp32 round-off of the transform, far inside 1e-5 of the
-        # spectrum's scale and (tiny signal) below the 1e-10 threshold itself
-        assert float(d.max()) <= max(1e-5 * scale, 1e-10), (float(d.max()), scale)
-        assert cleaned.any()
-        if scale < 1e-8:
-            assert float(np.abs(z.real[zo.real == 0]).max(initial=0.0)) <= 1e-10
+    x = (O.synth_signal(1024 * 6, seed=3) * np.float32(2e-12)).astype(np.float32)
+    z, _, _ = S.stft(x, w, **opts)
+    zo, _, _ = O.stft(x, w, **opts)
+    g, r = z.view(np.float32).ravel(), zo.astype(np.complex64).view(np.float32).ravel()
+    assert (r == 0).sum() > r.size // 2
+    wrong = (g == 0) != (r == 0)
+    assert wrong.sum() <= 4 and np.all(np.abs(np.abs(g[wrong].astype(np.float64)) - 1e-10) < 2e-15)
+    x = np.cos(2 * np.pi * 8 * n / 1024).astype(np.float32)  # bin-centred tone: most bins are ~0 in the reference
+    z, _, _ = S.stft(x, w, **opts)
+    zo, _, _ = O.stft(x, w, **opts)
+    assert float(np.max(np.abs(z - zo))) <= 1e-5 * float(np.max(np.abs(zo)))

@@ -379,7 +379,11 @@ int nxsig_group_allgather(nxsig_group* g, const void* const* send, const int64_t
  *                        LOCAL groups only.
  *   mem == NXSIG_DEVICE: x[i] is local member i's INPUT SHARD on its own device — rows [c0, c1) of the tensor
  *                        (channels axis: f32[c1 - c0][length], rows batch_stride apart) or the sample span [s0, s1) of
- *                        every row (frames axis: f32[batch][s1 - s0], rows batch_stride apart).  gather == 0: z[i] receives
+ *                        every row (frames axis: f32[batch][s1 - s0]).  batch_stride == 0 means DENSE per-member shards
+ *                        (row stride = the member's own row length) and is what frame shards should pass: their spans
+ *                        differ from member to member whenever the frame count does not divide evenly, so one stride
+ *                        cannot describe them; a non-zero batch_stride applies to every member and must be at least
+ *                        the member's row length (NXSIG_ERR_INVALID_ARG otherwise).  gather == 0: z[i] receives
  *                        the member's output shard (c64[c1 - c0][M][K] / c64[batch][m1 - m0][K]) and stays on its device.
  *                        gather == 1: z[i] is a full c64[batch][M][K] buffer on every member's device; shards are
  *                        computed in place and all-gathered (frames axis: batch must be 1).  Asynchronous.

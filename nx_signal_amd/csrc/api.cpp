@@ -98,8 +98,9 @@ int ctx_twiddles(Ctx* c, int K, const float2** out) {
 }
 
 int ctx_table(Ctx* c, uint64_t tag, const void* host, size_t bytes, const void** out) {
-  // content-addressed: key = fnv1a(tag, content) ^ size.  A hit is VERIFIED (size + content of the kept host copy): on a
-  // 64-bit collision the next key is probed instead of silently handing out another table (a wrong window / filter).
+  // content-addressed: key = fnv1a(tag, content) ^ size.  A hit on a table of up to 1 MiB is VERIFIED against the kept host copy
+  // (size + content): on a 64-bit collision the next key is probed instead of silently handing out another table (a wrong
+  // window / filter).  Larger tables keep no host copy and are matched on hash + size only.
   uint64_t key = fnv1a(tag, host, bytes) ^ (uint64_t)bytes;
   for (int probe = 0; probe < 8; ++probe, key = key * 0x9E3779B97F4A7C15ull + 1) {
     auto it = c->tables.find(key);
@@ -109,19 +110,25 @@ int ctx_table(Ctx* c, uint64_t tag, const void* host, size_t bytes, const void**
       NXSIG_HIP_TRY(hipMalloc(&t.ptr, bytes ? bytes : 4));
       NXSIG_HIP_TRY(hipMemcpyAsync(t.ptr, host, bytes, hipMemcpyHostToDevice, c->stream));
       NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
-      if (bytes <= ((size_t)1 << 20)) t.host.assign(static_cast<const unsigned char*>(host), static_cast<const unsigned char*>(host) + bytes);
+      t.has_host = bytes <= ((size_t)1 << 20);
+      if (t.has_host) t.host.assign(static_cast<const unsigned char*>(host), static_cast<const unsigned char*>(host) + bytes);
       it = c->tables.emplace(key, std::move(t)).first;
       *out = it->second.ptr;
       return NXSIG_OK;
     }
     const DeviceTable& t = it->second;
-    if (t.bytes == bytes && (t.host.empty() ? bytes > ((size_t)1 << 20) : std::memcmp(t.host.data(), host, bytes) == 0)) {
+    if (t.bytes == bytes && (!t.has_host || bytes == 0 || std::memcmp(t.host.data(), host, bytes) == 0)) {
       *out = t.ptr;
       return NXSIG_OK;
     }
   }
   return set_error(NXSIG_ERR_HIP, "table cache: repeated hash collisions");
 }
+
+static thread_local const Ctx* t_mel_defer = nullptr;
+MelDeferScope::MelDeferScope(const Ctx* c) { t_mel_defer = c; }
+MelDeferScope::~MelDeferScope() { t_mel_defer = nullptr; }
+bool mel_deferred(const Ctx* c) { return t_mel_defer == c; }
 
 int ctx_scratch(Ctx* c, int slot, size_t bytes, void** out) {
   if (c->scratch_bytes[slot] < bytes) {
@@ -189,7 +196,9 @@ int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
     return launch_istft(c, b, window_host);
   }
   if (!handled && (rc = launch_istft_generic(c, a))) return rc;
-  return launch_istft_edge_fix(c, a, window_host);  // ill-conditioned edge samples recomputed in double
+  if ((rc = launch_istft_edge_fix(c, a, window_host))) return rc;  // ill-conditioned edge samples recomputed in double
+  // kernels that invert several frames per transform reported their non-finite units: those samples again, frame by frame
+  return launch_istft_nf_fix(c, a, a.nf_list, a.nf_frames_per_unit);
 }
 // filters longer than the overlap-save kernels take (> 4096 taps: impulse responses of seconds): one transform of
 // next_pow2(L + taps - 1) points per row, the way the reference's fftconvolve does it (lib/nx_signal/convolution.ex:252-329),

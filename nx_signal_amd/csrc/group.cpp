@@ -90,6 +90,17 @@ static std::string rccl_error() { return rccl_state().error; }
     if (_r != ncclSuccess) return set_error(NXSIG_ERR_HIP, std::string(#expr) + ": " + (R)->GetErrorString(_r)); \
   } while (0)
 
+// ncclGroupStart ... ncclGroupEnd that is closed on EVERY way out: an early error return between the two calls would leave the
+// thread's RCCL group open, and every later collective of the thread would be queued and never launched (a hang).
+struct NcclBracket {
+  Rccl* R;
+  bool open = false;
+  explicit NcclBracket(Rccl* r) : R(r) {}
+  ncclResult_t start() { const ncclResult_t r = R->GroupStart(); open = r == ncclSuccess; return r; }
+  ncclResult_t end() { open = false; return R->GroupEnd(); }
+  ~NcclBracket() { if (open) (void)R->GroupEnd(); }
+};
+
 struct Member {
   int rank = 0;
   int device = 0;
@@ -229,9 +240,16 @@ int nxsig_shard_istft(int64_t num_frames, int32_t frame_length, int32_t hop, int
 int nxsig_rendezvous_publish(const char* path, const void* data, size_t bytes) {
   NXSIG_API_BEGIN
   if (!path || !*path || (!data && bytes)) return set_error(NXSIG_ERR_INVALID_ARG, "rendezvous_publish: bad arguments");
+  // a file left behind by an earlier launch that used the same path (a crashed run of the same parent) must never be taken for
+  // this launch's: drop it before anything is published.  The new content appears atomically (rename of a private temp file
+  // created exclusively with mode 0600: nobody else can have planted or can read it).
+  (void)::unlink(path);
   const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
-  FILE* f = std::fopen(tmp.c_str(), "wb");
-  if (!f) return set_error(NXSIG_ERR_INVALID_ARG, "rendezvous_publish: cannot create " + tmp);
+  (void)::unlink(tmp.c_str());
+  const int fd = ::open(tmp.c_str(), O_CREAT | O_EXCL | O_WRONLY | O_NOFOLLOW, 0600);
+  if (fd < 0) return set_error(NXSIG_ERR_INVALID_ARG, "rendezvous_publish: cannot create " + tmp);
+  FILE* f = ::fdopen(fd, "wb");
+  if (!f) { ::close(fd); std::remove(tmp.c_str()); return set_error(NXSIG_ERR_INVALID_ARG, "rendezvous_publish: cannot open " + tmp); }
   const size_t n = bytes ? std::fwrite(data, 1, bytes, f) : 0;
   const int ce = std::fclose(f);
   if (n != bytes || ce != 0) { std::remove(tmp.c_str()); return set_error(NXSIG_ERR_INVALID_ARG, "rendezvous_publish: short write to " + tmp); }
@@ -318,13 +336,27 @@ int nxsig_group_create_rank(int32_t world, int32_t rank, int32_t device, const c
   if (rc) { destroy_group(g); return rc; }
   ncclUniqueId id;
   std::memset(&id, 0, sizeof(id));
+  // what travels through the file: the id framed by a tag and the world size, so that a file of the right length that is not
+  // this launch's id (another tool's, a different world size after a relaunch) is not accepted as one
+  struct RdzvBlob { char magic[8]; int32_t world; int32_t version; ncclUniqueId id; } blob;
+  static const char kMagic[8] = {'N', 'X', 'S', 'I', 'G', 'R', 'V', '1'};
   if (rank == 0) {
     ncclResult_t r = R->GetUniqueId(&id);
     if (r != ncclSuccess) { destroy_group(g); return set_error(NXSIG_ERR_HIP, std::string("ncclGetUniqueId: ") + R->GetErrorString(r)); }
-    if (world > 1 && (rc = nxsig_rendezvous_publish(rendezvous_path, &id, sizeof(id)))) { destroy_group(g); return rc; }
-  } else if ((rc = nxsig_rendezvous_fetch(rendezvous_path, &id, sizeof(id), timeout_ms > 0 ? timeout_ms : 120000, 600))) {
-    destroy_group(g);
-    return rc;
+    std::memset(&blob, 0, sizeof(blob));
+    std::memcpy(blob.magic, kMagic, 8); blob.world = world; blob.version = 1; blob.id = id;
+    if (world > 1 && (rc = nxsig_rendezvous_publish(rendezvous_path, &blob, sizeof(blob)))) { destroy_group(g); return rc; }
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int64_t budget = timeout_ms > 0 ? timeout_ms : 120000;
+    for (;;) {
+      const int64_t spent = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (spent >= budget) { destroy_group(g); return set_error(NXSIG_ERR_INVALID_ARG, std::string("group_create_rank: no valid rendezvous file at ") + rendezvous_path); }
+      if ((rc = nxsig_rendezvous_fetch(rendezvous_path, &blob, sizeof(blob), (int32_t)(budget - spent), 600))) { destroy_group(g); return rc; }
+      if (std::memcmp(blob.magic, kMagic, 8) == 0 && blob.world == world && blob.version == 1) break;
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));   // not ours (yet): rank 0 replaces it when it publishes
+    }
+    id = blob.id;
   }
   if (hipSetDevice(device) != hipSuccess) { destroy_group(g); return set_error(NXSIG_ERR_HIP, "hipSetDevice failed"); }
   ncclResult_t r = R->CommInitRank(&g->m[0].comm, world, id, rank);
@@ -365,13 +397,16 @@ int nxsig_group_barrier(nxsig_group* grp) {
     if ((rc = nxsig_sync(mb.ctx))) return rc;
   if (!g->has_rccl) return NXSIG_OK;
   Rccl* R = rccl();
-  NXSIG_NCCL_TRY(R, R->GroupStart());
-  for (auto& mb : g->m) {
-    NXSIG_HIP_TRY(hipSetDevice(mb.device));
-    int* w = reinterpret_cast<int*>(mb.cell);
-    NXSIG_NCCL_TRY(R, R->AllReduce(w, w + 16, 1, ncclInt32, ncclSum, mb.comm, stream_of(mb)));
+  {
+    NcclBracket br(R);
+    NXSIG_NCCL_TRY(R, br.start());
+    for (auto& mb : g->m) {
+      NXSIG_HIP_TRY(hipSetDevice(mb.device));
+      int* w = reinterpret_cast<int*>(mb.cell);
+      NXSIG_NCCL_TRY(R, R->AllReduce(w, w + 16, 1, ncclInt32, ncclSum, mb.comm, stream_of(mb)));
+    }
+    NXSIG_NCCL_TRY(R, br.end());
   }
-  NXSIG_NCCL_TRY(R, R->GroupEnd());
   for (auto& mb : g->m)
     if ((rc = nxsig_sync(mb.ctx))) return rc;
   return NXSIG_OK;
@@ -411,7 +446,8 @@ static int allgather_locked(Group* g, const void* const* send, const int64_t* co
     if (!recv[i] || (!send[i] && counts[g->m[i].rank] > 0)) return set_error(NXSIG_ERR_INVALID_ARG, "group_allgather: null buffer");
   if (g->has_rccl) {
     Rccl* R = rccl();
-    NXSIG_NCCL_TRY(R, R->GroupStart());
+    NcclBracket br(R);
+    NXSIG_NCCL_TRY(R, br.start());
     for (size_t i = 0; i < g->m.size(); ++i) {
       Member& mb = g->m[i];
       NXSIG_HIP_TRY(hipSetDevice(mb.device));
@@ -426,7 +462,7 @@ static int allgather_locked(Group* g, const void* const* send, const int64_t* co
         }
       }
     }
-    NXSIG_NCCL_TRY(R, R->GroupEnd());
+    NXSIG_NCCL_TRY(R, br.end());
     return NXSIG_OK;
   }
   if (g->ranked) return set_error(NXSIG_ERR_UNSUPPORTED, "group_allgather: a ranked group without RCCL cannot assemble");
@@ -468,6 +504,18 @@ struct Plan {
   std::vector<int64_t> count;                                      // output bytes per rank
 };
 
+// Row stride of one member's DEVICE input shard.  batch_stride == 0: the shard is dense, f32[rows][in_len] — the form to use for
+// frame / sample shards, whose spans differ from member to member when the frame count does not divide evenly (a single stride
+// for the whole group cannot describe them: with batch > 1 the later members' rows would be read at the wrong offset).
+// Otherwise batch_stride applies to every member and must cover the member's row.
+static int shard_stride(int64_t batch_stride, int64_t rows, int64_t in_len, int64_t* out) {
+  if (batch_stride == 0) { *out = in_len; return NXSIG_OK; }
+  if (rows > 1 && batch_stride < in_len)
+    return set_error(NXSIG_ERR_INVALID_ARG, "sharded: batch_stride is shorter than a member's rows (pass 0 for dense per-member shards)");
+  *out = batch_stride;
+  return NXSIG_OK;
+}
+
 // runs `compute(member, part, x_dev, out_dev)` for every local member; host mode stages through per-member device buffers
 template <class Compute>
 int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_stride, int32_t axis, int32_t gather,
@@ -485,7 +533,10 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
       char* dst = static_cast<char*>(out[i]);
       if (gather) dst += by_rows ? p.row0 * pl.out_items_total * pl.item_bytes : p.out0 * pl.item_bytes;
       send[i] = dst;
-      if (p.rows > 0 && p.out_len > 0 && (rc = compute(g->m[i], p, static_cast<const float*>(x[i]), batch_stride, dst))) return rc;
+      // every member's device shard has its OWN row length (frame / sample shards: its span of the rows)
+      int64_t stride = 0;
+      if ((rc = shard_stride(batch_stride, p.rows, p.in_len, &stride))) return rc;
+      if (p.rows > 0 && p.out_len > 0 && (rc = compute(g->m[i], p, static_cast<const float*>(x[i]), stride, dst))) return rc;
     }
     if (!gather) return NXSIG_OK;
     return allgather_locked(g, send.data(), pl.count.data(), out);
@@ -757,6 +808,7 @@ int nxsig_stft_mel_sharded_f32(nxsig_group* grp, const float* const* x, int64_t 
     if (mem == NXSIG_DEVICE) {
       if (!x[i] || !out[i]) return fail(set_error(NXSIG_ERR_INVALID_ARG, "stft_mel_sharded: null shard pointer"));
       xin = x[i]; dst = out[i];
+      if ((rc = shard_stride(batch_stride, q.rows, q.in_len, &stride))) return fail(rc);
     } else {  // the member's rows / spans, packed densely on its device
       if ((rc = nxsig_alloc(mb.ctx, (size_t)(q.rows * q.in_len) * sizeof(float), &q.din))) return fail(rc);
       if ((rc = nxsig_alloc(mb.ctx, (size_t)q.count * sizeof(float), &q.dout))) return fail(rc);
@@ -765,9 +817,10 @@ int nxsig_stft_mel_sharded_f32(nxsig_group* grp, const float* const* x, int64_t 
                                (size_t)q.in_len * sizeof(float)))) return fail(rc);
       xin = static_cast<const float*>(q.din); dst = static_cast<float*>(q.dout); stride = q.in_len;
     }
-    c->mel_defer = true;
-    rc = nxsig_stft_mel_f32(mb.ctx, xin, q.in_len, (int32_t)q.rows, stride, window, p, mel_bins, filters, dst, nullptr, NXSIG_DEVICE);
-    c->mel_defer = false;
+    {
+      MelDeferScope defer(c);   // pass 1 only: the clamp waits for the all-reduced maximum
+      rc = nxsig_stft_mel_f32(mb.ctx, xin, q.in_len, (int32_t)q.rows, stride, window, p, mel_bins, filters, dst, nullptr, NXSIG_DEVICE);
+    }
     if (rc) return fail(rc);
     void* gm = nullptr;
     if ((rc = ctx_scratch(c, 5, 256, &gm))) return fail(rc);
@@ -777,12 +830,13 @@ int nxsig_stft_mel_sharded_f32(nxsig_group* grp, const float* const* x, int64_t 
   // the exchange step of the log-mel path: max over the WHOLE tensor (Nx.reduce_max, lib/nx_signal.ex:511) and the non-finite flag
   if (g->has_rccl) {
     Rccl* R = rccl();
-    NXSIG_NCCL_TRY(R, R->GroupStart());
+    NcclBracket br(R);
+    NXSIG_NCCL_TRY(R, br.start());
     for (size_t i = 0; i < nl; ++i) {
       NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
       NXSIG_NCCL_TRY(R, R->AllReduce(sh[i].cell, sh[i].cell, 2, ncclInt32, ncclMax, g->m[i].comm, stream_of(g->m[i])));
     }
-    NXSIG_NCCL_TRY(R, R->GroupEnd());
+    NXSIG_NCCL_TRY(R, br.end());
   } else if (nl > 1) {  // members of one process sharing devices (no communicators): through the host
     int best[2] = {(int)0x80000000, 0};
     for (size_t i = 0; i < nl; ++i) {

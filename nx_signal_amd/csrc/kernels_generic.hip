@@ -434,11 +434,11 @@ struct EdgeFixArgs {
   const float2* filt;       // optional c64[N]: the frames are z * filt rounded to c64 (IstftLaunch::filt), or nullptr
 };
 
-__global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
-  __shared__ double red[2 * kThreads];
+// one output sample of one row, along the reference's chain in double (whole workgroup; `red` = 2 * kThreads doubles of LDS).
+// ALL = false: only ill-conditioned samples (1e-10 < den < tau) are recomputed; true: any sample (den <= 1e-10 divides by 1, :635)
+template <bool ALL>
+__device__ __forceinline__ void istft_sample_f64(const EdgeFixArgs& a, const int64_t row, const int64_t n, double* red) {
   const int tid = threadIdx.x;
-  const int64_t n = a.idx ? a.idx[blockIdx.x] : (int64_t)blockIdx.x;
-  if (n >= a.out_len) return;
   int64_t m_hi = n / a.hop;
   if (m_hi > a.M - 1) m_hi = a.M - 1;
   int64_t m_lo = (n - a.N + 1 <= 0) ? 0 : (n - a.N + a.hop) / a.hop;
@@ -447,9 +447,10 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
     const float w = fabsf(a.window[n - m * a.hop]);
     den += (double)(w * w);
   }
-  const float d = (float)den;
-  if (!(d > 1.0e-10f) || d >= a.tau) return;  // uniform across the block
-  const float2* zb = a.z + (size_t)blockIdx.y * a.M * a.N;
+  float d = (float)den;
+  if (ALL) { if (!(d > 1.0e-10f)) d = 1.0f; }
+  else if (!(d > 1.0e-10f) || d >= a.tau) return;  // uniform across the block
+  const float2* zb = a.z + (size_t)row * a.M * a.N;
   double acc_re = 0.0, acc_im = 0.0;
   for (int64_t m = m_lo; m <= m_hi; ++m) {
     const int j = (int)(n - m * a.hop);
@@ -489,7 +490,38 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
     }
     __syncthreads();
   }
-  if (tid == 0) a.y[(size_t)blockIdx.y * a.out_len + n] = make_float2((float)acc_re / d, (float)acc_im / d);
+  if (tid == 0) a.y[(size_t)row * a.out_len + n] = make_float2((float)acc_re / d, (float)acc_im / d);
+}
+
+__global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
+  __shared__ double red[2 * kThreads];
+  const int64_t n = a.idx ? a.idx[blockIdx.x] : (int64_t)blockIdx.x;
+  if (n >= a.out_len) return;
+  istft_sample_f64<false>(a, (int64_t)blockIdx.y, n, red);
+}
+
+// ---- non-finite bins under kernels that invert SEVERAL frames with one transform (k_istft_wave_half: 2, _quad: 4 / 8).  The
+// reference inverts every frame on its own (Nx.ifft row by row, lib/nx_signal.ex:609), so an Inf / NaN bin reaches only the
+// samples of ITS frame; inside a shared transform it reaches the partner frames' samples too.  Those kernels therefore report
+// every unit that holds a non-finite bin ((row << 40) | first frame, appended to a device list), and this pass recomputes the
+// output samples the unit's frames touch with the per-sample chain above — frame by frame, exactly as the reference does.  Done
+// out of line on purpose: an in-kernel "solo" route cost the streaming kernels their third wave per SIMD (-12 %).
+// list[0] = number of entries appended (may exceed the capacity list[1]); entries follow as int64 from list + 2.
+__global__ __launch_bounds__(kThreads) void k_istft_nf_fix(EdgeFixArgs a, const int* __restrict__ list, int32_t frames_per_unit) {
+  __shared__ double red[2 * kThreads];
+  int cnt = list[0];
+  if (cnt > list[1]) cnt = list[1];
+  if (cnt <= 0) return;
+  const int64_t* ent = reinterpret_cast<const int64_t*>(list + 2);
+  const int64_t span = (int64_t)(frames_per_unit - 1) * a.hop + a.N;   // samples the unit's frames touch
+  const int64_t total = (int64_t)cnt * span;
+  for (int64_t wk = blockIdx.x; wk < total; wk += gridDim.x) {
+    const int64_t e = wk / span, si = wk - e * span;
+    const int64_t row = ent[e] >> 40, m0 = ent[e] & (((int64_t)1 << 40) - 1);
+    const int64_t n = m0 * a.hop + si;
+    if (n < a.out_len) istft_sample_f64<true>(a, row, n, red);
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------ framing
@@ -1271,6 +1303,41 @@ int launch_fir_generic(Ctx* c, const FirLaunch& s) {
   return NXSIG_OK;
 }
 
+// the list a frame-packing istft kernel reports its non-finite units to (see k_istft_nf_fix): {count, capacity, int64 entries};
+// the count is zeroed on the stream ahead of the kernel
+int istft_nf_list(Ctx* c, int64_t capacity, int** list) {
+  if (capacity > 0x7fffffffLL) capacity = 0x7fffffffLL;
+  void* p = nullptr;
+  int rc = ctx_scratch(c, 23, (size_t)(capacity + 1) * 8, &p);
+  if (rc) return rc;
+  const int hdr[2] = {0, (int)capacity};
+  NXSIG_HIP_TRY(hipMemcpyAsync(p, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));   // 8 bytes from pageable memory: staged at once
+  *list = reinterpret_cast<int*>(p);
+  return NXSIG_OK;
+}
+
+int launch_istft_nf_fix(Ctx* c, const IstftLaunch& s, const int* list, int frames_per_unit) {
+  if (!list || s.M == 0 || s.batch == 0) return NXSIG_OK;
+  EdgeFixArgs a;
+  a.z = s.z; a.filt = s.filt; a.M = s.M; a.N = s.N; a.hop = s.hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
+  a.y = s.y; a.out_len = s.M * s.hop + (s.N - s.hop);
+  a.idx = nullptr; a.n_idx = 0; a.tau = 0.0f;
+  {  // inverse twiddles in double (host libm), cached per N (the table of launch_istft_edge_fix)
+    std::vector<double2> tw((size_t)s.N);
+    for (int j = 0; j < s.N; ++j) {
+      const double ang = 6.283185307179586476925286766559 * (double)j / (double)s.N;
+      tw[j] = make_double2(std::cos(ang), std::sin(ang));
+    }
+    const void* d = nullptr;
+    int rc = ctx_table(c, 0xED6Eull, tw.data(), tw.size() * sizeof(double2), &d);
+    if (rc) return rc;
+    a.tw = reinterpret_cast<const double2*>(d);
+  }
+  hipLaunchKernelGGL(k_istft_nf_fix, dim3((unsigned)(c->num_cus * 8)), dim3(kThreads), 0, c->stream, a, list, (int32_t)frames_per_unit);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
 // launched after ANY istft main kernel (generic or tuned): see k_istft_edge_fix
 int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host) {
   if (s.M == 0 || s.batch == 0) return NXSIG_OK;
@@ -1567,7 +1634,7 @@ int launch_mel_init(Ctx* c, int** gmax) {
   return NXSIG_OK;
 }
 int launch_mel_finish(Ctx* c, float* out, int64_t n, int* gmax) {
-  if (n <= 0 || c->mel_defer) return NXSIG_OK;
+  if (n <= 0 || mel_deferred(c)) return NXSIG_OK;
   hipLaunchKernelGGL(k_mel_pass2, dim3((unsigned)((n + 4 * kThreads - 1) / (4 * kThreads))), dim3(kThreads), 0, c->stream, out, n, gmax);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;

@@ -29,7 +29,13 @@ struct IstftWaveArgs {
   v2f* y;                     // c64[batch][segs_per_row * hop]
   v2f* dummy;
   const v2f* filt = nullptr;  // c64[K] spectrum filter (FILT variant of k_istft_wave only)
+  int* nf_list = nullptr;     // kernels that invert several frames per transform: units that hold a non-finite bin are reported here
+                              // ({count, capacity, int64 (row << 40 | first frame) ...}) and redone frame by frame by k_istft_nf_fix
 };
+__device__ __forceinline__ void istft_report_nonfinite(int* list, int64_t row, int64_t first_frame) {
+  const int i = atomicAdd(list, 1);
+  if (i < list[1]) reinterpret_cast<int64_t*>(list + 2)[i] = (row << 40) | first_frame;
+}
 
 // c64 product the way Nx.multiply forms it on the BinaryBackend: in double, each component rounded once (same expression as
 // k_spectrum_mul, so the fused and the two-step chain agree bit for bit)
@@ -282,7 +288,8 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_4k(IstftWaveArgs a) {
 // core returns sample n = lane + 64 q of frame 0 in zz[0][q] and of frame 1 in zz[1][q]: the overlap-add between the
 // two frames and with the pending sums stays in registers for every hop that is a multiple of 64.
 template <int K, int R, bool SCALE, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_istft_wave_half(IstftWaveArgs a) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 VGPRs: the third wave per SIMD is worth 12 %
+void k_istft_wave_half(IstftWaveArgs a) {
   constexpr int NH = K / 2;              // frame length (= fft_length)
   constexpr int R3 = K / 256;
   constexpr int NQ = K / 128;            // samples per lane per frame (n = lane + 64 q, q < NQ)
@@ -340,10 +347,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3))) 
     v2f sum = v2f{0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      sum += r0[q] + r1[q];
       const v2f t = wcmul(r1[q], v2f{tw_re[q], tw_im[q]});
       d[q] = r0[q] + t;
       d[q + NQ] = r0[q] - t;
+      sum += d[q];   // C0 + w C1 is non-finite whenever C0 or C1 is
     }
     nf_next = wave_any_nonfinite(sum.x, sum.y);
   };
@@ -351,36 +358,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3))) 
   combine();
 
   for (int64_t m = m_start; m < j1; m += 2) {
-    const bool nf = nf_next;
+    // a pair that holds a non-finite bin shares it between its two frames here; the reference inverts frame by frame (:609): the
+    // unit is reported and k_istft_nf_fix redoes its samples (an in-kernel solo route cost the third wave per SIMD: -12 %)
+    if (__builtin_expect(nf_next, 0) && lane == 0) istft_report_nonfinite(a.nf_list, row, m);
+    issue_loads(m + 2 < j1 ? m + 2 : m);
+    __builtin_amdgcn_sched_barrier(0);
     v2f zz[2][NQ];
-    if (__builtin_expect(nf, 0)) {
-      // The reference inverts every frame on its own (Nx.ifft row by row, lib/nx_signal.ex:609): a non-finite bin reaches only
-      // the samples of ITS frame.  The pair leaves the shared transform: frame 1 alone (C0 = 0) gives zz[1], frame 0 alone
-      // (C1 = 0) gives zz[0].  Cold path, arranged so that it needs no more registers than the streaming path (or the whole
-      // kernel drops from 3 to 2 waves per SIMD: measured -12 %): the pair's spectra are read again from memory, d[] is reused,
-      // and the next pair's loads are issued only afterwards (the prefetch registers are free during the two transforms).
-      const int64_t last = a.M - 1;
-      const v2f* p0 = zrow + (size_t)(m < last ? m : last) * NH;
-      const v2f* p1 = zrow + (size_t)(m + 1 < last ? m + 1 : last) * NH;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) { const v2f t = wcmul(p1[64 * q], v2f{tw_re[q], tw_im[q]}); d[q] = t; d[q + NQ] = v2f{0.f, 0.f} - t; }
-      wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
-      v2f keep[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) keep[q] = zz[1][q];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) { d[q] = p0[64 * q]; d[q + NQ] = d[q]; }
-      wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) zz[1][q] = keep[q];
-      __builtin_amdgcn_sched_barrier(0);
-      issue_loads(m + 2 < j1 ? m + 2 : m);
-    } else {
-      issue_loads(m + 2 < j1 ? m + 2 : m);
-      __builtin_amdgcn_sched_barrier(0);
-      wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
-    }
+    wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
     __builtin_amdgcn_sched_barrier(0);
     combine();
     __builtin_amdgcn_sched_barrier(0);
@@ -426,7 +410,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3))) 
 // bit-stable; 16-byte LDS reads, no read-modify-write chains).  The first J hop positions are normalised and stored
 // with 16-byte stores; the following N - hop positions become the carry of the next unit (a small LDS strip per wave).
 template <int K, int J, int R, bool SCALE, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_istft_wave_quad(IstftWaveArgs a) {
+__global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
   constexpr int NJ = K / J;              // frame length (= fft_length)
   constexpr int P = K / 64;
   constexpr int PJ = P / J;              // bins per lane per frame: k0 = lane + 64 s', s' < PJ
@@ -485,15 +469,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3))) 
     for (int s = 0; s < PJ; ++s) {
       v2f t[J];
       t[0] = r[0][s];
-      sum += t[0];
 #pragma unroll
       for (int j = 1; j < J; ++j) {
         const v2f w = s_twQ[(j - 1) * NJ + lane + 64 * s];
-        sum += r[j][s];
         t[j] = wcmul(r[j][s], v2f{w.x, -w.y});
       }
       if (J == 4) dft4<false>(t[0], t[1], t[2], t[3]);
       else dft8<false>(t);
+      sum += t[0];   // the butterfly's first output is the sum of the J (twiddled) bins: non-finite whenever one of them is
 #pragma unroll
       for (int m = 0; m < J; ++m) d[s + PJ * m] = t[m];
     }
@@ -503,42 +486,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3))) 
   pack();
 
   for (int64_t u = us; u < u1; ++u) {
-    const bool nf = nf_next;
+    if (__builtin_expect(nf_next, 0) && lane == 0) istft_report_nonfinite(a.nf_list, row, u * J);   // see k_istft_wave_half
+    issue_loads(u + 1 < u1 ? u + 1 : u);  // unconditional prefetch keeps the loop branch-free
+    __builtin_amdgcn_sched_barrier(0);
     v2f zz[2][NQ];
-    if (__builtin_expect(nf, 0)) {
-      // solo route (see k_istft_wave_half): every frame of the unit alone through the transform, the other J - 1 sequences zero;
-      // element (par, q) of the result belongs to frame (2 lane + par) mod J and is taken from that frame's pass
-#pragma nounroll
-      for (int js = 0; js < J; ++js) {
-        const int64_t m = u * J + js;
-        const v2f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * NJ;
-        v2f zs[2][NQ];   // (d[] is free: pack() below rebuilds it for the next unit)
-#pragma unroll
-        for (int s = 0; s < PJ; ++s) {
-          v2f c = pz[64 * s];
-          if (js > 0) { const v2f w = s_twQ[(js - 1) * NJ + lane + 64 * s]; c = wcmul(c, v2f{w.x, -w.y}); }
-          // forward radix-J butterfly of a sequence that is zero except at j = js: t[mm] = c w_J^(js mm)
-#pragma unroll
-          for (int mm = 0; mm < J; ++mm) {
-            const int ph = (js * mm) % J;                         // w_J^ph = exp(-2 pi i ph / J)
-            const float ang = -6.283185307179586f * (float)ph / (float)J;
-            d[s + PJ * mm] = wcmul(c, v2f{__builtin_cosf(ang), __builtin_sinf(ang)});
-          }
-        }
-        wave_fft_core<K, true>(d, zs, xb, s_twB, s_twC, lane);
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            if (js == 0 || (2 * lane + e) % J == js) zz[e][q] = zs[e][q];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      issue_loads(u + 1 < u1 ? u + 1 : u);   // only now: the prefetch registers were free during the J transforms (see _half)
-    } else {
-      issue_loads(u + 1 < u1 ? u + 1 : u);  // unconditional prefetch keeps the loop branch-free
-      __builtin_amdgcn_sched_barrier(0);
-      wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
-    }
+    wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
     __builtin_amdgcn_sched_barrier(0);
     pack();
     __builtin_amdgcn_sched_barrier(0);
@@ -973,6 +925,9 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
     if (rc4) return rc4;
     a.twH = reinterpret_cast<const v2f*>(dh);
     const size_t lds = (size_t)(K / 2) * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)(K / 2) * 8 + (size_t)W * XCH * 8;
+    // every run also walks its halo units: capacity = units walked by all runs
+    { int rcl = istft_nf_list(c, a.total_runs * ((run_len + R + 1) / 2 + 1), &a.nf_list); if (rcl) return rcl; }
+    s.nf_list = a.nf_list; s.nf_frames_per_unit = 2;
     if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_half<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     else hipLaunchKernelGGL((k_istft_wave_half<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
   } else if (DBL) {
@@ -1036,6 +991,8 @@ static int launch_istft_wave_quad(Ctx* c, const IstftLaunch& s, const float* win
   a.total_runs = a.runs_per_row * s.batch;
   const int64_t blocks = (a.total_runs + W - 1) / W;
   const size_t lds = (size_t)NJ * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)(J - 1) * NJ * 8 + (size_t)W * XCH * 8 + (size_t)W * CPAD * 8;
+  { int rcl = istft_nf_list(c, a.total_runs * (run_len + (R - 1 + J - 1) / J + 1), &a.nf_list); if (rcl) return rcl; }
+  s.nf_list = a.nf_list; s.nf_frames_per_unit = J;
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

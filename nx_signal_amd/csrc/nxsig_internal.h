@@ -60,6 +60,7 @@ struct DeviceTable {
   void* ptr = nullptr;
   size_t bytes = 0;
   std::vector<unsigned char> host;  // copy of the content (tables <= 1 MiB): a hash hit is verified against it
+  bool has_host = false;            // (a zero-byte table has a host copy too: an empty one)
 };
 
 struct Ctx {
@@ -101,10 +102,20 @@ struct Ctx {
   std::multimap<size_t, void*> pool_free;   // size -> block
   std::map<void*, size_t> pool_live;        // blocks handed out by nxsig_alloc
   size_t pool_cached = 0, pool_cap = 0;     // bytes sitting in pool_free; cap (0 = not yet decided)
-  // set by the sharded log-mel (group.cpp): the clamp pass of stft_to_mel / the fused mel sink is NOT launched — the running
-  // maximum of this context's shard must first be all-reduced with the other members'; the group launches the pass afterwards
-  bool mel_defer = false;
 };
+
+// Set (for the calling THREAD and one context) by the sharded log-mel of group.cpp while it runs pass 1 on a member: the clamp
+// pass of stft_to_mel / the fused mel sink is NOT launched — the running maximum of the member's shard must first be
+// all-reduced with the other members'; the group launches the pass afterwards.  Thread-local on purpose: another thread that
+// calls nxsig_stft_mel_f32 / stft_to_mel on the same context at the same time keeps its own clamp pass, and the scope guard
+// clears the mark on every way out.
+struct MelDeferScope {
+  explicit MelDeferScope(const Ctx* c);
+  ~MelDeferScope();
+  MelDeferScope(const MelDeferScope&) = delete;
+  MelDeferScope& operator=(const MelDeferScope&) = delete;
+};
+bool mel_deferred(const Ctx* c);
 
 int ctx_twiddles(Ctx* c, int K, const float2** out);
 int ctx_table(Ctx* c, uint64_t tag, const void* host, size_t bytes, const void** out);
@@ -139,7 +150,13 @@ struct IstftLaunch {
   float2* y;             // device c64[batch][M*hop + N-hop]
   const float2* filt = nullptr;  // optional device c64[K]: every frame's spectrum is multiplied by it first (z * H of the
                                  // STFT-domain filtering chain, guides/filtering.livemd:141), rounded to c64 like Nx.multiply
+  // set by a wave launcher whose kernel inverts several frames with ONE transform: the device list of units that hold a
+  // non-finite bin and the frames per unit; launch_istft then recomputes those units' samples frame by frame (k_istft_nf_fix)
+  mutable const int* nf_list = nullptr;
+  mutable int nf_frames_per_unit = 0;
 };
+int istft_nf_list(Ctx* c, int64_t capacity, int** list);
+int launch_istft_nf_fix(Ctx* c, const IstftLaunch& s, const int* list, int frames_per_unit);
 int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host);
 
 int launch_as_windowed(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, const Framing& fr, float* out);

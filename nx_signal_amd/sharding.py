@@ -72,7 +72,14 @@ def rendezvous_path(env=None) -> str:
     """File through which rank 0 hands the ncclUniqueId to the other ranks of ONE node: unique per launch (the launcher's
     pid and its rendezvous port), removed by rank 0 once the communicator is up."""
     env = os.environ if env is None else env
-    d = env.get("NXSIG_RDZV_DIR", "/tmp")
+    d = env.get("NXSIG_RDZV_DIR")
+    if d is None:
+        # a directory only this user can write to (0700, ownership checked): nobody else can plant an id file there
+        d = os.path.join("/tmp", "nxsig-%d" % os.getuid())
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.stat(d)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise RuntimeError(f"{d} is not a private directory of this user (set NXSIG_RDZV_DIR)")
     return os.path.join(d, "nxsig_rdzv_%s_%s_%d" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
 
 
@@ -184,7 +191,9 @@ def stft_sharded(group: Group, data, window, axis: str = "channels", gather: boo
                 m0, m1, _, _ = shard_frames(M, N, hop, group.world, r)
                 shape = (batch, m1 - m0, K)
             outs.append(group.contexts[i].empty(shape, np.complex64))
-        stride = int(data[0].shape[-1])
+        # channel shards: rows of the full length; frame shards: every member's buffer is dense [batch][its span] and the spans
+        # differ from member to member when the frame count does not divide evenly -> 0 = "dense per-member shards" (nxsig.h)
+        stride = int(data[0].shape[-1]) if ax == CHANNELS else 0
         xs = (C.c_void_p * n)(*[C.c_void_p(d.ptr) for d in data])
         zs = (C.c_void_p * n)(*[C.c_void_p(o.ptr) for o in outs])
         _lib.check(lib.nxsig_stft_sharded_f32(group.handle, xs, int(length), int(batch), stride, w.ctypes.data_as(C.c_void_p),
@@ -326,7 +335,9 @@ def mel_spectrogram_sharded(group: Group, data, window, axis: str = "channels", 
             raise _lib.ArgumentError("device shards need length= and batch= of the whole tensor")
         M = int(_lib.check(lib.nxsig_num_frames(int(length), N, hop, _lib.PAD_VALID, 0, 0)))
         outs = [group.contexts[i].empty(shard_shape(r, int(batch), M), np.float32) for i, r in enumerate(group.ranks)]
-        stride = int(data[0].shape[-1])
+        # channel shards: rows of the full length; frame shards: every member's buffer is dense [batch][its span] and the spans
+        # differ from member to member when the frame count does not divide evenly -> 0 = "dense per-member shards" (nxsig.h)
+        stride = int(data[0].shape[-1]) if ax == CHANNELS else 0
         xs = (C.c_void_p * n)(*[C.c_void_p(d.ptr) for d in data])
         ys = (C.c_void_p * n)(*[C.c_void_p(o.ptr) for o in outs])
         _lib.check(lib.nxsig_stft_mel_sharded_f32(group.handle, xs, int(length), int(batch), stride, wp, C.byref(p), mb, fp, ax, ys,

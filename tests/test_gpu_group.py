@@ -112,6 +112,41 @@ def test_stft_device_shards_stay_on_their_device(pair):
         assert float(np.max(np.abs(o.numpy()[0] - full[0])) / np.max(np.abs(full[0]))) < 1e-6
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_device_frame_shards_with_several_rows_and_unequal_spans(world):
+    """batch > 1, frames axis, frame count not divisible by the member count: the members' dense device shards have rows of
+    DIFFERENT lengths (round 2 read the later members' rows 1.. at member 0's stride: ADVICE r02)"""
+    grp = sharding.Group.local(world, devices=[0] * world)
+    try:
+        B, N, hop = 3, 512, 128
+        M = 8 * 13 + 5                                   # 109 frames: 2 x 55 - 1, 8 x 14 - 3
+        L = N + hop * (M - 1)
+        x = np.stack([O.synth_signal(L, seed=300 + c) for c in range(B)])
+        w = S.windows.hann(N)
+        opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=8000)
+        full, _, _ = S.stft(x, w, **opts)
+        assert full.shape[1] == M
+        shards, spans = [], []
+        for i, r in enumerate(grp.ranks):
+            m0, m1, s0, s1 = sharding.shard_frames(M, N, hop, grp.world, r)
+            spans.append((m0, m1, s1 - s0))
+            shards.append(grp.contexts[i].to_device(np.ascontiguousarray(x[:, s0:s1])))
+        assert len({sp[2] for sp in spans}) > 1          # the spans really differ
+        outs = sharding.stft_sharded(grp, shards, w, axis="frames", length=L, batch=B, **opts)
+        grp.sync()
+        for (m0, m1, _), o in zip(spans, outs):
+            got = o.numpy()
+            assert got.shape == (B, m1 - m0, N)
+            assert float(np.max(np.abs(got - full[:, m0:m1])) / np.max(np.abs(full))) < 1e-6
+        mel = sharding.mel_spectrogram_sharded(grp, shards, w, axis="frames", length=L, batch=B, mel_bins=40, **opts)
+        grp.sync()
+        ref = S.mel_spectrogram(x, w, mel_bins=40, **opts)
+        for (m0, m1, _), o in zip(spans, mel):
+            assert float(np.max(np.abs(o.numpy() - np.asarray(ref)[:, m0:m1]))) < 1e-4
+    finally:
+        grp.close()
+
+
 def test_allgather_of_unequal_shards(pair, solo):
     rng = np.random.default_rng(3)
     parts = [rng.integers(0, 2 ** 31, size=n, dtype=np.int64).astype(np.uint32) for n in (1000, 37)]

@@ -389,7 +389,8 @@ defmodule NxSignalAMD do
     {params, overlap_length, m, batch_shape}
   end
 
-  defp times_and_frequencies({frame_length, _hop, fft_length, _pad, _lo, _hi, _scaling, fs}, m) do
+  @doc false
+  def times_and_frequencies({frame_length, _hop, fft_length, _pad, _lo, _hi, _scaling, fs}, m) do
     # times = linspace(N / (2 fs), M N / (2 fs), n: M) (lib/nx_signal.ex:108-111, quirk B4), f32 arithmetic like the reference
     step = frame_length / (2 * fs)
     times = Nx.linspace(step, step * m, n: m, name: :frames, type: :f32)

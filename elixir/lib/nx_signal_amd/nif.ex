@@ -65,4 +65,21 @@ defmodule NxSignalAMD.NIF do
 
   def stft_mel_sharded(_group, _x, _length, _batch, _window, _params, _mel_bins, _filters, _axis),
     do: :erlang.nif_error(:nif_not_loaded)
+
+  # device-resident shards (NxSignalAMD.Sharded.Tensor): one dense buffer per group member
+  def shard_range(_kind, _a, _b, _c, _world, _rank), do: :erlang.nif_error(:nif_not_loaded)
+  def group_scatter(_group, _bin, _batch, _row_bytes, _parts), do: :erlang.nif_error(:nif_not_loaded)
+  def group_gather(_group, _bufs, _batch, _row_bytes, _parts), do: :erlang.nif_error(:nif_not_loaded)
+
+  def stft_sharded_dev(_group, _x_bufs, _length, _batch, _window, _params, _axis, _gather),
+    do: :erlang.nif_error(:nif_not_loaded)
+
+  def istft_sharded_dev(_group, _z_bufs, _frames, _batch, _window, _params, _axis, _gather),
+    do: :erlang.nif_error(:nif_not_loaded)
+
+  def fir_sharded_dev(_group, _x_bufs, _length, _batch, _taps, _mode, _axis, _gather),
+    do: :erlang.nif_error(:nif_not_loaded)
+
+  def stft_mel_sharded_dev(_group, _x_bufs, _length, _batch, _window, _params, _mel_bins, _filters, _axis),
+    do: :erlang.nif_error(:nif_not_loaded)
 end

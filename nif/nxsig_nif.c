@@ -32,15 +32,27 @@ static ErlNifResourceType* BUF_RES;
 static ErlNifResourceType* GRP_RES;
 
 typedef struct { nxsig_ctx* ctx; } ctx_res_t;
-typedef struct { ctx_res_t* owner; void* dptr; size_t bytes; } buf_res_t;
 typedef struct { nxsig_group* grp; } grp_res_t;
+/* a device buffer lives on ONE context: a context resource (owner) or member `member` of a group (gowner); the buffer keeps
+ * whichever it belongs to alive, so the memory can always be returned to the allocator it came from */
+typedef struct { ctx_res_t* owner; grp_res_t* gowner; int member; void* dptr; size_t bytes; } buf_res_t;
 
 static void ctx_dtor(ErlNifEnv* env, void* obj) { (void)env; ctx_res_t* r = obj; if (r->ctx) nxsig_ctx_destroy(r->ctx); }
 static void buf_dtor(ErlNifEnv* env, void* obj) {
   (void)env;
   buf_res_t* b = obj;
   if (b->dptr && b->owner && b->owner->ctx) nxsig_free(b->owner->ctx, b->dptr);
+  if (b->dptr && b->gowner && b->gowner->grp) {
+    nxsig_ctx* c = nxsig_group_ctx(b->gowner->grp, b->member);
+    if (c) nxsig_free(c, b->dptr);
+  }
   if (b->owner) enif_release_resource(b->owner);
+  if (b->gowner) enif_release_resource(b->gowner);
+}
+static nxsig_ctx* buf_ctx(const buf_res_t* b) {
+  if (b->owner) return b->owner->ctx;
+  if (b->gowner && b->gowner->grp) return nxsig_group_ctx(b->gowner->grp, b->member);
+  return NULL;
 }
 static void grp_dtor(ErlNifEnv* env, void* obj) { (void)env; grp_res_t* g = obj; if (g->grp) nxsig_group_destroy(g->grp); }
 
@@ -107,7 +119,15 @@ static int get_params(ErlNifEnv* env, ERL_NIF_TERM t, nxsig_stft_params* p) {
 
 static ERL_NIF_TERM make_buf(ErlNifEnv* env, ctx_res_t* c, void* d, size_t bytes) {
   buf_res_t* r = enif_alloc_resource(BUF_RES, sizeof *r);
-  r->owner = c; enif_keep_resource(c); r->dptr = d; r->bytes = bytes;
+  r->owner = c; enif_keep_resource(c); r->gowner = NULL; r->member = 0; r->dptr = d; r->bytes = bytes;
+  ERL_NIF_TERM t = enif_make_resource(env, r);
+  enif_release_resource(r);
+  return t;
+}
+/* a buffer on member `member` of a group */
+static ERL_NIF_TERM make_gbuf(ErlNifEnv* env, grp_res_t* g, int member, void* d, size_t bytes) {
+  buf_res_t* r = enif_alloc_resource(BUF_RES, sizeof *r);
+  r->owner = NULL; r->gowner = g; enif_keep_resource(g); r->member = member; r->dptr = d; r->bytes = bytes;
   ERL_NIF_TERM t = enif_make_resource(env, r);
   enif_release_resource(r);
   return t;
@@ -547,8 +567,10 @@ static ERL_NIF_TERM nif_from_device(ErlNifEnv* env, int argc, const ERL_NIF_TERM
   buf_res_t* b;
   ErlNifBinary ob;
   if (argc != 1 || !get_buf(env, argv[0], &b)) return enif_make_badarg(env);
+  nxsig_ctx* bc = buf_ctx(b);
+  if (!bc) return enif_make_badarg(env);
   if (!enif_alloc_binary(b->bytes, &ob)) return mk_oom(env);
-  int rc = nxsig_download(b->owner->ctx, ob.data, b->dptr, b->bytes);
+  int rc = nxsig_download(bc, ob.data, b->dptr, b->bytes);
   if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
   return mk_ok(env, enif_make_binary(env, &ob));
 }
@@ -833,6 +855,291 @@ static ERL_NIF_TERM nif_fir_sharded(ErlNifEnv* env, int argc, const ERL_NIF_TERM
   return mk_ok(env, enif_make_binary(env, &yb));
 }
 
+/* ------------------------------------------------------------------------------------------------ device-resident shards
+ * NxSignalAMD.Sharded.Tensor: one dense device buffer per group member, the payload never visits the host between
+ * group_scatter (Sharded.to_device) and group_gather (Sharded.from_device).  The reference axis being sharded is Nx's
+ * vectorized axis (lib/nx_signal.ex:358-363) or, for one long stream, the frame / sample axis. */
+#define NXSIG_MAX_MEMBERS 64
+
+/* shard_range(kind, a, b, c, world, rank) -> {x0, x1, y0, y1}
+ *   kind 0: nxsig_shard_range(total = a)            -> {begin, end, 0, 0}
+ *   kind 1: nxsig_shard_frames(num_frames = a, frame_length = b, hop = c)   -> {m0, m1, s0, s1}
+ *   kind 2: nxsig_shard_istft(num_frames = a, frame_length = b, hop = c)    -> {f0, f1, n0, n1}
+ *   kind 3: nxsig_shard_fir(length = a, num_taps = b, mode = c)             -> {n0, n1, s0, s1} */
+static ERL_NIF_TERM nif_shard_range(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  int kind, world, rank;
+  ErlNifSInt64 a, b, c;
+  if (argc != 6 || !enif_get_int(env, argv[0], &kind) || !enif_get_int64(env, argv[1], &a) || !enif_get_int64(env, argv[2], &b) ||
+      !enif_get_int64(env, argv[3], &c) || !enif_get_int(env, argv[4], &world) || !enif_get_int(env, argv[5], &rank))
+    return enif_make_badarg(env);
+  if (b < -0x7fffffff || b > 0x7fffffff || c < -0x7fffffff || c > 0x7fffffff) return enif_make_badarg(env);
+  int64_t r[4] = {0, 0, 0, 0};
+  int rc;
+  switch (kind) {
+    case 0: rc = nxsig_shard_range(a, world, rank, &r[0], &r[1]); break;
+    case 1: rc = nxsig_shard_frames(a, (int32_t)b, (int32_t)c, world, rank, &r[0], &r[1], &r[2], &r[3]); break;
+    case 2: rc = nxsig_shard_istft(a, (int32_t)b, (int32_t)c, world, rank, &r[0], &r[1], &r[2], &r[3]); break;
+    case 3: rc = nxsig_shard_fir(a, (int32_t)b, (int32_t)c, world, rank, &r[0], &r[1], &r[2], &r[3]); break;
+    default: return enif_make_badarg(env);
+  }
+  if (rc) return mk_error(env, rc);
+  return mk_ok(env, enif_make_tuple4(env, enif_make_int64(env, r[0]), enif_make_int64(env, r[1]), enif_make_int64(env, r[2]),
+                                     enif_make_int64(env, r[3])));
+}
+
+/* [{row0, rows, off_bytes, len_bytes}, ...] — one entry per LOCAL member, in member order */
+typedef struct { int64_t row0, rows, off, len; } part_t;
+static int get_parts(ErlNifEnv* env, ERL_NIF_TERM list, int n, part_t* out) {
+  unsigned len;
+  if (!enif_get_list_length(env, list, &len) || (int)len != n) return 0;
+  ERL_NIF_TERM head, tail = list;
+  for (int i = 0; i < n; ++i) {
+    const ERL_NIF_TERM* e;
+    int arity;
+    ErlNifSInt64 v[4];
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !enif_get_tuple(env, head, &arity, &e) || arity != 4) return 0;
+    for (int k = 0; k < 4; ++k)
+      if (!enif_get_int64(env, e[k], &v[k]) || v[k] < 0) return 0;
+    out[i].row0 = v[0]; out[i].rows = v[1]; out[i].off = v[2]; out[i].len = v[3];
+  }
+  return 1;
+}
+static int get_bufs(ErlNifEnv* env, ERL_NIF_TERM list, grp_res_t* g, int n, buf_res_t** out) {
+  unsigned len;
+  if (!enif_get_list_length(env, list, &len) || (int)len != n) return 0;
+  ERL_NIF_TERM head, tail = list;
+  for (int i = 0; i < n; ++i) {
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !get_buf(env, head, &out[i])) return 0;
+    if (out[i]->gowner != g || out[i]->member != i) return 0;   /* buffer i must live on member i of THIS group */
+  }
+  return 1;
+}
+static ERL_NIF_TERM bufs_to_list(ErlNifEnv* env, grp_res_t* g, int n, void** d, const size_t* bytes) {
+  ERL_NIF_TERM t[NXSIG_MAX_MEMBERS];
+  for (int i = 0; i < n; ++i) t[i] = make_gbuf(env, g, i, d[i], bytes[i]);
+  return enif_make_list_from_array(env, t, (unsigned)n);
+}
+static void free_members(grp_res_t* g, int n, void** d) {
+  for (int i = 0; i < n; ++i)
+    if (d[i]) { nxsig_free(nxsig_group_ctx(g->grp, i), d[i]); d[i] = NULL; }
+}
+
+/* group_scatter(group, bin, batch, row_bytes, parts) -> {:ok, [buf]}: member i receives rows [row0, row0 + rows) x bytes
+ * [off, off + len) of the host tensor [batch][row_bytes], packed densely ([rows][len]) on its own device */
+static ERL_NIF_TERM nif_group_scatter(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  ErlNifBinary b;
+  ErlNifSInt64 batch, row_bytes;
+  part_t parts[NXSIG_MAX_MEMBERS];
+  if (argc != 5 || !get_grp(env, argv[0], &g) || !enif_inspect_binary(env, argv[1], &b) || !enif_get_int64(env, argv[2], &batch) ||
+      !enif_get_int64(env, argv[3], &row_bytes))
+    return enif_make_badarg(env);
+  const int n = nxsig_group_local_count(g->grp);
+  if (n < 1 || n > NXSIG_MAX_MEMBERS || batch < 1 || row_bytes < 1 || (uint64_t)b.size / (uint64_t)batch != (uint64_t)row_bytes ||
+      b.size % (size_t)batch || !get_parts(env, argv[4], n, parts))
+    return enif_make_badarg(env);
+  for (int i = 0; i < n; ++i)
+    if (parts[i].row0 + parts[i].rows > batch || parts[i].off + parts[i].len > row_bytes) return enif_make_badarg(env);
+  void* d[NXSIG_MAX_MEMBERS] = {0};
+  size_t bytes[NXSIG_MAX_MEMBERS];
+  for (int i = 0; i < n; ++i) {
+    nxsig_ctx* c = nxsig_group_ctx(g->grp, i);
+    bytes[i] = (size_t)parts[i].rows * (size_t)parts[i].len;
+    int rc = nxsig_alloc(c, bytes[i] ? bytes[i] : 4, &d[i]);
+    for (int64_t r = 0; !rc && r < parts[i].rows && parts[i].len > 0; ++r)
+      rc = nxsig_upload(c, (char*)d[i] + (size_t)r * (size_t)parts[i].len,
+                        b.data + (size_t)(parts[i].row0 + r) * (size_t)row_bytes + (size_t)parts[i].off, (size_t)parts[i].len);
+    if (rc) { free_members(g, n, d); return mk_error(env, rc); }
+  }
+  return mk_ok(env, bufs_to_list(env, g, n, d, bytes));
+}
+
+/* group_gather(group, [buf], batch, row_bytes, parts) -> {:ok, bin}: the inverse of group_scatter for RESULT shards */
+static ERL_NIF_TERM nif_group_gather(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  ErlNifBinary ob;
+  ErlNifSInt64 batch, row_bytes;
+  part_t parts[NXSIG_MAX_MEMBERS];
+  buf_res_t* bufs[NXSIG_MAX_MEMBERS];
+  if (argc != 5 || !get_grp(env, argv[0], &g) || !enif_get_int64(env, argv[2], &batch) || !enif_get_int64(env, argv[3], &row_bytes))
+    return enif_make_badarg(env);
+  const int n = nxsig_group_local_count(g->grp);
+  if (n < 1 || n > NXSIG_MAX_MEMBERS || batch < 1 || row_bytes < 1 || !get_bufs(env, argv[1], g, n, bufs) || !get_parts(env, argv[4], n, parts))
+    return enif_make_badarg(env);
+  for (int i = 0; i < n; ++i)
+    if (parts[i].row0 + parts[i].rows > batch || parts[i].off + parts[i].len > row_bytes ||
+        bufs[i]->bytes < (size_t)parts[i].rows * (size_t)parts[i].len)
+      return enif_make_badarg(env);
+  if (!out_bin(&ob, (uint64_t)batch, (uint64_t)row_bytes, 1, 1)) return mk_oom(env);
+  memset(ob.data, 0, ob.size);   /* positions no shard covers (none for the plans of nxsig_shard_*) read as zero */
+  for (int i = 0; i < n; ++i) {
+    nxsig_ctx* c = nxsig_group_ctx(g->grp, i);
+    int rc = nxsig_sync(c);      /* the shard may still be in flight on the member's stream */
+    for (int64_t r = 0; !rc && r < parts[i].rows && parts[i].len > 0; ++r)
+      rc = nxsig_download(c, ob.data + (size_t)(parts[i].row0 + r) * (size_t)row_bytes + (size_t)parts[i].off,
+                          (const char*)bufs[i]->dptr + (size_t)r * (size_t)parts[i].len, (size_t)parts[i].len);
+    if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  }
+  return mk_ok(env, enif_make_binary(env, &ob));
+}
+
+/* output shard sizes (bytes per member) of the sharded calls; gather: every member holds the whole tensor */
+static int out_sizes(grp_res_t* g, int n, int axis, int gather, int64_t batch, int64_t items_per_row, int64_t item_bytes, int kind, int64_t a,
+                     int32_t b, int32_t c, size_t* bytes) {
+  const int world = nxsig_group_world(g->grp);
+  for (int i = 0; i < n; ++i) {
+    const int rank = nxsig_group_rank(g->grp, i);
+    int64_t rows = batch, items = items_per_row;
+    if (!gather) {
+      int64_t r[4];
+      int rc;
+      if (axis == NXSIG_SHARD_CHANNELS) { if ((rc = nxsig_shard_range(batch, world, rank, &r[0], &r[1]))) return rc; rows = r[1] - r[0]; }
+      else if (kind == 1) { if ((rc = nxsig_shard_frames(a, b, c, world, rank, &r[0], &r[1], &r[2], &r[3]))) return rc; items = r[1] - r[0]; }
+      else if (kind == 2) { if ((rc = nxsig_shard_istft(a, b, c, world, rank, &r[0], &r[1], &r[2], &r[3]))) return rc; items = r[3] - r[2]; }
+      else { if ((rc = nxsig_shard_fir(a, b, c, world, rank, &r[0], &r[1], &r[2], &r[3]))) return rc; items = r[1] - r[0]; }
+    }
+    size_t sz = (size_t)item_bytes;
+    if (!mul_size(&sz, (uint64_t)rows) || !mul_size(&sz, (uint64_t)items)) return NXSIG_ERR_OOM;
+    bytes[i] = sz;
+  }
+  return 0;
+}
+static int alloc_members(grp_res_t* g, int n, const size_t* bytes, void** d) {
+  for (int i = 0; i < n; ++i) {
+    int rc = nxsig_alloc(nxsig_group_ctx(g->grp, i), bytes[i] ? bytes[i] : 4, &d[i]);
+    if (rc) { free_members(g, n, d); return rc; }
+  }
+  return 0;
+}
+
+/* stft_sharded_dev(group, [x_buf], length, batch, window_bin, params, axis, gather) -> {:ok, [z_buf], num_frames}
+ * x_buf i = member i's dense input shard (rows [c0, c1) of the tensor / the span [s0, s1) of every row); the result shards
+ * (or, gather = 1, the whole c64[batch][M][K] on every member, assembled by the RCCL all-gather) stay on their devices */
+static ERL_NIF_TERM nif_stft_sharded_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  ErlNifBinary w;
+  ErlNifSInt64 length;
+  int batch, axis, gather;
+  nxsig_stft_params p;
+  buf_res_t* xb[NXSIG_MAX_MEMBERS];
+  if (argc != 8 || !get_grp(env, argv[0], &g) || !enif_get_int64(env, argv[2], &length) || !enif_get_int(env, argv[3], &batch) ||
+      !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p) || !enif_get_int(env, argv[6], &axis) ||
+      !enif_get_int(env, argv[7], &gather))
+    return enif_make_badarg(env);
+  const int n = nxsig_group_local_count(g->grp);
+  if (n < 1 || n > NXSIG_MAX_MEMBERS || batch < 1 || length < 1 || w.size != (size_t)p.frame_length * 4 || !get_bufs(env, argv[1], g, n, xb))
+    return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
+  if (m < 0) return mk_error(env, (int)m);
+  size_t bytes[NXSIG_MAX_MEMBERS];
+  void* z[NXSIG_MAX_MEMBERS] = {0};
+  int rc = out_sizes(g, n, axis, gather, batch, m, (int64_t)p.fft_length * 8, 1, m, p.frame_length, p.hop, bytes);
+  if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
+  if ((rc = alloc_members(g, n, bytes, z))) return mk_error(env, rc);
+  const float* xs[NXSIG_MAX_MEMBERS];
+  nxsig_c64* zs[NXSIG_MAX_MEMBERS];
+  for (int i = 0; i < n; ++i) { xs[i] = (const float*)xb[i]->dptr; zs[i] = (nxsig_c64*)z[i]; }
+  /* channel shards: rows of the full length; frame shards: dense per-member spans (batch_stride 0, see nxsig.h) */
+  rc = nxsig_stft_sharded_f32(g->grp, xs, length, batch, axis == NXSIG_SHARD_CHANNELS ? length : 0, (const float*)w.data, &p, axis, gather, zs,
+                              NXSIG_DEVICE);
+  if (rc) { free_members(g, n, z); return mk_error(env, rc); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), bufs_to_list(env, g, n, z, bytes), enif_make_int64(env, m));
+}
+
+/* istft_sharded_dev(group, [z_buf], num_frames, batch, window_bin, params, axis, gather) -> {:ok, [y_buf]} */
+static ERL_NIF_TERM nif_istft_sharded_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  ErlNifBinary w;
+  ErlNifSInt64 m;
+  int batch, axis, gather;
+  nxsig_stft_params p;
+  buf_res_t* zb[NXSIG_MAX_MEMBERS];
+  if (argc != 8 || !get_grp(env, argv[0], &g) || !enif_get_int64(env, argv[2], &m) || !enif_get_int(env, argv[3], &batch) ||
+      !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p) || !enif_get_int(env, argv[6], &axis) ||
+      !enif_get_int(env, argv[7], &gather))
+    return enif_make_badarg(env);
+  const int n = nxsig_group_local_count(g->grp);
+  if (n < 1 || n > NXSIG_MAX_MEMBERS || batch < 1 || m < 1 || w.size != (size_t)p.frame_length * 4 || !get_bufs(env, argv[1], g, n, zb))
+    return enif_make_badarg(env);
+  int64_t out_len = nxsig_ola_length(m, p.frame_length, p.hop);
+  if (out_len < 0) return mk_error(env, (int)out_len);
+  size_t bytes[NXSIG_MAX_MEMBERS];
+  void* y[NXSIG_MAX_MEMBERS] = {0};
+  int rc = out_sizes(g, n, axis, gather, batch, out_len, 8, 2, m, p.frame_length, p.hop, bytes);
+  if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
+  if ((rc = alloc_members(g, n, bytes, y))) return mk_error(env, rc);
+  const nxsig_c64* zs[NXSIG_MAX_MEMBERS];
+  nxsig_c64* ys[NXSIG_MAX_MEMBERS];
+  for (int i = 0; i < n; ++i) { zs[i] = (const nxsig_c64*)zb[i]->dptr; ys[i] = (nxsig_c64*)y[i]; }
+  rc = nxsig_istft_sharded_c64(g->grp, zs, m, batch, (const float*)w.data, &p, axis, gather, ys, NXSIG_DEVICE);
+  if (rc) { free_members(g, n, y); return mk_error(env, rc); }
+  return mk_ok(env, bufs_to_list(env, g, n, y, bytes));
+}
+
+/* fir_sharded_dev(group, [x_buf], length, batch, taps_bin, mode, axis, gather) -> {:ok, [y_buf]} */
+static ERL_NIF_TERM nif_fir_sharded_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  ErlNifBinary h;
+  ErlNifSInt64 length;
+  int batch, mode, axis, gather;
+  buf_res_t* xb[NXSIG_MAX_MEMBERS];
+  if (argc != 8 || !get_grp(env, argv[0], &g) || !enif_get_int64(env, argv[2], &length) || !enif_get_int(env, argv[3], &batch) ||
+      !enif_inspect_binary(env, argv[4], &h) || !enif_get_int(env, argv[5], &mode) || !enif_get_int(env, argv[6], &axis) ||
+      !enif_get_int(env, argv[7], &gather))
+    return enif_make_badarg(env);
+  const int n = nxsig_group_local_count(g->grp);
+  if (n < 1 || n > NXSIG_MAX_MEMBERS || batch < 1 || length < 1 || h.size < 4 || h.size % 4 || h.size / 4 > 0x7fffffff ||
+      !get_bufs(env, argv[1], g, n, xb))
+    return enif_make_badarg(env);
+  const int taps = (int)(h.size / 4);
+  int64_t out_len = nxsig_conv_length(length, taps, mode);
+  if (out_len < 0) return mk_error(env, (int)out_len);
+  size_t bytes[NXSIG_MAX_MEMBERS];
+  void* y[NXSIG_MAX_MEMBERS] = {0};
+  int rc = out_sizes(g, n, axis, gather, batch, out_len, 4, 3, length, taps, mode, bytes);
+  if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
+  if ((rc = alloc_members(g, n, bytes, y))) return mk_error(env, rc);
+  const float* xs[NXSIG_MAX_MEMBERS];
+  float* ys[NXSIG_MAX_MEMBERS];
+  for (int i = 0; i < n; ++i) { xs[i] = (const float*)xb[i]->dptr; ys[i] = (float*)y[i]; }
+  rc = nxsig_fir_sharded_f32(g->grp, xs, length, batch, axis == NXSIG_SHARD_CHANNELS ? length : 0, (const float*)h.data, taps, mode, axis, gather,
+                             ys, NXSIG_DEVICE);
+  if (rc) { free_members(g, n, y); return mk_error(env, rc); }
+  return mk_ok(env, bufs_to_list(env, g, n, y, bytes));
+}
+
+/* stft_mel_sharded_dev(group, [x_buf], length, batch, window_bin, params, mel_bins, filters_bin, axis) -> {:ok, [o_buf], M} */
+static ERL_NIF_TERM nif_stft_mel_sharded_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  grp_res_t* g;
+  ErlNifBinary w, f;
+  ErlNifSInt64 length;
+  int batch, bins, axis;
+  nxsig_stft_params p;
+  buf_res_t* xb[NXSIG_MAX_MEMBERS];
+  if (argc != 9 || !get_grp(env, argv[0], &g) || !enif_get_int64(env, argv[2], &length) || !enif_get_int(env, argv[3], &batch) ||
+      !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p) || !enif_get_int(env, argv[6], &bins) ||
+      !enif_inspect_binary(env, argv[7], &f) || !enif_get_int(env, argv[8], &axis))
+    return enif_make_badarg(env);
+  const int n = nxsig_group_local_count(g->grp);
+  if (n < 1 || n > NXSIG_MAX_MEMBERS || batch < 1 || length < 1 || bins < 1 || w.size != (size_t)p.frame_length * 4 || p.fft_length < 2 ||
+      f.size % 4 || f.size / 4 / (size_t)bins != (size_t)p.fft_length || f.size / 4 % (size_t)bins || !get_bufs(env, argv[1], g, n, xb))
+    return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
+  if (m < 0) return mk_error(env, (int)m);
+  size_t bytes[NXSIG_MAX_MEMBERS];
+  void* o[NXSIG_MAX_MEMBERS] = {0};
+  int rc = out_sizes(g, n, axis, 0, batch, m, (int64_t)bins * 4, 1, m, p.frame_length, p.hop, bytes);
+  if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
+  if ((rc = alloc_members(g, n, bytes, o))) return mk_error(env, rc);
+  const float* xs[NXSIG_MAX_MEMBERS];
+  float* os[NXSIG_MAX_MEMBERS];
+  for (int i = 0; i < n; ++i) { xs[i] = (const float*)xb[i]->dptr; os[i] = (float*)o[i]; }
+  rc = nxsig_stft_mel_sharded_f32(g->grp, xs, length, batch, axis == NXSIG_SHARD_CHANNELS ? length : 0, (const float*)w.data, &p, bins,
+                                  (const float*)f.data, axis, os, NULL, NXSIG_DEVICE);
+  if (rc) { free_members(g, n, o); return mk_error(env, rc); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), bufs_to_list(env, g, n, o, bytes), enif_make_int64(env, m));
+}
+
 static int load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {
   (void)priv; (void)info;
   CTX_RES = enif_open_resource_type(env, NULL, "nxsig_ctx", ctx_dtor, ERL_NIF_RT_CREATE | ERL_NIF_RT_TAKEOVER, NULL);
@@ -880,6 +1187,13 @@ static ErlNifFunc funcs[] = {
     {"istft_sharded", 8, nif_istft_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir_sharded", 8, nif_fir_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_mel_sharded", 9, nif_stft_mel_sharded, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"shard_range", 6, nif_shard_range, 0},
+    {"group_scatter", 5, nif_group_scatter, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"group_gather", 5, nif_group_gather, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_sharded_dev", 8, nif_stft_sharded_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"istft_sharded_dev", 8, nif_istft_sharded_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"fir_sharded_dev", 8, nif_fir_sharded_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_mel_sharded_dev", 9, nif_stft_mel_sharded_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 ERL_NIF_INIT(Elixir.NxSignalAMD.NIF, funcs, load, NULL, upgrade, NULL)

@@ -338,6 +338,7 @@ struct WaveArgs {
   int64_t u_split, u_add0, u_add1;  // unit u of the launch is unit-in-row u + (u < u_split ? u_add0 : u_add1)
   int64_t chunk;              // units per workgroup (contiguous)
   int64_t xcd_span = 0;       // > 0: workgroup b takes chunk (b % 8) * xcd_span + b / 8 (consecutive chunks on one XCD); 0: chunk b
+  int32_t early_loads = 0;    // 1: the first unit's sample loads are issued BEFORE the tables are staged (start-up latencies overlap)
   const float* wtab;          // device f32[fft_length]: window zero-padded / truncated to the fft length
   const v2f* twB;             // device c64[16][16]: w_256^(t k)
   const v2f* twC;             // device c64[R3][256]: w_C^(t i)
@@ -420,23 +421,27 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   v2f* s_twR = s_twC + R3 * 256;
   v2f* s_x = s_twR + (MODE == kModeReal2x ? K : (MODE == kModeQuad ? TWQ : 0));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < KOUT; i += kWaveThreads) s_w[i] = a.wtab[i];
-  for (int i = tid; i < 256; i += kWaveThreads) s_twB[i] = a.twB[i];
-  for (int i = tid; i < R3 * 256; i += kWaveThreads) s_twC[i] = a.twC[i];
-  if (MODE == kModeReal2x)
-    for (int i = tid; i < K; i += kWaveThreads) s_twR[i] = a.twR[i];
-  if (MODE == kModeQuad)
-    for (int i = tid; i < TWQ; i += kWaveThreads) s_twR[i] = a.twR[i];  // [j-1][k0] = conj(w_K^(j k0))
-  // MEL: [nnz] filter weights, [mel_bins + 1] offsets, [mel_bins] first bins after the exchange buffers
+  // the tables are staged (and the workgroup's only barrier passed) AFTER the first unit's sample loads have been issued, see
+  // below: the two memory round trips of a workgroup's start-up overlap (a short launch is mostly start-up: config 2 as written)
   float* s_csr = reinterpret_cast<float*>(s_x + W * XCH);
   int* s_off = reinterpret_cast<int*>(s_csr + (MEL ? mp->nnz : 0));
   int* s_lo = s_off + (MEL ? mp->mel_bins + 1 : 0);
-  if (MEL) {
-    for (int i = tid; i < mp->nnz; i += kWaveThreads) s_csr[i] = mp->csr_w[i];
-    for (int i = tid; i <= mp->mel_bins; i += kWaveThreads) s_off[i] = mp->csr_off[i];
-    for (int i = tid; i < mp->mel_bins; i += kWaveThreads) s_lo[i] = mp->csr_lo[i];
-  }
-  __syncthreads();  // the only workgroup barrier: tables are read-only afterwards
+  auto stage_tables = [&]() {
+    for (int i = tid; i < KOUT; i += kWaveThreads) s_w[i] = a.wtab[i];
+    for (int i = tid; i < 256; i += kWaveThreads) s_twB[i] = a.twB[i];
+    for (int i = tid; i < R3 * 256; i += kWaveThreads) s_twC[i] = a.twC[i];
+    if (MODE == kModeReal2x)
+      for (int i = tid; i < K; i += kWaveThreads) s_twR[i] = a.twR[i];
+    if (MODE == kModeQuad)
+      for (int i = tid; i < TWQ; i += kWaveThreads) s_twR[i] = a.twR[i];  // [j-1][k0] = conj(w_K^(j k0))
+    // MEL: [nnz] filter weights, [mel_bins + 1] offsets, [mel_bins] first bins after the exchange buffers
+    if (MEL) {
+      for (int i = tid; i < mp->nnz; i += kWaveThreads) s_csr[i] = mp->csr_w[i];
+      for (int i = tid; i <= mp->mel_bins; i += kWaveThreads) s_off[i] = mp->csr_off[i];
+      for (int i = tid; i < mp->mel_bins; i += kWaveThreads) s_lo[i] = mp->csr_lo[i];
+    }
+    __syncthreads();  // the only workgroup barrier: tables are read-only afterwards
+  };
   v2f* xb = s_x + wave * XCH;
   // MEL: after the core the exchange buffer is idle: |X|^2 of frame f of the unit at mags[f * KOUT/2 + k], k < KOUT/2
   float* mags = reinterpret_cast<float*>(xb);
@@ -580,10 +585,15 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   };
   advance(nrow, nuin);
   v2f d[P];  // windowed samples of the current pair: re = frame A, im = frame B (exact f32 products, :101)
-  if (!GENERAL && p_begin + wave < p_end) {
-    issue_loads(row, pinof(uin));
-    window_mul(d);
+  const bool have_first = !GENERAL && p_begin + wave < p_end;
+  if (a.early_loads) {
+    if (have_first) issue_loads(row, pinof(uin));   // raw samples travel while the tables are staged
+    stage_tables();
+  } else {
+    stage_tables();
+    if (have_first) issue_loads(row, pinof(uin));
   }
+  if (have_first) window_mul(d);
 
   // ---- Nx.fft's clean-up (SURVEY App. A rule 7; call site lib/nx_signal.ex:102): every component of the finished spectrum
   // with |x| <= eps = 1e-10 becomes +0, BEFORE the :spectrum / :psd division (:113-127).  NaN compares false and stays.
@@ -1222,6 +1232,12 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
                              : mel ? env_int("NXSIG_MEL_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
                                  : env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : (MODE == kModeQuad ? (J == 2 ? 2 : 3) : 8));  // measured optima (input from HBM)
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
+  // a launch so small that its workgroups all fit on the chip at once (three per CU; BASELINE config 2 as written: one 60 s
+  // stream, 703 workgroups) is one round of start-up latencies: three pairs per wave amortise them better than two (+1.5 ... 2.6 %
+  // in interleaved sweeps, tools/sweep_stft.py with SWEEP_B=1; the steady-state optimum of many rounds stays at two)
+  if (MODE == kModePair && !mel && units_per_wave == 2 && !std::getenv("NXSIG_WAVE_UNITS_PER_WAVE") &&
+      (a.total_pairs + 2 * W - 1) / (2 * W) <= (int64_t)c->num_cus * 3)
+    a.chunk = (int64_t)W * 3;
   // Interior frames [m_lo, m_hi): every one of the KOUT samples the streaming front-end reads lies inside the signal,
   // whatever the padding mode (window_padding :reflect / :same / explicit only touch the first and last few frames).
   // Interior units go to the branch-free software-pipelined kernel; the edge units to the bounds-checked one.
@@ -1261,6 +1277,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     a.total_pairs = upr * s.batch;
     int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
     a.xcd_span = 0;
+    a.early_loads = env_int("NXSIG_EARLY_LOADS", 0);
     if (env_int("NXSIG_XCD_REMAP", 0) && blocks >= 64) { a.xcd_span = (blocks + 7) / 8; blocks = a.xcd_span * 8; }
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
     if (lds > 64 * 1024)

@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_group_ranked.py: one RANKED member (one process per rank) of a two-rank group whose ranks share the
+"""Worker of tests/test_gpu_group_ranked.py: one RANKED member (one process per rank) of a 2- or 8-rank group whose ranks share the
 single GPU of the test box.  RCCL refuses two ranks on one device of one host, so every rank claims its own host id
 (NCCL_HOSTID) and the pair talks through RCCL's socket transport over loopback: the whole multi-process path — file
 rendezvous of the ncclUniqueId, ncclCommInitRank, barrier, all-reduce, all-gather of EQUAL shards (ncclAllGather, in place)
@@ -16,14 +16,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     import faulthandler
 
-    faulthandler.dump_traceback_later(120, exit=True)  # a hang prints where every thread is and ends the process
+    faulthandler.dump_traceback_later(240, exit=True)  # a hang prints where every thread is and ends the process
     rank, world, path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     os.dup2(2, 1)  # RCCL's banner goes to stdout: keep it away from the verdict line
     import nx_signal_amd as S
     from nx_signal_amd import sharding
     from oracle import nx_oracle as O
 
-    g = sharding.Group.ranked(world=world, rank=rank, device=0, path=path, timeout_ms=60000)
+    g = sharding.Group.ranked(world=world, rank=rank, device=0, path=path, timeout_ms=150000)
     ctx = g.contexts[0]
     assert g.world == world and g.local_count == 1 and g.ranks == [rank] and g.has_rccl
     g.barrier()
@@ -45,7 +45,7 @@ def main():
     ctx.sync()
     assert np.array_equal(eq.numpy(), np.stack([np.arange(4096, dtype=np.uint32) + 100000 * (r + 1) for r in range(world)])), "in-place all-gather"
     # sharded stft on device shards: channels (3 + 2 of 5) and frame ranges of one stream, assembled on every rank
-    B, L, N, hop = 5, 30000, 1024, 256
+    B, L, N, hop = max(5, world + 3), 30000, 1024, 256   # every rank owns at least one channel (11 over 8 ranks: 2, 2, 2, 1, ...)
     x = np.stack([O.synth_signal(L, seed=100 + c) for c in range(B)])
     w = S.windows.hann(N)
     opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000)

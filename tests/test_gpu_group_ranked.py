@@ -1,4 +1,4 @@
-"""The one-process-per-GPU (RANKED) multi-GPU path with TWO real processes and real RCCL on a one-GPU box: see
+"""The one-process-per-GPU (RANKED) multi-GPU path with TWO and with EIGHT real processes and real RCCL on a one-GPU box: see
 tests/ranked_worker.py.  The ranks share device 0, claim distinct NCCL_HOSTIDs and use RCCL's socket transport over the
 loopback interface, so ncclCommInitRank(world = 2), the file rendezvous, the all-reduce barrier and both all-gather shapes
 run exactly as they do across GPUs (only the transport differs: sockets instead of xGMI)."""
@@ -12,22 +12,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranked_processes_share_one_gpu(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranked_processes_share_one_gpu(tmp_path, world):
+    """world = 8 is the size the 8-GPU node runs: the rendezvous file is fetched by seven ranks, ncclCommInitRank meets eight
+    peers, the unequal-shard assembly is eight broadcasts per rank (11 channels over 8 ranks: 2, 2, 2, 1, 1, 1, 1, 1)"""
     path = str(tmp_path / "rdzv")
     procs = []
-    for rank in range(2):
+    for rank in range(world):
         env = dict(os.environ, NCCL_HOSTID=f"nxsig-test-rank{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_DEBUG="WARN")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ranked_worker.py"), str(rank), "2", path],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ranked_worker.py"), str(rank), str(world), path],
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=300))
+            outs.append(p.communicate(timeout=420))
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
             raise
     for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, (rank, se[-3000:])
-        assert f"RANKED-OK rank {rank} of 2" in se, se[-2000:]
+        assert f"RANKED-OK rank {rank} of {world}" in se, se[-2000:]
     assert not os.path.exists(path)  # rank 0 removed the rendezvous file once the communicator was up

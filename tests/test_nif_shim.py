@@ -69,7 +69,7 @@ def test_nif_ex_matches_the_shim_table():
     assert called <= set(table), called - set(table)
     # GPU entry points are dirty jobs (a scheduler thread must never block on the GPU)
     for (name, ar), flags in table.items():
-        if name in ("window", "firwin", "fft_frequencies", "sinc", "buf_size", "group_info", "device_count"):
+        if name in ("window", "firwin", "fft_frequencies", "sinc", "buf_size", "group_info", "device_count", "shard_range"):
             continue
         assert flags in (1, 2), (name, ar, flags)
 
@@ -316,6 +316,102 @@ def test_sharded_calls_through_the_nif():
         H.call("stft_mel_sharded", g, xq, 30000, 3, w, PARAMS, 80, np.ascontiguousarray(filt[:, :100]), 0)
     del g, g1, ctx
     H.release_all()
+
+
+def _plan(H, kind, a, b, c, world, pick):
+    return [pick(H.call("shard_range", kind, a, b, c, world, r)[1]) for r in range(world)]
+
+
+@gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_device_resident_shards_through_the_nif(world):
+    """NxSignalAMD.Sharded.Tensor, term for term: group_scatter (Sharded.Tensor.to_device) -> stft_sharded_dev ->
+    istft_sharded_dev / fir_sharded_dev / stft_mel_sharded_dev -> group_gather (from_device).  Between the first and the last
+    call the payload exists only as buffer resources on the members' devices; the result bits equal the unsharded calls'."""
+    ok, g = H.call("group_create", [0] * world)
+    assert H.call("group_info", g)[:2] == (world, world)
+    B, L, N, hop = 5, 40000, 1024, 256
+    x = np.stack([O.synth_signal(L, seed=700 + c) for c in range(B)])
+    w = S.windows.hann(N)
+    z, _, _ = S.stft(x, w, overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+    M = z.shape[1]
+    y = S.istft(z, w, overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+    h = S.filters.firwin(257, [4000.0], sampling_rate=48000)
+    yf = S.filters.fir(x, h)
+
+    # ---- channels: rows [c0, c1) per member
+    rows = _plan(H, 0, B, 0, 0, world, lambda r: (r[0], r[1] - r[0]))
+    def rplan(row_bytes):
+        return [(r0, n, 0, row_bytes) for r0, n in rows]
+    ok, xb = H.call("group_scatter", g, x, B, L * 4, rplan(L * 4))
+    assert len(xb) == world and all(isinstance(b, H.Res) for b in xb)
+    assert [H.call("buf_size", b) for b in xb] == [n * L * 4 for _, n in rows]
+    ok, zb, m = H.call("stft_sharded_dev", g, xb, L, B, w, PARAMS, 0, 0)
+    assert m == M and [H.call("buf_size", b) for b in zb] == [n * M * N * 8 for _, n in rows]
+    ok, zbin = H.call("group_gather", g, zb, B, M * N * 8, rplan(M * N * 8))
+    assert np.array_equal(c64(zbin).view(np.uint32), z.reshape(-1).view(np.uint32))
+    ok, yb = H.call("istft_sharded_dev", g, zb, M, B, w, PARAMS, 0, 0)          # the chain stays on the devices
+    ok, ybin = H.call("group_gather", g, yb, B, y.shape[1] * 8, rplan(y.shape[1] * 8))
+    assert np.array_equal(c64(ybin).view(np.uint32), y.reshape(-1).view(np.uint32))
+    ok, fb = H.call("fir_sharded_dev", g, xb, L, B, h, 1, 0, 0)
+    ok, fbin = H.call("group_gather", g, fb, B, L * 4, rplan(L * 4))
+    assert np.array_equal(f32(fbin).view(np.uint32), yf.reshape(-1).view(np.uint32))
+    # gather: every member ends up with the whole spectrum; member 0's copy is downloaded like a DeviceTensor
+    ok, zfull, m = H.call("stft_sharded_dev", g, xb, L, B, w, PARAMS, 0, 1)
+    assert all(H.call("buf_size", b) == B * M * N * 8 for b in zfull)
+    for b in (zfull[0], zfull[-1]):
+        ok, one = H.call("from_device", b)
+        assert np.array_equal(c64(one).view(np.uint32), z.reshape(-1).view(np.uint32))
+    # the sharded log-mel with its all-reduce, on device shards
+    xq = x.copy()
+    xq[0] *= np.float32(1e-3)
+    filt = S.mel_filters(N, 80, 48000.0)
+    mel = S.mel_spectrogram(xq, w, overlap_length=N - hop, fft_length=N, sampling_rate=48000, mel_bins=80)
+    ok, xqb = H.call("group_scatter", g, xq, B, L * 4, rplan(L * 4))
+    ok, mb, m = H.call("stft_mel_sharded_dev", g, xqb, L, B, w, PARAMS, 80, filt, 0)
+    ok, mbin = H.call("group_gather", g, mb, B, M * 80 * 4, rplan(M * 80 * 4))
+    assert np.array_equal(f32(mbin).view(np.uint32), mel.reshape(-1).view(np.uint32))
+
+    # ---- frames of long streams (batch > 1: the members' spans differ in length)
+    fr = [H.call("shard_range", 1, M, N, hop, world, r)[1] for r in range(world)]      # (m0, m1, s0, s1)
+    ok, xs = H.call("group_scatter", g, x, B, L * 4, [(0, B, s0 * 4, (s1 - s0) * 4) for _, _, s0, s1 in fr])
+    ok, zs, m = H.call("stft_sharded_dev", g, xs, L, B, w, PARAMS, 1, 0)
+    ok, zbin = H.call("group_gather", g, zs, B, M * N * 8, [(0, B, m0 * N * 8, (m1 - m0) * N * 8) for m0, m1, _, _ in fr])
+    assert float(np.max(np.abs(c64(zbin).reshape(z.shape) - z)) / np.max(np.abs(z))) < 1e-6
+    ir = [H.call("shard_range", 2, M, N, hop, world, r)[1] for r in range(world)]      # (f0, f1, n0, n1)
+    ok, zi = H.call("group_scatter", g, z, B, M * N * 8, [(0, B, f0 * N * 8, (f1 - f0) * N * 8) for f0, f1, _, _ in ir])
+    ok, yi = H.call("istft_sharded_dev", g, zi, M, B, w, PARAMS, 1, 0)
+    ok, ybin = H.call("group_gather", g, yi, B, y.shape[1] * 8, [(0, B, n0 * 8, (n1 - n0) * 8) for _, _, n0, n1 in ir])
+    assert np.array_equal(c64(ybin).view(np.uint32), y.reshape(-1).view(np.uint32))
+    sr = [H.call("shard_range", 3, L, 257, 1, world, r)[1] for r in range(world)]      # (n0, n1, s0, s1)
+    ok, xf = H.call("group_scatter", g, x, B, L * 4, [(0, B, s0 * 4, (s1 - s0) * 4) for _, _, s0, s1 in sr])
+    ok, ff = H.call("fir_sharded_dev", g, xf, L, B, h, 1, 1, 0)
+    ok, fbin = H.call("group_gather", g, ff, B, L * 4, [(0, B, n0 * 4, (n1 - n0) * 4) for n0, n1, _, _ in sr])
+    assert float(np.max(np.abs(f32(fbin).reshape(yf.shape) - yf)) / np.max(np.abs(yf))) < 1e-6
+
+    # ---- misuse: buffers of another group / in the wrong order / too few, malformed plans
+    ok, g2 = H.call("group_create", [0] * world)
+    with pytest.raises(H.BadArg):
+        H.call("stft_sharded_dev", g2, xb, L, B, w, PARAMS, 0, 0)
+    with pytest.raises(H.BadArg):
+        H.call("stft_sharded_dev", g, list(reversed(xb)), L, B, w, PARAMS, 0, 0)
+    with pytest.raises(H.BadArg):
+        H.call("stft_sharded_dev", g, xb[:-1], L, B, w, PARAMS, 0, 0)
+    with pytest.raises(H.BadArg):
+        H.call("group_scatter", g, x, B, L * 4, [(0, B + 1, 0, L * 4)] * world)
+    with pytest.raises(H.BadArg):
+        H.call("group_gather", g, zb, B, M * N * 8, [(0, B, 0, M * N * 8 + 8)] * world)
+    with pytest.raises(H.BadArg):
+        H.call("shard_range", 7, 10, 0, 0, world, 0)
+    # the buffers keep their group alive: drop the group term first, then the buffers
+    live = H.lib().fake_live_resources()
+    del g, g2
+    H.release_all()
+    ok, one = H.call("from_device", zfull[1])
+    assert np.array_equal(c64(one).view(np.uint32), z.reshape(-1).view(np.uint32))
+    del xb, zb, yb, fb, zfull, xqb, mb, xs, zs, zi, yi, xf, ff
+    H.release_all()
+    assert H.lib().fake_live_resources() < live
 
 
 @gpu

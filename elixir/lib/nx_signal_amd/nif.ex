@@ -47,6 +47,8 @@ defmodule NxSignalAMD.NIF do
   def buf_size(_buf), do: :erlang.nif_error(:nif_not_loaded)
   def stft_dev(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def stft_onesided_dev(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def stft_packed_dev(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def istft_packed_dev(_ctx, _z, _frames, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft_dev(_ctx, _z, _frames, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft_filtered_dev(_ctx, _z, _frames, _batch, _window, _params, _h), do: :erlang.nif_error(:nif_not_loaded)
   def fir_dev(_ctx, _x, _length, _batch, _taps, _mode), do: :erlang.nif_error(:nif_not_loaded)

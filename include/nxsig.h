@@ -261,6 +261,25 @@ int nxsig_stft_onesided_f32(nxsig_ctx* ctx, const float* x, int64_t length, int3
                             const nxsig_stft_params* params, nxsig_c64* out, int64_t* num_frames_out, int32_t mem);
 
 /*
+ * The PACKED one-sided pair (opt-in; not in the reference API): the reference's STFT-domain filtering chain
+ * stft -> z * H -> istft (guides/filtering.livemd:137-159) moves the full two-sided spectrum, 8 KB + 2 KB of HBM traffic per
+ * frame at fft_length 1024, although for a real signal half of z mirrors the other half and the imaginary part of the istft
+ * result is round-off (callers take Nx.real / Nx.as_type, lib/nx_signal.ex:550).  The packed pair keeps what is independent:
+ *   nxsig_stft_packed_f32    out c64[batch][M][fft_length / 2]: bins 0 .. fft_length/2 - 1 exactly as nxsig_stft_onesided_f32
+ *                            writes them, except that the imaginary part of bin 0 (zero for a real frame) carries
+ *                            Re X[fft_length / 2], the Nyquist bin (real for a real frame) — nothing of a real frame's
+ *                            spectrum is lost.  fft_length even.  4 KB per frame.
+ *   nxsig_istft_packed_f32   the inverse of exactly that layout (a pointwise product z * H of two packed tensors must treat
+ *                            bin 0 as the two reals it is): y REAL f32[batch][M * hop + frame_length - hop], equal to the real part
+ *                            of nxsig_istft_c64 on the full Hermitian spectrum to fp32 round-off.  1 KB per frame.
+ * frame_length == fft_length as for istft; fused kernel for 1024 / hop 128 ... 1024, other shapes go through the full layout.
+ */
+int nxsig_stft_packed_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* window,
+                          const nxsig_stft_params* params, nxsig_c64* out, int64_t* num_frames_out, int32_t mem);
+int nxsig_istft_packed_f32(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
+                           const nxsig_stft_params* params, float* y, int32_t mem);
+
+/*
  * Magnitude spectrogram fused with the STFT (opt-in, not in the reference API): what
  * guides/spectrogram.livemd:76-92 computes from NxSignal.stft/3 — Nx.abs(s) of the bins below fft_length / 2, optionally
  * as dBFS 20 * log(|s| / reduce_max|s|) / log(10) — without writing the complex spectrum to HBM: fft_length * 2 bytes per

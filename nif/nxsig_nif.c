@@ -606,8 +606,9 @@ static ERL_NIF_TERM nif_stft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
   return enif_make_tuple3(env, mk_atom(env, "ok"), make_buf(env, c, z, zbytes), enif_make_int64(env, m));
 }
 
-/* stft_onesided_dev(ctx, x_buf, length, batch, window_bin, params) -> {:ok, z_buf, num_frames}   (bins 0 .. fft_length/2 - 1 only: c64[batch][M][fft_length / 2]) */
-static ERL_NIF_TERM nif_stft_onesided_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+/* stft_onesided_dev / stft_packed_dev(ctx, x_buf, length, batch, window_bin, params) -> {:ok, z_buf, num_frames}
+ * c64[batch][M][fft_length / 2]: bins 0 .. fft_length/2 - 1; packed: the imaginary part of bin 0 carries Re X[fft_length / 2] */
+static ERL_NIF_TERM stft_half_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[], int packed) {
   ctx_res_t* c;
   buf_res_t* x;
   ErlNifBinary w;
@@ -626,9 +627,39 @@ static ERL_NIF_TERM nif_stft_onesided_dev(ErlNifEnv* env, int argc, const ERL_NI
   void* z = NULL;
   int rc = nxsig_alloc(c->ctx, zbytes, &z);
   if (rc) return mk_error(env, rc);
-  rc = nxsig_stft_onesided_f32(c->ctx, (const float*)x->dptr, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)z, NULL, NXSIG_DEVICE);
+  rc = packed ? nxsig_stft_packed_f32(c->ctx, (const float*)x->dptr, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)z, NULL, NXSIG_DEVICE)
+              : nxsig_stft_onesided_f32(c->ctx, (const float*)x->dptr, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)z, NULL, NXSIG_DEVICE);
   if (rc) { nxsig_free(c->ctx, z); return mk_error(env, rc); }
   return enif_make_tuple3(env, mk_atom(env, "ok"), make_buf(env, c, z, zbytes), enif_make_int64(env, m));
+}
+static ERL_NIF_TERM nif_stft_onesided_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { return stft_half_dev(env, argc, argv, 0); }
+static ERL_NIF_TERM nif_stft_packed_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { return stft_half_dev(env, argc, argv, 1); }
+
+/* istft_packed_dev(ctx, z_buf, num_frames, batch, window_bin, params) -> {:ok, y_buf}: z packed c64[batch][M][fft_length / 2],
+ * y REAL f32[batch][M * hop + frame_length - hop] */
+static ERL_NIF_TERM nif_istft_packed_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  buf_res_t* z;
+  ErlNifBinary w;
+  ErlNifSInt64 m;
+  int batch;
+  nxsig_stft_params p;
+  if (argc != 6 || !get_ctx(env, argv[0], &c) || !get_buf(env, argv[1], &z) || !enif_get_int64(env, argv[2], &m) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p))
+    return enif_make_badarg(env);
+  if (batch < 1 || m < 1 || p.fft_length < 2 || z->owner != c || w.size != (size_t)p.frame_length * 4 ||
+      z->bytes / 8 / (size_t)batch / (size_t)m < (size_t)(p.fft_length / 2))
+    return enif_make_badarg(env);
+  int64_t n = nxsig_ola_length(m, p.frame_length, p.hop);
+  if (n < 0) return mk_error(env, (int)n);
+  size_t ybytes = 4;
+  if (!mul_size(&ybytes, (uint64_t)batch) || !mul_size(&ybytes, (uint64_t)n)) return mk_oom(env);
+  void* y = NULL;
+  int rc = nxsig_alloc(c->ctx, ybytes, &y);
+  if (rc) return mk_error(env, rc);
+  rc = nxsig_istft_packed_f32(c->ctx, (const nxsig_c64*)z->dptr, m, batch, (const float*)w.data, &p, (float*)y, NXSIG_DEVICE);
+  if (rc) { nxsig_free(c->ctx, y); return mk_error(env, rc); }
+  return mk_ok(env, make_buf(env, c, y, ybytes));
 }
 
 /* istft_dev(ctx, z_buf, num_frames, batch, window_bin, params) -> {:ok, y_buf} */
@@ -1177,6 +1208,8 @@ static ErlNifFunc funcs[] = {
     {"buf_size", 1, nif_buf_size, 0},
     {"stft_dev", 6, nif_stft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_onesided_dev", 6, nif_stft_onesided_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_packed_dev", 6, nif_stft_packed_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"istft_packed_dev", 6, nif_istft_packed_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_dev", 6, nif_istft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_filtered_dev", 7, nif_istft_filtered_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir_dev", 6, nif_fir_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},

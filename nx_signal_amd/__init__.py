@@ -211,7 +211,21 @@ def stft_onesided(data, window, ctx: Context | None = None, **opts):
     return _stft(data, window, ctx, opts, True)
 
 
-def _stft(data, window, ctx, opts, onesided):
+def stft_packed(data, window, ctx: Context | None = None, **opts):
+    """Extension (not in the reference API): the one-sided spectrum of `stft_onesided` with NOTHING of a real frame's spectrum
+    lost — the imaginary part of bin 0 (zero for a real frame) carries Re X[fft_length / 2], the Nyquist bin.  The layout
+    `istft_packed` inverts: together they run the reference's stft -> z * H -> istft chain (guides/filtering.livemd:137-159) at
+    4 KB + 1 KB of HBM traffic per 1024-point frame instead of 8 + 2.  Returns (z c64[..., M, K // 2], times, frequencies[:K // 2])."""
+    return _stft(data, window, ctx, opts, True, packed=True)
+
+
+def istft_packed(data, window, ctx: Context | None = None, **opts):
+    """Inverse of `stft_packed`: c64[..., M, K // 2] (packed) -> REAL f32[..., M * hop + overlap], equal to
+    `istft(full Hermitian spectrum).real` to fp32 round-off.  Options as for `istft` (fft_length, if given, is the FULL length)."""
+    return _istft(data, window, ctx, opts, None, packed=True)
+
+
+def _stft(data, window, ctx, opts, onesided, packed=False):
     p, N, hop, K = _resolve_stft_opts(window, opts)
     w = _window_host(window)
     fs = float(p.sampling_rate)
@@ -221,7 +235,9 @@ def _stft(data, window, ctx, opts, onesided):
     Kout = K // 2 if onesided else K
     if onesided and K < 2:
         raise ArgumentError("stft_onesided: fft_length >= 2 required")
-    entry = lib.nxsig_stft_onesided_f32 if onesided else lib.nxsig_stft_f32
+    entry = lib.nxsig_stft_packed_f32 if packed else (lib.nxsig_stft_onesided_f32 if onesided else lib.nxsig_stft_f32)
+    if packed and K % 2:
+        raise ArgumentError("stft_packed: fft_length must be even")
     if is_device(data):
         ptr, shape, dt = device_view(data)
         if dt != np.float32:
@@ -266,7 +282,7 @@ def istft_filtered(data, h, window, ctx: Context | None = None, **opts):
     return _istft(data, window, ctx, opts, hh)
 
 
-def _istft(data, window, ctx, opts, hh):
+def _istft(data, window, ctx, opts, hh, packed=False):
     o = _validate(opts, {"fft_length": None, "overlap_length": None, "scaling": None, "sampling_rate": 1000}, "istft")
     w = _window_host(window)
     N = int(w.shape[0])
@@ -295,6 +311,8 @@ def _istft(data, window, ctx, opts, hh):
     if len(shape) < 2:
         raise ArgumentError("istft expects a tensor of shape {..., frames, frequencies}")
     Mf, Kin = int(shape[-2]), int(shape[-1])
+    if packed:
+        Kin *= 2   # the packed rows hold fft_length / 2 complex values
     K = _resolve_fft_length(o["fft_length"], Kin)
     if K != Kin:
         raise NxSignalUnsupported("istft: fft_length different from the spectrum's last axis (ifft pad/truncate) is not built")
@@ -305,15 +323,18 @@ def _istft(data, window, ctx, opts, hh):
     out_len = _lib.check(lib.nxsig_ola_length(Mf, N, hop))
 
     def call(zp, yp, mem):
+        if packed:
+            return lib.nxsig_istft_packed_f32(c.handle, zp, Mf, batch, _as_ptr(w), C.byref(p), yp, mem)
         if hh is None:
             return lib.nxsig_istft_c64(c.handle, zp, Mf, batch, _as_ptr(w), C.byref(p), yp, mem)
         return lib.nxsig_istft_filtered_c64(c.handle, zp, Mf, batch, _as_ptr(w), C.byref(p), _as_ptr(hh), yp, mem)
 
+    odt = np.float32 if packed else np.complex64
     if is_device(data):
-        y = c.empty(tuple(shape[:-2]) + (out_len,), np.complex64)
+        y = c.empty(tuple(shape[:-2]) + (out_len,), odt)
         _lib.check(call(C.c_void_p(ptr), C.c_void_p(y.ptr), _lib.DEVICE))
         return y
-    y = np.empty(tuple(shape[:-2]) + (out_len,), dtype=np.complex64)
+    y = np.empty(tuple(shape[:-2]) + (out_len,), dtype=odt)
     _lib.check(call(_as_ptr(zin), _as_ptr(y), _lib.HOST))
     return y
 

@@ -85,6 +85,8 @@ SIGNATURES = {
     "nxsig_stft_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _p, C.POINTER(_i64), _i32]),
     "nxsig_stft_onesided_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _p, C.POINTER(_i64), _i32]),
     "nxsig_istft_c64": (C.c_int, [_p, _p, _i64, _i32, _p, C.POINTER(StftParams), _p, _i32]),
+    "nxsig_stft_packed_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _p, C.POINTER(_i64), _i32]),
+    "nxsig_istft_packed_f32": (C.c_int, [_p, _p, _i64, _i32, _p, C.POINTER(StftParams), _p, _i32]),
     "nxsig_istft_filtered_c64": (C.c_int, [_p, _p, _i64, _i32, _p, C.POINTER(StftParams), _p, _p, _i32]),
     "nxsig_as_windowed_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _i32, _i32, _i32, _i64, _i64, _p, C.POINTER(_i64), _i32]),
     "nxsig_overlap_and_add": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32]),

@@ -35,6 +35,7 @@ UNITS = [
     ("kernels_wave_8k.hip", []),
     ("kernels_wave_rows.hip", []),
     ("kernels_wave_fir32.hip", []),
+    ("kernels_wave_packed.hip", []),
 ]
 
 

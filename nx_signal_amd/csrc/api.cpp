@@ -181,9 +181,29 @@ int launch_stft(Ctx* c, const StftLaunch& a) {
   return launch_stft_generic(c, a);
 }
 int launch_istft_edge_fix(Ctx* c, const IstftLaunch& a, const float* window_host);
+int launch_istft_packed_wave(Ctx* c, const IstftLaunch& a, const float* window_host, bool* handled);
 int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
   bool handled = false;
-  int rc = launch_istft_wave(c, a, window_host, &handled);
+  int rc;
+  if (a.onesided) {  // packed half spectrum in, real signal out (nxsig_istft_packed_f32)
+    if ((rc = launch_istft_packed_wave(c, a, window_host, &handled))) return rc;
+    if (handled) {
+      if ((rc = launch_istft_edge_fix(c, a, window_host))) return rc;
+      return launch_istft_nf_fix(c, a, a.nf_list, a.nf_frames_per_unit);
+    }
+    // no fused kernel for this geometry: the Hermitian rows are written out, the complex path runs, its real part is kept
+    const int64_t out_len = a.M * a.hop + (a.N - a.hop);
+    void *zf = nullptr, *yf = nullptr;
+    if ((rc = ctx_scratch(c, 24, (size_t)a.batch * a.M * a.K * sizeof(float2), &zf))) return rc;
+    if ((rc = ctx_scratch(c, 25, (size_t)a.batch * out_len * sizeof(float2), &yf))) return rc;
+    if ((rc = launch_full_from_packed(c, a.z, (int64_t)a.batch * a.M, a.K, reinterpret_cast<float2*>(zf)))) return rc;
+    IstftLaunch b = a;
+    b.onesided = false; b.z = reinterpret_cast<const float2*>(zf); b.y = reinterpret_cast<float2*>(yf);
+    b.nf_list = nullptr; b.nf_frames_per_unit = 0;
+    if ((rc = launch_istft(c, b, window_host))) return rc;
+    return launch_real_from_c64(c, b.y, (int64_t)a.batch * out_len, reinterpret_cast<float*>(a.y));
+  }
+  rc = launch_istft_wave(c, a, window_host, &handled);
   if (rc) return rc;
   if (!handled && a.filt) {
     // no fused kernel for this geometry: the filter product is materialised once (the two-step chain), then the plain path runs
@@ -703,7 +723,7 @@ int nxsig_stft_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch
 }
 
 static int istft_common(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
-                        const nxsig_stft_params* p, const nxsig_c64* h, nxsig_c64* y, int32_t mem) {
+                        const nxsig_stft_params* p, const nxsig_c64* h, nxsig_c64* y, int32_t mem, bool onesided = false) {
   NXSIG_CHECK_CTX(ctx)
   if (!z || !window || !p || !y) return set_error(NXSIG_ERR_INVALID_ARG, "istft: null pointer argument");
   int rc = check_mem(mem);
@@ -719,8 +739,9 @@ static int istft_common(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, 
   if (K != N)
     return set_error(NXSIG_ERR_INVALID_ARG,
                      "istft: fft_length must equal the window length (the reference broadcasts {M,K} x {N}, lib/nx_signal.ex:628)");
+  if (onesided && (K & 1)) return set_error(NXSIG_ERR_INVALID_ARG, "istft_packed: fft_length must be even");
   IstftLaunch a;
-  a.M = num_frames; a.batch = batch; a.N = N; a.hop = hop; a.K = K;
+  a.M = num_frames; a.batch = batch; a.N = N; a.hop = hop; a.K = K; a.onesided = onesided;
   a.has_scale = p->scaling != NXSIG_SCALE_NONE;
   a.scale_mul = a.has_scale ? scaling_factor(window, N, p->scaling, p->sampling_rate) : 1.0f;
   const void* wdev = nullptr;
@@ -733,7 +754,8 @@ static int istft_common(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, 
     a.filt = reinterpret_cast<const float2*>(hd);
   }
   const int64_t out_len = num_frames * hop + (N - hop);
-  const size_t zbytes = (size_t)batch * num_frames * K * sizeof(float2), ybytes = (size_t)batch * out_len * sizeof(float2);
+  const size_t zbytes = (size_t)batch * num_frames * (onesided ? K / 2 : K) * sizeof(float2);
+  const size_t ybytes = (size_t)batch * out_len * (onesided ? sizeof(float) : sizeof(float2));
   if (mem == NXSIG_DEVICE) {
     a.z = reinterpret_cast<const float2*>(z); a.y = reinterpret_cast<float2*>(y);
     return launch_istft(c, a, window);
@@ -751,6 +773,13 @@ int nxsig_istft_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int3
                     const nxsig_stft_params* p, nxsig_c64* y, int32_t mem) {
   NXSIG_API_BEGIN
   return istft_common(ctx, z, num_frames, batch, window, p, nullptr, y, mem);
+  NXSIG_API_END
+}
+
+int nxsig_istft_packed_f32(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
+                           const nxsig_stft_params* p, float* y, int32_t mem) {
+  NXSIG_API_BEGIN
+  return istft_common(ctx, z, num_frames, batch, window, p, nullptr, reinterpret_cast<nxsig_c64*>(y), mem, true);
   NXSIG_API_END
 }
 
@@ -1117,10 +1146,24 @@ int nxsig_stft_mel_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t b
   NXSIG_API_END
 }
 
+}  // extern "C"
+static int stft_onesided_impl(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* window,
+                              const nxsig_stft_params* p, nxsig_c64* out, int64_t* num_frames_out, int32_t mem, bool packed);
+extern "C" {
 int nxsig_stft_onesided_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* window,
                             const nxsig_stft_params* p, nxsig_c64* out, int64_t* num_frames_out, int32_t mem) {
+  return stft_onesided_impl(ctx, x, length, batch, batch_stride, window, p, out, num_frames_out, mem, false);
+}
+int nxsig_stft_packed_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* window,
+                          const nxsig_stft_params* p, nxsig_c64* out, int64_t* num_frames_out, int32_t mem) {
+  return stft_onesided_impl(ctx, x, length, batch, batch_stride, window, p, out, num_frames_out, mem, true);
+}
+}  // extern "C"
+static int stft_onesided_impl(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* window,
+                              const nxsig_stft_params* p, nxsig_c64* out, int64_t* num_frames_out, int32_t mem, bool packed) {
   NXSIG_API_BEGIN
   if (!x || !window || !p || !out) return set_error(NXSIG_ERR_INVALID_ARG, "stft_onesided: null pointer argument");
+  if (packed && (p->fft_length & 1)) return set_error(NXSIG_ERR_INVALID_ARG, "stft_packed: fft_length must be even");
   int rc = check_mem(mem);
   if (rc) return rc;
   if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "stft_onesided: batch must be in [1, 65535]");
@@ -1154,19 +1197,20 @@ int nxsig_stft_onesided_f32(nxsig_ctx* ctx, const float* x, int64_t length, int3
     a.x = reinterpret_cast<const float*>(xd); od = reinterpret_cast<float2*>(o2);
   }
   bool handled = false;
-  rc = launch_stft_mag_wave(c, a, 3 /* complex bins */, reinterpret_cast<float*>(od), &handled);
+  rc = launch_stft_mag_wave(c, a, packed ? 4 : 3 /* complex bins */, reinterpret_cast<float*>(od), &handled);
   if (rc) return rc;
   if (!handled) {  // two-step path: full spectrum in a scratch buffer, then the slice
     void* zs = nullptr;
     if ((rc = ctx_scratch(c, 4, (size_t)batch * fr.M * p->fft_length * sizeof(float2), &zs))) return rc;
     a.z = reinterpret_cast<float2*>(zs);
     if ((rc = launch_stft(c, a))) return rc;
-    if ((rc = launch_half_from_spectrum(c, a.z, (int64_t)batch * fr.M, p->fft_length, od))) return rc;
+    if ((rc = launch_half_from_spectrum(c, a.z, (int64_t)batch * fr.M, p->fft_length, od, packed))) return rc;
   }
   if (mem == NXSIG_DEVICE) return NXSIG_OK;
   return st.out_copy(out, od, obytes);
   NXSIG_API_END
 }
+extern "C" {
 
 int nxsig_stft_magnitude_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride,
                              const float* window, const nxsig_stft_params* p, int32_t kind, float* out,

@@ -432,7 +432,19 @@ struct EdgeFixArgs {
   float tau;
   const double2* tw;        // w_N^j = exp(+2 pi i j / N) in double, j in [0, N)
   const float2* filt;       // optional c64[N]: the frames are z * filt rounded to c64 (IstftLaunch::filt), or nullptr
+  int32_t onesided = 0;     // 1: z is the packed half spectrum c64[batch][M][N / 2] (Re X[N/2] in the imaginary part of bin 0)
+                            //    and y is REAL f32[batch][out_len] (nxsig_istft_packed_f32)
 };
+// bin k of frame row zr in either layout
+__device__ __forceinline__ float2 istft_bin(const EdgeFixArgs& a, const float2* __restrict__ zr, int k) {
+  if (!a.onesided) return zr[k];
+  const int half = a.N >> 1;
+  if (k == 0) return make_float2(zr[0].x, 0.0f);
+  if (k < half) return zr[k];
+  if (k == half) return make_float2(zr[0].y, 0.0f);
+  const float2 c = zr[a.N - k];
+  return make_float2(c.x, -c.y);
+}
 
 // one output sample of one row, along the reference's chain in double (whole workgroup; `red` = 2 * kThreads doubles of LDS).
 // ALL = false: only ill-conditioned samples (1e-10 < den < tau) are recomputed; true: any sample (den <= 1e-10 divides by 1, :635)
@@ -450,17 +462,18 @@ __device__ __forceinline__ void istft_sample_f64(const EdgeFixArgs& a, const int
   float d = (float)den;
   if (ALL) { if (!(d > 1.0e-10f)) d = 1.0f; }
   else if (!(d > 1.0e-10f) || d >= a.tau) return;  // uniform across the block
-  const float2* zb = a.z + (size_t)row * a.M * a.N;
+  const int rowlen = a.onesided ? (a.N >> 1) : a.N;
+  const float2* zb = a.z + (size_t)row * a.M * rowlen;
   double acc_re = 0.0, acc_im = 0.0;
   for (int64_t m = m_lo; m <= m_hi; ++m) {
     const int j = (int)(n - m * a.hop);
-    const float2* zr = zb + (size_t)m * a.N;
+    const float2* zr = zb + (size_t)m * rowlen;
     double sr = 0.0, si = 0.0;
     int tix = (int)(((int64_t)j * tid) % a.N);                 // twiddle index j k mod N, advanced without a division per term
     const int tstep = (int)(((int64_t)j * kThreads) % a.N);
     for (int k = tid; k < a.N; k += kThreads) {
       const double2 t = a.tw[tix];
-      float2 v = zr[k];
+      float2 v = istft_bin(a, zr, k);
       if (a.filt) {
         const float2 h = a.filt[k];
         v = make_float2((float)((double)v.x * (double)h.x - (double)v.y * (double)h.y),
@@ -490,7 +503,10 @@ __device__ __forceinline__ void istft_sample_f64(const EdgeFixArgs& a, const int
     }
     __syncthreads();
   }
-  if (tid == 0) a.y[(size_t)row * a.out_len + n] = make_float2((float)acc_re / d, (float)acc_im / d);
+  if (tid == 0) {
+    if (a.onesided) reinterpret_cast<float*>(a.y)[(size_t)row * a.out_len + n] = (float)acc_re / d;
+    else a.y[(size_t)row * a.out_len + n] = make_float2((float)acc_re / d, (float)acc_im / d);
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
@@ -1321,7 +1337,7 @@ int launch_istft_nf_fix(Ctx* c, const IstftLaunch& s, const int* list, int frame
   EdgeFixArgs a;
   a.z = s.z; a.filt = s.filt; a.M = s.M; a.N = s.N; a.hop = s.hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
   a.y = s.y; a.out_len = s.M * s.hop + (s.N - s.hop);
-  a.idx = nullptr; a.n_idx = 0; a.tau = 0.0f;
+  a.idx = nullptr; a.n_idx = 0; a.tau = 0.0f; a.onesided = s.onesided ? 1 : 0;
   {  // inverse twiddles in double (host libm), cached per N (the table of launch_istft_edge_fix)
     std::vector<double2> tw((size_t)s.N);
     for (int j = 0; j < s.N; ++j) {
@@ -1356,7 +1372,7 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
       uint32_t tb = (uint32_t)v[1];
       std::memcpy(&a.tau, &tb, 4);
       a.z = s.z; a.filt = s.filt; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
-      a.y = s.y; a.out_len = out_len;
+      a.y = s.y; a.out_len = out_len; a.onesided = s.onesided ? 1 : 0;
       a.tw = reinterpret_cast<const double2*>(v[2]);
       a.idx = reinterpret_cast<const int64_t*>(v[3]);
       a.n_idx = (int64_t)v[4];
@@ -1381,7 +1397,7 @@ int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host
   EdgeFixArgs a;
   a.tau = (float)(0.02 * dmax);
   a.z = s.z; a.filt = s.filt; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
-  a.y = s.y; a.out_len = out_len;
+  a.y = s.y; a.out_len = out_len; a.onesided = s.onesided ? 1 : 0;
   a.idx = nullptr; a.n_idx = 0;
   // inverse twiddles in double (host libm), cached per N
   {
@@ -1586,21 +1602,62 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
 }
 
 // bins below K / 2 of every row (two-step form of the one-sided spectrum sink)
-__global__ __launch_bounds__(kThreads) void k_half_from_spectrum(const float2* __restrict__ z, int64_t rows, int32_t K, float2* __restrict__ out) {
+// packed: the imaginary part of bin 0 carries Re X[K/2] (the layout nxsig_istft_packed_f32 inverts)
+__global__ __launch_bounds__(kThreads) void k_half_from_spectrum(const float2* __restrict__ z, int64_t rows, int32_t K, float2* __restrict__ out,
+                                                                 int packed) {
   const int half = K / 2;
   const int64_t total = rows * half;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
     const int64_t r = i / half;
-    out[i] = z[(size_t)r * K + (i - r * half)];
+    const int k = (int)(i - r * half);
+    float2 v = z[(size_t)r * K + k];
+    if (packed && k == 0) v.y = z[(size_t)r * K + half].x;
+    out[i] = v;
   }
 }
-int launch_half_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, float2* out) {
+// the inverse re-layout: full Hermitian rows c64[rows][K] from packed rows c64[rows][K / 2] (shapes without a fused inverse)
+__global__ __launch_bounds__(kThreads) void k_full_from_packed(const float2* __restrict__ zp, int64_t rows, int32_t K, float2* __restrict__ out) {
+  const int half = K / 2;
+  const int64_t total = rows * K;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t r = i / K;
+    const int k = (int)(i - r * K);
+    const float2* row = zp + (size_t)r * half;
+    float2 v;
+    if (k == 0) v = make_float2(row[0].x, 0.0f);
+    else if (k < half) v = row[k];
+    else if (k == half) v = make_float2(row[0].y, 0.0f);
+    else { const float2 c = row[K - k]; v = make_float2(c.x, -c.y); }
+    out[i] = v;
+  }
+}
+__global__ __launch_bounds__(kThreads) void k_real_from_c64(const float2* __restrict__ in, int64_t n, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) out[i] = in[i].x;
+}
+static unsigned capped_blocks(const Ctx* c, int64_t total) {
+  int64_t blocks = (total + kThreads - 1) / kThreads;
+  const int64_t cap = (int64_t)c->num_cus * 32;
+  return (unsigned)(blocks > cap ? cap : (blocks < 1 ? 1 : blocks));
+}
+int launch_full_from_packed(Ctx* c, const float2* zp, int64_t rows, int32_t K, float2* out) {
+  if (rows * K == 0) return NXSIG_OK;
+  hipLaunchKernelGGL(k_full_from_packed, dim3(capped_blocks(c, rows * K)), dim3(kThreads), 0, c->stream, zp, rows, K, out);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+int launch_real_from_c64(Ctx* c, const float2* in, int64_t n, float* out) {
+  if (n == 0) return NXSIG_OK;
+  hipLaunchKernelGGL(k_real_from_c64, dim3(capped_blocks(c, n)), dim3(kThreads), 0, c->stream, in, n, out);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+int launch_half_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, float2* out, bool packed) {
   const int64_t total = rows * (K / 2);
   if (total == 0) return NXSIG_OK;
   int64_t blocks = (total + kThreads - 1) / kThreads;
   const int64_t cap = (int64_t)c->num_cus * 32;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(k_half_from_spectrum, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, z, rows, K, out);
+  hipLaunchKernelGGL(k_half_from_spectrum, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, z, rows, K, out, packed ? 1 : 0);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
 }

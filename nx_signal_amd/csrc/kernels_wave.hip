@@ -29,6 +29,8 @@ struct IstftWaveArgs {
   v2f* y;                     // c64[batch][segs_per_row * hop]
   v2f* dummy;
   const v2f* filt = nullptr;  // c64[K] spectrum filter (FILT variant of k_istft_wave only)
+  int32_t dbg_no_halo = 0;    // EXPERIMENT ONLY (NXSIG_ISTFT_DBG_NOHALO=1): runs skip their halo frames -> wrong sums at run starts;
+                              // measures what a geometry would cost if partial sums were handed over instead of recomputed
   int* nf_list = nullptr;     // kernels that invert several frames per transform: units that hold a non-finite bin are reported here
                               // ({count, capacity, int64 (row << 40 | first frame) ...}) and redone frame by frame by k_istft_nf_fix
 };
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
   const int64_t j0 = (run - row * a.runs_per_row) * a.run_len;
   int64_t j1 = j0 + a.run_len;
   if (j1 > a.segs_per_row) j1 = a.segs_per_row;
-  const int64_t m_start = j0 >= (R - 1) ? j0 - (R - 1) : 0;
+  const int64_t m_start = (j0 >= (R - 1) && !a.dbg_no_halo) ? j0 - (R - 1) : (a.dbg_no_halo ? j0 : 0);
 
   // this lane's window values wv[par][q] = w[2 lane + par + 128 q]
   float wv[2][NQ];
@@ -858,7 +860,7 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
 
 // guarded normaliser rows (lib/nx_signal.ex:630-635) as RECIPROCALS: f32[2R-1][hop] = head segments 0..R-2, the interior
 // segment, tail segments; double accumulation in ascending frame order, one rounding
-static int istft_den_table(Ctx* c, int R, int hop, const float* window_host, const float** out) {
+int istft_den_table(Ctx* c, int R, int hop, const float* window_host, const float** out) {
   const uint64_t dkey = fnv1a(0xDE18ull ^ ((uint64_t)R << 32) ^ ((uint64_t)hop << 8), window_host, (size_t)R * hop * sizeof(float));
   auto hit = c->memo.find(dkey);
   if (hit != c->memo.end()) { *out = reinterpret_cast<const float*>(hit->second[0]); return NXSIG_OK; }
@@ -904,6 +906,7 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t total_segs = a.segs_per_row * s.batch;
+  a.dbg_no_halo = env_int("NXSIG_ISTFT_DBG_NOHALO", 0);
   const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", (DBL || s.filt) ? 8 : 12);  // the filtered variant holds 16 more
                                                                                          // complex values per lane: 2 waves per SIMD  // = resident waves per CU: one even round
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);

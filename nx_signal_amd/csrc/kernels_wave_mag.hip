@@ -11,6 +11,7 @@ int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool
   if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
   if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
   MelLaunch mel{0, nullptr, out, handled, kind};
+  if (kind == 4 && s.K != 1024) return NXSIG_OK;   // packed one-sided form: fused for the pair front-end, two-step elsewhere
   switch (s.K) {
     case 1024: return launch_wave<1024, kModePair, 4, 2, kSinkMag>(c, s, &mel);
     case 512: return launch_wave<1024, kModeQuad, 4, 2, kSinkMag>(c, s, &mel);

@@ -80,8 +80,9 @@ struct Ctx {
   // scratch buffer reused by multi-stage paths (generic istft, host staging)
   // slots: 0 multi-stage temporaries, 1/2 host staging in/out, 3 wave-kernel dummy sink, 4 fused-path spectrum, 5 reduction cells,
   // 6-9 four-step / Bluestein rows, 10-12 fft_nd ping-pong, 13-15 n-D fftconvolve, 16 long-transform stft frames, 17-19 host staging of n-D calls
-  void* scratch[24] = {};
-  size_t scratch_bytes[24] = {};
+  // 20 istft filter fallback, 21 long FIR, 22 FIR row flags, 23 istft non-finite unit list, 24/25 packed istft fallback
+  void* scratch[32] = {};
+  size_t scratch_bytes[32] = {};
   // per-K tables of the tuned wave kernels (pass-B / pass-C twiddles), built once
   struct WaveTables { const void* twB = nullptr; const void* twC = nullptr; const void* twI = nullptr;
                       const void* twBi = nullptr; const void* twCi = nullptr;    // ...i = conjugated (inverse transform)
@@ -154,7 +155,13 @@ struct IstftLaunch {
   // non-finite bin and the frames per unit; launch_istft then recomputes those units' samples frame by frame (k_istft_nf_fix)
   mutable const int* nf_list = nullptr;
   mutable int nf_frames_per_unit = 0;
+  // packed one-sided form (nxsig_istft_packed_f32): z is c64[batch][M][K / 2] — bins 0 .. K/2 - 1 with Re X[K/2] in the imaginary
+  // part of bin 0 — and y is REAL f32[batch][M*hop + N-hop]
+  bool onesided = false;
 };
+int launch_half_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, float2* out, bool packed);
+int launch_full_from_packed(Ctx* c, const float2* zp, int64_t rows, int32_t K, float2* out);
+int launch_real_from_c64(Ctx* c, const float2* in, int64_t n, float* out);
 int istft_nf_list(Ctx* c, int64_t capacity, int** list);
 int launch_istft_nf_fix(Ctx* c, const IstftLaunch& s, const int* list, int frames_per_unit);
 int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host);
@@ -180,7 +187,6 @@ struct FirLaunch {
   int* row_flags = nullptr;
 };
 int launch_fir(Ctx* c, const FirLaunch& a);
-int launch_half_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, float2* out);
 int launch_mag_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, int kind, float* out);
 int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool* handled);
 int launch_spectrum_mul(Ctx* c, const float2* z, int64_t rows, int32_t K, const float2* h_dev, float2* out);

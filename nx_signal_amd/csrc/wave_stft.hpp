@@ -390,7 +390,8 @@ struct MelWaveArgs {
   float* out;                 // f32[batch][M][mel_bins] (log10 power, before the clamp pass) / f32[batch][M][fft_length/2] (MAG)
   int* gmax;
   int32_t mag_kind;           // MAG sink: 0 = |X|, 1 = |X|^2, 2 = |X| with a running maximum (dBFS pass follows),
-                              // 3 = the complex bins themselves (one-sided spectrum: out is c64[...][fft_length / 2])
+                              // 3 = the complex bins themselves (one-sided spectrum: out is c64[...][fft_length / 2]),
+                              // 4 = the same with Re X[fft_length / 2] packed into the imaginary part of bin 0 (pair mode only)
 };
 
 // ST (pair / real-2x front-ends, complex-spectrum sink, streaming kernel): cache policy of the spectrum stores.
@@ -783,7 +784,15 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
             *reinterpret_cast<v2f*>(&mags[KH + 2 * lane + 128 * q]) = pb2;
           }
         } else if (MAG) {
-          if (mp->mag_kind == 3) {  // one-sided complex spectrum: two adjacent bins per 16-byte store
+          if (mp->mag_kind >= 3) {  // one-sided complex spectrum: two adjacent bins per 16-byte store
+            if (MODE == kModePair && mp->mag_kind == 4 && q == 0 && lane == 0) {
+              // packed form (kind 4, nxsig_stft_packed_f32): the Nyquist bin X[K/2] of a real frame is real and bin 0's imaginary
+              // part is zero -> Re X[K/2] rides there.  Z[K/2] sits on lane 0 (zz[0][NQ/2]): its real part belongs to frame A,
+              // its imaginary part to frame B (XA[K/2] = Re Z, XB[K/2] = Im Z); clean-up and scaling as for every bin
+              float nyA = fft_eps0(zz[0][NQ / 2].x), nyB = fft_eps0(zz[0][NQ / 2].y);
+              if (SCALE) { nyA = nyA / a.div; nyB = nyB / a.div; }
+              xa.y = nyA; xbv.y = nyB;
+            }
             v2f* c0 = reinterpret_cast<v2f*>(mp->out) + ((size_t)crow * a.M + m0) * KH + 2 * lane + 128 * q;
             __builtin_nontemporal_store(xa, (gv4f*)c0);
             if (MODE == kModePair && stB) __builtin_nontemporal_store(xbv, (gv4f*)(c0 + KH));
@@ -1230,7 +1239,9 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
   // the kernel time), at the price of re-loading the 12 KB of tables per workgroup from L2.
   const int units_per_wave = (mel && mel->mag_kind >= 0) ? env_int("NXSIG_MAG_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
                              : mel ? env_int("NXSIG_MEL_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
-                                 : env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : (MODE == kModeQuad ? (J == 2 ? 2 : 3) : 8));  // measured optima (input from HBM)
+                                 : env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : (MODE == kModeQuad ? (J == 8 ? 8 : 4) : 8));  // measured optima, input
+                                 // from HBM (round 3, tools/bench_configs.py gen512 / gen256 / gen128 with NXSIG_BENCH_ALT_INPUTS=4: 4 units per
+                                 // wave 0.646 / 0.631 of 8 TB/s against 0.591 / 0.611 at round 2's 2 / 3; fft_length 128: 8 -> 0.593 against 0.572)
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   // a launch so small that its workgroups all fit on the chip at once (three per CU; BASELINE config 2 as written: one 60 s
   // stream, 703 workgroups) is one round of start-up latencies: three pairs per wave amortise them better than two (+1.5 ... 2.6 %

@@ -259,6 +259,19 @@ def test_device_resident_chain_through_the_nif(nctx):
     ok, zhb = H.call("from_device", zh)
     assert mh == m and np.array_equal(c64(zhb).reshape(m, 512).view(np.uint32), np.ascontiguousarray(z[:, :512]).view(np.uint32))
     del zh
+    # the packed one-sided pair on the device: stft_packed_dev -> istft_packed_dev -> one download of a REAL signal
+    ok, zp, mp = H.call("stft_packed_dev", nctx, xb, 48000, 1, w, PARAMS)
+    ok, zpb = H.call("from_device", zp)
+    zpw, _, _ = S.stft_packed(x, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert mp == m and np.array_equal(c64(zpb).view(np.uint32), zpw.reshape(-1).view(np.uint32))
+    ok, yp = H.call("istft_packed_dev", nctx, zp, mp, 1, w, PARAMS)
+    ok, ypb = H.call("from_device", yp)
+    ypw = S.istft_packed(zpw, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert np.array_equal(f32(ypb).view(np.uint32), ypw.view(np.uint32))
+    assert float(np.max(np.abs(f32(ypb)[1024:-1024] - x[1024:48000 - 1024 - 128]))) < 2e-6 * float(np.max(np.abs(x)))
+    with pytest.raises(H.BadArg):
+        H.call("istft_packed_dev", nctx, zp, mp * 2, 1, w, PARAMS)   # more frames than the buffer holds
+    del zp, yp
     ok, fy, n = H.call("fir_dev", nctx, xb, 48000, 1, S.filters.firwin(257, [4000.0], sampling_rate=48000), 1)
     ok, fo = H.call("from_device", fy)
     assert n == 48000 and np.array_equal(f32(fo).view(np.uint32), S.filters.fir(x, S.filters.firwin(257, [4000.0], sampling_rate=48000)).view(np.uint32))

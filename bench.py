@@ -134,6 +134,7 @@ def secondary_rooflines(ctx, lib, S, _lib, C):
         # HBM bytes per launch from the PMC passes of the same launch shape (profiles/traffic.json), checked against the shape
         traffic = traffic_tab.get(traffic_key + "_bytes_per_launch") if traffic_key and traffic_tab.get(traffic_key + "_algorithmic_bytes") == nbytes else None
         d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+             "traffic_source": "profiles/traffic.json (PMC passes of tools/profile_bench.sh, not measured in this run)",
              "kernel_ms": ms, "kernel_us": {"min": round(min(laps) * 1e3, 1), "median": round(float(np.median(laps)) * 1e3, 1),
                                             "max": round(max(laps) * 1e3, 1)}, "workload": workload, "kernel": kernel}
         d.update(extra)
@@ -366,6 +367,12 @@ def main():
                 break
         precondition.update(launches=len(hist), first10_us=[round(v * 1e3, 1) for v in hist[:10]],
                             last10_us=[round(v * 1e3, 1) for v in hist[-10:]], min_us=round(min(hist) * 1e3, 1))
+        # what a COLD caller sees: launches 4 .. 10 of the first series sit on the power excursion of a GPU that was idle
+        # (boost clocks overshoot the power budget about 5 launches in); reported beside the settled figure, never instead of it
+        if len(hist) >= 10:
+            burst_ms = float(np.mean(hist[3:10]))
+            precondition["cold_burst"] = {"launches": "4..10 of the first series", "mean_us": round(burst_ms * 1e3, 1),
+                                          "frac": (B * M * BYTES_PER_FRAME) / (burst_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     for _ in range(args.warmup):
         step()
@@ -477,6 +484,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/traffic.json: PMC FETCH_SIZE x 2 + WRITE_SIZE per launch of this launch shape, collected "
+                                  "by tools/profile_bench.sh in separate rocprofv3 --pmc passes; NOT measured in this run",
                 "kernel_ms": kernel_ms, "bytes_per_frame": BYTES_PER_FRAME, "frac_of_measured_copy_6290": achieved / 6290.0,
                 "kernel_us": {"min": round(min(laps) * 1e3, 1), "median": round(float(np.median(laps)) * 1e3, 1),
                               "p90": round(float(np.percentile(laps, 90)) * 1e3, 1), "max": round(max(laps) * 1e3, 1)},

@@ -338,7 +338,9 @@ struct WaveArgs {
   int64_t u_split, u_add0, u_add1;  // unit u of the launch is unit-in-row u + (u < u_split ? u_add0 : u_add1)
   int64_t chunk;              // units per workgroup (contiguous)
   int64_t xcd_span = 0;       // > 0: workgroup b takes chunk (b % 8) * xcd_span + b / 8 (consecutive chunks on one XCD); 0: chunk b
-  int32_t early_loads = 0;    // 1: the first unit's sample loads are issued BEFORE the tables are staged (start-up latencies overlap)
+  int32_t early_loads = 0;    // 1: the first unit's sample loads are issued BEFORE the tables are staged (start-up latencies overlap;
+                              //    NXSIG_EARLY_LOADS, measured: no gain, off)
+  int32_t prio = 1;           // raised wave priority during the transform (NXSIG_WAVE_PRIO)
   const float* wtab;          // device f32[fft_length]: window zero-padded / truncated to the fft length
   const v2f* twB;             // device c64[16][16]: w_256^(t k)
   const v2f* twC;             // device c64[R3][256]: w_C^(t i)
@@ -847,7 +849,12 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
+      // raised wave priority while the transform runs: a wave that has its data gets through the butterflies and back to its memory
+      // operations ahead of waves that are still waiting (NXSIG_WAVE_PRIO=0: off; interleaved A/B, tools/sweep_*.py: stft +0.6 %,
+      // istft +0.5 %, FIR +1.3 ... 2.5 %)
+      if (a.prio) __builtin_amdgcn_s_setprio(2);
       wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);
+      if (a.prio) __builtin_amdgcn_s_setprio(0);
       if (!GENERAL && !LATE) {
         __builtin_amdgcn_sched_barrier(0);
         window_mul(d);
@@ -1289,6 +1296,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
     a.xcd_span = 0;
     a.early_loads = env_int("NXSIG_EARLY_LOADS", 0);
+    a.prio = env_int("NXSIG_WAVE_PRIO", 1);
     if (env_int("NXSIG_XCD_REMAP", 0) && blocks >= 64) { a.xcd_span = (blocks + 7) / 8; blocks = a.xcd_span * 8; }
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
     if (lds > 64 * 1024)

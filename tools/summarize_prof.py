@@ -36,6 +36,12 @@ for f in find("trace", "*kernel_trace.csv"):
         r0 = meta[key]
         print(f"  {short(key[0]):64s} grid={key[1]} wg={key[2]} n={len(v)} mean_us={sum(v)/len(v)/1e3:.2f} median_us={v2[len(v2)//2]/1e3:.2f} min_us={v2[0]/1e3:.2f}"
               f" | VGPR={r0.get('VGPR_Count')} accVGPR={r0.get('Accum_VGPR_Count')} SGPR={r0.get('SGPR_Count')} LDS={r0.get('LDS_Block_Size')} scratch={r0.get('Scratch_Size')}")
+        if 12 <= len(v) <= 80 and not any(t in key[0] for t in ("edge_fix", "nf_fix", "poison")):
+            # bench.py's secondary blocks (configs 3 / 4 / 5): warm-up launches first, the TIMED window is the last 20 (istft) / 10 launches
+            for nwin in (20, 10):
+                if len(v) > nwin:
+                    t = v[-nwin:]
+                    print(f"      last {nwin} launches: mean_us={sum(t)/len(t)/1e3:.2f} median_us={sorted(t)[len(t)//2]/1e3:.2f} min_us={min(t)/1e3:.2f} max_us={max(t)/1e3:.2f}")
         if len(v) > 40:  # bench.py: pre-conditioning + warm-up launches come first, the TIMED window is the last --steps launches
             t = v[-20:]
             print(f"      last 20 launches (bench.py's timed window at --steps 20): mean_us={sum(t)/len(t)/1e3:.2f} min_us={min(t)/1e3:.2f} max_us={max(t)/1e3:.2f}"

@@ -29,7 +29,7 @@ struct IstftWaveArgs {
   v2f* y;                     // c64[batch][segs_per_row * hop]
   v2f* dummy;
   const v2f* filt = nullptr;  // c64[K] spectrum filter (FILT variant of k_istft_wave only)
-  int32_t dbg_prio = 1;       // raised wave priority during the transform (NXSIG_WAVE_PRIO, see stft_wave_body)
+  int32_t dbg_prio = 0;       // raised wave priority during the transform (NXSIG_WAVE_PRIO=1: experiment, see stft_wave_body)
   int32_t dbg_no_halo = 0;    // EXPERIMENT ONLY (NXSIG_ISTFT_DBG_NOHALO=1): runs skip their halo frames -> wrong sums at run starts;
                               // measures what a geometry would cost if partial sums were handed over instead of recomputed
   int* nf_list = nullptr;     // kernels that invert several frames per transform: units that hold a non-finite bin are reported here
@@ -685,7 +685,7 @@ struct FirWaveArgs {
   const v2f* twC;
   float* y;                            // f32[batch][out_len]
   int* row_flags;                      // FirLaunch::row_flags: a non-finite sample poisons its whole row, like the reference's one transform
-  int32_t dbg_prio = 1;                // raised wave priority during the two transforms (NXSIG_WAVE_PRIO, see stft_wave_body)
+  int32_t dbg_prio = 0;                // raised wave priority during the two transforms (NXSIG_WAVE_PRIO=1: experiment, see stft_wave_body)
 };
 
 int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, int32_t taps, int64_t first_block, int64_t pb_lo,
@@ -913,7 +913,7 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t total_segs = a.segs_per_row * s.batch;
   a.dbg_no_halo = env_int("NXSIG_ISTFT_DBG_NOHALO", 0);
-  a.dbg_prio = env_int("NXSIG_WAVE_PRIO", 1);
+  a.dbg_prio = env_int("NXSIG_WAVE_PRIO", 0);
   const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", (DBL || s.filt) ? 8 : 12);  // the filtered variant holds 16 more
                                                                                          // complex values per lane: 2 waves per SIMD  // = resident waves per CU: one even round
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
@@ -1225,7 +1225,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   Ctx::WaveTables& wt = c->wave_tables[K];
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
-  a.y = s.y; a.row_flags = s.row_flags; a.dbg_prio = env_int("NXSIG_WAVE_PRIO", 1);
+  a.y = s.y; a.row_flags = s.row_flags; a.dbg_prio = env_int("NXSIG_WAVE_PRIO", 0);
   // 8-byte vector access needs every offset even: taps-1 multiple of 128 (=> V even), even strides, aligned bases
   const bool fast8 = ((s.taps - 1) % 128 == 0) && (s.batch_stride % 2 == 0) && (s.out_len % 2 == 0) && (out_start % 2 == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 7) == 0);

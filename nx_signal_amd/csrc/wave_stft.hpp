@@ -340,7 +340,7 @@ struct WaveArgs {
   int64_t xcd_span = 0;       // > 0: workgroup b takes chunk (b % 8) * xcd_span + b / 8 (consecutive chunks on one XCD); 0: chunk b
   int32_t early_loads = 0;    // 1: the first unit's sample loads are issued BEFORE the tables are staged (start-up latencies overlap;
                               //    NXSIG_EARLY_LOADS, measured: no gain, off)
-  int32_t prio = 1;           // raised wave priority during the transform (NXSIG_WAVE_PRIO)
+  int32_t prio = 0;           // raised wave priority during the transform (NXSIG_WAVE_PRIO=1: experiment, off by default)
   const float* wtab;          // device f32[fft_length]: window zero-padded / truncated to the fft length
   const v2f* twB;             // device c64[16][16]: w_256^(t k)
   const v2f* twC;             // device c64[R3][256]: w_C^(t i)
@@ -849,9 +849,9 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      // raised wave priority while the transform runs: a wave that has its data gets through the butterflies and back to its memory
-      // operations ahead of waves that are still waiting (NXSIG_WAVE_PRIO=0: off; interleaved A/B, tools/sweep_*.py: stft +0.6 %,
-      // istft +0.5 %, FIR +1.3 ... 2.5 %)
+      // EXPERIMENT (NXSIG_WAVE_PRIO=1, default off): raised wave priority while the transform runs.  Back-to-back sweeps
+      // (tools/sweep_*.py) read +0.5 ... 2.5 %, but in bench.py's per-launch laps the iSTFT lost 5 % (0.573 / 0.589 against
+      // 0.607 / 0.630 of 8 TB/s, two interleaved runs each) and the single 60 s stream 3 %: profiles/r03/negative_results.md
       if (a.prio) __builtin_amdgcn_s_setprio(2);
       wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);
       if (a.prio) __builtin_amdgcn_s_setprio(0);
@@ -1296,7 +1296,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
     a.xcd_span = 0;
     a.early_loads = env_int("NXSIG_EARLY_LOADS", 0);
-    a.prio = env_int("NXSIG_WAVE_PRIO", 1);
+    a.prio = env_int("NXSIG_WAVE_PRIO", 0);
     if (env_int("NXSIG_XCD_REMAP", 0) && blocks >= 64) { a.xcd_span = (blocks + 7) / 8; blocks = a.xcd_span * 8; }
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
     if (lds > 64 * 1024)

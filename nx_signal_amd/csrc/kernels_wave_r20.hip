@@ -81,6 +81,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
   }
   __syncthreads();
   float vmax = -3.0e38f;
+  bool melbad = false;
   v2f* buf = s_x + wave * BUF;
   float* S = reinterpret_cast<float*>(buf);
   const int g = lane / 20, l20 = lane % 20;       // transform of the unit (g == 3: idle lanes), lane inside it
@@ -235,12 +236,13 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
     // |z|^2 poisons the whole tensor through reduce_max (:511).
     build(-1);
     bool solo = false;
-    if (!MEL) {
+    {
       v2f t = v[0];
 #pragma unroll
       for (int n1 = 1; n1 < 20; ++n1) t += v[n1];
       const bool nf = ((__float_as_uint(t.x) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(t.y) & 0x7f800000u) == 0x7f800000u);
       solo = __builtin_amdgcn_ballot_w64(nf) != 0;
+      if (MEL) { melbad |= solo; solo = false; }   // log-mel: the whole tensor is poisoned instead (gmax[1], see stft_wave_body)
     }
     if (solo) {
 #pragma nounroll
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
 #pragma unroll
         for (int f = 0; f < 6; ++f) {
           const int64_t m = 6 * u + f;
+          melbad |= (m < a.M) && !(acc[f] < INFINITY);
           const float av = acc[f] > 1.0e-10f ? acc[f] : 1.0e-10f;
           const float vv = __log2f(av) * 0.30102999566398120f;
           if (m < a.M) { b.out[((size_t)row * a.M + m) * b.mel_bins + mb] = vv; vmax = vv > vmax ? vv : vmax; }
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
       const int i = __float_as_int(vmax);
       atomicMax(b.gmax, i >= 0 ? i : i ^ 0x7fffffff);
     }
+    if (MEL && __builtin_amdgcn_ballot_w64(melbad) != 0 && lane == 0) atomicOr(b.gmax + 1, 1);
   }
 }
 

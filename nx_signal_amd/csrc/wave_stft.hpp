@@ -451,6 +451,11 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   constexpr int FPU = MODE == kModePair ? 2 : (MODE == kModeQuad ? 2 * J : 1);  // frames per unit
   constexpr int KH = KOUT / 2;
   float vmax = -3.0e38f;
+  // log-mel: a non-finite |z|^2 poisons the WHOLE tensor in the reference (its dense Nx.dot forms inf x 0 with the zero weights of every
+  // band, the NaN reaches reduce_max, lib/nx_signal.ex:505-511) and so it does in the two-step k_mel_tile; the sparse band sums here
+  // never form that product, so the kernel raises the non-finite flag (gmax[1]) itself: when a unit's windowed samples are not all
+  // finite, or a band sum is not
+  bool melbad = false;
   auto mel_tail = [&](int64_t crow, int64_t mA) {
     wave_lds_fence();
     // ---- sparse filterbank + log10
@@ -467,6 +472,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
       }
 #pragma unroll
       for (int f = 0; f < FPU; ++f) {
+        melbad |= !(acc[f] < INFINITY);
         const float av = acc[f] > 1.0e-10f ? acc[f] : 1.0e-10f;
         // hardware log2 (v_log_f32, ~1 ulp) * log10(2): |error| ~ 1e-7, far inside the 1e-4 the reference's tests use
         const float v = __log2f(av) * 0.30102999566398120f;
@@ -835,6 +841,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
     // input in HBM rather than in the Infinity Cache the quad kernels were waiting here (4.0 instead of 6.0 TB/s).
     constexpr bool LATE = MODE == kModeQuad || STAGED;
     v2f zz[2][NQ];  // zz[par][q] = Z[2 lane + par + 128 q]
+    if (MEL && unit_nonfinite(d)) melbad = true;
     if (CAN_SOLO && unit_nonfinite(d)) {
 #pragma nounroll
       for (int f = 0; f < FPU && mA + f < a.M; ++f) {
@@ -878,6 +885,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
       const int i = __float_as_int(vmax);
       atomicMax(mp->gmax, i >= 0 ? i : i ^ 0x7fffffff);
     }
+    if (MEL && __builtin_amdgcn_ballot_w64(melbad) != 0 && lane == 0) atomicOr(mp->gmax + 1, 1);   // k_mel_pass2: everything becomes NaN
   }
 }
 
@@ -977,6 +985,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
   const int half = Kb / 2;
   float* mags = reinterpret_cast<float*>(xb + C / 2);  // MEL: |XA|^2 at [k], |XB|^2 at [half + k]; U lives in xb[0 .. Kb)
   float vmax = -3.0e38f;
+  bool melbad = false;   // log-mel: a non-finite |z|^2 poisons the whole tensor (see stft_wave_body)
 
   const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
   int64_t p_end = p_begin + a.chunk;
@@ -1065,7 +1074,9 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
     };  // xform_sink
     // non-finite samples: the reference transforms every frame alone (lib/nx_signal.ex:94-102); a pair whose windowed samples
     // are not all finite leaves the paired route and its frames ride alone, one after the other (same scheme as stft_wave_body)
-    if (load_unit(-1) && !MEL && haveB) {
+    const bool unit_nf = load_unit(-1);
+    if (MEL && unit_nf) melbad = true;
+    if (unit_nf && !MEL && haveB) {
 #pragma nounroll
       for (int sel = 0; sel < 2; ++sel) {
         load_unit(sel);
@@ -1086,6 +1097,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
           accA = fmaf(mags[k0 + (j - o0)], wv, accA);
           accB = fmaf(mags[half + k0 + (j - o0)], wv, accB);
         }
+        melbad |= !(accA < INFINITY) || (haveB && !(accB < INFINITY));
         accA = accA > 1.0e-10f ? accA : 1.0e-10f;
         accB = accB > 1.0e-10f ? accB : 1.0e-10f;
         const float vA = __log2f(accA) * 0.30102999566398120f, vB = __log2f(accB) * 0.30102999566398120f;
@@ -1103,6 +1115,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
       const int i = __float_as_int(vmax);
       atomicMax(b.gmax, i >= 0 ? i : i ^ 0x7fffffff);
     }
+    if (MEL && __builtin_amdgcn_ballot_w64(melbad) != 0 && lane == 0) atomicOr(b.gmax + 1, 1);   // see stft_wave_body
   }
 }
 

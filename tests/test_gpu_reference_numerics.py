@@ -224,3 +224,28 @@ def test_fir_zeroes_what_the_inverse_transform_of_fftconvolve_zeroes(taps):
     far = np.abs(np.abs(r) - 1e-10) > 3e-11          # samples the spectra's clean-up cannot move across the threshold
     assert np.array_equal((g == 0)[far & (np.abs(g) < 5e-11)], (r == 0)[far & (np.abs(g) < 5e-11)])
     assert np.max(np.abs(g - r)) < 2.5e-10
+
+
+# ------------------------------------------------------------------------------------------------ log-mel
+@pytest.mark.parametrize("K,N,hop,pad", [(1024, 1024, 256, "valid"), (512, 400, 160, "reflect"), (400, 400, 160, "valid"), (2048, 2048, 512, "valid"),
+                                         (1000, 1000, 250, "valid"), (256, 256, 64, "valid")])
+def test_log_mel_non_finite_sample_poisons_the_whole_tensor_like_reduce_max(K, N, hop, pad):
+    """stft_to_mel clamps against Nx.reduce_max of the WHOLE tensor (lib/nx_signal.ex:511) and its dense Nx.dot multiplies a
+    non-finite |z|^2 with every band's zero weights: one Inf / NaN sample leaves no finite value.  The fused sink (every front-end)
+    and the two-step path do the same; clean data afterwards is clean again."""
+    x = poisoned(30000, 2, K + hop, [(1, 12345, np.inf)])
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, sampling_rate=16000)
+    zo, _, _ = O.stft(x, w, **opts)
+    mo = O.stft_to_mel(zo.reshape(-1, K), 16000, K, mel_bins=40).reshape(zo.shape[:-1] + (40,))   # one tensor: one reduce_max
+    assert not np.isfinite(mo).any()
+    fused = np.asarray(S.mel_spectrogram(x, w, mel_bins=40, **opts))
+    assert fused.shape == mo.shape and not np.isfinite(fused).any()
+    z, _, _ = S.stft(x, w, **opts)
+    two = np.asarray(S.stft_to_mel(z, 16000, fft_length=K, mel_bins=40))
+    assert not np.isfinite(two).any()
+    x[1, 12345] = 0.5
+    fused = np.asarray(S.mel_spectrogram(x, w, mel_bins=40, **opts))
+    zo, _, _ = O.stft(x, w, **opts)
+    ref = O.stft_to_mel(zo.reshape(-1, K), 16000, K, mel_bins=40).reshape(fused.shape)
+    assert np.isfinite(fused).all() and float(np.max(np.abs(fused - ref))) < 1e-4

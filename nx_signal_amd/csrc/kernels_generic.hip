@@ -1323,12 +1323,18 @@ int launch_fir_generic(Ctx* c, const FirLaunch& s) {
 // the count is zeroed on the stream ahead of the kernel
 int istft_nf_list(Ctx* c, int64_t capacity, int** list) {
   if (capacity > 0x7fffffffLL) capacity = 0x7fffffffLL;
-  void* p = nullptr;
-  int rc = ctx_scratch(c, 23, (size_t)(capacity + 1) * 8, &p);
-  if (rc) return rc;
-  const int hdr[2] = {0, (int)capacity};
-  NXSIG_HIP_TRY(hipMemcpyAsync(p, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));   // 8 bytes from pageable memory: staged at once
-  *list = reinterpret_cast<int*>(p);
+  if (c->scratch_bytes[23] < (size_t)(capacity + 1) * 8) {
+    // (re)allocation: the capacity word is written once, synchronously (it describes the buffer, not the call)
+    const int64_t cap = capacity < 4096 ? 4096 : capacity * 2;
+    void* p = nullptr;
+    int rc = ctx_scratch(c, 23, (size_t)(cap + 1) * 8, &p);
+    if (rc) return rc;
+    const int hdr[2] = {0, (int)(cap > 0x7fffffffLL ? 0x7fffffffLL : cap)};
+    NXSIG_HIP_TRY(hipMemcpy(p, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+  }
+  // per call: the count goes back to zero on the stream, ahead of the kernel (a memset node: capturable into a HIP graph)
+  NXSIG_HIP_TRY(hipMemsetAsync(c->scratch[23], 0, sizeof(int), c->stream));
+  *list = reinterpret_cast<int*>(c->scratch[23]);
   return NXSIG_OK;
 }
 

@@ -768,6 +768,85 @@ def test_stft_istft_are_capturable_into_a_hip_graph():
     assert np.array_equal(yd.numpy().view(np.uint32), y_ref_h.view(np.uint32))
 
 
+def test_frame_packing_istft_fir_and_packed_pair_are_capturable_into_a_hip_graph():
+    """the passes round 3 added behind these entry points are graph-capturable too: the non-finite unit list of the frame-packing
+    inverse kernels is reset by a memset NODE (not a host copy), the FIR's row flags are consumed by its own poison pass, the
+    packed pair is a kernel + the two fix-up passes.  Replays are bit-identical to the eager calls, and a replay on data that now
+    holds a non-finite value takes the fix-up route (the list / the flags are device state, not captured host state)."""
+    import ctypes as C
+
+    from nx_signal_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+
+    def ok(rc, what):
+        assert rc == 0, f"{what} -> hip error {rc}"
+
+    N, hop, L = 512, 128, 40000
+    x = O.synth_signal(L, seed=5)
+    w = S.windows.hann(N)
+    w1 = S.windows.hann(1024)
+    h = S.filters.firwin(257, [0.2])
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+    opts1 = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)
+    ctx = S.Context(0)
+    xd = ctx.to_device(x)
+    z_ref, _, _ = S.stft(xd, w, ctx=ctx, **opts)                   # warm-up calls: build and cache every table
+    y_ref = S.istft(z_ref, w, ctx=ctx, **opts).numpy()
+    f_ref = S.filters.fir(xd, h, ctx=ctx).numpy()
+    zp_ref, _, _ = S.stft_packed(xd, w1, ctx=ctx, **opts1)
+    yp_ref = S.istft_packed(zp_ref, w1, ctx=ctx, **opts1).numpy()
+    lib = _lib.load()
+    M, M1 = z_ref.shape[0], zp_ref.shape[0]
+    zd = ctx.to_device(z_ref.numpy())
+    yd = ctx.empty(y_ref.shape, np.complex64)
+    fd = ctx.empty(f_ref.shape, np.float32)
+    zpd = ctx.empty((M1, 512), np.complex64)
+    ypd = ctx.empty(yp_ref.shape, np.float32)
+    p = _lib.StftParams(N, hop, N, _lib.PAD_VALID, 0, 0, _lib.SCALE_NONE, 0, 48000.0)
+    p1 = _lib.StftParams(1024, 256, 1024, _lib.PAD_VALID, 0, 0, _lib.SCALE_NONE, 0, 48000.0)
+    wp, w1p, hp = w.ctypes.data_as(C.c_void_p), w1.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p)
+    V = C.c_void_p
+    stream, graph, gexec = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    ok(hip.hipStreamCreate(C.byref(stream)), "hipStreamCreate")
+    ctx.set_stream(stream.value)
+    try:
+        ok(hip.hipStreamBeginCapture(stream, 0), "hipStreamBeginCapture")
+        _lib.check(lib.nxsig_istft_c64(ctx.handle, V(zd.ptr), M, 1, wp, C.byref(p), V(yd.ptr), _lib.DEVICE))
+        _lib.check(lib.nxsig_fir_f32(ctx.handle, V(xd.ptr), L, 1, L, hp, 257, _lib.CONV_SAME, V(fd.ptr), _lib.DEVICE))
+        _lib.check(lib.nxsig_stft_packed_f32(ctx.handle, V(xd.ptr), L, 1, L, w1p, C.byref(p1), V(zpd.ptr), None, _lib.DEVICE))
+        _lib.check(lib.nxsig_istft_packed_f32(ctx.handle, V(zpd.ptr), M1, 1, w1p, C.byref(p1), V(ypd.ptr), _lib.DEVICE))
+        ok(hip.hipStreamEndCapture(stream, C.byref(graph)), "hipStreamEndCapture")
+        ok(hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
+        for _ in range(2):
+            ok(hip.hipGraphLaunch(gexec, stream), "hipGraphLaunch")
+        ok(hip.hipStreamSynchronize(stream), "hipStreamSynchronize")
+        assert np.array_equal(yd.numpy().view(np.uint32), y_ref.view(np.uint32))
+        assert np.array_equal(fd.numpy().view(np.uint32), f_ref.view(np.uint32))
+        assert np.array_equal(zpd.numpy().view(np.uint32), zp_ref.numpy().view(np.uint32))
+        assert np.array_equal(ypd.numpy().view(np.uint32), yp_ref.view(np.uint32))
+        # the same graph on data with a non-finite value: the device-side list / flags route it through the fix-up passes
+        zbad = z_ref.numpy().copy()
+        zbad[40, 7] = np.inf
+        _lib.check(lib.nxsig_upload(ctx.handle, V(zd.ptr), zbad.ctypes.data_as(V), zbad.nbytes))
+        xbad = x.copy()
+        xbad[20000] = np.nan
+        _lib.check(lib.nxsig_upload(ctx.handle, V(xd.ptr), xbad.ctypes.data_as(V), xbad.nbytes))
+        ok(hip.hipGraphLaunch(gexec, stream), "hipGraphLaunch")
+        ok(hip.hipStreamSynchronize(stream), "hipStreamSynchronize")
+        yo = O.istft(zbad, w, **opts)
+        assert np.array_equal(np.isfinite(yd.numpy()), np.isfinite(yo))
+        assert not np.isfinite(fd.numpy()).any()
+        zo1, _, _ = O.stft(xbad, w1, **opts1)
+        assert np.array_equal(np.isfinite(zpd.numpy()).all(axis=-1), np.isfinite(zo1).all(axis=-1))
+    finally:
+        ctx.set_stream(None)
+        if gexec.value:
+            hip.hipGraphExecDestroy(gexec)
+        if graph.value:
+            hip.hipGraphDestroy(graph)
+        hip.hipStreamDestroy(stream)
+
+
 # ------------------------------------------------------------------------------- concurrency (dirty-scheduler threads)
 def test_concurrent_calls_from_several_threads():
     """NIF dirty schedulers are arbitrary OS threads: calls on one shared context (serialised by its mutex) and on

@@ -377,7 +377,10 @@ void k_istft_wave_half(IstftWaveArgs a) {
     for (int e = 0; e < 2; ++e) {
       const int64_t j = m + e;              // frame index = index of the segment it completes
       const float live = j < a.M ? 1.0f : 0.0f;
-      const int64_t trow = j < R - 1 ? j : (j >= a.M ? R + (j - a.M) : R - 1);
+      // (the phantom second half of an odd last pair, j == segs_per_row, is never stored: keep its table row inside the table —
+      //  round 3: the read one row past the 2R - 1 rows faulted when the table ended its allocation)
+      const int64_t jt = j < a.segs_per_row ? j : a.segs_per_row - 1;
+      const int64_t trow = jt < R - 1 ? jt : (jt >= a.M ? R + (jt - a.M) : R - 1);
       const float* dp = a.den + trow * a.hop + lane;
       const bool store = (j >= j0) && (j < j1);
       v2f* yp = store ? a.y + (size_t)row * a.segs_per_row * a.hop + j * a.hop + lane : a.dummy + lane;
@@ -694,7 +697,8 @@ int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batc
 // STREAM = true : interior pairs only, 8-byte vector access, branch-free and software-pipelined like k_stft_wave
 //                 (requires (taps-1) % 128 == 0 and even offsets — checked by the launcher)
 // STREAM = false: the few edge pairs of every row (and every pair when the fast conditions fail): bounds-checked
-template <int K, bool STREAM, int W, bool HREG = false>
+// SC1: cache policy of the streaming stores: true = "sc1 nt" (write-through), false = "nt" (see launch_fir_wave_W)
+template <int K, bool STREAM, int W, bool HREG = false, bool SC1 = true>
 __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
   constexpr int P = K / 64;
   constexpr int R3 = K / 256;
@@ -777,8 +781,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       for (int q = 0; q < NQ; ++q) {
         if (128 * q >= tm1) {  // uniform: (taps-1) % 128 == 0
           // fft_eps0: the clean-up Nx.ifft applies to fftconvolve's result (convolution.ex:282)
-          ys.st8(fft_eps0(v2f{u[0][q].x, u[1][q].x}), lane * 8 + 512 * q - tm1 * 4);
-          ys.st8(fft_eps0(v2f{u[0][q].y, u[1][q].y}), lane * 8 + 512 * q - tm1 * 4 + a.V * 4);
+          ys.template st8<SC1 ? 18 : 2>(fft_eps0(v2f{u[0][q].x, u[1][q].x}), lane * 8 + 512 * q - tm1 * 4);
+          ys.template st8<SC1 ? 18 : 2>(fft_eps0(v2f{u[0][q].y, u[1][q].y}), lane * 8 + 512 * q - tm1 * 4 + a.V * 4);
         }
       }
       row = nrow; pin = npin;
@@ -1272,7 +1276,8 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_wave<K, false, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (hreg) {
-      if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W, K == 1024>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      if (stream && !env_int("NXSIG_FIR_SC1", 1)) hipLaunchKernelGGL((k_fir_wave<K, true, W, K == 1024, false>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      else if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W, K == 1024>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
       else hipLaunchKernelGGL((k_fir_wave<K, false, W, K == 1024>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     } else if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     else hipLaunchKernelGGL((k_fir_wave<K, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);

@@ -138,7 +138,9 @@ __global__ __launch_bounds__(64 * W) void k_istft_packed(IstftPackedArgs a) {
     for (int e = 0; e < 2; ++e) {
       const int64_t j = m + e;              // frame index = index of the segment it completes
       const float live = j < a.M ? 1.0f : 0.0f;
-      const int64_t trow = j < R - 1 ? j : (j >= a.M ? R + (j - a.M) : R - 1);
+      // (the phantom second half of an odd last pair, j == segs_per_row, is never stored: keep its table row inside the table)
+      const int64_t jt = j < a.segs_per_row ? j : a.segs_per_row - 1;
+      const int64_t trow = jt < R - 1 ? jt : (jt >= a.M ? R + (jt - a.M) : R - 1);
       const float* dp = a.den + trow * a.hop + 2 * lane;
       const bool store = (j >= j0) && (j < j1);
       float* yp = store ? a.y + (size_t)row * a.segs_per_row * a.hop + j * a.hop + 2 * lane : a.dummy + 2 * lane;

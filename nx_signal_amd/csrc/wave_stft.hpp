@@ -322,9 +322,10 @@ struct StreamRow {
   __device__ __forceinline__ void st4(float v, int byte_off) const {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, byte_off, 0, kAux);
   }
+  template <int AUX = kAux>
   __device__ __forceinline__ void st8(v2f v, int byte_off) const {
     typedef int v2i __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, byte_off, 0, kAux);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, byte_off, 0, AUX);
   }
 };
 
@@ -1430,7 +1431,13 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
       }
     }
     if constexpr (MODE == kModePair && C == 1024) {
-      const int stp = env_int("NXSIG_STORE_POLICY", 1);  // A/B switch of the headline kernel only (evidence in profiles/)
+      // Store cache policy by the size of the result (round 3, tools/sweep_stft.py NXSIG_STORE_POLICY 0 1 with SWEEP_B = 1 ... 96
+      // streams of 60 s): a spectrum of 0.15 ... 2.2 GB leaves faster through plain non-temporal stores (3 streams: +10 ... 14 %,
+      // 4: +14 ... 18 %, 8: +8 %, 12 / 16: +5 %), from 24 streams on the write-through "sc1 nt" form wins as measured in round 2
+      // (32: +1 ... 5 %, flat to 96 streams = 8.8 GB); one stream (92 MB, Infinity-Cache resident) shows no preference.
+      // NXSIG_STORE_POLICY forces one (0 / 1 / 2).
+      const int64_t out_bytes = (int64_t)s.batch * s.fr.M * KOUT * 8;
+      const int stp = env_int("NXSIG_STORE_POLICY", (out_bytes > ((int64_t)150 << 20) && out_bytes <= ((int64_t)2200 << 20)) ? 0 : 1);
       if (!done && !npred && (stp == 0 || stp == 2)) {
         done = true;
         if (stp == 0) rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 0, 0>, upr, big, u_lo, u_lo)

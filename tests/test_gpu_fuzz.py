@@ -304,3 +304,61 @@ def test_fuzz_long_rows_and_columns(seed):
     got = fn(y, axes=[1], lengths=[Kc])
     assert got.shape == (y.shape[0], Kc, inner)
     assert nerr(got, npf(y.astype(np.complex128), n=Kc, axis=1)) < 1e-5, (y.shape, Kc, inverse)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_fuzz_non_finite_samples_follow_the_reference(seed):
+    """round 3: random geometry (every front-end / padding / scaling), a few Inf / NaN samples at random places: the frames
+    that are non-finite are exactly the oracle's, the finite ones agree as usual (lib/nx_signal.ex:94-102: one Nx.fft row per frame)"""
+    rng = np.random.default_rng(7000 + seed)
+    K = int(rng.choice([1024, 1024, 512, 256, 128, 2048, 4096, 400, 1000, 300, 64, 8192]))
+    N = int(rng.choice([K, K, max(2, int(K * 0.8))]))
+    hop = int(rng.choice([max(1, N // 4), max(1, N // 2), int(rng.integers(1, N + 1))]))
+    pad = ["valid", "valid", "reflect", "same"][rng.integers(4)]
+    B = int(rng.integers(1, 4))
+    L = N + hop * int(rng.integers(3, 60)) + int(rng.integers(0, hop))
+    x = rng.standard_normal((B, L)).astype(np.float32)
+    for _ in range(int(rng.integers(1, 5))):
+        x[rng.integers(B), rng.integers(L)] = [np.inf, -np.inf, np.nan][rng.integers(3)]
+    w = make_window(rng, N)
+    scaling = [None, "spectrum", "psd"][rng.integers(3)]
+    opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=8000)
+    z, _, _ = S.stft(x, w, **opts)
+    zo, _, _ = O.stft(x, w, **opts)
+    fin, fino = np.isfinite(z).all(axis=-1), np.isfinite(zo).all(axis=-1)
+    assert np.array_equal(fin, fino), (K, N, hop, pad, L, B, np.argwhere(fin != fino)[:6])
+    if fin.any():
+        assert nerr(z[fin], zo[fin]) < 1e-5, (K, N, hop, pad)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_istft_non_finite_bins_and_packed_pair(seed):
+    """round 3: (a) istft with a few non-finite bins: sample-for-sample the oracle's finite pattern (Nx.ifft row by row, :609);
+    (b) stft_packed -> istft_packed against the oracle's full-spectrum stft / the real part of its istft"""
+    rng = np.random.default_rng(8000 + seed)
+    N = int(rng.choice([1024, 1024, 512, 256, 128, 2048, 400, 64]))
+    hop = int(rng.choice([N // 4, N // 2, N, N // 8]))
+    M = int(rng.integers(2 * (N // hop), 90))
+    B = int(rng.integers(1, 4))
+    w = S.windows.hann(N) if rng.integers(2) else S.windows.hamming(N)
+    scaling = [None, "spectrum", "psd"][rng.integers(3)]
+    opts = dict(overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=16000)
+    z = (rng.standard_normal((B, M, N)) + 1j * rng.standard_normal((B, M, N))).astype(np.complex64)
+    for _ in range(int(rng.integers(1, 4))):
+        z[rng.integers(B), rng.integers(M), rng.integers(N)] = [np.inf, np.nan, complex(0, np.inf)][rng.integers(3)]
+    y = np.asarray(S.istft(z, w, **opts))
+    yo = np.stack([O.istft(z[b], w, **opts) for b in range(B)])
+    fin, fino = np.isfinite(y), np.isfinite(yo)
+    assert np.array_equal(fin, fino), (N, hop, M, B, np.argwhere(fin != fino)[:6])
+    if fin.any():
+        assert nerr(y[fin], yo[fin]) < 1e-5
+    # (b) the packed pair
+    x = rng.standard_normal((B, N + hop * (M - 1))).astype(np.float32)
+    zp, _, _ = S.stft_packed(x, w, **opts)
+    zo, _, _ = O.stft(x, w, **opts)
+    pk = zo[..., : N // 2].copy()
+    pk[..., 0] = pk[..., 0].real + 1j * zo[..., N // 2].real
+    assert nerr(zp, pk) < 1e-5, (N, hop, M)
+    yr = np.asarray(S.istft_packed(pk.astype(np.complex64), w, **opts))
+    yro = np.stack([O.istft(zo[b].astype(np.complex64), w, **opts) for b in range(B)]).real
+    assert yr.dtype == np.float32 and nerr(yr, yro) < 1e-5, (N, hop, M, nerr(yr, yro))

@@ -74,12 +74,18 @@ def rendezvous_path(env=None) -> str:
     env = os.environ if env is None else env
     d = env.get("NXSIG_RDZV_DIR")
     if d is None:
-        # a directory only this user can write to (0700, ownership checked): nobody else can plant an id file there
+        # a directory only this user can write to (0700, ownership checked): nobody else can plant an id file there.  Every rank
+        # of a launch must arrive at the SAME path, so if that directory cannot be had (it exists with other permissions, /tmp is
+        # read-only ...) all ranks fall back to /tmp itself, where the C side still creates the file exclusively with mode 0600
+        # and validates its content
         d = os.path.join("/tmp", "nxsig-%d" % os.getuid())
-        os.makedirs(d, mode=0o700, exist_ok=True)
-        st = os.stat(d)
-        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
-            raise RuntimeError(f"{d} is not a private directory of this user (set NXSIG_RDZV_DIR)")
+        try:
+            os.makedirs(d, mode=0o700, exist_ok=True)
+            st = os.stat(d)
+            if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+                d = "/tmp"
+        except OSError:
+            d = "/tmp"
     return os.path.join(d, "nxsig_rdzv_%s_%s_%d" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
 
 

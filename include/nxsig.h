@@ -41,6 +41,10 @@ typedef struct nxsig_c64 {
   float re, im;
 } nxsig_c64;
 
+typedef struct nxsig_c128 {
+  double re, im;
+} nxsig_c128;
+
 typedef enum nxsig_status {
   NXSIG_OK = 0,
   NXSIG_ERR_INVALID_ARG = -1, /* maps to ArgumentError on the Elixir side */
@@ -321,6 +325,47 @@ int nxsig_istft_filtered_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_fra
  */
 int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const nxsig_c64* b, int64_t n2, int32_t mode,
                           nxsig_c64* out, int32_t mem);
+
+/* ---------------------------------------------------------------- f64 / c128 tier --------
+ * The reference computes in the type of its operands: f64 samples or an f64 window promote the product of lib/nx_signal.ex:101
+ * to f64 and Nx.fft returns c128 (:102); a c128 spectrum is inverted in c128 (:609); Windows.* / firwin / fft_frequencies take
+ * `type: {:f, 64}` (lib/nx_signal/windows.ex:58, :99 ..., filters.ex:154, nx_signal.ex:155).  These entry points are that
+ * tier: the argument conventions of their f32 namesakes with double / nxsig_c128 payloads, double arithmetic on the device
+ * (workgroup-per-frame kernels, kernels_f64.hip — the tuned wave kernels stay the f32 path).  Limits: fft_length a power of two
+ * <= 8192, any other length <= 4096 (Bluestein) or <= 65536 with at most 8192 samples per row (table DFT); FIR up to 4097 taps.
+ * NXSIG_ERR_UNSUPPORTED beyond.  `window` is f64[N] when window_is_f64, else f32[N]: the reference forms the :scaling
+ * scalar and the |w|^2 normaliser in the window's OWN type before promoting (Nx.sum(window) :116, :614; :630-633).
+ */
+/* NxSignal.Windows.*(n, type: {:f, 64}) — lib/nx_signal/windows.ex: every op of the f32 generator rounded to double instead */
+int nxsig_window_f64(int32_t kind, int32_t n, int32_t is_periodic, double beta, double eps, double* out);
+/* NxSignal.Waveforms.sinc on an f64 tensor — lib/nx_signal/waveforms.ex:451-457 (its pi() stays the f32 constant) */
+int nxsig_sinc_f64(const double* t, int64_t n, double* out);
+/* NxSignal.Filters.firwin(..., type: {:f, 64}) — lib/nx_signal/filters.ex:147-279 */
+int nxsig_firwin_f64(int32_t num_taps, const double* cutoff, int32_t n_cutoff, int32_t window_kind, double kaiser_beta,
+                     int32_t pass_zero, int32_t scale, double sampling_rate, double* out);
+/* NxSignal.fft_frequencies(fs, type: {:f, 64}) — lib/nx_signal.ex:154-166 */
+int nxsig_fft_frequencies_f64(double sampling_rate, int32_t fft_length, int32_t endpoint, double* out);
+/* NxSignal.stft/3 on f64 samples — lib/nx_signal.ex:68-130: x f64[batch][length] -> z c128[batch][M][K] */
+int nxsig_stft_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batch, int64_t batch_stride, const void* window,
+                   int32_t window_is_f64, const nxsig_stft_params* params, nxsig_c128* z, int64_t* num_frames_out, int32_t mem);
+/* NxSignal.istft/3 on a c128 spectrum — lib/nx_signal.ex:582-638: z c128[batch][M][K] -> y c128[batch][M*hop + N-hop] */
+int nxsig_istft_c128(nxsig_ctx* ctx, const nxsig_c128* z, int64_t num_frames, int32_t batch, const void* window, int32_t window_is_f64,
+                     const nxsig_stft_params* params, nxsig_c128* y, int32_t mem);
+/* Nx.fft / Nx.ifft(length: K) over rows in c128 — lib/nx_signal/transforms.ex:5-21: in f64 (in_is_real) or c128 */
+int nxsig_fft_c128(nxsig_ctx* ctx, const void* in, int32_t in_is_real, int64_t rows, int32_t n_in, int32_t fft_length, int32_t inverse,
+                   nxsig_c128* out, int32_t mem);
+/* NxSignal.as_windowed/2 of an f64 tensor — lib/nx_signal.ex:249-364 */
+int nxsig_as_windowed_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batch, int64_t batch_stride, int32_t window_length,
+                          int32_t stride, int32_t pad_mode, int64_t pad_lo, int64_t pad_hi, double* out, int64_t* num_frames_out,
+                          int32_t mem);
+/* NxSignal.overlap_and_add/2 of an f64 (components = 1) or c128 (2) tensor — lib/nx_signal.ex:684-736 */
+int nxsig_overlap_and_add_f64(nxsig_ctx* ctx, const double* frames, int64_t num_frames, int32_t batch, int32_t frame_length,
+                              int32_t overlap_length, int32_t components, double* out, int32_t mem);
+/* Convolution.convolve(x, h, method: :fft, mode:) of f64 rows with f64 taps — lib/nx_signal/convolution.ex:252-329 */
+int nxsig_fir_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batch, int64_t batch_stride, const double* h,
+                  int32_t num_taps, int32_t mode, double* y, int32_t mem);
+int nxsig_fir_slice_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batch, int64_t batch_stride, const double* h,
+                        int32_t num_taps, int64_t out_start, int64_t out_len, double* y, int32_t mem);
 
 /* ============================================================== multi-GPU groups ====
  * The path shards with NO data-path exchange: channels (the reference's vectorized axes,

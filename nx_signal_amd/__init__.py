@@ -54,18 +54,20 @@ def _host_f32(x, what: str) -> np.ndarray:
         return np.ascontiguousarray(a.astype(np.float32))
     if a.dtype == np.float64:
         raise ArgumentError(
-            f"{what}: float64 input would produce a c128 result in the reference; this path computes f32/c64 — "
-            "cast to float32 explicitly"
+            f"{what}: float64 input would produce an f64 / c128 result in the reference; this entry point computes f32 / c64 — "
+            "cast to float32 explicitly (stft, istft, as_windowed, overlap_and_add, fft_nd over the last axis and 1-D fftconvolve "
+            "take float64 / complex128 and compute in double)"
         )
     raise ArgumentError(f"{what}: unsupported dtype {a.dtype}")
 
 
 def _window_host(window) -> np.ndarray:
+    """the window as the host array handed to the library: f32, or f64 when the caller's is (the f64 tier, include/nxsig.h)"""
     w = np.asarray(window)
     if w.ndim != 1:
         raise ArgumentError(f"window must be a rank-1 tensor, got shape {w.shape}")
     if w.dtype == np.float64:
-        raise ArgumentError("window: float64 is outside this path; NxSignal.Windows produce f32")
+        return np.ascontiguousarray(w)
     return np.ascontiguousarray(w.astype(np.float32))
 
 
@@ -117,6 +119,12 @@ def fft_frequencies(sampling_rate, **opts):
     if o["fft_length"] is None:
         raise ArgumentError("missing :fft_length option")
     K = int(o["fft_length"])
+    if o["type"] in ("f64", np.float64):
+        out = np.empty(K, dtype=np.float64)
+        _lib.check(_lib.load().nxsig_fft_frequencies_f64(float(sampling_rate), K, int(bool(o["endpoint"])), _as_ptr(out)))
+        return out
+    if o["type"] not in ("f32", np.float32):
+        raise ArgumentError(f"fft_frequencies: type must be f32 or f64, got {o['type']!r}")
     out = np.empty(K, dtype=np.float32)
     _lib.check(_lib.load().nxsig_fft_frequencies_f32(float(sampling_rate), K, int(bool(o["endpoint"])), _as_ptr(out)))
     return out
@@ -136,17 +144,27 @@ def as_windowed(tensor, ctx: Context | None = None, **opts):
     M = C.c_int64()
     if is_device(tensor):
         ptr, shape, dt = device_view(tensor)
-        if dt != np.float32:
-            raise ArgumentError("as_windowed: device input must be float32")
+        if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ArgumentError("as_windowed: device input must be float32 or float64")
         c = _ctx_of(tensor, ctx)
         L = shape[-1]
         batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
         m = _lib.check(lib.nxsig_num_frames(L, N, int(stride), mode, lo, hi))
-        out = c.empty(shape[:-1] + (m, N), np.float32)
-        _lib.check(lib.nxsig_as_windowed_f32(c.handle, C.c_void_p(ptr), L, batch, L, N, int(stride), mode, lo, hi,
-                                             C.c_void_p(out.ptr), C.byref(M), _lib.DEVICE))
+        out = c.empty(shape[:-1] + (m, N), dt)
+        entry = lib.nxsig_as_windowed_f64 if dt == np.dtype(np.float64) else lib.nxsig_as_windowed_f32
+        _lib.check(entry(c.handle, C.c_void_p(ptr), L, batch, L, N, int(stride), mode, lo, hi, C.c_void_p(out.ptr), C.byref(M), _lib.DEVICE))
         return out
     src = np.asarray(tensor)
+    if src.dtype == np.float64:   # f64 tier: 8-byte words through the same gather
+        x = np.ascontiguousarray(src)
+        c = _ctx_of(None, ctx)
+        L = x.shape[-1]
+        batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
+        m = _lib.check(lib.nxsig_num_frames(L, N, int(stride), mode, lo, hi))
+        out = np.empty(x.shape[:-1] + (m, N), dtype=np.float64)
+        _lib.check(lib.nxsig_as_windowed_f64(c.handle, _as_ptr(x), L, batch, L, N, int(stride), mode, lo, hi, _as_ptr(out), C.byref(M),
+                                             _lib.HOST))
+        return out
     if src.dtype.kind in "iub":
         # framing is a pure gather (doctests :182-246 keep s64): 32-bit words travel through the kernel untouched, so integer
         # tensors stay EXACT (no rounding through f32); wider integers go through int32 when every value fits
@@ -238,10 +256,16 @@ def _stft(data, window, ctx, opts, onesided, packed=False):
     entry = lib.nxsig_stft_packed_f32 if packed else (lib.nxsig_stft_onesided_f32 if onesided else lib.nxsig_stft_f32)
     if packed and K % 2:
         raise ArgumentError("stft_packed: fft_length must be even")
+    # f64 tier: f64 samples or an f64 window make the reference compute in f64 / c128 (Nx.multiply promotes, :101-102)
+    data_f64 = (device_view(data)[2] == np.dtype(np.float64)) if is_device(data) else (np.asarray(data).dtype == np.float64)
+    if data_f64 or w.dtype == np.float64:
+        if onesided:
+            raise ArgumentError("stft_onesided / stft_packed are f32 extensions; the f64 tier returns the full c128 spectrum")
+        return _stft_f64(data, w, ctx, p, N, hop, K, data_f64)
     if is_device(data):
         ptr, shape, dt = device_view(data)
         if dt != np.float32:
-            raise ArgumentError("stft: device input must be float32")
+            raise ArgumentError("stft: device input must be float32 or float64")
         c = _ctx_of(data, ctx)
         L = shape[-1]
         batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
@@ -264,6 +288,43 @@ def _stft(data, window, ctx, opts, onesided, packed=False):
     _lib.check(lib.nxsig_stft_times_f32(N, fs, m, _as_ptr(times)))
     freqs = fft_frequencies(fs, fft_length=K)
     return z, times, (freqs[:Kout] if onesided else freqs)
+
+
+def _stft_f64(data, w, ctx, p, N, hop, K, data_f64):
+    """stft of f64 samples and / or with an f64 window: c128 spectrum (nxsig_stft_f64); times / frequencies stay f32 like the
+    reference's (their linspace calls do not take the data type, lib/nx_signal.ex:106-111)"""
+    lib = _lib.load()
+    M = C.c_int64()
+    fs = float(p.sampling_rate)
+    mode, lo, hi = p.pad_mode, p.pad_lo, p.pad_hi
+    wflag = int(w.dtype == np.float64)
+    if is_device(data):
+        if not data_f64:
+            raise NxSignalUnsupported("stft: an f64 window with device-resident f32 samples is not built; widen the samples first")
+        ptr, shape, _ = device_view(data)
+        c = _ctx_of(data, ctx)
+        L = shape[-1]
+        batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
+        m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
+        z = c.empty(shape[:-1] + (m, K), np.complex128)
+        _lib.check(lib.nxsig_stft_f64(c.handle, C.c_void_p(ptr), L, batch, L, _as_ptr(w), wflag, C.byref(p), C.c_void_p(z.ptr),
+                                      C.byref(M), _lib.DEVICE))
+    else:
+        a = np.asarray(data)
+        if a.dtype.kind not in "fiub":
+            raise ArgumentError(f"stft: unsupported dtype {a.dtype}")
+        x = np.ascontiguousarray(a.astype(np.float64))   # f32 / integer samples widen exactly
+        if x.ndim < 1:
+            raise ArgumentError("stft expects a tensor of rank >= 1")
+        c = _ctx_of(None, ctx)
+        L = x.shape[-1]
+        batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
+        m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
+        z = np.empty(x.shape[:-1] + (m, K), dtype=np.complex128)
+        _lib.check(lib.nxsig_stft_f64(c.handle, _as_ptr(x), L, batch, L, _as_ptr(w), wflag, C.byref(p), _as_ptr(z), C.byref(M), _lib.HOST))
+    times = np.empty(m, dtype=np.float32)
+    _lib.check(lib.nxsig_stft_times_f32(N, fs, m, _as_ptr(times)))
+    return z, times, fft_frequencies(fs, fft_length=K)
 
 
 def istft(data, window, ctx: Context | None = None, **opts):
@@ -296,18 +357,24 @@ def _istft(data, window, ctx, opts, hh, packed=False):
         raise ArgumentError(f"overlap_length must be a number less than the window size {N}, got: {N}")
     hop = N - overlap
     lib = _lib.load()
+    wide = False   # f64 tier: a c128 spectrum is inverted in c128 (Nx.ifft :609)
     if is_device(data):
         ptr, shape, dt = device_view(data)
-        if dt != np.complex64:
-            raise ArgumentError("istft: device input must be complex64")
+        if dt not in (np.dtype(np.complex64), np.dtype(np.complex128)):
+            raise ArgumentError("istft: device input must be complex64 or complex128")
+        wide = dt == np.dtype(np.complex128)
         c = _ctx_of(data, ctx)
     else:
         zin = np.asarray(data)
-        if zin.dtype == np.complex128:
-            raise ArgumentError("istft: complex128 input is outside this path; cast to complex64")
-        zin = np.ascontiguousarray(zin.astype(np.complex64))
+        wide = zin.dtype in (np.complex128, np.float64)
+        zin = np.ascontiguousarray(zin.astype(np.complex128 if wide else np.complex64))
         shape = zin.shape
         c = _ctx_of(None, ctx)
+    if wide and (packed or hh is not None):
+        raise ArgumentError("istft_packed / istft_filtered are f32 extensions; the f64 tier takes the full c128 spectrum")
+    if w.dtype == np.float64 and not wide:
+        # the reference would invert in c64 (Nx.ifft rounds to c64) and only then promote the frames to c128: not modelled
+        raise NxSignalUnsupported("istft: a c64 spectrum with an f64 window is not built; pass the spectrum as complex128")
     if len(shape) < 2:
         raise ArgumentError("istft expects a tensor of shape {..., frames, frequencies}")
     Mf, Kin = int(shape[-2]), int(shape[-1])
@@ -323,13 +390,15 @@ def _istft(data, window, ctx, opts, hh, packed=False):
     out_len = _lib.check(lib.nxsig_ola_length(Mf, N, hop))
 
     def call(zp, yp, mem):
+        if wide:
+            return lib.nxsig_istft_c128(c.handle, zp, Mf, batch, _as_ptr(w), int(w.dtype == np.float64), C.byref(p), yp, mem)
         if packed:
             return lib.nxsig_istft_packed_f32(c.handle, zp, Mf, batch, _as_ptr(w), C.byref(p), yp, mem)
         if hh is None:
             return lib.nxsig_istft_c64(c.handle, zp, Mf, batch, _as_ptr(w), C.byref(p), yp, mem)
         return lib.nxsig_istft_filtered_c64(c.handle, zp, Mf, batch, _as_ptr(w), C.byref(p), _as_ptr(hh), yp, mem)
 
-    odt = np.float32 if packed else np.complex64
+    odt = np.complex128 if wide else (np.float32 if packed else np.complex64)
     if is_device(data):
         y = c.empty(tuple(shape[:-2]) + (out_len,), odt)
         _lib.check(call(C.c_void_p(ptr), C.c_void_p(y.ptr), _lib.DEVICE))
@@ -354,7 +423,9 @@ def overlap_and_add(tensor, ctx: Context | None = None, **opts):
     else:
         src = np.asarray(tensor)
         src_dtype = src.dtype
-        if src.dtype.kind == "c":
+        if src.dtype in (np.float64, np.complex128):
+            arr = np.ascontiguousarray(src)   # f64 tier
+        elif src.dtype.kind == "c":
             arr = np.ascontiguousarray(src.astype(np.complex64))
         else:
             if src.dtype.kind in "iu" and src.size and src.ndim >= 2:
@@ -373,16 +444,17 @@ def overlap_and_add(tensor, ctx: Context | None = None, **opts):
         raise ArgumentError(f"overlap_length must be a number less than the window size {N}, got: {N}")
     if not dev:
         c = _ctx_of(None, ctx)
-    comps = 2 if np.dtype(dt) == np.complex64 else 1
+    comps = 2 if np.dtype(dt).kind == "c" else 1
+    entry = lib.nxsig_overlap_and_add_f64 if np.dtype(dt) in (np.dtype(np.float64), np.dtype(np.complex128)) else lib.nxsig_overlap_and_add
     batch = int(np.prod(shape[:-2], dtype=np.int64)) if len(shape) > 2 else 1
     out_len = Mf * (N - overlap) + overlap
     out_shape = tuple(shape[:-2]) + (out_len,)
     if dev:
         out = c.empty(out_shape, dt)
-        _lib.check(lib.nxsig_overlap_and_add(c.handle, C.c_void_p(ptr), Mf, batch, N, overlap, comps, C.c_void_p(out.ptr), _lib.DEVICE))
+        _lib.check(entry(c.handle, C.c_void_p(ptr), Mf, batch, N, overlap, comps, C.c_void_p(out.ptr), _lib.DEVICE))
         return out
     out = np.empty(out_shape, dtype=dt)
-    _lib.check(lib.nxsig_overlap_and_add(c.handle, _as_ptr(arr), Mf, batch, N, overlap, comps, _as_ptr(out), _lib.HOST))
+    _lib.check(entry(c.handle, _as_ptr(arr), Mf, batch, N, overlap, comps, _as_ptr(out), _lib.HOST))
     target = o["type"] if o["type"] is not None else src_dtype  # code default: the input type (:685, B10)
     return out.astype(target) if np.dtype(target) != out.dtype else out
 

@@ -101,6 +101,18 @@ SIGNATURES = {
     "nxsig_fftconvolve_nd": (C.c_int, [_p, _p, _i32, C.POINTER(_i64), _p, _i32, C.POINTER(_i64), _i32, _i32, _p, C.POINTER(_i64), _i32]),
     "nxsig_convolve_direct": (C.c_int, [_p, _p, _i32, C.POINTER(_i64), _p, _i32, C.POINTER(_i64), _i32, _i32, _p, C.POINTER(_i64), _i32]),
     "nxsig_fir_slice_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32]),
+    # f64 / c128 tier
+    "nxsig_window_f64": (C.c_int, [_i32, _i32, _i32, _f64, _f64, _p]),
+    "nxsig_sinc_f64": (C.c_int, [_p, _i64, _p]),
+    "nxsig_firwin_f64": (C.c_int, [_i32, C.POINTER(_f64), _i32, _i32, _f64, _i32, _i32, _f64, _p]),
+    "nxsig_fft_frequencies_f64": (C.c_int, [_f64, _i32, _i32, _p]),
+    "nxsig_stft_f64": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _i32, C.POINTER(StftParams), _p, C.POINTER(_i64), _i32]),
+    "nxsig_istft_c128": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, C.POINTER(StftParams), _p, _i32]),
+    "nxsig_fft_c128": (C.c_int, [_p, _p, _i32, _i64, _i32, _i32, _i32, _p, _i32]),
+    "nxsig_as_windowed_f64": (C.c_int, [_p, _p, _i64, _i32, _i64, _i32, _i32, _i32, _i64, _i64, _p, C.POINTER(_i64), _i32]),
+    "nxsig_overlap_and_add_f64": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32]),
+    "nxsig_fir_f64": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _i32, _i32, _p, _i32]),
+    "nxsig_fir_slice_f64": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _i32, _i64, _i64, _p, _i32]),
     "nxsig_timer_lap": (C.c_int, [_p]),
     "nxsig_timer_laps": (C.c_int, [_p, _pf, _i32, C.POINTER(_i32)]),
     # multi-GPU groups

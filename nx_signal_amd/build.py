@@ -36,6 +36,7 @@ UNITS = [
     ("kernels_wave_rows.hip", []),
     ("kernels_wave_fir32.hip", []),
     ("kernels_wave_packed.hip", []),
+    ("kernels_f64.hip", []),  # the f64 / c128 tier (workgroup-per-frame kernels in double)
 ]
 
 

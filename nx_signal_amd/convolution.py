@@ -100,6 +100,29 @@ def _fftconvolve_nd(a, b, mode, ctx):
     return out.reshape(-1)[: int(np.prod(shape))].reshape(shape).copy()
 
 
+def _fftconvolve_f64(a, h, mode, ctx):
+    """f64 tier: real operands of which at least one is f64 — both transforms in c128 (nxsig_fir_f64).  A mixed f32 / f64
+    pair is computed entirely in double (the reference rounds the f32 operand's spectrum to c64 before promoting it: ours is
+    the more accurate of the two, equal within the f32 operand's rounding)."""
+    lib = _lib.load()
+    x = np.ascontiguousarray(a.astype(np.float64))
+    h64 = np.ascontiguousarray(h.astype(np.float64))
+    if x.ndim == 1 and x.shape[0] < h64.shape[0]:
+        if mode == "same":
+            full = _fftconvolve_f64(h64, x, "full", ctx)
+            start = (full.shape[0] - a.shape[0]) // 2
+            return full[start:start + a.shape[0]]
+        x, h64 = h64, x
+    c = ctx or default_context()
+    L = int(x.shape[-1])
+    batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
+    n_out = _lib.check(lib.nxsig_conv_length(L, h64.size, _MODES[mode]))
+    y = np.empty(x.shape[:-1] + (n_out,), dtype=np.float64)
+    _lib.check(lib.nxsig_fir_f64(c.handle, x.ctypes.data_as(C.c_void_p), L, batch, L, h64.ctypes.data_as(C.c_void_p), h64.size,
+                                 _MODES[mode], y.ctypes.data_as(C.c_void_p), _lib.HOST))
+    return y
+
+
 def fftconvolve(in1, in2, ctx=None, **opts):
     """1-D real case of fftconvolve: the longer operand streams through HBM, the shorter one is the FIR kernel.
     in1 may carry leading batch axes (independent channels) when it is the signal."""
@@ -157,7 +180,7 @@ def fftconvolve(in1, in2, ctx=None, **opts):
     if a.ndim != 1 and a.ndim != h.ndim and a.ndim < 1:
         raise ArgumentError("Rank of in1 and in2 must be equal.")
     if a.dtype == np.float64 or h.dtype == np.float64:
-        raise ArgumentError("fftconvolve: float64 is outside this path (f32/c64); cast to float32 explicitly")
+        return _fftconvolve_f64(a, h, mode, ctx)
     x = np.ascontiguousarray(a.astype(np.float32))
     if x.ndim == 1 and x.shape[0] < h32.shape[0]:
         x, h32 = h32, x  # convolution commutes; keep the longer operand as the stream

@@ -268,6 +268,7 @@ struct DeviceGuard {
       for (auto& kv : c->tables) (void)hipFree(kv.second.ptr);
       c->tables.clear();
       c->wave_tables.clear();
+      c->f64_tables.clear();
       c->memo_dev = c->memo_devK = nullptr;
       c->memo.clear();
     }
@@ -1264,6 +1265,258 @@ int nxsig_stft_magnitude_f32(nxsig_ctx* ctx, const float* x, int64_t length, int
   if (mem == NXSIG_DEVICE) return NXSIG_OK;
   return st.out_copy(out, od, obytes);
   NXSIG_API_END
+}
+
+/* ---------------------------------------------------------------- f64 / c128 tier (kernels_f64.hip) */
+int nxsig_window_f64(int32_t kind, int32_t n, int32_t is_periodic, double beta, double eps, double* out) {
+  NXSIG_API_BEGIN
+  return window_f64(kind, n, is_periodic != 0, beta, eps, out);
+  NXSIG_API_END
+}
+
+int nxsig_sinc_f64(const double* t, int64_t n, double* out) {
+  NXSIG_API_BEGIN
+  if (n < 0 || (n > 0 && (!t || !out))) return set_error(NXSIG_ERR_INVALID_ARG, "sinc: bad arguments");
+  sinc_f64(t, n, out);
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_firwin_f64(int32_t num_taps, const double* cutoff, int32_t n_cutoff, int32_t window_kind, double kaiser_beta,
+                     int32_t pass_zero, int32_t scale, double sampling_rate, double* out) {
+  NXSIG_API_BEGIN
+  return firwin_f64(num_taps, cutoff, n_cutoff, window_kind, kaiser_beta, pass_zero != 0, scale != 0, sampling_rate, out);
+  NXSIG_API_END
+}
+
+int nxsig_fft_frequencies_f64(double sampling_rate, int32_t fft_length, int32_t endpoint, double* out) {
+  NXSIG_API_BEGIN
+  if (fft_length < 1 || !out) return set_error(NXSIG_ERR_INVALID_ARG, "fft_frequencies: fft_length must be >= 1");
+  fft_frequencies_f64(sampling_rate, fft_length, endpoint != 0, out);
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+// the caller's window as f64 on the device; `wide` receives the exactly widened host copy of an f32 window
+static int window_dev_f64(Ctx* c, const void* window, int32_t window_is_f64, int N, std::vector<double>& wide, const double** dev) {
+  const double* wh = reinterpret_cast<const double*>(window);
+  if (!window_is_f64) {
+    wide.resize(N);
+    for (int i = 0; i < N; ++i) wide[i] = (double)reinterpret_cast<const float*>(window)[i];
+    wh = wide.data();
+  }
+  const void* d = nullptr;
+  int rc = ctx_table(c, 0x57494E3634ull, wh, (size_t)N * sizeof(double), &d);
+  if (rc) return rc;
+  *dev = reinterpret_cast<const double*>(d);
+  return NXSIG_OK;
+}
+// the scalar of :scaling in the window's own type (Nx.sum(window) / Nx.sqrt(fs * Nx.sum(window ** 2))), widened
+static double scaling_of(const void* window, int32_t window_is_f64, int N, int scaling, double fs) {
+  if (window_is_f64) return scaling_factor_f64(reinterpret_cast<const double*>(window), N, scaling, fs);
+  return (double)scaling_factor(reinterpret_cast<const float*>(window), N, scaling, fs);
+}
+
+int nxsig_stft_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batch, int64_t batch_stride, const void* window,
+                   int32_t window_is_f64, const nxsig_stft_params* p, nxsig_c128* z, int64_t* num_frames_out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!x || !window || !p || !z) return set_error(NXSIG_ERR_INVALID_ARG, "stft: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch must be in [1, 65535]");
+  if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch_stride < length");
+  if (p->fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft: fft_length must be >= 1");
+  if ((rc = check_scaling(p->scaling))) return rc;
+  Framing fr;
+  if ((rc = make_framing(length, p->frame_length, p->hop, p->pad_mode, p->pad_lo, p->pad_hi, &fr))) return rc;
+  if (num_frames_out) *num_frames_out = fr.M;
+  StftLaunchD a;
+  a.fr = fr; a.batch = batch; a.batch_stride = batch_stride; a.K = p->fft_length;
+  a.has_scale = p->scaling != NXSIG_SCALE_NONE;
+  a.div = a.has_scale ? scaling_of(window, window_is_f64, p->frame_length, p->scaling, p->sampling_rate) : 1.0;
+  std::vector<double> wide;
+  if ((rc = window_dev_f64(c, window, window_is_f64, p->frame_length, wide, &a.window))) return rc;
+  const size_t zbytes = (size_t)batch * fr.M * p->fft_length * sizeof(double2);
+  if (mem == NXSIG_DEVICE) {
+    a.x = x; a.z = reinterpret_cast<double2*>(z);
+    return launch_stft_f64(c, a);
+  }
+  Staged st(c);
+  const void* xd = nullptr; void* zd = nullptr;
+  const size_t xbytes = ((size_t)(batch - 1) * batch_stride + length) * sizeof(double);
+  if ((rc = st.in(1, x, xbytes, &xd))) return rc;
+  if ((rc = st.out_alloc(2, zbytes, &zd))) return rc;
+  a.x = reinterpret_cast<const double*>(xd); a.z = reinterpret_cast<double2*>(zd);
+  if ((rc = launch_stft_f64(c, a))) return rc;
+  return st.out_copy(z, zd, zbytes);
+  NXSIG_API_END
+}
+
+int nxsig_istft_c128(nxsig_ctx* ctx, const nxsig_c128* z, int64_t num_frames, int32_t batch, const void* window, int32_t window_is_f64,
+                     const nxsig_stft_params* p, nxsig_c128* y, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!z || !window || !p || !y) return set_error(NXSIG_ERR_INVALID_ARG, "istft: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "istft: batch must be in [1, 65535]");
+  if (num_frames < 1) return set_error(NXSIG_ERR_INVALID_ARG, "istft: num_frames must be >= 1");
+  if ((rc = check_scaling(p->scaling))) return rc;
+  const int N = p->frame_length, hop = p->hop, K = p->fft_length;
+  if (N < 1 || hop < 1) return set_error(NXSIG_ERR_INVALID_ARG, "istft: frame_length and hop must be >= 1");
+  if (hop > N) return set_error(NXSIG_ERR_INVALID_ARG, "overlap_length must be a number less than the window size");
+  if (K != N)
+    return set_error(NXSIG_ERR_INVALID_ARG,
+                     "istft: fft_length must equal the window length (the reference broadcasts {M,K} x {N}, lib/nx_signal.ex:628)");
+  IstftLaunchD a;
+  a.M = num_frames; a.batch = batch; a.N = N; a.hop = hop; a.K = K; a.window_f32 = window_is_f64 ? 0 : 1;
+  a.has_scale = p->scaling != NXSIG_SCALE_NONE;
+  a.scale_mul = a.has_scale ? scaling_of(window, window_is_f64, N, p->scaling, p->sampling_rate) : 1.0;
+  std::vector<double> wide;
+  if ((rc = window_dev_f64(c, window, window_is_f64, N, wide, &a.window))) return rc;
+  const int64_t out_len = num_frames * hop + (N - hop);
+  const size_t zbytes = (size_t)batch * num_frames * K * sizeof(double2), ybytes = (size_t)batch * out_len * sizeof(double2);
+  if (mem == NXSIG_DEVICE) {
+    a.z = reinterpret_cast<const double2*>(z); a.y = reinterpret_cast<double2*>(y);
+    return launch_istft_f64(c, a);
+  }
+  Staged st(c);
+  const void* zd = nullptr; void* yd = nullptr;
+  if ((rc = st.in(1, z, zbytes, &zd))) return rc;
+  if ((rc = st.out_alloc(2, ybytes, &yd))) return rc;
+  a.z = reinterpret_cast<const double2*>(zd); a.y = reinterpret_cast<double2*>(yd);
+  if ((rc = launch_istft_f64(c, a))) return rc;
+  return st.out_copy(y, yd, ybytes);
+  NXSIG_API_END
+}
+
+int nxsig_fft_c128(nxsig_ctx* ctx, const void* in, int32_t in_is_real, int64_t rows, int32_t n_in, int32_t fft_length, int32_t inverse,
+                   nxsig_c128* out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!in || !out) return set_error(NXSIG_ERR_INVALID_ARG, "fft: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (rows < 1 || n_in < 1 || fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fft: rows, n_in and fft_length must be >= 1");
+  const size_t ibytes = (size_t)rows * n_in * (in_is_real ? sizeof(double) : sizeof(double2));
+  const size_t obytes = (size_t)rows * fft_length * sizeof(double2);
+  if (mem == NXSIG_DEVICE) return launch_fft_f64(c, in, in_is_real != 0, rows, n_in, fft_length, inverse != 0, reinterpret_cast<double2*>(out));
+  Staged st(c);
+  const void* id = nullptr; void* od = nullptr;
+  if ((rc = st.in(1, in, ibytes, &id))) return rc;
+  if ((rc = st.out_alloc(2, obytes, &od))) return rc;
+  if ((rc = launch_fft_f64(c, id, in_is_real != 0, rows, n_in, fft_length, inverse != 0, reinterpret_cast<double2*>(od)))) return rc;
+  return st.out_copy(out, od, obytes);
+  NXSIG_API_END
+}
+
+int nxsig_as_windowed_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batch, int64_t batch_stride, int32_t window_length,
+                          int32_t stride, int32_t pad_mode, int64_t pad_lo, int64_t pad_hi, double* out, int64_t* num_frames_out,
+                          int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!x || !out) return set_error(NXSIG_ERR_INVALID_ARG, "as_windowed: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "as_windowed: batch must be in [1, 65535]");
+  if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "as_windowed: batch_stride < length");
+  Framing fr;
+  if ((rc = make_framing(length, window_length, stride, pad_mode, pad_lo, pad_hi, &fr))) return rc;
+  if (num_frames_out) *num_frames_out = fr.M;
+  const size_t obytes = (size_t)batch * fr.M * fr.N * sizeof(double);
+  if (mem == NXSIG_DEVICE) return launch_as_windowed_f64(c, x, batch_stride, batch, fr, out);
+  Staged st(c);
+  const void* xd = nullptr; void* od = nullptr;
+  const size_t xbytes = ((size_t)(batch - 1) * batch_stride + length) * sizeof(double);
+  if ((rc = st.in(1, x, xbytes, &xd))) return rc;
+  if ((rc = st.out_alloc(2, obytes, &od))) return rc;
+  if ((rc = launch_as_windowed_f64(c, reinterpret_cast<const double*>(xd), batch_stride, batch, fr, reinterpret_cast<double*>(od)))) return rc;
+  return st.out_copy(out, od, obytes);
+  NXSIG_API_END
+}
+
+int nxsig_overlap_and_add_f64(nxsig_ctx* ctx, const double* frames, int64_t num_frames, int32_t batch, int32_t frame_length,
+                              int32_t overlap_length, int32_t components, double* out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!frames || !out) return set_error(NXSIG_ERR_INVALID_ARG, "overlap_and_add: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (components != 1 && components != 2) return set_error(NXSIG_ERR_INVALID_ARG, "overlap_and_add: components must be 1 (f64) or 2 (c128)");
+  if (batch < 1 || batch > 65535 || num_frames < 1 || frame_length < 1)
+    return set_error(NXSIG_ERR_INVALID_ARG, "overlap_and_add: batch, num_frames and frame_length must be >= 1");
+  if (overlap_length >= frame_length)
+    return set_error(NXSIG_ERR_INVALID_ARG, "overlap_length must be a number less than the window size " +
+                                                std::to_string(frame_length) + ", got: " + std::to_string(frame_length));
+  if (overlap_length < 0) return set_error(NXSIG_ERR_INVALID_ARG, "overlap_and_add: overlap_length must be >= 0");
+  const int hop = frame_length - overlap_length;
+  const int64_t out_len = num_frames * hop + overlap_length;
+  const size_t ibytes = (size_t)batch * num_frames * frame_length * components * sizeof(double);
+  const size_t obytes = (size_t)batch * out_len * components * sizeof(double);
+  if (mem == NXSIG_DEVICE) return launch_ola_f64(c, frames, num_frames, batch, frame_length, hop, components, nullptr, false, false, out);
+  Staged st(c);
+  const void* fd = nullptr; void* od = nullptr;
+  if ((rc = st.in(1, frames, ibytes, &fd))) return rc;
+  if ((rc = st.out_alloc(2, obytes, &od))) return rc;
+  if ((rc = launch_ola_f64(c, reinterpret_cast<const double*>(fd), num_frames, batch, frame_length, hop, components, nullptr, false, false,
+                           reinterpret_cast<double*>(od)))) return rc;
+  return st.out_copy(out, od, obytes);
+  NXSIG_API_END
+}
+
+static int fir_common_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batch, int64_t batch_stride, const double* h,
+                          int32_t num_taps, int64_t start, int64_t out_len, double* y, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!x || !h || !y) return set_error(NXSIG_ERR_INVALID_ARG, "fir: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535 || length < 1 || num_taps < 1)
+    return set_error(NXSIG_ERR_INVALID_ARG, "fir: batch, length and num_taps must be >= 1");
+  if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "fir: batch_stride < length");
+  if (start < 0 || out_len < 1 || start + out_len > length + num_taps - 1)
+    return set_error(NXSIG_ERR_INVALID_ARG, "fir: requested slice lies outside the full convolution");
+  FirLaunchD a;
+  a.L = length; a.batch = batch; a.batch_stride = batch_stride; a.h_host = h; a.taps = num_taps;
+  a.out_start = start; a.out_len = out_len;
+  const size_t ybytes = (size_t)batch * out_len * sizeof(double);
+  if (mem == NXSIG_DEVICE) {
+    a.x = x; a.y = y;
+    return launch_fir_f64(c, a);
+  }
+  Staged st(c);
+  const void* xd = nullptr; void* yd = nullptr;
+  const size_t xbytes = ((size_t)(batch - 1) * batch_stride + length) * sizeof(double);
+  if ((rc = st.in(1, x, xbytes, &xd))) return rc;
+  if ((rc = st.out_alloc(2, ybytes, &yd))) return rc;
+  a.x = reinterpret_cast<const double*>(xd); a.y = reinterpret_cast<double*>(yd);
+  if ((rc = launch_fir_f64(c, a))) return rc;
+  return st.out_copy(y, yd, ybytes);
+  NXSIG_API_END
+}
+
+int nxsig_fir_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batch, int64_t batch_stride, const double* h,
+                  int32_t num_taps, int32_t mode, double* y, int32_t mem) {
+  if (length < 1 || num_taps < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fir: batch, length and num_taps must be >= 1");
+  const int64_t full = length + num_taps - 1;
+  int64_t out_len, start;
+  switch (mode) {
+    case NXSIG_CONV_FULL: out_len = full; start = 0; break;
+    case NXSIG_CONV_SAME: out_len = length; start = (full - out_len) / 2; break;
+    case NXSIG_CONV_VALID:
+      out_len = (length >= num_taps ? length - num_taps : num_taps - length) + 1;
+      start = (full - out_len) / 2;
+      break;
+    default:
+      return set_error(NXSIG_ERR_INVALID_ARG, "expected mode to be one of [:full, :same, :valid]");
+  }
+  return fir_common_f64(ctx, x, length, batch, batch_stride, h, num_taps, start, out_len, y, mem);
+}
+
+int nxsig_fir_slice_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batch, int64_t batch_stride, const double* h,
+                        int32_t num_taps, int64_t out_start, int64_t out_len, double* y, int32_t mem) {
+  return fir_common_f64(ctx, x, length, batch, batch_stride, h, num_taps, out_start, out_len, y, mem);
 }
 
 }  // extern "C"

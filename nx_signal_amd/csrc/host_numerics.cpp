@@ -18,59 +18,65 @@ namespace nxsig {
 
 static const double kPi = 3.14159265358979323846;
 
-static inline float cos32(float x) { return (float)std::cos((double)x); }
-static inline float sin32(float x) { return (float)std::sin((double)x); }
-static inline float sqrt32(float x) { return (float)std::sqrt((double)x); }
-static inline float exp32(float x) { return (float)std::exp((double)x); }
-static inline float pow32(float x, double p) { return (float)std::pow((double)x, p); }
+// T = float: the f32 generators of the reference's defaults; T = double: `type: {:f, 64}` (every op rounds to double)
+template <typename T> static inline T cosT(T x) { return (T)std::cos((double)x); }
+template <typename T> static inline T sinT(T x) { return (T)std::sin((double)x); }
+template <typename T> static inline T sqrtT(T x) { return (T)std::sqrt((double)x); }
+template <typename T> static inline T expT(T x) { return (T)std::exp((double)x); }
+template <typename T> static inline T powT(T x, double p) { return (T)std::pow((double)x, p); }
 
 // Nx.linspace(start, stop, n:, endpoint:) in f32: iota * step + start
-static void linspace32(float start, float stop, int64_t n, bool endpoint, float* out) {
-  const float div = (float)(endpoint ? n - 1 : n);
-  const float step = (stop - start) / div;
-  for (int64_t i = 0; i < n; ++i) out[i] = (float)i * step + start;
+template <typename T>
+static void linspace32(T start, T stop, int64_t n, bool endpoint, T* out) {
+  const T div = (T)(endpoint ? n - 1 : n);
+  const T step = (stop - start) / div;
+  for (int64_t i = 0; i < n; ++i) out[i] = (T)i * step + start;
 }
 
 // Nx.cos(mult * @pi * n / (l - 1)): `mult * @pi` folds in double, becomes an f32 constant, then
 // (c * n) and the division are each rounded to f32 (windows.ex:185-186, :244, :298).
-static inline float cos_term(float k, double mult, int lm1) {
-  const float c = (float)(mult * kPi);
-  const float ang = (c * k) / (float)lm1;
-  return cos32(ang);
+template <typename T>
+static inline T cos_term(T k, double mult, int lm1) {
+  const T c = (T)(mult * kPi);
+  const T ang = (c * k) / (T)lm1;
+  return cosT<T>(ang);
 }
 
-static void win_bartlett(int n, float* w) {  // windows.ex:57-78
+template <typename T>
+static void win_bartlett(int n, T* w) {  // windows.ex:57-78
   const int n2 = n / 2, left = n2 + n % 2;
-  const float nf = (float)n;
-  for (int i = 0; i < left; ++i) w[i] = ((float)i * 2.0f) / nf;
+  const T nf = (T)n;
+  for (int i = 0; i < left; ++i) w[i] = ((T)i * (T)2.0) / nf;
   for (int i = 0; i < n2; ++i) {
-    const float idx = (float)i + (float)left;
-    w[left + i] = 2.0f - (idx * 2.0f) / nf;
+    const T idx = (T)i + (T)left;
+    w[left + i] = (T)2.0 - (idx * (T)2.0) / nf;
   }
 }
 
-static void win_triangular(int n, float* w) {  // windows.ex:98-126
+template <typename T>
+static void win_triangular(int n, T* w) {  // windows.ex:98-126
   const int h = (n + 1) / 2;
-  std::vector<float> left(h);
+  std::vector<T> left(h);
   if (n % 2 == 1) {
-    for (int i = 0; i < h; ++i) left[i] = (((float)i + 1.0f) * 2.0f) / (float)(n + 1);
+    for (int i = 0; i < h; ++i) left[i] = (((T)i + (T)1.0) * (T)2.0) / (T)(n + 1);
     for (int i = 0; i < h; ++i) w[i] = left[i];
     for (int i = 1; i < h; ++i) w[h + i - 1] = left[h - 1 - i];
   } else {
-    for (int i = 0; i < h; ++i) left[i] = (2.0f * ((float)i + 1.0f) - 1.0f) / (float)n;
+    for (int i = 0; i < h; ++i) left[i] = ((T)2.0 * ((T)i + (T)1.0) - (T)1.0) / (T)n;
     for (int i = 0; i < h; ++i) w[i] = left[i];
     for (int i = 0; i < h; ++i) w[h + i] = left[h - 1 - i];
   }
 }
 
-static void win_blackman(int n, bool periodic, float* w) {  // windows.ex:160-202
+template <typename T>
+static void win_blackman(int n, bool periodic, T* w) {  // windows.ex:160-202
   const int l = periodic ? n + 1 : n;
   const int m = (l + 1) / 2;
-  std::vector<float> left(m), full;
+  std::vector<T> left(m), full;
   for (int i = 0; i < m; ++i) {
-    const float k = (float)i;
-    const float a = 0.42f - 0.5f * cos_term(k, 2.0, l - 1);
-    left[i] = a + 0.08f * cos_term(k, 4.0, l - 1);
+    const T k = (T)i;
+    const T a = (T)0.42 - (T)0.5 * cos_term(k, 2.0, l - 1);
+    left[i] = a + (T)0.08 * cos_term(k, 4.0, l - 1);
   }
   full = left;
   if (l % 2 == 0) {
@@ -81,71 +87,77 @@ static void win_blackman(int n, bool periodic, float* w) {  // windows.ex:160-20
   for (int i = 0; i < n; ++i) w[i] = full[i];  // periodic: drop the last sample
 }
 
-static void win_cosine2(int n, bool periodic, float a0, float a1, bool hann, float* w) {
+template <typename T>
+static void win_cosine2(int n, bool periodic, T a0, T a1, bool hann, T* w) {
   // hamming (windows.ex:225-250): 0.54 - 0.46*cos(.) ; hann (:278-305): 0.5*(1 - cos(.))
   const int l = periodic ? n + 1 : n;
   for (int i = 0; i < n; ++i) {
-    const float c = cos_term((float)i, 2.0, l - 1);
-    w[i] = hann ? 0.5f * (1.0f - c) : a0 - a1 * c;
+    const T c = cos_term((T)i, 2.0, l - 1);
+    w[i] = hann ? (T)0.5 * ((T)1.0 - c) : a0 - a1 * c;
   }
 }
 
-static float kaiser_i0(float x) {  // windows.ex:371-386
-  const float ax = std::fabs(x);
-  if (ax < 3.75f) {
-    float s = 1.0f + pow32(ax, 2) / 4.0f;
-    s = s + pow32(ax, 4) / 64.0f;
-    s = s + pow32(ax, 6) / 2304.0f;
-    s = s + pow32(ax, 8) / 147456.0f;
+template <typename T>
+static T kaiser_i0(T x) {  // windows.ex:371-386
+  const T ax = std::fabs(x);
+  if (ax < (T)3.75) {
+    T s = (T)1.0 + powT<T>(ax, 2) / (T)4.0;
+    s = s + powT<T>(ax, 4) / (T)64.0;
+    s = s + powT<T>(ax, 6) / (T)2304.0;
+    s = s + powT<T>(ax, 8) / (T)147456.0;
     return s;
   }
-  const float two_pi = 2.0f * (float)kPi;
+  const T two_pi = (T)(2.0f * (float)kPi);   // 2 * Nx.Constants.pi(): an f32 tensor whatever the window type
   // The bracket reproduces the reference's kaiser doctests (windows.ex:322-338) bit-for-bit only when
   // evaluated in double and rounded once (empirical; see oracle/nx_oracle.py:_kaiser_i0).
   const double a = (double)ax;
-  const float bracket = (float)(1.0 + 1.0 / (8.0 * a) + 9.0 / (128.0 * a * a));
-  return exp32(ax) / sqrt32(two_pi * ax) * bracket;
+  const T bracket = (T)(1.0 + 1.0 / (8.0 * a) + 9.0 / (128.0 * a * a));
+  return expT<T>(ax) / sqrtT<T>(two_pi * ax) * bracket;
 }
 
-static void win_kaiser(int n, bool periodic, double beta, double eps, float* w) {  // windows.ex:341-369
+template <typename T>
+static void win_kaiser(int n, bool periodic, double beta, double eps, T* w) {  // windows.ex:341-369
   const int wl = periodic ? n + 1 : n;
-  std::vector<float> ratio(wl);
-  linspace32(-1.0f, 1.0f, wl, true, ratio.data());
-  const float den = kaiser_i0((float)beta);
+  std::vector<T> ratio(wl);
+  linspace32(-(T)1.0, (T)1.0, wl, true, ratio.data());
+  const T den = (T)kaiser_i0((float)beta);   // kaiser_bessel_i0(beta) on the NUMBER beta: an f32 tensor (windows.ex:362)
   for (int i = 0; i < n; ++i) {
-    float arg = 1.0f - pow32(ratio[i], 2);
-    arg = std::max(arg, (float)eps);
-    const float r = (float)beta * sqrt32(arg);
+    T arg = (T)1.0 - powT<T>(ratio[i], 2);
+    arg = std::max(arg, (T)eps);
+    const T r = (T)beta * sqrtT<T>(arg);
     w[i] = kaiser_i0(r) / den;
   }
 }
 
-int window_f32(int kind, int n, bool periodic, double beta, double eps, float* out) {
+template <typename T>
+static int window_t(int kind, int n, bool periodic, double beta, double eps, T* out) {
   if (n < 0 || !out) return set_error(NXSIG_ERR_INVALID_ARG, "window: n must be >= 0 and out non-null");
   switch (kind) {
     case NXSIG_WIN_RECTANGULAR:
-      for (int i = 0; i < n; ++i) out[i] = 1.0f;
+      for (int i = 0; i < n; ++i) out[i] = (T)1.0;
       return NXSIG_OK;
     case NXSIG_WIN_BARTLETT: win_bartlett(n, out); return NXSIG_OK;
     case NXSIG_WIN_TRIANGULAR: win_triangular(n, out); return NXSIG_OK;
     case NXSIG_WIN_BLACKMAN: win_blackman(n, periodic, out); return NXSIG_OK;
-    case NXSIG_WIN_HAMMING: win_cosine2(n, periodic, 0.54f, 0.46f, false, out); return NXSIG_OK;
-    case NXSIG_WIN_HANN: win_cosine2(n, periodic, 0.f, 0.f, true, out); return NXSIG_OK;
+    case NXSIG_WIN_HAMMING: win_cosine2(n, periodic, (T)0.54, (T)0.46, false, out); return NXSIG_OK;
+    case NXSIG_WIN_HANN: win_cosine2(n, periodic, (T)0., (T)0., true, out); return NXSIG_OK;
     case NXSIG_WIN_KAISER: win_kaiser(n, periodic, beta, eps, out); return NXSIG_OK;
     default: return set_error(NXSIG_ERR_INVALID_ARG, "unknown window kind " + std::to_string(kind));
   }
 }
 
-void sinc_f32(const float* t, int64_t n, float* out) {  // waveforms.ex:451-457
-  const float pi32 = (float)kPi;
+template <typename T>
+static void sinc_t(const T* t, int64_t n, T* out) {  // waveforms.ex:451-457
+  const T pi32 = (T)(float)kPi;   // pi() of Nx.Constants: f32 whatever the type of t (waveforms.ex:452)
   for (int64_t i = 0; i < n; ++i) {
-    const float x = t[i] * pi32;
-    out[i] = (x == 0.0f) ? 1.0f : sin32(x) / x;
+    const T x = t[i] * pi32;
+    out[i] = (x == (T)0.0) ? (T)1.0 : sinT<T>(x) / x;
   }
 }
 
-int firwin_f32(int num_taps, const double* cutoff, int n_cutoff, int window_kind, double beta, bool pass_zero,
-               bool scale, double sampling_rate, float* out) {  // filters.ex:147-252
+template <typename T>
+static int firwin_t(int num_taps, const double* cutoff, int n_cutoff, int window_kind, double beta, bool pass_zero,
+               bool scale, double sampling_rate, T* out) {  // filters.ex:147-252
   if (num_taps < 1 || n_cutoff < 1 || !cutoff || !out)
     return set_error(NXSIG_ERR_INVALID_ARG, "firwin: num_taps >= 1 and a non-empty cutoff list are required");
   const double nyq = sampling_rate / 2.0;
@@ -171,9 +183,9 @@ int firwin_f32(int num_taps, const double* cutoff, int n_cutoff, int window_kind
       return set_error(NXSIG_ERR_INVALID_ARG,
                        "unknown window, supported: :hamming, :hann, :blackman, :bartlett, :rectangular, {:kaiser, beta}");
   }
-  const float m = (float)((num_taps - 1) / 2.0);
-  std::vector<float> alpha(num_taps), h(num_taps, 0.0f), tmp(num_taps), sa(num_taps), sb(num_taps);
-  for (int i = 0; i < num_taps; ++i) alpha[i] = (float)i - m;
+  const T m = (T)((num_taps - 1) / 2.0);
+  std::vector<T> alpha(num_taps), h(num_taps, (T)0.0), tmp(num_taps), sa(num_taps), sb(num_taps);
+  for (int i = 0; i < num_taps; ++i) alpha[i] = (T)i - m;
   std::vector<double> freqs;
   freqs.push_back(0.0);
   for (double c : cl) freqs.push_back(c);
@@ -181,18 +193,18 @@ int firwin_f32(int num_taps, const double* cutoff, int n_cutoff, int window_kind
   for (size_t i = 0; i + 1 < freqs.size(); ++i) {
     const bool use = pass_zero ? (i % 2 == 0) : (i % 2 == 1);
     if (!use) continue;
-    const float a = (float)freqs[i], b = (float)freqs[i + 1];  // defnp args: floats become f32 tensors
+    const T a = (T)(float)freqs[i], b = (T)(float)freqs[i + 1];  // defnp args: floats become f32 tensors (whatever `type`)
     for (int k = 0; k < num_taps; ++k) tmp[k] = a * alpha[k];
-    sinc_f32(tmp.data(), num_taps, sa.data());
+    sinc_t<T>(tmp.data(), num_taps, sa.data());
     for (int k = 0; k < num_taps; ++k) tmp[k] = b * alpha[k];
-    sinc_f32(tmp.data(), num_taps, sb.data());
+    sinc_t<T>(tmp.data(), num_taps, sb.data());
     for (int k = 0; k < num_taps; ++k) {  // acc + b*sinc(b*alpha) - a*sinc(a*alpha)  (:223-227)
-      const float ca = a * sa[k], cb = b * sb[k];
+      const T ca = a * sa[k], cb = b * sb[k];
       h[k] = (h[k] + cb) - ca;
     }
   }
-  std::vector<float> w(num_taps);
-  int rc = window_f32(window_kind, num_taps, /*periodic=*/false, beta, 1.0e-7, w.data());  // :254-279
+  std::vector<T> w(num_taps);
+  int rc = window_t<T>(window_kind, num_taps, /*periodic=*/false, beta, 1.0e-7, w.data());  // :254-279
   if (rc != NXSIG_OK) return rc;
   for (int k = 0; k < num_taps; ++k) h[k] = h[k] * w[k];
   if (scale) {  // firwin_scale :229-252
@@ -200,20 +212,37 @@ int firwin_f32(int num_taps, const double* cutoff, int n_cutoff, int window_kind
     if (pass_zero) sf = 0.0;
     else if (n_cutoff == 1) sf = 1.0;
     else sf = (cl[0] + cl[1]) / 2.0;
-    const float c = (float)(kPi * sf);
+    const T c = (T)(kPi * sf);
     double acc = 0.0;  // Nx.dot: accumulate in double, round once
-    for (int k = 0; k < num_taps; ++k) acc += (double)h[k] * (double)cos32(alpha[k] * c);
-    const float s = std::fabs((float)acc);
+    for (int k = 0; k < num_taps; ++k) acc += (double)h[k] * (double)cosT<T>(alpha[k] * c);
+    const T s = std::fabs((T)acc);
     for (int k = 0; k < num_taps; ++k) h[k] = h[k] / s;
   }
   std::copy(h.begin(), h.end(), out);
   return NXSIG_OK;
 }
 
-void fft_frequencies_f32(double fs, int K, bool endpoint, float* out) {  // nx_signal.ex:154-166
-  const float step = (float)fs / (float)K;
-  linspace32(0.0f, step * (float)K, K, endpoint, out);
+template <typename T>
+static void fft_frequencies_t(double fs, int K, bool endpoint, T* out) {  // nx_signal.ex:154-166
+  const float step = (float)fs / (float)K;   // sampling_rate enters the defn as an f32 tensor
+  linspace32((T)0.0, (T)(step * (float)K), K, endpoint, out);
 }
+
+int window_f32(int kind, int n, bool periodic, double beta, double eps, float* out) { return window_t<float>(kind, n, periodic, beta, eps, out); }
+int window_f64(int kind, int n, bool periodic, double beta, double eps, double* out) { return window_t<double>(kind, n, periodic, beta, eps, out); }
+void sinc_f32(const float* t, int64_t n, float* out) { sinc_t<float>(t, n, out); }
+void sinc_f64(const double* t, int64_t n, double* out) { sinc_t<double>(t, n, out); }
+int firwin_f32(int num_taps, const double* cutoff, int n_cutoff, int window_kind, double beta, bool pass_zero, bool scale,
+               double sampling_rate, float* out) {
+  return firwin_t<float>(num_taps, cutoff, n_cutoff, window_kind, beta, pass_zero, scale, sampling_rate, out);
+}
+int firwin_f64(int num_taps, const double* cutoff, int n_cutoff, int window_kind, double beta, bool pass_zero, bool scale,
+               double sampling_rate, double* out) {
+  return firwin_t<double>(num_taps, cutoff, n_cutoff, window_kind, beta, pass_zero, scale, sampling_rate, out);
+}
+void fft_frequencies_f32(double fs, int K, bool endpoint, float* out) { fft_frequencies_t<float>(fs, K, endpoint, out); }
+void fft_frequencies_f64(double fs, int K, bool endpoint, double* out) { fft_frequencies_t<double>(fs, K, endpoint, out); }
+
 
 void stft_times_f32(int N, double fs, int64_t M, float* out) {  // nx_signal.ex:108-111
   const float two_fs = 2.0f * (float)fs;
@@ -234,7 +263,7 @@ void mel_filters_f32(int K, int mel_bins, double fs, double max_mel, double f_sp
   for (int i = 0; i < mel_bins + 2; ++i) {
     const float lin = fsp * mels[i];
     const float arg = logstep * (mels[i] - min_log_mel);
-    const float lg = min_log_hz * exp32(arg);
+    const float lg = min_log_hz * expT<float>(arg);
     mel_f[i] = (mels[i] >= min_log_mel) ? lg : lin;
   }
   for (int b = 0; b < mel_bins; ++b) {
@@ -252,6 +281,17 @@ void mel_filters_f32(int K, int mel_bins, double fs, double max_mel, double f_sp
 
 // f32 scalar the spectrum is divided by (stft :116/:119) or multiplied by (istft :614/:617).
 // Nx.sum accumulates in double and rounds once; window ** 2 is an exact f32 product.
+// f64 window: Nx.sum in f64 (sequential double accumulation), sampling_rate an f32 tensor, the square root in double
+double scaling_factor_f64(const double* w, int N, int scaling, double fs) {
+  double acc = 0.0;
+  if (scaling == NXSIG_SCALE_SPECTRUM) {
+    for (int i = 0; i < N; ++i) acc += w[i];
+    return acc;
+  }
+  for (int i = 0; i < N; ++i) acc += w[i] * w[i];
+  return std::sqrt((double)(float)fs * acc);
+}
+
 float scaling_factor(const float* w, int N, int scaling, double fs) {
   double acc = 0.0;
   if (scaling == NXSIG_SCALE_SPECTRUM) {
@@ -261,7 +301,7 @@ float scaling_factor(const float* w, int N, int scaling, double fs) {
   for (int i = 0; i < N; ++i) acc += (double)(w[i] * w[i]);
   const float s2 = (float)acc;
   const float prod = (float)fs * s2;
-  return sqrt32(prod);
+  return sqrtT<float>(prod);
 }
 
 }  // namespace nxsig

@@ -43,6 +43,13 @@ void fft_frequencies_f32(double fs, int K, bool endpoint, float* out);
 void stft_times_f32(int N, double fs, int64_t M, float* out);
 float scaling_factor(const float* w, int N, int scaling, double fs);
 void mel_filters_f32(int K, int mel_bins, double fs, double max_mel, double f_sp, float* out);
+// the same generators evaluated in f64 (`type: {:f, 64}` of the reference: every op rounds to double)
+int window_f64(int kind, int n, bool periodic, double beta, double eps, double* out);
+void sinc_f64(const double* t, int64_t n, double* out);
+int firwin_f64(int num_taps, const double* cutoff, int n_cutoff, int window_kind, double beta, bool pass_zero,
+               bool scale, double sampling_rate, double* out);
+void fft_frequencies_f64(double fs, int K, bool endpoint, double* out);
+double scaling_factor_f64(const double* w, int N, int scaling, double fs);
 
 // ---- framing geometry (as_windowed, lib/nx_signal.ex:257-331) ----
 struct Framing {
@@ -77,10 +84,13 @@ struct Ctx {
   std::map<int, DeviceTable> twiddles;
   // content-addressed small tables (windows, filter spectra ...): key = fnv1a(tag, bytes)
   std::map<uint64_t, DeviceTable> tables;
+  // f64 tier (kernels_f64.hip): device pointers of its twiddle / chirp tables by (kind << 32 | length); the storage belongs to `tables`
+  std::map<int64_t, const void*> f64_tables;
   // scratch buffer reused by multi-stage paths (generic istft, host staging)
   // slots: 0 multi-stage temporaries, 1/2 host staging in/out, 3 wave-kernel dummy sink, 4 fused-path spectrum, 5 reduction cells,
   // 6-9 four-step / Bluestein rows, 10-12 fft_nd ping-pong, 13-15 n-D fftconvolve, 16 long-transform stft frames, 17-19 host staging of n-D calls
-  // 20 istft filter fallback, 21 long FIR, 22 FIR row flags, 23 istft non-finite unit list, 24/25 packed istft fallback
+  // 20 istft filter fallback, 21 long FIR, 22 FIR row flags, 23 istft non-finite unit list, 24/25 packed istft fallback,
+  // 27 frames of the f64 istft
   void* scratch[32] = {};
   size_t scratch_bytes[32] = {};
   // per-K tables of the tuned wave kernels (pass-B / pass-C twiddles), built once
@@ -207,6 +217,46 @@ int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t*
 int launch_fftconvolve_nd(Ctx* c, const void* a, bool a_is_real, const int64_t* s1, const void* b, bool b_is_real, const int64_t* s2,
                           int rank, int mode, void* out, int64_t* out_shape);
 int launch_stft_big(Ctx* c, const StftLaunch& s);
+
+// ---- f64 / c128 tier (kernels_f64.hip) ----
+struct StftLaunchD {
+  const double* x;       // device f64[batch][L], rows batch_stride apart
+  int64_t batch_stride;
+  int32_t batch;
+  Framing fr;
+  int32_t K;
+  const double* window;  // device f64[N]
+  double div;            // the spectrum is DIVIDED by this
+  int32_t has_scale;
+  double2* z;            // device c128[batch][M][K]
+};
+struct IstftLaunchD {
+  const double2* z;      // device c128[batch][M][K]
+  int64_t M;
+  int32_t batch, N, hop, K;
+  const double* window;  // device f64[N]
+  double scale_mul;
+  int32_t has_scale;
+  int32_t window_f32;    // the caller's window was f32: the |w|^2 normaliser is formed with f32 roundings like the reference's
+  double2* y;            // device c128[batch][M*hop + N-hop]
+};
+struct FirLaunchD {
+  const double* x;
+  int64_t L, batch_stride;
+  int32_t batch;
+  const double* h_host;
+  int32_t taps;
+  int64_t out_start, out_len;
+  double* y;
+};
+int launch_stft_f64(Ctx* c, const StftLaunchD& s);
+int launch_istft_f64(Ctx* c, const IstftLaunchD& s);
+int launch_fft_f64(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse, double2* out,
+                   const double* post_window = nullptr, double post_scale = 1.0, bool has_post_scale = false);
+int launch_ola_f64(Ctx* c, const double* frames, int64_t M, int32_t batch, int32_t N, int32_t hop, int32_t comps, const double* window,
+                   bool norm, bool window_f32, double* out);
+int launch_as_windowed_f64(Ctx* c, const double* x, int64_t batch_stride, int32_t batch, const Framing& f, double* out);
+int launch_fir_f64(Ctx* c, const FirLaunchD& s);
 int launch_fftconvolve_c64(Ctx* c, const float2* a, int64_t n1, const float2* b, int64_t n2, int64_t start, int64_t len,
                            float2* out);
 

@@ -34,11 +34,13 @@ def firwin(num_taps, cutoff, **opts):
         raise ArgumentError(
             f"unknown window {win!r}, supported: :hamming, :hann, :blackman, :bartlett, :rectangular, {{:kaiser, beta}}"
         )
-    if o["type"] not in ("f32", np.float32):
-        raise ArgumentError("firwin: only type f32 is built")
+    f64 = o["type"] in ("f64", np.float64)
+    if not f64 and o["type"] not in ("f32", np.float32):
+        raise ArgumentError("firwin: type must be f32 or f64")
     cut = (C.c_double * len(cutoff))(*[float(c) for c in cutoff])
-    out = np.empty(int(num_taps), dtype=np.float32)
-    _lib.check(_lib.load().nxsig_firwin_f32(int(num_taps), cut, len(cutoff), kind, beta, int(bool(o["pass_zero"])),
+    out = np.empty(int(num_taps), dtype=np.float64 if f64 else np.float32)
+    entry = _lib.load().nxsig_firwin_f64 if f64 else _lib.load().nxsig_firwin_f32
+    _lib.check(entry(int(num_taps), cut, len(cutoff), kind, beta, int(bool(o["pass_zero"])),
                                             int(bool(o["scale"])), float(o["sampling_rate"]),
                                             out.ctypes.data_as(C.c_void_p)))
     return out

@@ -32,7 +32,7 @@ def _run(tensor, inverse, opts, ctx):
     else:
         a = np.asarray(tensor)
         if a.dtype in (np.float64, np.complex128):
-            raise ArgumentError("fft_nd: f64/c128 is outside this path; cast to float32/complex64")
+            return _run_f64(a, inverse, axes, lengths, ctx)
         a = np.ascontiguousarray(a.astype(np.complex64 if np.iscomplexobj(a) else np.float32))
         shape, is_real = a.shape, not np.iscomplexobj(a)
         c = ctx or default_context()
@@ -64,6 +64,25 @@ def _run(tensor, inverse, opts, ctx):
     out = np.empty(tuple(out_shape), np.complex64)
     _lib.check(lib.nxsig_fft_nd(c.handle, a.ctypes.data_as(C.c_void_p), int(is_real), sh, rank, axs, lns, len(ax_n), int(inverse),
                                 out.ctypes.data_as(C.c_void_p), _lib.HOST))
+    return out
+
+
+def _run_f64(a, inverse, axes, lengths, ctx):
+    """f64 tier (nxsig_fft_c128): Nx.fft / Nx.ifft in c128 over the LAST axis; other axes are not built in double"""
+    if a.ndim == 0:
+        raise ArgumentError("fft_nd: expected a tensor of rank >= 1")
+    if len(axes) != 1 or int(axes[0]) % a.ndim != a.ndim - 1:
+        raise _lib.NxSignalUnsupported("fft_nd: f64 / c128 tensors are transformed over the last axis only")
+    a = np.ascontiguousarray(a)
+    n_in = int(a.shape[-1])
+    K = int(lengths[0]) if lengths[0] is not None else n_in
+    if K < 1:
+        raise ArgumentError("fft_nd: lengths must be positive")
+    rows = int(np.prod(a.shape[:-1], dtype=np.int64)) if a.ndim > 1 else 1
+    c = ctx or default_context()
+    out = np.empty(a.shape[:-1] + (K,), np.complex128)
+    _lib.check(_lib.load().nxsig_fft_c128(c.handle, a.ctypes.data_as(C.c_void_p), int(a.dtype == np.float64), rows, n_in, K, int(inverse),
+                                          out.ctypes.data_as(C.c_void_p), _lib.HOST))
     return out
 
 

@@ -17,19 +17,25 @@ def _validate(opts, allowed, fn):
     return out
 
 
-def _gen(kind, n, periodic=True, beta=0.0, eps=1.0e-7):
+def _is_f64(t):
+    return t in ("f64", np.float64) or (not isinstance(t, str) and t is not None and np.dtype(t) == np.float64)
+
+
+def _gen(kind, n, periodic=True, beta=0.0, eps=1.0e-7, t=None):
+    """t = f64: the generator evaluated in double (`type: {:f, 64}`), else f32"""
     if not isinstance(n, (int, np.integer)):
         raise ArgumentError(f"window length must be an integer, got: {n!r}")
+    if _is_f64(t):
+        out = np.empty(int(n), dtype=np.float64)
+        _lib.check(_lib.load().nxsig_window_f64(kind, int(n), int(bool(periodic)), float(beta), float(eps),
+                                                out.ctypes.data_as(_lib.C.c_void_p)))
+        return out
+    if t not in (None, "f32", np.float32):
+        raise ArgumentError(f"window type must be f32 or f64 (got {t!r})")
     out = np.empty(int(n), dtype=np.float32)
     _lib.check(_lib.load().nxsig_window_f32(kind, int(n), int(bool(periodic)), float(beta), float(eps),
                                             out.ctypes.data_as(_lib.C.c_void_p)))
     return out
-
-
-def _typed(w, t):
-    if t in (None, "f32", np.float32):
-        return w
-    raise ArgumentError(f"only type f32 is built for this window (got {t!r})")
 
 
 def rectangular(n, **opts):
@@ -46,34 +52,34 @@ def rectangular(n, **opts):
 def bartlett(n, **opts):
     """windows.ex:57-78 — rejects :name (quirk B11)."""
     o = _validate(opts, {"type": "f32"}, "bartlett")
-    return _typed(_gen(_lib.WIN_BARTLETT, n), o["type"])
+    return _gen(_lib.WIN_BARTLETT, n, t=o["type"])
 
 
 def triangular(n, **opts):
     """windows.ex:98-126."""
     o = _validate(opts, {"name": None, "type": "f32"}, "triangular")
-    return _typed(_gen(_lib.WIN_TRIANGULAR, n), o["type"])
+    return _gen(_lib.WIN_TRIANGULAR, n, t=o["type"])
 
 
 def blackman(n, **opts):
     """windows.ex:160-202."""
     o = _validate(opts, {"name": None, "is_periodic": True, "type": "f32"}, "blackman")
-    return _typed(_gen(_lib.WIN_BLACKMAN, n, o["is_periodic"]), o["type"])
+    return _gen(_lib.WIN_BLACKMAN, n, o["is_periodic"], t=o["type"])
 
 
 def hamming(n, **opts):
     """windows.ex:225-250."""
     o = _validate(opts, {"name": None, "is_periodic": True, "type": "f32"}, "hamming")
-    return _typed(_gen(_lib.WIN_HAMMING, n, o["is_periodic"]), o["type"])
+    return _gen(_lib.WIN_HAMMING, n, o["is_periodic"], t=o["type"])
 
 
 def hann(n, **opts):
     """windows.ex:278-305."""
     o = _validate(opts, {"name": None, "is_periodic": True, "type": "f32"}, "hann")
-    return _typed(_gen(_lib.WIN_HANN, n, o["is_periodic"]), o["type"])
+    return _gen(_lib.WIN_HANN, n, o["is_periodic"], t=o["type"])
 
 
 def kaiser(n, **opts):
     """windows.ex:341-369."""
     o = _validate(opts, {"name": None, "eps": 1.0e-7, "beta": 12.0, "is_periodic": True, "type": "f32"}, "kaiser")
-    return _typed(_gen(_lib.WIN_KAISER, n, o["is_periodic"], o["beta"], o["eps"]), o["type"])
+    return _gen(_lib.WIN_KAISER, n, o["is_periodic"], o["beta"], o["eps"], t=o["type"])

@@ -145,7 +145,9 @@ def test_option_validation_raises_argument_error_without_gpu():
         S.stft(x, w, window_padding="zeros")  # documented but raises (B2)
     with pytest.raises(S.ArgumentError, match="unknown keys"):
         S.stft(x, w, hop_length=2)
-    with pytest.raises(S.ArgumentError, match="float64"):
+    with pytest.raises(S.ArgumentError, match="f32 extensions"):   # float64 samples belong to the f64 tier (full c128 spectrum only)
+        S.stft_onesided(np.zeros(16), w)
+    with pytest.raises(S.NxSignalDeviceError):   # ... which computes on the GPU like everything else: no CPU fallback
         S.stft(np.zeros(16), w)
     with pytest.raises(S.ArgumentError, match="invalid :scaling"):
         S.istft(np.zeros((3, 4), np.complex64), w, scaling="power")

@@ -66,13 +66,23 @@ defmodule NxSignalAMD do
     {flat, vec_axes} = devectorize(data)
     {batch_shape, length} = split_last(Nx.shape(flat))
     batch = Tuple.product(batch_shape)
-    x = flat |> Nx.as_type(:f32) |> Nx.to_binary()
-    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
-    {:ok, z, m, t, f} = NIF.stft(context(), x, length, batch, w, params) |> unwrap!()
+    # f64 samples or an f64 window: Nx.multiply promotes and Nx.fft returns c128 (lib/nx_signal.ex:101-102) -> the f64 tier
+    wide = Nx.type(data) == {:f, 64} or Nx.type(window) == {:f, 64}
+
+    {:ok, z, m, t, f} =
+      if wide do
+        {w, w64} = window_binary(window)
+        NIF.stft_f64(context(), flat |> Nx.as_type(:f64) |> Nx.to_binary(), length, batch, w, w64, params)
+      else
+        x = flat |> Nx.as_type(:f32) |> Nx.to_binary()
+        NIF.stft(context(), x, length, batch, window |> Nx.as_type(:f32) |> Nx.to_binary(), params)
+      end
+      |> unwrap!()
+
     names = List.duplicate(nil, tuple_size(batch_shape)) ++ [:frames, :frequencies]
 
     z =
-      Nx.from_binary(z, :c64)
+      Nx.from_binary(z, if(wide, do: :c128, else: :c64))
       |> Nx.reshape(append(batch_shape, [m, fft_length]), names: names)
       |> revectorize(vec_axes)
 
@@ -161,11 +171,34 @@ defmodule NxSignalAMD do
   def istft(%Nx.Tensor{} = data, window, opts) do
     {flat, vec_axes} = devectorize(data)
     {params, _overlap, m, batch_shape} = istft_params!(Nx.shape(flat), window, opts)
-    z = flat |> Nx.as_type(:c64) |> Nx.to_binary()
-    w = window |> Nx.as_type(:f32) |> Nx.to_binary()
-    {:ok, y} = NIF.istft(context(), z, m, Tuple.product(batch_shape), w, params) |> unwrap!()
     out_len = m * elem(params, 1) + (elem(params, 0) - elem(params, 1))
-    Nx.from_binary(y, :c64) |> Nx.reshape(append(batch_shape, [out_len])) |> revectorize(vec_axes)
+
+    cond do
+      Nx.type(data) in [{:c, 128}, {:f, 64}] ->
+        # a c128 spectrum is inverted in c128 (Nx.ifft, lib/nx_signal.ex:609): the f64 tier
+        {w, w64} = window_binary(window)
+        z = flat |> Nx.as_type(:c128) |> Nx.to_binary()
+        {:ok, y} = NIF.istft_c128(context(), z, m, Tuple.product(batch_shape), w, w64, params) |> unwrap!()
+        Nx.from_binary(y, :c128) |> Nx.reshape(append(batch_shape, [out_len])) |> revectorize(vec_axes)
+
+      Nx.type(window) == {:f, 64} ->
+        # the reference would invert in c64 and only then promote the frames: that mix is not modelled
+        raise ArgumentError, "istft: a c64 spectrum with an f64 window is not built; pass the spectrum as c128"
+
+      true ->
+        z = flat |> Nx.as_type(:c64) |> Nx.to_binary()
+        w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+        {:ok, y} = NIF.istft(context(), z, m, Tuple.product(batch_shape), w, params) |> unwrap!()
+        Nx.from_binary(y, :c64) |> Nx.reshape(append(batch_shape, [out_len])) |> revectorize(vec_axes)
+    end
+  end
+
+  # the window as the binary the f64 tier takes: f64 when the tensor is, else f32 (the :scaling scalar and the |w|^2
+  # normaliser are formed in the window's own type, include/nxsig.h)
+  defp window_binary(window) do
+    if Nx.type(window) == {:f, 64},
+      do: {Nx.to_binary(window), 1},
+      else: {window |> Nx.as_type(:f32) |> Nx.to_binary(), 0}
   end
 
   @doc """
@@ -222,6 +255,23 @@ defmodule NxSignalAMD do
     {pad_mode, lo, hi} = padding!(opts[:padding])
     {flat, vec_axes} = devectorize(tensor)
     {batch_shape, length} = split_last(Nx.shape(flat))
+
+    if Nx.type(tensor) == {:f, 64} do
+      as_windowed_f64(flat, vec_axes, batch_shape, length, window_length, stride, pad_mode, lo, hi)
+    else
+      as_windowed_words32(tensor, flat, vec_axes, batch_shape, length, window_length, stride, pad_mode, lo, hi)
+    end
+  end
+
+  defp as_windowed_f64(flat, vec_axes, batch_shape, length, window_length, stride, pad_mode, lo, hi) do
+    {:ok, frames, m} =
+      NIF.as_windowed_f64(context(), Nx.to_binary(flat), length, Tuple.product(batch_shape), window_length, stride, pad_mode, lo, hi)
+      |> unwrap!()
+
+    Nx.from_binary(frames, :f64) |> Nx.reshape(append(batch_shape, [m, window_length])) |> revectorize(vec_axes)
+  end
+
+  defp as_windowed_words32(tensor, flat, vec_axes, batch_shape, length, window_length, stride, pad_mode, lo, hi) do
     # a pure gather: 32-bit words travel untouched (bit-exact for f32 / s32 / u32); other integer types go through s32 when
     # every value fits, so that no integer is ever rounded through f32
     {words, word_type} = to_words32(flat)
@@ -268,16 +318,17 @@ defmodule NxSignalAMD do
     {m, n} = {elem(shape, rank - 2), elem(shape, rank - 1)}
     batch_shape = shape |> Tuple.delete_at(rank - 1) |> Tuple.delete_at(rank - 2)
 
-    {bin_type, components} =
-      case Nx.Type.normalize!(opts[:type]) do
-        {:c, _} -> {:c64, 2}
-        _ -> {:f32, 1}
+    # f64 / c128 tensors are added in double by the f64 tier; everything else through f32 / c64
+    {bin_type, components, nif} =
+      case {Nx.type(tensor), Nx.Type.normalize!(opts[:type])} do
+        {{:c, 128}, _} -> {:c128, 2, &NIF.overlap_and_add_f64/7}
+        {{:f, 64}, _} -> {:f64, 1, &NIF.overlap_and_add_f64/7}
+        {_, {:c, _}} -> {:c64, 2, &NIF.overlap_and_add/7}
+        _ -> {:f32, 1, &NIF.overlap_and_add/7}
       end
 
     frames = flat |> Nx.as_type(bin_type) |> Nx.to_binary()
-
-    {:ok, out} =
-      NIF.overlap_and_add(context(), frames, m, Tuple.product(batch_shape), n, overlap_length, components) |> unwrap!()
+    {:ok, out} = nif.(context(), frames, m, Tuple.product(batch_shape), n, overlap_length, components) |> unwrap!()
 
     out_len = m * (n - overlap_length) + overlap_length
 
@@ -291,8 +342,15 @@ defmodule NxSignalAMD do
   def fft_frequencies(sampling_rate, opts \\ []) do
     opts = Keyword.validate!(opts, [:fft_length, :name, type: {:f, 32}, endpoint: false])
     fft_length = opts[:fft_length] || raise ArgumentError, "missing :fft_length option"
-    {:ok, bin} = NIF.fft_frequencies(sampling_rate * 1.0, fft_length, if(opts[:endpoint], do: 1, else: 0)) |> unwrap!()
-    Nx.from_binary(bin, :f32) |> Nx.reshape({fft_length}, names: [opts[:name]]) |> Nx.as_type(opts[:type])
+    endpoint = if(opts[:endpoint], do: 1, else: 0)
+
+    if Nx.Type.normalize!(opts[:type]) == {:f, 64} do
+      {:ok, bin} = NIF.fft_frequencies_f64(sampling_rate * 1.0, fft_length, endpoint) |> unwrap!()
+      Nx.from_binary(bin, :f64) |> Nx.reshape({fft_length}, names: [opts[:name]])
+    else
+      {:ok, bin} = NIF.fft_frequencies(sampling_rate * 1.0, fft_length, endpoint) |> unwrap!()
+      Nx.from_binary(bin, :f32) |> Nx.reshape({fft_length}, names: [opts[:name]]) |> Nx.as_type(opts[:type])
+    end
   end
 
   @doc "See `NxSignal.mel_filters/4` (lib/nx_signal.ex:397-445): `f32[mels: mel_bins][frequencies: fft_length]`."

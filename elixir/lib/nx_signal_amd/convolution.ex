@@ -67,11 +67,15 @@ defmodule NxSignalAMD.Convolution do
         # the streaming case: overlap-save FIR, `in1` may carry leading batch axes
         {batch_shape, length} = NxSignalAMD.split_last(Nx.shape(in1))
         batch = Tuple.product(batch_shape)
-        x = in1 |> Nx.as_type(:f32) |> Nx.to_binary()
-        h = in2 |> Nx.as_type(:f32) |> Nx.to_binary()
-        {:ok, y} = NIF.fir(ctx, x, length, batch, h, mode) |> NxSignalAMD.unwrap!()
-        n_out = div(byte_size(y), 4 * max(batch, 1))
-        Nx.from_binary(y, :f32) |> Nx.reshape(Tuple.insert_at(batch_shape, tuple_size(batch_shape), n_out))
+        # f64 operands: both transforms in c128 (the f64 tier); a mixed pair is computed entirely in double
+        {type, nif, es} =
+          if Nx.type(in1) == {:f, 64} or Nx.type(in2) == {:f, 64}, do: {:f64, &NIF.fir_f64/6, 8}, else: {:f32, &NIF.fir/6, 4}
+
+        x = in1 |> Nx.as_type(type) |> Nx.to_binary()
+        h = in2 |> Nx.as_type(type) |> Nx.to_binary()
+        {:ok, y} = nif.(ctx, x, length, batch, h, mode) |> NxSignalAMD.unwrap!()
+        n_out = div(byte_size(y), es * max(batch, 1))
+        Nx.from_binary(y, type) |> Nx.reshape(Tuple.insert_at(batch_shape, tuple_size(batch_shape), n_out))
 
       Nx.rank(in1) != Nx.rank(in2) ->
         raise ArgumentError, "Rank of in1 and in2 must be equal."

@@ -23,11 +23,20 @@ defmodule NxSignalAMD.Filters do
         w -> raise ArgumentError, "unknown window #{inspect(w)}, supported: :hamming, :hann, :blackman, :bartlett, :rectangular, {:kaiser, beta}"
       end
 
-    {:ok, bin} =
-      NIF.firwin(num_taps, Enum.map(cutoff, &(&1 * 1.0)), kind, beta, b(opts[:pass_zero]), b(opts[:scale]), opts[:sampling_rate] * 1.0)
-      |> NxSignalAMD.unwrap!()
+    args = [num_taps, Enum.map(cutoff, &(&1 * 1.0)), kind, beta, b(opts[:pass_zero]), b(opts[:scale]), opts[:sampling_rate] * 1.0]
 
-    Nx.from_binary(bin, :f32)
+    case Nx.Type.normalize!(opts[:type]) do
+      {:f, 64} ->
+        {:ok, bin} = apply(NIF, :firwin_f64, args) |> NxSignalAMD.unwrap!()
+        Nx.from_binary(bin, :f64)
+
+      {:f, 32} ->
+        {:ok, bin} = apply(NIF, :firwin, args) |> NxSignalAMD.unwrap!()
+        Nx.from_binary(bin, :f32)
+
+      other ->
+        raise ArgumentError, "firwin: type must be {:f, 32} or {:f, 64}, got: #{inspect(other)}"
+    end
   end
 
   def fir(x, taps, opts \\ [])
@@ -62,11 +71,15 @@ defmodule NxSignalAMD.Filters do
     r = tuple_size(shape)
     length = elem(shape, r - 1)
     batch_shape = Tuple.delete_at(shape, r - 1)
-    xb = x |> Nx.as_type(:f32) |> Nx.to_binary()
-    hb = taps |> Nx.as_type(:f32) |> Nx.to_binary()
-    {:ok, y} = NIF.fir(NxSignalAMD.context(), xb, length, Tuple.product(batch_shape), hb, @modes[opts[:mode]]) |> NxSignalAMD.unwrap!()
-    n_out = div(byte_size(y), 4 * max(Tuple.product(batch_shape), 1))
-    Nx.from_binary(y, :f32) |> Nx.reshape(Tuple.insert_at(batch_shape, r - 1, n_out))
+    # f64 operands are transformed in c128 by the reference (convolution.ex:276-284): the f64 tier
+    {type, nif, es} =
+      if Nx.type(x) == {:f, 64} or Nx.type(taps) == {:f, 64}, do: {:f64, &NIF.fir_f64/6, 8}, else: {:f32, &NIF.fir/6, 4}
+
+    xb = x |> Nx.as_type(type) |> Nx.to_binary()
+    hb = taps |> Nx.as_type(type) |> Nx.to_binary()
+    {:ok, y} = nif.(NxSignalAMD.context(), xb, length, Tuple.product(batch_shape), hb, @modes[opts[:mode]]) |> NxSignalAMD.unwrap!()
+    n_out = div(byte_size(y), es * max(Tuple.product(batch_shape), 1))
+    Nx.from_binary(y, type) |> Nx.reshape(Tuple.insert_at(batch_shape, r - 1, n_out))
   end
 
   defp b(true), do: 1

@@ -84,4 +84,20 @@ defmodule NxSignalAMD.NIF do
 
   def stft_mel_sharded_dev(_group, _x_bufs, _length, _batch, _window, _params, _mel_bins, _filters, _axis),
     do: :erlang.nif_error(:nif_not_loaded)
+
+  # f64 / c128 tier (include/nxsig.h): the reference computes in the type of its operands
+  def window_f64(_kind, _n, _periodic, _beta, _eps), do: :erlang.nif_error(:nif_not_loaded)
+  def firwin_f64(_taps, _cutoff, _kind, _beta, _pass_zero, _scale, _fs), do: :erlang.nif_error(:nif_not_loaded)
+  def fft_frequencies_f64(_fs, _fft_length, _endpoint), do: :erlang.nif_error(:nif_not_loaded)
+  def sinc_f64(_t), do: :erlang.nif_error(:nif_not_loaded)
+  def stft_f64(_ctx, _x, _length, _batch, _window, _window_is_f64, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def istft_c128(_ctx, _z, _frames, _batch, _window, _window_is_f64, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def fir_f64(_ctx, _x, _length, _batch, _taps, _mode), do: :erlang.nif_error(:nif_not_loaded)
+  def fft_c128(_ctx, _in, _is_real, _rows, _n_in, _fft_length, _inverse), do: :erlang.nif_error(:nif_not_loaded)
+
+  def as_windowed_f64(_ctx, _x, _length, _batch, _window_length, _stride, _pad_mode, _lo, _hi),
+    do: :erlang.nif_error(:nif_not_loaded)
+
+  def overlap_and_add_f64(_ctx, _frames, _num_frames, _batch, _frame_length, _overlap, _components),
+    do: :erlang.nif_error(:nif_not_loaded)
 end

@@ -17,11 +17,34 @@ defmodule NxSignalAMD.Transforms do
     axes_n = Enum.map(axes, fn ax -> if ax < 0, do: ax + rank, else: ax end)
     lengths = (opts[:lengths] || List.duplicate(nil, length(axes))) |> Enum.zip(axes_n) |> Enum.map(fn {l, ax} -> l || Enum.at(shape, ax) end)
 
+    if Nx.type(tensor) in [{:f, 64}, {:c, 128}] do
+      run_f64(tensor, shape, rank, axes_n, lengths, inverse)
+    else
+      run_f32(tensor, shape, axes_n, lengths, inverse)
+    end
+  end
+
+  # f64 / c128 tensors: Nx.fft / Nx.ifft in c128 over the LAST axis (the f64 tier, include/nxsig.h); other axes are not built in double
+  defp run_f64(tensor, shape, rank, axes_n, lengths, inverse) do
+    if axes_n != [rank - 1] do
+      raise ArgumentError, "fft_nd: f64 / c128 tensors are transformed over the last axis only"
+    end
+
+    [k] = lengths
+    n_in = List.last(shape)
+    rows = div(Enum.product(shape), n_in)
+    is_real = if Nx.type(tensor) == {:f, 64}, do: 1, else: 0
+
+    {:ok, out} =
+      NIF.fft_c128(NxSignalAMD.context(), Nx.to_binary(tensor), is_real, rows, n_in, k, inverse) |> NxSignalAMD.unwrap!()
+
+    Nx.from_binary(out, :c128) |> Nx.reshape(shape |> List.replace_at(rank - 1, k) |> List.to_tuple())
+  end
+
+  defp run_f32(tensor, shape, axes_n, lengths, inverse) do
     {bin, is_real} =
       case Nx.type(tensor) do
         {:c, 64} -> {Nx.to_binary(tensor), 0}
-        {:c, _} -> raise ArgumentError, "only c64 complex tensors are supported"
-        {:f, 64} -> raise ArgumentError, "f64 tensors are not supported by the MI355X path"
         _ -> {tensor |> Nx.as_type(:f32) |> Nx.to_binary(), 1}
       end
 

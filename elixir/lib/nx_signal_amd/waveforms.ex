@@ -6,7 +6,12 @@ defmodule NxSignalAMD.Waveforms do
   """
   alias NxSignalAMD.NIF
 
-  @doc "See `NxSignal.Waveforms.sinc/1`. Returns an f32 tensor of the input's shape."
+  @doc "See `NxSignal.Waveforms.sinc/1`. Returns an f32 tensor of the input's shape (f64 for an f64 tensor)."
+  def sinc(%Nx.Tensor{type: {:f, 64}} = t) do
+    {:ok, out} = NIF.sinc_f64(Nx.to_binary(t)) |> NxSignalAMD.unwrap!()
+    Nx.from_binary(out, :f64) |> Nx.reshape(Nx.shape(t))
+  end
+
   def sinc(%Nx.Tensor{} = t) do
     shape = Nx.shape(t)
     {:ok, out} = NIF.sinc(t |> Nx.as_type(:f32) |> Nx.to_binary()) |> NxSignalAMD.unwrap!()

@@ -387,6 +387,197 @@ static ERL_NIF_TERM nif_fft(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[])
   return mk_ok(env, enif_make_binary(env, &ob));
 }
 
+/* ------------------------------------------------------------------------------------------------ f64 / c128 tier
+ * The reference computes in the type of its operands (include/nxsig.h "f64 / c128 tier"): f64 / c128 binaries in, the same out. */
+/* window_f64(kind, n, periodic, beta, eps) -> {:ok, f64 binary}   (NxSignal.Windows.*(n, type: {:f, 64})) */
+static ERL_NIF_TERM nif_window_f64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  int kind, n, per;
+  double beta, eps;
+  if (argc != 5 || !enif_get_int(env, argv[0], &kind) || !enif_get_int(env, argv[1], &n) || !enif_get_int(env, argv[2], &per) ||
+      !get_number(env, argv[3], &beta) || !get_number(env, argv[4], &eps) || n < 0)
+    return enif_make_badarg(env);
+  ErlNifBinary b;
+  if (!out_bin(&b, (uint64_t)n, 1, 1, 8)) return mk_oom(env);
+  int rc = nxsig_window_f64(kind, n, per, beta, eps, (double*)b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &b));
+}
+
+/* firwin_f64(num_taps, [cutoff], window_kind, beta, pass_zero, scale, sampling_rate) -> {:ok, f64 binary} */
+static ERL_NIF_TERM nif_firwin_f64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  int taps, kind, pz, sc;
+  double beta, fs, cut[64];
+  unsigned len;
+  if (argc != 7 || !enif_get_int(env, argv[0], &taps) || !enif_get_list_length(env, argv[1], &len) || len > 64 ||
+      !enif_get_int(env, argv[2], &kind) || !get_number(env, argv[3], &beta) || !enif_get_int(env, argv[4], &pz) ||
+      !enif_get_int(env, argv[5], &sc) || !get_number(env, argv[6], &fs) || taps < 1)
+    return enif_make_badarg(env);
+  ERL_NIF_TERM head, tail = argv[1];
+  for (unsigned i = 0; i < len; ++i)
+    if (!enif_get_list_cell(env, tail, &head, &tail) || !get_number(env, head, &cut[i])) return enif_make_badarg(env);
+  ErlNifBinary b;
+  if (!out_bin(&b, (uint64_t)taps, 1, 1, 8)) return mk_oom(env);
+  int rc = nxsig_firwin_f64(taps, cut, (int)len, kind, beta, pz, sc, fs, (double*)b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &b));
+}
+
+/* fft_frequencies_f64(sampling_rate, fft_length, endpoint) -> {:ok, f64 binary} */
+static ERL_NIF_TERM nif_fft_frequencies_f64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  double fs;
+  int k, endpoint;
+  if (argc != 3 || !get_number(env, argv[0], &fs) || !enif_get_int(env, argv[1], &k) || !enif_get_int(env, argv[2], &endpoint) || k < 1)
+    return enif_make_badarg(env);
+  ErlNifBinary b;
+  if (!out_bin(&b, (uint64_t)k, 1, 1, 8)) return mk_oom(env);
+  int rc = nxsig_fft_frequencies_f64(fs, k, endpoint, (double*)b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &b));
+}
+
+/* sinc_f64(t_bin) -> {:ok, f64 binary} */
+static ERL_NIF_TERM nif_sinc_f64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ErlNifBinary t, b;
+  if (argc != 1 || !enif_inspect_binary(env, argv[0], &t) || t.size % 8) return enif_make_badarg(env);
+  if (!out_bin(&b, t.size / 8, 1, 1, 8)) return mk_oom(env);
+  int rc = nxsig_sinc_f64((const double*)t.data, (int64_t)(t.size / 8), (double*)b.data);
+  if (rc) { enif_release_binary(&b); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &b));
+}
+
+/* stft_f64(ctx, x_bin (f64), length, batch, window_bin, window_is_f64, params) -> {:ok, z_bin (c128), num_frames, times_bin, freqs_bin}
+ * times / frequencies stay f32 like the reference's (lib/nx_signal.ex:106-111) */
+static ERL_NIF_TERM nif_stft_f64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary x, w, zb, tb, fb;
+  ErlNifSInt64 length;
+  int batch, wf64;
+  nxsig_stft_params p;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !enif_get_int(env, argv[5], &wf64) ||
+      !get_params(env, argv[6], &p))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || x.size % 8 || x.size / 8 / (size_t)batch != (size_t)length ||
+      w.size != (size_t)p.frame_length * (wf64 ? 8 : 4))
+    return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
+  if (m < 0) return mk_error(env, (int)m);
+  if (!out_bin(&zb, (uint64_t)batch, (uint64_t)m, (uint64_t)p.fft_length, 16)) return mk_oom(env);
+  int rc = nxsig_stft_f64(c->ctx, (const double*)x.data, length, batch, length, w.data, wf64, &p, (nxsig_c128*)zb.data, NULL, NXSIG_HOST);
+  if (rc) { enif_release_binary(&zb); return mk_error(env, rc); }
+  if (!out_bin(&tb, (uint64_t)m, 1, 1, 4)) { enif_release_binary(&zb); return mk_oom(env); }
+  if (!out_bin(&fb, (uint64_t)p.fft_length, 1, 1, 4)) { enif_release_binary(&zb); enif_release_binary(&tb); return mk_oom(env); }
+  if ((rc = nxsig_stft_times_f32(p.frame_length, p.sampling_rate, m, (float*)tb.data)) ||
+      (rc = nxsig_fft_frequencies_f32(p.sampling_rate, p.fft_length, 0, (float*)fb.data))) {
+    enif_release_binary(&zb); enif_release_binary(&tb); enif_release_binary(&fb);
+    return mk_error(env, rc);
+  }
+  return enif_make_tuple5(env, mk_atom(env, "ok"), enif_make_binary(env, &zb), enif_make_int64(env, m), enif_make_binary(env, &tb),
+                          enif_make_binary(env, &fb));
+}
+
+/* istft_c128(ctx, z_bin (c128), num_frames, batch, window_bin, window_is_f64, params) -> {:ok, y_bin (c128)} */
+static ERL_NIF_TERM nif_istft_c128(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary z, w, yb;
+  ErlNifSInt64 m;
+  int batch, wf64;
+  nxsig_stft_params p;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &z) || !enif_get_int64(env, argv[2], &m) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !enif_get_int(env, argv[5], &wf64) ||
+      !get_params(env, argv[6], &p))
+    return enif_make_badarg(env);
+  if (batch < 1 || m < 1 || z.size % 16 || z.size / 16 / (size_t)batch / (size_t)m != (size_t)p.fft_length ||
+      z.size / 16 % ((size_t)batch * (size_t)m) || w.size != (size_t)p.frame_length * (wf64 ? 8 : 4))
+    return enif_make_badarg(env);
+  int64_t n = nxsig_ola_length(m, p.frame_length, p.hop);
+  if (n < 0) return mk_error(env, (int)n);
+  if (!out_bin(&yb, (uint64_t)batch, (uint64_t)n, 1, 16)) return mk_oom(env);
+  int rc = nxsig_istft_c128(c->ctx, (const nxsig_c128*)z.data, m, batch, w.data, wf64, &p, (nxsig_c128*)yb.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&yb); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &yb));
+}
+
+/* fir_f64(ctx, x_bin (f64), length, batch, taps_bin (f64), mode) -> {:ok, y_bin (f64)} */
+static ERL_NIF_TERM nif_fir_f64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary x, h, yb;
+  ErlNifSInt64 length;
+  int batch, mode;
+  if (argc != 6 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &h) || !enif_get_int(env, argv[5], &mode))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || x.size % 8 || x.size / 8 / (size_t)batch != (size_t)length || h.size < 8 || h.size % 8 ||
+      h.size / 8 > 0x7fffffff)
+    return enif_make_badarg(env);
+  int64_t n = nxsig_conv_length(length, (int64_t)(h.size / 8), mode);
+  if (n < 0) return mk_error(env, (int)n);
+  if (!out_bin(&yb, (uint64_t)batch, (uint64_t)n, 1, 8)) return mk_oom(env);
+  int rc = nxsig_fir_f64(c->ctx, (const double*)x.data, length, batch, length, (const double*)h.data, (int)(h.size / 8), mode,
+                         (double*)yb.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&yb); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &yb));
+}
+
+/* fft_c128(ctx, in_bin, in_is_real, rows, n_in, fft_length, inverse) -> {:ok, c128 binary}   (Nx.fft / Nx.ifft of f64 / c128 rows) */
+static ERL_NIF_TERM nif_fft_c128(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary in, ob;
+  ErlNifSInt64 rows;
+  int is_real, n_in, k, inv;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &in) || !enif_get_int(env, argv[2], &is_real) ||
+      !enif_get_int64(env, argv[3], &rows) || !enif_get_int(env, argv[4], &n_in) || !enif_get_int(env, argv[5], &k) ||
+      !enif_get_int(env, argv[6], &inv))
+    return enif_make_badarg(env);
+  const size_t es = is_real ? 8 : 16;
+  if (rows < 1 || n_in < 1 || k < 1 || in.size % es || in.size / es / (size_t)rows != (size_t)n_in || in.size / es % (size_t)rows)
+    return enif_make_badarg(env);
+  if (!out_bin(&ob, (uint64_t)rows, (uint64_t)k, 1, 16)) return mk_oom(env);
+  int rc = nxsig_fft_c128(c->ctx, in.data, is_real, rows, n_in, k, inv, (nxsig_c128*)ob.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &ob));
+}
+
+/* as_windowed_f64(ctx, x_bin, length, batch, window_length, stride, pad_mode, pad_lo, pad_hi) -> {:ok, frames_bin, num_frames} */
+static ERL_NIF_TERM nif_as_windowed_f64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary x, ob;
+  ErlNifSInt64 length, lo, hi;
+  int batch, wl, stride, pad;
+  if (argc != 9 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_get_int(env, argv[4], &wl) || !enif_get_int(env, argv[5], &stride) ||
+      !enif_get_int(env, argv[6], &pad) || !enif_get_int64(env, argv[7], &lo) || !enif_get_int64(env, argv[8], &hi))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || x.size % 8 || x.size / 8 / (size_t)batch != (size_t)length) return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, wl, stride, pad, lo, hi);
+  if (m < 0) return mk_error(env, (int)m);
+  if (!out_bin(&ob, (uint64_t)batch, (uint64_t)m, (uint64_t)wl, 8)) return mk_oom(env);
+  int rc = nxsig_as_windowed_f64(c->ctx, (const double*)x.data, length, batch, length, wl, stride, pad, lo, hi, (double*)ob.data, NULL,
+                                 NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return enif_make_tuple3(env, mk_atom(env, "ok"), enif_make_binary(env, &ob), enif_make_int64(env, m));
+}
+
+/* overlap_and_add_f64(ctx, frames_bin, num_frames, batch, frame_length, overlap_length, components) -> {:ok, out_bin} */
+static ERL_NIF_TERM nif_overlap_and_add_f64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary f, ob;
+  ErlNifSInt64 m;
+  int batch, n, overlap, comps;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &f) || !enif_get_int64(env, argv[2], &m) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_get_int(env, argv[4], &n) || !enif_get_int(env, argv[5], &overlap) ||
+      !enif_get_int(env, argv[6], &comps))
+    return enif_make_badarg(env);
+  if (batch < 1 || m < 1 || n < 1 || (comps != 1 && comps != 2) || f.size % ((size_t)8 * (size_t)comps) ||
+      f.size / 8 / (size_t)comps / (size_t)batch / (size_t)m != (size_t)n || f.size / 8 / (size_t)comps % ((size_t)batch * (size_t)m))
+    return enif_make_badarg(env);
+  int64_t out_len = (overlap >= 0 && overlap < n) ? m * (int64_t)(n - overlap) + overlap : 1;
+  if (!out_bin(&ob, (uint64_t)batch, (uint64_t)out_len, (uint64_t)comps, 8)) return mk_oom(env);
+  int rc = nxsig_overlap_and_add_f64(c->ctx, (const double*)f.data, m, batch, n, overlap, comps, (double*)ob.data, NXSIG_HOST);
+  if (rc) { enif_release_binary(&ob); return mk_error(env, rc); }
+  return mk_ok(env, enif_make_binary(env, &ob));
+}
+
 /* fftconvolve_c64(ctx, a_bin, b_bin, mode) -> {:ok, c64 binary}   (1-D complex case of Convolution.fftconvolve/3) */
 static ERL_NIF_TERM nif_fftconvolve_c64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
@@ -1227,6 +1418,16 @@ static ErlNifFunc funcs[] = {
     {"istft_sharded_dev", 8, nif_istft_sharded_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir_sharded_dev", 8, nif_fir_sharded_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_mel_sharded_dev", 9, nif_stft_mel_sharded_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"window_f64", 5, nif_window_f64, 0},
+    {"firwin_f64", 7, nif_firwin_f64, 0},
+    {"fft_frequencies_f64", 3, nif_fft_frequencies_f64, 0},
+    {"sinc_f64", 1, nif_sinc_f64, 0},
+    {"stft_f64", 7, nif_stft_f64, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"istft_c128", 7, nif_istft_c128, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"fir_f64", 6, nif_fir_f64, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"fft_c128", 7, nif_fft_c128, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"as_windowed_f64", 9, nif_as_windowed_f64, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"overlap_and_add_f64", 7, nif_overlap_and_add_f64, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 ERL_NIF_INIT(Elixir.NxSignalAMD.NIF, funcs, load, NULL, upgrade, NULL)

@@ -69,7 +69,8 @@ def test_nif_ex_matches_the_shim_table():
     assert called <= set(table), called - set(table)
     # GPU entry points are dirty jobs (a scheduler thread must never block on the GPU)
     for (name, ar), flags in table.items():
-        if name in ("window", "firwin", "fft_frequencies", "sinc", "buf_size", "group_info", "device_count", "shard_range"):
+        if name in ("window", "firwin", "fft_frequencies", "sinc", "buf_size", "group_info", "device_count", "shard_range",
+                    "window_f64", "firwin_f64", "fft_frequencies_f64", "sinc_f64"):
             continue
         assert flags in (1, 2), (name, ar, flags)
 
@@ -108,6 +109,16 @@ def test_host_generators_through_the_nif(golden):
     assert np.array_equal(f32(b), S.waveforms.sinc(np.array([0.0, 0.25, 1.0], np.float32)))
     # integers are accepted where Elixir callers may pass them (sampling_rate: 48000)
     assert H.call("fft_frequencies", 16000, 10, 0)[0] == "ok"
+    # the f64 generators (`type: {:f, 64}`): the same bits as the ctypes path
+    f64 = lambda b: np.frombuffer(b, np.float64)  # noqa: E731
+    ok, b = H.call("window_f64", 6, 33, 1, 9.0, 1e-7)
+    assert np.array_equal(f64(b), S.windows.kaiser(33, beta=9.0, type="f64"))
+    ok, b = H.call("firwin_f64", 31, [0.2, 0.5], 4, 0.0, 0, 1, 2.0)
+    assert np.array_equal(f64(b), S.filters.firwin(31, [0.2, 0.5], pass_zero=False, type="f64"))
+    ok, b = H.call("fft_frequencies_f64", 44100.0, 16, 0)
+    assert np.array_equal(f64(b), S.fft_frequencies(44100.0, fft_length=16, type="f64"))
+    ok, b = H.call("sinc_f64", np.array([0.0, 0.25, 1.0]))
+    assert np.array_equal(f64(b), S.waveforms.sinc(np.array([0.0, 0.25, 1.0])))
 
 
 def test_malformed_terms_are_badarg_not_crashes():
@@ -179,6 +190,39 @@ def test_stft_istft_fir_through_the_nif_equal_the_ctypes_path(nctx):
     with pytest.raises(H.BadArg):
         H.call("istft", nctx, z, 184, 2, w[:100], PARAMS)
     assert H.lib().fake_live_binaries() == 0
+
+
+@gpu
+def test_f64_tier_through_the_nif(nctx):
+    """stft_f64 / istft_c128 / fir_f64 / fft_c128 / as_windowed_f64 / overlap_and_add_f64 with the term shapes nx_signal_amd.ex builds"""
+    rng = np.random.Generator(np.random.PCG64(3))
+    N, hop = 256, 64
+    x = rng.standard_normal((2, 4000))
+    w64 = S.windows.hann(N, type="f64")
+    w32 = S.windows.hann(N)
+    prm = (N, hop, N, 0, 0, 0, 1, 8000.0)
+    for w, flag in ((w64, 1), (w32, 0)):
+        ok, zb, m, tb, fb = H.call("stft_f64", nctx, x, x.shape[1], 2, w, flag, prm)
+        z, t, f = S.stft(x, w, overlap_length=N - hop, scaling="spectrum", sampling_rate=8000.0)
+        assert ok == "ok" and m == z.shape[1]
+        assert np.array_equal(np.frombuffer(zb, np.complex128).reshape(z.shape), z) and np.array_equal(f32(tb), t) and np.array_equal(f32(fb), f)
+        ok, yb = H.call("istft_c128", nctx, z, m, 2, w, flag, prm)
+        assert np.array_equal(np.frombuffer(yb, np.complex128).reshape(2, -1), S.istft(z, w, overlap_length=N - hop, scaling="spectrum", sampling_rate=8000.0))
+    h = S.filters.firwin(129, [0.3], type="f64")
+    ok, yb = H.call("fir_f64", nctx, x, x.shape[1], 2, h, 1)
+    assert np.array_equal(np.frombuffer(yb, np.float64).reshape(2, -1), S.filters.fir(x, h))
+    ok, ob = H.call("fft_c128", nctx, x, 1, 2, x.shape[1], 4096, 0)
+    assert np.array_equal(np.frombuffer(ob, np.complex128).reshape(2, 4096), S.transforms.fft_nd(x, lengths=[4096]))
+    ok, fb, m = H.call("as_windowed_f64", nctx, x, x.shape[1], 2, 100, 30, 1, 0, 0)
+    fr = S.as_windowed(x, window_length=100, stride=30, padding="reflect")
+    assert m == fr.shape[1] and np.array_equal(np.frombuffer(fb, np.float64).reshape(fr.shape), fr)
+    ok, ob = H.call("overlap_and_add_f64", nctx, fr, m, 2, 100, 70, 1)
+    assert np.array_equal(np.frombuffer(ob, np.float64).reshape(2, -1), S.overlap_and_add(fr, overlap_length=70))
+    with pytest.raises(H.BadArg):
+        H.call("stft_f64", nctx, x.astype(np.float32), x.shape[1], 2, w64, 1, prm)   # f32 bytes where f64 are announced
+    with pytest.raises(H.NifError) as e:
+        H.call("fir_f64", nctx, x, x.shape[1], 2, rng.standard_normal(5000), 1)
+    assert e.value.code == -2   # beyond the tier's 4097 taps: reported, not approximated
 
 
 @gpu

@@ -29,9 +29,6 @@ struct IstftWaveArgs {
   v2f* y;                     // c64[batch][segs_per_row * hop]
   v2f* dummy;
   const v2f* filt = nullptr;  // c64[K] spectrum filter (FILT variant of k_istft_wave only)
-  int32_t dbg_prio = 0;       // raised wave priority during the transform (NXSIG_WAVE_PRIO=1: experiment, see stft_wave_body)
-  int32_t dbg_no_halo = 0;    // EXPERIMENT ONLY (NXSIG_ISTFT_DBG_NOHALO=1): runs skip their halo frames -> wrong sums at run starts;
-                              // measures what a geometry would cost if partial sums were handed over instead of recomputed
   int* nf_list = nullptr;     // kernels that invert several frames per transform: units that hold a non-finite bin are reported here
                               // ({count, capacity, int64 (row << 40 | first frame) ...}) and redone frame by frame by k_istft_nf_fix
 };
@@ -76,7 +73,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
   const int64_t j0 = (run - row * a.runs_per_row) * a.run_len;
   int64_t j1 = j0 + a.run_len;
   if (j1 > a.segs_per_row) j1 = a.segs_per_row;
-  const int64_t m_start = (j0 >= (R - 1) && !a.dbg_no_halo) ? j0 - (R - 1) : (a.dbg_no_halo ? j0 : 0);
+  const int64_t m_start = j0 >= (R - 1) ? j0 - (R - 1) : 0;   // the run's R - 1 halo frames are recomputed (hand-over bound: +7 %)
 
   // this lane's window values wv[par][q] = w[2 lane + par + 128 q]
   float wv[2][NQ];
@@ -120,9 +117,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
     issue_loads(m + 1 < j1 ? m + 1 : m);  // unconditional prefetch keeps the loop branch-free
     __builtin_amdgcn_sched_barrier(0);
     v2f zz[2][NQ];
-    if (a.dbg_prio) __builtin_amdgcn_s_setprio(2);
     wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);  // inverse direction (tables are conjugated)
-    if (a.dbg_prio) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     take_frame();
     __builtin_amdgcn_sched_barrier(0);
@@ -688,7 +683,6 @@ struct FirWaveArgs {
   const v2f* twC;
   float* y;                            // f32[batch][out_len]
   int* row_flags;                      // FirLaunch::row_flags: a non-finite sample poisons its whole row, like the reference's one transform
-  int32_t dbg_prio = 0;                // raised wave priority during the two transforms (NXSIG_WAVE_PRIO=1: experiment, see stft_wave_body)
 };
 
 int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, int32_t taps, int64_t first_block, int64_t pb_lo,
@@ -763,14 +757,12 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       issue_loads(more ? nrow : row, more ? npin : pin);  // unconditional prefetch: branch-free loop
       __builtin_amdgcn_sched_barrier(0);
       if (wave_any_nonfinite(nfs.x, nfs.y) && lane == 0) atomicOr(a.row_flags + row, 1);
-      if (a.dbg_prio) __builtin_amdgcn_s_setprio(2);
       v2f d[P];
       wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);
 #pragma unroll
       for (int s = 0; s < P; ++s) d[s] = wcmul(d[s], HREG ? hv[HREG ? s : 0] : s_H[lane + 64 * s]);  // Z H / K
       v2f u[2][NQ];
       wave_fft_core<K, true, true>(d, u, xb, s_twB, s_twC, lane);  // inverse: u = (y1[n], y2[n])
-      if (a.dbg_prio) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       pack();  // next pair (its samples landed during the two transforms)
       __builtin_amdgcn_sched_barrier(0);
@@ -916,8 +908,6 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t total_segs = a.segs_per_row * s.batch;
-  a.dbg_no_halo = env_int("NXSIG_ISTFT_DBG_NOHALO", 0);
-  a.dbg_prio = env_int("NXSIG_WAVE_PRIO", 0);
   const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", (DBL || s.filt) ? 8 : 12);  // the filtered variant holds 16 more
                                                                                          // complex values per lane: 2 waves per SIMD  // = resident waves per CU: one even round
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
@@ -1229,7 +1219,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   Ctx::WaveTables& wt = c->wave_tables[K];
   a.twB = reinterpret_cast<const v2f*>(wt.twB);
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
-  a.y = s.y; a.row_flags = s.row_flags; a.dbg_prio = env_int("NXSIG_WAVE_PRIO", 0);
+  a.y = s.y; a.row_flags = s.row_flags;
   // 8-byte vector access needs every offset even: taps-1 multiple of 128 (=> V even), even strides, aligned bases
   const bool fast8 = ((s.taps - 1) % 128 == 0) && (s.batch_stride % 2 == 0) && (s.out_len % 2 == 0) && (out_start % 2 == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 7) == 0);

@@ -338,10 +338,6 @@ struct WaveArgs {
   int64_t units_per_row;      // k_stft_wave: units of each row covered by this launch (interior or edge set)
   int64_t u_split, u_add0, u_add1;  // unit u of the launch is unit-in-row u + (u < u_split ? u_add0 : u_add1)
   int64_t chunk;              // units per workgroup (contiguous)
-  int64_t xcd_span = 0;       // > 0: workgroup b takes chunk (b % 8) * xcd_span + b / 8 (consecutive chunks on one XCD); 0: chunk b
-  int32_t early_loads = 0;    // 1: the first unit's sample loads are issued BEFORE the tables are staged (start-up latencies overlap;
-                              //    NXSIG_EARLY_LOADS, measured: no gain, off)
-  int32_t prio = 0;           // raised wave priority during the transform (NXSIG_WAVE_PRIO=1: experiment, off by default)
   const float* wtab;          // device f32[fft_length]: window zero-padded / truncated to the fft length
   const v2f* twB;             // device c64[16][16]: w_256^(t k)
   const v2f* twC;             // device c64[R3][256]: w_C^(t i)
@@ -491,10 +487,9 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
     __builtin_nontemporal_store(v, (gv2f*)rowp);
   };
 
-  // the dispatcher deals workgroups round-robin over the 8 XCDs (each with its own L2): with xcd_span set, an XCD walks ONE
-  // contiguous eighth of the chunks, so the input a chunk shares with its neighbour (frame overlap at the seam) is in its L2
-  const int64_t chunk_id = a.xcd_span > 0 ? (int64_t)(blockIdx.x & 7) * a.xcd_span + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
-  const int64_t p_begin = chunk_id * a.chunk;
+  // workgroup b takes chunk b: the dispatcher deals consecutive chunks round-robin over the 8 XCDs (an XCD-contiguous walk and
+  // persistent variants measured slower: profiles/r02, profiles/r03/negative_results.md)
+  const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
   int64_t p_end = p_begin + a.chunk;
   if (p_end > a.total_pairs) p_end = a.total_pairs;
 
@@ -596,13 +591,8 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   advance(nrow, nuin);
   v2f d[P];  // windowed samples of the current pair: re = frame A, im = frame B (exact f32 products, :101)
   const bool have_first = !GENERAL && p_begin + wave < p_end;
-  if (a.early_loads) {
-    if (have_first) issue_loads(row, pinof(uin));   // raw samples travel while the tables are staged
-    stage_tables();
-  } else {
-    stage_tables();
-    if (have_first) issue_loads(row, pinof(uin));
-  }
+  stage_tables();
+  if (have_first) issue_loads(row, pinof(uin));
   if (have_first) window_mul(d);
 
   // ---- Nx.fft's clean-up (SURVEY App. A rule 7; call site lib/nx_signal.ex:102): every component of the finished spectrum
@@ -857,12 +847,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      // EXPERIMENT (NXSIG_WAVE_PRIO=1, default off): raised wave priority while the transform runs.  Back-to-back sweeps
-      // (tools/sweep_*.py) read +0.5 ... 2.5 %, but in bench.py's per-launch laps the iSTFT lost 5 % (0.573 / 0.589 against
-      // 0.607 / 0.630 of 8 TB/s, two interleaved runs each) and the single 60 s stream 3 %: profiles/r03/negative_results.md
-      if (a.prio) __builtin_amdgcn_s_setprio(2);
       wave_fft_core<K>(d, zz, xb, s_twB, s_twC, lane);
-      if (a.prio) __builtin_amdgcn_s_setprio(0);
       if (!GENERAL && !LATE) {
         __builtin_amdgcn_sched_barrier(0);
         window_mul(d);
@@ -1308,10 +1293,6 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     a.units_per_row = upr; a.u_split = split; a.u_add0 = add0; a.u_add1 = add1;
     a.total_pairs = upr * s.batch;
     int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
-    a.xcd_span = 0;
-    a.early_loads = env_int("NXSIG_EARLY_LOADS", 0);
-    a.prio = env_int("NXSIG_WAVE_PRIO", 0);
-    if (env_int("NXSIG_XCD_REMAP", 0) && blocks >= 64) { a.xcd_span = (blocks + 7) / 8; blocks = a.xcd_span * 8; }
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

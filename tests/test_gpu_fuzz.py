@@ -362,3 +362,58 @@ def test_fuzz_istft_non_finite_bins_and_packed_pair(seed):
     yr = np.asarray(S.istft_packed(pk.astype(np.complex64), w, **opts))
     yro = np.stack([O.istft(zo[b].astype(np.complex64), w, **opts) for b in range(B)]).real
     assert yr.dtype == np.float32 and nerr(yr, yro) < 1e-5, (N, hop, M, nerr(yr, yro))
+
+
+F64_LENGTHS = [4, 8, 32, 64, 128, 512, 1024, 2048, 4096, 8192, 100, 400, 640, 1000, 3000, 48, 7, 60, 5000]
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_fuzz_f64_tier(seed):
+    """stft / istft / fftconvolve on f64 / c128 tensors (and mixed f32 / f64 operands) against the oracle's f64 section: random
+    lengths over all three transform kinds (in-place radix-2^2, Bluestein, table DFT), hops, paddings, scalings, window types"""
+    rng = np.random.default_rng(9000 + seed)
+    K = F64_LENGTHS[rng.integers(len(F64_LENGTHS))]
+    N = int(rng.choice([K, K, max(1, K // 2), max(1, int(K * 0.8)), min(K + K // 4, 8192)]))
+    hop = int(rng.integers(1, N + 1))
+    bshape = [(), (2,), (3,), (2, 2)][rng.integers(4)]
+    pad = ["valid", "reflect", "same", [(int(rng.integers(0, N + 1)), int(rng.integers(0, N + 1)))]][rng.integers(4)]
+    M_target = int(rng.integers(1, 12))
+    L = N + (M_target - 1) * hop + int(rng.integers(0, hop))
+    if pad == "reflect":
+        L = max(L, N // 2 + 2)
+    scaling = [None, "spectrum", "psd"][rng.integers(3)]
+    wtype = ["f64", "f64", "f32"][rng.integers(3)]
+    name = ["hann", "hamming", "blackman", "kaiser"][rng.integers(4)]
+    w = getattr(S.windows, name)(N, type=wtype, is_periodic=bool(rng.integers(2)))
+    if N == 1:
+        w = np.ones(1, w.dtype)
+    x = rng.standard_normal(bshape + (L,))
+    if wtype == "f64" and rng.integers(3) == 0:
+        x = x.astype(np.float32)   # f32 samples meet an f64 window: still the f64 tier
+    opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=float(rng.choice([100, 16000, 48000])))
+    z, t, f = S.stft(x, w, **opts)
+    zo, to, fo = O.stft_f64(x, w, **opts)
+    assert z.dtype == np.complex128 and z.shape == zo.shape, (opts, L)
+    fin = np.isfinite(zo.real) & np.isfinite(zo.imag)
+    if not fin.all():   # a window that sums to zero under :scaling divides by zero in the reference as well: same NaN / Inf pattern
+        zc = np.ascontiguousarray(z).view(np.float64)
+        zoc = np.ascontiguousarray(zo).view(np.float64)
+        assert np.array_equal(np.isnan(zc), np.isnan(zoc)) and np.array_equal(np.isposinf(zc), np.isposinf(zoc)) and \
+            np.array_equal(np.isneginf(zc), np.isneginf(zoc)), (K, N, hop, L, pad, scaling, wtype)
+        return
+    assert nerr(z, zo) < 1e-12, (K, N, hop, L, pad, scaling, wtype, nerr(z, zo))
+    assert np.array_equal(t, to, equal_nan=True) and np.array_equal(f, fo)
+    if K == N:   # invert what was just transformed; compared where the |w|^2 normaliser is well conditioned
+        ov = dict(overlap_length=N - hop, fft_length=N, scaling=scaling, sampling_rate=opts["sampling_rate"])
+        y = S.istft(zo, w, **ov)
+        yo = O.istft_f64(zo, w, overlap_length=N - hop, scaling=scaling, sampling_rate=opts["sampling_rate"])
+        den = O.overlap_and_add_f64(np.broadcast_to(np.abs(w.astype(np.float64)) ** 2, (zo.shape[-2], N)).copy(), N - hop)
+        ok = den > 1.0e-6
+        if ok.any() and np.max(np.abs(yo[..., ok])) > 0:
+            assert nerr(y[..., ok], yo[..., ok]) < 1e-11, (N, hop, scaling, wtype)
+    taps = int(rng.choice([1, 2, 17, 129, 300, 1025, 3000]))
+    xs = rng.standard_normal((2, int(rng.integers(taps, 20000))))
+    h = rng.standard_normal(taps) / np.sqrt(taps)
+    mode = ["full", "same", "valid"][rng.integers(3)]
+    yc = S.convolution.fftconvolve(xs, h, mode=mode)
+    assert yc.dtype == np.float64 and nerr(yc, O.fftconvolve_f64(xs, h, mode=mode)) < 1e-11, (taps, mode)

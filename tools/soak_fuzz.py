@@ -16,7 +16,7 @@ def main():
     fams = [F.test_fuzz_stft, F.test_fuzz_istft, F.test_fuzz_fir, F.test_fuzz_stft_long_rows_interior_edge_split, F.test_fuzz_fused_sinks, F.test_fuzz_istft_n400,
             F.test_fuzz_fir_any_taps_offsets_and_slices, F.test_fuzz_istft_filtered_and_direct_convolution,
             F.test_fuzz_stft_to_mel_bits, F.test_fuzz_long_rows_and_columns, ND.test_convolve_direct_register_window_kernel_fuzz,
-            F.test_fuzz_non_finite_samples_follow_the_reference, F.test_fuzz_istft_non_finite_bins_and_packed_pair]
+            F.test_fuzz_non_finite_samples_follow_the_reference, F.test_fuzz_istft_non_finite_bins_and_packed_pair, F.test_fuzz_f64_tier]
     only = os.environ.get("SOAK_ONLY")
     if only:
         fams = [f for f in fams if only in f.__name__]

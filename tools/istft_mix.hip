@@ -54,6 +54,33 @@ __global__ __launch_bounds__(256) void k_chunk(const v4f* __restrict__ in, v4f* 
   }
 }
 
+// contiguous sub-runs: wave w of a workgroup takes frames c0 + off_w .. of its chunk one after the other (a register-resident
+// overlap-add like k_istft_wave's), wave 0 reads `halo` frames in front of the chunk first and takes `halo` fewer frames of its own
+// (every wave processes `cpw` frames): the geometry of a chunked iSTFT with a tail hand-off between the waves of a workgroup
+__global__ __launch_bounds__(256) void k_chunk_runs(const v4f* __restrict__ in, v4f* __restrict__ out, size_t frames, int cpw, int halo) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t per_chunk = (size_t)4 * cpw - halo;
+  const size_t c0 = (size_t)blockIdx.x * per_chunk;
+  size_t f0 = c0 + (wave == 0 ? 0 : (size_t)wave * cpw - halo);
+  const size_t n_own = wave == 0 ? cpw - halo : cpw;
+  v4f carry = {0, 0, 0, 0};
+  if (wave == 0)
+    for (int h = 0; h < halo; ++h) {
+      const size_t f = c0 >= (size_t)halo ? c0 - halo + h : h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) carry += in[f * 512 + 64 * j + lane];
+    }
+  for (size_t it = 0; it < n_own; ++it) {
+    const size_t f = f0 + it;
+    if (f >= frames) return;
+    v4f acc = carry;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += in[f * 512 + 64 * j + lane];
+    __builtin_nontemporal_store(acc, out + f * 128 + lane);
+    __builtin_nontemporal_store(acc * 2.0f, out + f * 128 + 64 + lane);
+  }
+}
+
 int main() {
   const size_t frames = 16 * 11247;  // config 3
   v4f *a, *b;
@@ -73,6 +100,14 @@ int main() {
       const unsigned grid = (unsigned)((frames + 4 * cpw - 1) / (4 * cpw));
       float ms = time([&] { hipLaunchKernelGGL(k_chunk, dim3(grid), dim3(256), 0, 0, a, b, frames, cpw, halo); });
       printf("chunk geometry: %2d frames per wave, halo %d frames per chunk  %7.1f GB/s (10240 B/frame, halo reads not counted)\n", cpw, halo, frames * 10240.0 / ms / 1e6);
+    }
+  for (int cpw : {4, 5, 6, 8, 10, 12, 16, 24})
+    for (int halo : {0, 3}) {
+      const size_t per_chunk = (size_t)4 * cpw - halo;
+      const unsigned grid = (unsigned)((frames + per_chunk - 1) / per_chunk);
+      float ms = time([&] { hipLaunchKernelGGL(k_chunk_runs, dim3(grid), dim3(256), 0, 0, a, b, frames, cpw, halo); });
+      printf("chunked runs: %2d frames per wave (wave 0: %d halo + %d own)  %7.1f GB/s (10240 B/frame, halo reads not counted)\n", cpw, halo, cpw - halo,
+             frames * 10240.0 / ms / 1e6);
     }
   return 0;
 }

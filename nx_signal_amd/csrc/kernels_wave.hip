@@ -49,7 +49,9 @@ __device__ __forceinline__ v2f cmul_c64_rounded(v2f a, v2f b) {
 // guides/filtering.livemd:141): a lane always loads the same 16 bins, so its 16 filter values sit in registers and the separate
 // read-modify-write pass over the spectrogram (16 KB of HBM traffic per frame on top of this kernel's 10) disappears.  (Keeping the
 // table in LDS to stay at 3 waves per SIMD was measured too: it spills 25 registers and runs 30 % slower than this form.)
-template <int K, int R, bool SCALE, int W, bool FILT = false, bool NTL = false>   // NTL: non-temporal loads of the spectrogram
+// DEEP: the spectrum is prefetched TWO frames ahead into two register sets that trade roles every iteration (the loop is unrolled
+// by two): 32 more registers, i.e. two waves per SIMD instead of three, for twice the bytes in flight per wave
+template <int K, int R, bool SCALE, int W, bool FILT = false, bool NTL = false, bool DEEP = false>   // NTL: non-temporal loads of the spectrogram
 __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
   constexpr int P = K / 64;
   constexpr int R3 = K / 256;
@@ -92,11 +94,11 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
       for (int qq = 0; qq < QS; ++qq) pend[i][e][qq] = v2f{0.f, 0.f};
 
   const v2f* zrow = a.z + (size_t)row * a.M * K + lane;
-  v2f r[P];
-  auto issue_loads = [&](int64_t m) {
+  v2f r[P], r2[DEEP ? P : 1];
+  auto issue_into = [&](v2f* dst, int64_t m) {
     const v2f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * K;  // clamped: frames past the end contribute zero
 #pragma unroll
-    for (int s = 0; s < P; ++s) r[s] = NTL ? __builtin_nontemporal_load(pz + 64 * s) : pz[64 * s];
+    for (int s = 0; s < P; ++s) dst[s] = NTL ? __builtin_nontemporal_load(pz + 64 * s) : pz[64 * s];
   };
   v2f hv[FILT ? P : 1];
   if (FILT) {
@@ -104,22 +106,30 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
     for (int s = 0; s < P; ++s) hv[FILT ? s : 0] = a.filt[lane + 64 * s];
   }
   v2f d[P];
-  auto take_frame = [&]() {   // the prefetched spectrum (times the filter) becomes the core's input
+  auto take_from = [&](const v2f* src) {   // the prefetched spectrum (times the filter) becomes the core's input
 #pragma unroll
     for (int s = 0; s < P; ++s) {
-      d[s] = FILT ? cmul_c64_rounded(r[s], hv[FILT ? s : 0]) : r[s];
+      d[s] = FILT ? cmul_c64_rounded(src[s], hv[FILT ? s : 0]) : src[s];
     }
   };
-  issue_loads(m_start);
-  take_frame();
+  if (DEEP) {
+    issue_into(r2, m_start);
+    issue_into(r, m_start + 1 < j1 ? m_start + 1 : m_start);
+    take_from(r2);
+  } else {
+    issue_into(r, m_start);
+    take_from(r);
+  }
 
-  for (int64_t m = m_start; m < j1; ++m) {
-    issue_loads(m + 1 < j1 ? m + 1 : m);  // unconditional prefetch keeps the loop branch-free
+  // one frame: rn holds (or is receiving) frame m + 1, rf is free and receives the frame after it
+  auto body = [&](const int64_t m, v2f* rn, v2f* rf) {
+    if (DEEP) issue_into(rf, m + 2 < j1 ? m + 2 : m);
+    else issue_into(rf, m + 1 < j1 ? m + 1 : m);  // unconditional prefetch keeps the loop branch-free
     __builtin_amdgcn_sched_barrier(0);
     v2f zz[2][NQ];
     wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);  // inverse direction (tables are conjugated)
     __builtin_amdgcn_sched_barrier(0);
-    take_frame();
+    take_from(rn);
     __builtin_amdgcn_sched_barrier(0);
 
     const float live = m < a.M ? 1.0f : 0.0f;  // tail flush: frames m >= M do not exist
@@ -161,6 +171,14 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
       const v4f o = v4f{out[0][qq].x * den[qq].x, out[0][qq].y * den[qq].x, out[1][qq].x * den[qq].y, out[1][qq].y * den[qq].y};
       __builtin_nontemporal_store(o, (gv4f*)(yp + 128 * qq));
     }
+  };
+  if (DEEP) {
+    for (int64_t m = m_start; m < j1; m += 2) {
+      body(m, r, r2);
+      if (m + 1 < j1) body(m + 1, r2, r);
+    }
+  } else {
+    for (int64_t m = m_start; m < j1; ++m) body(m, r, r);
   }
 }
 
@@ -287,9 +305,9 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_4k(IstftWaveArgs a) {
 // Z[k0 + K/2] = C0 - w_K^k0 C1 is built lane-locally in the core's input layout (k0 = lane + 64 s'), and the inverse
 // core returns sample n = lane + 64 q of frame 0 in zz[0][q] and of frame 1 in zz[1][q]: the overlap-add between the
 // two frames and with the pending sums stays in registers for every hop that is a multiple of 64.
-template <int K, int R, bool SCALE, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 VGPRs: the third wave per SIMD is worth 12 %
-void k_istft_wave_half(IstftWaveArgs a) {
+// DEEP: the next TWO pairs are in flight (see k_istft_wave): two waves per SIMD with 16 KB of loads each
+template <int K, int R, bool SCALE, int W, bool DEEP>
+__device__ __forceinline__ void istft_wave_half_body(const IstftWaveArgs& a) {
   constexpr int NH = K / 2;              // frame length (= fft_length)
   constexpr int R3 = K / 256;
   constexpr int NQ = K / 128;            // samples per lane per frame (n = lane + 64 q, q < NQ)
@@ -331,42 +349,51 @@ void k_istft_wave_half(IstftWaveArgs a) {
     for (int qq = 0; qq < QS; ++qq) pend[i][qq] = v2f{0.f, 0.f};
 
   const v2f* zrow = a.z + (size_t)row * a.M * NH + lane;
-  v2f r0[NQ], r1[NQ];
-  auto issue_loads = [&](int64_t m) {
+  v2f ra[2][NQ], rb[DEEP ? 2 : 1][DEEP ? NQ : 1];   // two register sets in the DEEP form: they trade roles every pair
+  auto issue_into = [&](v2f (*dst)[DEEP ? NQ : NQ], int64_t m) {
     const int64_t last = a.M - 1;
     const v2f* p0 = zrow + (size_t)(m < last ? m : last) * NH;
     const v2f* p1 = zrow + (size_t)(m + 1 < last ? m + 1 : last) * NH;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { r0[q] = __builtin_nontemporal_load(p0 + 64 * q); r1[q] = __builtin_nontemporal_load(p1 + 64 * q); }
+    for (int q = 0; q < NQ; ++q) { dst[0][q] = __builtin_nontemporal_load(p0 + 64 * q); dst[1][q] = __builtin_nontemporal_load(p1 + 64 * q); }
   };
   v2f d[2 * NQ];
-  // combine() also tells whether the pair holds a non-finite bin (the sum of the bins is finite iff they all are; an overflowing
+  // combine also tells whether the pair holds a non-finite bin (the sum of the bins is finite iff they all are; an overflowing
   // sum merely sends a finite pair down the solo route, which computes the same frames)
   bool nf_next = false;
-  auto combine = [&]() {
+  auto combine_from = [&](const v2f (*src)[NQ]) {
     v2f sum = v2f{0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const v2f t = wcmul(r1[q], v2f{tw_re[q], tw_im[q]});
-      d[q] = r0[q] + t;
-      d[q + NQ] = r0[q] - t;
+      const v2f t = wcmul(src[1][q], v2f{tw_re[q], tw_im[q]});
+      d[q] = src[0][q] + t;
+      d[q + NQ] = src[0][q] - t;
       sum += d[q];   // C0 + w C1 is non-finite whenever C0 or C1 is
     }
     nf_next = wave_any_nonfinite(sum.x, sum.y);
   };
-  issue_loads(m_start);
-  combine();
+  v2f (*rbp)[NQ] = reinterpret_cast<v2f (*)[NQ]>(&rb[0][0]);   // only dereferenced when DEEP
+  if (DEEP) {
+    issue_into(rbp, m_start);
+    issue_into(ra, m_start + 2 < j1 ? m_start + 2 : m_start);
+    combine_from(rbp);
+  } else {
+    issue_into(ra, m_start);
+    combine_from(ra);
+  }
 
-  for (int64_t m = m_start; m < j1; m += 2) {
+  // one pair: rn holds (or is receiving) the next pair, rf is free and receives the one after it
+  auto body = [&](const int64_t m, v2f (*rn)[NQ], v2f (*rf)[NQ]) {
     // a pair that holds a non-finite bin shares it between its two frames here; the reference inverts frame by frame (:609): the
     // unit is reported and k_istft_nf_fix redoes its samples (an in-kernel solo route cost the third wave per SIMD: -12 %)
     if (__builtin_expect(nf_next, 0) && lane == 0) istft_report_nonfinite(a.nf_list, row, m);
-    issue_loads(m + 2 < j1 ? m + 2 : m);
+    if (DEEP) issue_into(rf, m + 4 < j1 ? m + 4 : m);
+    else issue_into(rf, m + 2 < j1 ? m + 2 : m);
     __builtin_amdgcn_sched_barrier(0);
     v2f zz[2][NQ];
     wave_fft_core<K, true>(d, zz, xb, s_twB, s_twC, lane);
     __builtin_amdgcn_sched_barrier(0);
-    combine();
+    combine_from(rn);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -400,8 +427,23 @@ void k_istft_wave_half(IstftWaveArgs a) {
         __builtin_nontemporal_store(out * rd, (__attribute__((address_space(1))) v2f*)(yp + 64 * qq));
       }
     }
+  };
+  if (DEEP) {
+    for (int64_t m = m_start; m < j1; m += 4) {
+      body(m, ra, rbp);
+      if (m + 2 < j1) body(m + 2, rbp, ra);
+    }
+  } else {
+    for (int64_t m = m_start; m < j1; m += 2) body(m, ra, ra);
   }
 }
+
+template <int K, int R, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 VGPRs: the third wave per SIMD is worth 12 %
+void k_istft_wave_half(IstftWaveArgs a) { istft_wave_half_body<K, R, SCALE, W, false>(a); }
+
+template <int K, int R, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) void k_istft_wave_half_deep(IstftWaveArgs a) { istft_wave_half_body<K, R, SCALE, W, true>(a); }
 
 // ---- iSTFT for N = K/J (J = 4: N = 256, J = 8: N = 128): J consecutive frames per 1024-point inverse FFT.
 // Y[k0 + N m] = 1/J sum_j (C_j[k0] w_K^(j k0)) w_J^(jm) is a lane-local forward radix-J butterfly in the core's input
@@ -908,7 +950,14 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t total_segs = a.segs_per_row * s.batch;
-  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", (DBL || s.filt) ? 8 : 12);  // the filtered variant holds 16 more
+  // Two-frames-ahead prefetch (DEEP, round 3): 8 resident waves per CU with 16 KB of loads in flight each instead of 12 with 8 KB.
+  // Interleaved A/B sweeps (tools/sweep_istft.py NXSIG_ISTFT_DEEP 0 1; 1 / 2 / 4 / 8 / 16 / 32 streams of 60 s): +1.5 / +8 / +14 /
+  // +10 / +2 / +0.4 %; hop 128 / 512: +1.3 / +3 %; bench.py's laps of config 3: +1.3 %.  NXSIG_ISTFT_DEEP=0 selects the one-ahead form.
+  const bool deep = !DBL && !HALF && !s.filt && env_int("NXSIG_ISTFT_DEEP", 1);
+  // the N = 512 pair kernel likewise at hop = N / 4 (2 / 8 / 16 streams of 60 s: +13 / +9 / +5 %); at hop N / 8 and N / 2 the
+  // one-ahead form with three waves per SIMD stays ahead (-4 % / -4 ... -7 % for the deep form) and is kept there
+  const bool half_deep = HALF && env_int("NXSIG_ISTFT_HALF_DEEP", R == 4 ? 1 : 0);
+  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", (DBL || s.filt || deep || half_deep) ? 8 : 12);  // the filtered variant holds 16 more
                                                                                          // complex values per lane: 2 waves per SIMD  // = resident waves per CU: one even round
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", 8);
@@ -932,7 +981,10 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
     // every run also walks its halo units: capacity = units walked by all runs
     { int rcl = istft_nf_list(c, a.total_runs * ((run_len + R + 1) / 2 + 1), &a.nf_list); if (rcl) return rcl; }
     s.nf_list = a.nf_list; s.nf_frames_per_unit = 2;
-    if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_half<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    if (half_deep) {
+      if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_half_deep<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      else hipLaunchKernelGGL((k_istft_wave_half_deep<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    } else if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_half<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     else hipLaunchKernelGGL((k_istft_wave_half<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
   } else if (DBL) {
     std::vector<float2> twH((size_t)K);
@@ -954,6 +1006,9 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
     if (s.filt) {
       if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
       else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    } else if (deep) {
+      if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, false, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, false, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     } else if (env_int("NXSIG_ISTFT_NT_LOADS", 1)) {
       if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, false, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
       else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, false, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
@@ -986,7 +1041,9 @@ static int launch_istft_wave_quad(Ctx* c, const IstftLaunch& s, const float* win
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t units_per_row = (a.segs_per_row + J - 1) / J;
   const int64_t total_units = units_per_row * s.batch;
-  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", 24);  // two rounds of the 12 resident waves per CU
+  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", 12);  // = the resident waves per CU (round 3: 3.63 / 3.38 TB/s against 3.47 / 3.33 at 24
+                                                                    // for N = 256 / 128, 8 x 60 s; a two-units-ahead prefetch like k_istft_wave's
+                                                                    // DEEP form measured -3 ... +3 % here and was not kept)
   int64_t run_len = (total_units + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", 8);
   if (run_len < min_run) run_len = min_run;

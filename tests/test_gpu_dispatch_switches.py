@@ -29,6 +29,9 @@ CASES = [
     ("NXSIG_DISABLE_4K=1", ("tests/test_gpu_tuned_kernels.py", "4096")),
     ("NXSIG_DISABLE_FUSED_FILTER=1", ISTFT),
     ("NXSIG_ISTFT_NT_LOADS=0", ISTFT),
+    ("NXSIG_ISTFT_DEEP=0", ISTFT),
+    ("NXSIG_ISTFT_HALF_DEEP=0", ("tests/test_gpu_tuned_kernels.py", "half_n512")),
+    ("NXSIG_ISTFT_HALF_DEEP=1", ("tests/test_gpu_tuned_kernels.py", "half_n512")),
     ("NXSIG_STORE_POLICY=0", STFT),
     ("NXSIG_STORE_POLICY=2", STFT),
     ("NXSIG_WAVE_NO_SPLIT=1", STFT),

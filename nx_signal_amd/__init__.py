@@ -46,6 +46,19 @@ def _validate(opts: dict, allowed: dict, fn: str) -> dict:
     return out
 
 
+def _as_tensor(x):
+    """What Nx.tensor/1 would make of a host value: numpy arrays keep their dtype (np.float64 IS f64: the f64 tier); plain Python
+    numbers and (nested) lists follow Nx's inference — floats become f32, complex numbers c64, integers stay integers."""
+    if isinstance(x, np.ndarray) or is_device(x):
+        return x
+    a = np.asarray(x)
+    if a.dtype == np.float64:
+        return a.astype(np.float32)
+    if a.dtype == np.complex128:
+        return a.astype(np.complex64)
+    return a
+
+
 def _host_f32(x, what: str) -> np.ndarray:
     a = np.asarray(x)
     if a.dtype == np.float32:
@@ -142,6 +155,7 @@ def as_windowed(tensor, ctx: Context | None = None, **opts):
     N = int(o["window_length"])
     lib = _lib.load()
     M = C.c_int64()
+    tensor = _as_tensor(tensor)
     if is_device(tensor):
         ptr, shape, dt = device_view(tensor)
         if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
@@ -244,6 +258,7 @@ def istft_packed(data, window, ctx: Context | None = None, **opts):
 
 
 def _stft(data, window, ctx, opts, onesided, packed=False):
+    data, window = _as_tensor(data), _as_tensor(window)
     p, N, hop, K = _resolve_stft_opts(window, opts)
     w = _window_host(window)
     fs = float(p.sampling_rate)
@@ -344,6 +359,7 @@ def istft_filtered(data, h, window, ctx: Context | None = None, **opts):
 
 
 def _istft(data, window, ctx, opts, hh, packed=False):
+    data, window = _as_tensor(data), _as_tensor(window)
     o = _validate(opts, {"fft_length": None, "overlap_length": None, "scaling": None, "sampling_rate": 1000}, "istft")
     w = _window_host(window)
     N = int(w.shape[0])
@@ -415,6 +431,7 @@ def overlap_and_add(tensor, ctx: Context | None = None, **opts):
         raise ArgumentError("missing :overlap_length option")
     overlap = int(o["overlap_length"])
     lib = _lib.load()
+    tensor = _as_tensor(tensor)
     dev = is_device(tensor)
     if dev:
         ptr, shape, dt = device_view(tensor)

@@ -134,6 +134,8 @@ def fftconvolve(in1, in2, ctx=None, **opts):
     if mode not in _MODES:
         raise ArgumentError(f"expected mode to be one of [:full, :same, :valid], got: {mode!r}")
     lib = _lib.load()
+    from . import _as_tensor   # Python numbers / lists follow Nx.tensor's inference (f32); np.float64 arrays are f64
+    in1, in2 = _as_tensor(in1), _as_tensor(in2)
     dev = is_device(in1)
     h = np.asarray(in2) if not is_device(in2) else None
     if h is None:

@@ -30,7 +30,8 @@ def _run(tensor, inverse, opts, ctx):
             raise ArgumentError("fft_nd: device input must be float32 or complex64")
         is_real = dt == np.dtype(np.float32)
     else:
-        a = np.asarray(tensor)
+        from . import _as_tensor   # Python numbers / lists follow Nx.tensor's inference (f32 / c64)
+        a = np.asarray(_as_tensor(tensor))
         if a.dtype in (np.float64, np.complex128):
             return _run_f64(a, inverse, axes, lengths, ctx)
         a = np.ascontiguousarray(a.astype(np.complex64 if np.iscomplexobj(a) else np.float32))

@@ -7,7 +7,7 @@ from . import _lib
 
 
 def sinc(t):
-    a = np.asarray(t)
+    a = t if isinstance(t, np.ndarray) else np.asarray(t, dtype=np.float32)   # Nx.tensor(number / list) is f32; an np.float64 array is f64
     if a.dtype == np.float64:   # f64 tensor: evaluated in double (the pi() of the reference's defn stays the f32 constant)
         a = np.ascontiguousarray(a)
         out = np.empty_like(a)

@@ -188,3 +188,17 @@ def test_f64_limits_are_reported_not_approximated():
         S.istft(np.zeros((3, 8), np.complex64), np.ones(8))
     with pytest.raises(S.ArgumentError):
         S.stft_packed(sig(100, 1), np.ones(8, np.float32))
+
+
+def test_python_lists_follow_nx_tensor_inference():
+    """Nx.tensor([0.1, ...]) is f32: a plain list of Python floats must take the f32 path; only an np.float64 ARRAY is an f64 tensor"""
+    xs = [float(v) for v in sig(64, 1)]
+    w = S.windows.hann(16)
+    assert S.stft(xs, w)[0].dtype == np.complex64 and S.stft(np.asarray(xs), w)[0].dtype == np.complex128
+    z = S.stft(xs, w)[0]
+    assert S.istft(z.tolist(), w).dtype == np.complex64
+    assert S.as_windowed(xs, window_length=8).dtype == np.float32 and S.as_windowed([1, 2, 3, 4, 5], window_length=2).dtype.kind == "i"
+    assert S.overlap_and_add([[1.0, 2.0], [3.0, 4.0]], overlap_length=1).dtype == np.float32
+    assert S.convolution.fftconvolve(xs, [0.5, 0.25]).dtype == np.float32
+    assert S.transforms.fft_nd(xs).dtype == np.complex64 and S.transforms.fft_nd(np.asarray(xs)).dtype == np.complex128
+    assert S.waveforms.sinc([0.0, 0.5]).dtype == np.float32

@@ -3,7 +3,7 @@
  * Computes stft -> istft of a 2-channel chirp with a library-generated Hann window on HOST buffers and on DEVICE
  * buffers, checks both agree bit for bit and that the round trip reproduces the input on the interior; then the multi-GPU
  * entry points with no host language in the loop: a LOCAL group (two members on device 0: shards + assembly by copies; one
- * member: the RCCL all-gather) must reproduce the unsharded spectrum bit for bit; and a 2-D fft_nd round trip. */
+ * member: the RCCL all-gather) must reproduce the unsharded spectrum bit for bit; a 2-D fft_nd round trip; the f64 / c128 tier. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -124,6 +124,36 @@ int main(void) {
         const double want = (r < 6 && c < 10) ? (double)t[r * 10 + c] : 0.0;
         if (fabs((double)b[r * 16 + c].re - want) > 2e-5 || fabs((double)b[r * 16 + c].im) > 2e-5) { fprintf(stderr, "fft_nd round trip at (%d, %d)\n", r, c); return 7; }
       }
+  }
+  /* ---- the f64 / c128 tier through the C boundary: stft of the widened signal with an f64 window, then istft; the round trip must
+   *      reproduce the samples to double precision (a c64 detour would stop near 1e-7), and fir_f64 with a 3-tap filter must equal
+   *      the direct sum */
+  double worst64 = 0.0;
+  {
+    double* w64 = (double*)malloc(N * sizeof(double));
+    double* x64 = (double*)malloc((size_t)CH * L * sizeof(double));
+    CHECK(nxsig_window_f64(NXSIG_WIN_HANN, N, 1, 0.0, 1e-7, w64));
+    for (size_t i = 0; i < (size_t)CH * L; ++i) x64[i] = (double)x[i] + 1e-9 * (double)(i % 97);
+    nxsig_c128* z64 = (nxsig_c128*)malloc((size_t)CH * M * N * sizeof(nxsig_c128));
+    nxsig_c128* y64 = (nxsig_c128*)malloc((size_t)CH * out_len * sizeof(nxsig_c128));
+    CHECK(nxsig_stft_f64(ctx, x64, L, CH, L, w64, 1, &p, z64, NULL, NXSIG_HOST));
+    CHECK(nxsig_istft_c128(ctx, z64, M, CH, w64, 1, &p, y64, NXSIG_HOST));
+    for (int c = 0; c < CH; ++c)
+      for (int64_t i = N; i < out_len - N; ++i) {
+        const double d = fabs(y64[(size_t)c * out_len + i].re - x64[(size_t)c * L + i]);
+        if (d > worst64) worst64 = d;
+      }
+    const double h3[3] = {0.25, 0.5, 0.25};
+    double* f64o = (double*)malloc((size_t)CH * L * sizeof(double));
+    CHECK(nxsig_fir_f64(ctx, x64, L, CH, L, h3, 3, NXSIG_CONV_SAME, f64o, NXSIG_HOST));
+    for (int c = 0; c < CH; ++c)
+      for (int64_t i = 1; i + 1 < L; ++i) {
+        const double* xr = x64 + (size_t)c * L;
+        const double d = fabs(f64o[(size_t)c * L + i] - (0.25 * xr[i - 1] + 0.5 * xr[i] + 0.25 * xr[i + 1]));
+        if (d > worst64) worst64 = d;
+      }
+    free(w64); free(x64); free(z64); free(y64); free(f64o);
+    if (!(worst64 < 1e-12)) { fprintf(stderr, "f64 tier: error %.3g\n", worst64); return 8; }
   }
   CHECK(nxsig_free(ctx, xd)); CHECK(nxsig_free(ctx, zd)); CHECK(nxsig_free(ctx, yd));
   nxsig_ctx_destroy(ctx);

@@ -57,6 +57,29 @@ def synth(seed: int) -> np.ndarray:
     return rng.standard_normal(L, dtype=np.float32)  # N(0,1), never zero-filled (DVFS)
 
 
+def effective_cores():
+    """CPU time this process may actually burn, in cores: min(affinity mask, cgroup CPU quota).  A container on a 256-thread host
+    reports 256 from nproc / sched_getaffinity while its cgroup grants a handful (the measured all-thread speed-up says which)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota, src = None, None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota, src = float(q) / float(per), "cgroup v2 cpu.max"
+    except Exception:
+        pass
+    if quota is None:
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota, src = q / per, "cgroup v1 cfs_quota"
+        except Exception:
+            pass
+    eff = aff if quota is None else min(float(aff), quota)
+    return {"affinity": aff, "cgroup_quota": quota, "effective": eff, "source": src or "sched_getaffinity (no cgroup CPU quota set)"}
+
+
 def cpu_baseline(max_seconds: float):
     """oracle C port (single thread, like one BEAM scheduler) on a bounded sample of the same workload."""
     from oracle import bb_baseline, nx_oracle as O
@@ -93,19 +116,43 @@ def cpu_baseline(max_seconds: float):
         "sample": f"first {frames} frames of one 60 s mono 48 kHz stream (N=1024 hop=256 Hann), oracle/bb_baseline.c "
                   f"recursive radix-2 in f64, 1 thread; Nx.BinaryBackend itself cannot run here (no BEAM: "
                   f"elixir={'found' if _which('elixir') else 'not found'})",
-        "all_cores": {"value": done / dtn, "cores": cores, "seconds": dtn, "speedup_over_1_thread": (done / dtn) / (frames / dt1),
+        "all_cores": {"value": done / dtn, "cores": cores, "cores_effective": effective_cores(), "seconds": dtn,
+                      "speedup_over_1_thread": (done / dtn) / (frames / dt1),
                       "sample": f"{reps} passes over the 60 s stream ({done} frames), OpenMP static over frames"},
     }
 
 
-def secondary_rooflines(ctx, lib, S, _lib, C):
+def load_diag():
+    """tools/libnxsig_diag.so (tools/diag_mix.hip, built by __graft_entry__.build()): no-math traffic models of the iSTFT / FIR
+    kernels in their shipped geometry.  Measurement infrastructure only; absent -> the mix ceilings are reported as null."""
+    import ctypes as C
+
+    path = os.path.join(ROOT, "tools", "libnxsig_diag.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        d = C.CDLL(path)
+        d.nxdiag_istft_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int]
+        d.nxdiag_fir_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int]
+        return d
+    except OSError:
+        return None
+
+
+def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, seconds45=600, streams3=16, channels45=8, keep_z4=False):
     """Rooflines of the other BASELINE configs at their FULL per-GPU shard, measured like the headline (HIP events on the
     library's stream, one interval per launch, device-resident data; algorithmic bytes per SURVEY 8d):
       config 3  istft N=1024 hop=256, 16 x 60 s            10 240 B/frame  (K*8 read + hop*8 written, c64 out)
       config 4  stft  N=2048 hop=512, 8 ch x 600 s          18 432 B/frame  (one GPU's share of 64 channels)
-      config 5  fir   257 taps :same, 8 ch x 600 s          8 B/sample      (4 in + 4 out)"""
+      config 5  fir   257 taps :same, 8 ch x 600 s          8 B/sample      (4 in + 4 out)
+    Under a launcher EVERY rank runs this on its own shard (`barrier` lines the ranks up before each timed series so the GPUs of the
+    node work at the same time); main() reduces the per-rank kernel times with max-over-ranks.  `mix_ceiling` (configs 3 / 5): the
+    same traffic with no math in the kernel's launch geometry (tools/diag_mix.hip), timed the same way in this process."""
     out = {}
     rng = np.random.Generator(np.random.PCG64(99))
+    diag = load_diag()
+    stream = C.c_void_p(lib.nxsig_get_stream(ctx.handle)) if diag is not None else None
+    sync = barrier if barrier is not None else (lambda: None)
 
     def fill(buf, rows, n):
         chunk = rng.standard_normal(n, dtype=np.float32)
@@ -117,6 +164,7 @@ def secondary_rooflines(ctx, lib, S, _lib, C):
         for _ in range(warm):
             fn()
         ctx.sync()
+        sync()
         ctx.timer_lap()
         for _ in range(reps):
             fn()
@@ -136,36 +184,53 @@ def secondary_rooflines(ctx, lib, S, _lib, C):
         d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
              "traffic_source": "profiles/traffic.json (PMC passes of tools/profile_bench.sh, not measured in this run)",
              "kernel_ms": ms, "kernel_us": {"min": round(min(laps) * 1e3, 1), "median": round(float(np.median(laps)) * 1e3, 1),
-                                            "max": round(max(laps) * 1e3, 1)}, "workload": workload, "kernel": kernel}
+                                            "max": round(max(laps) * 1e3, 1)}, "workload": workload, "kernel": kernel, "algorithmic_bytes": nbytes}
         d.update(extra)
         return d
 
+    def ceiling(d, nbytes, fn, what):
+        """the no-math traffic model interleaved after the kernel: same buffers, same stream, same clocks"""
+        if diag is None:
+            d["mix_ceiling"] = None
+            return
+        laps = measure(fn, 20, 10)
+        ms = float(np.mean(laps))
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        d["mix_ceiling"] = {"GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "kernel_over_ceiling": d["achieved"] / gbs, "what": what}
+
     # ---- config 3: istft of 16 x 60 s
+    L3 = SR * seconds3
+    M3 = (L3 - N_FFT) // HOP + 1
     try:
-        B3 = 16
+        B3 = streams3
         w = S.windows.hann(N_FFT)
-        x3 = ctx.empty((B3, L), np.float32)
-        fill(x3, B3, L)
+        x3 = ctx.empty((B3, L3), np.float32)
+        fill(x3, B3, L3)
         z3, _, _ = S.stft(x3, w, ctx=ctx, overlap_length=N_FFT - HOP, fft_length=N_FFT, sampling_rate=SR)
-        y3 = ctx.empty((B3, M * HOP + N_FFT - HOP), np.complex64)
+        y3 = ctx.empty((B3, M3 * HOP + N_FFT - HOP), np.complex64)
         p3 = _lib.StftParams(N_FFT, HOP, N_FFT, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
         wp = w.ctypes.data_as(C.c_void_p)
-        laps = measure(lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(z3.ptr), M, B3, wp, C.byref(p3), C.c_void_p(y3.ptr), _lib.DEVICE)), 20, 30)
-        out["roofline_istft"] = block("config 3: istft N=1024 hop=256, 16 x 60 s mono 48 kHz, c64 out", "k_istft_wave<1024> (+ k_istft_edge_fix)",
-                                      B3 * M * (N_FFT * 8 + HOP * 8), laps, {"bytes_per_frame": N_FFT * 8 + HOP * 8, "frames_per_s": B3 * M / (float(np.mean(laps)) * 1e-3)}, "istft")
+        laps = measure(lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(z3.ptr), M3, B3, wp, C.byref(p3), C.c_void_p(y3.ptr), _lib.DEVICE)), 20, 30)
+        nb3 = B3 * M3 * (N_FFT * 8 + HOP * 8)
+        out["roofline_istft"] = block(f"config 3: istft N=1024 hop=256, {B3} x {seconds3} s mono 48 kHz, c64 out", "k_istft_wave<1024> (+ k_istft_edge_fix)",
+                                      nb3, laps, {"bytes_per_frame": N_FFT * 8 + HOP * 8, "frames": B3 * M3, "frames_per_s": B3 * M3 / (float(np.mean(laps)) * 1e-3)}, "istft")
         # round trip of config 3 on interior samples (size-independent property): y ~ x
         chk = np.empty(4096, np.complex64)
         _lib.check(lib.nxsig_download(ctx.handle, chk.ctypes.data_as(C.c_void_p), C.c_void_p(y3.ptr + 8 * 100000), chk.nbytes))
         ref = np.empty(4096, np.float32)
         _lib.check(lib.nxsig_download(ctx.handle, ref.ctypes.data_as(C.c_void_p), C.c_void_p(x3.ptr + 4 * 100000), ref.nbytes))
         out["roofline_istft"]["roundtrip_max_err"] = float(np.max(np.abs(chk.real - ref)) / np.max(np.abs(ref)))
+        # the y buffer is scratch from here on (the round trip has been read)
+        ceiling(out["roofline_istft"], nb3, lambda: diag.nxdiag_istft_mix(stream, C.c_void_p(z3.ptr), C.c_void_p(y3.ptr), B3 * M3, 8, 3),
+                "tools/diag_mix.hip k_istft_mix: 8 KiB nt-read + 2 KiB nt-written per frame, no math, 8 runs per CU, two frames ahead, 3 halo frames per run")
         for b in (x3, z3, y3):
             b.free()
     except Exception as e:  # noqa: BLE001
         out["roofline_istft"] = {"error": repr(e)[:200]}
     # ---- configs 4 / 5: one GPU's 8 channels x 10 min
+    z4 = None
     try:
-        B4, L4, N4, H4 = 8, SR * 600, 2048, 512
+        B4, L4, N4, H4 = channels45, SR * seconds45, 2048, 512
         M4 = (L4 - N4) // H4 + 1
         x4 = ctx.empty((B4, L4), np.float32)
         fill(x4, B4, L4)
@@ -174,20 +239,111 @@ def secondary_rooflines(ctx, lib, S, _lib, C):
         p4 = _lib.StftParams(N4, H4, N4, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
         wp4 = w4.ctypes.data_as(C.c_void_p)
         laps = measure(lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, wp4, C.byref(p4), C.c_void_p(z4.ptr), None, _lib.DEVICE)), 10, 15)
-        out["roofline_stft2048"] = block("config 4 (one GPU's shard of 64 channels): stft N=2048 hop=512, 8 ch x 600 s @48 kHz", "k_stft_wave<1024, real-2x>",
-                                         B4 * M4 * (H4 * 4 + N4 * 8), laps, {"bytes_per_frame": H4 * 4 + N4 * 8, "frames_per_s": B4 * M4 / (float(np.mean(laps)) * 1e-3)}, "stft2048")
-        z4.free()
+        out["roofline_stft2048"] = block(f"config 4 (one GPU's shard of 64 channels): stft N=2048 hop=512, {B4} ch x {seconds45} s @48 kHz", "k_stft_wave<1024, real-2x>",
+                                         B4 * M4 * (H4 * 4 + N4 * 8), laps, {"bytes_per_frame": H4 * 4 + N4 * 8, "frames": B4 * M4, "frames_per_s": B4 * M4 / (float(np.mean(laps)) * 1e-3)}, "stft2048")
+        if not keep_z4:
+            z4.free()
+            z4 = None
         h = S.filters.firwin(257, [4000.0], sampling_rate=float(SR))
         y5 = ctx.empty((B4, L4), np.float32)
         hp = h.ctypes.data_as(C.c_void_p)
         laps = measure(lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, hp, 257, _lib.CONV_SAME, C.c_void_p(y5.ptr), _lib.DEVICE)), 10, 15)
-        out["roofline_fir"] = block("config 5 (one GPU's shard): fir 257 taps :same (overlap-save), 8 ch x 600 s @48 kHz", "k_fir_wave<1024>",
-                                    B4 * L4 * 8, laps, {"bytes_per_sample": 8, "samples_per_s": B4 * L4 / (float(np.mean(laps)) * 1e-3)}, "fir")
+        out["roofline_fir"] = block(f"config 5 (one GPU's shard): fir 257 taps :same, {B4} ch x {seconds45} s @48 kHz", "nxsig_fir_f32 (stream + edge + poison pass)",
+                                    B4 * L4 * 8, laps, {"bytes_per_sample": 8, "samples": B4 * L4, "samples_per_s": B4 * L4 / (float(np.mean(laps)) * 1e-3)}, "fir")
+        ceiling(out["roofline_fir"], B4 * L4 * 8, lambda: diag.nxdiag_fir_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(y5.ptr), B4, L4, 8),
+                "tools/diag_mix.hip k_fir_mix: the overlap-save stream of k_fir_wave<1024> (two 1024-sample blocks read per 1536 outputs, 8-byte accesses, sc1 nt stores), no math")
         x4.free()
         y5.free()
     except Exception as e:  # noqa: BLE001
         out["roofline_fir"] = out.get("roofline_fir") or {"error": repr(e)[:200]}
+    out["_z4"] = z4
     return out
+
+
+def assembly_config4(ctx, group, lib, S, _lib, C, world, rank, channels, seconds, share_gpu):
+    """the config-4-sized final assembly, timed SEPARATELY from frames/s.  Every rank computes its shard of the 64-channel
+    spectrogram (stft N=2048 hop=512, `channels` x `seconds` s; 8 x 600 s = 7.37 GB) straight into its slot of a full-size buffer and
+    `nxsig_group_allgather` (RCCL ncclAllGather, in place) leaves all `world` shards on every GPU — 51.6 GB received per GPU at
+    world 8, priced against the 7 x 153 GB/s of xGMI links a GPU has.  If the buffers do not fit, the channel count is halved."""
+    N4, H4 = 2048, 512
+    L4 = SR * seconds
+    M4 = (L4 - N4) // H4 + 1
+    ch = channels
+    zt = x4 = None
+    while True:
+        try:
+            zt = ctx.empty((world, ch, M4, N4), np.complex64)
+            x4 = ctx.empty((ch, L4), np.float32)
+            break
+        except Exception as e:  # noqa: BLE001  (out of memory: a smaller shard)
+            for b in (zt, x4):
+                if b is not None:
+                    b.free()
+            zt = x4 = None
+            if ch == 1:
+                return {"error": "config-4-sized assembly buffers do not fit: " + repr(e)[:120]}
+            ch //= 2
+    shard = ch * M4 * N4 * 8
+    rng = np.random.Generator(np.random.PCG64(4242 + rank))
+    chunk = rng.standard_normal(L4, dtype=np.float32)
+    for r in range(ch):
+        xr = np.roll(chunk, 977 * r)
+        _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(x4.ptr + r * L4 * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
+    own = zt.ptr + rank * shard
+    w4 = S.windows.hann(N4)
+    p4 = _lib.StftParams(N4, H4, N4, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
+    _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(x4.ptr), L4, ch, L4, w4.ctypes.data_as(C.c_void_p), C.byref(p4), C.c_void_p(own), None, _lib.DEVICE))
+    ctx.sync()
+    before = np.empty((64, N4), np.complex64)
+    _lib.check(lib.nxsig_download(ctx.handle, before.ctypes.data_as(C.c_void_p), C.c_void_p(own), before.nbytes))
+    counts = [shard] * world
+    group.allgather([own], counts, [zt.ptr])  # warm-up (connection set-up, first-touch of the peers' buffers)
+    group.barrier()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        group.allgather([own], counts, [zt.ptr])
+    ctx.sync()
+    group.barrier()
+    dt = (time.perf_counter() - t0) / reps
+    dt = group.allreduce([dt], "max")[0]
+    after = np.empty((64, N4), np.complex64)
+    _lib.check(lib.nxsig_download(ctx.handle, after.ctypes.data_as(C.c_void_p), C.c_void_p(own), after.nbytes))
+    # a peer's shard really arrived: rank r's slot is non-zero and differs from the own one (different seeds)
+    peer = (rank + 1) % world
+    got = np.empty((64, N4), np.complex64)
+    _lib.check(lib.nxsig_download(ctx.handle, got.ctypes.data_as(C.c_void_p), C.c_void_p(zt.ptr + peer * shard), got.nbytes))
+    recv = (world - 1) * shard / dt / 1e9
+    res = {"collective": "nxsig_group_allgather (RCCL ncclAllGather through the C ABI, in place), every rank's config-4 shard",
+           "workload": f"stft N=2048 hop=512, {ch} ch x {seconds} s per rank", "bytes_per_rank": int(shard), "world": world,
+           "bytes_received_per_gpu": int((world - 1) * shard), "ms": dt * 1e3, "recv_GBps_per_rank": recv,
+           "frac_of_xgmi_7x153": recv / (7 * 153.0), "own_shard_intact": bool(np.array_equal(before.view(np.uint32), after.view(np.uint32))),
+           "peer_shard_arrived": bool(world == 1 or (np.any(got != 0) and not np.array_equal(got.view(np.uint32), after.view(np.uint32))))}
+    if share_gpu:
+        res["note"] = "--share-gpu: the ranks share one device and talk over sockets, the rate says nothing about xGMI"
+    zt.free()
+    x4.free()
+    return res
+
+
+def reduce_secondary(sec, world, allreduce):
+    """N > 1: BASELINE configs 3 / 4 / 5 as the node runs them — every rank its own shard at the same time — reduced with
+    max-over-ranks of the per-rank mean kernel time (one all-reduce of three doubles).  A rank whose block failed contributes +inf."""
+    keys = [("roofline_istft", "config3", "frames"), ("roofline_stft2048", "config4", "frames"), ("roofline_fir", "config5", "samples")]
+    mine = [float(sec.get(k, {}).get("kernel_ms", 1e30)) for k, _, _ in keys]
+    worst = allreduce(mine, "max")
+    res = {}
+    for (k, name, unit), ms in zip(keys, worst):
+        d = sec.get(k, {})
+        if ms >= 1e29 or "algorithmic_bytes" not in d:
+            res[name] = {"error": d.get("error", "a rank failed this block"), "ranks": world}
+            continue
+        per_gpu = d["algorithmic_bytes"] / (ms * 1e-3) / 1e9
+        res[name] = {"workload": d["workload"] + f" — on each of {world} ranks at the same time", "ranks": world,
+                     "kernel_ms_max_over_ranks": ms, "kernel_ms_rank0": d["kernel_ms"],
+                     f"{unit}_per_s_total": world * d[unit] / (ms * 1e-3), "per_gpu_GBps": per_gpu, "per_gpu_frac": per_gpu / HBM_PEAK_GBS,
+                     "rank0": {kk: d[kk] for kk in ("frac", "kernel_us", "mix_ceiling") if kk in d}}
+    return res
 
 
 class FileControl:
@@ -249,6 +405,43 @@ class FileControl:
                 pass
 
 
+def self_spawn(args) -> int:
+    """`python bench.py --gpus N` with no RANK / WORLD_SIZE in the environment: start N copies of this script, one per GPU, with the
+    variables a launcher sets (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT).  Rank 0 inherits stdout
+    (the ONE JSON line), every rank inherits stderr.  Refuses — loudly, exit 2 — when the node has fewer than N GPUs (unless
+    --share-gpu, the one-GPU test mode)."""
+    import ctypes as C
+    import socket
+    import subprocess
+
+    from nx_signal_amd import _lib
+
+    n = args.gpus
+    ndev = C.c_int(0)
+    try:
+        _lib.check(_lib.load().nxsig_device_count(C.byref(ndev)))
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: cannot count GPUs ({e!r})", file=sys.stderr)
+        return 2
+    if ndev.value < n and not args.share_gpu:
+        print(f"bench.py: --gpus {n} requested but this node has {ndev.value} GPU(s); refusing to report a {n}-GPU line from fewer devices "
+              f"(--share-gpu is the one-GPU test mode)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NXSIG_BENCH_SELF_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr.fileno()))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
 def _which(exe):
     import shutil
 
@@ -268,6 +461,12 @@ def main():
                     help="TEST MODE for one-GPU boxes: every rank uses device LOCAL_RANK %% device_count and claims its own "
                          "NCCL_HOSTID, so several ranks can form an RCCL communicator on ONE GPU (socket transport over lo); "
                          "exercises the launcher / rendezvous / collective path, the rate is NOT a scaling figure")
+    ap.add_argument("--secondary-seconds", type=int, default=600, help="length of the config 4 / 5 channels (BASELINE: 600 s; tests shrink it)")
+    ap.add_argument("--secondary-channels", type=int, default=8, help="channels per GPU of configs 4 / 5 (BASELINE: 64 channels / 8 GPUs)")
+    ap.add_argument("--istft-seconds", type=int, default=SECONDS, help="length of the config 3 streams (BASELINE: 60 s)")
+    ap.add_argument("--assembly-channels", type=int, default=None,
+                    help="N > 1: channels of the config-4-sized all-gather per rank (default: the whole shard = --secondary-channels; "
+                         "--share-gpu: 1, because N ranks x N shards must fit ONE device there)")
     ap.add_argument("--precondition", type=int, default=300,
                     help="max untimed launches spent settling the clocks before the warm-up steps (0 = none)")
     args = ap.parse_args()
@@ -278,10 +477,17 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one child per GPU, the environment a launcher would
+        # set), never a silent 1-GPU run that reports n_gpus: 1 for a --gpus N request
+        os.dup2(saved_stdout, 1)
+        sys.exit(self_spawn(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
+        if "WORLD_SIZE" in os.environ and world >= 1 and args.gpus > 1:
+            print(f"[bench rank {rank}] --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: measuring {world} rank(s)", file=sys.stderr)
         args.gpus = world
 
     import nx_signal_amd as S
@@ -351,10 +557,19 @@ def main():
             if filectl is not None:
                 filectl.barrier()
 
+    # ---- what a cold caller sees: the first 20 launches from idle, one HIP-event interval each
+    step()  # the first call of a shape builds the context's tables (window, twiddles: a one-time 4 ms): not a rate
+    ctx.sync()
+    ctx.timer_lap()
+    for _ in range(20):
+        step()
+        ctx.timer_lap()
+    cold20 = ctx.timer_laps()
+
     # ---- clock pre-conditioning (untimed, see the module docstring)
     precondition = {"launches": 0, "settled": False}
     if args.precondition > 0:
-        hist = []
+        hist = list(cold20)
         while len(hist) < args.precondition:
             ctx.timer_lap()
             for _ in range(10):
@@ -453,6 +668,27 @@ def main():
         zo, _, _ = O.stft(x0[: (nchk - 1) * HOP + N_FFT], w, overlap_length=N_FFT - HOP, fft_length=N_FFT, sampling_rate=SR)
         verify = float(np.max(np.abs(z0 - zo)) / np.max(np.abs(zo)))
 
+    # ---- BASELINE configs 3 / 4 / 5 at their full per-GPU shard: on every rank at the same time (N > 1: max-over-ranks)
+    for b in (xd, zd):
+        b.free()
+    sec, sec_multi, assembly4 = {}, None, None
+    if not args.no_secondary:
+        sec = secondary_rooflines(ctx, lib, S, _lib, C, barrier=barrier if world > 1 else None, seconds3=args.istft_seconds,
+                                  seconds45=args.secondary_seconds, channels45=args.secondary_channels)
+        sec.pop("_z4", None)
+        if world > 1:
+            try:
+                sec_multi = reduce_secondary(sec, world, group.allreduce if group is not None else filectl.allreduce)
+            except Exception as e:  # noqa: BLE001
+                sec_multi = {"error": repr(e)[:200]}
+    if group is not None and world > 1 and not args.no_secondary:
+        ch = args.assembly_channels if args.assembly_channels is not None else (1 if args.share_gpu else args.secondary_channels)
+        secs = min(args.secondary_seconds, 60) if (args.share_gpu and args.assembly_channels is None) else args.secondary_seconds
+        try:
+            assembly4 = assembly_config4(ctx, group, lib, S, _lib, C, world, rank, ch, secs, args.share_gpu)
+        except Exception as e:  # noqa: BLE001
+            assembly4 = {"error": repr(e)[:200]}
+
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -490,6 +726,9 @@ def main():
                 "kernel_us": {"min": round(min(laps) * 1e3, 1), "median": round(float(np.median(laps)) * 1e3, 1),
                               "p90": round(float(np.percentile(laps, 90)) * 1e3, 1), "max": round(max(laps) * 1e3, 1)},
             },
+            "value_cold": (world * B * M / (float(np.mean(cold20)) * 1e-3)) if cold20 else None,
+            "value_cold_note": "frames/s of the first 20 launches (after the one table-building call) following the idle period of the input upload, before any pre-conditioning "
+                               "(what a caller that issues a handful of calls from idle sees); `value` is the settled rate",
             "precondition": precondition,
             "comm": ({"backend": "RCCL via libnxsig.so (ncclCommInitRank)", "world": world, "torch": False} if group is not None
                      else ({"backend": "file control plane (RCCL group creation failed)", "world": world, "torch": False,
@@ -499,8 +738,11 @@ def main():
             "max_norm_err_vs_oracle": verify,
             "device": ctx.name(),
         }
-        if world == 1 and not args.no_secondary:
-            out.update(secondary_rooflines(ctx, lib, S, _lib, C))
+        out.update(sec)  # roofline_istft / roofline_stft2048 / roofline_fir of THIS rank (N = 1: the whole story)
+        if sec_multi is not None:
+            out.update(sec_multi)  # config3 / config4 / config5: the node's figures, max-over-ranks
+        if assembly4 is not None:
+            out["assembly_config4"] = assembly4
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         sys.stdout.flush()

@@ -88,5 +88,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return OUT
 
 
+def build_diag(force: bool = False, verbose: bool = True) -> str:
+    """tools/libnxsig_diag.so: the no-math traffic models bench.py times beside the iSTFT / FIR kernels (`mix_ceiling`).
+    Measurement infrastructure — libnxsig.so neither links nor loads it."""
+    src = os.path.join(ROOT, "tools", "diag_mix.hip")
+    out = os.path.join(ROOT, "tools", "libnxsig_diag.so")
+    if force or _stale(out, [src]):
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", src, "-o", out]
+        if verbose:
+            print("[nxsig build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_diag(force="--force" in sys.argv))

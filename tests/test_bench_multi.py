@@ -1,0 +1,107 @@
+"""bench.py at N > 1: `--gpus N` can never silently become a 1-GPU line, and under a launcher or on its own
+it measures BASELINE configs 3 / 4 / 5 on every rank plus the config-4-sized assembly.  The GPU cases run N RANKED processes with
+real RCCL on ONE device (--share-gpu: one NCCL_HOSTID per rank, socket transport) at reduced sizes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "3", "--warmup", "1", "--streams", "2", "--cpu-seconds", "0", "--precondition", "0", "--no-verify",
+         "--secondary-seconds", "20", "--secondary-channels", "2", "--istft-seconds", "10"]
+
+
+def test_gpus_n_without_devices_fails_loudly():
+    """no GPU here: `python bench.py --gpus 2` must exit non-zero with a message and print NO JSON line (never n_gpus: 1)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = "-1"  # also on a GPU box: no device visible
+    env["ROCR_VISIBLE_DEVICES"] = "-1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "GPU" in r.stderr
+
+
+def test_self_spawn_sets_a_launcher_environment(monkeypatch):
+    """the self-spawn path hands every child RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (checked without a GPU by
+    intercepting Popen and the device count)"""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import ctypes as C
+
+    import bench
+    from nx_signal_amd import _lib
+
+    class FakeLib:
+        def nxsig_device_count(self, p):
+            C.cast(p, C.POINTER(C.c_int))[0] = 4
+            return 0
+
+    seen = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None):
+            seen.append((cmd, env, stdout))
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(_lib, "load", lambda: FakeLib())
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    rc = bench.self_spawn(argparse.Namespace(gpus=4, share_gpu=False))
+    assert rc == 0 and len(seen) == 4
+    ports = {e["MASTER_PORT"] for _, e, _ in seen}
+    assert len(ports) == 1
+    for r, (cmd, env, out) in enumerate(seen):
+        assert env["RANK"] == str(r) and env["LOCAL_RANK"] == str(r) and env["WORLD_SIZE"] == "4" and env["MASTER_ADDR"] == "127.0.0.1"
+        assert cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+        assert (out is None) == (r == 0)  # only rank 0 owns stdout: ONE JSON line
+    # fewer devices than ranks: refused
+    seen.clear()
+    assert bench.self_spawn(argparse.Namespace(gpus=8, share_gpu=False)) == 2 and not seen
+
+
+def _check_line(line, n):
+    d = json.loads(line)
+    assert d["n_gpus"] == n and d["scaling"] == "weak"
+    assert d["comm"]["backend"].startswith("RCCL")
+    for k, unit in (("config3", "frames_per_s_total"), ("config4", "frames_per_s_total"), ("config5", "samples_per_s_total")):
+        assert d[k]["ranks"] == n and d[k][unit] > 0 and 0 < d[k]["per_gpu_frac"] < 1, d[k]
+        assert d[k]["kernel_ms_max_over_ranks"] >= d[k]["kernel_ms_rank0"] * 0.999
+    a = d["assembly_config4"]
+    assert a["world"] == n and a["own_shard_intact"] and a["peer_shard_arrived"] and a["recv_GBps_per_rank"] > 0
+    assert d["assembly"]["own_shard_intact"]
+    assert d["value"] > 0 and d["value_cold"] > 0
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2])
+def test_gpus_n_self_spawns_and_measures_configs_4_and_5(n):
+    """plain `python bench.py --gpus 2 --share-gpu` (no launcher): n_gpus == 2, RCCL, config 3 / 4 / 5 blocks, both assemblies"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--share-gpu"] + SMALL, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    _check_line(lines[0], n)
+
+
+@pytest.mark.gpu
+def test_driver_launch_line_four_ranks_share_gpu():
+    """the driver's own launch line at world 4 on one device"""
+    pytest.importorskip("torch")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--share-gpu"] + SMALL
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    _check_line(lines[0], 4)

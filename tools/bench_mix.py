@@ -1,0 +1,68 @@
+"""The iSTFT / FIR kernels beside their no-math traffic models (tools/diag_mix.hip) in ONE process, interleaved rounds: which part of
+the distance to the roofline is the access pattern's and which the math's.  usage: python tools/bench_mix.py [rounds=3]"""
+import ctypes as C, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import nx_signal_amd as S
+from nx_signal_amd import _lib
+import bench
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+ctx = S.Context(0); lib = _lib.load(); diag = bench.load_diag()
+diag.nxdiag_istft_mix2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int]
+diag.nxdiag_fir_mix2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int]
+stream = C.c_void_p(lib.nxsig_get_stream(ctx.handle))
+rng = np.random.Generator(np.random.PCG64(7))
+N, HOP, SR, L = 1024, 256, 48000, 48000 * 60
+M = (L - N) // HOP + 1
+
+def timeit(fn, reps=20, warm=10):
+    for _ in range(warm): fn()
+    ctx.sync(); ctx.timer_lap()
+    for _ in range(reps):
+        fn(); ctx.timer_lap()
+    return float(np.mean(ctx.timer_laps()))
+
+# ---- istft, config 3
+B = 16
+w = S.windows.hann(N)
+x = ctx.to_device(rng.standard_normal((B, L), dtype=np.float32))
+z, _, _ = S.stft(x, w, ctx=ctx, overlap_length=N - HOP, fft_length=N, sampling_rate=SR)
+y = ctx.empty((B, M * HOP + N - HOP), np.complex64)
+p = _lib.StftParams(N, HOP, N, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
+wp = w.ctypes.data_as(C.c_void_p)
+nb = B * M * 10240
+cases = {"istft kernel": lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(z.ptr), M, B, wp, C.byref(p), C.c_void_p(y.ptr), 1))}
+for wpc in (8, 12, 16):
+    for lb in (8, 16):
+        for halo in (3, 0):
+            cases[f"istft mix {wpc} runs/CU {lb:2d}-B loads halo {halo}"] = (lambda wpc=wpc, lb=lb, halo=halo: diag.nxdiag_istft_mix2(stream, C.c_void_p(z.ptr), C.c_void_p(y.ptr), B * M, wpc, halo, lb))
+res = {k: [] for k in cases}
+for r in range(rounds):
+    for k, fn in cases.items():
+        res[k].append(nb / (timeit(fn) * 1e-3) / 1e9)
+for k, v in res.items():
+    print(json.dumps({"case": k, "GBps": [round(a, 1) for a in v], "frac_of_8TBps": round(float(np.median(v)) / 8000, 4)}), flush=True)
+for b in (x, z, y): b.free()
+
+# ---- fir, config 5
+B4, L4 = 8, SR * 600
+x4 = ctx.empty((B4, L4), np.float32)
+chunk = rng.standard_normal(L4, dtype=np.float32)
+for r in range(B4):
+    xr = np.roll(chunk, 977 * r)
+    _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(x4.ptr + r * L4 * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
+y5 = ctx.empty((B4, L4), np.float32)
+h = S.filters.firwin(257, [4000.0], sampling_rate=float(SR)); hp = h.ctypes.data_as(C.c_void_p)
+nb = B4 * L4 * 8
+cases = {"fir kernel": lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, hp, 257, _lib.CONV_SAME, C.c_void_p(y5.ptr), 1))}
+for ppw in (8, 16):
+    for wide in (0, 1):
+        cases[f"fir mix {ppw} pairs/wave {'16' if wide else ' 8'}-B accesses"] = (lambda ppw=ppw, wide=wide: diag.nxdiag_fir_mix2(stream, C.c_void_p(x4.ptr), C.c_void_p(y5.ptr), B4, L4, ppw, wide))
+res = {k: [] for k in cases}
+for r in range(rounds):
+    for k, fn in cases.items():
+        res[k].append(nb / (timeit(fn, 10, 5) * 1e-3) / 1e9)
+for k, v in res.items():
+    print(json.dumps({"case": k, "GBps": [round(a, 1) for a in v], "frac_of_8TBps": round(float(np.median(v)) / 8000, 4)}), flush=True)

@@ -1,0 +1,129 @@
+// No-math traffic models of the iSTFT and FIR kernels in their SHIPPED launch geometry, as a tiny shared library that bench.py
+// loads next to libnxsig.so so that `roofline_istft.mix_ceiling` / `roofline_fir.mix_ceiling` are measured in the same process, on
+// the same box and stream as the kernels they bound.  Measurement infrastructure: libnxsig.so never links or
+// loads this file, and nothing here computes a result anybody uses.
+//
+//   nxdiag_istft_mix : k_istft_wave<1024, R = 4, DEEP>'s stream — 8 resident waves per CU, each walks one run of consecutive frames
+//                      (R - 1 halo frames in front are read, not written), 8 KiB non-temporal 8-byte loads per frame issued two
+//                      frames ahead, 2 KiB of non-temporal 16-byte stores per frame.
+//   nxdiag_fir_mix   : k_fir_wave<1024, STREAM, 4, HREG>'s stream — 257 taps, V = 768: a wave takes one block pair per iteration
+//                      (two 1024-sample blocks read with 8-byte loads, default policy; 2 V outputs leave through 8-byte `sc1 nt`
+//                      buffer stores), 8 pairs per wave, 4 waves per workgroup, one pair prefetched.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int LB>   // LB = bytes per lane per load: 8 (the shipped kernel's loads) or 16 (experiment)
+__global__ __launch_bounds__(256) void k_istft_mix(const v2f* __restrict__ z, v4f* __restrict__ y, long frames, long run_len, int halo) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long j0 = wave * run_len;
+  long j1 = j0 + run_len; if (j1 > frames) j1 = frames;
+  if (j0 >= j1) return;
+  const long m0 = j0 >= halo ? j0 - halo : 0;
+  v2f r0[16], r1[16];
+  auto issue = [&](v2f (&r)[16], long m) {
+    if (LB == 8) {
+      const v2f* p = z + (size_t)(m < frames ? m : frames - 1) * 1024 + lane;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) r[s] = __builtin_nontemporal_load(p + 64 * s);
+    } else {
+      const v4f* p = reinterpret_cast<const v4f*>(z + (size_t)(m < frames ? m : frames - 1) * 1024) + lane;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) { const v4f t = __builtin_nontemporal_load(p + 64 * s); r[2 * s] = v2f{t.x, t.y}; r[2 * s + 1] = v2f{t.z, t.w}; }
+    }
+  };
+  auto consume = [&](v2f (&r)[16], long m) {
+    v2f a = r[0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s) a += r[s];
+    if (m >= j0 && m < j1) {
+      __builtin_nontemporal_store(v4f{a.x, a.y, a.y, a.x}, y + (size_t)m * 128 + lane);
+      __builtin_nontemporal_store(v4f{a.y, a.x, a.x, a.y}, y + (size_t)m * 128 + 64 + lane);
+    }
+  };
+  issue(r0, m0); issue(r1, m0 + 1);
+  for (long m = m0; m < j1; m += 2) {
+    consume(r0, m); issue(r0, m + 2);
+    consume(r1, m + 1); issue(r1, m + 3);
+  }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long v = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
+template <int WIDE>   // 0: the shipped kernel's 8-byte accesses; 1: the pair's 1792-sample span once with 16-byte loads, 16-byte stores
+__global__ __launch_bounds__(256) void k_fir_mix(const float* __restrict__ x, float* __restrict__ y, long L, long pairs_per_row, long total, long chunk) {
+  constexpr int V = 768, TM1 = 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long p0 = (long)blockIdx.x * chunk;
+  long p1 = p0 + chunk; if (p1 > total) p1 = total;
+  v2f r[16];
+  auto issue = [&](long p) {
+    const long row = p / pairs_per_row, pi = p - row * pairs_per_row;
+    if (WIDE) {
+      const v4f* s4 = reinterpret_cast<const v4f*>(x + row * L + pi * 2 * V) + lane;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { const v4f t = s4[64 * q]; r[2 * q] = v2f{t.x, t.y}; r[2 * q + 1] = v2f{t.z, t.w}; }
+      r[14] = r[0]; r[15] = r[1];
+    } else {
+      const v2f* s2 = reinterpret_cast<const v2f*>(x + row * L + pi * 2 * V) + lane;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { r[q] = s2[64 * q]; r[8 + q] = s2[V / 2 + 64 * q]; }
+    }
+  };
+  if (p0 + wave < p1) issue(p0 + wave);
+  for (long p = p0 + wave; p < p1; p += 4) {
+    v2f acc = r[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) acc += r[q];
+    issue(p + 4 < p1 ? p + 4 : p);
+    const long row = p / pairs_per_row, pi = p - row * pairs_per_row;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(y + row * L + pi * 2 * V + TM1, 2 * V * 4);
+    if (WIDE) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const v2f o = acc * (float)(j + 1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{o.x, o.y, o.y, o.x}), rs, lane * 16 + 1024 * j, 0, 18);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const v2f o = acc * (float)(j + 1);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, o), rs, lane * 8 + 512 * j, 0, 18);
+      }
+    }
+  }
+}
+
+extern "C" {
+// z: c64[frames][1024] (8 KiB per frame), y: c64[frames][256] (2 KiB per frame); returns 0 or a hipError_t
+int nxdiag_istft_mix2(void* stream, const void* z, void* y, long frames, int waves_per_cu, int halo, int load_bytes) {
+  int dev = 0; hipDeviceProp_t pr;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 1;
+  const long waves = (long)pr.multiProcessorCount * waves_per_cu;
+  const long run_len = (frames + waves - 1) / waves;
+  const unsigned grid = (unsigned)(((frames + run_len - 1) / run_len + 3) / 4);
+  if (load_bytes == 16) hipLaunchKernelGGL(k_istft_mix<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
+  else hipLaunchKernelGGL(k_istft_mix<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
+  return (int)hipGetLastError();
+}
+int nxdiag_istft_mix(void* stream, const void* z, void* y, long frames, int waves_per_cu, int halo) { return nxdiag_istft_mix2(stream, z, y, frames, waves_per_cu, halo, 8); }
+// x, y: f32[rows][L]
+int nxdiag_fir_mix2(void* stream, const void* x, void* y, long rows, long L, int pairs_per_wave, int wide) {
+  const long V = 768;
+  const long pairs_per_row = (L - 1024 - V) / (2 * V);
+  const long total = rows * pairs_per_row, chunk = 4L * pairs_per_wave;
+  const dim3 grid((unsigned)((total + chunk - 1) / chunk));
+  if (wide) hipLaunchKernelGGL(k_fir_mix<1>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, L, pairs_per_row, total, chunk);
+  else hipLaunchKernelGGL(k_fir_mix<0>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, L, pairs_per_row, total, chunk);
+  return (int)hipGetLastError();
+}
+int nxdiag_fir_mix(void* stream, const void* x, void* y, long rows, long L, int pairs_per_wave) { return nxdiag_fir_mix2(stream, x, y, rows, L, pairs_per_wave, 0); }
+}

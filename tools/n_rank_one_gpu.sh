@@ -11,7 +11,7 @@ OUT=${2:-gpurun_out/n_rank}
 mkdir -p "$OUT"
 export NCCL_SOCKET_IFNAME=lo NCCL_IB_DISABLE=1 NCCL_DEBUG=WARN
 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port 29541 \
-  bench.py --gpus "$N" --steps 10 --warmup 2 --streams 4 --cpu-seconds 0 --share-gpu > "$OUT/bench_${N}_ranks.json" 2> "$OUT/bench_${N}_ranks.err"
+  bench.py --gpus "$N" --steps 10 --warmup 2 --streams 4 --cpu-seconds 0 --share-gpu ${NXSIG_BENCH_EXTRA:-} > "$OUT/bench_${N}_ranks.json" 2> "$OUT/bench_${N}_ranks.err"
 echo "exit $?"
 cat "$OUT/bench_${N}_ranks.json"
 grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl\|^W0\|^\*\*\*" "$OUT/bench_${N}_ranks.err" | tail -8

@@ -98,6 +98,13 @@ int nxsig_abi_version(void);
 int nxsig_device_count(int* count);
 int nxsig_ctx_create(int device, nxsig_ctx** out);
 void nxsig_ctx_destroy(nxsig_ctx* ctx);
+/* Dispatch / geometry switches of ONE context ("Switches").  nxsig_ctx_create reads the NXSIG_<NAME> variables of
+ * the process environment once; after that no call looks at the environment — a launch only reads the context's switches, and
+ * these three functions change them at run time (A/B sweeps, tests).  `name` is "NXSIG_FOO" or "FOO"; unknown names are
+ * NXSIG_ERR_INVALID_ARG.  clear(name = NULL) returns every switch to the launchers' defaults. */
+int nxsig_ctx_set_tuning(nxsig_ctx* ctx, const char* name, int32_t value);
+int nxsig_ctx_get_tuning(nxsig_ctx* ctx, const char* name, int32_t* value, int32_t* is_set);
+int nxsig_ctx_clear_tuning(nxsig_ctx* ctx, const char* name);
 const char* nxsig_last_error(void); /* thread-local, valid until the next call on this thread */
 /* human readable device line ("AMD Instinct MI355X gfx950 256 CUs") into buf */
 int nxsig_device_name(nxsig_ctx* ctx, char* buf, size_t buflen);

@@ -62,6 +62,9 @@ SIGNATURES = {
     "nxsig_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "nxsig_ctx_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
     "nxsig_ctx_destroy": (None, [_p]),
+    "nxsig_ctx_set_tuning": (C.c_int, [_p, C.c_char_p, _i32]),
+    "nxsig_ctx_get_tuning": (C.c_int, [_p, C.c_char_p, C.POINTER(_i32), C.POINTER(_i32)]),
+    "nxsig_ctx_clear_tuning": (C.c_int, [_p, C.c_char_p]),
     "nxsig_last_error": (C.c_char_p, []),
     "nxsig_device_name": (C.c_int, [_p, C.c_char_p, _sz]),
     "nxsig_alloc": (C.c_int, [_p, _sz, C.POINTER(_p)]),

@@ -301,7 +301,6 @@ struct Staged {
     if (e <= a) return;
     unsigned hw = std::thread::hardware_concurrency();
     unsigned T = hw >= 8 ? 4 : 1;  // more threads contend on the process' mmap lock: 8 / 16 / 32 measured slower
-    if (const char* v = std::getenv("NXSIG_PREFAULT_THREADS")) { const int n = std::atoi(v); if (n >= 1 && n <= 64) T = (unsigned)n; }
     const size_t per = (((e - a) / T) + page - 1) & ~(size_t)(page - 1);
     auto work = [](uintptr_t s0, uintptr_t s1) {
       const uintptr_t page = 4096;
@@ -320,9 +319,8 @@ struct Staged {
     for (auto& t : th) t.join();
   }
   int out_copy(void* host, const void* dev, size_t bytes) {
-    size_t CH = (size_t)32 << 20;
-    if (const char* v = std::getenv("NXSIG_D2H_CHUNK_MB")) { const int n = std::atoi(v); if (n >= 1 && n <= 4096) CH = (size_t)n << 20; }
-    if (bytes < ((size_t)32 << 20) || env_flag("NXSIG_NO_PREFAULT")) {
+    const size_t CH = (size_t)32 << 20;
+    if (bytes < ((size_t)32 << 20) || tune(c, kT_NO_PREFAULT, 0)) {
       NXSIG_HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
       NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));
       return NXSIG_OK;
@@ -344,10 +342,6 @@ struct Staged {
     }
     return NXSIG_OK;
   }
-  static bool env_flag(const char* name) {
-    const char* v = std::getenv(name);
-    return v && *v && *v != '0';
-  }
 };
 
 }  // namespace nxsig
@@ -366,6 +360,28 @@ using namespace nxsig;
   Ctx* c = reinterpret_cast<Ctx*>(ctx);                                                 \
   DeviceGuard guard(c);                                                                 \
   if (!guard.ok) return set_error(NXSIG_ERR_HIP, "hipSetDevice failed");
+
+namespace nxsig {
+static const char* const kTuneNames[kTuneCount] = {
+#define NXSIG_X(n) "NXSIG_" #n,
+    NXSIG_TUNABLES(NXSIG_X)
+#undef NXSIG_X
+};
+const char* tuning_name(int key) { return key >= 0 && key < kTuneCount ? kTuneNames[key] : ""; }
+int tuning_index(const char* name) {
+  if (!name) return -1;
+  for (int k = 0; k < kTuneCount; ++k)
+    if (!std::strcmp(name, kTuneNames[k]) || !std::strcmp(name, kTuneNames[k] + 6)) return k;
+  return -1;
+}
+// the library's ONE look at the process environment for its switches: at context creation, never in a launch
+void tuning_from_env(Tuning* t) {
+  for (int k = 0; k < kTuneCount; ++k) {
+    const char* v = std::getenv(kTuneNames[k]);
+    if (v && *v) { t->v[k] = (int32_t)std::strtol(v, nullptr, 10); t->set[k] = true; }
+  }
+}
+}  // namespace nxsig
 
 static int check_mem(int32_t mem) {
   if (mem != NXSIG_HOST && mem != NXSIG_DEVICE) return set_error(NXSIG_ERR_INVALID_ARG, "mem must be NXSIG_HOST or NXSIG_DEVICE");
@@ -389,6 +405,43 @@ int nxsig_device_count(int* count) {
   NXSIG_API_END
 }
 
+int nxsig_ctx_set_tuning(nxsig_ctx* ctx, const char* name, int32_t value) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  const int k = tuning_index(name);
+  if (k < 0) return set_error(NXSIG_ERR_INVALID_ARG, std::string("no such switch: ") + (name ? name : "(null)"));
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->tuning.v[k] = value;
+  c->tuning.set[k] = true;
+  if (k == kT_POOL_MAX_MB) c->pool_cap = 0;  // decided again at the next nxsig_free
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_ctx_get_tuning(nxsig_ctx* ctx, const char* name, int32_t* value, int32_t* is_set) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  const int k = tuning_index(name);
+  if (k < 0) return set_error(NXSIG_ERR_INVALID_ARG, std::string("no such switch: ") + (name ? name : "(null)"));
+  if (value) *value = c->tuning.v[k];
+  if (is_set) *is_set = c->tuning.set[k] ? 1 : 0;
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
+int nxsig_ctx_clear_tuning(nxsig_ctx* ctx, const char* name) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (name == nullptr) { c->tuning = Tuning(); return NXSIG_OK; }
+  const int k = tuning_index(name);
+  if (k < 0) return set_error(NXSIG_ERR_INVALID_ARG, std::string("no such switch: ") + name);
+  c->tuning.set[k] = false;
+  c->tuning.v[k] = 0;
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
 int nxsig_ctx_create(int device, nxsig_ctx** out) {
   NXSIG_API_BEGIN
   if (!out) return set_error(NXSIG_ERR_INVALID_ARG, "out is null");
@@ -402,6 +455,7 @@ int nxsig_ctx_create(int device, nxsig_ctx** out) {
   hipDeviceProp_t prop;
   NXSIG_HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount;
+  tuning_from_env(&c->tuning);
   c->dev_name = std::string(prop.name) + " " + prop.gcnArchName + " " + std::to_string(prop.multiProcessorCount) + " CUs";
   NXSIG_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   NXSIG_HIP_TRY(hipEventCreate(&c->ev_start));
@@ -497,7 +551,7 @@ int nxsig_free(nxsig_ctx* ctx, void* dptr) {
   if (c->pool_cap == 0) {  // NXSIG_POOL_MAX_MB (0 disables caching); default: a quarter of the device memory
     size_t free_b = 0, total_b = 0;
     c->pool_cap = 1;
-    if (const char* v = std::getenv("NXSIG_POOL_MAX_MB")) c->pool_cap = (size_t)std::strtoull(v, nullptr, 10) << 20 | 1;
+    if (c->tuning.set[kT_POOL_MAX_MB]) c->pool_cap = (size_t)(c->tuning.v[kT_POOL_MAX_MB] < 0 ? 0 : c->tuning.v[kT_POOL_MAX_MB]) << 20 | 1;
     else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) c->pool_cap = total_b / 4 | 1;
   }
   const size_t sz = it->second;

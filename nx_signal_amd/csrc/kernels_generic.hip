@@ -1104,7 +1104,7 @@ static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows
     int rcw = launch_fft_rows_wave(c, in, in_is_real, rows, n_in, K, inverse, post_window, post_scale, has_post_scale, out, &handled, clean);
     if (rcw || handled) return rcw;
   }
-  if ((is_pow2(K) && (K > kMaxLdsPow2 || K >= fft_tiled_min())) || (!is_pow2(K) && K > 4096)) {
+  if ((is_pow2(K) && (K > kMaxLdsPow2 || K >= fft_tiled_min(c))) || (!is_pow2(K) && K > 4096)) {
     // beyond the LDS-resident kernels: four-step / Bluestein rows in HBM (kernels_nd.hip), then the istft epilogue if any
     int rcb = launch_fft_big(c, in, in_is_real, rows, n_in, K, inverse, out, clean);
     if (rcb) return rcb;
@@ -1530,11 +1530,11 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
   int maxw = 1;
   for (int b = 0; b < mel_bins; ++b) maxw = std::max(maxw, band[b].y - band[b].x);
   const bool wlds = (size_t)mel_bins * maxw <= 4096;
-  static const bool tile_off = [] { const char* v = std::getenv("NXSIG_MEL_TILE"); return v && std::atoi(v) == 0; }();
+  const bool tile_off = tune(c, kT_MEL_TILE, 1) == 0;
   int fb_log2 = -1;
   size_t lds = 0;
-  static const size_t budget = [] { const char* v = std::getenv("NXSIG_MEL_LDS_KB"); return (size_t)(v ? std::atoi(v) : 56) * 1024; }();
-  static const int nt_knob = [] { const char* v = std::getenv("NXSIG_MEL_NT"); return v ? std::atoi(v) : 0; }();
+  const size_t budget = (size_t)tune(c, kT_MEL_LDS_KB, 56) * 1024;
+  const int nt_knob = 0;
   for (int l = 6; l >= 0 && !tile_off && mel_bins <= 256; --l) {
     const size_t need = ((size_t)(1 << l) * (hs + mel_bins) + maxw + (wlds ? (size_t)mel_bins * maxw : 0)) * sizeof(float);
     if (need + 6200 <= budget) { fb_log2 = l; lds = need; break; }   // + the kernel's static tables

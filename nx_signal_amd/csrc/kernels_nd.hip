@@ -434,8 +434,8 @@ static int fft_fourstep_tiled(Ctx* c, const void* in, bool in_is_real, int64_t r
   while (((int64_t)1 << lg) < K) ++lg;
   const int lg1 = (lg + 1) / 2, lg2 = lg - lg1;
   const int K1 = 1 << lg1, K2 = 1 << lg2;
-  static const int elems = [] { const char* v = std::getenv("NXSIG_FFT_TILE_ELEMS"); const int e = v ? std::atoi(v) : 8192; return e >= 1024 && e <= 16384 ? e : 8192; }();
-  static const int ntk = [] { const char* v = std::getenv("NXSIG_FFT_TILE_NT"); return v ? std::atoi(v) : 512; }();
+  const int elems = [&] { const int e = tune(c, kT_FFT_TILE_ELEMS, 8192); return e >= 1024 && e <= 16384 ? e : 8192; }();
+  const int ntk = tune(c, kT_FFT_TILE_NT, 512);
   const float2 *lo = nullptr, *hi = nullptr, *tw1 = nullptr, *tw2 = nullptr;
   int rc = twolevel_tables(c, K, &lo, &hi);
   if (rc) return rc;
@@ -484,7 +484,7 @@ static int fft_fourstep_tiled(Ctx* c, const void* in, bool in_is_real, int64_t r
 static int fft_columns_tiled(Ctx* c, const void* src, bool src_real, int64_t outer, int64_t na, int64_t inner, int64_t K, bool inverse,
                              float2* dst, bool* handled) {
   *handled = false;
-  static const bool on = [] { const char* v = std::getenv("NXSIG_FFT_COLUMNS"); return !(v && std::atoi(v) == 0); }();
+  const bool on = tune(c, kT_FFT_COLUMNS, 1) != 0;
   if (!on || !nd_is_pow2(K) || K < 16 || K > 1024 || (inner & 7) != 0 || outer < 1) return NXSIG_OK;
   int lg = 0;
   while (((int64_t)1 << lg) < K) ++lg;
@@ -556,22 +556,22 @@ static int fft_bluestein_big(Ctx* c, const void* in, bool in_is_real, int64_t ro
   return NXSIG_OK;
 }
 
-int64_t fft_tiled_min() {
-  static const int64_t v = [] { const char* e = std::getenv("NXSIG_FFT_TILED_MIN"); const int64_t m = e ? std::atoll(e) : 8192; return m < 8192 ? 8192 : m; }();
-  return v;
+int64_t fft_tiled_min(const Ctx* c) {
+  const int64_t m = tune(c, kT_FFT_TILED_MIN, 8192);
+  return m < 8192 ? 8192 : m;
 }
 
 // rows of any length.  Lengths the LDS-resident kernels cover go straight to launch_fft.
 int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out, bool clean) {
   if (rows == 0) return NXSIG_OK;
   if (K < 1 || n_in < 1) return set_error(NXSIG_ERR_INVALID_ARG, "fft: lengths must be >= 1");
-  const bool small = (nd_is_pow2(K) && K <= 8192 && K < fft_tiled_min()) || (!nd_is_pow2(K) && K <= 4096);
+  const bool small = (nd_is_pow2(K) && K <= 8192 && K < fft_tiled_min(c)) || (!nd_is_pow2(K) && K <= 4096);
   if (small) {
     if (n_in > 0x7fffffff) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: rows longer than 2^31");
     return launch_fft(c, in, in_is_real, rows, (int32_t)n_in, (int32_t)K, inverse, out, clean);
   }
   if (nd_is_pow2(K)) {
-    static const bool tiled = [] { const char* v = std::getenv("NXSIG_FFT_TILED"); return !(v && std::atoi(v) == 0); }();
+    const bool tiled = tune(c, kT_FFT_TILED, 1) != 0;
     if (tiled && K <= ((int64_t)1 << 20)) return fft_fourstep_tiled(c, in, in_is_real, rows, n_in, K, inverse, out, clean);
     return fft_fourstep(c, in, in_is_real, rows, n_in, K, inverse, out, clean);
   }
@@ -700,7 +700,7 @@ int launch_fftconvolve_nd(Ctx* c, const void* a, bool a_is_real, const int64_t* 
                           int rank, int mode, void* out, int64_t* out_shape) {
   if (rank < 1 || rank > 8) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: rank must be in [1, 8]");
   int64_t full[8], padded[8], res[8], start[8];
-  static const bool pow2_lengths = [] { const char* v = std::getenv("NXSIG_CONV_POW2"); return !(v && std::atoi(v) == 0); }();
+  const bool pow2_lengths = tune(c, kT_CONV_POW2, 1) != 0;
   std::vector<int32_t> axes;
   std::vector<int64_t> lens;
   for (int d = 0; d < rank; ++d) {
@@ -989,7 +989,7 @@ int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t*
   }
   if (g.total > (int64_t)0x7fffffff * kT) return set_error(NXSIG_ERR_UNSUPPORTED, "convolve: result too large for one launch");
   {
-    static const bool fast_on = [] { const char* v = std::getenv("NXSIG_DIRECT_FAST"); return !(v && std::atoi(v) == 0); }();
+    const bool fast_on = tune(c, kT_DIRECT_FAST, 1) != 0;
     bool lead_one = true;
     for (int d = 0; d + 2 < rank; ++d) lead_one = lead_one && sk[d] == 1;
     if (fast_on && lead_one && sk[rank - 1] <= 0x7fffffff && (rank < 2 || sk[rank - 2] <= 0x7fffffff)) {

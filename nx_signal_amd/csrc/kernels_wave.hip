@@ -875,7 +875,7 @@ int launch_stft_wave_8k(Ctx* c, const StftLaunch& s, bool* handled);            
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   *handled = false;
   if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
-  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   if (s.window_padK == nullptr) return NXSIG_OK;
   // 4 waves per workgroup everywhere: 8 / 12 / 16 measured equal or slower (tables are re-read from L2 either way)
   switch (s.K) {
@@ -895,7 +895,7 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
     int rc20 = launch_stft_r20(c, s, handled, nullptr);
     if (rc20 || *handled) return rc20;
   }
-  if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0)) {
+  if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !tune(c, kT_DISABLE_BLUE_WAVE, 0)) {
     *handled = true;  // non-power-of-two: Bluestein through the 1024- (Kb <= 512) or 2048-point core
     return s.K <= 512 ? launch_blue_wave<1024>(c, s) : launch_blue_wave<2048>(c, s);
   }
@@ -953,15 +953,15 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   // Two-frames-ahead prefetch (DEEP, round 3): 8 resident waves per CU with 16 KB of loads in flight each instead of 12 with 8 KB.
   // Interleaved A/B sweeps (tools/sweep_istft.py NXSIG_ISTFT_DEEP 0 1; 1 / 2 / 4 / 8 / 16 / 32 streams of 60 s): +1.5 / +8 / +14 /
   // +10 / +2 / +0.4 %; hop 128 / 512: +1.3 / +3 %; bench.py's laps of config 3: +1.3 %.  NXSIG_ISTFT_DEEP=0 selects the one-ahead form.
-  const bool deep = !DBL && !HALF && !s.filt && env_int("NXSIG_ISTFT_DEEP", 1);
+  const bool deep = !DBL && !HALF && !s.filt && tune(c, kT_ISTFT_DEEP, 1);
   // the N = 512 pair kernel likewise at hop = N / 4 (2 / 8 / 16 streams of 60 s: +13 / +9 / +5 %); at hop N / 8 and N / 2 the
   // one-ahead form with three waves per SIMD stays ahead (-4 % / -4 ... -7 % for the deep form) and is kept there
-  const bool half_deep = HALF && env_int("NXSIG_ISTFT_HALF_DEEP", R == 4 ? 1 : 0);
-  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", (DBL || s.filt || deep || half_deep) ? 8 : 12);  // the filtered variant holds 16 more
+  const bool half_deep = HALF && tune(c, kT_ISTFT_HALF_DEEP, R == 4 ? 1 : 0);
+  const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, (DBL || s.filt || deep || half_deep) ? 8 : 12);  // the filtered variant holds 16 more
                                                                                          // complex values per lane: 2 waves per SIMD  // = resident waves per CU: one even round
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   // (a floor of 8 left a single 60 s stream with 1 406 runs of 8 + 3 frames for 2 048 wave slots: 2.58 TB/s against 2.96 at 4 ... 6)
-  const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", (!HALF && !DBL) ? 4 : 8);   // (N = 512 / 2048: 8 stays 1 ... 3 % ahead)
+  const int min_run = tune(c, kT_ISTFT_MIN_RUN, (!HALF && !DBL) ? 4 : 8);   // (N = 512 / 2048: 8 stays 1 ... 3 % ahead)
   if (run_len < min_run) run_len = min_run;
   if (HALF) run_len = (run_len + 1) & ~(int64_t)1;  // frame pairs: runs start at even segments
   a.run_len = run_len;
@@ -1003,18 +1003,16 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   } else {
     a.twH = nullptr;
     const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8;
-    // the spectrogram is read once (5 % run halos aside): non-temporal loads, +2…5 % in interleaved A/B runs (NXSIG_ISTFT_NT_LOADS=0: off)
+    // the spectrogram is read once (5 % run halos aside): non-temporal loads (+2…5 % in interleaved A/B runs, round 2; the
+    // default-policy instantiation went with its switch in round 4)
     if (s.filt) {
       if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
       else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     } else if (deep) {
       if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, false, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
       else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, false, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-    } else if (env_int("NXSIG_ISTFT_NT_LOADS", 1)) {
-      if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, false, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-      else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, false, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-    } else if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-    else hipLaunchKernelGGL((k_istft_wave<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    } else if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, false, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, false, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
   }
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
@@ -1042,11 +1040,11 @@ static int launch_istft_wave_quad(Ctx* c, const IstftLaunch& s, const float* win
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t units_per_row = (a.segs_per_row + J - 1) / J;
   const int64_t total_units = units_per_row * s.batch;
-  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", 12);  // = the resident waves per CU (round 3: 3.63 / 3.38 TB/s against 3.47 / 3.33 at 24
+  const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, 12);  // = the resident waves per CU (round 3: 3.63 / 3.38 TB/s against 3.47 / 3.33 at 24
                                                                     // for N = 256 / 128, 8 x 60 s; a two-units-ahead prefetch like k_istft_wave's
                                                                     // DEEP form measured -3 ... +3 % here and was not kept)
   int64_t run_len = (total_units + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
-  const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", 8);
+  const int min_run = tune(c, kT_ISTFT_MIN_RUN, 8);
   if (run_len < min_run) run_len = min_run;
   a.run_len = run_len;
   a.runs_per_row = (units_per_row + run_len - 1) / run_len;
@@ -1094,9 +1092,9 @@ static int launch_istft_wave_4k(Ctx* c, const IstftLaunch& s, const float* windo
     a.twH = reinterpret_cast<const v2f*>(d4);
   }
   const int64_t total_segs = a.segs_per_row * s.batch;
-  const int waves_per_cu = env_int("NXSIG_ISTFT4K_RUNS_PER_CU", 4);  // one wave per SIMD
+  const int waves_per_cu = 4;  // one wave per SIMD
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
-  const int min_run = env_int("NXSIG_ISTFT_MIN_RUN", 8);
+  const int min_run = tune(c, kT_ISTFT_MIN_RUN, 8);
   if (run_len < min_run) run_len = min_run;
   a.run_len = run_len;
   a.runs_per_row = (a.segs_per_row + run_len - 1) / run_len;
@@ -1117,10 +1115,10 @@ int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, boo
 int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   *handled = false;
   if (s.M == 0 || s.batch == 0) return NXSIG_OK;
-  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   if (window_host == nullptr) return NXSIG_OK;
   // a spectrum filter is fused into the N = 1024 kernel only; elsewhere the caller multiplies first (launch_istft)
-  if (s.filt && (s.K != 1024 || env_int("NXSIG_DISABLE_FUSED_FILTER", 0))) return NXSIG_OK;
+  if (s.filt && (s.K != 1024 || tune(c, kT_DISABLE_FUSED_FILTER, 0))) return NXSIG_OK;
   if (s.K == 512 && s.N == 512) {  // two frames per 1024-point inverse FFT
     if (s.hop != 64 && s.hop != 128 && s.hop != 256 && s.hop != 512) return NXSIG_OK;
     if (s.M < 2 * (512 / s.hop) - 1) return NXSIG_OK;
@@ -1173,7 +1171,7 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
       default: return launch_istft_wave_R<8, 4, false, true>(c, s, s.window, window_host);
     }
   }
-  if (s.K == 4096 && s.N == 4096 && !env_int("NXSIG_DISABLE_4K", 0)) {  // four passes through the 1024-point inverse core per frame
+  if (s.K == 4096 && s.N == 4096 && !tune(c, kT_DISABLE_4K, 0)) {  // four passes through the 1024-point inverse core per frame
     if (s.hop != 512 && s.hop != 1024 && s.hop != 2048 && s.hop != 4096) return NXSIG_OK;
     if (s.M < 2 * (4096 / s.hop) - 1) return NXSIG_OK;
     int rc5 = ensure_wave_tables_1024(c);
@@ -1227,7 +1225,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   *handled = false;
   constexpr int R3 = K / 256, XCH = K + K / 16 + 16;
   if (s_in.out_len <= 0 || s_in.batch == 0) return NXSIG_OK;
-  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   if (s_in.taps > K / 2 + 1) return NXSIG_OK;  // a block would be < 50 % efficient: the generic path uses bigger blocks
   // The block geometry may treat the filter as LONGER than it is: trailing zero taps change nothing (the spectrum H is that of
   // the taps zero-padded to K either way), only the valid part of a block shrinks.  Rounding taps - 1 up to a multiple of 32
@@ -1237,7 +1235,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   {
     const int q = K == 1024 ? 32 : 128;
     const int eff = ((s_in.taps - 1 + q - 1) / q) * q + 1;
-    if (eff <= K / 2 + 1 && env_int("NXSIG_FIR_PAD_TAPS", 1)) s.taps = eff;
+    if (eff <= K / 2 + 1 && tune(c, kT_FIR_PAD_TAPS, 1)) s.taps = eff;
   }
   int rc = ensure_wave_tables(c, K);
   if (rc) return rc;
@@ -1264,7 +1262,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   // hit whole cache lines when the rows of y are 128-byte aligned.  With mode :same, out_start = div(taps - 1, 2) is rarely
   // aligned by itself, and partial-line streaming writes cost a factor 2 (measured: 255 taps :same 2.2 -> 4.4 TB/s).  The shift
   // is applied by moving the signal's origin: x' = x + phase, valid indices [-phase, L - phase), out_start' = out_start - phase.
-  const int64_t phase = env_int("NXSIG_FIR_PHASE", 1) ? (s.out_start % 32) : 0;
+  const int64_t phase = tune(c, kT_FIR_PHASE, 1) ? (s.out_start % 32) : 0;
   const int64_t out_start = s.out_start - phase;
   a.x = s.x + phase; a.xlo = -phase; a.xhi = s.L - phase;
   a.L = s.L; a.batch_stride = s.batch_stride; a.batch = s.batch; a.taps = s.taps;
@@ -1283,7 +1281,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
                      ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 7) == 0);
   // the 32 x 32 kernel (kernels_wave_fir32.hip, 4-byte accesses: no alignment conditions) takes what the 8-byte kernel cannot;
   // where both apply the 8-byte kernel is ~4 % faster (NXSIG_FIR32: 0 never, 1 when needed, 2 always)
-  const int fir32_mode = env_int("NXSIG_FIR32", 1);
+  const int fir32_mode = tune(c, kT_FIR32, 1);
   const bool use32 = K == 1024 && (s.taps - 1) % 32 == 0 && (fir32_mode == 2 || (fir32_mode == 1 && !fast8));
   const bool fast = use32 || fast8;
   // interior pairs pb in [pb_lo, pb_hi): block pair (b1, b1+1), b1 = first_block + 2 pb, reads x'[b1 V - (taps-1) .. +V+K)
@@ -1306,13 +1304,13 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     }
     a.pb_lo = lo; a.pb_hi = hi;
   }
-  const bool hreg = K == 1024 && W <= 8 && env_int("NXSIG_FIR_HREG", 1);  // 156 VGPRs: three waves per SIMD
+  const bool hreg = K == 1024 && W <= 8 && tune(c, kT_FIR_HREG, 1);  // 156 VGPRs: three waves per SIMD
   const size_t lds = 256 * 8 + (size_t)R3 * 256 * 8 + (hreg ? 0 : (size_t)K * 8) + (size_t)W * XCH * 8;
   auto launch = [&](bool stream, int64_t units_per_row) -> int {
     if (units_per_row <= 0) return NXSIG_OK;
     a.units_per_row = units_per_row;
     a.total_units = units_per_row * s.batch;
-    const int units_per_wave = env_int("NXSIG_FIR_UNITS_PER_WAVE", 8);  // short chunks, many workgroups (see launch_wave)
+    const int units_per_wave = tune(c, kT_FIR_UNITS_PER_WAVE, 8);  // short chunks, many workgroups (see launch_wave)
     a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
     // the edge launch has few, slow (bounds-checked) units: one per wave so that they all run concurrently, unless every pair
     // goes through it (filters whose taps - 1 is not a multiple of 128)
@@ -1324,8 +1322,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_wave<K, false, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (hreg) {
-      if (stream && !env_int("NXSIG_FIR_SC1", 1)) hipLaunchKernelGGL((k_fir_wave<K, true, W, K == 1024, false>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-      else if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W, K == 1024>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W, K == 1024>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
       else hipLaunchKernelGGL((k_fir_wave<K, false, W, K == 1024>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     } else if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     else hipLaunchKernelGGL((k_fir_wave<K, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
@@ -1344,19 +1341,10 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
 }
 
 int launch_fir_wave(Ctx* c, const FirLaunch& s, bool* handled) {
-  // 2048-sample blocks (32 points per lane) for 514..1025 taps; NXSIG_FIR_K=2048 forces them for shorter filters
-  if (s.taps > 513 || env_int("NXSIG_FIR_K", 1024) == 2048) {
-    switch (env_int("NXSIG_FIR_W", 6)) {
-      case 4: return launch_fir_wave_W<4, 2048>(c, s, handled);
-      default: return launch_fir_wave_W<6, 2048>(c, s, handled);
-    }
-  }
-  switch (env_int("NXSIG_FIR_W", 4)) {
-    case 4: return launch_fir_wave_W<4>(c, s, handled);
-    case 7: return launch_fir_wave_W<7>(c, s, handled);
-    case 14: return launch_fir_wave_W<14>(c, s, handled);
-    default: return launch_fir_wave_W<4>(c, s, handled);
-  }
+  // 2048-sample blocks (32 points per lane, six waves per workgroup) for 514..1025 taps; four-wave workgroups on 1024-sample
+  // blocks otherwise (7- and 14-wave workgroups measured slower in round 2 and went with their switch in round 4)
+  if (s.taps > 513) return launch_fir_wave_W<6, 2048>(c, s, handled);
+  return launch_fir_wave_W<4>(c, s, handled);
 }
 
 }  // namespace nxsig

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_wave_8k(Wave8kArgs a) {
 int launch_stft_wave_8k(Ctx* c, const StftLaunch& s, bool* handled) {
   *handled = false;
   constexpr int W = 8, K = 1024, XCH = K + K / 16 + 16;
-  if (s.K != 8192 || s.fr.N > 8192 || env_int("NXSIG_DISABLE_8K", 0)) return NXSIG_OK;
+  if (s.K != 8192 || s.fr.N > 8192 || tune(c, kT_DISABLE_8K, 0)) return NXSIG_OK;
   if ((int)c->memo_win.size() != s.fr.N) return NXSIG_OK;  // the host copy of this call's window (ctx_window) is needed
   int rc = ensure_wave_tables(c, K);
   if (rc) return rc;
@@ -200,7 +200,7 @@ int launch_stft_wave_8k(Ctx* c, const StftLaunch& s, bool* handled) {
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
-  const int fpw = env_int("NXSIG_8K_FRAMES_PER_WAVE", 2);
+  const int fpw = 2;
   const int64_t big = (int64_t)1 << 62;
   if (s.fr.N < 8192)
     rc = s.has_scale ? go(k_stft_wave_8k<true, W, false, true>, m_hi - m_lo, big, m_lo, m_lo, fpw)

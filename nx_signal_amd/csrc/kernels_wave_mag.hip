@@ -9,7 +9,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
 int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool* handled) {
   *handled = false;
   if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
-  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   MelLaunch mel{0, nullptr, out, handled, kind};
   if (kind == 4 && s.K != 1024) return NXSIG_OK;   // packed one-sided form: fused for the pair front-end, two-step elsewhere
   switch (s.K) {
@@ -31,7 +31,7 @@ int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool
         if (rc20 || h20) return rc20;
       }
       if (kind == 3) return NXSIG_OK;
-      if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0))
+      if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !tune(c, kT_DISABLE_BLUE_WAVE, 0))
         return s.K <= 512 ? launch_blue_wave<1024, kSinkMag>(c, s, &mel) : launch_blue_wave<2048, kSinkMag>(c, s, &mel);
       return NXSIG_OK;
   }

@@ -9,7 +9,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
 int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled) {
   *handled = false;
   if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
-  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   MelLaunch mel{mel_bins, filters_host, out, handled};
   switch (s.K) {
     case 1024: return launch_wave<1024, kModePair, 4, 2, kSinkMel>(c, s, &mel);
@@ -24,7 +24,7 @@ int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float*
         int rc20 = launch_stft_r20(c, s, &h20, &mel);
         if (rc20 || h20) return rc20;
       }
-      if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !env_int("NXSIG_DISABLE_BLUE_WAVE", 0))
+      if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !tune(c, kT_DISABLE_BLUE_WAVE, 0))
         return s.K <= 512 ? launch_blue_wave<1024, kSinkMel>(c, s, &mel) : launch_blue_wave<2048, kSinkMel>(c, s, &mel);
       return NXSIG_OK;
   }

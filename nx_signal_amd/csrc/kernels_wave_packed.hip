@@ -199,7 +199,7 @@ static int launch_istft_packed_R(Ctx* c, const IstftLaunch& s, const float* wind
     a.twH = reinterpret_cast<const v2f*>(dh);
   }
   const int64_t total_segs = a.segs_per_row * s.batch;
-  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", 12);
+  const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, 12);
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   if (run_len < 8) run_len = 8;
   run_len = (run_len + 1) & ~(int64_t)1;
@@ -220,7 +220,7 @@ static int launch_istft_packed_R(Ctx* c, const IstftLaunch& s, const float* wind
 int launch_istft_packed_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   *handled = false;
   if (s.M == 0 || s.batch == 0 || window_host == nullptr || s.filt) return NXSIG_OK;
-  if (env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   if (s.K != 1024 || s.N != 1024) return NXSIG_OK;
   if (s.hop != 128 && s.hop != 256 && s.hop != 512 && s.hop != 1024) return NXSIG_OK;
   if (s.M < 2 * (1024 / s.hop) - 1) return NXSIG_OK;

@@ -311,7 +311,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   *handled = false;
   constexpr int W = 4, KB = 400, BUF = 1280;
   if (s.K != KB || s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
-  if (env_int("NXSIG_DISABLE_R20", 0) || env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_R20, 0) || tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   const int nuse = s.fr.N < KB ? s.fr.N : KB;
   if (5 * (int64_t)s.fr.hop + nuse > 2 * BUF) return NXSIG_OK;  // the unit's span must fit the wave's buffer
   R20Args b;
@@ -364,7 +364,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   b.units_per_row = (a.pairs_per_row + 2) / 3;
   b.total_units = b.units_per_row * s.batch;
   a.total_pairs = b.total_units;
-  b.fast_ok = env_int("NXSIG_R20_NO_PREFETCH", 0) ? 0 : 1;  // 16-byte register prefetch of aligned spans (measured: 5.35 vs 4.1-4.9 TB/s for loads at the point of use)
+  b.fast_ok = 1;  // 16-byte register prefetch of aligned spans (measured: 5.35 vs 4.1-4.9 TB/s for loads at the point of use)
   std::vector<float2> tw((size_t)KB);
   for (int n2 = 0; n2 < 20; ++n2)
     for (int k1 = 0; k1 < 20; ++k1) {
@@ -375,7 +375,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   int rc = ctx_table(c, 0x20A20ull, tw.data(), tw.size() * sizeof(float2), &dt);
   if (rc) return rc;
   b.tw = reinterpret_cast<const v2f*>(dt);
-  const int units_per_wave = env_int("NXSIG_R20_UNITS_PER_WAVE", sink == kSinkMel ? 8 : 2);  // the mel sink amortises its CSR preload
+  const int units_per_wave = (sink == kSinkMel ? 8 : 2);  // the mel sink amortises its CSR preload
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   const int64_t blocks = (b.total_units + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
@@ -556,7 +556,7 @@ int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, boo
   *handled = false;
   constexpr int W = 4, KB = 400, BUF = 1280, CMAX = 400;
   if (s.K != KB || s.N != KB || s.M == 0 || s.batch == 0 || window_host == nullptr) return NXSIG_OK;
-  if (env_int("NXSIG_DISABLE_R20", 0) || env_int("NXSIG_DISABLE_WAVE", 0)) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_R20, 0) || tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   const int hop = s.hop;
   if (hop < 2 || (hop & 1) || hop > KB) return NXSIG_OK;            // 16-byte LDS gathers need an even hop
   const int RP = (KB + hop - 1) / hop;
@@ -615,7 +615,7 @@ int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, boo
   const int64_t segs = (a.out_len + hop - 1) / hop;              // hop segments of the output (the last may be partial)
   a.units_per_row = (segs + 2) / 3;
   const int64_t total_units = a.units_per_row * s.batch;
-  const int waves_per_cu = env_int("NXSIG_ISTFT_RUNS_PER_CU", 8);  // = resident waves per CU (58 KB of LDS per workgroup)
+  const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, 8);  // = resident waves per CU (58 KB of LDS per workgroup)
   int64_t run_len = (total_units + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   if (run_len < 8) run_len = 8;
   a.run_len = run_len;

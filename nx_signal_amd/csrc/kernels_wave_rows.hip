@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64 * W) void k_fft_rows_wave_4k(RowsWaveArgs a) {
 int launch_fft_rows_wave(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse,
                          const float* post_window, float post_scale, bool has_post_scale, float2* out, bool* handled, bool clean) {
   *handled = false;
-  if ((K != 1024 && K != 2048 && K != 4096) || rows < 1 || env_int("NXSIG_DISABLE_WAVE_ROWS", 0)) return NXSIG_OK;
+  if ((K != 1024 && K != 2048 && K != 4096) || rows < 1 || tune(c, kT_DISABLE_WAVE_ROWS, 0)) return NXSIG_OK;
   if (post_window && (reinterpret_cast<uintptr_t>(post_window) & 7) != 0) return NXSIG_OK;
   const int C = K == 2048 ? 2048 : 1024;
   int rc = ensure_wave_tables(c, C);
@@ -165,7 +165,7 @@ int launch_fft_rows_wave(Ctx* c, const void* in, bool in_is_real, int64_t rows, 
   a.post_window = post_window; a.post_scale = post_scale; a.has_post_scale = has_post_scale ? 1 : 0; a.clean = clean ? 1 : 0;
   a.out = reinterpret_cast<v2f*>(out);
   constexpr int W = 4;
-  const int rpw = env_int("NXSIG_ROWS_PER_WAVE", K == 4096 ? 2 : 4);
+  const int rpw = (K == 4096 ? 2 : 4);
   a.chunk = (int64_t)W * (rpw < 1 ? 1 : rpw);
   const int64_t blocks = (rows + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: too many rows for one launch");

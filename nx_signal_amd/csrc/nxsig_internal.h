@@ -62,6 +62,32 @@ struct Framing {
 };
 int make_framing(int64_t L, int32_t N, int32_t hop, int32_t pad_mode, int64_t pad_lo, int64_t pad_hi, Framing* out);
 
+// ---- dispatch / geometry switches ----
+// Read from the environment ONCE per context, in nxsig_ctx_create (tuning_from_env: the library's one getenv loop); afterwards a
+// launch only reads the context's Tuning struct.  nxsig_ctx_set_tuning changes a switch of one context at run time (the A/B sweep
+// tools, tests); nothing in a launch path looks at the process environment.  Names are the NXSIG_<NAME> variables of
+// INTEGRATION.md.  The knobs of concluded experiments are gone (round 4): their winning value is a constant at the use site.
+#define NXSIG_TUNABLES(X)                                                                                                      \
+  X(DISABLE_WAVE) X(DISABLE_WAVE_ROWS) X(DISABLE_BLUE_WAVE) X(DISABLE_R20) X(DISABLE_8K) X(DISABLE_4K) X(DISABLE_FUSED_FILTER) \
+  X(ISTFT_DEEP) X(ISTFT_HALF_DEEP) X(ISTFT_RUNS_PER_CU) X(ISTFT_MIN_RUN)                                                      \
+  X(STORE_POLICY) X(WAVE_NO_SPLIT) X(NO_AL8) X(NO_STAGE) X(WAVE_UNITS_PER_WAVE)                                                \
+  X(FIR32) X(FIR_PAD_TAPS) X(FIR_PHASE) X(FIR_HREG) X(FIR_UNITS_PER_WAVE)                                                      \
+  X(MEL_TILE) X(MEL_LDS_KB) X(FFT_TILED) X(FFT_TILE_ELEMS) X(FFT_TILE_NT) X(FFT_COLUMNS) X(FFT_TILED_MIN) X(CONV_POW2)          \
+  X(DIRECT_FAST) X(POOL_MAX_MB) X(NO_PREFAULT)
+enum TuneKey : int {
+#define NXSIG_X(n) kT_##n,
+  NXSIG_TUNABLES(NXSIG_X)
+#undef NXSIG_X
+  kTuneCount
+};
+struct Tuning {
+  int32_t v[kTuneCount] = {};
+  bool set[kTuneCount] = {};
+};
+void tuning_from_env(Tuning* t);       // api.cpp
+int tuning_index(const char* name);    // "NXSIG_FOO" or "FOO" -> TuneKey, -1 when there is no such switch
+const char* tuning_name(int key);      // "NXSIG_FOO"
+
 // ---- device tables cached per context ----
 struct DeviceTable {
   void* ptr = nullptr;
@@ -113,7 +139,10 @@ struct Ctx {
   std::multimap<size_t, void*> pool_free;   // size -> block
   std::map<void*, size_t> pool_live;        // blocks handed out by nxsig_alloc
   size_t pool_cached = 0, pool_cap = 0;     // bytes sitting in pool_free; cap (0 = not yet decided)
+  Tuning tuning;                            // dispatch / geometry switches (environment at creation, nxsig_ctx_set_tuning later)
 };
+// value of a switch for this context, or the launcher's default when nobody set it
+static inline int tune(const Ctx* c, TuneKey k, int dflt) { return c->tuning.set[k] ? (int)c->tuning.v[k] : dflt; }
 
 // Set (for the calling THREAD and one context) by the sharded log-mel of group.cpp while it runs pass 1 on a member: the clamp
 // pass of stft_to_mel / the fused mel sink is NOT launched — the running maximum of the member's shard must first be
@@ -208,7 +237,7 @@ int launch_mel_init(Ctx* c, int** gmax);
 int launch_mel_finish(Ctx* c, float* out, int64_t n, int* gmax);
 // kernels_nd.hip: rows of any length (four-step / Bluestein beyond the LDS-resident kernels), device-side fft_nd, n-D fftconvolve
 int launch_fft_big(Ctx* c, const void* in, bool in_is_real, int64_t rows, int64_t n_in, int64_t K, bool inverse, float2* out, bool clean = true);
-int64_t fft_tiled_min();   // power-of-two row lengths from here up run the two-pass tiled four-step of kernels_nd.hip
+int64_t fft_tiled_min(const Ctx* c);   // power-of-two row lengths from here up run the two-pass tiled four-step of kernels_nd.hip
 int launch_rows_post(Ctx* c, float2* a, int64_t rows, int64_t K, const float* window, float scale, bool has_scale, float div, bool has_div);
 int launch_fft_nd(Ctx* c, const void* in, bool in_is_real, const int64_t* shape, int rank, const int32_t* axes, const int64_t* lengths,
                   int n_axes, bool inverse, float2* out);

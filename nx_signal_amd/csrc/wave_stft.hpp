@@ -1106,11 +1106,6 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
 }
 
 // ============================================================================================ host side (shared by the wave translation units)
-static int env_int(const char* name, int dflt) {
-  const char* v = std::getenv(name);
-  return v ? std::atoi(v) : dflt;
-}
-
 static int ensure_wave_tables(Ctx* c, const int C) {
   const int R3 = C / 256;
   const double two_pi = 6.283185307179586476925286766559;
@@ -1243,16 +1238,16 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
   // dispatcher hands chunks out in order.  Many short-lived workgroups balance the load across CUs / XCDs
   // dynamically: measured +12 % over a static equal partition with long-lived workgroups (the slowest CU set
   // the kernel time), at the price of re-loading the 12 KB of tables per workgroup from L2.
-  const int units_per_wave = (mel && mel->mag_kind >= 0) ? env_int("NXSIG_MAG_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
-                             : mel ? env_int("NXSIG_MEL_UNITS_PER_WAVE", MODE == kModePair ? 16 : 8)
-                                 : env_int("NXSIG_WAVE_UNITS_PER_WAVE", MODE == kModePair ? 2 : (MODE == kModeQuad ? (J == 8 ? 8 : 4) : 8));  // measured optima, input
+  const int units_per_wave = (mel && mel->mag_kind >= 0) ? (MODE == kModePair ? 16 : 8)
+                             : mel ? (MODE == kModePair ? 16 : 8)
+                                 : tune(c, kT_WAVE_UNITS_PER_WAVE, MODE == kModePair ? 2 : (MODE == kModeQuad ? (J == 8 ? 8 : 4) : 8));  // measured optima, input
                                  // from HBM (round 3, tools/bench_configs.py gen512 / gen256 / gen128 with NXSIG_BENCH_ALT_INPUTS=4: 4 units per
                                  // wave 0.646 / 0.631 of 8 TB/s against 0.591 / 0.611 at round 2's 2 / 3; fft_length 128: 8 -> 0.593 against 0.572)
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   // a launch so small that its workgroups all fit on the chip at once (three per CU; BASELINE config 2 as written: one 60 s
   // stream, 703 workgroups) is one round of start-up latencies: three pairs per wave amortise them better than two (+1.5 ... 2.6 %
   // in interleaved sweeps, tools/sweep_stft.py with SWEEP_B=1; the steady-state optimum of many rounds stays at two)
-  if (MODE == kModePair && !mel && units_per_wave == 2 && !std::getenv("NXSIG_WAVE_UNITS_PER_WAVE") &&
+  if (MODE == kModePair && !mel && units_per_wave == 2 && !c->tuning.set[kT_WAVE_UNITS_PER_WAVE] &&
       (a.total_pairs + 2 * W - 1) / (2 * W) <= (int64_t)c->num_cus * 3)
     a.chunk = (int64_t)W * 3;
   // Interior frames [m_lo, m_hi): every one of the KOUT samples the streaming front-end reads lies inside the signal,
@@ -1272,7 +1267,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
   // quad front-ends: staged input (16-byte loads of the unit's contiguous span, re-distributed through LDS) when the span
   // is 16-byte aligned; units must then be complete (no phantom frames) and have 3 floats of slack behind the span
   int stg = 0;
-  if (MODE == kModeQuad && !env_int("NXSIG_NO_STAGE", 0) && s.fr.hop <= KOUT &&
+  if (MODE == kModeQuad && !tune(c, kT_NO_STAGE, 0) && s.fr.hop <= KOUT &&
       (reinterpret_cast<uintptr_t>(s.x) & 15) == 0 && (s.batch_stride & 3) == 0 && (lo & 3) == 0) {
     const int span4 = ((F - 1) * s.fr.hop + KOUT + 3) & ~3;
     stg = (span4 + 255) / 256 <= 4 ? 4 : 8;
@@ -1282,7 +1277,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     u_hi = mh / F;  // complete units only
     if (u_hi < u_lo) u_hi = u_lo;
   }
-  if (env_int("NXSIG_WAVE_NO_SPLIT", 0) && !(u_lo == 0 && u_hi == a.pairs_per_row)) u_hi = u_lo = 0;
+  if (tune(c, kT_WAVE_NO_SPLIT, 0) && !(u_lo == 0 && u_hi == a.pairs_per_row)) u_hi = u_lo = 0;
   const bool scale = s.has_scale != 0;
   const bool npred = s.fr.N < KOUT;
   const int64_t chunk_main = a.chunk;
@@ -1404,7 +1399,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     }
     if constexpr (MODE == kModeReal2x) {
       // even hop / padding / row stride and an 8-byte aligned signal: the frame's samples travel as 8-byte loads
-      if (!done && !npred && !env_int("NXSIG_NO_AL8", 0) && (reinterpret_cast<uintptr_t>(s.x) & 7) == 0 && (s.batch_stride & 1) == 0 &&
+      if (!done && !npred && !tune(c, kT_NO_AL8, 0) && (reinterpret_cast<uintptr_t>(s.x) & 7) == 0 && (s.batch_stride & 1) == 0 &&
           (hop & 1) == 0 && (lo & 1) == 0) {
         done = true;
         rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 2>, upr, big, u_lo, u_lo)
@@ -1418,7 +1413,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
       // (32: +1 ... 5 %, flat to 96 streams = 8.8 GB); one stream (92 MB, Infinity-Cache resident) shows no preference.
       // NXSIG_STORE_POLICY forces one (0 / 1 / 2).
       const int64_t out_bytes = (int64_t)s.batch * s.fr.M * KOUT * 8;
-      const int stp = env_int("NXSIG_STORE_POLICY", (out_bytes > ((int64_t)150 << 20) && out_bytes <= ((int64_t)2200 << 20)) ? 0 : 1);
+      const int stp = tune(c, kT_STORE_POLICY, (out_bytes > ((int64_t)150 << 20) && out_bytes <= ((int64_t)2200 << 20)) ? 0 : 1);
       if (!done && !npred && (stp == 0 || stp == 2)) {
         done = true;
         if (stp == 0) rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 0, 0>, upr, big, u_lo, u_lo)
@@ -1509,7 +1504,7 @@ static int launch_blue_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = 
     if ((rcm = launch_mel_init(c, &b.gmax))) return rcm;
     lds += (size_t)b.nnz * 4 + (size_t)(2 * mel->mel_bins + 1) * 4;
   }
-  const int units_per_wave = env_int("NXSIG_BLUE_UNITS_PER_WAVE", 4);
+  const int units_per_wave = 4;
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   const int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");

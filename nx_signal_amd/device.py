@@ -42,6 +42,19 @@ class Context:
     def sync(self):
         _lib.check(self._lib.nxsig_sync(self.handle))
 
+    def set_tuning(self, name: str, value: int):
+        """one dispatch / geometry switch of this context (INTEGRATION.md "Switches"); the environment is only read at creation"""
+        _lib.check(self._lib.nxsig_ctx_set_tuning(self.handle, name.encode(), int(value)))
+
+    def get_tuning(self, name: str):
+        """(value, is_set) of a switch"""
+        v, st = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.nxsig_ctx_get_tuning(self.handle, name.encode(), C.byref(v), C.byref(st)))
+        return int(v.value), bool(st.value)
+
+    def clear_tuning(self, name=None):
+        _lib.check(self._lib.nxsig_ctx_clear_tuning(self.handle, None if name is None else name.encode()))
+
     def timer_start(self):
         _lib.check(self._lib.nxsig_timer_start(self.handle))
 

@@ -1,7 +1,9 @@
 """The dispatch switches of the library ("Environment variables") select kernels the default dispatch does not take:
-the generic kernels behind every tuned one, the alternative FIR / mel / long-transform / n-D forms.  Each switch is read once per
-process, so each case here is a fresh interpreter that runs the parity tests that reach the switched path — in the default
-`-m gpu` run, not only in tools/run_matrix.sh (which runs the FULL suites per switch and stays the thorough form)."""
+the generic kernels behind every tuned one, the alternative FIR / mel / long-transform / n-D forms.  A context reads the
+NXSIG_<NAME> variables ONCE, at creation, into its switch table; no launch looks at the environment (round 4).  Two kinds of cases:
+in-process ones flip switches of a live context through nxsig_ctx_set_tuning (what the sweep tools do), and one fresh interpreter per
+switch with the variable set runs the parity tests that reach the switched path — in the default `-m gpu` run, not only in
+tools/run_matrix.sh (which runs the FULL suites per switch and stays the thorough form)."""
 import os
 import re
 import subprocess
@@ -28,7 +30,6 @@ CASES = [
     ("NXSIG_DISABLE_8K=1", ("tests/test_gpu_tuned_kernels.py", "8192")),
     ("NXSIG_DISABLE_4K=1", ("tests/test_gpu_tuned_kernels.py", "4096")),
     ("NXSIG_DISABLE_FUSED_FILTER=1", ISTFT),
-    ("NXSIG_ISTFT_NT_LOADS=0", ISTFT),
     ("NXSIG_ISTFT_DEEP=0", ISTFT),
     ("NXSIG_ISTFT_HALF_DEEP=0", ("tests/test_gpu_tuned_kernels.py", "half_n512")),
     ("NXSIG_ISTFT_HALF_DEEP=1", ("tests/test_gpu_tuned_kernels.py", "half_n512")),
@@ -66,3 +67,72 @@ def test_parity_under_a_dispatch_switch(switch, sel):
     assert r.returncode == 0, tail
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= 2, tail   # the selection reaches real tests under the switch
+
+
+def test_switches_live_in_the_context_and_the_environment_is_read_once(monkeypatch):
+    import numpy as np
+
+    import nx_signal_amd as S
+    from nx_signal_amd import _lib
+    from oracle import nx_oracle as O
+
+    monkeypatch.setenv("NXSIG_DISABLE_WAVE", "1")
+    c1 = S.Context(0)
+    monkeypatch.delenv("NXSIG_DISABLE_WAVE")
+    c2 = S.Context(0)
+    assert c1.get_tuning("NXSIG_DISABLE_WAVE") == (1, True) and c1.get_tuning("DISABLE_WAVE") == (1, True)
+    assert c2.get_tuning("NXSIG_DISABLE_WAVE") == (0, False)
+    os.environ["NXSIG_DISABLE_WAVE"] = "1"       # after creation: nobody looks
+    try:
+        assert c2.get_tuning("NXSIG_DISABLE_WAVE") == (0, False)
+        rng = np.random.default_rng(3)
+        x = rng.standard_normal(60000).astype(np.float32)
+        w = S.windows.hann(1024)
+        opts = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)
+        zo, _, _ = O.stft(x, w, **opts)
+        z_generic = S.stft(c1.to_device(x), w, ctx=c1, **opts)[0].numpy()   # c1: generic kernels (environment at creation)
+        z_tuned = S.stft(c2.to_device(x), w, ctx=c2, **opts)[0].numpy()     # c2: wave kernels
+        for z in (z_generic, z_tuned):
+            assert np.max(np.abs(z - zo)) / np.max(np.abs(zo)) < 1e-5
+        assert not np.array_equal(z_generic.view(np.uint32), z_tuned.view(np.uint32))   # two different kernels really ran
+        c2.set_tuning("NXSIG_DISABLE_WAVE", 1)    # flip the live context: the same bits as c1 now
+        assert np.array_equal(S.stft(c2.to_device(x), w, ctx=c2, **opts)[0].numpy().view(np.uint32), z_generic.view(np.uint32))
+        c2.clear_tuning("DISABLE_WAVE")
+        assert np.array_equal(S.stft(c2.to_device(x), w, ctx=c2, **opts)[0].numpy().view(np.uint32), z_tuned.view(np.uint32))
+        with pytest.raises(_lib.ArgumentError):
+            c2.set_tuning("NXSIG_NO_SUCH_SWITCH", 1)
+        c1.clear_tuning()
+        assert c1.get_tuning("DISABLE_WAVE") == (0, False)
+    finally:
+        del os.environ["NXSIG_DISABLE_WAVE"]
+
+
+@pytest.mark.parametrize("name,values", [("NXSIG_FIR32", (0, 2)), ("NXSIG_FIR_HREG", (0,)), ("NXSIG_FIR_PHASE", (0,)), ("NXSIG_ISTFT_DEEP", (0,)),
+                                         ("NXSIG_STORE_POLICY", (0, 2)), ("NXSIG_WAVE_UNITS_PER_WAVE", (1, 3))])
+def test_flipping_a_switch_in_process_keeps_parity(name, values):
+    """what tools/sweep_*.py do: several values of one switch on ONE context, each result against the oracle"""
+    import numpy as np
+
+    import nx_signal_amd as S
+    from oracle import nx_oracle as O
+
+    ctx = S.Context(0)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 90000)).astype(np.float32)
+    w = S.windows.hann(1024)
+    opts = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)
+    h = S.filters.firwin(257, [4000.0], sampling_rate=48000.0)
+    zo = np.stack([O.stft(r, w, **opts)[0] for r in x])
+    yo = np.stack([O.istft(z, w, **opts) for z in zo])
+    fo = np.stack([O.fftconvolve(r, h, mode="same") for r in x])
+    for v in (None,) + tuple(values):
+        if v is not None:
+            ctx.set_tuning(name, v)
+        xd = ctx.to_device(x)
+        z = S.stft(xd, w, ctx=ctx, **opts)[0].numpy()
+        y = S.istft(ctx.to_device(zo), w, ctx=ctx, **opts).numpy()
+        f = S.filters.fir(xd, h, mode="same", ctx=ctx).numpy() if hasattr(S.filters, "fir") else None
+        assert np.max(np.abs(z - zo)) / np.max(np.abs(zo)) < 1e-5, (name, v)
+        assert np.max(np.abs(y - yo)) / np.max(np.abs(yo)) < 1e-5, (name, v)
+        if f is not None:
+            assert np.max(np.abs(f - fo)) / np.max(np.abs(fo)) < 1e-5, (name, v)

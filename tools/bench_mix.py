@@ -44,6 +44,17 @@ for r in range(rounds):
         res[k].append(nb / (timeit(fn) * 1e-3) / 1e9)
 for k, v in res.items():
     print(json.dumps({"case": k, "GBps": [round(a, 1) for a in v], "frac_of_8TBps": round(float(np.median(v)) / 8000, 4)}), flush=True)
+# the same streams over CONSTANT data (zeros): what part of the ceiling is the data's (bus toggling / power), not the pattern's
+zero = np.zeros(1 << 22, np.uint8)
+for off in range(0, B * M * N * 8, zero.nbytes):
+    nbz = min(zero.nbytes, B * M * N * 8 - off)
+    _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(z.ptr + off), zero.ctypes.data_as(C.c_void_p), nbz))
+res = {k: [] for k in cases if " 8 runs/CU" in k or k == "istft kernel"}
+for r in range(rounds):
+    for k in res:
+        res[k].append(nb / (timeit(cases[k]) * 1e-3) / 1e9)
+for k, v in res.items():
+    print(json.dumps({"case": k + "  [zero-filled spectrum]", "GBps": [round(a, 1) for a in v], "frac_of_8TBps": round(float(np.median(v)) / 8000, 4)}), flush=True)
 for b in (x, z, y): b.free()
 
 # ---- fir, config 5

@@ -431,9 +431,10 @@ def self_spawn(args) -> int:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    nonce = "%x" % int.from_bytes(os.urandom(8), "little")  # one per launch: part of the rendezvous file's name
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), NXSIG_BENCH_SELF_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), NXSIG_BENCH_SELF_SPAWNED="1", NXSIG_RDZV_NONCE=nonce, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr.fileno()))
     rc = 0

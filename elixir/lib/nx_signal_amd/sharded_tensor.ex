@@ -24,7 +24,7 @@ defmodule NxSignalAMD.Sharded.Tensor do
   alias NxSignalAMD.NIF
 
   @enforce_keys [:group, :bufs, :shape, :type, :axis, :parts]
-  defstruct [:group, :bufs, :shape, :type, :axis, :parts, names: nil, full: false]
+  defstruct [:group, :bufs, :shape, :type, :axis, :parts, names: nil, full: false, for: nil]
 
   @type part :: {non_neg_integer(), non_neg_integer(), non_neg_integer(), non_neg_integer()}
   @type t :: %__MODULE__{
@@ -35,7 +35,8 @@ defmodule NxSignalAMD.Sharded.Tensor do
           axis: :channels | :frames,
           parts: [part()],
           names: list() | nil,
-          full: boolean()
+          full: boolean(),
+          for: nil | {:stft | :istft | :fir | :result, term(), term()}
         }
 
   @axes %{channels: 0, frames: 1, samples: 1}
@@ -105,6 +106,20 @@ defmodule NxSignalAMD.Sharded.Tensor do
     end
   end
 
+  # A shard by FRAMES holds exactly the span the call it was scattered `for:` reads (its halo included).  Feeding it to another
+  # call — or to the same call with another frame length / hop / tap count — would make the library read past the member's
+  # buffer on the device (the NIF refuses such buffers too: `badarg`).  Shards by channels hold whole rows and feed anything.
+  defp check_plan!(%__MODULE__{axis: :channels}, _want), do: :ok
+  defp check_plan!(%__MODULE__{full: true}, _want), do: :ok
+  defp check_plan!(%__MODULE__{for: want}, want), do: :ok
+
+  defp check_plan!(%__MODULE__{for: have}, want) do
+    raise ArgumentError,
+          "these frame shards were laid out for #{inspect(have)} and cannot feed #{inspect(want)}: " <>
+            "a member holds only the span (and halo) that plan needs. Download with from_device/1 and scatter again with " <>
+            "to_device(group, tensor, axis: :frames, for: #{inspect(want)}), or shard by channels"
+  end
+
   defp elem_bytes({:f, 32}), do: 4
   defp elem_bytes({:c, 64}), do: 8
 
@@ -168,7 +183,7 @@ defmodule NxSignalAMD.Sharded.Tensor do
       end
 
     {:ok, bufs} = NIF.group_scatter(group, Nx.to_binary(flat), batch, row_bytes, parts) |> NxSignalAMD.unwrap!()
-    %__MODULE__{group: group, bufs: bufs, shape: shape, type: type, axis: opts[:axis], parts: parts, names: names}
+    %__MODULE__{group: group, bufs: bufs, shape: shape, type: type, axis: opts[:axis], parts: parts, names: names, for: opts[:for]}
   end
 
   @doc "Downloads every member's shard into its place of one `Nx.Tensor` (waits for the members' streams)."
@@ -213,6 +228,7 @@ defmodule NxSignalAMD.Sharded.Tensor do
     {batch_shape, length} = NxSignalAMD.split_last(x.shape)
     batch = Tuple.product(batch_shape)
     w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+    check_plan!(x, {:stft, elem(params, 0), elem(params, 1)})
 
     {:ok, bufs, m} =
       NIF.stft_sharded_dev(x.group, x.bufs, length, batch, w, params, Map.fetch!(@axes, x.axis), if(gather, do: 1, else: 0))
@@ -226,7 +242,18 @@ defmodule NxSignalAMD.Sharded.Tensor do
         do: rows_plan(x.group, batch, m * item),
         else: stft_out_plan(x.group, batch, m, elem(params, 0), elem(params, 1), item)
 
-    z = %__MODULE__{group: x.group, bufs: bufs, shape: shape, type: {:c, 64}, axis: x.axis, parts: parts, names: nil, full: gather}
+    z = %__MODULE__{
+      group: x.group,
+      bufs: bufs,
+      shape: shape,
+      type: {:c, 64},
+      axis: x.axis,
+      parts: parts,
+      names: nil,
+      full: gather,
+      for: {:result, :stft, {elem(params, 0), elem(params, 1)}}
+    }
+
     {t, f} = NxSignalAMD.times_and_frequencies(params, m)
     {z, t, f}
   end
@@ -243,6 +270,7 @@ defmodule NxSignalAMD.Sharded.Tensor do
     {params, _overlap, m, batch_shape} = NxSignalAMD.istft_params!(z.shape, window, istft_opts)
     batch = Tuple.product(batch_shape)
     w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+    check_plan!(z, {:istft, elem(params, 0), elem(params, 1)})
 
     {:ok, bufs} =
       NIF.istft_sharded_dev(z.group, z.bufs, m, batch, w, params, Map.fetch!(@axes, z.axis), if(gather, do: 1, else: 0))
@@ -255,7 +283,18 @@ defmodule NxSignalAMD.Sharded.Tensor do
       if z.axis == :channels, do: rows_plan(z.group, batch, out_len * 8), else: istft_out_plan(z.group, batch, m, n, hop)
 
     shape = Tuple.insert_at(batch_shape, tuple_size(batch_shape), out_len)
-    %__MODULE__{group: z.group, bufs: bufs, shape: shape, type: {:c, 64}, axis: z.axis, parts: parts, names: nil, full: gather}
+
+    %__MODULE__{
+      group: z.group,
+      bufs: bufs,
+      shape: shape,
+      type: {:c, 64},
+      axis: z.axis,
+      parts: parts,
+      names: nil,
+      full: gather,
+      for: {:result, :istft, {n, hop}}
+    }
   end
 
   @doc "FIR filtering (`NxSignalAMD.Filters.fir/3`) on device shards. Options: `mode:` (`:same`), `gather:`."
@@ -266,6 +305,7 @@ defmodule NxSignalAMD.Sharded.Tensor do
     batch = Tuple.product(batch_shape)
     hb = taps |> Nx.as_type(:f32) |> Nx.to_binary()
     num_taps = div(byte_size(hb), 4)
+    check_plan!(x, {:fir, num_taps, opts[:mode]})
 
     {:ok, bufs} =
       NIF.fir_sharded_dev(x.group, x.bufs, length, batch, hb, mode, Map.fetch!(@axes, x.axis), if(opts[:gather], do: 1, else: 0))
@@ -282,7 +322,17 @@ defmodule NxSignalAMD.Sharded.Tensor do
       if x.axis == :channels, do: rows_plan(x.group, batch, n_out * 4), else: fir_plan(x.group, batch, length, num_taps, mode, :out)
 
     shape = Tuple.insert_at(batch_shape, tuple_size(batch_shape), n_out)
-    %__MODULE__{group: x.group, bufs: bufs, shape: shape, type: {:f, 32}, axis: x.axis, parts: parts, names: nil, full: opts[:gather]}
+    %__MODULE__{
+      group: x.group,
+      bufs: bufs,
+      shape: shape,
+      type: {:f, 32},
+      axis: x.axis,
+      parts: parts,
+      names: nil,
+      full: opts[:gather],
+      for: {:result, :fir, {num_taps, opts[:mode]}}
+    }
   end
 
   @doc """
@@ -298,6 +348,7 @@ defmodule NxSignalAMD.Sharded.Tensor do
     {batch_shape, length} = NxSignalAMD.split_last(x.shape)
     batch = Tuple.product(batch_shape)
     w = window |> Nx.as_type(:f32) |> Nx.to_binary()
+    check_plan!(x, {:stft, elem(params, 0), elem(params, 1)})
 
     {:ok, bufs, m} =
       NIF.stft_mel_sharded_dev(x.group, x.bufs, length, batch, w, params, mel_bins, filters, Map.fetch!(@axes, x.axis))

@@ -22,10 +22,30 @@
  *   - a group resource owns one context per member GPU and the RCCL communicators (nxsig_group_create_local).
  */
 #include <erl_nif.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 
 #include "../include/nxsig.h"
+
+/* What this file assumes about <erl_nif.h>, checked at COMPILE time against whichever header it meets — the stand-in of the test
+ * suite (tests/stub/erl_nif.h, written from the documentation) or a real OTP one (nif/Makefile, -Werror).  A first `mix compile`
+ * on a BEAM box that disagrees with any of these stops here with the reason, not in a dirty scheduler at run time. */
+_Static_assert(sizeof(ERL_NIF_TERM) == sizeof(void*), "ERL_NIF_TERM is one machine word");
+_Static_assert(sizeof(ErlNifSInt64) == 8 && sizeof(ErlNifUInt64) == 8, "64-bit integer terms (enif_get_int64 / enif_make_int64)");
+_Static_assert(ERL_NIF_DIRTY_JOB_CPU_BOUND == 1 && ERL_NIF_DIRTY_JOB_IO_BOUND == 2, "dirty-scheduler flags of ErlNifFunc.flags");
+_Static_assert(offsetof(ErlNifBinary, size) == 0 && offsetof(ErlNifBinary, data) == sizeof(size_t), "ErlNifBinary starts {size, data}");
+_Static_assert(offsetof(ErlNifFunc, name) == 0 && offsetof(ErlNifFunc, arity) == sizeof(char*) &&
+               offsetof(ErlNifFunc, fptr) > offsetof(ErlNifFunc, arity) && offsetof(ErlNifFunc, flags) > offsetof(ErlNifFunc, fptr),
+               "ErlNifFunc is {name, arity, fptr, flags}: the funcs[] table below is written positionally");
+_Static_assert(offsetof(ErlNifEntry, major) == 0 && offsetof(ErlNifEntry, funcs) > offsetof(ErlNifEntry, num_of_funcs),
+               "ErlNifEntry starts {major, minor, name, num_of_funcs, funcs}");
+_Static_assert(ERL_NIF_RT_CREATE == 1 && ERL_NIF_RT_TAKEOVER == 2, "resource-type flags");
+_Static_assert(ERL_NIF_LATIN1 == 1, "atom encoding passed to enif_get_atom");
+#ifdef ERL_NIF_MAJOR_VERSION   /* a real OTP header: dirty NIFs without a build flag need NIF API 2.11 (OTP 20) or later */
+_Static_assert(ERL_NIF_MAJOR_VERSION == 2 && ERL_NIF_MINOR_VERSION >= 11, "needs the NIF API of OTP 20 or later (dirty schedulers)");
+#endif
+_Static_assert(sizeof(nxsig_c64) == 8 && sizeof(float) == 4 && sizeof(double) == 8, "tensor element sizes of the binaries");
 
 static ErlNifResourceType* CTX_RES;
 static ErlNifResourceType* BUF_RES;
@@ -1161,7 +1181,8 @@ static ERL_NIF_TERM nif_group_scatter(ErlNifEnv* env, int argc, const ERL_NIF_TE
       b.size % (size_t)batch || !get_parts(env, argv[4], n, parts))
     return enif_make_badarg(env);
   for (int i = 0; i < n; ++i)
-    if (parts[i].row0 + parts[i].rows > batch || parts[i].off + parts[i].len > row_bytes) return enif_make_badarg(env);
+    if (parts[i].row0 > batch || parts[i].rows > batch - parts[i].row0 || parts[i].off > row_bytes || parts[i].len > row_bytes - parts[i].off)
+      return enif_make_badarg(env);   /* compared without adding: the four values come from Erlang and may sum past INT64_MAX */
   void* d[NXSIG_MAX_MEMBERS] = {0};
   size_t bytes[NXSIG_MAX_MEMBERS];
   for (int i = 0; i < n; ++i) {
@@ -1189,8 +1210,8 @@ static ERL_NIF_TERM nif_group_gather(ErlNifEnv* env, int argc, const ERL_NIF_TER
   if (n < 1 || n > NXSIG_MAX_MEMBERS || batch < 1 || row_bytes < 1 || !get_bufs(env, argv[1], g, n, bufs) || !get_parts(env, argv[4], n, parts))
     return enif_make_badarg(env);
   for (int i = 0; i < n; ++i)
-    if (parts[i].row0 + parts[i].rows > batch || parts[i].off + parts[i].len > row_bytes ||
-        bufs[i]->bytes < (size_t)parts[i].rows * (size_t)parts[i].len)
+    if (parts[i].row0 > batch || parts[i].rows > batch - parts[i].row0 || parts[i].off > row_bytes || parts[i].len > row_bytes - parts[i].off ||
+        (parts[i].len > 0 && (uint64_t)parts[i].rows > (uint64_t)bufs[i]->bytes / (uint64_t)parts[i].len))
       return enif_make_badarg(env);
   if (!out_bin(&ob, (uint64_t)batch, (uint64_t)row_bytes, 1, 1)) return mk_oom(env);
   memset(ob.data, 0, ob.size);   /* positions no shard covers (none for the plans of nxsig_shard_*) read as zero */
@@ -1226,6 +1247,32 @@ static int out_sizes(grp_res_t* g, int n, int axis, int gather, int64_t batch, i
   }
   return 0;
 }
+/* INPUT shard sizes (bytes per member) the sharded calls will READ, from the same partition rules: kind 1 stft (f32 samples; a =
+ * num_frames, b = frame_length, c = hop, items_per_row = length), kind 2 istft (c64 frames of item_bytes = K * 8; a = num_frames),
+ * kind 3 fir (f32 samples; a = length, b = taps, c = mode).  A buffer smaller than this would be read out of bounds on the device:
+ * the *_sharded_dev NIFs refuse it. */
+static int in_sizes(grp_res_t* g, int n, int axis, int64_t batch, int64_t items_per_row, int64_t item_bytes, int kind, int64_t a, int32_t b,
+                    int32_t c, size_t* bytes) {
+  const int world = nxsig_group_world(g->grp);
+  for (int i = 0; i < n; ++i) {
+    const int rank = nxsig_group_rank(g->grp, i);
+    int64_t rows = batch, items = items_per_row, r[4];
+    int rc;
+    if (axis == NXSIG_SHARD_CHANNELS) { if ((rc = nxsig_shard_range(batch, world, rank, &r[0], &r[1]))) return rc; rows = r[1] - r[0]; }
+    else if (kind == 1) { if ((rc = nxsig_shard_frames(a, b, c, world, rank, &r[0], &r[1], &r[2], &r[3]))) return rc; items = r[3] - r[2]; }
+    else if (kind == 2) { if ((rc = nxsig_shard_istft(a, b, c, world, rank, &r[0], &r[1], &r[2], &r[3]))) return rc; items = r[1] - r[0]; }
+    else { if ((rc = nxsig_shard_fir(a, b, c, world, rank, &r[0], &r[1], &r[2], &r[3]))) return rc; items = r[3] - r[2]; }
+    size_t sz = (size_t)item_bytes;
+    if (rows < 0 || items < 0 || !mul_size(&sz, (uint64_t)rows) || !mul_size(&sz, (uint64_t)items)) return NXSIG_ERR_OOM;
+    bytes[i] = sz;
+  }
+  return 0;
+}
+static int bufs_hold(int n, buf_res_t** b, const size_t* need) {
+  for (int i = 0; i < n; ++i)
+    if (b[i]->bytes < need[i]) return 0;
+  return 1;
+}
 static int alloc_members(grp_res_t* g, int n, const size_t* bytes, void** d) {
   for (int i = 0; i < n; ++i) {
     int rc = nxsig_alloc(nxsig_group_ctx(g->grp, i), bytes[i] ? bytes[i] : 4, &d[i]);
@@ -1255,7 +1302,10 @@ static ERL_NIF_TERM nif_stft_sharded_dev(ErlNifEnv* env, int argc, const ERL_NIF
   if (m < 0) return mk_error(env, (int)m);
   size_t bytes[NXSIG_MAX_MEMBERS];
   void* z[NXSIG_MAX_MEMBERS] = {0};
-  int rc = out_sizes(g, n, axis, gather, batch, m, (int64_t)p.fft_length * 8, 1, m, p.frame_length, p.hop, bytes);
+  int rc = in_sizes(g, n, axis, batch, length, 4, 1, m, p.frame_length, p.hop, bytes);
+  if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
+  if (!bufs_hold(n, xb, bytes)) return enif_make_badarg(env);   /* a shard scattered for another plan: it would be read out of bounds */
+  rc = out_sizes(g, n, axis, gather, batch, m, (int64_t)p.fft_length * 8, 1, m, p.frame_length, p.hop, bytes);
   if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
   if ((rc = alloc_members(g, n, bytes, z))) return mk_error(env, rc);
   const float* xs[NXSIG_MAX_MEMBERS];
@@ -1287,7 +1337,10 @@ static ERL_NIF_TERM nif_istft_sharded_dev(ErlNifEnv* env, int argc, const ERL_NI
   if (out_len < 0) return mk_error(env, (int)out_len);
   size_t bytes[NXSIG_MAX_MEMBERS];
   void* y[NXSIG_MAX_MEMBERS] = {0};
-  int rc = out_sizes(g, n, axis, gather, batch, out_len, 8, 2, m, p.frame_length, p.hop, bytes);
+  int rc = in_sizes(g, n, axis, batch, m, (int64_t)p.frame_length * 8, 2, m, p.frame_length, p.hop, bytes);
+  if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
+  if (!bufs_hold(n, zb, bytes)) return enif_make_badarg(env);   /* e.g. the frame shards of stft(axis: :frames): istft needs halo frames too */
+  rc = out_sizes(g, n, axis, gather, batch, out_len, 8, 2, m, p.frame_length, p.hop, bytes);
   if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
   if ((rc = alloc_members(g, n, bytes, y))) return mk_error(env, rc);
   const nxsig_c64* zs[NXSIG_MAX_MEMBERS];
@@ -1318,7 +1371,10 @@ static ERL_NIF_TERM nif_fir_sharded_dev(ErlNifEnv* env, int argc, const ERL_NIF_
   if (out_len < 0) return mk_error(env, (int)out_len);
   size_t bytes[NXSIG_MAX_MEMBERS];
   void* y[NXSIG_MAX_MEMBERS] = {0};
-  int rc = out_sizes(g, n, axis, gather, batch, out_len, 4, 3, length, taps, mode, bytes);
+  int rc = in_sizes(g, n, axis, batch, length, 4, 3, length, taps, mode, bytes);
+  if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
+  if (!bufs_hold(n, xb, bytes)) return enif_make_badarg(env);
+  rc = out_sizes(g, n, axis, gather, batch, out_len, 4, 3, length, taps, mode, bytes);
   if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
   if ((rc = alloc_members(g, n, bytes, y))) return mk_error(env, rc);
   const float* xs[NXSIG_MAX_MEMBERS];
@@ -1350,7 +1406,10 @@ static ERL_NIF_TERM nif_stft_mel_sharded_dev(ErlNifEnv* env, int argc, const ERL
   if (m < 0) return mk_error(env, (int)m);
   size_t bytes[NXSIG_MAX_MEMBERS];
   void* o[NXSIG_MAX_MEMBERS] = {0};
-  int rc = out_sizes(g, n, axis, 0, batch, m, (int64_t)bins * 4, 1, m, p.frame_length, p.hop, bytes);
+  int rc = in_sizes(g, n, axis, batch, length, 4, 1, m, p.frame_length, p.hop, bytes);
+  if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
+  if (!bufs_hold(n, xb, bytes)) return enif_make_badarg(env);
+  rc = out_sizes(g, n, axis, 0, batch, m, (int64_t)bins * 4, 1, m, p.frame_length, p.hop, bytes);
   if (rc) return rc == NXSIG_ERR_OOM ? mk_oom(env) : mk_error(env, rc);
   if ((rc = alloc_members(g, n, bytes, o))) return mk_error(env, rc);
   const float* xs[NXSIG_MAX_MEMBERS];

@@ -263,15 +263,21 @@ int nxsig_rendezvous_fetch(const char* path, void* data, size_t bytes, int32_t t
   if (!path || !*path || (!data && bytes)) return set_error(NXSIG_ERR_INVALID_ARG, "rendezvous_fetch: bad arguments");
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
-    struct stat st;
-    if (stat(path, &st) == 0 && (size_t)st.st_size == bytes &&
-        (max_age_s <= 0 || std::time(nullptr) - st.st_mtime <= (time_t)max_age_s)) {
-      FILE* f = std::fopen(path, "rb");
-      if (f) {
-        const size_t n = bytes ? std::fread(data, 1, bytes, f) : 0;
-        std::fclose(f);
-        if (n == bytes) return NXSIG_OK;
+    // O_NOFOLLOW + fstat on the OPEN descriptor: a regular file that belongs to this user, of the expected size and young enough
+    // (the fetch used to follow symlinks and never looked at the owner when the /tmp fallback directory is in use)
+    const int fd = ::open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd >= 0) {
+      struct stat st;
+      bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && (size_t)st.st_size == bytes &&
+                (max_age_s <= 0 || std::time(nullptr) - st.st_mtime <= (time_t)max_age_s);
+      size_t n = 0;
+      while (ok && n < bytes) {
+        const ssize_t k = ::read(fd, static_cast<char*>(data) + n, bytes - n);
+        if (k <= 0) break;
+        n += (size_t)k;
       }
+      ::close(fd);
+      if (ok && n == bytes) return NXSIG_OK;
     }
     const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
     if (ms > timeout_ms) return set_error(NXSIG_ERR_INVALID_ARG, std::string("rendezvous_fetch: timed out waiting for ") + path);

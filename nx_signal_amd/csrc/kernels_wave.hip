@@ -132,6 +132,27 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
     take_from(rn);
     __builtin_amdgcn_sched_barrier(0);
 
+    // Nx.ifft's clean-up (:609; |x| <= 1e-10 -> +0 on the transform's result x = zz / K, ahead of scale and window) concerns digital
+    // silence only.  Round 4: a lane takes the minimum magnitude of its 32 components (one v_min3 per two) and the compare-and-
+    // select per component runs only when some lane of the wave holds one at or below the threshold (wave-uniform, cold);
+    // |zz / K| <= eps  <=>  |zz| <= eps K exactly (K is a power of two).  NaN passes through both ways.
+    {
+      float amin = 3.0e38f;
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(zz[e][q].x), __builtin_fabsf(zz[e][q].y)));
+      constexpr float kEpsK = kFftEps * (float)K;
+      if (__builtin_amdgcn_ballot_w64(amin <= kEpsK) != 0) {   // cold
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            zz[e][q].x = __builtin_fabsf(zz[e][q].x) <= kEpsK ? 0.0f : zz[e][q].x;
+            zz[e][q].y = __builtin_fabsf(zz[e][q].y) <= kEpsK ? 0.0f : zz[e][q].y;
+          }
+      }
+    }
     const float live = m < a.M ? 1.0f : 0.0f;  // tail flush: frames m >= M do not exist
     const int64_t j = m;                        // segment j is complete once frame j has been folded in
     // guarded normaliser of segment j from the host table (head rows 0..R-2, interior row R-1, tail rows R..2R-2)
@@ -150,7 +171,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
         v2f f[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          v2f v = fft_eps0(zz[e][i * QS + qq] * invK);  // Nx.ifft's clean-up (:609) precedes scale and window
+          v2f v = zz[e][i * QS + qq] * invK;  // (cleaned above when anything needed it)
           if (SCALE) v = v * a.scale;
           f[i] = v * (wv[e][i * QS + qq] * live);
         }
@@ -782,14 +803,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       }
     };
     v2f zz[2][NQ];  // zz[par][q] = (x1[n], x2[n]), n = 2 lane + par + 128 q
-    // pack() also sums the pair's samples: the sum is finite iff they all are (an overflowing sum of finite samples merely
-    // poisons a row whose outputs overflow anyway) -> FirLaunch::row_flags
-    v2f nfs = v2f{0.f, 0.f};
     auto pack = [&]() {
-      v2f t = r1[0] + r2[0];
-#pragma unroll
-      for (int q = 1; q < NQ; ++q) t += r1[q] + r2[q];
-      nfs = t;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) { zz[0][q] = v2f{r1[q].x, r2[q].x}; zz[1][q] = v2f{r1[q].y, r2[q].y}; }
     };
@@ -798,7 +812,6 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       const bool more = pr + W < p_end;
       issue_loads(more ? nrow : row, more ? npin : pin);  // unconditional prefetch: branch-free loop
       __builtin_amdgcn_sched_barrier(0);
-      if (wave_any_nonfinite(nfs.x, nfs.y) && lane == 0) atomicOr(a.row_flags + row, 1);
       v2f d[P];
       wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);
 #pragma unroll
@@ -808,15 +821,33 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       pack();  // next pair (its samples landed during the two transforms)
       __builtin_amdgcn_sched_barrier(0);
+      // Non-finite samples (round 4: tested on the OUTPUTS the inverse core holds anyway instead of one packed add per input
+      // point).  Every bin of a block's forward transform depends on every sample of the block and every output on every bin, so
+      // an Inf / NaN sample leaves NO finite output in its block: one output value per block (u[..].x: block 1, .y: block 2) says
+      // whether the block held one.  (Finite samples whose transform overflows poison a row whose outputs overflow anyway.)
+      if (wave_any_nonfinite(u[0][NQ - 1].x, u[0][NQ - 1].y) && lane == 0) atomicOr(a.row_flags + row, 1);
+      // Nx.ifft's clean-up (|y| <= 1e-10 -> +0, convolution.ex:282) concerns digital silence only: a lane first takes the minimum
+      // magnitude of its outputs (one v_min3 per two values) and the wave applies the compare-and-select per value only when some
+      // lane holds a value at or below the threshold (wave-uniform branch, cold) — 2 instructions per output became 1/2
+      float amin = 3.0e38f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (128 * q >= tm1) {
+          amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(u[0][q].x), __builtin_fabsf(u[0][q].y)));
+          amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(u[1][q].x), __builtin_fabsf(u[1][q].y)));
+        }
+      if (__builtin_amdgcn_ballot_w64(amin <= kFftEps) != 0) {   // cold
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { u[0][q] = fft_eps0(u[0][q]); u[1][q] = fft_eps0(u[1][q]); }
+      }
       const int64_t b1 = a.first_block + 2 * (a.pb_lo + pin);
       // the pair's two valid parts are one contiguous run of 2 V outputs: streaming stores (sc1 nt) through a row descriptor
       const StreamRow ys(a.y + (size_t)row * a.out_len + (b1 * a.V - a.out_start), (uint32_t)(2 * a.V) * 4);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (128 * q >= tm1) {  // uniform: (taps-1) % 128 == 0
-          // fft_eps0: the clean-up Nx.ifft applies to fftconvolve's result (convolution.ex:282)
-          ys.template st8<SC1 ? 18 : 2>(fft_eps0(v2f{u[0][q].x, u[1][q].x}), lane * 8 + 512 * q - tm1 * 4);
-          ys.template st8<SC1 ? 18 : 2>(fft_eps0(v2f{u[0][q].y, u[1][q].y}), lane * 8 + 512 * q - tm1 * 4 + a.V * 4);
+          ys.template st8<SC1 ? 18 : 2>(v2f{u[0][q].x, u[1][q].x}, lane * 8 + 512 * q - tm1 * 4);
+          ys.template st8<SC1 ? 18 : 2>(v2f{u[0][q].y, u[1][q].y}, lane * 8 + 512 * q - tm1 * 4 + a.V * 4);
         }
       }
       row = nrow; pin = npin;

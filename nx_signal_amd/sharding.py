@@ -86,7 +86,10 @@ def rendezvous_path(env=None) -> str:
                 d = "/tmp"
         except OSError:
             d = "/tmp"
-    return os.path.join(d, "nxsig_rdzv_%s_%s_%d" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
+    # unique per LAUNCH: the launcher's pid and port, the elastic run id and restart count (a restarted worker group of the same
+    # launcher must not meet the id file of the group that died), and an optional nonce a launcher may hand to all its ranks
+    return os.path.join(d, "nxsig_rdzv_%s_%s_%s_%s_%d" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "none"),
+                                                            env.get("TORCHELASTIC_RESTART_COUNT", "0"), env.get("NXSIG_RDZV_NONCE", "0"), os.getppid()))
 
 
 class Group:

@@ -94,7 +94,7 @@ ErlNifResourceType* enif_open_resource_type(ErlNifEnv*, const char* module_str, 
                                             ErlNifResourceFlags flags, ErlNifResourceFlags* tried);
 void* enif_alloc_resource(ErlNifResourceType* type, size_t size);
 void enif_release_resource(void* obj);
-int enif_keep_resource(void* obj);
+void enif_keep_resource(void* obj);   /* returns nothing in OTP */
 ERL_NIF_TERM enif_make_resource(ErlNifEnv*, void* obj);
 int enif_get_resource(ErlNifEnv*, ERL_NIF_TERM, ErlNifResourceType* type, void** objp);
 

@@ -147,7 +147,7 @@ void* enif_alloc_resource(ErlNifResourceType* type, size_t size) {
   h->refc = 1; h->type = type; h->size = size; ++g_live_resources;
   return h + 1;
 }
-int enif_keep_resource(void* obj) { ++((res_hdr*)obj - 1)->refc; return 1; }
+void enif_keep_resource(void* obj) { ++((res_hdr*)obj - 1)->refc; }   /* void in OTP: the shim must not use a result */
 void enif_release_resource(void* obj) {
   res_hdr* h = (res_hdr*)obj - 1;
   if (--h->refc == 0) { if (h->type->dtor) { ++g_dtor_calls; h->type->dtor(NULL, obj); } --g_live_resources; free(h); }

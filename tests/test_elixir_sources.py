@@ -28,3 +28,21 @@ def test_elixir_blocks_and_brackets_balance():
                 assert name not in seen, (f, name)
                 seen.add(name)
             last = name
+
+
+def test_generated_golden_exs_is_in_sync_with_the_json():
+    """elixir/test/golden_vectors_test.exs is generated from tests/golden/reference_vectors.json (tools/gen_elixir_golden_test.py):
+    the committed file must be what the generator writes today, and must cover every family of vectors the JSON holds"""
+    import json
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_elixir_golden_test.py"), "--check"])
+    assert r.returncode == 0, "run python tools/gen_elixir_golden_test.py"
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))
+    text = open(os.path.join(ROOT, "elixir", "test", "golden_vectors_test.exs")).read()
+    n_tests = len(re.findall(r'^  test "', text, re.M))
+    families = [k for k in g if isinstance(g[k], list) and k != "fft_rows"]   # fft_rows pins Nx.fft itself (not an NxSignal function)
+    assert n_tests == sum(len(g[k]) for k in families), (n_tests, {k: len(g[k]) for k in families})
+    for v in g["windows"]:
+        assert v["src"] in text

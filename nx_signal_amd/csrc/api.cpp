@@ -410,8 +410,7 @@ int nxsig_ctx_set_tuning(nxsig_ctx* ctx, const char* name, int32_t value) {
   NXSIG_CHECK_CTX(ctx)
   const int k = tuning_index(name);
   if (k < 0) return set_error(NXSIG_ERR_INVALID_ARG, std::string("no such switch: ") + (name ? name : "(null)"));
-  std::lock_guard<std::mutex> lk(c->mu);
-  c->tuning.v[k] = value;
+  c->tuning.v[k] = value;   // (NXSIG_CHECK_CTX holds the context's mutex)
   c->tuning.set[k] = true;
   if (k == kT_POOL_MAX_MB) c->pool_cap = 0;  // decided again at the next nxsig_free
   return NXSIG_OK;
@@ -432,7 +431,6 @@ int nxsig_ctx_get_tuning(nxsig_ctx* ctx, const char* name, int32_t* value, int32
 int nxsig_ctx_clear_tuning(nxsig_ctx* ctx, const char* name) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
-  std::lock_guard<std::mutex> lk(c->mu);
   if (name == nullptr) { c->tuning = Tuning(); return NXSIG_OK; }
   const int k = tuning_index(name);
   if (k < 0) return set_error(NXSIG_ERR_INVALID_ARG, std::string("no such switch: ") + name);

@@ -132,27 +132,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
     take_from(rn);
     __builtin_amdgcn_sched_barrier(0);
 
-    // Nx.ifft's clean-up (:609; |x| <= 1e-10 -> +0 on the transform's result x = zz / K, ahead of scale and window) concerns digital
-    // silence only.  Round 4: a lane takes the minimum magnitude of its 32 components (one v_min3 per two) and the compare-and-
-    // select per component runs only when some lane of the wave holds one at or below the threshold (wave-uniform, cold);
-    // |zz / K| <= eps  <=>  |zz| <= eps K exactly (K is a power of two).  NaN passes through both ways.
-    {
-      float amin = 3.0e38f;
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(zz[e][q].x), __builtin_fabsf(zz[e][q].y)));
-      constexpr float kEpsK = kFftEps * (float)K;
-      if (__builtin_amdgcn_ballot_w64(amin <= kEpsK) != 0) {   // cold
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            zz[e][q].x = __builtin_fabsf(zz[e][q].x) <= kEpsK ? 0.0f : zz[e][q].x;
-            zz[e][q].y = __builtin_fabsf(zz[e][q].y) <= kEpsK ? 0.0f : zz[e][q].y;
-          }
-      }
-    }
+    ifft_eps_cold<NQ>(zz, kFftEps * (float)K);   // Nx.ifft's clean-up (:609), cold form: wave_stft.hpp
     const float live = m < a.M ? 1.0f : 0.0f;  // tail flush: frames m >= M do not exist
     const int64_t j = m;                        // segment j is complete once frame j has been folded in
     // guarded normaliser of segment j from the host table (head rows 0..R-2, interior row R-1, tail rows R..2R-2)
@@ -416,6 +396,7 @@ __device__ __forceinline__ void istft_wave_half_body(const IstftWaveArgs& a) {
     __builtin_amdgcn_sched_barrier(0);
     combine_from(rn);
     __builtin_amdgcn_sched_barrier(0);
+    ifft_eps_cold<NQ>(zz, kFftEps * (float)K);   // Nx.ifft's clean-up (:609), cold form: wave_stft.hpp
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int64_t j = m + e;              // frame index = index of the segment it completes
@@ -432,7 +413,7 @@ __device__ __forceinline__ void istft_wave_half_body(const IstftWaveArgs& a) {
         v2f f[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          v2f v = fft_eps0(zz[e][i * QS + qq] * invK);
+          v2f v = zz[e][i * QS + qq] * invK;
           if (SCALE) v = v * a.scale;
           f[i] = v * (wv[i * QS + qq] * live);
         }
@@ -487,6 +468,14 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
   constexpr int CARRY = NJ - HOP;        // positions handed to the next unit
   constexpr int OUTN = J * HOP;          // positions finished per unit
   constexpr int CPAD = CARRY > 0 ? CARRY : 2;
+  // Parked frames sit NJP = NJ + 16 / J complex values apart (round 4).  A park write of one instruction alternates between J / 2
+  // frames at the same sample index (lane l, parity e: frame (2 l + e) mod J, sample (2 l + e) / J + ...): with the frames NJ
+  // apart — a multiple of 32 banks — those lanes met in the same banks (2-way conflicts for N = 256, 4-way for N = 128: 11 % of the
+  // kernel's LDS cycles, profiles/r03/istft256_sq_counters.txt).  2 NJP complex = 4 NJ + 64 / J dwords puts frame e + 2 sixteen
+  // (J = 4) or eight (J = 8) banks after frame e: the 16 lanes of a ds_write_b64 group cover all 32 banks once.  The gather's
+  // 16-byte reads stay aligned (NJP * 8 B is a multiple of 16) and contiguous across lanes.
+  constexpr int NJP = NJ + 16 / J;
+  static_assert(J * NJP <= XCH, "padded frames must fit the wave's exchange buffer");
   static_assert(OUTN % 128 == 0, "J hop must be a multiple of 128");
   static_assert(2 * HOP >= 128 / J, "lanes of one instruction would share an accumulator cell");
   float* s_w = reinterpret_cast<float*>(g_wave_smem);
@@ -516,6 +505,15 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
   const float invK = 1.0f / (float)K;
   const int64_t out_len = a.segs_per_row * HOP;
 
+  // this lane's window values: a lane parks sample n = (2 lane + e) / J + (128 / J) q of frame (2 lane + e) mod J
+  constexpr bool WREG = J == 4;   // N = 256: 16 registers, still three waves per SIMD; N = 128 re-reads the LDS table
+  float wreg[WREG ? 2 : 1][WREG ? NQ : 1];
+  if (WREG) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) wreg[WREG ? e : 0][WREG ? q : 0] = s_w[(2 * lane + e + 128 * q) / J];
+  }
   const v2f* zrow = a.z + (size_t)row * a.M * NJ + lane;
   v2f r[J][PJ];
   auto issue_loads = [&](int64_t u) {
@@ -563,17 +561,19 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
 
     // ---- park the unit's J windowed frames in the (now idle) exchange buffer, frame-major: xb[j NJ + n]
     //      ((IDFT / N) * scale) * window, lib/nx_signal.ex:609-628, same rounding order; plain writes, no ordering issue
+    ifft_eps_cold<NQ>(zz, kFftEps * (float)K);   // Nx.ifft's clean-up (:609), cold form: wave_stft.hpp
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < 2; ++e) {
+      const int je = (2 * lane + e) % J;   // the frame this lane holds at parity e (128 q is a multiple of J)
+      const float live = (u * J + je) < a.M ? 1.0f : 0.0f;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int i = 2 * lane + e + 128 * q;
-        const int j = i % J, n = i / J;
-        v2f v = fft_eps0(zz[e][q] * invK);
+        const int n = (2 * lane + e + 128 * q) / J;
+        v2f v = zz[e][q] * invK;
         if (SCALE) v = v * a.scale;
-        const float live = (u * J + j) < a.M ? 1.0f : 0.0f;
-        xb[j * NJ + n] = v * (s_w[n] * live);
+        xb[je * NJP + n] = v * ((WREG ? wreg[WREG ? e : 0][WREG ? q : 0] : s_w[n]) * live);
       }
+    }
     wave_lds_fence();
     // position t of the unit (t = 0 is sample u J hop of the row) = carry of earlier units + frames j with 0 <= t - j hop < NJ,
     // summed in ascending frame order; every lane takes adjacent pairs (16-byte LDS reads: hop is even)
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int off = t - j * HOP;
-        if (off >= 0 && off < NJ) acc += *reinterpret_cast<const v4f*>(&xb[j * NJ + off]);
+        if (off >= 0 && off < NJ) acc += *reinterpret_cast<const v4f*>(&xb[j * NJP + off]);
       }
       return acc;
     };

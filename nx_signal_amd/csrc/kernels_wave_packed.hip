@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_packed(IstftPackedArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     combine();
     __builtin_amdgcn_sched_barrier(0);
+    ifft_eps_cold<NQ>(zz, kFftEps * (float)K);   // Nx.ifft's clean-up (:609), cold form: wave_stft.hpp
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int64_t j = m + e;              // frame index = index of the segment it completes
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_packed(IstftPackedArgs a) {
         v2f f[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          v2f v = fft_eps0(zz[e][i * QS + qq] * invK);   // Nx.ifft's clean-up (:609) precedes scale and window
+          v2f v = zz[e][i * QS + qq] * invK;
           if (SCALE) v = v * a.scale;
           f[i] = v * (wv[i * QS + qq] * live);
         }

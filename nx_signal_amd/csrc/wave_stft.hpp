@@ -49,6 +49,29 @@ __device__ __forceinline__ bool wave_any_nonfinite(float sx, float sy) {
 __device__ __forceinline__ v2f fft_eps0(v2f v) { return v2f{fft_eps0(v.x), fft_eps0(v.y)}; }
 __device__ __forceinline__ v4f fft_eps0(v4f v) { return v4f{fft_eps0(v.x), fft_eps0(v.y), fft_eps0(v.z), fft_eps0(v.w)}; }
 
+// Nx.ifft's clean-up (|x| <= 1e-10 -> +0 on the transform's result x = zz / K, ahead of scale and window; lib/nx_signal.ex:609) in
+// its COLD form (round 4): the threshold concerns digital silence only, so a lane first takes the minimum magnitude of the
+// components it holds (one v_min3 per two values) and the compare-and-select per component runs only when some lane of the wave
+// holds one at or below the threshold (wave-uniform branch).  |zz / K| <= eps  <=>  |zz| <= eps K exactly (K a power of two);
+// NaN passes through both ways (minNum ignores it, the select keeps it).  2 VALU per component became 1/2.
+template <int NQ>
+__device__ __forceinline__ void ifft_eps_cold(v2f (*zz)[NQ], const float thr) {
+  float amin = 3.0e38f;
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(zz[e][q].x), __builtin_fabsf(zz[e][q].y)));
+  if (__builtin_amdgcn_ballot_w64(amin <= thr) != 0) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        zz[e][q].x = __builtin_fabsf(zz[e][q].x) <= thr ? 0.0f : zz[e][q].x;
+        zz[e][q].y = __builtin_fabsf(zz[e][q].y) <= thr ? 0.0f : zz[e][q].y;
+      }
+  }
+}
+
 // front-ends of the C-point complex core
 enum : int {
   kModePair = 0,    // two adjacent real frames of length C as re / im          (fft_length == C)
@@ -344,6 +367,7 @@ struct WaveArgs {
   const v2f* twR;             // device c64[C]: w_2C^k (real-2x mode only)
   float div;
   int32_t has_scale;
+  int32_t spec_clean;         // 1: speculative eps clean-up of the spectrum sink (stft_wave_body), 0: eager
   v2f* z;
   v2f* dummy;                 // device c64[K]: sink for the phantom second frame of an odd tail (keeps the loop branch-free)
 };
@@ -597,7 +621,12 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
 
   // ---- Nx.fft's clean-up (SURVEY App. A rule 7; call site lib/nx_signal.ex:102): every component of the finished spectrum
   // with |x| <= eps = 1e-10 becomes +0, BEFORE the :spectrum / :psd division (:113-127).  NaN compares false and stays.
-  auto eps_clean = [](v4f v) { return fft_eps0(v); };
+  // Round 4, spectrum sink of the streaming kernels: the clean-up is SPECULATIVE.  The threshold concerns digital silence only, so
+  // the first drain of a unit stores the untangled spectrum as it is while every lane tracks the minimum magnitude of what it stores
+  // (one v_min3 per two components instead of a compare + select per component); when some lane of the wave met a component at or
+  // below the threshold, the unit is drained AGAIN with the clean-up (cold; the wave's own later stores to the same addresses land
+  // after the first ones).  NaN never trips the test (minNum) and passes through both drains unchanged.
+  constexpr bool SPEC_CLEAN = SINK == kSinkSpectrum && !GENERAL;
   // ---- non-finite samples.  The reference transforms every frame on its own (one Nx.fft row per frame, lib/nx_signal.ex:94-102),
   // so an Inf / NaN sample reaches only the frames that contain it.  Frames that share one complex transform here (2 in pair mode,
   // 2J in quad mode) would share it: a unit whose windowed samples are not all finite therefore leaves the paired route and runs
@@ -656,8 +685,21 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
 
   // ---- Hermitian untangle through partner lanes + eps clean-up + scaling + store.  SOLO: only slot 0 of the unit (real part of
   // sequence 0) is meaningful; it is frame mS of the row and leaves through plain non-temporal stores.
-  auto drain = [&](auto solo_c, v2f (*zz)[NQ], const int64_t crow, const int64_t mA, const bool haveB, const int64_t mS) {
+  auto drain = [&](auto solo_c, auto spec_c, v2f (*zz)[NQ], const int64_t crow, const int64_t mA, const bool haveB, const int64_t mS) -> bool {
     constexpr bool SOLO = decltype(solo_c)::value;
+    constexpr bool SPEC = decltype(spec_c)::value;   // store uncleaned, report whether anything needed the clean-up
+    float amin = 3.0e38f;
+    // skip_y: component .y of this value is a STRUCTURAL zero — the imaginary part of a real frame's DC / Nyquist bin, formed as
+    // x - x = +0 exactly (the bin is its own Hermitian partner) — and must not trip the test: every unit holds those.
+    auto eps_clean = [&](v4f v, const bool skip_y = false) -> v4f {
+      if constexpr (SPEC) {
+        amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(v.x), skip_y ? 3.0e38f : __builtin_fabsf(v.y)));
+        amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+        return v;
+      } else {
+        return fft_eps0(v);
+      }
+    };
     const int src0 = ((64 - lane) & 63) << 2, src1 = (63 - lane) << 2;
     if constexpr (MODE == kModeQuad) {
       constexpr int HQ = NQ / J;  // bins per lane per parity of the short spectra
@@ -699,8 +741,10 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
           p1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(cs[j][1][HQ - 1 - q].y)));
           if (lane == 0) p0 = own0;
           const v2f z0v = cs[j][0][q], z1v = cs[j][1][q];
-          v4f xa = eps_clean(v4f{z0v.x + p0.x, z0v.y - p0.y, z1v.x + p1.x, z1v.y - p1.y} * 0.5f);
-          v4f xbv = eps_clean(v4f{z0v.y + p0.y, p0.x - z0v.x, z1v.y + p1.y, p1.x - z1v.x} * 0.5f);
+          // bins 0 and KOUT / 2 of the short spectra: lane 0 at q = 0 and q = HQ / 2 (J = 8: KOUT / 2 = 64 sits on lane 32, q = 0)
+          const bool self = HQ >= 2 ? (lane == 0 && (q == 0 || q == HQ / 2)) : ((lane & 31) == 0);
+          v4f xa = eps_clean(v4f{z0v.x + p0.x, z0v.y - p0.y, z1v.x + p1.x, z1v.y - p1.y} * 0.5f, self);
+          v4f xbv = eps_clean(v4f{z0v.y + p0.y, p0.x - z0v.x, z1v.y + p1.y, p1.x - z1v.x} * 0.5f, self);
           if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }
           const bool stA = SOLO || m0 + 2 * j < a.M, stB = !SOLO && m0 + 2 * j + 1 < a.M;
           if (MEL || MAG) {
@@ -772,8 +816,11 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
           xbv = xa - to;
           xa = xa + to;
         }
-        xa = eps_clean(xa);
-        if (!SOLO) xbv = eps_clean(xbv);
+        // pair: bins 0 and K / 2 (lane 0, q = 0 and NQ / 2) are their own partners; real-2x: bins 0 and K of the 2K-point spectrum
+        // (lane 0, q = 0: E and O are real there and w = 1)
+        const bool self = lane == 0 && (q == 0 || (MODE == kModePair && q == NQ / 2));
+        xa = eps_clean(xa, self);
+        if (!SOLO) xbv = eps_clean(xbv, self);
         if (SCALE) { xa = xa / a.div; xbv = xbv / a.div; }  // true division like the reference (:116/:119)
         if (MEL) {
           const v2f pa2 = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};      // |X[k]|^2, |X[k+1]|^2
@@ -811,6 +858,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
         }
       }
     }
+    return SPEC && __builtin_amdgcn_ballot_w64(amin <= kFftEps) != 0;
   };
 
   for (int64_t pr = p_begin + wave; pr < p_end; pr += kWavesPerBlock) {
@@ -839,7 +887,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
         v2f ds[P];
         if (GENERAL) load_general(ds, crow, mA, f); else load_solo(ds, crow, mA + f);
         wave_fft_core<K>(ds, zz, xb, s_twB, s_twC, lane);
-        drain(std::true_type{}, zz, crow, mA, haveB, mA + f);
+        drain(std::true_type{}, std::false_type{}, zz, crow, mA, haveB, mA + f);
       }
       if (!GENERAL) {
         __builtin_amdgcn_sched_barrier(0);
@@ -853,7 +901,12 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
         window_mul(d);
         __builtin_amdgcn_sched_barrier(0);
       }
-      drain(std::false_type{}, zz, crow, mA, haveB, mA);
+      if (SPEC_CLEAN && a.spec_clean) {   // wave-uniform (a kernel argument: NXSIG_SPEC_CLEAN=0 selects the eager form for A/B runs)
+        if (drain(std::false_type{}, std::integral_constant<bool, SPEC_CLEAN>{}, zz, crow, mA, haveB, mA))
+          drain(std::false_type{}, std::false_type{}, zz, crow, mA, haveB, mA);   // cold: the unit again, with the clean-up
+      } else {
+        drain(std::false_type{}, std::false_type{}, zz, crow, mA, haveB, mA);
+      }
       if (MEL) mel_tail(crow, mA);
       if (!GENERAL && LATE) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1179,7 +1232,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
   a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
   a.pairs_per_row = MODE == kModePair ? (s.fr.M + 1) / 2 : (MODE == kModeQuad ? (s.fr.M + 2 * J - 1) / (2 * J) : s.fr.M);
   a.total_pairs = a.pairs_per_row * s.batch;
-  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
+  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.spec_clean = tune(c, kT_SPEC_CLEAN, 1); a.z = reinterpret_cast<v2f*>(s.z);
 
   static_assert(C == 1024 || C == 2048, "wave_fft_core covers 1024 (16*16*4) and 2048 (16*16*8, two butterflies per lane)");
   { int rc = ensure_wave_tables(c, C); if (rc) return rc; }
@@ -1453,7 +1506,7 @@ static int launch_blue_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = 
   a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
   a.pairs_per_row = (s.fr.M + 1) / 2;
   a.total_pairs = a.pairs_per_row * s.batch;
-  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
+  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.spec_clean = 0; a.z = reinterpret_cast<v2f*>(s.z);
   a.twR = nullptr; a.dummy = nullptr;
   { int rc = ensure_wave_tables(c, C); if (rc) return rc; }
   Ctx::WaveTables& wt = c->wave_tables[C];

@@ -35,9 +35,9 @@ wp = w.ctypes.data_as(C.c_void_p)
 nb = B * M * 10240
 cases = {"istft kernel": lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(z.ptr), M, B, wp, C.byref(p), C.c_void_p(y.ptr), 1))}
 for wpc in (8, 12, 16):
-    for lb in (8, 16):
+    for lb in (8, 16, 108, 116):
         for halo in (3, 0):
-            cases[f"istft mix {wpc} runs/CU {lb:2d}-B loads halo {halo}"] = (lambda wpc=wpc, lb=lb, halo=halo: diag.nxdiag_istft_mix2(stream, C.c_void_p(z.ptr), C.c_void_p(y.ptr), B * M, wpc, halo, lb))
+            cases[f"istft mix {wpc} runs/CU {lb % 100:2d}-B {'default-policy' if lb > 100 else 'nt'} loads halo {halo}"] = (lambda wpc=wpc, lb=lb, halo=halo: diag.nxdiag_istft_mix2(stream, C.c_void_p(z.ptr), C.c_void_p(y.ptr), B * M, wpc, halo, lb))
 res = {k: [] for k in cases}
 for r in range(rounds):
     for k, fn in cases.items():

@@ -16,7 +16,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <int LB>   // LB = bytes per lane per load: 8 (the shipped kernel's loads) or 16 (experiment)
+template <int LB, bool NT = true>   // LB = bytes per lane per load: 8 (the shipped kernel's loads) or 16; NT: non-temporal loads (shipped) or default policy
 __global__ __launch_bounds__(256) void k_istft_mix(const v2f* __restrict__ z, v4f* __restrict__ y, long frames, long run_len, int halo) {
   const int lane = threadIdx.x & 63;
   const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -29,11 +29,11 @@ __global__ __launch_bounds__(256) void k_istft_mix(const v2f* __restrict__ z, v4
     if (LB == 8) {
       const v2f* p = z + (size_t)(m < frames ? m : frames - 1) * 1024 + lane;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) r[s] = __builtin_nontemporal_load(p + 64 * s);
+      for (int s = 0; s < 16; ++s) r[s] = NT ? __builtin_nontemporal_load(p + 64 * s) : p[64 * s];
     } else {
       const v4f* p = reinterpret_cast<const v4f*>(z + (size_t)(m < frames ? m : frames - 1) * 1024) + lane;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) { const v4f t = __builtin_nontemporal_load(p + 64 * s); r[2 * s] = v2f{t.x, t.y}; r[2 * s + 1] = v2f{t.z, t.w}; }
+      for (int s = 0; s < 8; ++s) { const v4f t = NT ? __builtin_nontemporal_load(p + 64 * s) : p[64 * s]; r[2 * s] = v2f{t.x, t.y}; r[2 * s + 1] = v2f{t.z, t.w}; }
     }
   };
   auto consume = [&](v2f (&r)[16], long m) {
@@ -110,8 +110,11 @@ int nxdiag_istft_mix2(void* stream, const void* z, void* y, long frames, int wav
   const long waves = (long)pr.multiProcessorCount * waves_per_cu;
   const long run_len = (frames + waves - 1) / waves;
   const unsigned grid = (unsigned)(((frames + run_len - 1) / run_len + 3) / 4);
-  if (load_bytes == 16) hipLaunchKernelGGL(k_istft_mix<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
-  else hipLaunchKernelGGL(k_istft_mix<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
+  // load_bytes: 8 / 16 = non-temporal loads, 108 / 116 = default cache policy
+  if (load_bytes == 16) hipLaunchKernelGGL((k_istft_mix<16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
+  else if (load_bytes == 116) hipLaunchKernelGGL((k_istft_mix<16, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
+  else if (load_bytes == 108) hipLaunchKernelGGL((k_istft_mix<8, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
+  else hipLaunchKernelGGL((k_istft_mix<8, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
   return (int)hipGetLastError();
 }
 int nxdiag_istft_mix(void* stream, const void* z, void* y, long frames, int waves_per_cu, int halo) { return nxdiag_istft_mix2(stream, z, y, frames, waves_per_cu, halo, 8); }

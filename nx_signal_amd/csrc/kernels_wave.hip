@@ -456,7 +456,21 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_half_deep(IstftWaveArgs a
 // earlier units + the frames that cover the position, summed in ascending frame order (deterministic, run-to-run
 // bit-stable; 16-byte LDS reads, no read-modify-write chains).  The first J hop positions are normalised and stored
 // with 16-byte stores; the following N - hop positions become the carry of the next unit (a small LDS strip per wave).
-template <int K, int J, int R, bool SCALE, int W>
+// DPP quad_perm control that makes lane `to` of every group of G lanes (G = 2: lanes {0,1}, {2,3} of a quad; G = 4: the quad) read
+// lane `from`; the other lanes read themselves
+constexpr int hop_ctrl(int G, int from, int to) {
+  int sel[4] = {0, 1, 2, 3};
+  if (from >= G || to >= G) return 0xE4;   // (a dead branch of an unrolled lane loop: identity)
+  for (int base = 0; base < 4; base += G) sel[base + to] = base + from;
+  return sel[0] | (sel[1] << 2) | (sel[2] << 4) | (sel[3] << 6);
+}
+template <int CTRL>
+__device__ __forceinline__ v2f dpp_quad(v2f v) {
+  return v2f{__int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.x), CTRL, 0xf, 0xf, true)),
+             __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.y), CTRL, 0xf, 0xf, true))};
+}
+
+template <int K, int J, int R, bool SCALE, int W, bool REGOLA = true>
 __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
   constexpr int NJ = K / J;              // frame length (= fft_length)
   constexpr int P = K / 64;
@@ -474,6 +488,14 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
   // kernel's LDS cycles, profiles/r03/istft256_sq_counters.txt).  2 NJP complex = 4 NJ + 64 / J dwords puts frame e + 2 sixteen
   // (J = 4) or eight (J = 8) banks after frame e: the 16 lanes of a ds_write_b64 group cover all 32 banks once.  The gather's
   // 16-byte reads stay aligned (NJP * 8 B is a multiple of 16) and contiguous across lanes.
+  // REGOLA: overlap-add in registers (see the unit loop); false (NXSIG_ISTFT_REGOLA=0): the LDS park / gather form of rounds 2-3
+  constexpr int G = J / 2;               // lanes that share a sample index
+  constexpr int QW = 128 / J;            // samples per position step Q
+  constexpr int HQ = NQ / R;             // position steps per hop
+  constexpr int QF = J * HQ;             // finished steps per unit
+  constexpr int NC = NQ - HQ;            // carried steps
+  constexpr int NQT = QF + NC;
+  static_assert(NQ % R == 0 && HQ >= 1, "hop must be a multiple of 128 / J samples");
   constexpr int NJP = NJ + 16 / J;
   static_assert(J * NJP <= XCH, "padded frames must fit the wave's exchange buffer");
   static_assert(OUTN % 128 == 0, "J hop must be a multiple of 128");
@@ -504,9 +526,21 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
   for (int i = lane; i < CARRY; i += 64) carry[i] = v2f{0.f, 0.f};
   const float invK = 1.0f / (float)K;
   const int64_t out_len = a.segs_per_row * HOP;
+  // REGOLA: this lane's window values w[(lane >> 1) + 32 q], the interior reciprocal normaliser of its output position, the carry
+  v2f creg[REGOLA && NC > 0 ? NC : 1];
+  float wq[REGOLA ? NQ : 1];
+  float rd_int[REGOLA ? HQ : 1];
+  if (REGOLA) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) wq[REGOLA ? q : 0] = s_w[(lane / G) + QW * q];
+#pragma unroll
+    for (int Q = 0; Q < NC; ++Q) creg[REGOLA ? Q : 0] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < HQ; ++h) rd_int[REGOLA ? h : 0] = a.den[(R - 1) * HOP + (lane / G) + QW * h];
+  }
 
   // this lane's window values: a lane parks sample n = (2 lane + e) / J + (128 / J) q of frame (2 lane + e) mod J
-  constexpr bool WREG = J == 4;   // N = 256: 16 registers, still three waves per SIMD; N = 128 re-reads the LDS table
+  constexpr bool WREG = J == 4 && !REGOLA;   // N = 256 (LDS form): 16 registers, still three waves per SIMD; N = 128 re-reads the LDS table
   float wreg[WREG ? 2 : 1][WREG ? NQ : 1];
   if (WREG) {
 #pragma unroll
@@ -559,65 +593,136 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave_quad(IstftWaveArgs a) {
     pack();
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- park the unit's J windowed frames in the (now idle) exchange buffer, frame-major: xb[j NJ + n]
-    //      ((IDFT / N) * scale) * window, lib/nx_signal.ex:609-628, same rounding order; plain writes, no ordering issue
     ifft_eps_cold<NQ>(zz, kFftEps * (float)K);   // Nx.ifft's clean-up (:609), cold form: wave_stft.hpp
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int je = (2 * lane + e) % J;   // the frame this lane holds at parity e (128 q is a multiple of J)
-      const float live = (u * J + je) < a.M ? 1.0f : 0.0f;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int n = (2 * lane + e + 128 * q) / J;
+    if constexpr (REGOLA) {
+      // ---- the overlap-add stays in REGISTERS (round 4).  Element i = 2 lane + e + 128 q of the transform is sample
+      // n = lane / G + QW q of frame j = 2 (lane % G) + e (G = J / 2 lanes share a sample index, QW = 128 / J): a group of G
+      // adjacent lanes holds sample m' + QW q of all J frames of the unit.  Output position t' = m' + QW Q of the unit
+      // (t' = hop j + n, hop = QW HQ) takes frame j's sample q = Q - HQ j, so every position is summed INSIDE its lane group: the
+      // partial sum starts on the lane of the first frame that covers it (with the carry of the earlier units: always lane 0 of
+      // the group), collects that lane's two frames, hops to the next lane (DPP quad_perm) and so on — ascending frame order, one
+      // add per frame like the LDS form, whatever the unit alignment (sharded = unsharded bit for bit); the compiler fuses each
+      // product into its add here, so the two forms differ by that rounding (<= 1.6e-7 of the signal).  Q < QF = J HQ are finished and end on the lane of their last frame
+      // (lane g: Q in [2 g HQ, 2 (g + 1) HQ)); the NC = NQ - HQ positions beyond end on the last lane and hop back to lane 0 as
+      // the next unit's carry.  No LDS traffic, no per-position address arithmetic: the park / gather form spent ~400 of its ~900
+      // instructions per unit there (ISA histogram of N = 256: profiles/r04/README.md).
+      const int g_lane = lane % G;
+      // wave-uniform facts of the unit, as 32-bit numbers relative to its first segment / frame u J
+      const int64_t rel_m = a.M - u * J, rel_s = a.segs_per_row - u * J;
+      const int m_rel = rel_m > 64 ? 64 : (int)rel_m;        // frames j < m_rel of the unit exist
+      const int s_rel = rel_s > 64 ? 64 : (int)rel_s;        // segments k < s_rel of the unit exist
+      const bool interior = u * J >= R - 1 && m_rel >= J;    // every segment of the unit takes the interior normaliser row
+      const bool stored = u >= u0;                           // (a run's halo unit only feeds the carry)
+      const float live0 = 2 * g_lane < m_rel ? 1.0f : 0.0f, live1 = 2 * g_lane + 1 < m_rel ? 1.0f : 0.0f;
+      // windowed sample (e, q) of this lane: ((IDFT / N) * scale) * window, the reference's rounding order; every (e, q) enters
+      // exactly one position Q, so it is formed where it is consumed (no 32-register array of products)
+      auto elem = [&](const int e, const int q) -> v2f {
         v2f v = zz[e][q] * invK;
         if (SCALE) v = v * a.scale;
-        xb[je * NJP + n] = v * ((WREG ? wreg[WREG ? e : 0][WREG ? q : 0] : s_w[n]) * live);
+        return v * (wq[q] * (e ? live1 : live0));
+      };
+      v2f S[NQT];
+#pragma unroll
+      for (int Q = 0; Q < NQT; ++Q) {
+        // frames j with 0 <= Q - HQ j < NQ: jf .. jl, on lanes jf / 2 .. jl / 2 of the group
+        const int jl = Q / HQ < J - 1 ? Q / HQ : J - 1;
+        const int jf = Q - NQ + 1 > 0 ? (Q - NQ + 1 + HQ - 1) / HQ : 0;
+        v2f acc = v2f{0.f, 0.f};
+        if (Q < NC) acc = creg[Q < NC ? Q : 0];            // (jf = 0 there: the carry waits on lane 0)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (g < jf / 2 || g > jl / 2) continue;
+          if (g > jf / 2) acc = g == 1 ? dpp_quad<hop_ctrl(G, 0, 1)>(acc) : (g == 2 ? dpp_quad<hop_ctrl(G, 1, 2)>(acc) : dpp_quad<hop_ctrl(G, 2, 3)>(acc));
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int j = 2 * g + e, q = Q - HQ * j;
+            if (j >= jf && j <= jl) acc = acc + elem(e, (q >= 0 && q < NQ) ? q : 0);
+          }
+        }
+        S[Q] = acc;                                         // lives on lane jl / 2 of the group
       }
-    }
-    wave_lds_fence();
-    // position t of the unit (t = 0 is sample u J hop of the row) = carry of earlier units + frames j with 0 <= t - j hop < NJ,
-    // summed in ascending frame order; every lane takes adjacent pairs (16-byte LDS reads: hop is even)
-    auto gather = [&](int t) -> v4f {
-      v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
-      if (CARRY > 0 && t < CARRY) acc = *reinterpret_cast<const v4f*>(&carry[t]);
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int off = t - j * HOP;
-        if (off >= 0 && off < NJ) acc += *reinterpret_cast<const v4f*>(&xb[j * NJP + off]);
+      for (int Q = 0; Q < NC; ++Q)                          // the tail beyond the unit ended on the last lane: back to lane 0
+        creg[Q] = G == 2 ? dpp_quad<hop_ctrl(2, 1, 0)>(S[QF + Q]) : dpp_quad<hop_ctrl(4, 3, 0)>(S[QF + Q]);
+      // finished positions: lane g of a group stores Q = 2 g HQ + r, r < 2 HQ: hop segment 2 g + r / HQ of the unit, position
+      // m' + QW (r % HQ) inside it; store r of a wave writes G runs of QW consecutive samples
+      v2f* yrow = a.y + (size_t)row * out_len + u * (int64_t)OUTN + (lane / G) + (int64_t)g_lane * 2 * HOP;
+#pragma unroll
+      for (int r = 0; r < 2 * HQ; ++r) {
+        // this lane's value: S[2 g HQ + r] for its own g (one select per further lane of the group)
+        v2f val = S[r];
+#pragma unroll
+        for (int g = 1; g < G; ++g) val = g_lane == g ? S[2 * g * HQ + r] : val;
+        const int k = 2 * g_lane + r / HQ;                  // segment of the unit
+        float rd = rd_int[r % HQ];
+        if (!interior) {                                    // wave-uniform: the row's first unit(s) and its last ones
+          const int64_t seg = u * J + k;
+          const int64_t trow = seg < R - 1 ? seg : (seg >= a.M ? R + (seg - a.M) : R - 1);
+          rd = k < s_rel ? a.den[trow * HOP + (lane / G) + QW * (r % HQ)] : 0.0f;
+        }
+        v2f* yp = (stored && k < s_rel) ? yrow + QW * r : a.dummy + lane;
+        __builtin_nontemporal_store(val * rd, (gv2f*)yp);
       }
-      return acc;
-    };
-    // ---- finished positions: x reciprocal of the guarded normaliser, 16-byte stores
-    const int64_t t_unit = u * OUTN;
-    v2f* yrow = a.y + (size_t)row * out_len;
-#pragma unroll
-    for (int i = 0; i < OUTN / 128; ++i) {
-      const int t = 2 * lane + 128 * i;
-      const v4f acc = gather(t);
-      const int64_t seg = u * J + t / HOP;           // absolute hop segment
-      const int pos = t % HOP;
-      const int64_t trow = seg < R - 1 ? seg : (seg >= a.M ? R + (seg - a.M) : R - 1);
-      const bool inside = u >= u0 && t_unit + t < out_len;
-      const v2f rd = inside ? *reinterpret_cast<const v2f*>(a.den + trow * HOP + pos) : v2f{0.f, 0.f};
-      const v4f o = v4f{acc.x * rd.x, acc.y * rd.x, acc.z * rd.y, acc.w * rd.y};
-      v2f* yp = inside ? yrow + t_unit + t : a.dummy + 2 * lane;
-      __builtin_nontemporal_store(o, (gv4f*)yp);
+    } else {
+    // ---- park the unit's J windowed frames in the (now idle) exchange buffer, frame-major: xb[j NJ + n]
+      //      ((IDFT / N) * scale) * window, lib/nx_signal.ex:609-628, same rounding order; plain writes, no ordering issue
+  #pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int je = (2 * lane + e) % J;   // the frame this lane holds at parity e (128 q is a multiple of J)
+        const float live = (u * J + je) < a.M ? 1.0f : 0.0f;
+  #pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int n = (2 * lane + e + 128 * q) / J;
+          v2f v = zz[e][q] * invK;
+          if (SCALE) v = v * a.scale;
+          xb[je * NJP + n] = v * ((WREG ? wreg[WREG ? e : 0][WREG ? q : 0] : s_w[n]) * live);
+        }
+      }
+      wave_lds_fence();
+      // position t of the unit (t = 0 is sample u J hop of the row) = carry of earlier units + frames j with 0 <= t - j hop < NJ,
+      // summed in ascending frame order; every lane takes adjacent pairs (16-byte LDS reads: hop is even)
+      auto gather = [&](int t) -> v4f {
+        v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+        if (CARRY > 0 && t < CARRY) acc = *reinterpret_cast<const v4f*>(&carry[t]);
+  #pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int off = t - j * HOP;
+          if (off >= 0 && off < NJ) acc += *reinterpret_cast<const v4f*>(&xb[j * NJP + off]);
+        }
+        return acc;
+      };
+      // ---- finished positions: x reciprocal of the guarded normaliser, 16-byte stores
+      const int64_t t_unit = u * OUTN;
+      v2f* yrow = a.y + (size_t)row * out_len;
+  #pragma unroll
+      for (int i = 0; i < OUTN / 128; ++i) {
+        const int t = 2 * lane + 128 * i;
+        const v4f acc = gather(t);
+        const int64_t seg = u * J + t / HOP;           // absolute hop segment
+        const int pos = t % HOP;
+        const int64_t trow = seg < R - 1 ? seg : (seg >= a.M ? R + (seg - a.M) : R - 1);
+        const bool inside = u >= u0 && t_unit + t < out_len;
+        const v2f rd = inside ? *reinterpret_cast<const v2f*>(a.den + trow * HOP + pos) : v2f{0.f, 0.f};
+        const v4f o = v4f{acc.x * rd.x, acc.y * rd.x, acc.z * rd.y, acc.w * rd.y};
+        v2f* yp = inside ? yrow + t_unit + t : a.dummy + 2 * lane;
+        __builtin_nontemporal_store(o, (gv4f*)yp);
+      }
+      // ---- carry for the next unit: positions OUTN .. OUTN + CARRY - 1 (all reads first, then the writes)
+      constexpr int CI = (CARRY + 127) / 128;
+      v4f nc[CI > 0 ? CI : 1];
+  #pragma unroll
+      for (int i = 0; i < CI; ++i) {
+        const int t = 2 * lane + 128 * i;
+        nc[i] = t < CARRY ? gather(OUTN + t) : v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      wave_lds_fence();
+  #pragma unroll
+      for (int i = 0; i < CI; ++i) {
+        const int t = 2 * lane + 128 * i;
+        if (t < CARRY) *reinterpret_cast<v4f*>(&carry[t]) = nc[i];
+      }
+      wave_lds_fence();  // all reads of the buffer are done before the next pass A overwrites it
     }
-    // ---- carry for the next unit: positions OUTN .. OUTN + CARRY - 1 (all reads first, then the writes)
-    constexpr int CI = (CARRY + 127) / 128;
-    v4f nc[CI > 0 ? CI : 1];
-#pragma unroll
-    for (int i = 0; i < CI; ++i) {
-      const int t = 2 * lane + 128 * i;
-      nc[i] = t < CARRY ? gather(OUTN + t) : v4f{0.f, 0.f, 0.f, 0.f};
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < CI; ++i) {
-      const int t = 2 * lane + 128 * i;
-      if (t < CARRY) *reinterpret_cast<v4f*>(&carry[t]) = nc[i];
-    }
-    wave_lds_fence();  // all reads of the buffer are done before the next pass A overwrites it
   }
 }
 
@@ -1091,6 +1196,10 @@ static int launch_istft_wave_quad(Ctx* c, const IstftLaunch& s, const float* win
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
+  // register overlap-add by default (round 4, interleaved A/B on one box, 8 x 60 s: N = 256 hop 64 / 32: +9.5 / +8.8 %, N = 128 hop
+  // 32 / 16 / 64: +17.6 / +9.5 / +5.4 %); N = 256 at hop 128 keeps the LDS form (-3 % for the register form)
+  if (!tune(c, kT_ISTFT_REGOLA, (J == 4 && R == 2) ? 0 : 1))
+    return s.has_scale ? go(k_istft_wave_quad<K, J, R, true, W, false>) : go(k_istft_wave_quad<K, J, R, false, W, false>);
   return s.has_scale ? go(k_istft_wave_quad<K, J, R, true, W>) : go(k_istft_wave_quad<K, J, R, false, W>);
 }
 

@@ -133,7 +133,12 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 
     ifft_eps_cold<NQ>(zz, kFftEps * (float)K);   // Nx.ifft's clean-up (:609), cold form: wave_stft.hpp
-    const float live = m < a.M ? 1.0f : 0.0f;  // tail flush: frames m >= M do not exist
+    if (m >= a.M) {   // tail flush (wave-uniform, R - 1 iterations per row): frames m >= M do not exist and contribute zeros
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) zz[e][q] = v2f{0.f, 0.f};
+    }
     const int64_t j = m;                        // segment j is complete once frame j has been folded in
     // guarded normaliser of segment j from the host table (head rows 0..R-2, interior row R-1, tail rows R..2R-2)
     const int64_t trow = j < R - 1 ? j : (j >= a.M ? R + (j - a.M) : R - 1);
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
         for (int i = 0; i < R; ++i) {
           v2f v = zz[e][i * QS + qq] * invK;  // (cleaned above when anything needed it)
           if (SCALE) v = v * a.scale;
-          f[i] = v * (wv[e][i * QS + qq] * live);
+          f[i] = v * wv[e][i * QS + qq];
         }
         if (R == 1) { out[e][qq] = f[0]; }
         else {
@@ -938,8 +943,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         if (128 * q >= tm1) {
-          amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(u[0][q].x), __builtin_fabsf(u[0][q].y)));
-          amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(u[1][q].x), __builtin_fabsf(u[1][q].y)));
+          amin = min3abs(u[0][q].x, u[0][q].y, amin);
+          amin = min3abs(u[1][q].x, u[1][q].y, amin);
         }
       if (__builtin_amdgcn_ballot_w64(amin <= kFftEps) != 0) {   // cold
 #pragma unroll

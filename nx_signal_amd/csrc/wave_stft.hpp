@@ -54,13 +54,19 @@ __device__ __forceinline__ v4f fft_eps0(v4f v) { return v4f{fft_eps0(v.x), fft_e
 // components it holds (one v_min3 per two values) and the compare-and-select per component runs only when some lane of the wave
 // holds one at or below the threshold (wave-uniform branch).  |zz / K| <= eps  <=>  |zz| <= eps K exactly (K a power of two);
 // NaN passes through both ways (minNum ignores it, the select keeps it).  2 VALU per component became 1/2.
+// min(|a|, |b|, acc) in ONE instruction (the source-level fminf chain costs a canonicalising v_max per operand on top)
+__device__ __forceinline__ float min3abs(float a, float b, float acc) {
+  float r;
+  asm("v_min3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+  return r;
+}
 template <int NQ>
 __device__ __forceinline__ void ifft_eps_cold(v2f (*zz)[NQ], const float thr) {
   float amin = 3.0e38f;
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(zz[e][q].x), __builtin_fabsf(zz[e][q].y)));
+    for (int q = 0; q < NQ; ++q) amin = min3abs(zz[e][q].x, zz[e][q].y, amin);
   if (__builtin_amdgcn_ballot_w64(amin <= thr) != 0) {
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -693,8 +699,8 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
     // x - x = +0 exactly (the bin is its own Hermitian partner) — and must not trip the test: every unit holds those.
     auto eps_clean = [&](v4f v, const bool skip_y = false) -> v4f {
       if constexpr (SPEC) {
-        amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(v.x), skip_y ? 3.0e38f : __builtin_fabsf(v.y)));
-        amin = __builtin_fminf(amin, __builtin_fminf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+        amin = min3abs(v.x, skip_y ? 3.0e38f : v.y, amin);
+        amin = min3abs(v.z, v.w, amin);
         return v;
       } else {
         return fft_eps0(v);

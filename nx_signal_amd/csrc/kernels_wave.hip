@@ -864,8 +864,10 @@ int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batc
 // STREAM = true : interior pairs only, 8-byte vector access, branch-free and software-pipelined like k_stft_wave
 //                 (requires (taps-1) % 128 == 0 and even offsets — checked by the launcher)
 // STREAM = false: the few edge pairs of every row (and every pair when the fast conditions fail): bounds-checked
-// SC1: cache policy of the streaming stores: true = "sc1 nt" (write-through), false = "nt" (see launch_fir_wave_W)
-template <int K, bool STREAM, int W, bool HREG = false, bool SC1 = true>
+// TQ > 0: taps - 1 == 128 TQ at compile time (STREAM launches of the default kernels): which 128-sample slots of a block are valid
+// folds away — with a run-time tap count every slot cost a scalar branch plus the VALU book-keeping of its condition, which ate what
+// round 4's cheaper clean-up had saved (SQ_INSTS_VALU per pair 706 -> 688 instead of -> ~650).  TQ = 0: run-time tap count.
+template <int K, bool STREAM, int W, bool HREG = false, int TQ = 0>
 __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
   constexpr int P = K / 64;
   constexpr int R3 = K / 256;
@@ -891,7 +893,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
   const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
   int64_t p_end = p_begin + a.chunk;
   if (p_end > a.total_units) p_end = a.total_units;
-  const int tm1 = a.taps - 1;
+  const int tm1 = TQ > 0 ? 128 * TQ : a.taps - 1;
 
   if (STREAM) {
     int64_t row = (p_begin + wave) / a.units_per_row;
@@ -956,8 +958,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (128 * q >= tm1) {  // uniform: (taps-1) % 128 == 0
-          ys.template st8<SC1 ? 18 : 2>(v2f{u[0][q].x, u[1][q].x}, lane * 8 + 512 * q - tm1 * 4);
-          ys.template st8<SC1 ? 18 : 2>(v2f{u[0][q].y, u[1][q].y}, lane * 8 + 512 * q - tm1 * 4 + a.V * 4);
+          ys.template st8<18>(v2f{u[0][q].x, u[1][q].x}, lane * 8 + 512 * q - tm1 * 4);
+          ys.template st8<18>(v2f{u[0][q].y, u[1][q].y}, lane * 8 + 512 * q - tm1 * 4 + a.V * 4);
         }
       }
       row = nrow; pin = npin;
@@ -1462,15 +1464,32 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     if (!stream && a.total_units <= (int64_t)c->num_cus * W) a.chunk = W;
     const int64_t blocks = (a.total_units + a.chunk - 1) / a.chunk;
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: signal too long for one launch");
-    if (lds > 64 * 1024) {
-      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_wave<K, true, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_wave<K, false, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    hipError_t attr_rc = hipSuccess;
+    auto fire = [&](auto kernel) {   // kernels of the 2048-point blocks need > 64 KB of dynamic LDS: opt in per instantiation
+      if (lds > 64 * 1024) attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (attr_rc == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    };
+    // stream launches: taps - 1 is a multiple of 128 (fast8): K = 1024 serves 128 .. 512, K = 2048 (taps > 513) 640 .. 1024
+    const int tq = stream ? (s.taps - 1) / 128 : 0;
+    constexpr int TQ0 = K == 1024 ? 1 : 5;
+    auto go_stream = [&](auto hreg_c) {
+      constexpr bool HR = decltype(hreg_c)::value;
+      switch (tq - TQ0) {
+        case 0: fire(k_fir_wave<K, true, W, HR, TQ0>); break;
+        case 1: fire(k_fir_wave<K, true, W, HR, TQ0 + 1>); break;
+        case 2: fire(k_fir_wave<K, true, W, HR, TQ0 + 2>); break;
+        case 3: fire(k_fir_wave<K, true, W, HR, TQ0 + 3>); break;
+        default: fire(k_fir_wave<K, true, W, HR>); break;
+      }
+    };
     if (hreg) {
-      if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W, K == 1024>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-      else hipLaunchKernelGGL((k_fir_wave<K, false, W, K == 1024>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-    } else if (stream) hipLaunchKernelGGL((k_fir_wave<K, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
-    else hipLaunchKernelGGL((k_fir_wave<K, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      if (stream) go_stream(std::integral_constant<bool, K == 1024>{});
+      else fire(k_fir_wave<K, false, W, K == 1024>);
+    } else if (stream) {
+      if (K == 1024) fire(k_fir_wave<K, true, W>);   // (NXSIG_FIR_HREG=0: run-time tap count)
+      else go_stream(std::false_type{});
+    } else fire(k_fir_wave<K, false, W>);
+    NXSIG_HIP_TRY(attr_rc);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };

@@ -132,13 +132,11 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
     take_from(rn);
     __builtin_amdgcn_sched_barrier(0);
 
-    ifft_eps_cold<NQ>(zz, kFftEps * (float)K);   // Nx.ifft's clean-up (:609), cold form: wave_stft.hpp
-    if (m >= a.M) {   // tail flush (wave-uniform, R - 1 iterations per row): frames m >= M do not exist and contribute zeros
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) zz[e][q] = v2f{0.f, 0.f};
-    }
+    // (The clean-up stays EAGER here — a compare and a select per component — and the tail flush a multiply: the cold form of
+    // the other inverse kernels puts a wave-uniform branch into this loop, and the two-frames-ahead schedule lost more to the split
+    // scheduling region than the 33 instructions per frame were worth: -3.5 % against the round-3 build side by side,
+    // profiles/r04/ab_libs_round3_vs_round4.jsonl.)
+    const float live = m < a.M ? 1.0f : 0.0f;  // tail flush: frames m >= M do not exist
     const int64_t j = m;                        // segment j is complete once frame j has been folded in
     // guarded normaliser of segment j from the host table (head rows 0..R-2, interior row R-1, tail rows R..2R-2)
     const int64_t trow = j < R - 1 ? j : (j >= a.M ? R + (j - a.M) : R - 1);
@@ -156,9 +154,9 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
         v2f f[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          v2f v = zz[e][i * QS + qq] * invK;  // (cleaned above when anything needed it)
+          v2f v = fft_eps0(zz[e][i * QS + qq] * invK);  // Nx.ifft's clean-up (:609) precedes scale and window
           if (SCALE) v = v * a.scale;
-          f[i] = v * wv[e][i * QS + qq];
+          f[i] = v * (wv[e][i * QS + qq] * live);
         }
         if (R == 1) { out[e][qq] = f[0]; }
         else {

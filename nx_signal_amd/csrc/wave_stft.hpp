@@ -375,7 +375,6 @@ struct WaveArgs {
   const v2f* twR;             // device c64[C]: w_2C^k (real-2x mode only)
   float div;
   int32_t has_scale;
-  int32_t spec_clean;         // 1: speculative eps clean-up of the spectrum sink (stft_wave_body), 0: eager
   v2f* z;
   v2f* dummy;                 // device c64[K]: sink for the phantom second frame of an odd tail (keeps the loop branch-free)
 };
@@ -633,7 +632,9 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   // the first drain of a unit stores the untangled spectrum as it is while every lane tracks the minimum magnitude of what it stores
   // (one v_min3 per two components instead of a compare + select per component); when some lane of the wave met a component at or
   // below the threshold, the unit is drained AGAIN with the clean-up (cold; the wave's own later stores to the same addresses land
-  // after the first ones).  NaN never trips the test (minNum) and passes through both drains unchanged.
+  // after the first ones).  NaN never trips the test (minNum) and passes through both drains unchanged.  (A run-time switch between
+  // this and the eager form put a third copy of the drain into the kernel and cost the headline 5.5 % — measured against the previous
+  // build side by side in one process, tools/ab_libs.py — so there is none: the form is a compile-time property of the sink.)
   constexpr bool SPEC_CLEAN = SINK == kSinkSpectrum && !GENERAL;
   // ---- non-finite samples.  The reference transforms every frame on its own (one Nx.fft row per frame, lib/nx_signal.ex:94-102),
   // so an Inf / NaN sample reaches only the frames that contain it.  Frames that share one complex transform here (2 in pair mode,
@@ -909,12 +910,8 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
         window_mul(d);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (SPEC_CLEAN && a.spec_clean) {   // wave-uniform (a kernel argument: NXSIG_SPEC_CLEAN=0 selects the eager form for A/B runs)
-        if (drain(std::false_type{}, std::integral_constant<bool, SPEC_CLEAN>{}, zz, crow, mA, haveB, mA))
-          drain(std::false_type{}, std::false_type{}, zz, crow, mA, haveB, mA);   // cold: the unit again, with the clean-up
-      } else {
-        drain(std::false_type{}, std::false_type{}, zz, crow, mA, haveB, mA);
-      }
+      if (drain(std::false_type{}, std::integral_constant<bool, SPEC_CLEAN>{}, zz, crow, mA, haveB, mA))
+        drain(std::false_type{}, std::false_type{}, zz, crow, mA, haveB, mA);   // cold: the unit again, with the clean-up
       if (MEL) mel_tail(crow, mA);
       if (!GENERAL && LATE) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1240,7 +1237,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
   a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
   a.pairs_per_row = MODE == kModePair ? (s.fr.M + 1) / 2 : (MODE == kModeQuad ? (s.fr.M + 2 * J - 1) / (2 * J) : s.fr.M);
   a.total_pairs = a.pairs_per_row * s.batch;
-  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.spec_clean = tune(c, kT_SPEC_CLEAN, 1); a.z = reinterpret_cast<v2f*>(s.z);
+  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
 
   static_assert(C == 1024 || C == 2048, "wave_fft_core covers 1024 (16*16*4) and 2048 (16*16*8, two butterflies per lane)");
   { int rc = ensure_wave_tables(c, C); if (rc) return rc; }
@@ -1514,7 +1511,7 @@ static int launch_blue_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = 
   a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
   a.pairs_per_row = (s.fr.M + 1) / 2;
   a.total_pairs = a.pairs_per_row * s.batch;
-  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.spec_clean = 0; a.z = reinterpret_cast<v2f*>(s.z);
+  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
   a.twR = nullptr; a.dummy = nullptr;
   { int rc = ensure_wave_tables(c, C); if (rc) return rc; }
   Ctx::WaveTables& wt = c->wave_tables[C];

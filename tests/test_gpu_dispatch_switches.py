@@ -33,7 +33,6 @@ CASES = [
     ("NXSIG_ISTFT_DEEP=0", ISTFT),
     ("NXSIG_ISTFT_REGOLA=0", ISTFT),
     ("NXSIG_ISTFT_REGOLA=1", ISTFT),
-    ("NXSIG_SPEC_CLEAN=0", STFT),
     ("NXSIG_ISTFT_HALF_DEEP=0", ("tests/test_gpu_tuned_kernels.py", "half_n512")),
     ("NXSIG_ISTFT_HALF_DEEP=1", ("tests/test_gpu_tuned_kernels.py", "half_n512")),
     ("NXSIG_STORE_POLICY=0", STFT),

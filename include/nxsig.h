@@ -232,7 +232,13 @@ int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch,
                   int32_t num_taps, int32_t mode, float* y, int32_t mem);
 
 /* Any slice [out_start, out_start + out_len) of the FULL convolution of every row with h (the modes of nxsig_fir_f32 are
- * three such slices; sharded filtering asks for the slice a rank owns): y f32[batch][out_len]. */
+ * three such slices; sharded filtering asks for the slice a rank owns): y f32[batch][out_len].
+ * Non-finite samples: the reference filters a row by ONE transform (convolution.ex:276-284), so a row that holds an Inf / NaN has no
+ * finite output, and nxsig_fir_f32 returns such a row as NaN from end to end.  A SLICE call only looks at the blocks its outputs
+ * need: it returns NaN for the whole slice when one of THOSE samples is not finite, and finite values when the non-finite sample
+ * lies elsewhere in the row — so the slices of a row assembled by the caller (or by nxsig_fir_sharded_f32 on the samples axis) can
+ * be finite where the unsliced call is NaN.  Callers that need the reference's whole-row behaviour for sliced rows test the row
+ * themselves; finite rows are unaffected. */
 int nxsig_fir_slice_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
                         int32_t num_taps, int64_t out_start, int64_t out_len, float* y, int32_t mem);
 

@@ -434,6 +434,17 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   // STG > 0 (quad streaming kernels): the unit's contiguous input span travels as STG 16-byte loads per lane and is
   // re-distributed through the wave's exchange buffer instead of 32 strided 4-byte loads per lane (see issue_loads)
   constexpr bool STAGED = STG > 0 && MODE == kModeQuad && !GENERAL;  // (pair mode: measured slower, 5.49 vs 5.85 TB/s)
+  // STG == 5 (round 4): 4 loads per lane AND hop == KOUT / 4 known at compile time -> the parked span is PADDED against the bank
+  // conflicts of the gather.  Lanes of one ds_read_b32 that share a sample index but belong to different frame pairs (lane % J) read
+  // addresses 2 hop = KOUT / 2 floats apart — a multiple of 32 banks: J-way conflicts in every gather instruction (15 % of the
+  // kernel's LDS cycles, profiles/r03/stft512_sq_counters_input_in_hbm.txt).  With PADF = 32 / J floats inserted after every block of
+  // KOUT / 2 floats the J frame pairs land 32 / J banks apart and a 32-lane group covers every bank once.  The block index of a sample
+  // changes INSIDE a frame (at s = P / 2 for frame A; at s = P / 4 and 3 P / 4 for frame B = A + hop), which is a compile-time offset
+  // only when the hop is: hence the dedicated instantiation for the default 75 % overlap.
+  constexpr bool HQP = STG == 5;
+  constexpr int NST = HQP ? 4 : STG;       // 16-byte loads per lane
+  constexpr int PADF = 32 / J;             // floats of padding per block (HQP)
+  constexpr int BLK = (MODE == kModeQuad ? K / J : K) / 2;   // block = 2 hop = fft_length / 2 floats (HQP)
   constexpr bool MEL = SINK == kSinkMel;   // |X|^2 -> LDS -> sparse mel filterbank -> log10
   constexpr bool MAG = SINK == kSinkMag;   // |X| or |X|^2 of the bins below fft_length / 2 straight to HBM as f32
   constexpr int P = K / 64;     // complex points per lane
@@ -530,7 +541,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   // them in gfx9's in-order queue are the previous iteration's stores (a whole iteration old): no wait ever
   // drains fresh stores, and HBM latency hides under the butterflies.
   float ra[STAGED ? 1 : P], rb[STAGED ? 1 : P];
-  v4f rs[STAGED ? STG : 1];
+  v4f rs[STAGED ? NST : 1];
   constexpr int FPU_IN = MODE == kModeQuad ? 2 * J : 2;  // frames per unit
   const int span4 = STAGED ? (((FPU_IN - 1) * a.hop + KOUT + 3) & ~3) : 0;  // floats of one unit's input span, 16-byte multiple
   auto issue_loads = [&](int64_t row, int64_t pin) {
@@ -538,7 +549,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
       // the unit's frames 2J pin .. 2J pin + 2J - 1 read x[unit start .. + span): one contiguous, 16-byte aligned run
       const v4f* p4 = reinterpret_cast<const v4f*>(a.x + (size_t)row * a.batch_stride + (pin * FPU_IN * (int64_t)a.hop - a.lo)) + lane;
 #pragma unroll
-      for (int c = 0; c < (STAGED ? STG : 0); ++c)
+      for (int c = 0; c < (STAGED ? NST : 0); ++c)
         rs[c] = (256 * c + 4 * lane < span4) ? p4[64 * c] : v4f{0.f, 0.f, 0.f, 0.f};
     } else if (MODE == kModePair) {
       const int64_t mA = pin * 2;
@@ -572,10 +583,26 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
       // every lane picks its 2 P samples: frames 2 (lane % J), +1 of the unit, sample lane / J + (64 / J) s.
       float* xsf = reinterpret_cast<float*>(xb);
 #pragma unroll
-      for (int c = 0; c < (STAGED ? STG : 0); ++c)
-        if (256 * c + 4 * lane < span4) *reinterpret_cast<v4f*>(&xsf[256 * c + 4 * lane]) = rs[c];
+      for (int c = 0; c < (STAGED ? NST : 0); ++c) {
+        const int idx = 256 * c + 4 * lane;                       // (a 16-byte piece never straddles a block: BLK % 4 == 0)
+        if (idx < span4) *reinterpret_cast<v4f*>(&xsf[HQP ? idx + (idx / BLK) * PADF : idx]) = rs[c];
+      }
       wave_lds_fence();
       constexpr int JJ = MODE == kModeQuad ? J : 1;  // pair mode: frames 0, 1 of the unit, sample lane + 64 s
+      if constexpr (HQP) {
+        // frame A of pair j = lane % J starts block j; its sample n0 + (64 / J) s lies in block j + (s >= P / 2); frame B = A + hop
+        // = A + BLK / 2 lies in block j + (s >= P / 4) + (s >= 3 P / 4)
+        const float* fa = xsf + (lane % JJ) * (BLK + PADF) + (lane / JJ);
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+          const float w = s_w[(lane / JJ) + (64 / JJ) * s];
+          const int oa = (64 / JJ) * s + (s >= P / 2 ? PADF : 0);
+          const int ob = BLK / 2 + (64 / JJ) * s + ((s >= P / 4 ? 1 : 0) + (s >= 3 * P / 4 ? 1 : 0)) * PADF;
+          d[s] = v2f{fa[oa] * w, fa[ob] * w};
+        }
+        wave_lds_fence();
+        return;
+      }
       const float* fa = xsf + (2 * (lane % JJ)) * a.hop + (lane / JJ);
       const float* fb = fa + a.hop;
 #pragma unroll
@@ -1443,7 +1470,11 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     if constexpr (MODE == kModeQuad) {
       if (stg == 4) {
         done = true;
-        if (!npred) rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 4>, upr, big, u_lo, u_lo)
+        // hop == fft_length / 4 (the default 75 % overlap): the instantiation whose parked span is padded against bank conflicts
+        if (!npred && 4 * s.fr.hop == KOUT && tune(c, kT_STAGE_PAD, 1))
+          rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 5>, upr, big, u_lo, u_lo)
+                     : go(k_stft_wave<C, MODE, false, false, W, J, false, 5>, upr, big, u_lo, u_lo);
+        else if (!npred) rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 4>, upr, big, u_lo, u_lo)
                                : go(k_stft_wave<C, MODE, false, false, W, J, false, 4>, upr, big, u_lo, u_lo);
         else rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, true, 4>, upr, big, u_lo, u_lo)
                         : go(k_stft_wave<C, MODE, false, false, W, J, true, 4>, upr, big, u_lo, u_lo);

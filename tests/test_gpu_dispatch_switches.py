@@ -40,6 +40,7 @@ CASES = [
     ("NXSIG_WAVE_NO_SPLIT=1", STFT),
     ("NXSIG_NO_AL8=1", ("tests/test_gpu_tuned_kernels.py", "stft_wave_variants")),
     ("NXSIG_NO_STAGE=1", ("tests/test_gpu_tuned_kernels.py", "stft_wave_variants")),
+    ("NXSIG_STAGE_PAD=0", ("tests/test_gpu_tuned_kernels.py tests/test_gpu_parity.py", "stft_wave_variants or stft_matches_oracle")),
     ("NXSIG_FIR32=0", FIR),
     ("NXSIG_FIR32=2", FIR),
     ("NXSIG_FIR_PAD_TAPS=0", FIR),

@@ -29,6 +29,8 @@ struct IstftWaveArgs {
   v2f* y;                     // c64[batch][segs_per_row * hop]
   v2f* dummy;
   const v2f* filt = nullptr;  // c64[K] spectrum filter (FILT variant of k_istft_wave only)
+  const v2f* zeros = nullptr; // c64[K] of zeros: the spectrum the tail-flush frames m >= M of k_istft_wave read (their samples are then
+                              // exactly zero and no per-sample `live` factor is needed)
   int* nf_list = nullptr;     // kernels that invert several frames per transform: units that hold a non-finite bin are reported here
                               // ({count, capacity, int64 (row << 40 | first frame) ...}) and redone frame by frame by k_istft_nf_fix
 };
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
   const v2f* zrow = a.z + (size_t)row * a.M * K + lane;
   v2f r[P], r2[DEEP ? P : 1];
   auto issue_into = [&](v2f* dst, int64_t m) {
-    const v2f* pz = zrow + (size_t)(m < a.M ? m : a.M - 1) * K;  // clamped: frames past the end contribute zero
+    const v2f* pz = m < a.M ? zrow + (size_t)m * K : a.zeros + lane;  // frames past the end (tail flush) are a spectrum of zeros
 #pragma unroll
     for (int s = 0; s < P; ++s) dst[s] = NTL ? __builtin_nontemporal_load(pz + 64 * s) : pz[64 * s];
   };
@@ -132,11 +134,10 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
     take_from(rn);
     __builtin_amdgcn_sched_barrier(0);
 
-    // (The clean-up stays EAGER here — a compare and a select per component — and the tail flush a multiply: the cold form of
-    // the other inverse kernels puts a wave-uniform branch into this loop, and the two-frames-ahead schedule lost more to the split
-    // scheduling region than the 33 instructions per frame were worth: -3.5 % against the round-3 build side by side,
-    // profiles/r04/ab_libs_round3_vs_round4.jsonl.)
-    const float live = m < a.M ? 1.0f : 0.0f;  // tail flush: frames m >= M do not exist
+    // (The clean-up stays EAGER here — a compare and a select per component: the cold form of the other inverse kernels puts a
+    // wave-uniform branch into this loop, and the two-frames-ahead schedule lost more to the split scheduling region than the 33
+    // instructions per frame were worth: -3.5 % against the round-3 build side by side, profiles/r04/ab_libs_round3_vs_round4.jsonl.
+    // The tail flush needs no factor: frames m >= M were loaded from a spectrum of zeros.)
     const int64_t j = m;                        // segment j is complete once frame j has been folded in
     // guarded normaliser of segment j from the host table (head rows 0..R-2, interior row R-1, tail rows R..2R-2)
     const int64_t trow = j < R - 1 ? j : (j >= a.M ? R + (j - a.M) : R - 1);
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_wave(IstftWaveArgs a) {
         for (int i = 0; i < R; ++i) {
           v2f v = fft_eps0(zz[e][i * QS + qq] * invK);  // Nx.ifft's clean-up (:609) precedes scale and window
           if (SCALE) v = v * a.scale;
-          f[i] = v * (wv[e][i * QS + qq] * live);
+          f[i] = v * wv[e][i * QS + qq];
         }
         if (R == 1) { out[e][qq] = f[0]; }
         else {
@@ -1087,6 +1088,13 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   { int rc3 = istft_den_table(c, R, s.hop, window_host, &a.den); if (rc3) return rc3; }
   a.y = reinterpret_cast<v2f*>(s.y);
   a.filt = reinterpret_cast<const v2f*>(s.filt);
+  {
+    static const std::vector<float2> zero_row((size_t)K, make_float2(0.f, 0.f));
+    const void* dz = nullptr;
+    int rcz = ctx_table(c, 0x2E20ull, zero_row.data(), zero_row.size() * sizeof(float2), &dz);
+    if (rcz) return rcz;
+    a.zeros = reinterpret_cast<const v2f*>(dz);
+  }
   void* dummy = nullptr;
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);

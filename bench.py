@@ -145,8 +145,8 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
       config 3  istft N=1024 hop=256, 16 x 60 s            10 240 B/frame  (K*8 read + hop*8 written, c64 out)
       config 4  stft  N=2048 hop=512, 8 ch x 600 s          18 432 B/frame  (one GPU's share of 64 channels)
       config 5  fir   257 taps :same, 8 ch x 600 s          8 B/sample      (4 in + 4 out)
-    Under a launcher EVERY rank runs this on its own shard (`barrier` lines the ranks up before each timed series so the GPUs of the
-    node work at the same time); main() reduces the per-rank kernel times with max-over-ranks.  `mix_ceiling` (configs 3 / 5): the
+    Under a launcher EVERY rank runs this on its own shard (`barrier` lines the ranks up before each of the two blocks so the GPUs
+    of the node work at the same time); main() reduces the per-rank kernel times with max-over-ranks.  `mix_ceiling` (configs 3 / 5): the
     same traffic with no math in the kernel's launch geometry (tools/diag_mix.hip), timed the same way in this process."""
     out = {}
     rng = np.random.Generator(np.random.PCG64(99))
@@ -164,7 +164,6 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         for _ in range(warm):
             fn()
         ctx.sync()
-        sync()
         ctx.timer_lap()
         for _ in range(reps):
             fn()
@@ -198,6 +197,9 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         gbs = nbytes / (ms * 1e-3) / 1e9
         d["mix_ceiling"] = {"GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "kernel_over_ceiling": d["achieved"] / gbs, "what": what}
 
+    # N > 1: the ranks are lined up ONCE per block, outside the try blocks — a rank whose block fails still meets the others at the
+    # next line-up (a barrier inside the timed helpers would be skipped by a failing rank and hang the rest)
+    sync()
     # ---- config 3: istft of 16 x 60 s
     L3 = SR * seconds3
     M3 = (L3 - N_FFT) // HOP + 1
@@ -227,6 +229,7 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
             b.free()
     except Exception as e:  # noqa: BLE001
         out["roofline_istft"] = {"error": repr(e)[:200]}
+    sync()
     # ---- configs 4 / 5: one GPU's 8 channels x 10 min
     z4 = None
     try:
@@ -271,18 +274,23 @@ def assembly_config4(ctx, group, lib, S, _lib, C, world, rank, channels, seconds
     ch = channels
     zt = x4 = None
     while True:
+        # the shard size must be the SAME on every rank (it is the all-gather's count): a rank that cannot allocate makes every
+        # rank halve the channel count (one all-reduce per attempt), never just itself
+        ok, err = True, None
         try:
             zt = ctx.empty((world, ch, M4, N4), np.complex64)
             x4 = ctx.empty((ch, L4), np.float32)
-            break
         except Exception as e:  # noqa: BLE001  (out of memory: a smaller shard)
-            for b in (zt, x4):
-                if b is not None:
-                    b.free()
-            zt = x4 = None
-            if ch == 1:
-                return {"error": "config-4-sized assembly buffers do not fit: " + repr(e)[:120]}
-            ch //= 2
+            ok, err = False, repr(e)[:120]
+        if group.allreduce([0.0 if ok else 1.0], "max")[0] == 0.0:
+            break
+        for b in (zt, x4):
+            if b is not None:
+                b.free()
+        zt = x4 = None
+        if ch == 1:
+            return {"error": "config-4-sized assembly buffers do not fit on some rank" + (": " + err if err else "")}
+        ch //= 2
     shard = ch * M4 * N4 * 8
     rng = np.random.Generator(np.random.PCG64(4242 + rank))
     chunk = rng.standard_normal(L4, dtype=np.float32)

@@ -179,3 +179,20 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt.replace("oracle/nx_oracle.py:_kaiser_i0", ""), f
+
+
+def test_no_launch_path_reads_the_environment():
+    """round 4: the switches live in the context (Tuning); the library's sources call getenv in exactly two places — the loop of
+    nxsig_ctx_create (tuning_from_env) and the RCCL library path at group creation"""
+    import glob
+    import re
+
+    calls = []
+    for f in glob.glob(os.path.join(ROOT, "nx_signal_amd", "csrc", "*.*")):
+        if not f.endswith((".cpp", ".hip", ".hpp", ".h")):
+            continue
+        for i, line in enumerate(open(f).read().splitlines(), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bgetenv\s*\(", code):
+                calls.append((os.path.basename(f), i))
+    assert sorted(f for f, _ in calls) == ["api.cpp", "group.cpp"], calls

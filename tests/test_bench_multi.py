@@ -105,3 +105,47 @@ def test_driver_launch_line_four_ranks_share_gpu():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     _check_line(lines[0], 4)
+
+
+def test_reduce_secondary_takes_the_slowest_rank_and_survives_a_failed_block():
+    """config3 / config4 / config5 of the N > 1 line: totals = world x per-rank work / max-over-ranks time; a rank whose block failed
+    (no kernel_ms) turns that config into an error entry without disturbing the others"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    sec = {"roofline_istft": {"kernel_ms": 0.40, "algorithmic_bytes": 1842708480, "frames": 179952, "workload": "c3", "frac": 0.57, "kernel_us": {}},
+           "roofline_stft2048": {"kernel_ms": 1.45, "algorithmic_bytes": 8293957632, "frames": 449976, "workload": "c4", "frac": 0.71, "kernel_us": {}},
+           "roofline_fir": {"error": "boom"}}
+    seen = []
+
+    def allreduce(vals, op):
+        seen.append((list(vals), op))
+        return [max(v, w) for v, w in zip(vals, [0.50, 1.40, 1e30])]   # another rank: slower istft, faster stft, failed fir
+
+    out = bench.reduce_secondary(sec, 8, allreduce)
+    assert seen == [([0.40, 1.45, 1e30], "max")]
+    assert out["config3"]["kernel_ms_max_over_ranks"] == 0.50 and out["config3"]["ranks"] == 8
+    assert abs(out["config3"]["frames_per_s_total"] - 8 * 179952 / 0.50e-3) < 1.0
+    assert abs(out["config3"]["per_gpu_frac"] - 1842708480 / 0.50e-3 / 1e9 / 8000.0) < 1e-9
+    assert out["config4"]["kernel_ms_max_over_ranks"] == 1.45
+    assert "error" in out["config5"] and out["config5"]["ranks"] == 8
+
+
+def test_effective_cores_reads_the_cgroup_quota(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import builtins
+
+    import bench
+
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("1600000 100000\n")
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    e = bench.effective_cores()
+    assert e["cgroup_quota"] == 16.0 and e["effective"] == min(16.0, float(e["affinity"])) and "cpu.max" in e["source"]

@@ -1,5 +1,5 @@
 """The iSTFT / FIR kernels beside their no-math traffic models (tools/diag_mix.hip) in ONE process, interleaved rounds: which part of
-the distance to the roofline is the access pattern's and which the math's.  usage: python tools/bench_mix.py [rounds=3]"""
+the distance to the roofline is the access pattern's and which the math's.  usage: python tools/bench_mix.py [rounds=3] [stft istft fir]"""
 import ctypes as C, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +23,30 @@ def timeit(fn, reps=20, warm=10):
     for _ in range(reps):
         fn(); ctx.timer_lap()
     return float(np.mean(ctx.timer_laps()))
+
+# ---- stft headline, 32 x 60 s
+if "stft" in (sys.argv[2:] or ["stft", "istft", "fir"]):
+    diag.nxdiag_stft_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int]
+    Bs = 32
+    xs = ctx.empty((Bs, L), np.float32)
+    chunk0 = rng.standard_normal(L, dtype=np.float32)
+    for r in range(Bs):
+        xr = np.roll(chunk0, 977 * r)
+        _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(xs.ptr + r * L * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
+    zs = ctx.empty((Bs, M, N), np.complex64)
+    tab = ctx.to_device(rng.standard_normal(3072).astype(np.float32))
+    ws = S.windows.hann(N); ps = _lib.StftParams(N, HOP, N, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
+    nbs = Bs * M * 9216
+    cases = {"stft kernel (headline)": lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xs.ptr), L, Bs, L, ws.ctypes.data_as(C.c_void_p), C.byref(ps), C.c_void_p(zs.ptr), None, 1))}
+    for ppw in (1, 2, 3, 4):
+        cases[f"stft mix {ppw} pairs/wave"] = (lambda ppw=ppw: diag.nxdiag_stft_mix(stream, C.c_void_p(xs.ptr), C.c_void_p(zs.ptr), C.c_void_p(tab.ptr), Bs, L, HOP, ppw))
+    res = {k: [] for k in cases}
+    for r in range(rounds):
+        for k, fn in cases.items():
+            res[k].append(nbs / (timeit(fn) * 1e-3) / 1e9)
+    for k, v in res.items():
+        print(json.dumps({"case": k, "GBps": [round(a, 1) for a in v], "frac_of_8TBps": round(float(np.median(v)) / 8000, 4)}), flush=True)
+    for b in (xs, zs, tab): b.free()
 
 # ---- istft, config 3
 B = 16

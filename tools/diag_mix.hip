@@ -16,6 +16,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long v = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
 template <int LB, bool NT = true>   // LB = bytes per lane per load: 8 (the shipped kernel's loads) or 16; NT: non-temporal loads (shipped) or default policy
 __global__ __launch_bounds__(256) void k_istft_mix(const v2f* __restrict__ z, v4f* __restrict__ y, long frames, long run_len, int halo) {
   const int lane = threadIdx.x & 63;
@@ -52,11 +58,6 @@ __global__ __launch_bounds__(256) void k_istft_mix(const v2f* __restrict__ z, v4
   }
 }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long v = (unsigned long long)base;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
-}
 
 template <int WIDE>   // 0: the shipped kernel's 8-byte accesses; 1: the pair's 1792-sample span once with 16-byte loads, 16-byte stores
 __global__ __launch_bounds__(256) void k_fir_mix(const float* __restrict__ x, float* __restrict__ y, long L, long pairs_per_row, long total, long chunk) {
@@ -102,7 +103,51 @@ __global__ __launch_bounds__(256) void k_fir_mix(const float* __restrict__ x, fl
   }
 }
 
+// The headline STFT kernel's stream (k_stft_wave<1024, pair>): short-lived 4-wave workgroups, `ppw` frame pairs per wave handed out in
+// dispatch order; per pair 2 x 16 four-byte loads per lane (frames A and B, hop apart: 75 % of the bytes re-read from cache), next pair
+// prefetched; 2 x 8 sixteen-byte `sc1 nt` buffer stores per lane (two 8 KiB spectrum rows); 12 KB of tables read per workgroup.
+__global__ __launch_bounds__(256) void k_stft_mix(const float* __restrict__ x, v4f* __restrict__ zout, const float* __restrict__ tab, long L, long M,
+                                                  long pairs_per_row, long total_pairs, int ppw, int hop) {
+  __shared__ float s_tab[3072];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 3072; i += 256) s_tab[i] = tab[i];
+  __syncthreads();
+  const long p0 = (long)blockIdx.x * 4 * ppw;
+  long p1 = p0 + 4L * ppw; if (p1 > total_pairs) p1 = total_pairs;
+  float ra[16], rb[16];
+  auto issue = [&](long p) {
+    const long row = p / pairs_per_row, pi = p - row * pairs_per_row;
+    const float* pa = x + row * L + (2 * pi) * hop + lane;
+    const float* pb = pa + hop;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { ra[s] = pa[64 * s]; rb[s] = pb[64 * s]; }
+  };
+  if (p0 + wave < p1) issue(p0 + wave);
+  for (long p = p0 + wave; p < p1; p += 4) {
+    float a = s_tab[lane], b = s_tab[1024 + lane];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { a += ra[s]; b += rb[s]; }
+    issue(p + 4 < p1 ? p + 4 : p);
+    const long row = p / pairs_per_row, pi = p - row * pairs_per_row;
+    v4f* zr = zout + ((row * M + 2 * pi) * 1024L) / 2;      // row of 1024 c64 = 512 v4f
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(zr, 8192), rB = make_rsrc(zr + 512, 8192);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{a, b, a + (float)q, b}), rA, lane * 16 + 1024 * q, 0, 18);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{b, a, b + (float)q, a}), rB, lane * 16 + 1024 * q, 0, 18);
+    }
+  }
+}
+
 extern "C" {
+// x: f32[rows][L], z: c64[rows][M][1024] with M = (L - 1024) / hop + 1 (even frame counts per row are walked; an odd last frame is skipped)
+int nxdiag_stft_mix(void* stream, const void* x, void* z, const void* tab, long rows, long L, int hop, int pairs_per_wave) {
+  const long M = (L - 1024) / hop + 1, ppr = M / 2, total = rows * ppr;
+  const long per_wg = 4L * pairs_per_wave;
+  hipLaunchKernelGGL(k_stft_mix, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (v4f*)z,
+                     (const float*)tab, L, M, ppr, total, pairs_per_wave, hop);
+  return (int)hipGetLastError();
+}
 // z: c64[frames][1024] (8 KiB per frame), y: c64[frames][256] (2 KiB per frame); returns 0 or a hipError_t
 int nxdiag_istft_mix2(void* stream, const void* z, void* y, long frames, int waves_per_cu, int halo, int load_bytes) {
   int dev = 0; hipDeviceProp_t pr;

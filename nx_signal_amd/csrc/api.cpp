@@ -180,7 +180,6 @@ int launch_stft(Ctx* c, const StftLaunch& a) {
   if (rc || handled) return rc;
   return launch_stft_generic(c, a);
 }
-int launch_istft_edge_fix(Ctx* c, const IstftLaunch& a, const float* window_host);
 int launch_istft_packed_wave(Ctx* c, const IstftLaunch& a, const float* window_host, bool* handled);
 int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
   bool handled = false;
@@ -188,8 +187,7 @@ int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
   if (a.onesided) {  // packed half spectrum in, real signal out (nxsig_istft_packed_f32)
     if ((rc = launch_istft_packed_wave(c, a, window_host, &handled))) return rc;
     if (handled) {
-      if ((rc = launch_istft_edge_fix(c, a, window_host))) return rc;
-      return launch_istft_nf_fix(c, a, a.nf_list, a.nf_frames_per_unit);
+      return launch_istft_fix(c, a, window_host);
     }
     // no fused kernel for this geometry: the Hermitian rows are written out, the complex path runs, its real part is kept
     const int64_t out_len = a.M * a.hop + (a.N - a.hop);
@@ -216,9 +214,9 @@ int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
     return launch_istft(c, b, window_host);
   }
   if (!handled && (rc = launch_istft_generic(c, a))) return rc;
-  if ((rc = launch_istft_edge_fix(c, a, window_host))) return rc;  // ill-conditioned edge samples recomputed in double
-  // kernels that invert several frames per transform reported their non-finite units: those samples again, frame by frame
-  return launch_istft_nf_fix(c, a, a.nf_list, a.nf_frames_per_unit);
+  // ill-conditioned edge samples recomputed in double; kernels that invert several frames per transform reported their non-finite
+  // units: those samples again, frame by frame (one launch for both)
+  return launch_istft_fix(c, a, window_host);
 }
 // filters longer than the overlap-save kernels take (> 4096 taps: impulse responses of seconds): one transform of
 // next_pow2(L + taps - 1) points per row, the way the reference's fftconvolve does it (lib/nx_signal/convolution.ex:252-329),

@@ -427,8 +427,9 @@ struct EdgeFixArgs {
   int32_t has_scale;
   float2* y;                // c64[batch][out_len]
   int64_t out_len;
-  const int64_t* idx;       // flagged sample indices (host-computed: 1e-10 < den[n] < tau), or nullptr = scan all n
+  const int64_t* idx;       // flagged samples, host-computed (1e-10 < den[n] < tau): {n, m_lo, m_hi, bits of (float)den} each; nullptr = scan all n
   int64_t n_idx;
+  int32_t batch = 1;        // rows (edge role of k_istft_edge_fix)
   float tau;
   const double2* tw;        // w_N^j = exp(+2 pi i j / N) in double, j in [0, N)
   const float2* filt;       // optional c64[N]: the frames are z * filt rounded to c64 (IstftLaunch::filt), or nullptr
@@ -446,22 +447,13 @@ __device__ __forceinline__ float2 istft_bin(const EdgeFixArgs& a, const float2* 
   return make_float2(c.x, -c.y);
 }
 
-// one output sample of one row, along the reference's chain in double (whole workgroup; `red` = 2 * kThreads doubles of LDS).
-// ALL = false: only ill-conditioned samples (1e-10 < den < tau) are recomputed; true: any sample (den <= 1e-10 divides by 1, :635)
-template <bool ALL>
-__device__ __forceinline__ void istft_sample_f64(const EdgeFixArgs& a, const int64_t row, const int64_t n, double* red) {
-  const int tid = threadIdx.x;
-  int64_t m_hi = n / a.hop;
-  if (m_hi > a.M - 1) m_hi = a.M - 1;
-  int64_t m_lo = (n - a.N + 1 <= 0) ? 0 : (n - a.N + a.hop) / a.hop;
-  double den = 0.0;
-  for (int64_t m = m_lo; m <= m_hi; ++m) {
-    const float w = fabsf(a.window[n - m * a.hop]);
-    den += (double)(w * w);
-  }
-  float d = (float)den;
-  if (ALL) { if (!(d > 1.0e-10f)) d = 1.0f; }
-  else if (!(d > 1.0e-10f) || d >= a.tau) return;  // uniform across the block
+// one output sample of one row, along the reference's chain in double, by ONE WAVE (round 4: a whole workgroup per sample spent its
+// time in an 8-level LDS reduction with barriers; a wave keeps N / 64 terms per lane in flight and reduces with six shuffles, and four
+// times as many samples are resident per CU — the pass after config 3's kernel went from 15.6 to ~6 us).
+// the sum itself: frames m_lo .. m_hi cover sample n, d = the guarded normaliser
+__device__ __forceinline__ void istft_sample_body(const EdgeFixArgs& a, const int64_t row, const int64_t n, const int64_t m_lo, const int64_t m_hi,
+                                                  const float d) {
+  const int lane = threadIdx.x & 63;
   const int rowlen = a.onesided ? (a.N >> 1) : a.N;
   const float2* zb = a.z + (size_t)row * a.M * rowlen;
   double acc_re = 0.0, acc_im = 0.0;
@@ -469,11 +461,10 @@ __device__ __forceinline__ void istft_sample_f64(const EdgeFixArgs& a, const int
     const int j = (int)(n - m * a.hop);
     const float2* zr = zb + (size_t)m * rowlen;
     double sr = 0.0, si = 0.0;
-    int tix = (int)(((int64_t)j * tid) % a.N);                 // twiddle index j k mod N, advanced without a division per term
-    const int tstep = (int)(((int64_t)j * kThreads) % a.N);
-    for (int k = tid; k < a.N; k += kThreads) {
-      const double2 t = a.tw[tix];
-      float2 v = istft_bin(a, zr, k);
+    // twiddle index j k mod N, advanced without a division per term (32-bit: j < N, and N < 2^24 for every caller)
+    int tix = a.N < (1 << 24) ? (int)((uint32_t)(j * lane) % (uint32_t)a.N) : (int)(((int64_t)j * lane) % a.N);
+    const int tstep = a.N < (1 << 24) ? (int)((uint32_t)(j * 64) % (uint32_t)a.N) : (int)(((int64_t)j * 64) % a.N);
+    auto term = [&](const double2 t, float2 v, const int k) {
       if (a.filt) {
         const float2 h = a.filt[k];
         v = make_float2((float)((double)v.x * (double)h.x - (double)v.y * (double)h.y),
@@ -481,62 +472,113 @@ __device__ __forceinline__ void istft_sample_f64(const EdgeFixArgs& a, const int
       }
       sr += (double)v.x * t.x - (double)v.y * t.y;
       si += (double)v.x * t.y + (double)v.y * t.x;
+    };
+    constexpr int U = 16;  // loads in flight per lane: the sum is a chain of dependent loads otherwise (N / 64 round trips)
+    int k = lane;
+    for (; k + 64 * (U - 1) < a.N; k += 64 * U) {
+      double2 t[U];
+      float2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        t[u] = a.tw[tix];
+        v[u] = istft_bin(a, zr, k + 64 * u);
+        tix += tstep;
+        if (tix >= a.N) tix -= a.N;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) term(t[u], v[u], k + 64 * u);
+    }
+    for (; k < a.N; k += 64) {
+      term(a.tw[tix], istft_bin(a, zr, k), k);
       tix += tstep;
       if (tix >= a.N) tix -= a.N;
     }
-    red[tid] = sr;
-    red[kThreads + tid] = si;
-    __syncthreads();
-    for (int s = kThreads / 2; s > 0; s >>= 1) {
-      if (tid < s) { red[tid] += red[tid + s]; red[kThreads + tid] += red[kThreads + tid + s]; }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      double dr = red[0] / (double)a.N, di = red[kThreads] / (double)a.N;
-      if (fabs(dr) <= 1.0e-10) dr = 0.0;   // Nx.ifft's eps clean-up, on the double result like the reference (App. A rule 7)
-      if (fabs(di) <= 1.0e-10) di = 0.0;
-      float fr = (float)dr, fi = (float)di;  // Nx.ifft rounds to c64
-      if (a.has_scale) { fr *= a.scale; fi *= a.scale; }
-      const float w = a.window[j];
-      fr *= w; fi *= w;
-      acc_re += (double)fr; acc_im += (double)fi;
-    }
-    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sr += __shfl_xor(sr, off); si += __shfl_xor(si, off); }   // every lane ends with the same sums
+    double dr = sr / (double)a.N, di = si / (double)a.N;
+    if (fabs(dr) <= 1.0e-10) dr = 0.0;   // Nx.ifft's eps clean-up, on the double result like the reference (App. A rule 7)
+    if (fabs(di) <= 1.0e-10) di = 0.0;
+    float fr = (float)dr, fi = (float)di;  // Nx.ifft rounds to c64
+    if (a.has_scale) { fr *= a.scale; fi *= a.scale; }
+    const float w = a.window[j];
+    fr *= w; fi *= w;
+    acc_re += (double)fr; acc_im += (double)fi;
   }
-  if (tid == 0) {
+  if (lane == 0) {
     if (a.onesided) reinterpret_cast<float*>(a.y)[(size_t)row * a.out_len + n] = (float)acc_re / d;
     else a.y[(size_t)row * a.out_len + n] = make_float2((float)acc_re / d, (float)acc_im / d);
   }
 }
 
-__global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a) {
-  __shared__ double red[2 * kThreads];
-  const int64_t n = a.idx ? a.idx[blockIdx.x] : (int64_t)blockIdx.x;
-  if (n >= a.out_len) return;
-  istft_sample_f64<false>(a, (int64_t)blockIdx.y, n, red);
+// ALL = false: only ill-conditioned samples (1e-10 < den < tau) are recomputed; true: any sample (den <= 1e-10 divides by 1, :635)
+template <bool ALL>
+__device__ __forceinline__ void istft_sample_f64(const EdgeFixArgs& a, const int64_t row, const int64_t n) {
+  int64_t m_hi = n / a.hop;
+  if (m_hi > a.M - 1) m_hi = a.M - 1;
+  const int64_t m_lo = (n - a.N + 1 <= 0) ? 0 : (n - a.N + a.hop) / a.hop;
+  double den = 0.0;
+  for (int64_t m = m_lo; m <= m_hi; ++m) {
+    const float w = fabsf(a.window[n - m * a.hop]);
+    den += (double)(w * w);
+  }
+  float d = (float)den;
+  if (ALL) { if (!(d > 1.0e-10f)) d = 1.0f; }
+  else if (!(d > 1.0e-10f) || d >= a.tau) return;  // uniform across the wave
+  istft_sample_body(a, row, n, m_lo, m_hi, d);
 }
 
-// ---- non-finite bins under kernels that invert SEVERAL frames with one transform (k_istft_wave_half: 2, _quad: 4 / 8).  The
-// reference inverts every frame on its own (Nx.ifft row by row, lib/nx_signal.ex:609), so an Inf / NaN bin reaches only the
-// samples of ITS frame; inside a shared transform it reaches the partner frames' samples too.  Those kernels therefore report
-// every unit that holds a non-finite bin ((row << 40) | first frame, appended to a device list), and this pass recomputes the
-// output samples the unit's frames touch with the per-sample chain above — frame by frame, exactly as the reference does.  Done
-// out of line on purpose: an in-kernel "solo" route cost the streaming kernels their third wave per SIMD (-12 %).
-// list[0] = number of entries appended (may exceed the capacity list[1]); entries follow as int64 from list + 2.
-__global__ __launch_bounds__(kThreads) void k_istft_nf_fix(EdgeFixArgs a, const int* __restrict__ list, int32_t frames_per_unit) {
-  __shared__ double red[2 * kThreads];
+constexpr int kFixWaves = kThreads / 64;   // samples per workgroup of the two fix-up kernels
+
+// ONE pass after any istft main kernel, two roles (round 4: they were three launches — a memset of the list's count, the edge fix-up
+// and the non-finite fix-up — on every call of the frame-packing kernels):
+//  * workgroups [0, edge_blocks * batch): the edge fix-up.  A wave takes one candidate sample of one row; with `idx` the candidates and
+//    their frame range / normaliser come from the host ({n, m_lo, m_hi, bits of d} per entry), without it every sample is a candidate.
+//  * workgroups beyond: non-finite bins under kernels that invert SEVERAL frames with one transform (k_istft_wave_half: 2, _quad:
+//    4 / 8).  The reference inverts every frame on its own (Nx.ifft row by row, lib/nx_signal.ex:609), so an Inf / NaN bin reaches only
+//    the samples of ITS frame; inside a shared transform it reaches the partner frames' samples too.  Those kernels therefore report
+//    every unit that holds a non-finite bin ((row << 40) | first frame, appended to a device list), and these workgroups recompute the
+//    output samples the unit's frames touch with the per-sample chain above — frame by frame, exactly as the reference does.  Done out
+//    of line on purpose: an in-kernel "solo" route cost the streaming kernels their third wave per SIMD (-12 %).
+//    list[0] = number of entries appended (may exceed the capacity list[1]); entries follow as int64 from list + 2; list[-2] is a
+//    ticket: the workgroup that finishes last puts the count back to zero, so an empty list (every call but the poisoned ones) costs
+//    one load per workgroup and nothing is cleared between calls.
+__global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a, int64_t edge_blocks, int* __restrict__ list, int32_t frames_per_unit,
+                                                             int32_t nf_blocks) {
+  const int wave = threadIdx.x >> 6;
+  const int64_t b = blockIdx.x;
+  if (b < edge_blocks * a.batch) {
+    const int64_t row = b / edge_blocks;
+    const int64_t i = (b - row * edge_blocks) * kFixWaves + wave;
+    if (a.idx) {
+      if (i >= a.n_idx) return;
+      const int64_t* e = a.idx + 4 * i;
+      istft_sample_body(a, row, e[0], e[1], e[2], __int_as_float((int)e[3]));
+    } else if (i < a.out_len) {
+      istft_sample_f64<false>(a, row, i);
+    }
+    return;
+  }
   int cnt = list[0];
+  if (cnt <= 0) return;                // the usual case; nothing to put back either
   if (cnt > list[1]) cnt = list[1];
-  if (cnt <= 0) return;
   const int64_t* ent = reinterpret_cast<const int64_t*>(list + 2);
   const int64_t span = (int64_t)(frames_per_unit - 1) * a.hop + a.N;   // samples the unit's frames touch
   const int64_t total = (int64_t)cnt * span;
-  for (int64_t wk = blockIdx.x; wk < total; wk += gridDim.x) {
+  const int64_t nb = b - edge_blocks * a.batch;
+  for (int64_t wk = nb * kFixWaves + wave; wk < total; wk += (int64_t)nf_blocks * kFixWaves) {
     const int64_t e = wk / span, si = wk - e * span;
     const int64_t row = ent[e] >> 40, m0 = ent[e] & (((int64_t)1 << 40) - 1);
     const int64_t n = m0 * a.hop + si;
-    if (n < a.out_len) istft_sample_f64<true>(a, row, n, red);
-    __syncthreads();
+    if (n < a.out_len) istft_sample_f64<true>(a, row, n);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(list - 2, 1) == nf_blocks - 1) {   // every workgroup of this role has read the count and done its share
+      list[0] = 0;
+      list[-2] = 0;
+      __threadfence();
+    }
   }
 }
 
@@ -1319,140 +1361,123 @@ int launch_fir_generic(Ctx* c, const FirLaunch& s) {
   return NXSIG_OK;
 }
 
-// the list a frame-packing istft kernel reports its non-finite units to (see k_istft_nf_fix): {count, capacity, int64 entries};
-// the count is zeroed on the stream ahead of the kernel
+// the list a frame-packing istft kernel reports its non-finite units to (see k_istft_edge_fix): {ticket, pad | count, capacity, int64
+// entries}; the pointer handed out is the count's.  Count and ticket are zero between calls: the fix-up pass that consumes a
+// non-empty list puts them back (no per-call memset).
 int istft_nf_list(Ctx* c, int64_t capacity, int** list) {
   if (capacity > 0x7fffffffLL) capacity = 0x7fffffffLL;
-  if (c->scratch_bytes[23] < (size_t)(capacity + 1) * 8) {
-    // (re)allocation: the capacity word is written once, synchronously (it describes the buffer, not the call)
+  if (c->scratch_bytes[23] < (size_t)(capacity + 2) * 8) {
+    // (re)allocation: the header is written once, synchronously (it describes the buffer, not the call)
     const int64_t cap = capacity < 4096 ? 4096 : capacity * 2;
     void* p = nullptr;
-    int rc = ctx_scratch(c, 23, (size_t)(cap + 1) * 8, &p);
+    int rc = ctx_scratch(c, 23, (size_t)(cap + 2) * 8, &p);
     if (rc) return rc;
-    const int hdr[2] = {0, (int)(cap > 0x7fffffffLL ? 0x7fffffffLL : cap)};
+    const int hdr[4] = {0, 0, 0, (int)(cap > 0x7fffffffLL ? 0x7fffffffLL : cap)};
     NXSIG_HIP_TRY(hipMemcpy(p, hdr, sizeof(hdr), hipMemcpyHostToDevice));
   }
-  // per call: the count goes back to zero on the stream, ahead of the kernel (a memset node: capturable into a HIP graph)
-  NXSIG_HIP_TRY(hipMemsetAsync(c->scratch[23], 0, sizeof(int), c->stream));
-  *list = reinterpret_cast<int*>(c->scratch[23]);
+  *list = reinterpret_cast<int*>(c->scratch[23]) + 2;
   return NXSIG_OK;
 }
 
-int launch_istft_nf_fix(Ctx* c, const IstftLaunch& s, const int* list, int frames_per_unit) {
-  if (!list || s.M == 0 || s.batch == 0) return NXSIG_OK;
-  EdgeFixArgs a;
-  a.z = s.z; a.filt = s.filt; a.M = s.M; a.N = s.N; a.hop = s.hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
-  a.y = s.y; a.out_len = s.M * s.hop + (s.N - s.hop);
-  a.idx = nullptr; a.n_idx = 0; a.tau = 0.0f; a.onesided = s.onesided ? 1 : 0;
-  {  // inverse twiddles in double (host libm), cached per N (the table of launch_istft_edge_fix)
-    std::vector<double2> tw((size_t)s.N);
-    for (int j = 0; j < s.N; ++j) {
-      const double ang = 6.283185307179586476925286766559 * (double)j / (double)s.N;
-      tw[j] = make_double2(std::cos(ang), std::sin(ang));
-    }
-    const void* d = nullptr;
-    int rc = ctx_table(c, 0xED6Eull, tw.data(), tw.size() * sizeof(double2), &d);
-    if (rc) return rc;
-    a.tw = reinterpret_cast<const double2*>(d);
+// w_N^j = exp(+2 pi i j / N) in double (host libm): built once per context and N (the content-addressed table cache would
+// otherwise make every call recompute N sine / cosine pairs just to look the table up)
+static int edge_fix_twiddles(Ctx* c, int N, const double2** out) {
+  const uint64_t key = 0xED6E00000000ull ^ (uint64_t)(uint32_t)N;
+  auto hit = c->memo.find(key);
+  if (hit != c->memo.end()) { *out = reinterpret_cast<const double2*>(hit->second[0]); return NXSIG_OK; }
+  std::vector<double2> tw((size_t)N);
+  for (int j = 0; j < N; ++j) {
+    const double ang = 6.283185307179586476925286766559 * (double)j / (double)N;
+    tw[j] = make_double2(std::cos(ang), std::sin(ang));
   }
-  hipLaunchKernelGGL(k_istft_nf_fix, dim3((unsigned)(c->num_cus * 8)), dim3(kThreads), 0, c->stream, a, list, (int32_t)frames_per_unit);
-  NXSIG_HIP_TRY(hipGetLastError());
+  const void* d = nullptr;
+  int rc = ctx_table(c, 0xED6Eull, tw.data(), tw.size() * sizeof(double2), &d);
+  if (rc) return rc;
+  c->memo[key] = {reinterpret_cast<uint64_t>(d)};
+  *out = reinterpret_cast<const double2*>(d);
   return NXSIG_OK;
 }
 
-// launched after ANY istft main kernel (generic or tuned): see k_istft_edge_fix
-int launch_istft_edge_fix(Ctx* c, const IstftLaunch& s, const float* window_host) {
+// The pass after ANY istft main kernel (generic or tuned): k_istft_edge_fix, both roles in one launch — the ill-conditioned edge
+// samples recomputed in double and, for the kernels that invert several frames per transform (s.nf_list), the units they reported.
+int launch_istft_fix(Ctx* c, const IstftLaunch& s, const float* window_host) {
   if (s.M == 0 || s.batch == 0) return NXSIG_OK;
   const int N = s.N, hop = s.hop;
   const int64_t out_len = s.M * hop + (N - hop);
-  // everything derived on the host below is a pure function of (window, hop, M): memoised per context
-  // key = hash of (hop, M, N) AS DATA followed by the window's content (shifting them into the seed aliased for large M / hop)
-  const int64_t ekey_geom[3] = {(int64_t)hop, (int64_t)s.M, (int64_t)N};
-  const uint64_t ekey = fnv1a(fnv1a(0xED6Full, ekey_geom, sizeof(ekey_geom)), window_host, (size_t)N * sizeof(float));
-  {
-    auto hit = c->memo.find(ekey);
-    if (hit != c->memo.end()) {
-      const std::vector<uint64_t>& v = hit->second;  // {mode, tau bits, tw, idx, n_idx}
-      if (v[0] == 0) return NXSIG_OK;
-      EdgeFixArgs a;
-      uint32_t tb = (uint32_t)v[1];
-      std::memcpy(&a.tau, &tb, 4);
-      a.z = s.z; a.filt = s.filt; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
-      a.y = s.y; a.out_len = out_len; a.onesided = s.onesided ? 1 : 0;
-      a.tw = reinterpret_cast<const double2*>(v[2]);
-      a.idx = reinterpret_cast<const int64_t*>(v[3]);
-      a.n_idx = (int64_t)v[4];
-      const int64_t blocks = v[0] == 1 ? a.n_idx : out_len;
-      if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "istft: signal too long for the edge fix-up grid");
-      dim3 grid((unsigned)blocks, (unsigned)s.batch);
-      hipLaunchKernelGGL(k_istft_edge_fix, grid, dim3(kThreads), 0, c->stream, a);
-      NXSIG_HIP_TRY(hipGetLastError());
-      return NXSIG_OK;
-    }
-  }
-  // interior normaliser is periodic in n with period hop: den_mid[r] = sum_{j = r (mod hop)} |w[j]|^2
-  const int period = hop < N ? hop : N;
-  double dmin = 1e300, dmax = 0.0;
-  for (int r = 0; r < period; ++r) {
-    double d = 0.0;
-    for (int j = r; j < N; j += hop) { const float w = std::fabs(window_host[j]); d += (double)(w * w); }
-    dmin = d < dmin ? d : dmin;
-    dmax = d > dmax ? d : dmax;
-  }
-  if (!(dmax > 0.0)) { c->memo[ekey] = {0, 0, 0, 0, 0}; return NXSIG_OK; }
   EdgeFixArgs a;
-  a.tau = (float)(0.02 * dmax);
   a.z = s.z; a.filt = s.filt; a.M = s.M; a.N = N; a.hop = hop; a.window = s.window; a.scale = s.scale_mul; a.has_scale = s.has_scale;
-  a.y = s.y; a.out_len = out_len; a.onesided = s.onesided ? 1 : 0;
-  a.idx = nullptr; a.n_idx = 0;
-  // inverse twiddles in double (host libm), cached per N
-  {
-    std::vector<double2> tw((size_t)N);
-    for (int j = 0; j < N; ++j) {
-      const double ang = 6.283185307179586476925286766559 * (double)j / (double)N;
-      tw[j] = make_double2(std::cos(ang), std::sin(ang));
-    }
-    const void* d = nullptr;
-    int rc = ctx_table(c, 0xED6Eull, tw.data(), tw.size() * sizeof(double2), &d);
-    if (rc) return rc;
-    a.tw = reinterpret_cast<const double2*>(d);
-  }
-  int64_t blocks;
-  if (hop < N && dmin >= (double)a.tau) {
-    // well-conditioned interior: only samples of the partial-overlap head / tail can be flagged, and which ones is a
-    // pure function of the window -> list them on the host (a few hundred), launch exactly those
-    const int64_t head_cnt = (N - hop) < out_len ? (N - hop) : out_len;
-    const int64_t tail_start = s.M * hop > head_cnt ? s.M * hop : head_cnt;
-    std::vector<int64_t> idx;
-    auto consider = [&](int64_t n) {
-      int64_t m_hi = n / hop;
-      if (m_hi > s.M - 1) m_hi = s.M - 1;
-      const int64_t m_lo = (n - N + 1 <= 0) ? 0 : (n - N + hop) / hop;
-      double den = 0.0;
-      for (int64_t m = m_lo; m <= m_hi; ++m) { const float w = std::fabs(window_host[n - m * hop]); den += (double)(w * w); }
-      const float d = (float)den;
-      if (d > 1.0e-10f && d < a.tau) idx.push_back(n);
-    };
-    for (int64_t n = 0; n < head_cnt; ++n) consider(n);
-    for (int64_t n = tail_start; n < out_len; ++n) consider(n);
-    if (idx.empty()) { c->memo[ekey] = {0, 0, 0, 0, 0}; return NXSIG_OK; }
-    const void* d = nullptr;
-    int rc = ctx_table(c, 0x1D8ull, idx.data(), idx.size() * sizeof(int64_t), &d);
-    if (rc) return rc;
-    a.idx = reinterpret_cast<const int64_t*>(d);
-    a.n_idx = (int64_t)idx.size();
-    blocks = a.n_idx;
+  a.y = s.y; a.out_len = out_len; a.onesided = s.onesided ? 1 : 0; a.batch = s.batch;
+  a.idx = nullptr; a.n_idx = 0; a.tau = 0.0f; a.tw = nullptr;
+  // which samples are candidates is a pure function of (window, hop, M): memoised per context as {mode, tau bits, idx, n_idx}
+  // key = hash of (hop, M, N) AS DATA followed by the window's content (shifting them into the seed aliased for large M / hop)
+  uint64_t mode = 0;
+  const int64_t ekey_geom[3] = {(int64_t)hop, (int64_t)s.M, (int64_t)N};
+  const uint64_t ekey = fnv1a(fnv1a(0xED70ull, ekey_geom, sizeof(ekey_geom)), window_host, (size_t)N * sizeof(float));
+  auto hit = c->memo.find(ekey);
+  if (hit != c->memo.end()) {
+    const std::vector<uint64_t>& v = hit->second;
+    mode = v[0];
+    uint32_t tb = (uint32_t)v[1];
+    std::memcpy(&a.tau, &tb, 4);
+    a.idx = reinterpret_cast<const int64_t*>(v[2]);
+    a.n_idx = (int64_t)v[3];
   } else {
-    blocks = out_len;  // ill-conditioned interior (e.g. hop == N under a tapered window): every sample is a candidate
-  }
-  {
+    // interior normaliser is periodic in n with period hop: den_mid[r] = sum_{j = r (mod hop)} |w[j]|^2
+    const int period = hop < N ? hop : N;
+    double dmin = 1e300, dmax = 0.0;
+    for (int r = 0; r < period; ++r) {
+      double d = 0.0;
+      for (int j = r; j < N; j += hop) { const float w = std::fabs(window_host[j]); d += (double)(w * w); }
+      dmin = d < dmin ? d : dmin;
+      dmax = d > dmax ? d : dmax;
+    }
+    if (dmax > 0.0) {
+      a.tau = (float)(0.02 * dmax);
+      if (hop < N && dmin >= (double)a.tau) {
+        // well-conditioned interior: only samples of the partial-overlap head / tail can be flagged, and which ones is a
+        // pure function of the window -> list them on the host (a few hundred) with their frame range and normaliser
+        const int64_t head_cnt = (N - hop) < out_len ? (N - hop) : out_len;
+        const int64_t tail_start = s.M * hop > head_cnt ? s.M * hop : head_cnt;
+        std::vector<int64_t> idx;
+        auto consider = [&](int64_t n) {
+          int64_t m_hi = n / hop;
+          if (m_hi > s.M - 1) m_hi = s.M - 1;
+          const int64_t m_lo = (n - N + 1 <= 0) ? 0 : (n - N + hop) / hop;
+          double den = 0.0;
+          for (int64_t m = m_lo; m <= m_hi; ++m) { const float w = std::fabs(window_host[n - m * hop]); den += (double)(w * w); }
+          const float d = (float)den;
+          if (d > 1.0e-10f && d < a.tau) {
+            uint32_t db;
+            std::memcpy(&db, &d, 4);
+            idx.push_back(n); idx.push_back(m_lo); idx.push_back(m_hi); idx.push_back((int64_t)db);
+          }
+        };
+        for (int64_t n = 0; n < head_cnt; ++n) consider(n);
+        for (int64_t n = tail_start; n < out_len; ++n) consider(n);
+        if (!idx.empty()) {
+          const void* d = nullptr;
+          int rc = ctx_table(c, 0x1D9ull, idx.data(), idx.size() * sizeof(int64_t), &d);
+          if (rc) return rc;
+          a.idx = reinterpret_cast<const int64_t*>(d);
+          a.n_idx = (int64_t)idx.size() / 4;
+          mode = 1;
+        }
+      } else {
+        mode = 2;  // ill-conditioned interior (e.g. hop == N under a tapered window): every sample is a candidate
+      }
+    }
     uint32_t tb;
     std::memcpy(&tb, &a.tau, 4);
-    c->memo[ekey] = {a.idx ? 1ull : 2ull, (uint64_t)tb, reinterpret_cast<uint64_t>(a.tw), reinterpret_cast<uint64_t>(a.idx), (uint64_t)a.n_idx};
+    c->memo[ekey] = {mode, (uint64_t)tb, reinterpret_cast<uint64_t>(a.idx), (uint64_t)a.n_idx};
   }
+  if (mode == 0 && !s.nf_list) return NXSIG_OK;
+  { int rc = edge_fix_twiddles(c, N, &a.tw); if (rc) return rc; }
+  const int64_t edge_blocks = mode == 0 ? 0 : ((mode == 1 ? a.n_idx : out_len) + kFixWaves - 1) / kFixWaves;
+  const int32_t nf_blocks = s.nf_list ? c->num_cus * 2 : 0;
+  const int64_t blocks = edge_blocks * s.batch + nf_blocks;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "istft: signal too long for the edge fix-up grid");
-  dim3 grid((unsigned)blocks, (unsigned)s.batch);
-  hipLaunchKernelGGL(k_istft_edge_fix, grid, dim3(kThreads), 0, c->stream, a);
+  hipLaunchKernelGGL(k_istft_edge_fix, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, edge_blocks, s.nf_list,
+                     (int32_t)s.nf_frames_per_unit, nf_blocks);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
 }

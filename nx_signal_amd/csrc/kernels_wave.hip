@@ -1118,14 +1118,21 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   a.total_runs = a.runs_per_row * s.batch;
   const int64_t blocks = (a.total_runs + W - 1) / W;
   if (HALF) {
-    std::vector<float2> twH((size_t)K / 2);
-    for (int k0 = 0; k0 < K / 2; ++k0) {
-      const double ang = -6.283185307179586476925286766559 * (double)k0 / (double)K;
-      twH[k0] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-    }
     const void* dh = nullptr;
-    int rc4 = ctx_table(c, 0x7748ull ^ (uint64_t)K, twH.data(), twH.size() * sizeof(float2), &dh);
-    if (rc4) return rc4;
+    {  // built once per context (the content-addressed table cache alone would recompute the sines on every call to look it up)
+      auto hit = c->memo.find(0x774800000000ull ^ (uint64_t)K);
+      if (hit != c->memo.end()) dh = reinterpret_cast<const void*>(hit->second[0]);
+      else {
+        std::vector<float2> twH((size_t)K / 2);
+        for (int k0 = 0; k0 < K / 2; ++k0) {
+          const double ang = -6.283185307179586476925286766559 * (double)k0 / (double)K;
+          twH[k0] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+        int rc4 = ctx_table(c, 0x7748ull ^ (uint64_t)K, twH.data(), twH.size() * sizeof(float2), &dh);
+        if (rc4) return rc4;
+        c->memo[0x774800000000ull ^ (uint64_t)K] = {reinterpret_cast<uint64_t>(dh)};
+      }
+    }
     a.twH = reinterpret_cast<const v2f*>(dh);
     const size_t lds = (size_t)(K / 2) * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)(K / 2) * 8 + (size_t)W * XCH * 8;
     // every run also walks its halo units: capacity = units walked by all runs
@@ -1137,14 +1144,21 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
     } else if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_half<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     else hipLaunchKernelGGL((k_istft_wave_half<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
   } else if (DBL) {
-    std::vector<float2> twH((size_t)K);
-    for (int n = 0; n < K; ++n) {
-      const double ang = 6.283185307179586476925286766559 * (double)n / (double)(2 * K);
-      twH[n] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-    }
     const void* dh = nullptr;
-    int rc4 = ctx_table(c, 0x7749ull ^ (uint64_t)K, twH.data(), twH.size() * sizeof(float2), &dh);
-    if (rc4) return rc4;
+    {
+      auto hit = c->memo.find(0x774900000000ull ^ (uint64_t)K);
+      if (hit != c->memo.end()) dh = reinterpret_cast<const void*>(hit->second[0]);
+      else {
+        std::vector<float2> twH((size_t)K);
+        for (int n = 0; n < K; ++n) {
+          const double ang = 6.283185307179586476925286766559 * (double)n / (double)(2 * K);
+          twH[n] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+        int rc4 = ctx_table(c, 0x7749ull ^ (uint64_t)K, twH.data(), twH.size() * sizeof(float2), &dh);
+        if (rc4) return rc4;
+        c->memo[0x774900000000ull ^ (uint64_t)K] = {reinterpret_cast<uint64_t>(dh)};
+      }
+    }
     a.twH = reinterpret_cast<const v2f*>(dh);
     const size_t lds = (size_t)(2 * K) * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)K * 8 + (size_t)W * XCH * 8;
     if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_dbl<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
@@ -1234,14 +1248,19 @@ static int launch_istft_wave_4k(Ctx* c, const IstftLaunch& s, const float* windo
   { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
   a.dummy = reinterpret_cast<v2f*>(dummy);
   {
-    std::vector<float2> t4(K);
-    for (int k = 0; k < K; ++k) {
-      const double ang = 6.283185307179586476925286766559 * (double)k / 4096.0;  // conj(w_4096^k)
-      t4[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-    }
     const void* d4 = nullptr;
-    int rc4 = ctx_table(c, 0x8B14ull, t4.data(), t4.size() * sizeof(float2), &d4);
-    if (rc4) return rc4;
+    auto hit = c->memo.find(0x8B1400000000ull ^ (uint64_t)K);   // built once per context
+    if (hit != c->memo.end()) d4 = reinterpret_cast<const void*>(hit->second[0]);
+    else {
+      std::vector<float2> t4(K);
+      for (int k = 0; k < K; ++k) {
+        const double ang = 6.283185307179586476925286766559 * (double)k / 4096.0;  // conj(w_4096^k)
+        t4[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      }
+      int rc4 = ctx_table(c, 0x8B14ull, t4.data(), t4.size() * sizeof(float2), &d4);
+      if (rc4) return rc4;
+      c->memo[0x8B1400000000ull ^ (uint64_t)K] = {reinterpret_cast<uint64_t>(d4)};
+    }
     a.twH = reinterpret_cast<const v2f*>(d4);
   }
   const int64_t total_segs = a.segs_per_row * s.batch;

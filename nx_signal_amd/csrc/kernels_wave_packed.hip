@@ -189,14 +189,19 @@ static int launch_istft_packed_R(Ctx* c, const IstftLaunch& s, const float* wind
   { int rc = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc) return rc; }
   a.dummy = reinterpret_cast<float*>(dummy);
   {
-    std::vector<float2> twH((size_t)K / 2);
-    for (int k0 = 0; k0 < K / 2; ++k0) {
-      const double ang = -6.283185307179586476925286766559 * (double)k0 / (double)K;
-      twH[k0] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-    }
     const void* dh = nullptr;
-    int rc = ctx_table(c, 0x7748ull ^ (uint64_t)K, twH.data(), twH.size() * sizeof(float2), &dh);
-    if (rc) return rc;
+    auto hit = c->memo.find(0x774800000000ull ^ (uint64_t)K);   // shared with launch_istft_wave_R's pair kernel: built once per context
+    if (hit != c->memo.end()) dh = reinterpret_cast<const void*>(hit->second[0]);
+    else {
+      std::vector<float2> twH((size_t)K / 2);
+      for (int k0 = 0; k0 < K / 2; ++k0) {
+        const double ang = -6.283185307179586476925286766559 * (double)k0 / (double)K;
+        twH[k0] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      }
+      int rc = ctx_table(c, 0x7748ull ^ (uint64_t)K, twH.data(), twH.size() * sizeof(float2), &dh);
+      if (rc) return rc;
+      c->memo[0x774800000000ull ^ (uint64_t)K] = {reinterpret_cast<uint64_t>(dh)};
+    }
     a.twH = reinterpret_cast<const v2f*>(dh);
   }
   const int64_t total_segs = a.segs_per_row * s.batch;

@@ -191,8 +191,8 @@ struct IstftLaunch {
   const float2* filt = nullptr;  // optional device c64[K]: every frame's spectrum is multiplied by it first (z * H of the
                                  // STFT-domain filtering chain, guides/filtering.livemd:141), rounded to c64 like Nx.multiply
   // set by a wave launcher whose kernel inverts several frames with ONE transform: the device list of units that hold a
-  // non-finite bin and the frames per unit; launch_istft then recomputes those units' samples frame by frame (k_istft_nf_fix)
-  mutable const int* nf_list = nullptr;
+  // non-finite bin and the frames per unit; launch_istft then recomputes those units' samples frame by frame (k_istft_edge_fix's second role)
+  mutable int* nf_list = nullptr;
   mutable int nf_frames_per_unit = 0;
   // packed one-sided form (nxsig_istft_packed_f32): z is c64[batch][M][K / 2] — bins 0 .. K/2 - 1 with Re X[K/2] in the imaginary
   // part of bin 0 — and y is REAL f32[batch][M*hop + N-hop]
@@ -202,7 +202,7 @@ int launch_half_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, 
 int launch_full_from_packed(Ctx* c, const float2* zp, int64_t rows, int32_t K, float2* out);
 int launch_real_from_c64(Ctx* c, const float2* in, int64_t n, float* out);
 int istft_nf_list(Ctx* c, int64_t capacity, int** list);
-int launch_istft_nf_fix(Ctx* c, const IstftLaunch& s, const int* list, int frames_per_unit);
+int launch_istft_fix(Ctx* c, const IstftLaunch& s, const float* window_host);   // k_istft_edge_fix: edge samples + reported non-finite units
 int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host);
 
 int launch_as_windowed(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, const Framing& fr, float* out);

@@ -62,12 +62,32 @@ for wpc in (8, 12, 16):
     for lb in (8, 16, 108, 116):
         for halo in (3, 0):
             cases[f"istft mix {wpc} runs/CU {lb % 100:2d}-B {'default-policy' if lb > 100 else 'nt'} loads halo {halo}"] = (lambda wpc=wpc, lb=lb, halo=halo: diag.nxdiag_istft_mix2(stream, C.c_void_p(z.ptr), C.c_void_p(y.ptr), B * M, wpc, halo, lb))
+diag.nxdiag_istft_mix3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int]
+for rl in (2, 4, 8, 16, 32, 64):
+    for halo in (3, 0):
+        for lb in (8, 16):
+            cases[f"istft mix short-lived workgroups, {rl} frames/wave {lb:2d}-B nt loads halo {halo}"] = (lambda rl=rl, halo=halo, lb=lb: diag.nxdiag_istft_mix3(stream, C.c_void_p(z.ptr), C.c_void_p(y.ptr), B * M, rl, halo, lb))
+diag.nxdiag_istft_mix4.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int]
+for wpc in (8, 12):
+    for wb in (0, 1, 4, 8):
+        cases[f"istft mix {wpc} runs/CU halo 0, stores in bursts of {wb} frames" if wb else f"istft mix {wpc} runs/CU halo 0, NO stores (8 KiB per frame counted)"] = (lambda wpc=wpc, wb=wb: diag.nxdiag_istft_mix4(stream, C.c_void_p(z.ptr), C.c_void_p(y.ptr), B * M, wpc, 0, wb))
+diag.nxdiag_istft_mix_pol.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int]
+def polname(a): return "+".join(n for b, n in ((1, "sc0"), (16, "sc1"), (2, "nt")) if a & b) or "default"
+for la, sa in ((2, 0), (2, 2), (2, 16), (2, 18), (2, 1), (2, 17), (2, 19), (2, 3), (0, 2), (0, 18), (16, 18), (18, 18), (0, 0), (1, 18), (17, 18), (3, 18)):
+    cases[f"istft mix 8 runs/CU halo 0 policy: loads {polname(la)}, stores {polname(sa)}"] = (lambda la=la, sa=sa: _lib.check(diag.nxdiag_istft_mix_pol(stream, C.c_void_p(z.ptr), C.c_void_p(y.ptr), B * M, 8, la, sa)))
+if "istft-policy" in sys.argv[2:]:
+    cases = {k: v for k, v in cases.items() if "policy" in k or " 8 runs/CU  8-B nt" in k or k == "istft kernel"}
+if "istft-bursts" in sys.argv[2:]:
+    cases = {k: v for k, v in cases.items() if "bursts" in k or "NO stores" in k or " 8 runs/CU  8-B nt" in k or k == "istft kernel"}
+if "istft-short" in sys.argv[2:]:
+    cases = {k: v for k, v in cases.items() if "short-lived" in k or " 8 runs/CU  8-B nt" in k or k == "istft kernel"}
 res = {k: [] for k in cases}
 for r in range(rounds):
     for k, fn in cases.items():
-        res[k].append(nb / (timeit(fn) * 1e-3) / 1e9)
+        res[k].append((B * M * 8192 if "NO stores" in k else nb) / (timeit(fn) * 1e-3) / 1e9)
 for k, v in res.items():
     print(json.dumps({"case": k, "GBps": [round(a, 1) for a in v], "frac_of_8TBps": round(float(np.median(v)) / 8000, 4)}), flush=True)
+if "only-istft" in sys.argv[2:]: sys.exit(0)
 # the same streams over CONSTANT data (zeros): what part of the ceiling is the data's (bus toggling / power), not the pattern's
 zero = np.zeros(1 << 22, np.uint8)
 for off in range(0, B * M * N * 8, zero.nbytes):
@@ -92,7 +112,7 @@ y5 = ctx.empty((B4, L4), np.float32)
 h = S.filters.firwin(257, [4000.0], sampling_rate=float(SR)); hp = h.ctypes.data_as(C.c_void_p)
 nb = B4 * L4 * 8
 cases = {"fir kernel": lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, hp, 257, _lib.CONV_SAME, C.c_void_p(y5.ptr), 1))}
-for ppw in (8, 16):
+for ppw in (1, 2, 3, 4, 6, 8, 16):
     for wide in (0, 1):
         cases[f"fir mix {ppw} pairs/wave {'16' if wide else ' 8'}-B accesses"] = (lambda ppw=ppw, wide=wide: diag.nxdiag_fir_mix2(stream, C.c_void_p(x4.ptr), C.c_void_p(y5.ptr), B4, L4, ppw, wide))
 res = {k: [] for k in cases}

@@ -22,7 +22,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
 }
 
-template <int LB, bool NT = true>   // LB = bytes per lane per load: 8 (the shipped kernel's loads) or 16; NT: non-temporal loads (shipped) or default policy
+template <int LB, bool NT = true, int WB = 1>   // LB = bytes per lane per load: 8 (the shipped kernel's loads) or 16; NT: non-temporal loads (shipped) or default policy
+                                                // WB: frames per burst of stores (1 = shipped; 4 / 8: the same bytes in fewer, longer bursts; 0: no stores at all)
 __global__ __launch_bounds__(256) void k_istft_mix(const v2f* __restrict__ z, v4f* __restrict__ y, long frames, long run_len, int halo) {
   const int lane = threadIdx.x & 63;
   const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void k_istft_mix(const v2f* __restrict__ z, v4
   long j1 = j0 + run_len; if (j1 > frames) j1 = frames;
   if (j0 >= j1) return;
   const long m0 = j0 >= halo ? j0 - halo : 0;
-  v2f r0[16], r1[16];
+  v2f r0[16], r1[16], hold = v2f{0.f, 0.f};
   auto issue = [&](v2f (&r)[16], long m) {
     if (LB == 8) {
       const v2f* p = z + (size_t)(m < frames ? m : frames - 1) * 1024 + lane;
@@ -46,9 +47,20 @@ __global__ __launch_bounds__(256) void k_istft_mix(const v2f* __restrict__ z, v4
     v2f a = r[0];
 #pragma unroll
     for (int s = 1; s < 16; ++s) a += r[s];
-    if (m >= j0 && m < j1) {
-      __builtin_nontemporal_store(v4f{a.x, a.y, a.y, a.x}, y + (size_t)m * 128 + lane);
-      __builtin_nontemporal_store(v4f{a.y, a.x, a.x, a.y}, y + (size_t)m * 128 + 64 + lane);
+    if (WB == 0) { if (a.x == 1.2345f && a.y == 5.4321f) __builtin_nontemporal_store(v4f{a.x, a.y, a.y, a.x}, y + (size_t)m * 128 + lane); return; }
+    if (WB == 1) {
+      if (m >= j0 && m < j1) {
+        __builtin_nontemporal_store(v4f{a.x, a.y, a.y, a.x}, y + (size_t)m * 128 + lane);
+        __builtin_nontemporal_store(v4f{a.y, a.x, a.x, a.y}, y + (size_t)m * 128 + 64 + lane);
+      }
+    } else {
+      hold += a;
+      if (m >= j0 && m < j1 && ((m - j0) % WB == WB - 1 || m == j1 - 1)) {
+        const long mb = m - (m - j0) % WB;
+#pragma unroll
+        for (int t = 0; t < 2 * WB; ++t)
+          if (mb + t / 2 <= m) __builtin_nontemporal_store(v4f{hold.x, hold.y, hold.y + (float)t, hold.x}, y + (size_t)mb * 128 + 64 * t + lane);
+      }
     }
   };
   issue(r0, m0); issue(r1, m0 + 1);
@@ -58,6 +70,38 @@ __global__ __launch_bounds__(256) void k_istft_mix(const v2f* __restrict__ z, v4
   }
 }
 
+
+// the same persistent stream with the cache-policy bits of loads and stores as template parameters (buffer instructions: aux bit 0 = sc0,
+// bit 1 = nt, bit 4 = sc1) and, optionally, the stores going through a per-wave LDS-free register burst of WB frames
+template <int LAUX, int SAUX>
+__global__ __launch_bounds__(256) void k_istft_mix_pol(const v2f* __restrict__ z, v4f* __restrict__ y, long frames, long run_len) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long j0 = wave * run_len;
+  long j1 = j0 + run_len; if (j1 > frames) j1 = frames;
+  if (j0 >= j1) return;
+  v2i r0[16], r1[16];
+  auto issue = [&](v2i (&r)[16], long m) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(z + (size_t)(m < frames ? m : frames - 1) * 1024, 8192);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) r[s] = __builtin_amdgcn_raw_buffer_load_b64(rs, lane * 8 + 512 * s, 0, LAUX);
+  };
+  auto consume = [&](v2i (&r)[16], long m) {
+    v2i a = r[0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s) a += r[s];
+    if (m < j1) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(y + (size_t)m * 128, 2048);
+      __builtin_amdgcn_raw_buffer_store_b128(v4i{a.x, a.y, a.y, a.x}, rs, lane * 16, 0, SAUX);
+      __builtin_amdgcn_raw_buffer_store_b128(v4i{a.y, a.x, a.x, a.y}, rs, lane * 16 + 1024, 0, SAUX);
+    }
+  };
+  issue(r0, j0); issue(r1, j0 + 1);
+  for (long m = j0; m < j1; m += 2) {
+    consume(r0, m); issue(r0, m + 2);
+    consume(r1, m + 1); issue(r1, m + 3);
+  }
+}
 
 template <int WIDE>   // 0: the shipped kernel's 8-byte accesses; 1: the pair's 1792-sample span once with 16-byte loads, 16-byte stores
 __global__ __launch_bounds__(256) void k_fir_mix(const float* __restrict__ x, float* __restrict__ y, long L, long pairs_per_row, long total, long chunk) {
@@ -160,6 +204,39 @@ int nxdiag_istft_mix2(void* stream, const void* z, void* y, long frames, int wav
   else if (load_bytes == 116) hipLaunchKernelGGL((k_istft_mix<16, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
   else if (load_bytes == 108) hipLaunchKernelGGL((k_istft_mix<8, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
   else hipLaunchKernelGGL((k_istft_mix<8, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
+  return (int)hipGetLastError();
+}
+// the same stream handed out in SHORT runs to short-lived workgroups in dispatch order (the waves in flight then read one moving
+// window of the spectrum instead of 2048 far-apart ones): run_len frames per wave, grid = frames / (4 run_len)
+int nxdiag_istft_mix3(void* stream, const void* z, void* y, long frames, int run_len, int halo, int load_bytes) {
+  const unsigned grid = (unsigned)(((frames + run_len - 1) / run_len + 3) / 4);
+  if (load_bytes == 16) hipLaunchKernelGGL((k_istft_mix<16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, (long)run_len, halo);
+  else hipLaunchKernelGGL((k_istft_mix<8, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, (long)run_len, halo);
+  return (int)hipGetLastError();
+}
+int nxdiag_istft_mix_pol(void* stream, const void* z, void* y, long frames, int waves_per_cu, int laux, int saux) {
+  int dev = 0; hipDeviceProp_t pr;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 1;
+  const long waves = (long)pr.multiProcessorCount * waves_per_cu;
+  const long run_len = (frames + waves - 1) / waves;
+  const unsigned grid = (unsigned)(((frames + run_len - 1) / run_len + 3) / 4);
+#define POL(L_, S_) if (laux == L_ && saux == S_) { hipLaunchKernelGGL((k_istft_mix_pol<L_, S_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len); return (int)hipGetLastError(); }
+  POL(2, 0) POL(2, 2) POL(2, 16) POL(2, 18) POL(2, 1) POL(2, 17) POL(2, 19) POL(2, 3)
+  POL(0, 2) POL(0, 18) POL(16, 18) POL(18, 18) POL(0, 0) POL(1, 18) POL(17, 18) POL(3, 18)
+#undef POL
+  return 2;
+}
+// the persistent geometry with the stores in bursts of `wb` frames (0: no stores: the read side alone)
+int nxdiag_istft_mix4(void* stream, const void* z, void* y, long frames, int waves_per_cu, int halo, int wb) {
+  int dev = 0; hipDeviceProp_t pr;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 1;
+  const long waves = (long)pr.multiProcessorCount * waves_per_cu;
+  const long run_len = (frames + waves - 1) / waves;
+  const unsigned grid = (unsigned)(((frames + run_len - 1) / run_len + 3) / 4);
+  if (wb == 0) hipLaunchKernelGGL((k_istft_mix<8, true, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
+  else if (wb == 4) hipLaunchKernelGGL((k_istft_mix<8, true, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
+  else if (wb == 8) hipLaunchKernelGGL((k_istft_mix<8, true, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
+  else hipLaunchKernelGGL((k_istft_mix<8, true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v2f*)z, (v4f*)y, frames, run_len, halo);
   return (int)hipGetLastError();
 }
 int nxdiag_istft_mix(void* stream, const void* z, void* y, long frames, int waves_per_cu, int halo) { return nxdiag_istft_mix2(stream, z, y, frames, waves_per_cu, halo, 8); }

@@ -473,20 +473,26 @@ __device__ __forceinline__ void istft_sample_body(const EdgeFixArgs& a, const in
       sr += (double)v.x * t.x - (double)v.y * t.y;
       si += (double)v.x * t.y + (double)v.y * t.x;
     };
-    constexpr int U = 16;  // loads in flight per lane: the sum is a chain of dependent loads otherwise (N / 64 round trips)
+    // 16 spectrum loads in flight per lane (the sum is a chain of N / 64 dependent round trips otherwise), ONE table look-up per 16
+    // terms: w^(j k) is a 64-way gather of 16-byte entries over up to 64 cache lines, and 16 of those per wave kept the CU's texture
+    // path busy for most of this pass (4 416 waves after config 3's kernel: ~8 us of 20).  The other 15 twiddles follow by
+    // w^(j (k + 64)) = w^(j k) w^(64 j) in double: at most 15 roundings of 1.1e-16 on values that are then rounded to f32.
+    constexpr int U = 16;
+    const double2 wstep = a.tw[tstep];
+    const int cstep = a.N < (1 << 24) ? (int)((uint32_t)(tstep * U) % (uint32_t)a.N) : (int)(((int64_t)tstep * U) % a.N);
     int k = lane;
     for (; k + 64 * (U - 1) < a.N; k += 64 * U) {
-      double2 t[U];
+      double2 t = a.tw[tix];
       float2 v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        t[u] = a.tw[tix];
-        v[u] = istft_bin(a, zr, k + 64 * u);
-        tix += tstep;
-        if (tix >= a.N) tix -= a.N;
-      }
+      for (int u = 0; u < U; ++u) v[u] = istft_bin(a, zr, k + 64 * u);
 #pragma unroll
-      for (int u = 0; u < U; ++u) term(t[u], v[u], k + 64 * u);
+      for (int u = 0; u < U; ++u) {
+        term(t, v[u], k + 64 * u);
+        t = make_double2(t.x * wstep.x - t.y * wstep.y, t.x * wstep.y + t.y * wstep.x);
+      }
+      tix += cstep;
+      if (tix >= a.N) tix -= a.N;
     }
     for (; k < a.N; k += 64) {
       term(a.tw[tix], istft_bin(a, zr, k), k);

@@ -575,15 +575,14 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a, int6
     const int64_t e = wk / span, si = wk - e * span;
     const int64_t row = ent[e] >> 40, m0 = ent[e] & (((int64_t)1 << 40) - 1);
     const int64_t n = m0 * a.hop + si;
-    if (n < a.out_len) istft_sample_f64<true>(a, row, n);
+    if (row < a.batch && n < a.out_len) istft_sample_f64<true>(a, row, n);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
     if (atomicAdd(list - 2, 1) == nf_blocks - 1) {   // every workgroup of this role has read the count and done its share
-      list[0] = 0;
-      list[-2] = 0;
-      __threadfence();
+      atomicExch(list, 0);
+      atomicExch(list - 2, 0);
     }
   }
 }
@@ -630,15 +629,15 @@ __global__ __launch_bounds__(kThreads) void k_fir_poison(int* __restrict__ flags
 }
 
 int fir_row_flags(Ctx* c, int32_t batch, int** out) {
-  const size_t need = (size_t)batch * sizeof(int);
+  const size_t need = ((size_t)batch + 1) * sizeof(int);   // one ticket cell in front of the flags (k_fir_wave's edge launch)
   if (c->scratch_bytes[22] < need) {
     void* p = nullptr;
     const size_t bytes = need < 4096 ? 4096 : need * 2;
     int rc = ctx_scratch(c, 22, bytes, &p);
     if (rc) return rc;
-    NXSIG_HIP_TRY(hipMemsetAsync(p, 0, bytes, c->stream));   // zero between calls: k_fir_poison clears what it consumes
+    NXSIG_HIP_TRY(hipMemsetAsync(p, 0, bytes, c->stream));   // zero between calls: the poison pass clears what it consumes
   }
-  *out = reinterpret_cast<int*>(c->scratch[22]);
+  *out = reinterpret_cast<int*>(c->scratch[22]) + 1;
   return NXSIG_OK;
 }
 

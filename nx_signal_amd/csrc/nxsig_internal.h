@@ -224,6 +224,7 @@ struct FirLaunch {
   // row (Convolution.fftconvolve, lib/nx_signal/convolution.ex:276-284), so an Inf / NaN sample anywhere leaves no finite
   // output in that row; block-wise overlap-save would otherwise confine it to the blocks (and block pairs) that hold it.
   int* row_flags = nullptr;
+  mutable bool poison_folded = false;   // set by a launcher whose last kernel did the poison pass itself (k_fir_wave's edge launch)
 };
 int launch_fir(Ctx* c, const FirLaunch& a);
 int launch_mag_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, int kind, float* out);

@@ -135,6 +135,47 @@ def test_istft_non_finite_bins_reach_only_their_own_frames(N, hop):
     assert nerr(y[fin], yo[fino]) < 1e-5
 
 
+
+def test_istft_non_finite_report_list_is_consumed_by_the_pass_that_reads_it():
+    """The frame-packing inverse kernels append their poisoned units to a device list; the fix-up pass that redoes them puts the
+    count back to zero itself (no per-call memset).  A stale count would not change a value — the redo is idempotent — so the
+    check is the time: with EVERY unit poisoned the pass recomputes every sample in double (milliseconds); the clean call after
+    it must not pay that again, and a smaller clean problem must not be reached through stale entries."""
+    import time
+    N, hop, M = 512, 128, 3000
+    rng = np.random.default_rng(5)
+    z = (rng.standard_normal((2, M, N)) + 1j * rng.standard_normal((2, M, N))).astype(np.complex64)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N)
+    ctx = S.default_context()
+    zc = ctx.to_device(z)
+
+    def timed(buf):
+        ctx.sync()
+        t0 = time.perf_counter()
+        y = S.istft(buf, w, ctx=ctx, **opts)
+        ctx.sync()
+        return time.perf_counter() - t0, y
+
+    timed(zc)                                   # tables, first-launch costs
+    t_clean0, _ = timed(zc)
+    zp = z.copy()
+    zp[:, ::2, 7] = np.nan                      # one bin in every frame pair
+    zpd = ctx.to_device(zp)
+    t_poison, yp = timed(zpd)
+    assert not np.isfinite(yp.numpy()[:, N:-N]).any()
+    t_clean1, y1 = timed(zc)
+    y1 = y1.numpy()
+    assert np.isfinite(y1).all()
+    assert nerr(y1[0], O.istft(z[0], w, **opts)) < 1e-5
+    assert t_poison > 5 * t_clean0, (t_poison, t_clean0)          # the redo is what costs
+    assert t_clean1 < 0.5 * t_poison, (t_clean1, t_poison)        # ... and it is not paid again
+    zs = ctx.to_device(z[:1, :40])
+    ys = S.istft(zs, w, ctx=ctx, **opts).numpy()
+    assert np.isfinite(ys).all() and nerr(ys[0], O.istft(z[0, :40], w, **opts)) < 1e-5
+    for b in (zc, zpd, zs):
+        b.free()
+
 # ------------------------------------------------------------------------------------------------ eps clean-up
 def _cmp_cleaned(got, ref, what):
     """`ref` holds exact zeros where the reference cleaned a component.  fp32 arithmetic puts a value within round-off of the

@@ -70,7 +70,7 @@ defmodule NxSignalAMD.Sharded do
   end
 
   @doc """
-  `NxSignalAMD.mel_spectrogram/3` (`stft/3 |> stft_to_mel/3`, fused) sharded over `group` — the one sharded call with an
+  `NxSignalAMD.mel_spectrogram/3` (`stft/3 |> stft_to_mel/3`, fused) sharded over `group` — one of the two sharded calls with an
   exchange step: the clamp against `reduce_max(log_spec) - 8` (`lib/nx_signal.ex:511`) takes the maximum over the WHOLE tensor,
   so the members' running maxima are all-reduced (RCCL `ncclAllReduce` / `ncclMax` on one `int32` pair) between the two passes.
   Options: mel_spectrogram's plus `axis:` (`:channels` or `:frames`); `window_padding` must be `:valid`.

@@ -336,7 +336,7 @@ defmodule NxSignalAMD.Sharded.Tensor do
   end
 
   @doc """
-  The fused log-mel (`NxSignalAMD.mel_spectrogram/3`) on device shards — the one sharded call with an exchange step: the
+  The fused log-mel (`NxSignalAMD.mel_spectrogram/3`) on device shards — one of the two sharded calls with an exchange step (sample-sharded FIR exchanges one flag per row): the
   members' running maxima are all-reduced (RCCL `ncclAllReduce` / `ncclMax`) between its two passes, because
   `stft_to_mel/3` clamps against `Nx.reduce_max` of the WHOLE tensor (`lib/nx_signal.ex:511`).
   """

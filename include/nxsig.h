@@ -236,8 +236,8 @@ int nxsig_fir_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch,
  * Non-finite samples: the reference filters a row by ONE transform (convolution.ex:276-284), so a row that holds an Inf / NaN has no
  * finite output, and nxsig_fir_f32 returns such a row as NaN from end to end.  A SLICE call only looks at the blocks its outputs
  * need: it returns NaN for the whole slice when one of THOSE samples is not finite, and finite values when the non-finite sample
- * lies elsewhere in the row — so the slices of a row assembled by the caller (or by nxsig_fir_sharded_f32 on the samples axis) can
- * be finite where the unsliced call is NaN.  Callers that need the reference's whole-row behaviour for sliced rows test the row
+ * lies elsewhere in the row — so the slices of a row assembled BY THE CALLER can be finite where the unsliced call is NaN
+ * (nxsig_fir_sharded_f32 on the samples axis closes that itself: its members exchange one flag per row).  Callers that need the reference's whole-row behaviour for sliced rows test the row
  * themselves; finite rows are unaffected. */
 int nxsig_fir_slice_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch, int64_t batch_stride, const float* h,
                         int32_t num_taps, int64_t out_start, int64_t out_len, float* y, int32_t mem);
@@ -476,7 +476,11 @@ int nxsig_stft_sharded_f32(nxsig_group* g, const float* const* x, int64_t length
 int nxsig_istft_sharded_c64(nxsig_group* g, const nxsig_c64* const* z, int64_t num_frames, int32_t batch, const float* window,
                             const nxsig_stft_params* params, int32_t axis, int32_t gather, nxsig_c64* const* y, int32_t mem);
 /* FIR filtering (nxsig_fir_f32) sharded over the group; same conventions.  Channels axis: rows split.  Frames axis here
- * means OUTPUT SAMPLE ranges of every row with a (num_taps - 1)-sample input halo (nxsig_shard_fir). */
+ * means OUTPUT SAMPLE ranges of every row with a (num_taps - 1)-sample input halo (nxsig_shard_fir); it has ONE exchange step:
+ * a row that holds an Inf / NaN anywhere has no finite output in the reference (one transform per row, convolution.ex:276-284),
+ * so every member reads off its slice which rows its own samples poisoned, the flags (int32[batch]) are all-reduced with a maximum
+ * (ncclAllReduce; members of one process that share a device: through the host) and every member turns the flagged rows NaN —
+ * the sharded result equals the unsharded one for such rows too.  A ranked group without RCCL cannot do that: unsupported. */
 int nxsig_fir_sharded_f32(nxsig_group* g, const float* const* x, int64_t length, int32_t batch, int64_t batch_stride,
                           const float* h, int32_t num_taps, int32_t mode, int32_t axis, int32_t gather, float* const* y,
                           int32_t mem);

@@ -239,8 +239,6 @@ static int launch_fir_long(Ctx* c, const FirLaunch& a) {
   return NXSIG_OK;
 }
 
-int fir_row_flags(Ctx* c, int32_t batch, int** out);
-int launch_fir_poison(Ctx* c, const FirLaunch& a);
 int launch_fir(Ctx* c, const FirLaunch& a_in) {
   if (a_in.taps > 4096) return launch_fir_long(c, a_in);   // one transform per row, like the reference: non-finite rows come out NaN
   if (a_in.out_len <= 0 || a_in.batch == 0) return NXSIG_OK;

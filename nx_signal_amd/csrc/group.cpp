@@ -24,6 +24,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "nxsig_internal.h"
@@ -522,10 +523,14 @@ static int shard_stride(int64_t batch_stride, int64_t rows, int64_t in_len, int6
   return NXSIG_OK;
 }
 
-// runs `compute(member, part, x_dev, out_dev)` for every local member; host mode stages through per-member device buffers
-template <class Compute>
+// runs `compute(member, part, x_dev, out_dev)` for every local member; host mode stages through per-member device buffers.
+// `exchange(dst)` — optional — runs once every local member's compute is issued and before anything is assembled or downloaded:
+// the place of a call's exchange step (sample-sharded FIR: the members agree on which rows hold a non-finite sample); dst[i] is
+// member i's shard (nullptr when the member has none).
+template <class Compute, class Exchange = std::nullptr_t>
 int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_stride, int32_t axis, int32_t gather,
-                void* const* out, int32_t mem, Compute compute) {
+                void* const* out, int32_t mem, Compute compute, Exchange exchange = nullptr) {
+  constexpr bool kExchange = !std::is_same<Exchange, std::nullptr_t>::value;
   const size_t nl = g->m.size();
   const bool by_rows = axis == NXSIG_SHARD_CHANNELS;
   if (!by_rows && gather && pl.rows_total != 1 && mem == NXSIG_DEVICE)
@@ -543,6 +548,11 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
       int64_t stride = 0;
       if ((rc = shard_stride(batch_stride, p.rows, p.in_len, &stride))) return rc;
       if (p.rows > 0 && p.out_len > 0 && (rc = compute(g->m[i], p, static_cast<const float*>(x[i]), stride, dst))) return rc;
+    }
+    if constexpr (kExchange) {
+      std::vector<void*> dsts(nl);
+      for (size_t i = 0; i < nl; ++i) dsts[i] = const_cast<void*>(send[i]);
+      if ((rc = exchange(dsts))) return rc;
     }
     if (!gather) return NXSIG_OK;
     return allgather_locked(g, send.data(), pl.count.data(), out);
@@ -579,8 +589,15 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
       if ((r = nxsig_upload(mb.ctx, static_cast<float*>(din[i]) + row * p.in_len, xh + (p.row0 + row) * batch_stride + p.in0,
                             (size_t)p.in_len * sizeof(float)))) return fail(r);
     if ((r = compute(mb, p, static_cast<const float*>(din[i]), p.in_len, dst))) return fail(r);
-    if (gather) return;
-    // per-shard download straight into its place of the host result
+  };
+  auto fetch = [&](size_t i) {   // per-shard download straight into its place of the host result
+    Member& mb = g->m[i];
+    const Part& p = pl.part[mb.rank];
+    auto fail = [&](int code) { rcs[i] = code; msgs[i] = nxsig_last_error(); };
+    int r;
+    const int64_t shard_bytes = pl.count[mb.rank];
+    char* dst = static_cast<char*>(const_cast<void*>(send[i]));
+    if (gather || rcs[i] || p.rows == 0 || p.out_len == 0) return;
     if (by_rows) {
       if ((r = nxsig_download(mb.ctx, oh + p.row0 * pl.out_items_total * pl.item_bytes, dst, (size_t)shard_bytes))) return fail(r);
     } else {
@@ -589,15 +606,33 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
                                 (size_t)(p.out_len * pl.item_bytes)))) return fail(r);
     }
   };
-  {
+  auto on_every_member = [&](auto&& fn) {
     std::vector<std::thread> th;
-    for (size_t i = 1; i < nl; ++i) th.emplace_back(work, i);
-    work(0);
+    for (size_t i = 1; i < nl; ++i) th.emplace_back(fn, i);
+    fn(0);
     for (auto& t : th) t.join();
+  };
+  auto first_failure = [&]() -> int {
+    for (size_t i = 0; i < nl; ++i)
+      if (rcs[i]) { cleanup(); return set_error(rcs[i], msgs[i]); }
+    return NXSIG_OK;
+  };
+  if constexpr (kExchange) {
+    on_every_member(work);
+    if ((rc = first_failure())) return rc;
+    {
+      std::vector<void*> dsts(nl);
+      for (size_t i = 0; i < nl; ++i) {
+        const Part& p = pl.part[g->m[i].rank];
+        dsts[i] = (p.rows > 0 && p.out_len > 0) ? const_cast<void*>(send[i]) : nullptr;
+      }
+      if ((rc = exchange(dsts))) { std::string keep = nxsig_last_error(); cleanup(); return set_error(rc, keep); }
+    }
+    on_every_member(fetch);
+  } else {
+    on_every_member([&](size_t i) { work(i); fetch(i); });
   }
-  for (size_t i = 0; i < nl; ++i)
-    if (rcs[i]) { cleanup(); return set_error(rcs[i], msgs[i]); }
-  rc = NXSIG_OK;
+  if ((rc = first_failure())) return rc;
   if (gather) {
     if (!by_rows && pl.rows_total != 1) { cleanup(); return set_error(NXSIG_ERR_UNSUPPORTED, "sharded: assembly of frame / sample shards needs batch == 1"); }
     rc = allgather_locked(g, send.data(), pl.count.data(), dout.data());
@@ -745,7 +780,64 @@ int nxsig_fir_sharded_f32(nxsig_group* grp, const float* const* x, int64_t lengt
   auto compute = [&](Member& mb, const Part& q, const float* xd, int64_t stride, void* dst) -> int {
     return nxsig_fir_slice_f32(mb.ctx, xd, q.in_len, (int32_t)q.rows, stride, h, num_taps, q.out_start, q.out_len, static_cast<float*>(dst), NXSIG_DEVICE);
   };
-  return run_sharded(g, pl, reinterpret_cast<const void* const*>(x), batch_stride, axis, gather, reinterpret_cast<void* const*>(y), mem, compute);
+  if (axis == NXSIG_SHARD_CHANNELS)   // whole rows per member: nxsig_fir_slice_f32's own poison pass sees every sample of a row
+    return run_sharded(g, pl, reinterpret_cast<const void* const*>(x), batch_stride, axis, gather, reinterpret_cast<void* const*>(y), mem, compute);
+  // Sample shards: the reference filters a row by ONE transform (lib/nx_signal/convolution.ex:276-284), so an Inf / NaN anywhere in
+  // a row leaves no finite output in it — but a member only sees its own span.  The exchange step: every member reads off its slice
+  // which rows its own poison pass turned to NaN (one int per row), the flags are all-reduced with a maximum, and every member
+  // poisons the rows any member flagged.  With it the sharded call equals the unsharded one for non-finite rows too.
+  if (g->ranked && g->world > 1 && !g->has_rccl)
+    return set_error(NXSIG_ERR_UNSUPPORTED, "fir_sharded: a ranked group without RCCL cannot agree on the non-finite rows of sample shards");
+  auto exchange = [&](const std::vector<void*>& dst) -> int {
+    const size_t nl = g->m.size();
+    std::vector<int*> flags(nl, nullptr);
+    int rc2;
+    for (size_t i = 0; i < nl; ++i) {
+      Member& mb = g->m[i];
+      Ctx* c = reinterpret_cast<Ctx*>(mb.ctx);
+      const Part& q = pl.part[mb.rank];
+      std::lock_guard<std::mutex> cl(c->mu);
+      NXSIG_HIP_TRY(hipSetDevice(mb.device));
+      if ((rc2 = fir_row_flags(c, batch, &flags[i]))) return rc2;
+      if (dst[i] && (rc2 = launch_fir_flags_from_output(c, static_cast<const float*>(dst[i]), batch, q.out_len, flags[i]))) return rc2;
+    }
+    if (g->has_rccl) {
+      Rccl* R = rccl();
+      NcclBracket br(R);
+      NXSIG_NCCL_TRY(R, br.start());
+      for (size_t i = 0; i < nl; ++i) {
+        NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
+        NXSIG_NCCL_TRY(R, R->AllReduce(flags[i], flags[i], (size_t)batch, ncclInt32, ncclMax, g->m[i].comm, stream_of(g->m[i])));
+      }
+      NXSIG_NCCL_TRY(R, br.end());
+    } else if (nl > 1) {  // members of one process sharing devices (no communicators): through the host
+      std::vector<int> best((size_t)batch, 0), v((size_t)batch);
+      for (size_t i = 0; i < nl; ++i) {
+        NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
+        NXSIG_HIP_TRY(hipMemcpyAsync(v.data(), flags[i], v.size() * sizeof(int), hipMemcpyDeviceToHost, stream_of(g->m[i])));
+        NXSIG_HIP_TRY(hipStreamSynchronize(stream_of(g->m[i])));
+        for (int32_t r = 0; r < batch; ++r) best[r] = v[r] > best[r] ? v[r] : best[r];
+      }
+      for (size_t i = 0; i < nl; ++i) {
+        NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
+        NXSIG_HIP_TRY(hipMemcpyAsync(flags[i], best.data(), best.size() * sizeof(int), hipMemcpyHostToDevice, stream_of(g->m[i])));
+        NXSIG_HIP_TRY(hipStreamSynchronize(stream_of(g->m[i])));   // `best` lives on this stack frame
+      }
+    }
+    for (size_t i = 0; i < nl; ++i) {   // rows flagged anywhere: NaN on every member (the pass clears the flags it consumes)
+      Member& mb = g->m[i];
+      Ctx* c = reinterpret_cast<Ctx*>(mb.ctx);
+      const Part& q = pl.part[mb.rank];
+      std::lock_guard<std::mutex> cl(c->mu);
+      NXSIG_HIP_TRY(hipSetDevice(mb.device));
+      FirLaunch f{};
+      f.batch = batch; f.out_len = dst[i] ? q.out_len : 0; f.y = static_cast<float*>(dst[i]); f.row_flags = flags[i];
+      if (dst[i]) { if ((rc2 = launch_fir_poison(c, f))) return rc2; }
+      else NXSIG_HIP_TRY(hipMemsetAsync(flags[i], 0, (size_t)batch * sizeof(int), c->stream));   // nothing to poison here: just consume
+    }
+    return NXSIG_OK;
+  };
+  return run_sharded(g, pl, reinterpret_cast<const void* const*>(x), batch_stride, axis, gather, reinterpret_cast<void* const*>(y), mem, compute, exchange);
   NXSIG_API_END
 }
 

@@ -641,6 +641,22 @@ int fir_row_flags(Ctx* c, int32_t batch, int** out) {
   return NXSIG_OK;
 }
 
+// sample-sharded FIR (group.cpp): a member's slice came out NaN from end to end when ITS samples held an Inf / NaN (the poison pass
+// above); flags[r] = "row r of this slice is poisoned", read off the slice's first output, is what the members all-reduce so that
+// every slice of such a row ends up NaN like the reference's one transform leaves the whole row
+__global__ __launch_bounds__(kThreads) void k_fir_flags_from_output(const float* __restrict__ y, int32_t rows, int64_t out_len, int* __restrict__ flags) {
+  const int r = blockIdx.x * kThreads + threadIdx.x;
+  if (r >= rows) return;
+  const float v = y[(size_t)r * out_len];
+  flags[r] = (v - v == 0.0f) ? 0 : 1;
+}
+int launch_fir_flags_from_output(Ctx* c, const float* y, int32_t rows, int64_t out_len, int* flags) {
+  if (rows <= 0 || out_len <= 0) return NXSIG_OK;   // an empty slice holds nothing: its flags stay zero
+  hipLaunchKernelGGL(k_fir_flags_from_output, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, y, rows, out_len, flags);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
 int launch_fir_poison(Ctx* c, const FirLaunch& s) {
   if (!s.row_flags || s.batch == 0 || s.out_len <= 0) return NXSIG_OK;
   hipLaunchKernelGGL(k_fir_poison, dim3((unsigned)s.batch), dim3(kThreads), 0, c->stream, s.row_flags, s.y, s.out_len);

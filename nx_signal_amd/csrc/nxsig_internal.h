@@ -227,6 +227,9 @@ struct FirLaunch {
   mutable bool poison_folded = false;   // set by a launcher whose last kernel did the poison pass itself (k_fir_wave's edge launch)
 };
 int launch_fir(Ctx* c, const FirLaunch& a);
+int fir_row_flags(Ctx* c, int32_t batch, int** out);                                                     // kernels_generic.hip
+int launch_fir_poison(Ctx* c, const FirLaunch& a);
+int launch_fir_flags_from_output(Ctx* c, const float* y, int32_t rows, int64_t out_len, int* flags);     // sample-sharded FIR, group.cpp
 int launch_mag_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, int kind, float* out);
 int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool* handled);
 int launch_spectrum_mul(Ctx* c, const float2* z, int64_t rows, int32_t K, const float2* h_dev, float2* out);

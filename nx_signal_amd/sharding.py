@@ -285,30 +285,59 @@ def istft_sharded(group: Group, data, window, axis: str = "channels", gather: bo
     return y[0] if squeeze else y.reshape(z.shape[:-2] + (out_len,))
 
 
-def fir_sharded(group: Group, data, taps, mode: str = "same", axis: str = "channels", gather: bool = False):
-    """Filters.fir (overlap-save FFT convolution, nxsig_fir_f32) of a host array [channels, L] / [L] sharded over `group`."""
+def fir_sharded(group: Group, data, taps, mode: str = "same", axis: str = "channels", gather: bool = False, length=None, batch=None):
+    """Filters.fir (overlap-save FFT convolution, nxsig_fir_f32) sharded over `group`.
+
+    data: host array [channels, L] / [L] (LOCAL groups) -> the assembled host result, or a list with one DeviceBuffer per LOCAL
+          member holding that member's input shard (rows [c0, c1), or the sample span [s0, s1) of every row: shard_channels /
+          shard_fir) with `length=` and `batch=` of the whole tensor -> the list of per-member result DeviceBuffers (shards, or the
+          full tensor with gather=True).
+    Sample shards have one exchange step: a row that holds an Inf / NaN ANYWHERE comes out NaN from end to end, like the one
+    transform of Convolution.fftconvolve (lib/nx_signal/convolution.ex:276-284) leaves it — the members all-reduce one flag per row."""
     lib = _lib.load()
     h = np.ascontiguousarray(taps, dtype=np.float32)
     m = {"full": _lib.CONV_FULL, "same": _lib.CONV_SAME, "valid": _lib.CONV_VALID}.get(mode)
     if m is None:
         raise _lib.ArgumentError("expected mode to be one of [:full, :same, :valid]")
+    n = group.local_count
+    ax = _AXES[axis]
+    if isinstance(data, (list, tuple)) and data and isinstance(data[0], DeviceBuffer):
+        if length is None or batch is None:
+            raise _lib.ArgumentError("device shards need length= and batch= of the whole tensor")
+        n_out = int(_lib.check(lib.nxsig_conv_length(int(length), h.shape[0], m)))
+        outs = []
+        for i, r in enumerate(group.ranks):
+            if gather:
+                shape = (batch, n_out)
+            elif ax == CHANNELS:
+                c0, c1 = shard_channels(batch, group.world, r)
+                shape = (c1 - c0, n_out)
+            else:
+                n0, n1, _, _ = shard_fir(int(length), int(h.shape[0]), group.world, r, mode)
+                shape = (batch, n1 - n0)
+            outs.append(group.contexts[i].empty(shape, np.float32))
+        stride = int(data[0].shape[-1]) if ax == CHANNELS else 0   # 0 = dense per-member shards (nxsig.h)
+        xs = (C.c_void_p * n)(*[C.c_void_p(d.ptr) for d in data])
+        ys = (C.c_void_p * n)(*[C.c_void_p(o.ptr) for o in outs])
+        _lib.check(lib.nxsig_fir_sharded_f32(group.handle, xs, int(length), int(batch), stride, h.ctypes.data_as(C.c_void_p),
+                                             int(h.shape[0]), m, ax, int(bool(gather)), ys, _lib.DEVICE))
+        return outs
     x = np.ascontiguousarray(data, dtype=np.float32)
     squeeze = x.ndim == 1
     x2 = x.reshape(1, -1) if squeeze else x.reshape(-1, x.shape[-1])
     B, L = x2.shape
     n_out = int(_lib.check(lib.nxsig_conv_length(L, h.shape[0], m)))
     y = np.empty((B, n_out), np.float32)
-    n = group.local_count
     xs = (C.c_void_p * n)(*([x2.ctypes.data_as(C.c_void_p)] + [C.c_void_p(0)] * (n - 1)))
     ys = (C.c_void_p * n)(*([y.ctypes.data_as(C.c_void_p)] + [C.c_void_p(0)] * (n - 1)))
     _lib.check(lib.nxsig_fir_sharded_f32(group.handle, xs, L, B, L, h.ctypes.data_as(C.c_void_p), int(h.shape[0]), m,
-                                         _AXES[axis], int(bool(gather)), ys, _lib.HOST))
+                                         ax, int(bool(gather)), ys, _lib.HOST))
     return y[0] if squeeze else y.reshape(x.shape[:-1] + (n_out,))
 
 
 def mel_spectrogram_sharded(group: Group, data, window, axis: str = "channels", **opts):
-    """`stft(data, window) |> stft_to_mel` (the fused log-mel of `nx_signal_amd.mel_spectrogram`) sharded over `group` — the one
-    sharded call with an exchange step: the clamp against `reduce_max(log_spec) - 8` (lib/nx_signal.ex:511) takes the maximum
+    """`stft(data, window) |> stft_to_mel` (the fused log-mel of `nx_signal_amd.mel_spectrogram`) sharded over `group` — a sharded
+    call with an exchange step (sample-sharded `fir_sharded` is the other): the clamp against `reduce_max(log_spec) - 8` (lib/nx_signal.ex:511) takes the maximum
     over the WHOLE tensor, so the members' running maxima are all-reduced (RCCL ncclAllReduce / ncclMax; through the host when
     the members of one process share a device) between the two passes.  window_padding must be "valid".
 

@@ -73,6 +73,17 @@ def main():
     if rank == 0:
         alone = S.mel_spectrogram(xq[c0:c1], w, ctx, **mopts)
         assert not np.array_equal(alone, mine), "the exchange step must matter for the quiet shard"
+    # sample-sharded FIR: a NaN in the LAST rank's span must turn the row NaN on every rank (ncclAllReduce max of one flag per row),
+    # the clean row stays what the unsharded filter gives
+    h = S.filters.firwin(257, [4000.0], sampling_rate=48000)
+    xf = x[:2].copy()
+    xf[1, L - 9] = np.nan
+    yfull = np.asarray(S.filters.fir(xf, h, mode="same", ctx=ctx))
+    n0, n1, s0, s1 = sharding.shard_fir(L, 257, world, rank, "same")
+    part = sharding.fir_sharded(g, [ctx.to_device(np.ascontiguousarray(xf[:, s0:s1]))], h, mode="same", axis="samples", length=L, batch=2)[0].numpy()
+    assert part.shape == (2, n1 - n0)
+    assert not np.isfinite(part[1]).any(), "sample shards: the non-finite row is NaN on every rank"
+    assert float(np.max(np.abs(part[0] - yfull[0, n0:n1])) / np.max(np.abs(yfull[0]))) < 1e-6, "sample shards: the clean row"
     g.barrier()
     print(f"RANKED-OK rank {rank} of {world}", file=sys.stderr, flush=True)
     g.close()

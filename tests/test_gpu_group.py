@@ -193,6 +193,32 @@ def test_fir_shards(pair, mode):
     assert float(np.max(np.abs(got1 - ref)) / np.max(np.abs(ref))) < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["same", "full"])
+def test_fir_sample_shards_agree_on_non_finite_rows(pair, solo, mode):
+    """Convolution.fftconvolve filters a row with ONE transform (convolution.ex:276-284): an Inf / NaN anywhere leaves no finite
+    output in that row.  A sample shard sees only its own span, so the members exchange one flag per row (all-reduce, max) and
+    every member poisons the rows any member flagged: the sharded result equals the unsharded one for such rows too — and the
+    next, clean call is clean (the flags are consumed)."""
+    L = 90000
+    x = np.stack([O.synth_signal(L, seed=410 + c) for c in range(3)])
+    xp = x.copy()
+    xp[1, 1000] = np.nan          # first member's span
+    xp[2, L - 7] = np.inf         # second member's span
+    h = S.filters.firwin(257, [4000.0], sampling_rate=48000)
+    full = S.filters.fir(xp, h, mode=mode)
+    assert np.isfinite(full[0]).all() and not np.isfinite(full[1]).any() and not np.isfinite(full[2]).any()
+    for g in (pair, solo):
+        got = sharding.fir_sharded(g, xp, h, mode=mode, axis="samples")
+        assert np.array_equal(np.isfinite(got), np.isfinite(full))
+        assert float(np.max(np.abs(got[0] - full[0])) / np.max(np.abs(full[0]))) < 1e-6
+        clean = sharding.fir_sharded(g, x, h, mode=mode, axis="samples")
+        assert np.isfinite(clean).all()
+        ref = S.filters.fir(x, h, mode=mode)
+        assert float(np.max(np.abs(clean - ref)) / np.max(np.abs(ref))) < 1e-6
+    got1 = sharding.fir_sharded(pair, xp[1], h, mode=mode, axis="samples", gather=True)   # assembled on the device
+    assert not np.isfinite(got1).any()
+
+
 @pytest.mark.parametrize("N,hop,M,scaling", [
     (1024, 256, 61, None), (1024, 512, 40, "spectrum"), (1024, 1024, 9, None), (512, 128, 77, None), (2048, 512, 23, "psd"),
     (256, 64, 130, None), (400, 160, 51, None), (96, 24, 45, None), (1024, 256, 3, None),

@@ -1116,10 +1116,15 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
   a.y = reinterpret_cast<v2f*>(s.y);
   a.filt = reinterpret_cast<const v2f*>(s.filt);
   {
-    static const std::vector<float2> zero_row((size_t)K, make_float2(0.f, 0.f));
     const void* dz = nullptr;
-    int rcz = ctx_table(c, 0x2E20ull, zero_row.data(), zero_row.size() * sizeof(float2), &dz);
-    if (rcz) return rcz;
+    auto hitz = c->memo.find(0x2E2000000000ull ^ (uint64_t)K);   // looked up once per context (the table cache hashes the content)
+    if (hitz != c->memo.end()) dz = reinterpret_cast<const void*>(hitz->second[0]);
+    else {
+      static const std::vector<float2> zero_row((size_t)K, make_float2(0.f, 0.f));
+      int rcz = ctx_table(c, 0x2E20ull, zero_row.data(), zero_row.size() * sizeof(float2), &dz);
+      if (rcz) return rcz;
+      c->memo[0x2E2000000000ull ^ (uint64_t)K] = {reinterpret_cast<uint64_t>(dz)};
+    }
     a.zeros = reinterpret_cast<const v2f*>(dz);
   }
   void* dummy = nullptr;

@@ -135,8 +135,9 @@ def load_diag():
         d.nxdiag_istft_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int]
         d.nxdiag_fir_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int]
         d.nxdiag_stft_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int]
+        d.nxdiag_stft2048_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int]
         return d
-    except OSError:
+    except (OSError, AttributeError):   # missing, or an older build without one of the models
         return None
 
 
@@ -147,7 +148,7 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
       config 4  stft  N=2048 hop=512, 8 ch x 600 s          18 432 B/frame  (one GPU's share of 64 channels)
       config 5  fir   257 taps :same, 8 ch x 600 s          8 B/sample      (4 in + 4 out)
     Under a launcher EVERY rank runs this on its own shard (`barrier` lines the ranks up before each of the two blocks so the GPUs
-    of the node work at the same time); main() reduces the per-rank kernel times with max-over-ranks.  `mix_ceiling` (configs 3 / 5): the
+    of the node work at the same time); main() reduces the per-rank kernel times with max-over-ranks.  `mix_ceiling` (configs 3 / 4 / 5): the
     same traffic with no math in the kernel's launch geometry (tools/diag_mix.hip), timed the same way in this process."""
     out = {}
     rng = np.random.Generator(np.random.PCG64(99))
@@ -245,6 +246,14 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         laps = measure(lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, wp4, C.byref(p4), C.c_void_p(z4.ptr), None, _lib.DEVICE)), 10, 15)
         out["roofline_stft2048"] = block(f"config 4 (one GPU's shard of 64 channels): stft N=2048 hop=512, {B4} ch x {seconds45} s @48 kHz", "k_stft_wave<1024, real-2x>",
                                          B4 * M4 * (H4 * 4 + N4 * 8), laps, {"bytes_per_frame": H4 * 4 + N4 * 8, "frames": B4 * M4, "frames_per_s": B4 * M4 / (float(np.mean(laps)) * 1e-3)}, "stft2048")
+        if diag is not None:
+            tab4 = ctx.to_device(np.zeros(3072, np.float32))
+            ceiling(out["roofline_stft2048"], B4 * M4 * (H4 * 4 + N4 * 8),
+                    lambda: diag.nxdiag_stft2048_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(z4.ptr), C.c_void_p(tab4.ptr), B4, L4, H4, 8),
+                    "tools/diag_mix.hip k_stft2048_mix: the real-2x kernel's loads and stores in its launch geometry (8 frames per wave), no math")
+            tab4.free()
+            if keep_z4:   # the assembly gathers THIS spectrum: the model overwrote it
+                _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, wp4, C.byref(p4), C.c_void_p(z4.ptr), None, _lib.DEVICE))
         if not keep_z4:
             z4.free()
             z4 = None

@@ -48,6 +48,32 @@ if "stft" in (sys.argv[2:] or ["stft", "istft", "fir"]):
         print(json.dumps({"case": k, "GBps": [round(a, 1) for a in v], "frac_of_8TBps": round(float(np.median(v)) / 8000, 4)}), flush=True)
     for b in (xs, zs, tab): b.free()
 
+# ---- stft N = 2048 hop 512, config 4's shard
+if "stft2048" in (sys.argv[2:] or []):
+    diag.nxdiag_stft2048_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int]
+    B4, L4, N4, H4 = 8, SR * 600, 2048, 512
+    M4 = (L4 - N4) // H4 + 1
+    xs = ctx.empty((B4, L4), np.float32)
+    chunk0 = rng.standard_normal(L4, dtype=np.float32)
+    for r in range(B4):
+        xr = np.roll(chunk0, 977 * r)
+        _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(xs.ptr + r * L4 * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
+    zs = ctx.empty((B4, M4, N4), np.complex64)
+    tab = ctx.to_device(rng.standard_normal(3072).astype(np.float32))
+    ws = S.windows.hann(N4); ps = _lib.StftParams(N4, H4, N4, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
+    nbs = B4 * M4 * (H4 * 4 + N4 * 8)
+    cases = {"stft N=2048 kernel (config 4)": lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xs.ptr), L4, B4, L4, ws.ctypes.data_as(C.c_void_p), C.byref(ps), C.c_void_p(zs.ptr), None, 1))}
+    for upw in (1, 2, 4, 8, 12):
+        cases[f"stft2048 mix {upw} frames/wave"] = (lambda upw=upw: diag.nxdiag_stft2048_mix(stream, C.c_void_p(xs.ptr), C.c_void_p(zs.ptr), C.c_void_p(tab.ptr), B4, L4, H4, upw))
+    res = {k: [] for k in cases}
+    for r in range(rounds):
+        for k, fn in cases.items():
+            res[k].append(nbs / (timeit(fn, 10, 5) * 1e-3) / 1e9)
+    for k, v in res.items():
+        print(json.dumps({"case": k, "GBps": [round(a, 1) for a in v], "frac_of_8TBps": round(float(np.median(v)) / 8000, 4)}), flush=True)
+    for b in (xs, zs, tab): b.free()
+    sys.exit(0)
+
 # ---- istft, config 3
 B = 16
 w = S.windows.hann(N)

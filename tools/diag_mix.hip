@@ -183,7 +183,46 @@ __global__ __launch_bounds__(256) void k_stft_mix(const float* __restrict__ x, v
   }
 }
 
+// Config 4's kernel (k_stft_wave<1024, real-2x>: ONE 2048-sample frame per unit as even / odd samples): `upw` frames per wave handed out
+// like the pairs above; per frame 16 eight-byte loads per lane (hop = 512: three quarters of them re-read from cache), next frame
+// prefetched; 16 sixteen-byte `sc1 nt` buffer stores per lane (one 16 KiB spectrum row); the same 12 KB of tables per workgroup.
+__global__ __launch_bounds__(256) void k_stft2048_mix(const float* __restrict__ x, v4f* __restrict__ zout, const float* __restrict__ tab, long L, long M,
+                                                      long total, int upw, int hop) {
+  __shared__ float s_tab[3072];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 3072; i += 256) s_tab[i] = tab[i];
+  __syncthreads();
+  const long p0 = (long)blockIdx.x * 4 * upw;
+  long p1 = p0 + 4L * upw; if (p1 > total) p1 = total;
+  v2f r[16];
+  auto issue = [&](long p) {
+    const long row = p / M, m = p - row * M;
+    const v2f* pa = reinterpret_cast<const v2f*>(x + row * L + m * hop) + lane;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) r[s] = pa[64 * s];
+  };
+  if (p0 + wave < p1) issue(p0 + wave);
+  for (long p = p0 + wave; p < p1; p += 4) {
+    v2f a = v2f{s_tab[lane], s_tab[1024 + lane]};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a += r[s];
+    issue(p + 4 < p1 ? p + 4 : p);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(zout + p * 1024L, 16384);    // row of 2048 c64 = 1024 v4f
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{a.x, a.y, a.x + (float)q, a.y}), rs, lane * 16 + 1024 * q, 0, 18);
+  }
+}
+
 extern "C" {
+// x: f32[rows][L], z: c64[rows][M][2048] with M = (L - 2048) / hop + 1
+int nxdiag_stft2048_mix(void* stream, const void* x, void* z, const void* tab, long rows, long L, int hop, int units_per_wave) {
+  const long M = (L - 2048) / hop + 1, total = rows * M;
+  const long per_wg = 4L * units_per_wave;
+  hipLaunchKernelGGL(k_stft2048_mix, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (v4f*)z,
+                     (const float*)tab, L, M, total, units_per_wave, hop);
+  return (int)hipGetLastError();
+}
 // x: f32[rows][L], z: c64[rows][M][1024] with M = (L - 1024) / hop + 1 (even frame counts per row are walked; an odd last frame is skipped)
 int nxdiag_stft_mix(void* stream, const void* x, void* z, const void* tab, long rows, long L, int hop, int pairs_per_wave) {
   const long M = (L - 1024) / hop + 1, ppr = M / 2, total = rows * ppr;

@@ -249,7 +249,6 @@ int launch_fir(Ctx* c, const FirLaunch& a_in) {
   rc = launch_fir_wave(c, a, &handled);
   if (rc) return rc;
   if (!handled && (rc = launch_fir_generic(c, a))) return rc;
-  if (a.poison_folded) return NXSIG_OK;   // the streaming kernels' edge launch did it with its last workgroup
   return launch_fir_poison(c, a);   // rows that held an Inf / NaN sample: NaN from end to end (FirLaunch::row_flags)
 }
 

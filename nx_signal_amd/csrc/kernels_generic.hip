@@ -629,7 +629,7 @@ __global__ __launch_bounds__(kThreads) void k_fir_poison(int* __restrict__ flags
 }
 
 int fir_row_flags(Ctx* c, int32_t batch, int** out) {
-  const size_t need = ((size_t)batch + 1) * sizeof(int);   // one ticket cell in front of the flags (k_fir_wave's edge launch)
+  const size_t need = (size_t)batch * sizeof(int);
   if (c->scratch_bytes[22] < need) {
     void* p = nullptr;
     const size_t bytes = need < 4096 ? 4096 : need * 2;
@@ -637,7 +637,7 @@ int fir_row_flags(Ctx* c, int32_t batch, int** out) {
     if (rc) return rc;
     NXSIG_HIP_TRY(hipMemsetAsync(p, 0, bytes, c->stream));   // zero between calls: the poison pass clears what it consumes
   }
-  *out = reinterpret_cast<int*>(c->scratch[22]) + 1;
+  *out = reinterpret_cast<int*>(c->scratch[22]);
   return NXSIG_OK;
 }
 

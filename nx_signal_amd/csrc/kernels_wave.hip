@@ -855,7 +855,6 @@ struct FirWaveArgs {
   const v2f* twC;
   float* y;                            // f32[batch][out_len]
   int* row_flags;                      // FirLaunch::row_flags: a non-finite sample poisons its whole row, like the reference's one transform
-  int* poison_ticket = nullptr;        // edge launch only: its last workgroup does k_fir_poison's job (row_flags[-1])
 };
 
 int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, int32_t taps, int64_t first_block, int64_t pb_lo,
@@ -1008,32 +1007,6 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
             if (have2 && y2 >= 0 && y2 < a.out_len) yr[y2] = fft_eps0(zz[e2][q].y);
           }
         }
-    }
-    // The poison pass (rows that held an Inf / NaN sample come out NaN from end to end, FirLaunch::row_flags) rides on this launch
-    // instead of being a third one (4.5 us of config 5's 380): the workgroup that finishes LAST sees every flag the streaming launch
-    // (a kernel boundary ago) and this launch's other workgroups (release / acquire through the ticket) have raised.
-    if (a.poison_ticket) {   // uniform
-      __shared__ int s_last;
-      __syncthreads();
-      if (tid == 0) {
-        __threadfence();
-        s_last = atomicAdd(a.poison_ticket, 1) == (int)gridDim.x - 1;
-      }
-      __syncthreads();
-      if (s_last) {
-        __threadfence();
-        const float qnan = __int_as_float(0x7fc00000);
-        for (int r = 0; r < a.batch; ++r) {
-          if (atomicOr(a.row_flags + r, 0) == 0) continue;   // uniform; read where the other workgroups' atomics landed
-          float* yr = a.y + (size_t)r * a.out_len;
-          for (int64_t i = tid; i < a.out_len; i += 64 * W) yr[i] = qnan;
-        }
-        __syncthreads();
-        if (tid == 0) {
-          for (int r = 0; r < a.batch; ++r) atomicExch(a.row_flags + r, 0);   // cleared for the next call, like k_fir_poison
-          atomicExch(a.poison_ticket, 0);
-        }
-      }
     }
   }
 }
@@ -1519,7 +1492,6 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     // the edge launch has few, slow (bounds-checked) units: one per wave so that they all run concurrently, unless every pair
     // goes through it (filters whose taps - 1 is not a multiple of 128)
     if (!stream && a.total_units <= (int64_t)c->num_cus * W) a.chunk = W;
-    a.poison_ticket = stream ? nullptr : s.row_flags - 1;   // fir_row_flags keeps the ticket cell in front of the flags
     const int64_t blocks = (a.total_units + a.chunk - 1) / a.chunk;
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: signal too long for one launch");
     hipError_t attr_rc = hipSuccess;
@@ -1559,10 +1531,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     rc = launch(true, a.pb_hi - a.pb_lo);
   }
   if (rc) return rc;
-  const int64_t edge_units = a.pairs_per_row - (a.pb_hi - a.pb_lo);
-  rc = launch(false, edge_units);
-  if (rc == NXSIG_OK && edge_units > 0) s_in.poison_folded = true;   // the edge launch's last workgroup did k_fir_poison's job
-  return rc;
+  return launch(false, a.pairs_per_row - (a.pb_hi - a.pb_lo));
 }
 
 int launch_fir_wave(Ctx* c, const FirLaunch& s, bool* handled) {

@@ -224,7 +224,6 @@ struct FirLaunch {
   // row (Convolution.fftconvolve, lib/nx_signal/convolution.ex:276-284), so an Inf / NaN sample anywhere leaves no finite
   // output in that row; block-wise overlap-save would otherwise confine it to the blocks (and block pairs) that hold it.
   int* row_flags = nullptr;
-  mutable bool poison_folded = false;   // set by a launcher whose last kernel did the poison pass itself (k_fir_wave's edge launch)
 };
 int launch_fir(Ctx* c, const FirLaunch& a);
 int fir_row_flags(Ctx* c, int32_t batch, int** out);                                                     // kernels_generic.hip

@@ -16,8 +16,7 @@ CASES = {
     "stft_batch32": ([("k_stft_wave<1024, 0,", "max")], 32 * 11247 * 9216),
     "istft": ([("k_istft_wave<1024, 4,", "max"), ("nxsig::k_istft_edge_fix", "max")], 16 * 11247 * 10240),
     "stft2048": ([("k_stft_wave<1024, 1,", "max")], 8 * 56247 * 18432),
-    # (the edge launch also does the poison pass since round 4)
-    "fir": ([("k_fir_wave<1024, true,", "max"), ("k_fir_wave<1024, false,", "max")], 8 * 28800000 * 8),
+    "fir": ([("k_fir_wave<1024, true,", "max"), ("k_fir_wave<1024, false,", "max"), ("nxsig::k_fir_poison", "max")], 8 * 28800000 * 8),
 }
 
 

@@ -163,14 +163,20 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
             _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(buf.ptr + r * n * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
 
     def measure(fn, reps, warm):
+        import gc
         for _ in range(warm):
             fn()
         ctx.sync()
-        ctx.timer_lap()
-        for _ in range(reps):
-            fn()
+        gc.collect()
+        gc.disable()   # a collector pause while the launches are being queued lets the queue run dry (see lap_mean)
+        try:
             ctx.timer_lap()
-        return ctx.timer_laps()
+            for _ in range(reps):
+                fn()
+                ctx.timer_lap()
+            return ctx.timer_laps()
+        finally:
+            gc.enable()
 
     try:
         traffic_tab = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -620,6 +626,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    import gc
+    gc.collect()
+    gc.disable()   # no collector pause between two launches of the timed window
     barrier()
     t0 = time.perf_counter()
     ctx.timer_lap()
@@ -629,6 +638,7 @@ def main():
     laps = ctx.timer_laps()  # HIP events on the stream the kernels run on, one interval per step (synchronises)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     kernel_ms_total = float(sum(laps))
     if group is not None:
         elapsed, kernel_ms_total = group.allreduce([elapsed, kernel_ms_total], "max")

@@ -141,6 +141,15 @@ def load_diag():
         return None
 
 
+def lap_mean(laps):
+    """mean launch duration of a series of event-to-event laps -> (mean, laps left out).  A lap several times the median is not a
+    launch: the host thread was descheduled and the queue ran dry (seen once in ten boxes: one 6.5 ms lap among twenty of 0.4 ms).
+    Such laps are left out of the mean and counted (`stalled_laps`); min / median / max in `kernel_us` are over ALL laps."""
+    med = float(np.median(laps))
+    kept = [v for v in laps if v <= 3.0 * med]
+    return float(np.mean(kept)), len(laps) - len(kept)
+
+
 def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, seconds45=600, streams3=16, channels45=8, keep_z4=False):
     """Rooflines of the other BASELINE configs at their FULL per-GPU shard, measured like the headline (HIP events on the
     library's stream, one interval per launch, device-resident data; algorithmic bytes per SURVEY 8d):
@@ -182,14 +191,6 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         traffic_tab = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         traffic_tab = {}
-
-    def lap_mean(laps):
-        """mean launch duration of a series of event-to-event laps.  A lap several times the median is not a launch: the host
-        thread was descheduled and the queue ran dry (seen once in ten boxes: one 6.5 ms lap among twenty of 0.4 ms).  Such laps are
-        left out of the mean and counted in `stalled_laps`; min / median / max in `kernel_us` are over ALL laps."""
-        med = float(np.median(laps))
-        kept = [v for v in laps if v <= 3.0 * med]
-        return float(np.mean(kept)), len(laps) - len(kept)
 
     def block(workload, kernel, nbytes, laps, extra, traffic_key=None):
         ms, stalled = lap_mean(laps)

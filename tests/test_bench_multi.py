@@ -131,6 +131,18 @@ def test_reduce_secondary_takes_the_slowest_rank_and_survives_a_failed_block():
     assert "error" in out["config5"] and out["config5"]["ranks"] == 8
 
 
+def test_lap_mean_leaves_host_stalls_out_and_counts_them():
+    """one 6.5 ms lap among twenty of 0.4 ms is a queue that ran dry, not a launch (profiles/r04)"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    laps = [0.40] * 10 + [6.5] + [0.41] * 9
+    m, stalled = bench.lap_mean(laps)
+    assert stalled == 1 and abs(m - (0.40 * 10 + 0.41 * 9) / 19) < 1e-12
+    m, stalled = bench.lap_mean([0.40, 0.44, 0.39, 0.52])   # ordinary spread: nothing left out
+    assert stalled == 0 and abs(m - 0.4375) < 1e-12
+
+
 def test_effective_cores_reads_the_cgroup_quota(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import builtins

@@ -217,6 +217,18 @@ def test_fir_sample_shards_agree_on_non_finite_rows(pair, solo, mode):
         assert float(np.max(np.abs(clean - ref)) / np.max(np.abs(ref))) < 1e-6
     got1 = sharding.fir_sharded(pair, xp[1], h, mode=mode, axis="samples", gather=True)   # assembled on the device
     assert not np.isfinite(got1).any()
+    # device-resident sample shards (dense per-member spans): the same exchange, the shards stay on the device
+    L2 = xp.shape[1]
+    spans = [sharding.shard_fir(L2, 257, pair.world, r, mode) for r in pair.ranks]
+    ins = [pair.contexts[i].to_device(np.ascontiguousarray(xp[:, s0:s1])) for i, (_, _, s0, s1) in enumerate(spans)]
+    outs = sharding.fir_sharded(pair, ins, h, mode=mode, axis="samples", length=L2, batch=3)
+    for (n0, n1, _, _), o in zip(spans, outs):
+        part = o.numpy()
+        assert part.shape == (3, n1 - n0)
+        assert np.array_equal(np.isfinite(part), np.isfinite(full[:, n0:n1]))
+        assert float(np.max(np.abs(part[0] - full[0, n0:n1])) / np.max(np.abs(full[0]))) < 1e-6
+    for b_ in ins + outs:
+        b_.free()
 
 
 @pytest.mark.parametrize("N,hop,M,scaling", [

@@ -7,7 +7,8 @@
 //   k_stft_dft        remaining lengths: direct DFT, table twiddles, double accumulation
 //   k_fft_rows_*      Nx.fft / Nx.ifft(length:) over rows (+ optional x scale x window epilogue for istft)
 //   k_ola             deterministic overlap-add (+ |w|^2 normaliser with the 1e-10 guard) in fixed frame order
-//   k_istft_edge_fix  f64 recomputation of the few ill-conditioned OLA samples (see the comment at the kernel)
+//   k_istft_edge_fix  the ONE pass after any istft main kernel: f64 recomputation of the few ill-conditioned OLA samples and, for the
+//                     kernels that invert several frames per transform, of the units they reported as holding a non-finite bin
 //   k_as_windowed     framing gather
 //   k_fir_os          overlap-save block convolution, two real blocks packed as re/im of one complex FFT
 //   k_cmul_inplace    pointwise product of complex fftconvolve

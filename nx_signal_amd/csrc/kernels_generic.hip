@@ -450,7 +450,7 @@ __device__ __forceinline__ float2 istft_bin(const EdgeFixArgs& a, const float2* 
 
 // one output sample of one row, along the reference's chain in double, by ONE WAVE (round 4: a whole workgroup per sample spent its
 // time in an 8-level LDS reduction with barriers; a wave keeps N / 64 terms per lane in flight and reduces with six shuffles, and four
-// times as many samples are resident per CU — the pass after config 3's kernel went from 15.6 to ~6 us).
+// times as many samples are resident per CU — the pass after config 3's kernel went from 15.6 to 10.6 us in rocprofv3, together with the twiddle recurrence below).
 // the sum itself: frames m_lo .. m_hi cover sample n, d = the guarded normaliser
 __device__ __forceinline__ void istft_sample_body(const EdgeFixArgs& a, const int64_t row, const int64_t n, const int64_t m_lo, const int64_t m_hi,
                                                   const float d) {
@@ -476,7 +476,7 @@ __device__ __forceinline__ void istft_sample_body(const EdgeFixArgs& a, const in
     };
     // 16 spectrum loads in flight per lane (the sum is a chain of N / 64 dependent round trips otherwise), ONE table look-up per 16
     // terms: w^(j k) is a 64-way gather of 16-byte entries over up to 64 cache lines, and 16 of those per wave kept the CU's texture
-    // path busy for most of this pass (4 416 waves after config 3's kernel: ~8 us of 20).  The other 15 twiddles follow by
+    // path busy for most of this pass (4 416 waves after config 3's kernel: the pass took 20 us under the profiler with the gather, 13.5 without).  The other 15 twiddles follow by
     // w^(j (k + 64)) = w^(j k) w^(64 j) in double: at most 15 roundings of 1.1e-16 on values that are then rounded to f32.
     constexpr int U = 16;
     const double2 wstep = a.tw[tstep];

@@ -19,8 +19,8 @@ travels through a file on the node); barrier, max-over-ranks and the optional as
 
 Clock pre-conditioning: a GPU that has been idle starts a run of launches at boost clocks, overshoots its power budget
 about 5 launches in and takes ~20 launches to settle (round-1 trace: 576 -> 725 -> 571 us).  Before the W warm-up steps
-the bench therefore launches the same step until 10 consecutive launches lie within 3 % of the running minimum (at most
-300 launches / ~0.2 s), untimed, so that a short timed window (--steps 20) measures the steady state.  The per-launch
+the bench therefore launches the same step until the series has settled (`settled_tail`: the mean of the last 10 launches within
+2 % of the mean of the 10 before them and no outlier among them; at most 300 launches / ~0.2 s), untimed, so that a short timed window (--steps 20) measures the steady state.  The per-launch
 distribution of the TIMED steps (min / median / p90 / max) is printed so that a transient stays visible.
 
 Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch
@@ -142,28 +142,77 @@ def load_diag():
 
 
 def lap_mean(laps):
-    """mean launch duration of a series of event-to-event laps -> (mean, laps left out).  A lap several times the median is not a
+    """mean launch duration of a series of event-to-event laps -> (trimmed mean, laps left out).  A lap several times the median is not a
     launch: the host thread was descheduled and the queue ran dry (seen once in ten boxes: one 6.5 ms lap among twenty of 0.4 ms).
-    Such laps are left out of the mean and counted (`stalled_laps`); min / median / max in `kernel_us` are over ALL laps."""
+    Such laps are left out of the TRIMMED mean and counted (`stalled_laps`); every block reports the all-laps mean beside it
+    (`kernel_ms_all_laps` / `frac_all_laps`) and min / median / max over ALL laps — one policy for the headline and the secondaries."""
     med = float(np.median(laps))
     kept = [v for v in laps if v <= 3.0 * med]
     return float(np.mean(kept)), len(laps) - len(kept)
 
 
-def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, seconds45=600, streams3=16, channels45=8, keep_z4=False):
+def lap_us(laps):
+    return {"min": round(min(laps) * 1e3, 1), "median": round(float(np.median(laps)) * 1e3, 1),
+            "p90": round(float(np.percentile(laps, 90)) * 1e3, 1), "max": round(max(laps) * 1e3, 1), "n": len(laps)}
+
+
+SETTLE_RULE = "mean of the last 10 laps within 2 % of the mean of the 10 before them, and no lap of the last 10 above 1.10 x their minimum"
+
+
+def settled_tail(hist):
+    """the clock transient of a GPU that was idle (boost -> power excursion -> steady state: 576 -> 725 -> 571 us on the headline) is over when
+    two consecutive windows of 10 launches agree in the mean and the last one holds no outlier.  (Round 4's rule — 10 laps within 3 % of
+    the running MINIMUM — never fired on a box whose steady-state laps scatter by 6 %: 300 launches, settled: false, on a settled GPU.)"""
+    if len(hist) < 20:
+        return False
+    a, b = hist[-20:-10], hist[-10:]
+    return abs(float(np.mean(b)) / float(np.mean(a)) - 1.0) <= 0.02 and max(b) <= 1.10 * min(b)
+
+
+def settle(ctx, fn, cap, nbytes=None):
+    """The headline's clock pre-conditioning as a helper every block uses: launch `fn` from wherever the clocks are (after an upload: idle)
+    until the series has settled (`settled_tail`; at least 30, at most `cap` launches), one HIP-event interval per launch.  Returns what a cold caller saw (the first 20 laps) and whether the series settled."""
+    ctx.sync()
+    hist = []
+    settled = False
+    while len(hist) < max(cap, 20):
+        ctx.timer_lap()
+        for _ in range(10):
+            fn()
+            ctx.timer_lap()
+        hist += ctx.timer_laps()
+        if len(hist) >= 30 and settled_tail(hist):
+            settled = True
+            break
+    d = {"launches": len(hist), "settled": settled, "rule": SETTLE_RULE, "first10_us": [round(v * 1e3, 1) for v in hist[:10]],
+         "last10_us": [round(v * 1e3, 1) for v in hist[-10:]], "min_us": round(min(hist) * 1e3, 1)}
+    cold = float(np.mean(hist[:20]))
+    d["cold20"] = {"mean_us": round(cold * 1e3, 1)}
+    if nbytes:
+        d["cold20"]["frac"] = nbytes / (cold * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return d
+
+
+def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, seconds45=600, streams3=16, channels45=8, keep_z4=False,
+                        settle_cap=300, yard=None):
     """Rooflines of the other BASELINE configs at their FULL per-GPU shard, measured like the headline (HIP events on the
     library's stream, one interval per launch, device-resident data; algorithmic bytes per SURVEY 8d):
       config 3  istft N=1024 hop=256, 16 x 60 s            10 240 B/frame  (K*8 read + hop*8 written, c64 out)
       config 4  stft  N=2048 hop=512, 8 ch x 600 s          18 432 B/frame  (one GPU's share of 64 channels)
       config 5  fir   257 taps :same, 8 ch x 600 s          8 B/sample      (4 in + 4 out)
+    Every block is on the headline's footing: after the upload has left the GPU idle, the block's own kernel is
+    launched until the clocks have settled (`settle` / `settled_tail`, the headline's rule; at most `settle_cap`
+    launches; the first 20 laps are reported as `cold20`), then kernel and no-math traffic model (`mix_ceiling`, tools/diag_mix.hip: the
+    same traffic in the kernel's launch geometry) are timed INTERLEAVED — A B A B, 10 laps each after 2 untimed launches — so that
+    `kernel_over_ceiling` compares two series taken under the same clocks.
     Under a launcher EVERY rank runs this on its own shard (`barrier` lines the ranks up before each of the two blocks so the GPUs
-    of the node work at the same time); main() reduces the per-rank kernel times with max-over-ranks.  `mix_ceiling` (configs 3 / 4 / 5): the
-    same traffic with no math in the kernel's launch geometry (tools/diag_mix.hip), timed the same way in this process."""
+    of the node work at the same time); main() reduces the per-rank kernel times with max-over-ranks."""
     out = {}
     rng = np.random.Generator(np.random.PCG64(99))
     diag = load_diag()
     stream = C.c_void_p(lib.nxsig_get_stream(ctx.handle)) if diag is not None else None
     sync = barrier if barrier is not None else (lambda: None)
+    yard = yard or {}
 
     def fill(buf, rows, n):
         chunk = rng.standard_normal(n, dtype=np.float32)
@@ -187,34 +236,47 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         finally:
             gc.enable()
 
+    def interleaved(kernel_fn, mix_fn, rounds=2, reps=10):
+        """A B A B: `rounds` x (`reps` kernel laps, `reps` model laps), 2 untimed launches in front of each series"""
+        kl, ml = [], []
+        for _ in range(rounds):
+            kl += measure(kernel_fn, reps, 2)
+            if mix_fn is not None:
+                ml += measure(mix_fn, reps, 2)
+        return kl, ml
+
     try:
         traffic_tab = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         traffic_tab = {}
 
-    def block(workload, kernel, nbytes, laps, extra, traffic_key=None):
+    def block(workload, kernel, nbytes, laps, extra, pre, traffic_key=None):
         ms, stalled = lap_mean(laps)
+        ms_all = float(np.mean(laps))
         ach = nbytes / (ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes of the same launch shape (profiles/traffic.json), checked against the shape
         traffic = traffic_tab.get(traffic_key + "_bytes_per_launch") if traffic_key and traffic_tab.get(traffic_key + "_algorithmic_bytes") == nbytes else None
         d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
              "traffic_source": "profiles/traffic.json (PMC passes of tools/profile_bench.sh, not measured in this run)",
-             "kernel_ms": ms, "kernel_us": {"min": round(min(laps) * 1e3, 1), "median": round(float(np.median(laps)) * 1e3, 1),
-                                            "max": round(max(laps) * 1e3, 1)}, "workload": workload, "kernel": kernel, "algorithmic_bytes": nbytes}
-        if stalled:
-            d["stalled_laps"] = stalled
+             "kernel_ms": ms, "kernel_ms_all_laps": ms_all, "frac_all_laps": nbytes / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "stalled_laps": stalled, "kernel_us": lap_us(laps), "settled": bool(pre.get("settled")), "precondition": pre,
+             "cold20": pre.get("cold20"), "workload": workload, "kernel": kernel, "algorithmic_bytes": nbytes}
         d.update(extra)
         return d
 
-    def ceiling(d, nbytes, fn, what):
-        """the no-math traffic model interleaved after the kernel: same buffers, same stream, same clocks"""
-        if diag is None:
+    def ceiling(d, nbytes, mlaps, what, plain_key=None):
+        """the no-math traffic model, timed interleaved with the kernel: same buffers, same stream, same clocks"""
+        if not mlaps:
             d["mix_ceiling"] = None
-            return
-        laps = measure(fn, 20, 10)
-        ms, _ = lap_mean(laps)
-        gbs = nbytes / (ms * 1e-3) / 1e9
-        d["mix_ceiling"] = {"GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "kernel_over_ceiling": d["achieved"] / gbs, "what": what}
+        else:
+            ms, stalled = lap_mean(mlaps)
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            d["mix_ceiling"] = {"GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "kernel_over_ceiling": d["achieved"] / gbs, "what": what,
+                                "laps_us": lap_us(mlaps), "stalled_laps": stalled, "interleaved": "A B A B, 10 laps each"}
+        if plain_key and yard.get(plain_key):
+            # the geometry-free yardstick of the same read : write ratio, timed in this process by yardsticks()
+            d["plain_" + plain_key] = {k: yard[plain_key][k] for k in ("GBps", "frac_of_peak", "what") if k in yard[plain_key]}
+            d["plain_" + plain_key]["kernel_over_plain"] = d["achieved"] / yard[plain_key]["GBps"]
 
     # N > 1: the ranks are lined up ONCE per block, outside the try blocks — a rank whose block fails still meets the others at the
     # next line-up (a barrier inside the timed helpers would be skipped by a failing rank and hang the rest)
@@ -231,19 +293,21 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         y3 = ctx.empty((B3, M3 * HOP + N_FFT - HOP), np.complex64)
         p3 = _lib.StftParams(N_FFT, HOP, N_FFT, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
         wp = w.ctypes.data_as(C.c_void_p)
-        laps = measure(lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(z3.ptr), M3, B3, wp, C.byref(p3), C.c_void_p(y3.ptr), _lib.DEVICE)), 20, 30)
         nb3 = B3 * M3 * (N_FFT * 8 + HOP * 8)
-        out["roofline_istft"] = block(f"config 3: istft N=1024 hop=256, {B3} x {seconds3} s mono 48 kHz, c64 out", "k_istft_wave<1024> (+ k_istft_edge_fix)",
-                                      nb3, laps, {"bytes_per_frame": N_FFT * 8 + HOP * 8, "frames": B3 * M3, "frames_per_s": B3 * M3 / (lap_mean(laps)[0] * 1e-3)}, "istft")
-        # round trip of config 3 on interior samples (size-independent property): y ~ x
+        k3 = lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(z3.ptr), M3, B3, wp, C.byref(p3), C.c_void_p(y3.ptr), _lib.DEVICE))  # noqa: E731
+        pre = settle(ctx, k3, settle_cap, nb3)
+        # round trip of config 3 on interior samples (size-independent property): y ~ x — read BEFORE the model overwrites y
         chk = np.empty(4096, np.complex64)
         _lib.check(lib.nxsig_download(ctx.handle, chk.ctypes.data_as(C.c_void_p), C.c_void_p(y3.ptr + 8 * 100000), chk.nbytes))
         ref = np.empty(4096, np.float32)
         _lib.check(lib.nxsig_download(ctx.handle, ref.ctypes.data_as(C.c_void_p), C.c_void_p(x3.ptr + 4 * 100000), ref.nbytes))
+        m3 = (lambda: diag.nxdiag_istft_mix(stream, C.c_void_p(z3.ptr), C.c_void_p(y3.ptr), B3 * M3, 8, 3)) if diag is not None else None
+        laps, mlaps = interleaved(k3, m3)
+        out["roofline_istft"] = block(f"config 3: istft N=1024 hop=256, {B3} x {seconds3} s mono 48 kHz, c64 out", "k_istft_wave<1024> (+ k_istft_edge_fix)",
+                                      nb3, laps, {"bytes_per_frame": N_FFT * 8 + HOP * 8, "frames": B3 * M3, "frames_per_s": B3 * M3 / (lap_mean(laps)[0] * 1e-3)}, pre, "istft")
         out["roofline_istft"]["roundtrip_max_err"] = float(np.max(np.abs(chk.real - ref)) / np.max(np.abs(ref)))
-        # the y buffer is scratch from here on (the round trip has been read)
-        ceiling(out["roofline_istft"], nb3, lambda: diag.nxdiag_istft_mix(stream, C.c_void_p(z3.ptr), C.c_void_p(y3.ptr), B3 * M3, 8, 3),
-                "tools/diag_mix.hip k_istft_mix: 8 KiB nt-read + 2 KiB nt-written per frame, no math, 8 runs per CU, two frames ahead, 3 halo frames per run")
+        ceiling(out["roofline_istft"], nb3, mlaps,
+                "tools/diag_mix.hip k_istft_mix: 8 KiB nt-read + 2 KiB nt-written per frame, no math, 8 runs per CU, two frames ahead, 3 halo frames per run", "mix_4to1")
         for b in (x3, z3, y3):
             b.free()
     except Exception as e:  # noqa: BLE001
@@ -260,34 +324,108 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         z4 = ctx.empty((B4, M4, N4), np.complex64)
         p4 = _lib.StftParams(N4, H4, N4, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
         wp4 = w4.ctypes.data_as(C.c_void_p)
-        laps = measure(lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, wp4, C.byref(p4), C.c_void_p(z4.ptr), None, _lib.DEVICE)), 10, 15)
+        nb4 = B4 * M4 * (H4 * 4 + N4 * 8)
+        k4 = lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, wp4, C.byref(p4), C.c_void_p(z4.ptr), None, _lib.DEVICE))  # noqa: E731
+        pre = settle(ctx, k4, settle_cap, nb4)
+        tab4 = ctx.to_device(np.zeros(3072, np.float32)) if diag is not None else None
+        m4 = (lambda: diag.nxdiag_stft2048_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(z4.ptr), C.c_void_p(tab4.ptr), B4, L4, H4, 8)) if diag is not None else None
+        laps, mlaps = interleaved(k4, m4)
         out["roofline_stft2048"] = block(f"config 4 (one GPU's shard of 64 channels): stft N=2048 hop=512, {B4} ch x {seconds45} s @48 kHz", "k_stft_wave<1024, real-2x>",
-                                         B4 * M4 * (H4 * 4 + N4 * 8), laps, {"bytes_per_frame": H4 * 4 + N4 * 8, "frames": B4 * M4, "frames_per_s": B4 * M4 / (lap_mean(laps)[0] * 1e-3)}, "stft2048")
-        if diag is not None:
-            tab4 = ctx.to_device(np.zeros(3072, np.float32))
-            ceiling(out["roofline_stft2048"], B4 * M4 * (H4 * 4 + N4 * 8),
-                    lambda: diag.nxdiag_stft2048_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(z4.ptr), C.c_void_p(tab4.ptr), B4, L4, H4, 8),
-                    "tools/diag_mix.hip k_stft2048_mix: the real-2x kernel's loads and stores in its launch geometry (8 frames per wave), no math")
+                                         nb4, laps, {"bytes_per_frame": H4 * 4 + N4 * 8, "frames": B4 * M4, "frames_per_s": B4 * M4 / (lap_mean(laps)[0] * 1e-3)}, pre, "stft2048")
+        ceiling(out["roofline_stft2048"], nb4, mlaps,
+                "tools/diag_mix.hip k_stft2048_mix: the real-2x kernel's loads and stores in its launch geometry (8 frames per wave), no math", "mix_1to8")
+        if tab4 is not None:
             tab4.free()
-            if keep_z4:   # the assembly gathers THIS spectrum: the model overwrote it
-                _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, wp4, C.byref(p4), C.c_void_p(z4.ptr), None, _lib.DEVICE))
-        if not keep_z4:
+        if keep_z4:   # the assembly gathers THIS spectrum: the model overwrote it
+            k4()
+        else:
             z4.free()
             z4 = None
         h = S.filters.firwin(257, [4000.0], sampling_rate=float(SR))
         y5 = ctx.empty((B4, L4), np.float32)
         hp = h.ctypes.data_as(C.c_void_p)
-        laps = measure(lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, hp, 257, _lib.CONV_SAME, C.c_void_p(y5.ptr), _lib.DEVICE)), 10, 15)
+        k5 = lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, hp, 257, _lib.CONV_SAME, C.c_void_p(y5.ptr), _lib.DEVICE))  # noqa: E731
+        pre = settle(ctx, k5, settle_cap, B4 * L4 * 8)
+        m5 = (lambda: diag.nxdiag_fir_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(y5.ptr), B4, L4, 8)) if diag is not None else None
+        laps, mlaps = interleaved(k5, m5)
         out["roofline_fir"] = block(f"config 5 (one GPU's shard): fir 257 taps :same, {B4} ch x {seconds45} s @48 kHz", "nxsig_fir_f32 (stream + edge + poison pass)",
-                                    B4 * L4 * 8, laps, {"bytes_per_sample": 8, "samples": B4 * L4, "samples_per_s": B4 * L4 / (lap_mean(laps)[0] * 1e-3)}, "fir")
-        ceiling(out["roofline_fir"], B4 * L4 * 8, lambda: diag.nxdiag_fir_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(y5.ptr), B4, L4, 8),
-                "tools/diag_mix.hip k_fir_mix: the overlap-save stream of k_fir_wave<1024> (two 1024-sample blocks read per 1536 outputs, 8-byte accesses, sc1 nt stores), no math")
+                                    B4 * L4 * 8, laps, {"bytes_per_sample": 8, "samples": B4 * L4, "samples_per_s": B4 * L4 / (lap_mean(laps)[0] * 1e-3)}, pre, "fir")
+        ceiling(out["roofline_fir"], B4 * L4 * 8, mlaps,
+                "tools/diag_mix.hip k_fir_mix: the overlap-save stream of k_fir_wave<1024> (two 1024-sample blocks read per 1536 outputs, 8-byte accesses, sc1 nt stores), no math",
+                "mix_1to1")
         x4.free()
         y5.free()
     except Exception as e:  # noqa: BLE001
         out["roofline_fir"] = out.get("roofline_fir") or {"error": repr(e)[:200]}
     out["_z4"] = z4
     return out
+
+
+def yardsticks(ctx, lib, _lib, C, diag, xd, x_bytes, zd, z_bytes):
+    """Independent bandwidth yardsticks of THIS box, in this process, on the bench's own buffers: the runtime's
+    hipMemcpyDtoDAsync, a float4 grid-stride copy / read / fill, and plain 4 : 1, 1 : 8 and 1 : 1 read / write streams over 1 KiB wave
+    rows with no kernel-specific geometry (tools/diag_mix.hip k_y_*).  Each: 5 untimed + 20 timed launches (HIP events on the library's
+    stream) at two grid sizes, the better one reported.  `zd` (the spectrum buffer) and `xd` (the input) are scratch from here on."""
+    if diag is None or not hasattr(diag, "nxdiag_y_copy"):
+        return None
+    vp, sz = C.c_void_p, C.c_size_t
+    diag.nxdiag_y_copy.argtypes = [vp, vp, vp, sz, C.c_int]
+    diag.nxdiag_y_fill.argtypes = [vp, vp, sz, C.c_int]
+    diag.nxdiag_y_read.argtypes = [vp, vp, vp, sz, C.c_int]
+    diag.nxdiag_y_mix.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, C.c_int]
+    diag.nxdiag_y_memcpy.argtypes = [vp, vp, vp, sz]
+    stream = vp(lib.nxsig_get_stream(ctx.handle))
+    kib = 1024
+    half = (z_bytes // 2) // kib * kib
+    fifth = (z_bytes // 5) // kib * kib
+    steps41 = fifth // kib
+    steps18 = min(x_bytes // kib, z_bytes // (8 * kib))
+    Z, X = zd.ptr, xd.ptr
+    q4 = (z_bytes // (4 * kib))          # 4 KiB wave steps in the spectrum buffer
+    h4 = (half // (4 * kib))
+    # geometry g: > 0 = grid-stride over g long-lived workgroups, < 0 = short-lived workgroups handing out -g consecutive steps per wave
+    geos = (2048, 8192, -2, -8)
+    cases = [
+        ("read", z_bytes, "16-byte loads of the spectrum buffer, no stores", geos,
+         lambda g: diag.nxdiag_y_read(stream, vp(Z), vp(X), z_bytes, g) if g > 0 else diag.nxdiag_y_mix(stream, vp(Z), vp(X), q4, 4, 0, g)),
+        ("copy", 2 * half, "16-byte copy, first half of the spectrum buffer -> second half (read + written bytes)", geos,
+         lambda g: diag.nxdiag_y_copy(stream, vp(Z), vp(Z + half), half, g) if g > 0 else diag.nxdiag_y_mix(stream, vp(Z), vp(Z + half), h4, 4, 4, g)),
+        ("memcpy_dtod", 2 * half, "hipMemcpyDtoDAsync of the same halves (read + written bytes)", (0,), lambda g: diag.nxdiag_y_memcpy(stream, vp(Z), vp(Z + half), half)),
+        ("mix_4to1", steps41 * 5 * kib, "plain 4 : 1 stream (the iSTFT's ratio): a wave reads 4 KiB (4 x 16 B per lane) and writes 1 KiB per step", geos,
+         lambda g: diag.nxdiag_y_mix(stream, vp(Z), vp(Z + 4 * fifth), steps41, 4, 1, g)),
+        ("mix_1to8", steps18 * 9 * kib, "plain 1 : 8 stream (the STFT's ratio): a wave reads 1 KiB and writes 8 KiB per step", geos,
+         lambda g: diag.nxdiag_y_mix(stream, vp(X), vp(Z), steps18, 1, 8, g)),
+        ("mix_1to1", 2 * half, "plain 1 : 1 stream (the FIR's ratio) over 1 KiB wave rows", geos, lambda g: diag.nxdiag_y_mix(stream, vp(Z), vp(Z + half), half // kib, 1, 1, g)),
+        ("fill", z_bytes, "16-byte stores over the spectrum buffer, no loads (constant data: last, it overwrites the buffer)", geos,
+         lambda g: diag.nxdiag_y_fill(stream, vp(Z), z_bytes, g) if g > 0 else diag.nxdiag_y_mix(stream, vp(X), vp(Z), q4, 0, 4, g)),
+    ]
+    res = {}
+    for name, nbytes, what, grids, fn in cases:
+        best = None
+        for grid in grids:
+            rc = 0
+            for _ in range(5):
+                rc |= fn(grid)
+            ctx.sync()
+            ctx.timer_lap()
+            for _ in range(20):
+                rc |= fn(grid)
+                ctx.timer_lap()
+            laps = ctx.timer_laps()
+            if rc:
+                continue
+            ms, stalled = lap_mean(laps)
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            if best is None or gbs > best["GBps"]:
+                geo = "runtime" if grid == 0 else (f"grid-stride, {grid} workgroups" if grid > 0 else f"short-lived workgroups, {-grid} steps per wave")
+                best = {"GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "bytes": int(nbytes), "geometry": geo, "laps_us": lap_us(laps), "stalled_laps": stalled, "what": what,
+                        "all_geometries_GBps": {}}
+            res.setdefault("_all", {}).setdefault(name, {})[str(grid)] = round(gbs)
+        if best is not None:
+            best["all_geometries_GBps"] = res.get("_all", {}).get(name, {})
+        res[name] = best
+    res.pop("_all", None)
+    return res
 
 
 def assembly_config4(ctx, group, lib, S, _lib, C, world, rank, channels, seconds, share_gpu):
@@ -493,6 +631,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the roofline blocks of configs 3 / 4 / 5")
+    ap.add_argument("--no-yardsticks", action="store_true", help="skip the plain copy / read / fill / mix bandwidth yardsticks")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST MODE for one-GPU boxes: every rank uses device LOCAL_RANK %% device_count and claims its own "
                          "NCCL_HOSTID, so several ranks can form an RCCL communicator on ONE GPU (socket transport over lo); "
@@ -574,10 +713,8 @@ def main():
     # inputs resident in HBM before the timed region: B independent streams, seed = 1234 + global stream index
     xd = ctx.empty((B, L), np.float32)
     for b in range(B):
-        xb = synth(1234 + rank * B + b)
+        xb = synth(1234 + rank * B + b)   # reproducible: the in-run check below regenerates the streams it samples from these seeds
         _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(xd.ptr + b * L * 4), xb.ctypes.data_as(C.c_void_p), xb.nbytes))
-        if b == 0:
-            x0 = xb
     zd = ctx.empty((B, M, N_FFT), np.complex64)
     p = _lib.StftParams(N_FFT, HOP, N_FFT, _lib.PAD_VALID, 0, 0, _lib.SCALE_NONE, 0, float(SR))
     wp = w.ctypes.data_as(C.c_void_p)
@@ -603,7 +740,7 @@ def main():
     cold20 = ctx.timer_laps()
 
     # ---- clock pre-conditioning (untimed, see the module docstring)
-    precondition = {"launches": 0, "settled": False}
+    precondition = {"launches": 0, "settled": False, "rule": SETTLE_RULE}
     if args.precondition > 0:
         hist = list(cold20)
         while len(hist) < args.precondition:
@@ -612,8 +749,7 @@ def main():
                 step()
                 ctx.timer_lap()
             hist += ctx.timer_laps()
-            lo = min(hist)
-            if len(hist) >= 30 and max(hist[-10:]) <= 1.03 * lo:
+            if len(hist) >= 30 and settled_tail(hist):
                 precondition["settled"] = True
                 break
         precondition.update(launches=len(hist), first10_us=[round(v * 1e3, 1) for v in hist[:10]],
@@ -702,11 +838,33 @@ def main():
     if not args.no_verify and rank == 0:
         from oracle import nx_oracle as O  # checker only, outside the timed region
 
-        nchk = 512
-        z0 = np.empty((nchk, N_FFT), np.complex64)
-        _lib.check(lib.nxsig_download(ctx.handle, z0.ctypes.data_as(C.c_void_p), C.c_void_p(zd.ptr), z0.nbytes))
-        zo, _, _ = O.stft(x0[: (nchk - 1) * HOP + N_FFT], w, overlap_length=N_FFT - HOP, fft_length=N_FFT, sampling_rate=SR)
-        verify = float(np.max(np.abs(z0 - zo)) / np.max(np.abs(zo)))
+        # 64 (stream, frame) pairs over the WHOLE launch shape of the timed step: first / last stream, first / last
+        # frames of a row (the last pair of a row is ragged: M is odd), both sides of workgroup seams (a workgroup takes 8 frame pairs
+        # = 16 frames, a wave 2 pairs), both sides of the row seam, and seeded random picks in every remaining stream
+        picks = []
+        for b in sorted({0, 1, B // 2, B - 2, B - 1} & set(range(B))):
+            picks += [(b, m) for m in (0, 1, 3, 4, 15, 16, 17, M // 2 - 1, M // 2, M - 17, M - 16, M - 3, M - 2, M - 1) if 0 <= m < M]
+        prng = np.random.Generator(np.random.PCG64(77))
+        rest = [b for b in range(B) if b not in {p[0] for p in picks}]
+        while len(picks) < 64 and rest:
+            for b in rest:
+                if len(picks) < 64:
+                    picks.append((b, int(prng.integers(0, M))))
+        picks = picks[:64]
+        worst, scale_ref, by_stream = 0.0, 0.0, {}
+        for b, m in picks:
+            by_stream.setdefault(b, []).append(m)
+        for b, ms_ in by_stream.items():
+            xb = synth(1234 + rank * B + b)
+            for m in ms_:
+                zg = np.empty((1, N_FFT), np.complex64)
+                _lib.check(lib.nxsig_download(ctx.handle, zg.ctypes.data_as(C.c_void_p), C.c_void_p(zd.ptr + (b * M + m) * N_FFT * 8), zg.nbytes))
+                zo, _, _ = O.stft(xb[m * HOP: m * HOP + N_FFT], w, overlap_length=N_FFT - HOP, fft_length=N_FFT, sampling_rate=SR)
+                worst = max(worst, float(np.max(np.abs(zg - zo))))
+                scale_ref = max(scale_ref, float(np.max(np.abs(zo))))
+        verify = {"frames": len(picks), "streams": len(by_stream), "max_norm_err": worst / scale_ref, "tolerance": 1e-5,
+                  "last_frame_of_last_stream": (B - 1, M - 1) in picks,
+                  "what": "max |z_gpu - z_oracle| / max |z_oracle| over the sampled (stream, frame) pairs of the timed launch shape"}
 
     # ---- the headline's own no-math ceiling: the kernel's stream (32 four-byte loads and 16 sixteen-byte `sc1 nt` stores per lane and
     # frame pair, 2 pairs per wave, short-lived 4-wave workgroups, 12 KB of tables per workgroup) with no arithmetic, same buffers
@@ -737,13 +895,22 @@ def main():
         except Exception as e:  # noqa: BLE001
             headline_ceiling = {"error": repr(e)[:160]}
 
+    # ---- independent bandwidth yardsticks of this box (same process, same buffers; both are scratch from here on)
+    yard = None
+    if rank == 0 and not args.no_yardsticks:
+        try:
+            yard = yardsticks(ctx, lib, _lib, C, diag, xd, B * L * 4, zd, B * M * N_FFT * 8)
+        except Exception as e:  # noqa: BLE001
+            yard = {"error": repr(e)[:160]}
+
     # ---- BASELINE configs 3 / 4 / 5 at their full per-GPU shard: on every rank at the same time (N > 1: max-over-ranks)
     for b in (xd, zd):
         b.free()
     sec, sec_multi, assembly4 = {}, None, None
     if not args.no_secondary:
         sec = secondary_rooflines(ctx, lib, S, _lib, C, barrier=barrier if world > 1 else None, seconds3=args.istft_seconds,
-                                  seconds45=args.secondary_seconds, channels45=args.secondary_channels)
+                                  seconds45=args.secondary_seconds, channels45=args.secondary_channels, settle_cap=args.precondition,
+                                  yard=yard if isinstance(yard, dict) and "error" not in yard else None)
         sec.pop("_z4", None)
         if world > 1:
             try:
@@ -791,9 +958,13 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": "profiles/traffic.json: PMC FETCH_SIZE x 2 + WRITE_SIZE per launch of this launch shape, collected "
                                   "by tools/profile_bench.sh in separate rocprofv3 --pmc passes; NOT measured in this run",
-                "kernel_ms": kernel_ms, "bytes_per_frame": BYTES_PER_FRAME, "frac_of_measured_copy_6290": achieved / 6290.0,
-                "kernel_us": {"min": round(min(laps) * 1e3, 1), "median": round(float(np.median(laps)) * 1e3, 1),
-                              "p90": round(float(np.percentile(laps, 90)) * 1e3, 1), "max": round(max(laps) * 1e3, 1)},
+                "kernel_ms": kernel_ms, "bytes_per_frame": BYTES_PER_FRAME,
+                # two clocks, both printed: `frac` = mean HIP-event interval per step (the kernel's launch duration, what rocprofv3 shows);
+                # `frac_wall` = the same bytes over ms_per_step (the host clock `value` uses: barrier + sync on both sides included)
+                "frac_wall": (B * M * BYTES_PER_FRAME) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac_trimmed": (B * M * BYTES_PER_FRAME) / (lap_mean(laps)[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
+                "frac_of_copy_this_box": (achieved / yard["copy"]["GBps"]) if isinstance(yard, dict) and yard.get("copy") else None,
+                "kernel_us": lap_us(laps),
                 "mix_ceiling": headline_ceiling,
                 # laps several times the median are host stalls (the queue ran dry), not launches; `value` and `achieved` keep them —
                 # the contract times exactly K steps — and this says how many there were
@@ -808,7 +979,9 @@ def main():
                             "error": comm_error} if comm_error else None)),
             "single_stream": single,
             "assembly": assembly,
-            "max_norm_err_vs_oracle": verify,
+            "max_norm_err_vs_oracle": verify["max_norm_err"] if verify else None,
+            "verify": verify,
+            "yardsticks": yard,
             "device": ctx.name(),
         }
         out.update(sec)  # roofline_istft / roofline_stft2048 / roofline_fir of THIS rank (N = 1: the whole story)

@@ -14,6 +14,8 @@
 #endif
 
 #include "nxsig_internal.h"
+#include <strings.h>
+#include <cstdio>
 
 namespace nxsig {
 
@@ -370,13 +372,51 @@ int tuning_index(const char* name) {
     if (!std::strcmp(name, kTuneNames[k]) || !std::strcmp(name, kTuneNames[k] + 6)) return k;
   return -1;
 }
-// the library's ONE look at the process environment for its switches: at context creation, never in a launch
+// Admissible values of a switch.  The geometry knobs end up as divisors or loop counts in the launchers (ISTFT_RUNS_PER_CU = 0 was an
+// integer division by zero in launch_istft_wave_R), so they are range-checked HERE, once, for both ways in — the environment and
+// nxsig_ctx_set_tuning — instead of at every use site; the on / off switches take any non-negative value.
+static bool tuning_in_range(int k, long v, long* lo, long* hi) {
+  long a = 0, b = 1L << 30;
+  switch (k) {
+    case kT_ISTFT_RUNS_PER_CU: a = 1; b = 4096; break;         // resident waves per CU the run length is derived from
+    case kT_ISTFT_MIN_RUN: a = 1; b = 1 << 20; break;
+    case kT_WAVE_UNITS_PER_WAVE: a = 1; b = 4096; break;
+    case kT_FIR_UNITS_PER_WAVE: a = 1; b = 4096; break;
+    case kT_MEL_LDS_KB: a = 1; b = 160; break;               // LDS per CU on gfx950
+    case kT_FFT_TILE_ELEMS: a = 1024; b = 16384; break;
+    case kT_FFT_TILE_NT: a = 64; b = 1024; break;
+    case kT_FFT_TILED_MIN: a = 2; break;
+    case kT_STORE_POLICY: a = 0; b = 2; break;
+    default: break;
+  }
+  if (lo) *lo = a;
+  if (hi) *hi = b;
+  return v >= a && v <= b;
+}
+// the library's ONE look at the process environment for its switches: at context creation, never in a launch.  A value that is not
+// a number ("true", "on", "yes" / "false", "off", "no" aside, which mean 1 / 0) or lies outside the switch's range is IGNORED with
+// one line on stderr — never silently read as 0.
 void tuning_from_env(Tuning* t) {
   for (int k = 0; k < kTuneCount; ++k) {
     const char* v = std::getenv(kTuneNames[k]);
-    if (v && *v) { t->v[k] = (int32_t)std::strtol(v, nullptr, 10); t->set[k] = true; }
+    if (!v || !*v) continue;
+    char* end = nullptr;
+    long val = std::strtol(v, &end, 10);
+    while (end && (*end == ' ' || *end == '\t')) ++end;
+    if (end == v || (end && *end)) {
+      if (!strcasecmp(v, "true") || !strcasecmp(v, "on") || !strcasecmp(v, "yes")) val = 1;
+      else if (!strcasecmp(v, "false") || !strcasecmp(v, "off") || !strcasecmp(v, "no")) val = 0;
+      else { std::fprintf(stderr, "nxsig: %s=%s is not a number: ignored\n", kTuneNames[k], v); continue; }
+    }
+    long lo, hi;
+    if (!tuning_in_range(k, val, &lo, &hi)) {
+      std::fprintf(stderr, "nxsig: %s=%ld is outside [%ld, %ld]: ignored\n", kTuneNames[k], val, lo, hi);
+      continue;
+    }
+    t->v[k] = (int32_t)val; t->set[k] = true;
   }
 }
+bool tuning_value_ok(int key, long value, long* lo, long* hi) { return tuning_in_range(key, value, lo, hi); }
 }  // namespace nxsig
 
 static int check_mem(int32_t mem) {
@@ -406,6 +446,9 @@ int nxsig_ctx_set_tuning(nxsig_ctx* ctx, const char* name, int32_t value) {
   NXSIG_CHECK_CTX(ctx)
   const int k = tuning_index(name);
   if (k < 0) return set_error(NXSIG_ERR_INVALID_ARG, std::string("no such switch: ") + (name ? name : "(null)"));
+  long lo, hi;
+  if (!tuning_value_ok(k, value, &lo, &hi))
+    return set_error(NXSIG_ERR_INVALID_ARG, std::string(tuning_name(k)) + " must lie in [" + std::to_string(lo) + ", " + std::to_string(hi) + "]");
   c->tuning.v[k] = value;   // (NXSIG_CHECK_CTX holds the context's mutex)
   c->tuning.set[k] = true;
   if (k == kT_POOL_MAX_MB) c->pool_cap = 0;  // decided again at the next nxsig_free

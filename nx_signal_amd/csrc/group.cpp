@@ -523,7 +523,67 @@ static int shard_stride(int64_t batch_stride, int64_t rows, int64_t in_len, int6
   return NXSIG_OK;
 }
 
+// Assembly of frame / sample shards of a MULTI-ROW tensor (the reference's vectorised axes, lib/nx_signal.ex:358-363): member r holds
+// its dense shard [rows][out_len_r] items; row b of it belongs at (b * out_items_total + out0_r) items of the full tensor on every
+// member.  With RCCL: one ncclBroadcast per (rank, row) — root reads its dense shard, everybody (root included) receives in place —
+// fused into group launches of at most ~1024 operations.  Without (members of one process sharing devices): one strided 2-D copy per
+// (receiver, owner).  shard[i] = local member i's dense shard, full[i] = its full-size buffer.
+static int assemble_rows_locked(Group* g, const Plan& pl, const void* const* shard, void* const* full) {
+  const int W = g->world;
+  const int64_t rows = pl.rows_total, row_bytes = pl.out_items_total * pl.item_bytes;
+  for (size_t i = 0; i < g->m.size(); ++i) {
+    const Part& q = pl.part[g->m[i].rank];
+    if (!full[i] || (!shard[i] && q.rows > 0 && q.out_len > 0)) return set_error(NXSIG_ERR_INVALID_ARG, "sharded assembly: null buffer");
+  }
+  if (g->has_rccl) {
+    Rccl* R = rccl();
+    int64_t per_group = 1024 / (W > 0 ? W : 1);
+    if (per_group < 1) per_group = 1;
+    for (int64_t b0 = 0; b0 < rows; b0 += per_group) {
+      const int64_t b1 = b0 + per_group < rows ? b0 + per_group : rows;
+      NcclBracket br(R);
+      NXSIG_NCCL_TRY(R, br.start());
+      for (size_t i = 0; i < g->m.size(); ++i) {
+        Member& mb = g->m[i];
+        NXSIG_HIP_TRY(hipSetDevice(mb.device));
+        char* fb = static_cast<char*>(full[i]);
+        for (int r = 0; r < W; ++r) {
+          const Part& q = pl.part[r];
+          const int64_t seg = q.out_len * pl.item_bytes;
+          if (seg == 0 || q.rows == 0) continue;
+          for (int64_t b = b0; b < b1; ++b) {
+            char* dst = fb + b * row_bytes + q.out0 * pl.item_bytes;
+            const void* src = r == mb.rank ? static_cast<const void*>(static_cast<const char*>(shard[i]) + b * seg) : static_cast<const void*>(dst);
+            NXSIG_NCCL_TRY(R, R->Broadcast(src, dst, (size_t)seg, ncclChar, r, mb.comm, stream_of(mb)));
+          }
+        }
+      }
+      NXSIG_NCCL_TRY(R, br.end());
+    }
+    return NXSIG_OK;
+  }
+  if (g->ranked && g->world > 1) return set_error(NXSIG_ERR_UNSUPPORTED, "sharded assembly: a ranked group without RCCL cannot assemble");
+  int rc;
+  for (auto& mb : g->m)
+    if ((rc = nxsig_sync(mb.ctx))) return rc;
+  for (size_t i = 0; i < g->m.size(); ++i) {
+    NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
+    char* fb = static_cast<char*>(full[i]);
+    for (size_t j = 0; j < g->m.size(); ++j) {
+      const Part& q = pl.part[g->m[j].rank];
+      const int64_t seg = q.out_len * pl.item_bytes;
+      if (seg == 0 || q.rows == 0) continue;
+      NXSIG_HIP_TRY(hipMemcpy2DAsync(fb + q.out0 * pl.item_bytes, (size_t)row_bytes, shard[j], (size_t)seg, (size_t)seg, (size_t)rows,
+                                     hipMemcpyDeviceToDevice, stream_of(g->m[i])));
+    }
+  }
+  return NXSIG_OK;
+}
+
 // runs `compute(member, part, x_dev, out_dev)` for every local member; host mode stages through per-member device buffers.
+// `exchange(dst, local_rc)` joins a COLLECTIVE: in device mode (the form ranked multi-process groups use) it is entered even when a
+// local compute failed — the failure rides along as a status word, so that no rank is left waiting in the all-reduce — and every rank
+// returns the error afterwards.
 // `exchange(dst)` — optional — runs once every local member's compute is issued and before anything is assembled or downloaded:
 // the place of a call's exchange step (sample-sharded FIR: the members agree on which rows hold a non-finite sample); dst[i] is
 // member i's shard (nullptr when the member has none).
@@ -533,28 +593,53 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
   constexpr bool kExchange = !std::is_same<Exchange, std::nullptr_t>::value;
   const size_t nl = g->m.size();
   const bool by_rows = axis == NXSIG_SHARD_CHANNELS;
-  if (!by_rows && gather && pl.rows_total != 1 && mem == NXSIG_DEVICE)
-    return set_error(NXSIG_ERR_UNSUPPORTED, "sharded: in-place assembly of frame / sample shards needs batch == 1");
+  const bool by_row_segments = !by_rows && gather && pl.rows_total != 1;   // assembled frame / sample shards of a multi-row tensor
   int rc;
   if (mem == NXSIG_DEVICE) {
     std::vector<const void*> send(nl);
+    std::vector<void*> tmp(nl, nullptr);   // by_row_segments: the member's dense shard (the full buffer takes it row by row)
+    auto drop_tmp = [&]() {
+      std::string keep = nxsig_last_error();
+      for (size_t i = 0; i < nl; ++i)
+        if (tmp[i]) { (void)nxsig_sync(g->m[i].ctx); (void)nxsig_free(g->m[i].ctx, tmp[i]); }
+      (void)set_error(NXSIG_OK, keep);
+    };
+    int local_rc = NXSIG_OK;
+    std::string local_msg;
+    auto note = [&](int code) { if (code && !local_rc) { local_rc = code; local_msg = nxsig_last_error(); } };
     for (size_t i = 0; i < nl; ++i) {
       const Part& p = pl.part[g->m[i].rank];
-      if (!out[i] || (!x[i] && p.rows > 0 && p.out_len > 0)) return set_error(NXSIG_ERR_INVALID_ARG, "sharded: null shard pointer");
+      send[i] = nullptr;
+      if (!out[i] || (!x[i] && p.rows > 0 && p.out_len > 0)) { note(set_error(NXSIG_ERR_INVALID_ARG, "sharded: null shard pointer")); continue; }
       char* dst = static_cast<char*>(out[i]);
-      if (gather) dst += by_rows ? p.row0 * pl.out_items_total * pl.item_bytes : p.out0 * pl.item_bytes;
+      if (by_row_segments) {
+        if (pl.count[g->m[i].rank] > 0) {
+          if ((rc = nxsig_alloc(g->m[i].ctx, (size_t)pl.count[g->m[i].rank], &tmp[i]))) { note(rc); continue; }
+        }
+        dst = static_cast<char*>(tmp[i]);
+      } else if (gather) dst += by_rows ? p.row0 * pl.out_items_total * pl.item_bytes : p.out0 * pl.item_bytes;
       send[i] = dst;
       // every member's device shard has its OWN row length (frame / sample shards: its span of the rows)
       int64_t stride = 0;
-      if ((rc = shard_stride(batch_stride, p.rows, p.in_len, &stride))) return rc;
-      if (p.rows > 0 && p.out_len > 0 && (rc = compute(g->m[i], p, static_cast<const float*>(x[i]), stride, dst))) return rc;
+      if ((rc = shard_stride(batch_stride, p.rows, p.in_len, &stride))) { note(rc); continue; }
+      if (p.rows > 0 && p.out_len > 0 && (rc = compute(g->m[i], p, static_cast<const float*>(x[i]), stride, dst))) note(rc);
     }
     if constexpr (kExchange) {
       std::vector<void*> dsts(nl);
-      for (size_t i = 0; i < nl; ++i) dsts[i] = const_cast<void*>(send[i]);
-      if ((rc = exchange(dsts))) return rc;
-    }
+      for (size_t i = 0; i < nl; ++i) {
+        const Part& p = pl.part[g->m[i].rank];
+        dsts[i] = (p.rows > 0 && p.out_len > 0) ? const_cast<void*>(send[i]) : nullptr;   // an empty part has nothing to read off or poison
+      }
+      rc = exchange(dsts, local_rc);
+      if (local_rc) { drop_tmp(); return set_error(local_rc, local_msg); }
+      if (rc) { drop_tmp(); return rc; }
+    } else if (local_rc) { drop_tmp(); return set_error(local_rc, local_msg); }
     if (!gather) return NXSIG_OK;
+    if (by_row_segments) {
+      rc = assemble_rows_locked(g, pl, send.data(), out);
+      drop_tmp();   // waits for the member's stream before the dense shard goes back
+      return rc;
+    }
     return allgather_locked(g, send.data(), pl.count.data(), out);
   }
   // ---- host tensors: LOCAL groups only (one process sees the whole tensor); one thread per member keeps every GPU busy
@@ -563,7 +648,7 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
   const float* xh = static_cast<const float*>(x[0]);
   char* oh = static_cast<char*>(out[0]);
   const int64_t full_bytes = pl.rows_total * pl.out_items_total * pl.item_bytes;
-  std::vector<void*> din(nl, nullptr), dout(nl, nullptr);
+  std::vector<void*> din(nl, nullptr), dout(nl, nullptr), dtmp(nl, nullptr);
   std::vector<const void*> send(nl, nullptr);
   std::vector<int> rcs(nl, 0);
   std::vector<std::string> msgs(nl);
@@ -571,6 +656,7 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
     for (size_t i = 0; i < nl; ++i) {
       if (din[i]) (void)nxsig_free(g->m[i].ctx, din[i]);
       if (dout[i]) (void)nxsig_free(g->m[i].ctx, dout[i]);
+      if (dtmp[i]) (void)nxsig_free(g->m[i].ctx, dtmp[i]);
     }
   };
   auto work = [&](size_t i) {
@@ -581,7 +667,10 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
     const int64_t shard_bytes = pl.count[mb.rank];
     if ((r = nxsig_alloc(mb.ctx, (size_t)(gather ? full_bytes : shard_bytes), &dout[i]))) return fail(r);
     char* dst = static_cast<char*>(dout[i]);
-    if (gather) dst += by_rows ? p.row0 * pl.out_items_total * pl.item_bytes : p.out0 * pl.item_bytes;
+    if (by_row_segments) {   // the dense shard; the full buffer receives it row by row (assemble_rows_locked)
+      if (shard_bytes > 0 && (r = nxsig_alloc(mb.ctx, (size_t)shard_bytes, &dtmp[i]))) return fail(r);
+      dst = static_cast<char*>(dtmp[i]);
+    } else if (gather) dst += by_rows ? p.row0 * pl.out_items_total * pl.item_bytes : p.out0 * pl.item_bytes;
     send[i] = dst;
     if (p.rows == 0 || p.out_len == 0) return;
     if ((r = nxsig_alloc(mb.ctx, (size_t)(p.rows * p.in_len) * sizeof(float), &din[i]))) return fail(r);
@@ -626,7 +715,7 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
         const Part& p = pl.part[g->m[i].rank];
         dsts[i] = (p.rows > 0 && p.out_len > 0) ? const_cast<void*>(send[i]) : nullptr;
       }
-      if ((rc = exchange(dsts))) { std::string keep = nxsig_last_error(); cleanup(); return set_error(rc, keep); }
+      if ((rc = exchange(dsts, NXSIG_OK))) { std::string keep = nxsig_last_error(); cleanup(); return set_error(rc, keep); }
     }
     on_every_member(fetch);
   } else {
@@ -634,8 +723,7 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
   }
   if ((rc = first_failure())) return rc;
   if (gather) {
-    if (!by_rows && pl.rows_total != 1) { cleanup(); return set_error(NXSIG_ERR_UNSUPPORTED, "sharded: assembly of frame / sample shards needs batch == 1"); }
-    rc = allgather_locked(g, send.data(), pl.count.data(), dout.data());
+    rc = by_row_segments ? assemble_rows_locked(g, pl, send.data(), dout.data()) : allgather_locked(g, send.data(), pl.count.data(), dout.data());
     if (!rc) rc = nxsig_download(g->m[0].ctx, oh, dout[0], (size_t)full_bytes);  // synchronises member 0's stream
     for (size_t i = 1; i < nl && !rc; ++i) rc = nxsig_sync(g->m[i].ctx);
   }
@@ -788,9 +876,21 @@ int nxsig_fir_sharded_f32(nxsig_group* grp, const float* const* x, int64_t lengt
   // poisons the rows any member flagged.  With it the sharded call equals the unsharded one for non-finite rows too.
   if (g->ranked && g->world > 1 && !g->has_rccl)
     return set_error(NXSIG_ERR_UNSUPPORTED, "fir_sharded: a ranked group without RCCL cannot agree on the non-finite rows of sample shards");
-  auto exchange = [&](const std::vector<void*>& dst) -> int {
+  // flags[0 .. batch) = "row poisoned", flags[batch] = status word: a member whose compute failed contributes 1, so that every rank
+  // joins the all-reduce (nobody is left waiting in it) and every rank learns that the call failed somewhere.  Whatever happens, the
+  // flags are zero again when the exchange returns (stream-ordered memset): they live in the context's scratch and the next FIR call
+  // of any kind reads them.
+  auto exchange = [&](const std::vector<void*>& dst, int local_rc) -> int {
     const size_t nl = g->m.size();
     std::vector<int*> flags(nl, nullptr);
+    struct Clear {
+      Group* g; std::vector<int*>* flags; int32_t n;
+      ~Clear() {
+        for (size_t i = 0; i < flags->size(); ++i)
+          if ((*flags)[i] && hipSetDevice(g->m[i].device) == hipSuccess)
+            (void)hipMemsetAsync((*flags)[i], 0, (size_t)n * sizeof(int), stream_of(g->m[i]));
+      }
+    } clear{g, &flags, batch + 1};
     int rc2;
     for (size_t i = 0; i < nl; ++i) {
       Member& mb = g->m[i];
@@ -798,8 +898,13 @@ int nxsig_fir_sharded_f32(nxsig_group* grp, const float* const* x, int64_t lengt
       const Part& q = pl.part[mb.rank];
       std::lock_guard<std::mutex> cl(c->mu);
       NXSIG_HIP_TRY(hipSetDevice(mb.device));
-      if ((rc2 = fir_row_flags(c, batch, &flags[i]))) return rc2;
-      if (dst[i] && (rc2 = launch_fir_flags_from_output(c, static_cast<const float*>(dst[i]), batch, q.out_len, flags[i]))) return rc2;
+      if ((rc2 = fir_row_flags(c, batch + 1, &flags[i]))) return rc2;
+      if (local_rc) {   // this process failed somewhere: its slices say nothing; only the status word matters
+        const int one = 1;
+        NXSIG_HIP_TRY(hipMemsetAsync(flags[i], 0, (size_t)(batch + 1) * sizeof(int), c->stream));
+        NXSIG_HIP_TRY(hipMemcpyAsync(flags[i] + batch, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        NXSIG_HIP_TRY(hipStreamSynchronize(c->stream));   // `one` lives on this stack frame
+      } else if (dst[i] && (rc2 = launch_fir_flags_from_output(c, static_cast<const float*>(dst[i]), batch, q.out_len, flags[i]))) return rc2;
     }
     if (g->has_rccl) {
       Rccl* R = rccl();
@@ -807,16 +912,16 @@ int nxsig_fir_sharded_f32(nxsig_group* grp, const float* const* x, int64_t lengt
       NXSIG_NCCL_TRY(R, br.start());
       for (size_t i = 0; i < nl; ++i) {
         NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
-        NXSIG_NCCL_TRY(R, R->AllReduce(flags[i], flags[i], (size_t)batch, ncclInt32, ncclMax, g->m[i].comm, stream_of(g->m[i])));
+        NXSIG_NCCL_TRY(R, R->AllReduce(flags[i], flags[i], (size_t)batch + 1, ncclInt32, ncclMax, g->m[i].comm, stream_of(g->m[i])));
       }
       NXSIG_NCCL_TRY(R, br.end());
     } else if (nl > 1) {  // members of one process sharing devices (no communicators): through the host
-      std::vector<int> best((size_t)batch, 0), v((size_t)batch);
+      std::vector<int> best((size_t)batch + 1, 0), v((size_t)batch + 1);
       for (size_t i = 0; i < nl; ++i) {
         NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
         NXSIG_HIP_TRY(hipMemcpyAsync(v.data(), flags[i], v.size() * sizeof(int), hipMemcpyDeviceToHost, stream_of(g->m[i])));
         NXSIG_HIP_TRY(hipStreamSynchronize(stream_of(g->m[i])));
-        for (int32_t r = 0; r < batch; ++r) best[r] = v[r] > best[r] ? v[r] : best[r];
+        for (int32_t r = 0; r <= batch; ++r) best[r] = v[r] > best[r] ? v[r] : best[r];
       }
       for (size_t i = 0; i < nl; ++i) {
         NXSIG_HIP_TRY(hipSetDevice(g->m[i].device));
@@ -824,7 +929,14 @@ int nxsig_fir_sharded_f32(nxsig_group* grp, const float* const* x, int64_t lengt
         NXSIG_HIP_TRY(hipStreamSynchronize(stream_of(g->m[i])));   // `best` lives on this stack frame
       }
     }
-    for (size_t i = 0; i < nl; ++i) {   // rows flagged anywhere: NaN on every member (the pass clears the flags it consumes)
+    int failed_somewhere = 0;
+    {
+      NXSIG_HIP_TRY(hipSetDevice(g->m[0].device));
+      NXSIG_HIP_TRY(hipMemcpyAsync(&failed_somewhere, flags[0] + batch, sizeof(int), hipMemcpyDeviceToHost, stream_of(g->m[0])));
+      NXSIG_HIP_TRY(hipStreamSynchronize(stream_of(g->m[0])));
+    }
+    if (failed_somewhere) return set_error(NXSIG_ERR_INVALID_ARG, "fir_sharded: the call failed on another member of the group");
+    for (size_t i = 0; i < nl; ++i) {   // rows flagged anywhere: NaN on every member; `clear` zeroes the flags behind the pass
       Member& mb = g->m[i];
       Ctx* c = reinterpret_cast<Ctx*>(mb.ctx);
       const Part& q = pl.part[mb.rank];
@@ -832,8 +944,7 @@ int nxsig_fir_sharded_f32(nxsig_group* grp, const float* const* x, int64_t lengt
       NXSIG_HIP_TRY(hipSetDevice(mb.device));
       FirLaunch f{};
       f.batch = batch; f.out_len = dst[i] ? q.out_len : 0; f.y = static_cast<float*>(dst[i]); f.row_flags = flags[i];
-      if (dst[i]) { if ((rc2 = launch_fir_poison(c, f))) return rc2; }
-      else NXSIG_HIP_TRY(hipMemsetAsync(flags[i], 0, (size_t)batch * sizeof(int), c->stream));   // nothing to poison here: just consume
+      if (dst[i] && (rc2 = launch_fir_poison(c, f))) return rc2;
     }
     return NXSIG_OK;
   };

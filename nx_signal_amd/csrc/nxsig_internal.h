@@ -85,6 +85,7 @@ struct Tuning {
   bool set[kTuneCount] = {};
 };
 void tuning_from_env(Tuning* t);       // api.cpp
+bool tuning_value_ok(int key, long value, long* lo, long* hi);   // the admissible range of a switch (api.cpp)
 int tuning_index(const char* name);    // "NXSIG_FOO" or "FOO" -> TuneKey, -1 when there is no such switch
 const char* tuning_name(int key);      // "NXSIG_FOO"
 

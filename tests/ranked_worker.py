@@ -63,6 +63,12 @@ def main():
     lo, hi = m0 + (m0 & 1), m1 - ((m1 - m0 - (m0 & 1)) & 1)  # own frames whose frame PAIR (2j, 2j + 1) lies inside the shard
     if m0 % 2 == 0 and hi > lo:                                 # ... ride the same transform as in the unsharded launch: bit-identical
         assert np.array_equal(got[lo:hi].view(np.uint32), full[0][lo:hi].view(np.uint32))
+    # frame shards of a MULTI-ROW tensor, assembled on every rank: one ncclBroadcast per (rank, row)
+    xs3 = np.ascontiguousarray(x[:3, s0:s1])
+    outs = sharding.stft_sharded(g, [ctx.to_device(xs3)], w, axis="frames", gather=True, length=L, batch=3, **opts)
+    ctx.sync()
+    got3 = outs[0].numpy()
+    assert got3.shape == full[:3].shape and float(np.max(np.abs(got3 - full[:3])) / np.max(np.abs(full[:3]))) < 1e-6, "multi-row frame shards + RCCL assembly"
     # the sharded log-mel: rank 0's channels are quiet, so its clamp floor must come from the OTHER rank's maximum (ncclAllReduce max)
     xq = x.copy()
     xq[: sharding.shard_channels(B, world, 0)[1]] = x[: sharding.shard_channels(B, world, 0)[1]] * np.float32(1e-3)
@@ -84,6 +90,10 @@ def main():
     assert part.shape == (2, n1 - n0)
     assert not np.isfinite(part[1]).any(), "sample shards: the non-finite row is NaN on every rank"
     assert float(np.max(np.abs(part[0] - yfull[0, n0:n1])) / np.max(np.abs(yfull[0]))) < 1e-6, "sample shards: the clean row"
+    # the same call assembled: every rank ends up with both whole rows (row 1 NaN from end to end)
+    whole = sharding.fir_sharded(g, [ctx.to_device(np.ascontiguousarray(xf[:, s0:s1]))], h, mode="same", axis="samples", gather=True, length=L, batch=2)[0].numpy()
+    assert whole.shape == yfull.shape and not np.isfinite(whole[1]).any(), "assembled sample shards: the non-finite row"
+    assert float(np.max(np.abs(whole[0] - yfull[0])) / np.max(np.abs(yfull[0]))) < 1e-6, "assembled sample shards: the clean row"
     g.barrier()
     print(f"RANKED-OK rank {rank} of {world}", file=sys.stderr, flush=True)
     g.close()

@@ -139,3 +139,38 @@ def test_flipping_a_switch_in_process_keeps_parity(name, values):
         assert np.max(np.abs(y - yo)) / np.max(np.abs(yo)) < 1e-5, (name, v)
         if f is not None:
             assert np.max(np.abs(f - fo)) / np.max(np.abs(fo)) < 1e-5, (name, v)
+
+
+def test_switch_values_are_range_checked_both_ways_in():
+    """ISTFT_RUNS_PER_CU = 0 reached an integer division by zero in the iSTFT launchers, and a non-numeric environment value
+    was silently read as 0.  Both ways in are validated now: nxsig_ctx_set_tuning refuses an out-of-range value, the environment parser
+    ignores it (and says so on stderr); "true" / "off" mean 1 / 0."""
+    import numpy as np
+
+    import nx_signal_amd as S
+    from nx_signal_amd import _lib
+    from oracle import nx_oracle as O
+
+    ctx = S.Context(0)
+    for name, bad in (("NXSIG_ISTFT_RUNS_PER_CU", 0), ("NXSIG_ISTFT_RUNS_PER_CU", -3), ("NXSIG_ISTFT_MIN_RUN", 0), ("NXSIG_WAVE_UNITS_PER_WAVE", 0),
+                      ("NXSIG_FIR_UNITS_PER_WAVE", -1), ("NXSIG_STORE_POLICY", 7), ("NXSIG_MEL_LDS_KB", 0), ("NXSIG_DISABLE_WAVE", -1)):
+        with pytest.raises(_lib.ArgumentError):
+            ctx.set_tuning(name, bad)
+        assert ctx.get_tuning(name)[1] is False
+    code = (
+        "import numpy as np, nx_signal_amd as S\n"
+        "from oracle import nx_oracle as O\n"
+        "c = S.Context(0)\n"
+        "print('T', c.get_tuning('ISTFT_RUNS_PER_CU'), c.get_tuning('ISTFT_MIN_RUN'), c.get_tuning('DISABLE_WAVE'), c.get_tuning('FIR_HREG'), c.get_tuning('ISTFT_DEEP'))\n"
+        "x = np.random.default_rng(5).standard_normal(40000).astype(np.float32); w = S.windows.hann(1024)\n"
+        "o = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)\n"
+        "zo = O.stft(x, w, **o)[0]; y = S.istft(c.to_device(zo), w, ctx=c, **o).numpy(); yo = O.istft(zo, w, **o)\n"
+        "print('E', float(np.max(np.abs(y - yo)) / np.max(np.abs(yo))))\n"
+    )
+    env = dict(os.environ, NXSIG_ISTFT_RUNS_PER_CU="0", NXSIG_ISTFT_MIN_RUN="banana", NXSIG_DISABLE_WAVE="true", NXSIG_FIR_HREG="off", NXSIG_ISTFT_DEEP=" 0 ",
+               PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "T (0, False) (0, False) (1, True) (0, True) (0, True)" in r.stdout, r.stdout
+    assert "NXSIG_ISTFT_RUNS_PER_CU=0 is outside" in r.stderr and "NXSIG_ISTFT_MIN_RUN=banana is not a number" in r.stderr
+    assert float(re.search(r"E ([0-9.e+-]+)", r.stdout).group(1)) < 1e-5

@@ -79,6 +79,55 @@ def test_stft_frame_shards(pair, gather, L, N, hop):
     assert float(np.max(np.abs(got - zo)) / np.max(np.abs(zo))) < 1e-5
 
 
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("mem", ["host", "device"])
+def test_assembled_frame_and_sample_shards_of_a_multi_row_tensor(world, mem):
+    """`gather=True` on frame / sample shards was refused unless batch == 1.  The reference's vectorised axes have
+    no such limit (lib/nx_signal.ex:358-363): batch = 3 rows, every member ends up with the WHOLE [3, M, K] spectrum / [3, L] signal —
+    rank r's dense shard goes to its place row by row (one broadcast per (rank, row) with RCCL, one strided copy per pair without)."""
+    g = sharding.Group.local(world, devices=[0] * world)
+    try:
+        B, N, hop = 3, 1024, 256
+        L = N + hop * 203 + 17                     # 204 frames: 25.5 per member at world 8 — unequal spans
+        x = np.stack([O.synth_signal(L, seed=300 + c) for c in range(B)])
+        w = S.windows.hann(N)
+        opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+        full, _, _ = S.stft(x, w, **opts)
+        M = full.shape[1]
+        h = S.filters.firwin(257, [4000.0], sampling_rate=48000)
+        yfull = np.asarray(S.filters.fir(x, h, mode="same"))
+        zi = O.stft(x[0], w, **opts)[0]
+        zin = np.stack([zi, zi[::-1].copy(), (zi * np.complex64(0.5 + 0.25j)).astype(np.complex64)])   # non-Hermitian rows too
+        ifull = np.asarray(S.istft(zin, w, **opts))
+        if mem == "host":
+            got = sharding.stft_sharded(g, x, w, axis="frames", gather=True, **opts)
+            yg = sharding.fir_sharded(g, x, h, mode="same", axis="samples", gather=True)
+            ig = sharding.istft_sharded(g, zin, w, axis="frames", gather=True, **opts)
+            assert got.shape == full.shape and float(np.max(np.abs(got - full)) / np.max(np.abs(full))) < 1e-6
+            assert yg.shape == yfull.shape and float(np.max(np.abs(yg - yfull)) / np.max(np.abs(yfull))) < 1e-6
+            assert np.array_equal(bits(ig), bits(ifull))
+        else:
+            xs, hs, zs = [], [], []
+            for i, r in enumerate(g.ranks):
+                m0, m1, s0, s1 = sharding.shard_frames(M, N, hop, world, r)
+                xs.append(g.contexts[i].to_device(np.ascontiguousarray(x[:, s0:s1])))
+                n0, n1, t0, t1 = sharding.shard_fir(L, 257, world, r, "same")
+                hs.append(g.contexts[i].to_device(np.ascontiguousarray(x[:, t0:t1])))
+                f0, f1, _, _ = sharding.shard_istft(M, N, hop, world, r)
+                zs.append(g.contexts[i].to_device(np.ascontiguousarray(zin[:, f0:f1])))
+            outs = sharding.stft_sharded(g, xs, w, axis="frames", gather=True, length=L, batch=B, **opts)
+            youts = sharding.fir_sharded(g, hs, h, mode="same", axis="samples", gather=True, length=L, batch=B)
+            iouts = sharding.istft_sharded(g, zs, w, axis="frames", gather=True, num_frames=M, batch=B, **opts)
+            for i in range(world):                 # EVERY member holds the whole tensor
+                got = outs[i].numpy()
+                assert got.shape == full.shape and float(np.max(np.abs(got - full)) / np.max(np.abs(full))) < 1e-6, i
+                yg = youts[i].numpy()
+                assert yg.shape == yfull.shape and float(np.max(np.abs(yg - yfull)) / np.max(np.abs(yfull))) < 1e-6, i
+                assert np.array_equal(bits(iouts[i].numpy()), bits(ifull)), i
+    finally:
+        g.close()
+
+
 def test_stft_device_shards_stay_on_their_device(pair):
     """DEVICE mode: every member is handed its input shard in HBM and keeps its output shard there (no host round trip)"""
     B, L, N, hop = 4, 20000, 512, 128

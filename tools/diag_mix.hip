@@ -214,6 +214,42 @@ __global__ __launch_bounds__(256) void k_stft2048_mix(const float* __restrict__ 
   }
 }
 
+// ---- plain yardsticks: bandwidth figures that owe NOTHING to the geometry of a product kernel — grid-stride loops over
+// 1 KiB wave rows (64 lanes x 16 bytes), default cache policy, no tables, no descriptors.  bench.py times them in its own process on its
+// own buffers (`yardsticks` in the JSON line) so that "a 4 : 1 read / write stream tops out at 0.6x" is a measurement of the box and not
+// an argument made with the iSTFT's own traffic model.
+//   k_y_copy : float4 copy (the guide's 6.29 TB/s figure)      k_y_read : loads only        k_y_fill : stores only
+//   k_y_mix<RD, WR> : per step a wave reads RD KiB and writes WR KiB (4 : 1 = the iSTFT's ratio, 1 : 8 = the STFT's, 1 : 1 = the FIR's)
+__global__ __launch_bounds__(256) void k_y_copy(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void k_y_fill(v4f* __restrict__ out, size_t n, float v) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = v4f{v, v + 1.f, v + 2.f, v + 3.f};
+}
+__global__ __launch_bounds__(256) void k_y_read(const v4f* __restrict__ in, v4f* __restrict__ out, size_t n) {
+  v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += in[i];
+  if (acc.x == 12345.678f) out[threadIdx.x] = acc;   // never taken: keeps the loads alive
+}
+// SPW = 0: grid-stride (long-lived workgroups); SPW > 0: short-lived workgroups in dispatch order, SPW consecutive steps per wave
+template <int RD, int WR>
+__global__ __launch_bounds__(256) void k_y_mix(const v4f* __restrict__ in, v4f* __restrict__ out, size_t steps, int spw) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((size_t)gridDim.x * 256) >> 6;
+  size_t c0 = wave, c1 = steps, inc = nw;
+  if (spw > 0) { c0 = wave * (size_t)spw; c1 = c0 + spw < steps ? c0 + spw : steps; inc = 1; }
+  for (size_t c = c0; c < c1; c += inc) {
+    const v4f* p = in + c * (64 * RD) + lane;
+    v4f acc = RD > 0 ? p[0] : v4f{1.f, 2.f, 3.f, (float)lane};
+#pragma unroll
+    for (int j = 1; j < RD; ++j) acc += p[64 * j];
+    v4f* o = out + c * (64 * (WR > 0 ? WR : 1)) + lane;
+    if (WR == 0) { if (acc.x == 12345.678f) o[0] = acc; }   // read-only: never taken, keeps the loads alive
+#pragma unroll
+    for (int j = 0; j < WR; ++j) o[64 * j] = acc + (float)j;
+  }
+}
+
 extern "C" {
 // x: f32[rows][L], z: c64[rows][M][2048] with M = (L - 2048) / hop + 1
 int nxdiag_stft2048_mix(void* stream, const void* x, void* z, const void* tab, long rows, long L, int hop, int units_per_wave) {
@@ -290,4 +326,31 @@ int nxdiag_fir_mix2(void* stream, const void* x, void* y, long rows, long L, int
   return (int)hipGetLastError();
 }
 int nxdiag_fir_mix(void* stream, const void* x, void* y, long rows, long L, int pairs_per_wave) { return nxdiag_fir_mix2(stream, x, y, rows, L, pairs_per_wave, 0); }
+// ---- plain yardsticks: sizes in BYTES of the written side (copy / fill / mix) or of the read side (read); `grid` workgroups of 256
+int nxdiag_y_copy(void* stream, const void* in, void* out, size_t bytes, int grid) {
+  hipLaunchKernelGGL(k_y_copy, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v4f*)in, (v4f*)out, bytes / 16);
+  return (int)hipGetLastError();
+}
+int nxdiag_y_fill(void* stream, void* out, size_t bytes, int grid) {
+  hipLaunchKernelGGL(k_y_fill, dim3(grid), dim3(256), 0, (hipStream_t)stream, (v4f*)out, bytes / 16, 1.0f);
+  return (int)hipGetLastError();
+}
+int nxdiag_y_read(void* stream, const void* in, void* out, size_t bytes, int grid) {
+  hipLaunchKernelGGL(k_y_read, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v4f*)in, (v4f*)out, bytes / 16);
+  return (int)hipGetLastError();
+}
+// rd : wr in {4:1, 1:8, 1:1, 2:1}; `steps` wave steps, each reads rd KiB from `in` and writes wr KiB to `out`
+// grid > 0: grid-stride over `grid` workgroups; grid < 0: short-lived workgroups, -grid consecutive steps per wave (4 waves per workgroup)
+int nxdiag_y_mix(void* stream, const void* in, void* out, size_t steps, int rd, int wr, int grid) {
+  int spw = 0;
+  if (grid < 0) { spw = -grid; grid = (int)((steps + 4 * (size_t)spw - 1) / (4 * (size_t)spw)); }
+#define YM(R_, W_) if (rd == R_ && wr == W_) { hipLaunchKernelGGL((k_y_mix<R_, W_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const v4f*)in, (v4f*)out, steps, spw); return (int)hipGetLastError(); }
+  YM(4, 1) YM(1, 8) YM(1, 1) YM(2, 1) YM(8, 2) YM(2, 16) YM(4, 0) YM(0, 4) YM(4, 4)
+#undef YM
+  return 2;
+}
+// hipMemcpyDtoDAsync on the same stream (the runtime's own copy path: blit kernel or SDMA, whatever it picks)
+int nxdiag_y_memcpy(void* stream, const void* in, void* out, size_t bytes) {
+  return (int)hipMemcpyDtoDAsync((hipDeviceptr_t)out, (hipDeviceptr_t)in, bytes, (hipStream_t)stream);
+}
 }

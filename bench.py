@@ -842,8 +842,10 @@ def main():
         # frames of a row (the last pair of a row is ragged: M is odd), both sides of workgroup seams (a workgroup takes 8 frame pairs
         # = 16 frames, a wave 2 pairs), both sides of the row seam, and seeded random picks in every remaining stream
         picks = []
-        for b in sorted({0, 1, B // 2, B - 2, B - 1} & set(range(B))):
+        for b in sorted({0, B - 1}):
             picks += [(b, m) for m in (0, 1, 3, 4, 15, 16, 17, M // 2 - 1, M // 2, M - 17, M - 16, M - 3, M - 2, M - 1) if 0 <= m < M]
+        for b in sorted({1, B // 2, B - 2} & set(range(B)) - {0, B - 1}):
+            picks += [(b, m) for m in (0, 16, M // 2, M - 16, M - 2, M - 1) if 0 <= m < M]
         prng = np.random.Generator(np.random.PCG64(77))
         rest = [b for b in range(B) if b not in {p[0] for p in picks}]
         while len(picks) < 64 and rest:

@@ -42,12 +42,22 @@ defmodule NxSignalAMD do
   """
   def stft(data, window, opts \\ [])
 
-  def stft(%DeviceTensor{type: {:f, 32}} = data, window, opts) do
+  # f32 samples, or c64 samples (IQ data): the reference frames, multiplies and transforms whatever tensor it is given
+  # (lib/nx_signal.ex:94-102); complex samples take one transform per frame (nxsig_stft_c64)
+  def stft(%DeviceTensor{type: type} = data, window, opts) when type in [{:f, 32}, {:c, 64}] do
     {params, fft_length} = stft_params!(window, opts)
     {batch_shape, length} = split_last(data.shape)
     batch = Tuple.product(batch_shape)
     w = window |> Nx.as_type(:f32) |> Nx.to_binary()
-    {:ok, zref, m} = NIF.stft_dev(data.ctx, data.ref, length, batch, w, params) |> unwrap!()
+
+    {:ok, zref, m} =
+      if type == {:c, 64} do
+        NIF.stft_c64_dev(data.ctx, data.ref, length, batch, w, params)
+      else
+        NIF.stft_dev(data.ctx, data.ref, length, batch, w, params)
+      end
+      |> unwrap!()
+
     {t, f} = times_and_frequencies(params, m)
 
     z = %DeviceTensor{
@@ -69,13 +79,24 @@ defmodule NxSignalAMD do
     # f64 samples or an f64 window: Nx.multiply promotes and Nx.fft returns c128 (lib/nx_signal.ex:101-102) -> the f64 tier
     wide = Nx.type(data) == {:f, 64} or Nx.type(window) == {:f, 64}
 
+    complex = Nx.type(data) == {:c, 64}
+
     {:ok, z, m, t, f} =
-      if wide do
-        {w, w64} = window_binary(window)
-        NIF.stft_f64(context(), flat |> Nx.as_type(:f64) |> Nx.to_binary(), length, batch, w, w64, params)
-      else
-        x = flat |> Nx.as_type(:f32) |> Nx.to_binary()
-        NIF.stft(context(), x, length, batch, window |> Nx.as_type(:f32) |> Nx.to_binary(), params)
+      cond do
+        complex and Nx.type(window) != {:f, 64} ->
+          # c64 samples (IQ data): one transform per frame, c64 x f32 componentwise (lib/nx_signal.ex:101-102)
+          NIF.stft_c64(context(), Nx.to_binary(flat), length, batch, window |> Nx.as_type(:f32) |> Nx.to_binary(), params)
+
+        Nx.type(data) in [{:c, 64}, {:c, 128}] ->
+          raise ArgumentError, "stft: complex samples are built for c64 data with an f32 window (got #{inspect(Nx.type(data))})"
+
+        wide ->
+          {w, w64} = window_binary(window)
+          NIF.stft_f64(context(), flat |> Nx.as_type(:f64) |> Nx.to_binary(), length, batch, w, w64, params)
+
+        true ->
+          x = flat |> Nx.as_type(:f32) |> Nx.to_binary()
+          NIF.stft(context(), x, length, batch, window |> Nx.as_type(:f32) |> Nx.to_binary(), params)
       end
       |> unwrap!()
 

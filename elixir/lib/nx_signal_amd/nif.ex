@@ -19,6 +19,7 @@ defmodule NxSignalAMD.NIF do
   def mel_filters(_fft_length, _mel_bins, _fs, _max_mel, _spacing), do: :erlang.nif_error(:nif_not_loaded)
   def sinc(_t), do: :erlang.nif_error(:nif_not_loaded)
   def stft(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def stft_c64(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft(_ctx, _z, _frames, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft_filtered(_ctx, _z, _frames, _batch, _window, _params, _h), do: :erlang.nif_error(:nif_not_loaded)
   def fir(_ctx, _x, _length, _batch, _taps, _mode), do: :erlang.nif_error(:nif_not_loaded)
@@ -46,6 +47,7 @@ defmodule NxSignalAMD.NIF do
   def from_device(_buf), do: :erlang.nif_error(:nif_not_loaded)
   def buf_size(_buf), do: :erlang.nif_error(:nif_not_loaded)
   def stft_dev(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def stft_c64_dev(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def stft_onesided_dev(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def stft_packed_dev(_ctx, _x, _length, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft_packed_dev(_ctx, _z, _frames, _batch, _window, _params), do: :erlang.nif_error(:nif_not_loaded)

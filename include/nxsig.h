@@ -164,6 +164,15 @@ int nxsig_stft_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch
                    int32_t mem);
 
 /*
+ * NxSignal.stft/3 of COMPLEX samples (c64 IQ data) — lib/nx_signal.ex:94-102 frames, multiplies (:101, c64 x f32 componentwise) and
+ * transforms (:102, one Nx.fft row per frame: no pair packing) whatever tensor it is given.  Same parameters and outputs as
+ * nxsig_stft_f32 with x c64[batch][length] (interleaved re, im), rows `batch_stride` COMPLEX elements apart.
+ */
+int nxsig_stft_c64(nxsig_ctx* ctx, const nxsig_c64* x, int64_t length, int32_t batch, int64_t batch_stride,
+                   const float* window, const nxsig_stft_params* params, nxsig_c64* z, int64_t* num_frames_out,
+                   int32_t mem);
+
+/*
  * NxSignal.istft/3 — lib/nx_signal.ex:582-638 (Nx.ifft :609, inverse scaling :611-625, x window and
  * overlap_and_add :627-628, OLA(|w|^2) normaliser with the 1e-10 guard :630-637).
  *   z c64[batch][M][K]  ->  y c64[batch][M*hop + N-hop]   (complex output)

@@ -254,8 +254,9 @@ static ERL_NIF_TERM nif_sinc(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]
 }
 
 /* ------------------------------------------------------------------------------------------------ hot path, host tensors */
-/* stft(ctx, x_bin, length, batch, window_bin, params) -> {:ok, z_bin, num_frames, times_bin, freqs_bin} */
-static ERL_NIF_TERM nif_stft(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+/* stft(ctx, x_bin, length, batch, window_bin, params) -> {:ok, z_bin, num_frames, times_bin, freqs_bin}
+ * stft_c64: the same with x_bin holding c64 samples (interleaved f32 re, im) — lib/nx_signal.ex:94-102 on complex data */
+static ERL_NIF_TERM stft_host(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[], size_t elem) {
   ctx_res_t* c;
   ErlNifBinary x, w, zb, tb, fb;
   ErlNifSInt64 length;
@@ -264,12 +265,13 @@ static ERL_NIF_TERM nif_stft(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]
   if (argc != 6 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
       !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p))
     return enif_make_badarg(env);
-  if (batch < 1 || length < 1 || x.size / 4 / (size_t)batch != (size_t)length || x.size % 4 || w.size != (size_t)p.frame_length * 4)
+  if (batch < 1 || length < 1 || x.size / elem / (size_t)batch != (size_t)length || x.size % elem || w.size != (size_t)p.frame_length * 4)
     return enif_make_badarg(env);
   int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
   if (m < 0) return mk_error(env, (int)m);
   if (!out_bin(&zb, (uint64_t)batch, (uint64_t)m, (uint64_t)p.fft_length, 8)) return mk_oom(env);
-  int rc = nxsig_stft_f32(c->ctx, (const float*)x.data, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)zb.data, NULL, NXSIG_HOST);
+  int rc = elem == 8 ? nxsig_stft_c64(c->ctx, (const nxsig_c64*)x.data, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)zb.data, NULL, NXSIG_HOST)
+                     : nxsig_stft_f32(c->ctx, (const float*)x.data, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)zb.data, NULL, NXSIG_HOST);
   if (rc) { enif_release_binary(&zb); return mk_error(env, rc); }
   if (!out_bin(&tb, (uint64_t)m, 1, 1, 4)) { enif_release_binary(&zb); return mk_oom(env); }
   if (!out_bin(&fb, (uint64_t)p.fft_length, 1, 1, 4)) { enif_release_binary(&zb); enif_release_binary(&tb); return mk_oom(env); }
@@ -281,6 +283,9 @@ static ERL_NIF_TERM nif_stft(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]
   return enif_make_tuple5(env, mk_atom(env, "ok"), enif_make_binary(env, &zb), enif_make_int64(env, m), enif_make_binary(env, &tb),
                           enif_make_binary(env, &fb));
 }
+
+static ERL_NIF_TERM nif_stft(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { return stft_host(env, argc, argv, 4); }
+static ERL_NIF_TERM nif_stft_c64(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { return stft_host(env, argc, argv, 8); }
 
 /* istft(ctx, z_bin, num_frames, batch, window_bin, params) -> {:ok, y_bin} */
 static ERL_NIF_TERM nif_istft(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
@@ -792,8 +797,8 @@ static ERL_NIF_TERM nif_buf_size(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
   return enif_make_int64(env, (ErlNifSInt64)b->bytes);
 }
 
-/* stft_dev(ctx, x_buf, length, batch, window_bin, params) -> {:ok, z_buf, num_frames} */
-static ERL_NIF_TERM nif_stft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+/* stft_dev(ctx, x_buf, length, batch, window_bin, params) -> {:ok, z_buf, num_frames}; stft_c64_dev: x_buf holds c64 samples */
+static ERL_NIF_TERM stft_dev_impl(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[], size_t elem) {
   ctx_res_t* c;
   buf_res_t* x;
   ErlNifBinary w;
@@ -803,7 +808,7 @@ static ERL_NIF_TERM nif_stft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
   if (argc != 6 || !get_ctx(env, argv[0], &c) || !get_buf(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
       !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !get_params(env, argv[5], &p))
     return enif_make_badarg(env);
-  if (batch < 1 || length < 1 || x->owner != c || x->bytes / 4 / (size_t)batch < (size_t)length || w.size != (size_t)p.frame_length * 4)
+  if (batch < 1 || length < 1 || x->owner != c || x->bytes / elem / (size_t)batch < (size_t)length || w.size != (size_t)p.frame_length * 4)
     return enif_make_badarg(env);
   int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
   if (m < 0) return mk_error(env, (int)m);
@@ -812,10 +817,13 @@ static ERL_NIF_TERM nif_stft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
   void* z = NULL;
   int rc = nxsig_alloc(c->ctx, zbytes, &z);
   if (rc) return mk_error(env, rc);
-  rc = nxsig_stft_f32(c->ctx, (const float*)x->dptr, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)z, NULL, NXSIG_DEVICE);
+  rc = elem == 8 ? nxsig_stft_c64(c->ctx, (const nxsig_c64*)x->dptr, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)z, NULL, NXSIG_DEVICE)
+                 : nxsig_stft_f32(c->ctx, (const float*)x->dptr, length, batch, length, (const float*)w.data, &p, (nxsig_c64*)z, NULL, NXSIG_DEVICE);
   if (rc) { nxsig_free(c->ctx, z); return mk_error(env, rc); }
   return enif_make_tuple3(env, mk_atom(env, "ok"), make_buf(env, c, z, zbytes), enif_make_int64(env, m));
 }
+static ERL_NIF_TERM nif_stft_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { return stft_dev_impl(env, argc, argv, 4); }
+static ERL_NIF_TERM nif_stft_c64_dev(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) { return stft_dev_impl(env, argc, argv, 8); }
 
 /* stft_onesided_dev / stft_packed_dev(ctx, x_buf, length, batch, window_bin, params) -> {:ok, z_buf, num_frames}
  * c64[batch][M][fft_length / 2]: bins 0 .. fft_length/2 - 1; packed: the imaginary part of bin 0 carries Re X[fft_length / 2] */
@@ -1440,6 +1448,7 @@ static ErlNifFunc funcs[] = {
     {"mel_filters", 5, nif_mel_filters, ERL_NIF_DIRTY_JOB_CPU_BOUND},
     {"sinc", 1, nif_sinc, 0},
     {"stft", 6, nif_stft, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_c64", 6, nif_stft_c64, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft", 6, nif_istft, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_filtered", 7, nif_istft_filtered, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir", 6, nif_fir, ERL_NIF_DIRTY_JOB_IO_BOUND},
@@ -1457,6 +1466,7 @@ static ErlNifFunc funcs[] = {
     {"from_device", 1, nif_from_device, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"buf_size", 1, nif_buf_size, 0},
     {"stft_dev", 6, nif_stft_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_c64_dev", 6, nif_stft_c64_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_onesided_dev", 6, nif_stft_onesided_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stft_packed_dev", 6, nif_stft_packed_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_packed_dev", 6, nif_istft_packed_dev, ERL_NIF_DIRTY_JOB_IO_BOUND},

@@ -277,10 +277,17 @@ def _stft(data, window, ctx, opts, onesided, packed=False):
         if onesided:
             raise ArgumentError("stft_onesided / stft_packed are f32 extensions; the f64 tier returns the full c128 spectrum")
         return _stft_f64(data, w, ctx, p, N, hop, K, data_f64)
+    # complex samples (c64 IQ data): the reference frames, multiplies and transforms whatever tensor it is given (lib/nx_signal.ex:94-102):
+    # one transform per frame, nxsig_stft_c64
+    data_c64 = (device_view(data)[2] == np.dtype(np.complex64)) if is_device(data) else (np.asarray(data).dtype == np.complex64)
+    if data_c64:
+        if onesided:
+            raise ArgumentError("stft_onesided / stft_packed need real samples (a complex signal's spectrum is not Hermitian)")
+        entry = lib.nxsig_stft_c64
     if is_device(data):
         ptr, shape, dt = device_view(data)
-        if dt != np.float32:
-            raise ArgumentError("stft: device input must be float32 or float64")
+        if dt != np.float32 and not data_c64:
+            raise ArgumentError("stft: device input must be float32, float64 or complex64")
         c = _ctx_of(data, ctx)
         L = shape[-1]
         batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
@@ -289,7 +296,7 @@ def _stft(data, window, ctx, opts, onesided, packed=False):
         _lib.check(entry(c.handle, C.c_void_p(ptr), L, batch, L, _as_ptr(w), C.byref(p), C.c_void_p(z.ptr),
                                       C.byref(M), _lib.DEVICE))
     else:
-        x = _host_f32(data, "stft")
+        x = np.ascontiguousarray(np.asarray(data)) if data_c64 else _host_f32(data, "stft")
         if x.ndim < 1:
             raise ArgumentError("stft expects a tensor of rank >= 1")
         c = _ctx_of(None, ctx)

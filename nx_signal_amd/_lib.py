@@ -86,6 +86,7 @@ SIGNATURES = {
     "nxsig_fft_frequencies_f32": (C.c_int, [_f64, _i32, _i32, _p]),
     "nxsig_stft_times_f32": (C.c_int, [_i32, _f64, _i64, _p]),
     "nxsig_stft_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _p, C.POINTER(_i64), _i32]),
+    "nxsig_stft_c64": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _p, C.POINTER(_i64), _i32]),
     "nxsig_stft_onesided_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _p, C.POINTER(_i64), _i32]),
     "nxsig_istft_c64": (C.c_int, [_p, _p, _i64, _i32, _p, C.POINTER(StftParams), _p, _i32]),
     "nxsig_stft_packed_f32": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, C.POINTER(StftParams), _p, C.POINTER(_i64), _i32]),

@@ -814,6 +814,44 @@ int nxsig_stft_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch
   NXSIG_API_END
 }
 
+int nxsig_stft_c64(nxsig_ctx* ctx, const nxsig_c64* x, int64_t length, int32_t batch, int64_t batch_stride,
+                   const float* window, const nxsig_stft_params* p, nxsig_c64* z, int64_t* num_frames_out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!x || !window || !p || !z) return set_error(NXSIG_ERR_INVALID_ARG, "stft: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch must be in [1, 65535]");
+  if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch_stride < length");
+  if (p->fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft: fft_length must be >= 1");
+  rc = check_scaling(p->scaling);
+  if (rc) return rc;
+  Framing fr;
+  rc = make_framing(length, p->frame_length, p->hop, p->pad_mode, p->pad_lo, p->pad_hi, &fr);
+  if (rc) return rc;
+  if (num_frames_out) *num_frames_out = fr.M;
+  StftLaunch a;
+  a.fr = fr; a.batch = batch; a.batch_stride = batch_stride; a.K = p->fft_length;
+  a.has_scale = p->scaling != NXSIG_SCALE_NONE;
+  a.inv_scale_div = a.has_scale ? scaling_factor(window, p->frame_length, p->scaling, p->sampling_rate) : 1.0f;
+  rc = ctx_window(c, window, p->frame_length, p->fft_length, &a.window, &a.window_padK);
+  if (rc) return rc;
+  const size_t zbytes = (size_t)batch * fr.M * p->fft_length * sizeof(float2);
+  if (mem == NXSIG_DEVICE) {
+    a.x = reinterpret_cast<const float*>(x); a.z = reinterpret_cast<float2*>(z);
+    return launch_stft_c64(c, a);
+  }
+  Staged st(c);
+  const void* xd = nullptr; void* zd = nullptr;
+  const size_t xbytes = ((size_t)(batch - 1) * batch_stride + length) * sizeof(float2);
+  if ((rc = st.in(1, x, xbytes, &xd))) return rc;
+  if ((rc = st.out_alloc(2, zbytes, &zd))) return rc;
+  a.x = reinterpret_cast<const float*>(xd); a.z = reinterpret_cast<float2*>(zd);
+  if ((rc = launch_stft_c64(c, a))) return rc;
+  return st.out_copy(z, zd, zbytes);
+  NXSIG_API_END
+}
+
 static int istft_common(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
                         const nxsig_stft_params* p, const nxsig_c64* h, nxsig_c64* y, int32_t mem, bool onesided = false) {
   NXSIG_CHECK_CTX(ctx)

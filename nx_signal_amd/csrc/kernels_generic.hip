@@ -1222,6 +1222,56 @@ int launch_fft(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_
   return launch_fft_rows(c, in, in_is_real, rows, n_in, K, inverse, nullptr, 1.0f, false, out, clean);
 }
 
+// ---- NxSignal.stft of COMPLEX samples (c64 IQ data; the reference frames, multiplies and transforms whatever tensor it is given,
+// lib/nx_signal.ex:94-102).  fft_length 1024 / 2048 / 4096: one launch (launch_stft_c64_wave, kernels_wave_rows.hip: frame slice x
+// window fused into the row kernels' loads).  Every other length: the windowed frames (truncated to fft_length, :102) go to a scratch
+// tensor and the row transforms of Nx.fft take it from there — the same kernels, Bluestein and four-step paths as nxsig_fft —
+// followed by the :spectrum / :psd division.  c64 x f32 is componentwise (SURVEY App. A rule 9): two exact f32 products per sample.
+__global__ __launch_bounds__(kThreads) void k_frames_c64(const float2* __restrict__ x, int64_t batch_stride, FrameGeom g, int32_t n_use,
+                                                        const float* __restrict__ window, float2* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int64_t total = g.M * n_use;
+  if (idx >= total) return;
+  const int64_t m = idx / n_use;
+  const int32_t n = (int32_t)(idx - m * n_use);
+  const float2* xr = x + (size_t)blockIdx.y * batch_stride;
+  int64_t pos = m * g.hop + n - g.lo;
+  float2 v = make_float2(0.f, 0.f);
+  if (g.reflect) {   // lib/nx_signal.ex:349 (Nx.reflect)
+    if (g.L == 1) pos = 0;
+    else {
+      const int64_t period = 2 * (g.L - 1);
+      pos %= period;
+      if (pos < 0) pos += period;
+      if (pos >= g.L) pos = period - pos;
+    }
+    v = xr[pos];
+  } else if (pos >= 0 && pos < g.L) v = xr[pos];   // :338 (Nx.pad, zeros)
+  const float w = window[n];
+  out[(size_t)blockIdx.y * total + idx] = make_float2(v.x * w, v.y * w);
+}
+
+int launch_stft_c64_wave(Ctx* c, const StftLaunch& s, bool* handled);   // kernels_wave_rows.hip
+
+int launch_stft_c64(Ctx* c, const StftLaunch& s) {
+  if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
+  bool handled = false;
+  int rc = launch_stft_c64_wave(c, s, &handled);
+  if (rc || handled) return rc;
+  const int n_use = s.fr.N < s.K ? s.fr.N : s.K;
+  const int64_t rows = (int64_t)s.batch * s.fr.M;
+  void* frames = nullptr;
+  if ((rc = ctx_scratch(c, 26, (size_t)rows * n_use * sizeof(float2), &frames))) return rc;
+  const int64_t blocks = (s.fr.M * n_use + kThreads - 1) / kThreads;
+  if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
+  hipLaunchKernelGGL(k_frames_c64, dim3((unsigned)blocks, (unsigned)s.batch), dim3(kThreads), 0, c->stream,
+                     reinterpret_cast<const float2*>(s.x), s.batch_stride, to_geom(s.fr), n_use, s.window, reinterpret_cast<float2*>(frames));
+  NXSIG_HIP_TRY(hipGetLastError());
+  if ((rc = launch_fft_rows(c, frames, false, rows, n_use, s.K, false, nullptr, 1.0f, false, s.z))) return rc;
+  if (s.has_scale) return launch_rows_post(c, s.z, rows, s.K, nullptr, 1.0f, false, s.inv_scale_div, true);
+  return NXSIG_OK;
+}
+
 // generic istft: rows IFFT (x scale x window) into a scratch frames tensor, then the deterministic OLA + normaliser
 int launch_istft_generic(Ctx* c, const IstftLaunch& s) {
   if (s.M == 0 || s.batch == 0) return NXSIG_OK;

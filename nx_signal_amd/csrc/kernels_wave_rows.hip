@@ -24,6 +24,15 @@ struct RowsWaveArgs {
   int32_t clean;             // 1: eps clean-up of the finished transform (0 when the rows are a sub-step of a longer transform)
   int64_t chunk;            // rows per workgroup
   v2f* out;
+  // ---- framed input (NxSignal.stft of COMPLEX samples, lib/nx_signal.ex:94-102; forward only): row r is frame r % fM of signal row
+  // r / fM of `in` (c64[..][fL], rows fstride elements apart); element idx of the frame is padded-signal sample (r % fM) fhop + idx
+  // (zero / mirror padding by flo, lib/nx_signal.ex:338 / :349) times pre_window[idx] (componentwise exact f32 products, :101); the
+  // finished spectrum is divided by `div` (:113-127).  fM == 0: plain rows.
+  int64_t fM = 0, fL = 0, flo = 0, fstride = 0;
+  int32_t fhop = 0, freflect = 0;
+  const float* pre_window = nullptr;   // f32[n_in]
+  float div = 1.0f;
+  int32_t has_div = 0;
 };
 
 template <bool INV>
@@ -31,6 +40,7 @@ __device__ __forceinline__ v4f rows_epilogue(const RowsWaveArgs& a, v2f z0, v2f 
   v4f o = v4f{z0.x, z0.y, z1.x, z1.y};
   if (INV) o = o * invK;  // exact for powers of two
   if (a.clean) o = fft_eps0(o);  // Nx.fft / Nx.ifft clean-up, ahead of the istft epilogue
+  if (!INV && a.has_div) o = o / a.div;   // stft :spectrum / :psd: true division like the reference
   if (a.has_post_scale) o = o * a.post_scale;
   if (a.post_window) {
     const v2f w = *reinterpret_cast<const v2f*>(a.post_window + k);
@@ -44,6 +54,25 @@ __device__ __forceinline__ v2f rows_fetch(const RowsWaveArgs& a, const void* row
   if (idx >= a.n_in) return v2f{0.f, 0.f};
   if (a.in_is_real) return v2f{reinterpret_cast<const float*>(row)[idx], 0.f};
   return reinterpret_cast<const v2f*>(row)[idx];
+}
+
+// element `idx` of frame m of a complex signal row (framed input): padded-signal index q = m hop + idx
+__device__ __forceinline__ v2f rows_fetch_framed(const RowsWaveArgs& a, const v2f* sig, int64_t q0, int idx) {
+  if (idx >= a.n_in) return v2f{0.f, 0.f};
+  int64_t pos = q0 + idx - a.flo;
+  if (q0 - a.flo >= 0 && q0 - a.flo + a.n_in <= a.fL) {   // wave-uniform: the frame lies inside the signal (all but the edge frames)
+  } else if (a.freflect) {
+    if (a.fL == 1) pos = 0;
+    else {
+      const int64_t period = 2 * (a.fL - 1);
+      pos %= period;
+      if (pos < 0) pos += period;
+      if (pos >= a.fL) pos = period - pos;
+    }
+  } else if (pos < 0 || pos >= a.fL) return v2f{0.f, 0.f};   // zero padding (an exact 0 x w = 0 either way)
+  const v2f v = sig[pos];
+  const float w = a.pre_window[idx];
+  return v2f{v.x * w, v.y * w};
 }
 
 // K = 1024 / 2048: one core pass per row, the next row's points prefetched during the butterflies
@@ -65,6 +94,13 @@ __global__ __launch_bounds__(64 * W) void k_fft_rows_wave(RowsWaveArgs a) {
   const float invK = 1.0f / (float)K;
   v2f nx[P];
   auto issue = [&](int64_t r) {
+    if (!INV && a.fM > 0) {   // wave-uniform
+      const int64_t b = r / a.fM, m = r - b * a.fM;
+      const v2f* sig = static_cast<const v2f*>(a.in) + (size_t)b * a.fstride;
+#pragma unroll
+      for (int s = 0; s < P; ++s) nx[s] = rows_fetch_framed(a, sig, m * a.fhop, lane + 64 * s);
+      return;
+    }
     const char* row = static_cast<const char*>(a.in) + (size_t)r * row_bytes;
 #pragma unroll
     for (int s = 0; s < P; ++s) nx[s] = rows_fetch(a, row, lane + 64 * s);
@@ -104,9 +140,12 @@ __global__ __launch_bounds__(64 * W) void k_fft_rows_wave_4k(RowsWaveArgs a) {
   if (r_end > a.rows) r_end = a.rows;
   const size_t row_bytes = (size_t)a.n_in * (a.in_is_real ? 4 : 8);
   const float invK = 1.0f / (float)KOUT;
-  const bool full_c64 = !a.in_is_real && a.n_in >= KOUT && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 && (row_bytes & 15) == 0;  // uniform
+  const bool full_c64 = a.fM == 0 && !a.in_is_real && a.n_in >= KOUT && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 && (row_bytes & 15) == 0;  // uniform
   for (int64_t r = r_begin + wave; r < r_end; r += W) {
     const char* row = static_cast<const char*>(a.in) + (size_t)r * row_bytes;
+    const int64_t fb = a.fM > 0 ? r / a.fM : 0;
+    const v2f* fsig = static_cast<const v2f*>(a.in) + (size_t)fb * a.fstride;
+    const int64_t fq0 = a.fM > 0 ? (r - fb * a.fM) * a.fhop : 0;
     v2f y[4][2][NQ];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // sub-sequences (0, 1) then (2, 3): each 16-byte load carries two of them
@@ -118,8 +157,13 @@ __global__ __launch_bounds__(64 * W) void k_fft_rows_wave_4k(RowsWaveArgs a) {
       } else {
 #pragma unroll
         for (int s = 0; s < P; ++s) {
-          d0[s] = rows_fetch(a, row, 4 * (lane + 64 * s) + 2 * h);
-          d1[s] = rows_fetch(a, row, 4 * (lane + 64 * s) + 2 * h + 1);
+          if (!INV && a.fM > 0) {
+            d0[s] = rows_fetch_framed(a, fsig, fq0, 4 * (lane + 64 * s) + 2 * h);
+            d1[s] = rows_fetch_framed(a, fsig, fq0, 4 * (lane + 64 * s) + 2 * h + 1);
+          } else {
+            d0[s] = rows_fetch(a, row, 4 * (lane + 64 * s) + 2 * h);
+            d1[s] = rows_fetch(a, row, 4 * (lane + 64 * s) + 2 * h + 1);
+          }
         }
       }
       wave_fft_core<K, INV>(d0, y[2 * h], xb, s_twB, s_twC, lane);
@@ -146,9 +190,38 @@ __global__ __launch_bounds__(64 * W) void k_fft_rows_wave_4k(RowsWaveArgs a) {
   }
 }
 
+struct RowsFraming {   // framed input of launch_fft_rows_wave (see RowsWaveArgs)
+  int64_t M, L, lo, stride;
+  int32_t hop, reflect;
+  const float* pre_window;
+  float div;
+  int32_t has_div;
+};
+static const RowsFraming* g_rows_framing_none = nullptr;
+int launch_fft_rows_wave_framed(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse,
+                                const float* post_window, float post_scale, bool has_post_scale, float2* out, bool* handled, bool clean,
+                                const RowsFraming* fr);
 // returns handled = false for lengths / shapes the wave kernels do not take
 int launch_fft_rows_wave(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse,
                          const float* post_window, float post_scale, bool has_post_scale, float2* out, bool* handled, bool clean) {
+  return launch_fft_rows_wave_framed(c, in, in_is_real, rows, n_in, K, inverse, post_window, post_scale, has_post_scale, out, handled, clean,
+                                     g_rows_framing_none);
+}
+// NxSignal.stft of complex samples (lib/nx_signal.ex:94-102) for fft_length 1024 / 2048 / 4096 in ONE launch: frame slice x window fused
+// into the loads of the row kernels, :spectrum / :psd division into their epilogue.  handled = false: the caller takes the two-step path.
+int launch_stft_c64_wave(Ctx* c, const StftLaunch& s, bool* handled) {
+  *handled = false;
+  if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
+  RowsFraming f;
+  f.M = s.fr.M; f.L = s.fr.L; f.lo = s.fr.lo; f.stride = s.batch_stride; f.hop = s.fr.hop; f.reflect = s.fr.reflect;
+  f.pre_window = s.window; f.div = s.inv_scale_div; f.has_div = s.has_scale;
+  const int n_in = s.fr.N < s.K ? s.fr.N : s.K;   // Nx.fft(length: K) truncates longer frames
+  return launch_fft_rows_wave_framed(c, s.x, false, (int64_t)s.batch * s.fr.M, n_in, s.K, false, nullptr, 1.0f, false, s.z, handled, true, &f);
+}
+int launch_fft_rows_wave_framed(Ctx* c, const void* in, bool in_is_real, int64_t rows, int32_t n_in, int32_t K, bool inverse,
+                                const float* post_window, float post_scale, bool has_post_scale, float2* out, bool* handled, bool clean,
+                                const RowsFraming* fr) {
   *handled = false;
   if ((K != 1024 && K != 2048 && K != 4096) || rows < 1 || tune(c, kT_DISABLE_WAVE_ROWS, 0)) return NXSIG_OK;
   if (post_window && (reinterpret_cast<uintptr_t>(post_window) & 7) != 0) return NXSIG_OK;
@@ -164,6 +237,10 @@ int launch_fft_rows_wave(Ctx* c, const void* in, bool in_is_real, int64_t rows, 
   a.tw4k = nullptr;
   a.post_window = post_window; a.post_scale = post_scale; a.has_post_scale = has_post_scale ? 1 : 0; a.clean = clean ? 1 : 0;
   a.out = reinterpret_cast<v2f*>(out);
+  if (fr) {
+    a.fM = fr->M; a.fL = fr->L; a.flo = fr->lo; a.fstride = fr->stride; a.fhop = fr->hop; a.freflect = fr->reflect;
+    a.pre_window = fr->pre_window; a.div = fr->div; a.has_div = fr->has_div;
+  }
   constexpr int W = 4;
   const int rpw = (K == 4096 ? 2 : 4);
   a.chunk = (int64_t)W * (rpw < 1 ? 1 : rpw);

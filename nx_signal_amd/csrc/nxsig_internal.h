@@ -179,6 +179,7 @@ struct StftLaunch {
   float2* z;             // device c64[batch][M][K]
 };
 int launch_stft(Ctx* c, const StftLaunch& a);
+int launch_stft_c64(Ctx* c, const StftLaunch& a);   // complex samples: a.x holds c64[batch][L] (kernels_generic.hip)
 
 struct IstftLaunch {
   const float2* z;       // device c64[batch][M][K]

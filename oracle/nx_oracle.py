@@ -434,9 +434,15 @@ def stft(
     data = np.asarray(data)
     frames = as_windowed(data, N, hop, window_padding)  # :94-100
     if np.iscomplexobj(frames):
-        raise ValueError("complex stft input is outside the hot path")
-    fr = frames.astype(f32) * window.astype(f32)  # :101 exact f32 product
-    z = fft(fr.astype(f32), length=fft_length, eps=eps)  # :102
+        # c64 samples (IQ data): the reference frames, multiplies and transforms whatever tensor it is given (:94-102).  c64 x f32 is
+        # componentwise (SURVEY App. A rule 9: each component an exact f32 product), the transform is the same Nx.fft over c64 rows
+        fc = frames.astype(c64)
+        wf = window.astype(f32)
+        fr = ((fc.real.astype(f32) * wf) + 1j * (fc.imag.astype(f32) * wf)).astype(c64)  # :101
+        z = fft(fr, length=fft_length, eps=eps)  # :102
+    else:
+        fr = frames.astype(f32) * window.astype(f32)  # :101 exact f32 product
+        z = fft(fr.astype(f32), length=fft_length, eps=eps)  # :102
     K = z.shape[-1]
     M = z.shape[-2]
     sf = _scale_factor(window, scaling, sampling_rate)

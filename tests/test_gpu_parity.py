@@ -279,6 +279,55 @@ def test_stft_matches_oracle(case):
     assert np.array_equal(t, to, equal_nan=True) and np.array_equal(f, fo)
 
 
+@pytest.mark.parametrize("case", STFT_CASES, ids=lambda c: f"L{c[0]}-N{c[1]}-ov{c[2]}-K{c[3]}-{c[4] if isinstance(c[4], str) else 'explicit'}-{c[5]}")
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_stft_of_complex_samples_matches_oracle(case, where):
+    """c64 IQ data.  The reference frames, multiplies and transforms whatever tensor it is given
+    (lib/nx_signal.ex:94-102); every STFT_CASES shape — all padding modes, truncation / zero-padding, every scaling, wave / LDS /
+    Bluestein / four-step lengths — with complex samples, host and device-resident, equals the oracle to 1e-5."""
+    L, N, overlap, K, pad, scaling, fs, bshape = case
+    rng = np.random.default_rng(4321 + L + N)
+    x = (rng.standard_normal(bshape + (L,)) + 1j * rng.standard_normal(bshape + (L,))).astype(np.complex64)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=overlap, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=fs)
+    zo, to, fo = O.stft(x, w, **opts)
+    if where == "host":
+        z, t, f = S.stft(x, w, **opts)
+    else:
+        zd, t, f = S.stft(S.default_context(0).to_device(x), w, **opts)
+        z = zd.numpy()
+    assert z.dtype == np.complex64 and z.shape == zo.shape
+    assert_close(z, zo, str(case))
+    assert np.array_equal(t, to, equal_nan=True) and np.array_equal(f, fo)
+    # a complex signal's spectrum is NOT Hermitian: the result must differ from the real part's transform alone
+    if L >= 64:
+        zr, _, _ = O.stft(np.ascontiguousarray(x.real), w, **opts)
+        assert float(np.max(np.abs(zo - zr))) > 1e-3 * float(np.max(np.abs(zo)))
+
+
+def test_stft_of_complex_samples_long_stream_and_refusals():
+    """60 s of complex IQ at N = 1024 hop = 256 through the fused row kernels (one frame per transform), sampled against the oracle, and
+    linearity (size-independent property): stft(a + i b) == stft(a) + i stft(b) to fp32 round-off; the one-sided extensions refuse it"""
+    L, N, hop = 2_880_000, 1024, 256
+    rng = np.random.default_rng(77)
+    a = rng.standard_normal(L, dtype=np.float32)
+    b = rng.standard_normal(L, dtype=np.float32)
+    x = (a + 1j * b).astype(np.complex64)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+    ctx = S.default_context(0)
+    z = S.stft(ctx.to_device(x), w, **opts)[0].numpy()
+    assert z.shape == (11247, 1024)
+    for m in (0, 1, 5000, 11245, 11246):
+        zo = O.stft(x[m * hop: m * hop + N], w, **opts)[0][0]
+        assert float(np.max(np.abs(z[m] - zo)) / np.max(np.abs(zo))) < 1e-5, m
+    za = S.stft(a, w, **opts)[0]
+    zb = S.stft(b, w, **opts)[0]
+    assert float(np.max(np.abs(z - (za + 1j * zb))) / np.max(np.abs(z))) < 1e-6
+    with pytest.raises(S.ArgumentError):
+        S.stft_onesided(x[:9000], w, **opts)
+
+
 @pytest.mark.parametrize("K,N,hop", [(100, 100, 25), (1000, 1000, 250), (400, 400, 160), (65, 65, 13), (3000, 3000, 750),
                                      (4095, 4000, 1000), (640, 400, 160), (300, 500, 100), (4097, 4097, 2000), (7, 7, 3)])
 def test_stft_non_power_of_two_lengths(K, N, hop):

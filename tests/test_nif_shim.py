@@ -193,6 +193,30 @@ def test_stft_istft_fir_through_the_nif_equal_the_ctypes_path(nctx):
 
 
 @gpu
+def test_stft_of_complex_samples_through_the_nif(nctx):
+    """stft_c64 / stft_c64_dev: the term shapes nx_signal_amd.ex builds for c64 tensors (binary of interleaved f32 re, im)"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = (rng.standard_normal((2, 48000)) + 1j * rng.standard_normal((2, 48000))).astype(np.complex64)
+    w = S.windows.hann(1024)
+    ok, zb, m, tb, fb = H.call("stft_c64", nctx, x, 48000, 2, w, PARAMS)
+    z, t, f = S.stft(x, w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert ok == "ok" and m == 184
+    assert np.array_equal(c64(zb).view(np.uint32), z.reshape(-1).view(np.uint32))
+    assert np.array_equal(f32(tb), t) and np.array_equal(f32(fb), f)
+    zo, _, _ = O.stft(x[1], w, overlap_length=768, fft_length=1024, sampling_rate=48000)
+    assert float(np.max(np.abs(c64(zb)[zo.size:].reshape(zo.shape) - zo)) / np.max(np.abs(zo))) < 1e-5
+    ok, xb = H.call("to_device", nctx, x[0])
+    ok, zd, md = H.call("stft_c64_dev", nctx, xb, 48000, 1, w, PARAMS)
+    ok, back = H.call("from_device", zd)
+    assert md == 184 and np.array_equal(c64(back).view(np.uint32), z[0].reshape(-1).view(np.uint32))
+    for bad in ((nctx, x, 48001, 2, w, PARAMS), (nctx, x.real.astype(np.float32), 48000, 2, w, PARAMS), (nctx, x, 48000, 2, w[:1000], PARAMS)):
+        with pytest.raises(H.BadArg):
+            H.call("stft_c64", *bad)
+    with pytest.raises(H.BadArg):
+        H.call("stft_c64_dev", nctx, xb, 48000, 2, w, PARAMS)   # the buffer holds one complex row, not two
+
+
+@gpu
 def test_f64_tier_through_the_nif(nctx):
     """stft_f64 / istft_c128 / fir_f64 / fft_c128 / as_windowed_f64 / overlap_and_add_f64 with the term shapes nx_signal_amd.ex builds"""
     rng = np.random.Generator(np.random.PCG64(3))

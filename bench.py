@@ -122,6 +122,45 @@ def cpu_baseline(max_seconds: float):
     }
 
 
+class MemWatch:
+    """device-memory high-water mark of this rank (nxsig_mem_info = hipMemGetInfo, sampled after every allocation phase)"""
+
+    def __init__(self, ctx, lib, C):
+        self.ctx, self.lib, self.C = ctx, lib, C
+        self.total, self.min_free, self.marks = None, None, []
+
+    def sample(self, label):
+        f, t = self.C.c_size_t(), self.C.c_size_t()
+        try:
+            if self.lib.nxsig_mem_info(self.ctx.handle, self.C.byref(f), self.C.byref(t)) != 0:
+                return
+        except AttributeError:
+            return
+        self.total = t.value
+        used = t.value - f.value
+        if self.min_free is None or f.value < self.min_free:
+            self.min_free = f.value
+        self.marks.append((label, round(used / 2**30, 2)))
+
+    def report(self):
+        if self.total is None:
+            return None
+        return {"high_water_GiB": round((self.total - self.min_free) / 2**30, 2), "device_total_GiB": round(self.total / 2**30, 2),
+                "after_GiB_in_use": dict(self.marks)}
+
+
+def rccl_info(lib, C):
+    """the RCCL library libnxsig.so actually dlopen()ed: version code as ncclGetVersion reports it and the shared object's path"""
+    try:
+        v, buf = C.c_int32(0), C.create_string_buffer(512)
+        rc = lib.nxsig_rccl_info(C.byref(v), buf, 512)
+        code = int(v.value)
+        return {"loaded": rc == 0, "version_code": code, "version": f"{code // 10000}.{code // 100 % 100}.{code % 100}" if code else None,
+                "path": buf.value.decode(errors="replace") or None, "headers_built_against": "2.27.7 (/opt/rocm/include/rccl/rccl.h)"}
+    except Exception as e:  # noqa: BLE001
+        return {"loaded": False, "error": repr(e)[:120]}
+
+
 def load_diag():
     """tools/libnxsig_diag.so (tools/diag_mix.hip, built by __graft_entry__.build()): no-math traffic models of the iSTFT / FIR
     kernels in their shipped geometry.  Measurement infrastructure only; absent -> the mix ceilings are reported as null."""
@@ -194,7 +233,7 @@ def settle(ctx, fn, cap, nbytes=None):
 
 
 def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, seconds45=600, streams3=16, channels45=8, keep_z4=False,
-                        settle_cap=300, yard=None):
+                        settle_cap=300, yard=None, dry=False, mem=None):
     """Rooflines of the other BASELINE configs at their FULL per-GPU shard, measured like the headline (HIP events on the
     library's stream, one interval per launch, device-resident data; algorithmic bytes per SURVEY 8d):
       config 3  istft N=1024 hop=256, 16 x 60 s            10 240 B/frame  (K*8 read + hop*8 written, c64 out)
@@ -238,6 +277,8 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
 
     def interleaved(kernel_fn, mix_fn, rounds=2, reps=10):
         """A B A B: `rounds` x (`reps` kernel laps, `reps` model laps), 2 untimed launches in front of each series"""
+        if dry:   # preflight: ONE launch of the kernel and of its model
+            return measure(kernel_fn, 1, 0), (measure(mix_fn, 1, 0) if mix_fn is not None else [])
         kl, ml = [], []
         for _ in range(rounds):
             kl += measure(kernel_fn, reps, 2)
@@ -295,7 +336,9 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         wp = w.ctypes.data_as(C.c_void_p)
         nb3 = B3 * M3 * (N_FFT * 8 + HOP * 8)
         k3 = lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(z3.ptr), M3, B3, wp, C.byref(p3), C.c_void_p(y3.ptr), _lib.DEVICE))  # noqa: E731
-        pre = settle(ctx, k3, settle_cap, nb3)
+        if mem is not None:
+            mem.sample("config 3 buffers")
+        pre = settle(ctx, k3, settle_cap, nb3) if not dry else {"launches": 0, "settled": False, "dry": True}
         # round trip of config 3 on interior samples (size-independent property): y ~ x — read BEFORE the model overwrites y
         chk = np.empty(4096, np.complex64)
         _lib.check(lib.nxsig_download(ctx.handle, chk.ctypes.data_as(C.c_void_p), C.c_void_p(y3.ptr + 8 * 100000), chk.nbytes))
@@ -326,7 +369,9 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         wp4 = w4.ctypes.data_as(C.c_void_p)
         nb4 = B4 * M4 * (H4 * 4 + N4 * 8)
         k4 = lambda: _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, wp4, C.byref(p4), C.c_void_p(z4.ptr), None, _lib.DEVICE))  # noqa: E731
-        pre = settle(ctx, k4, settle_cap, nb4)
+        if mem is not None:
+            mem.sample("config 4 buffers")
+        pre = settle(ctx, k4, settle_cap, nb4) if not dry else {"launches": 0, "settled": False, "dry": True}
         tab4 = ctx.to_device(np.zeros(3072, np.float32)) if diag is not None else None
         m4 = (lambda: diag.nxdiag_stft2048_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(z4.ptr), C.c_void_p(tab4.ptr), B4, L4, H4, 8)) if diag is not None else None
         laps, mlaps = interleaved(k4, m4)
@@ -345,7 +390,9 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         y5 = ctx.empty((B4, L4), np.float32)
         hp = h.ctypes.data_as(C.c_void_p)
         k5 = lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(x4.ptr), L4, B4, L4, hp, 257, _lib.CONV_SAME, C.c_void_p(y5.ptr), _lib.DEVICE))  # noqa: E731
-        pre = settle(ctx, k5, settle_cap, B4 * L4 * 8)
+        if mem is not None:
+            mem.sample("config 5 buffers")
+        pre = settle(ctx, k5, settle_cap, B4 * L4 * 8) if not dry else {"launches": 0, "settled": False, "dry": True}
         m5 = (lambda: diag.nxdiag_fir_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(y5.ptr), B4, L4, 8)) if diag is not None else None
         laps, mlaps = interleaved(k5, m5)
         out["roofline_fir"] = block(f"config 5 (one GPU's shard): fir 257 taps :same, {B4} ch x {seconds45} s @48 kHz", "nxsig_fir_f32 (stream + edge + poison pass)",
@@ -385,13 +432,16 @@ def yardsticks(ctx, lib, _lib, C, diag, xd, x_bytes, zd, z_bytes):
     h4 = (half // (4 * kib))
     # geometry g: > 0 = grid-stride over g long-lived workgroups, < 0 = short-lived workgroups handing out -g consecutive steps per wave
     geos = (2048, 8192, -2, -8)
+    # the iSTFT kernel's own geometry on the plain stream: 8 resident waves per CU (2048 on the chip), each walking ONE contiguous run —
+    # 2048 far-apart address streams instead of one contiguous front
+    persist41 = steps41 // 2048 + 1
     cases = [
         ("read", z_bytes, "16-byte loads of the spectrum buffer, no stores", geos,
          lambda g: diag.nxdiag_y_read(stream, vp(Z), vp(X), z_bytes, g) if g > 0 else diag.nxdiag_y_mix(stream, vp(Z), vp(X), q4, 4, 0, g)),
         ("copy", 2 * half, "16-byte copy, first half of the spectrum buffer -> second half (read + written bytes)", geos,
          lambda g: diag.nxdiag_y_copy(stream, vp(Z), vp(Z + half), half, g) if g > 0 else diag.nxdiag_y_mix(stream, vp(Z), vp(Z + half), h4, 4, 4, g)),
         ("memcpy_dtod", 2 * half, "hipMemcpyDtoDAsync of the same halves (read + written bytes)", (0,), lambda g: diag.nxdiag_y_memcpy(stream, vp(Z), vp(Z + half), half)),
-        ("mix_4to1", steps41 * 5 * kib, "plain 4 : 1 stream (the iSTFT's ratio): a wave reads 4 KiB (4 x 16 B per lane) and writes 1 KiB per step", geos,
+        ("mix_4to1", steps41 * 5 * kib, "plain 4 : 1 stream (the iSTFT's ratio): a wave reads 4 KiB (4 x 16 B per lane) and writes 1 KiB per step", geos + (-persist41,),
          lambda g: diag.nxdiag_y_mix(stream, vp(Z), vp(Z + 4 * fifth), steps41, 4, 1, g)),
         ("mix_1to8", steps18 * 9 * kib, "plain 1 : 8 stream (the STFT's ratio): a wave reads 1 KiB and writes 8 KiB per step", geos,
          lambda g: diag.nxdiag_y_mix(stream, vp(X), vp(Z), steps18, 1, 8, g)),
@@ -417,10 +467,11 @@ def yardsticks(ctx, lib, _lib, C, diag, xd, x_bytes, zd, z_bytes):
             ms, stalled = lap_mean(laps)
             gbs = nbytes / (ms * 1e-3) / 1e9
             if best is None or gbs > best["GBps"]:
-                geo = "runtime" if grid == 0 else (f"grid-stride, {grid} workgroups" if grid > 0 else f"short-lived workgroups, {-grid} steps per wave")
+                geo = "runtime" if grid == 0 else (f"grid-stride, {grid} workgroups" if grid > 0 else (
+                    f"short-lived workgroups, {-grid} steps per wave" if -grid < 64 else f"persistent: 2048 waves, one contiguous run of {-grid} steps each"))
                 best = {"GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "bytes": int(nbytes), "geometry": geo, "laps_us": lap_us(laps), "stalled_laps": stalled, "what": what,
                         "all_geometries_GBps": {}}
-            res.setdefault("_all", {}).setdefault(name, {})[str(grid)] = round(gbs)
+            res.setdefault("_all", {}).setdefault(name, {})["persistent_2048_runs" if grid < -64 else str(grid)] = round(gbs)
         if best is not None:
             best["all_geometries_GBps"] = res.get("_all", {}).get(name, {})
         res[name] = best
@@ -428,7 +479,7 @@ def yardsticks(ctx, lib, _lib, C, diag, xd, x_bytes, zd, z_bytes):
     return res
 
 
-def assembly_config4(ctx, group, lib, S, _lib, C, world, rank, channels, seconds, share_gpu):
+def assembly_config4(ctx, group, lib, S, _lib, C, world, rank, channels, seconds, share_gpu, mem=None, reps=3):
     """the config-4-sized final assembly, timed SEPARATELY from frames/s.  Every rank computes its shard of the 64-channel
     spectrogram (stft N=2048 hop=512, `channels` x `seconds` s; 8 x 600 s = 7.37 GB) straight into its slot of a full-size buffer and
     `nxsig_group_allgather` (RCCL ncclAllGather, in place) leaves all `world` shards on every GPU — 51.6 GB received per GPU at
@@ -457,6 +508,8 @@ def assembly_config4(ctx, group, lib, S, _lib, C, world, rank, channels, seconds
             return {"error": "config-4-sized assembly buffers do not fit on some rank" + (": " + err if err else "")}
         ch //= 2
     shard = ch * M4 * N4 * 8
+    if mem is not None:
+        mem.sample("config-4 assembly buffers")
     rng = np.random.Generator(np.random.PCG64(4242 + rank))
     chunk = rng.standard_normal(L4, dtype=np.float32)
     for r in range(ch):
@@ -472,7 +525,6 @@ def assembly_config4(ctx, group, lib, S, _lib, C, world, rank, channels, seconds
     counts = [shard] * world
     group.allgather([own], counts, [zt.ptr])  # warm-up (connection set-up, first-touch of the peers' buffers)
     group.barrier()
-    reps = 3
     t0 = time.perf_counter()
     for _ in range(reps):
         group.allgather([own], counts, [zt.ptr])
@@ -632,6 +684,10 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the roofline blocks of configs 3 / 4 / 5")
     ap.add_argument("--no-yardsticks", action="store_true", help="skip the plain copy / read / fill / mix bandwidth yardsticks")
+    ap.add_argument("--dry", action="store_true",
+                    help="PREFLIGHT (first contact with an N-GPU node): allocate exactly what the run allocates, create the group, run ONE launch of every "
+                         "block and of both assemblies, and print one JSON line with `dry: true`, the per-rank memory high-water marks and the RCCL "
+                         "library actually loaded — no settling, no timing claims, no CPU baseline")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST MODE for one-GPU boxes: every rank uses device LOCAL_RANK %% device_count and claims its own "
                          "NCCL_HOSTID, so several ranks can form an RCCL communicator on ONE GPU (socket transport over lo); "
@@ -645,6 +701,8 @@ def main():
     ap.add_argument("--precondition", type=int, default=300,
                     help="max untimed launches spent settling the clocks before the warm-up steps (0 = none)")
     args = ap.parse_args()
+    if args.dry:
+        args.steps, args.warmup, args.precondition, args.cpu_seconds, args.no_yardsticks = 1, 0, 0, 0.0, True
 
     # The contract is ONE JSON line on stdout.  RCCL prints a banner ("Hostname : ...", "Librccl path : ...") to the
     # process' stdout when the communicator comes up, so file descriptor 1 points at stderr until the result is ready.
@@ -707,6 +765,8 @@ def main():
                 filectl = FileControl(_lib.load(), sharding.rendezvous_path() + ".ctl", world, rank)
     ctx = group.contexts[0] if group is not None else S.Context(local_rank)
     lib = _lib.load()
+    mem = MemWatch(ctx, lib, C)
+    mem.sample("start")
     w = S.windows.hann(N_FFT)
     B = args.streams
 
@@ -718,6 +778,7 @@ def main():
     zd = ctx.empty((B, M, N_FFT), np.complex64)
     p = _lib.StftParams(N_FFT, HOP, N_FFT, _lib.PAD_VALID, 0, 0, _lib.SCALE_NONE, 0, float(SR))
     wp = w.ctypes.data_as(C.c_void_p)
+    mem.sample("headline buffers")
 
     def step(batch=B):
         _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
@@ -734,7 +795,7 @@ def main():
     step()  # the first call of a shape builds the context's tables (window, twiddles: a one-time 4 ms): not a rate
     ctx.sync()
     ctx.timer_lap()
-    for _ in range(20):
+    for _ in range(1 if args.dry else 20):
         step()
         ctx.timer_lap()
     cold20 = ctx.timer_laps()
@@ -789,11 +850,11 @@ def main():
     achieved = (B * M * BYTES_PER_FRAME) / (kernel_ms * 1e-3) / 1e9  # GB/s per GPU, algorithmic bytes
 
     # config 2 exactly as written: ONE 60 s stream per launch, back-to-back launches (L3-resident; bound by the fixed latency of a 703-workgroup kernel)
-    for _ in range(20):
+    for _ in range(1 if args.dry else 20):
         step(1)
     ctx.sync()
     ctx.timer_start()
-    reps = 200
+    reps = 1 if args.dry else 200
     for _ in range(reps):
         step(1)
     single_ms = ctx.timer_stop() / reps
@@ -810,14 +871,15 @@ def main():
     if group is not None:
         try:  # the optional assembly must never take the measurement down with it
             zt = ctx.empty((world, M, N_FFT), np.complex64)  # full-size buffer: the own shard is computed in place
+            mem.sample("config-2 assembly buffer")
             own = zt.ptr + rank * M * N_FFT * 8
             _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, 1, L, wp, C.byref(p), C.c_void_p(own), None, _lib.DEVICE))
             counts = [M * N_FFT * 8] * world
-            for _ in range(2):
+            for _ in range(0 if args.dry else 2):
                 group.allgather([own], counts, [zt.ptr])
             group.barrier()
             tg = time.perf_counter()
-            reps_g = 5
+            reps_g = 1 if args.dry else 5
             for _ in range(reps_g):
                 group.allgather([own], counts, [zt.ptr])
             ctx.sync()
@@ -880,11 +942,11 @@ def main():
             _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(tabd.ptr), tb.ctypes.data_as(C.c_void_p), tb.nbytes))
             stream = C.c_void_p(lib.nxsig_get_stream(ctx.handle))
             mix = lambda: diag.nxdiag_stft_mix(stream, C.c_void_p(xd.ptr), C.c_void_p(zd.ptr), C.c_void_p(tabd.ptr), B, L, HOP, 2)  # noqa: E731
-            for _ in range(10):
+            for _ in range(0 if args.dry else 10):
                 mix()
             ctx.sync()
             ctx.timer_lap()
-            for _ in range(20):
+            for _ in range(1 if args.dry else 20):
                 mix()
                 ctx.timer_lap()
             mlaps = ctx.timer_laps()
@@ -912,7 +974,7 @@ def main():
     if not args.no_secondary:
         sec = secondary_rooflines(ctx, lib, S, _lib, C, barrier=barrier if world > 1 else None, seconds3=args.istft_seconds,
                                   seconds45=args.secondary_seconds, channels45=args.secondary_channels, settle_cap=args.precondition,
-                                  yard=yard if isinstance(yard, dict) and "error" not in yard else None)
+                                  yard=yard if isinstance(yard, dict) and "error" not in yard else None, dry=args.dry, mem=mem)
         sec.pop("_z4", None)
         if world > 1:
             try:
@@ -923,10 +985,20 @@ def main():
         ch = args.assembly_channels if args.assembly_channels is not None else (1 if args.share_gpu else args.secondary_channels)
         secs = min(args.secondary_seconds, 60) if (args.share_gpu and args.assembly_channels is None) else args.secondary_seconds
         try:
-            assembly4 = assembly_config4(ctx, group, lib, S, _lib, C, world, rank, ch, secs, args.share_gpu)
+            assembly4 = assembly_config4(ctx, group, lib, S, _lib, C, world, rank, ch, secs, args.share_gpu, mem=mem, reps=1 if args.dry else 3)
         except Exception as e:  # noqa: BLE001
             assembly4 = {"error": repr(e)[:200]}
 
+    mem.sample("end")
+    memrep = mem.report()
+    per_rank_hw = None
+    if world > 1 and memrep is not None and world <= 64:
+        mine = [0.0] * world
+        mine[rank] = memrep["high_water_GiB"]
+        try:
+            per_rank_hw = [round(v, 2) for v in group.allreduce(mine, "max")] if group is not None else None   # (the file control plane carries 4 doubles)
+        except Exception:  # noqa: BLE001
+            per_rank_hw = None
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -976,7 +1048,10 @@ def main():
             "value_cold_note": "frames/s of the first 20 launches (after the one table-building call) following the idle period of the input upload, before any pre-conditioning "
                                "(what a caller that issues a handful of calls from idle sees); `value` is the settled rate",
             "precondition": precondition,
-            "comm": ({"backend": "RCCL via libnxsig.so (ncclCommInitRank)", "world": world, "torch": False} if group is not None
+            "dry": bool(args.dry),
+            "preflight": {"memory_rank0": memrep, "high_water_GiB_per_rank": per_rank_hw, "rccl": rccl_info(lib, C) if ("RANK" in os.environ or args.dry) else None,
+                          "note": "dry run: one launch of every block, no settling — the figures above are NOT measurements" if args.dry else None},
+            "comm": ({"backend": "RCCL via libnxsig.so (ncclCommInitRank)", "world": world, "torch": False, "rccl": rccl_info(lib, C)} if group is not None
                      else ({"backend": "file control plane (RCCL group creation failed)", "world": world, "torch": False,
                             "error": comm_error} if comm_error else None)),
             "single_stream": single,

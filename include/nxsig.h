@@ -121,6 +121,8 @@ int nxsig_free(nxsig_ctx* ctx, void* dptr);
 int nxsig_upload(nxsig_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);   /* synchronous */
 int nxsig_download(nxsig_ctx* ctx, void* dst_host, const void* src_device, size_t bytes); /* synchronous */
 int nxsig_sync(nxsig_ctx* ctx);                       /* wait for everything enqueued on the ctx stream */
+/* free / total memory of the context's GPU right now (hipMemGetInfo): bench.py's preflight reads the high-water mark off it */
+int nxsig_mem_info(nxsig_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int nxsig_set_stream(nxsig_ctx* ctx, void* hip_stream); /* adopt a caller-owned hipStream_t (NULL = own stream) */
 void* nxsig_get_stream(nxsig_ctx* ctx);
 /* HIP-event stopwatch on the ctx stream (used by bench.py: events live on the stream the kernels run on) */
@@ -444,6 +446,10 @@ int32_t nxsig_group_local_count(const nxsig_group* g);  /* members driven by thi
 int32_t nxsig_group_rank(const nxsig_group* g, int32_t local_index);   /* global rank of a local member */
 nxsig_ctx* nxsig_group_ctx(nxsig_group* g, int32_t local_index);       /* its context (owned by the group) */
 int32_t nxsig_group_has_rccl(const nxsig_group* g);     /* 1 when the members hold RCCL communicators */
+/* The RCCL library the groups of this process dlopen()ed (group.cpp looks for NXSIG_RCCL_LIB, librccl.so.1, /opt/rocm/lib/librccl.so.1,
+ * librccl.so in that order — a process that imported torch finds torch's bundled copy first): *version = ncclGetVersion's code
+ * (e.g. 22606 = 2.26.6; 0: no library / no such symbol), path_buf = the shared object's path.  Loads the library if nobody has yet. */
+int nxsig_rccl_info(int32_t* version, char* path_buf, size_t buflen);
 /* waits for every local stream, then (RCCL) all-reduces one word across the group and waits again */
 int nxsig_group_barrier(nxsig_group* g);
 /* element-wise reduction of `n` (<= 64) host doubles over the PROCESSES of the group; op 0 = max, 1 = sum */

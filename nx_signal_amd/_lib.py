@@ -134,6 +134,8 @@ SIGNATURES = {
     "nxsig_group_rank": (_i32, [_p, _i32]),
     "nxsig_group_ctx": (_p, [_p, _i32]),
     "nxsig_group_has_rccl": (_i32, [_p]),
+    "nxsig_rccl_info": (C.c_int, [C.POINTER(_i32), C.c_char_p, _sz]),
+    "nxsig_mem_info": (C.c_int, [_p, C.POINTER(_sz), C.POINTER(_sz)]),
     "nxsig_group_barrier": (C.c_int, [_p]),
     "nxsig_group_allreduce_f64": (C.c_int, [_p, C.POINTER(_f64), _i32, _i32]),
     "nxsig_group_allgather": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_i64), C.POINTER(_p)]),

@@ -631,6 +631,17 @@ int nxsig_sync(nxsig_ctx* ctx) {
   NXSIG_API_END
 }
 
+int nxsig_mem_info(nxsig_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  size_t f = 0, t = 0;
+  NXSIG_HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
 int nxsig_set_stream(nxsig_ctx* ctx, void* hip_stream) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)

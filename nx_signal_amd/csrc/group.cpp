@@ -392,6 +392,25 @@ nxsig_ctx* nxsig_group_ctx(nxsig_group* g, int32_t i) {
   Group* G = reinterpret_cast<Group*>(g);
   return (G && i >= 0 && i < (int)G->m.size()) ? G->m[i].ctx : nullptr;
 }
+int nxsig_rccl_info(int32_t* version, char* path_buf, size_t buflen) {
+  NXSIG_API_BEGIN
+  if (version) *version = 0;
+  if (path_buf && buflen) path_buf[0] = 0;
+  Rccl* R = rccl();
+  if (!R) return set_error(NXSIG_ERR_UNSUPPORTED, "RCCL could not be loaded: " + rccl_error());
+  typedef ncclResult_t (*GetVersionFn)(int*);
+  GetVersionFn gv = reinterpret_cast<GetVersionFn>(dlsym(R->handle, "ncclGetVersion"));
+  int v = 0;
+  if (gv && gv(&v) == ncclSuccess && version) *version = v;
+  Dl_info info;
+  if (path_buf && buflen && dladdr(reinterpret_cast<void*>(R->AllReduce), &info) && info.dli_fname) {
+    std::strncpy(path_buf, info.dli_fname, buflen - 1);
+    path_buf[buflen - 1] = 0;
+  }
+  return NXSIG_OK;
+  NXSIG_API_END
+}
+
 int32_t nxsig_group_has_rccl(const nxsig_group* g) { return g && reinterpret_cast<const Group*>(g)->has_rccl ? 1 : 0; }
 
 int nxsig_group_barrier(nxsig_group* grp) {

@@ -93,6 +93,31 @@ def test_gpus_n_self_spawns_and_measures_configs_4_and_5(n):
 
 
 @pytest.mark.gpu
+def test_dry_preflight_allocates_and_launches_everything_once():
+    """`bench.py --gpus 2 --dry`: the whole N-GPU run in one pass — same buffers, the RANKED group, one launch of
+    every block, both assemblies — and a line that says so: dry: true, per-rank memory high-water marks, the RCCL actually loaded"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
+    small = [a for a in SMALL if a not in ("--no-verify",)]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dry"] + small, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["dry"] is True and d["n_gpus"] == 2 and d["steps"] == 1
+    pf = d["preflight"]
+    assert len(pf["high_water_GiB_per_rank"]) == 2 and all(v > 0 for v in pf["high_water_GiB_per_rank"])
+    assert pf["memory_rank0"]["high_water_GiB"] > 0 and "config 4 buffers" in pf["memory_rank0"]["after_GiB_in_use"]
+    assert pf["rccl"]["loaded"] and pf["rccl"]["version_code"] > 20000 and "rccl" in pf["rccl"]["path"]
+    assert d["comm"]["rccl"]["version"] == pf["rccl"]["version"]
+    for k in ("roofline_istft", "roofline_stft2048", "roofline_fir"):
+        assert "error" not in d[k] and d[k]["kernel_us"]["n"] == 1, d[k]
+    assert d["assembly_config4"]["own_shard_intact"] and d["assembly"]["own_shard_intact"]
+    assert d["verify"]["max_norm_err"] < 1e-5
+
+
+@pytest.mark.gpu
 def test_driver_launch_line_four_ranks_share_gpu():
     """the driver's own launch line at world 4 on one device"""
     pytest.importorskip("torch")

@@ -445,6 +445,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   constexpr int NST = HQP ? 4 : STG;       // 16-byte loads per lane
   constexpr int PADF = 32 / J;             // floats of padding per block (HQP)
   constexpr int BLK = (MODE == kModeQuad ? K / J : K) / 2;   // block = 2 hop = fft_length / 2 floats (HQP)
+  constexpr bool HALFW = MODE == kModeReal2x;   // the untangle's 1/2 rides in the staged window (see stage_tables)
   constexpr bool MEL = SINK == kSinkMel;   // |X|^2 -> LDS -> sparse mel filterbank -> log10
   constexpr bool MAG = SINK == kSinkMag;   // |X| or |X|^2 of the bins below fft_length / 2 straight to HBM as f32
   constexpr int P = K / 64;     // complex points per lane
@@ -469,7 +470,12 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   int* s_off = reinterpret_cast<int*>(s_csr + (MEL ? mp->nnz : 0));
   int* s_lo = s_off + (MEL ? mp->mel_bins + 1 : 0);
   auto stage_tables = [&]() {
-    for (int i = tid; i < KOUT; i += kWaveThreads) s_w[i] = a.wtab[i];
+    // the window travels HALVED (round 5): the 1/2 of the Hermitian untangle XA = (Z + conj Z') / 2 rides in the window — an exact power of
+    // two, so (x w / 2) and every butterfly sum downstream are the same bits scaled by 1/2 (underflow aside: |x w| < 2^-125, far
+    // below the 1e-10 clean-up threshold) — and the drains lose four packed multiplies per bin group (32 of ~660 VALU per frame pair)
+    // Real-2x front-end only (A/B against the previous build, tools/ab_libs.py: config 4's shard +2.2 %; the pair kernel's schedule
+    // LOST 1 % to the same change and keeps its multiplies)
+    for (int i = tid; i < KOUT; i += kWaveThreads) s_w[i] = HALFW ? a.wtab[i] * 0.5f : a.wtab[i];
     for (int i = tid; i < 256; i += kWaveThreads) s_twB[i] = a.twB[i];
     for (int i = tid; i < R3 * 256; i += kWaveThreads) s_twC[i] = a.twC[i];
     if (MODE == kModeReal2x)
@@ -841,9 +847,10 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
         p1.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src1, __float_as_int(zz[1][NQ - 1 - q].y)));
         if (lane == 0) p0 = own0;
         const v2f z0 = zz[0][q], z1 = zz[1][q];
-        // XA = ((a + c), (b - d)) / 2 ; XB = ((b + d), (c - a)) / 2   with Z = a + ib, Z[K-k] = c + id
-        v4f xa = v4f{z0.x + p0.x, z0.y - p0.y, z1.x + p1.x, z1.y - p1.y} * 0.5f;
-        v4f xbv = v4f{z0.y + p0.y, p0.x - z0.x, z1.y + p1.y, p1.x - z1.x} * 0.5f;
+        // XA = ((a + c), (b - d)) / 2 ; XB = ((b + d), (c - a)) / 2   with Z = a + ib, Z[K-k] = c + id (Z arrives halved)
+        v4f xa = v4f{z0.x + p0.x, z0.y - p0.y, z1.x + p1.x, z1.y - p1.y};
+        v4f xbv = v4f{z0.y + p0.y, p0.x - z0.x, z1.y + p1.y, p1.x - z1.x};
+        if (!HALFW) { xa = xa * 0.5f; xbv = xbv * 0.5f; }   // (HALFW: the 1/2 rides in the window, see stage_tables)
         if (MODE == kModeReal2x) {
           // xa = E[k], xbv = O[k] (spectra of the even / odd samples): X[k] = E + w_2K^k O, X[k+K] = E - w_2K^k O
           const v4f t = *reinterpret_cast<const v4f*>(&s_twR[2 * lane + 128 * q]);

@@ -280,6 +280,54 @@ def test_fir_sample_shards_agree_on_non_finite_rows(pair, solo, mode):
         b_.free()
 
 
+@pytest.mark.parametrize("taps", [5, 33, 257, 600, 1025, 2049, 5001])
+@pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
+def test_fir_sample_shards_non_finite_rows_for_every_filter_length(pair, taps, bad):
+    """the exchange reads a member's "row poisoned" flag off the FIRST output of its slice, which relies on "an Inf / NaN
+    sample leaves no finite output in its row" holding in EVERY kernel family a slice can take — the 32-point kernel (short filters),
+    the 1024- / 2048-point overlap-save kernels, the edge kernels and the single-transform path beyond 4096 taps — and for Inf as well
+    as NaN.  One bad sample in the second member's span, far from the seam: every member's slice of that row must come out
+    non-finite from end to end, the clean rows must equal the unsharded filter, and the next clean call must be clean."""
+    L = 60000
+    x = np.stack([O.synth_signal(L, seed=430 + c) for c in range(2)])
+    xp = x.copy()
+    xp[1, L - 2000] = bad
+    h = S.filters.firwin(taps, [4000.0], sampling_rate=48000)
+    full = S.filters.fir(xp, h, mode="same")
+    assert np.isfinite(full[0]).all() and not np.isfinite(full[1]).any()
+    got = sharding.fir_sharded(pair, xp, h, mode="same", axis="samples")
+    assert np.isfinite(got[0]).all() and not np.isfinite(got[1]).any(), (taps, bad)
+    assert float(np.max(np.abs(got[0] - full[0])) / np.max(np.abs(full[0]))) < 1e-5
+    clean = sharding.fir_sharded(pair, x, h, mode="same", axis="samples")
+    assert np.isfinite(clean).all()
+
+
+def test_fir_sample_shards_with_an_empty_part_leave_no_stale_flags():
+    """with more members than outputs some parts are empty (out_len == 0).  Their flags hold the group maximum after the
+    all-reduce and used to stay set in the context's scratch: the next unrelated FIR call on that context then turned rows NaN."""
+    g = sharding.Group.local(8, devices=[0] * 8)
+    try:
+        h = np.array([0.25, 0.5, 0.25], np.float32)
+        x = np.array([[1.0, np.nan, 3.0, 4.0, 5.0], [1.0, 2.0, 3.0, 4.0, 5.0]], np.float32)   # 5 outputs over 8 members: 3 empty parts
+        got = sharding.fir_sharded(g, x, h, mode="same", axis="samples")
+        assert not np.isfinite(got[0]).any() and np.isfinite(got[1]).all()
+        spans = [sharding.shard_fir(5, 3, 8, r, "same") for r in g.ranks]
+        assert any(n1 == n0 for n0, n1, _, _ in spans)
+        ins = [g.contexts[i].to_device(np.ascontiguousarray(x[:, s0:s1])) if s1 > s0 else g.contexts[i].empty((2, 0), np.float32) for i, (_, _, s0, s1) in enumerate(spans)]
+        outs = sharding.fir_sharded(g, ins, h, mode="same", axis="samples", length=5, batch=2)
+        for (n0, n1, _, _), o in zip(spans, outs):
+            if n1 > n0:
+                part = o.numpy()
+                assert not np.isfinite(part[0]).any() and np.isfinite(part[1]).all()
+        # every member's context is clean afterwards: an ordinary FIR call on it returns finite rows
+        ref = np.stack([O.synth_signal(4000, seed=440 + c) for c in range(2)])
+        for c in g.contexts:
+            y = S.filters.fir(c.to_device(ref), h, mode="same", ctx=c).numpy()
+            assert np.isfinite(y).all()
+    finally:
+        g.close()
+
+
 @pytest.mark.parametrize("N,hop,M,scaling", [
     (1024, 256, 61, None), (1024, 512, 40, "spectrum"), (1024, 1024, 9, None), (512, 128, 77, None), (2048, 512, 23, "psd"),
     (256, 64, 130, None), (400, 160, 51, None), (96, 24, 45, None), (1024, 256, 3, None),

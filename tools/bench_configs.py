@@ -218,6 +218,30 @@ def main():
         gbs = batch * M * bpf / (ms * 1e-3) / 1e9
         print(json.dumps({"case": "istft N=1024 hop=256, 16 x 60 s (config 3 batched)", "ms": ms, "frames_per_s": batch * M / (ms * 1e-3),
                           "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / PEAK}), flush=True)
+    if "inv2048" in which:
+        # the inverse of BASELINE config 4's shard: 8 channels x 600 s, N = 2048 hop = 512 (7.4 GB of spectrum in, 1.8 GB out) and the
+        # round trip stft -> istft on interior samples (size-independent property)
+        N, hop, L, batch = 2048, 512, 28800000, 8
+        w = S.windows.hann(N)
+        M = (L - N) // hop + 1
+        xd = ctx.empty((batch, L), np.float32)
+        fill_normal(ctx, xd, (batch, L), 11)
+        zd, _, _ = S.stft(xd, w, overlap_length=N - hop, fft_length=N, sampling_rate=48000)
+        out_len = M * hop + N - hop
+        yd = ctx.empty((batch, out_len), np.complex64)
+        p = _lib.StftParams(N, hop, N, 0, 0, 0, _lib.SCALE_NONE, 0, 48000.0)
+        wp = w.ctypes.data_as(C.c_void_p)
+        fn = lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(zd.ptr), M, batch, wp, C.byref(p), C.c_void_p(yd.ptr), _lib.DEVICE))
+        ms = timeit(ctx, fn, reps=10, warm=10)
+        bpf = N * 8 + hop * 8
+        gbs = batch * M * bpf / (ms * 1e-3) / 1e9
+        chk = np.empty(8192, np.complex64)
+        ref = np.empty(8192, np.float32)
+        _lib.check(lib.nxsig_download(ctx.handle, chk.ctypes.data_as(C.c_void_p), C.c_void_p(yd.ptr + 8 * (3 * out_len + 1234567)), chk.nbytes))
+        _lib.check(lib.nxsig_download(ctx.handle, ref.ctypes.data_as(C.c_void_p), C.c_void_p(xd.ptr + 4 * (3 * L + 1234567)), ref.nbytes))
+        print(json.dumps({"case": "istft N=2048 hop=512, 8 ch x 600 s (the inverse of config 4's shard)", "ms": ms, "frames_per_s": batch * M / (ms * 1e-3),
+                          "algorithmic_GBps": gbs, "frac_of_8TBps": gbs / PEAK,
+                          "roundtrip_max_err": float(np.max(np.abs(chk.real - ref)) / np.max(np.abs(ref)))}), flush=True)
     for name in which:
         if name.startswith("fir") and name != "fir":  # e.g. fir1025: other filter lengths on the config 5 shard
             taps = int(name[3:])

@@ -32,6 +32,7 @@ UNITS = [
     ("kernels_wave_mel.hip", []),
     ("kernels_wave_mag.hip", []),
     ("kernels_wave_r20.hip", []),
+    ("kernels_wave_rab.hip", []),   # composite fft lengths 320 / 480 / 640 / 960 (round 5)
     ("kernels_wave_8k.hip", []),
     ("kernels_wave_rows.hip", []),
     ("kernels_wave_fir32.hip", []),

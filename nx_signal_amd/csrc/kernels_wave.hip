@@ -1012,6 +1012,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
 }
 
 int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_r20.hip
+int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled);                           // kernels_wave_rab.hip
 int launch_stft_wave_8k(Ctx* c, const StftLaunch& s, bool* handled);                      // kernels_wave_8k.hip
 
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
@@ -1036,6 +1037,10 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   if (s.K == 400) {  // 20 x 20 native kernel (kernels_wave_r20.hip)
     int rc20 = launch_stft_r20(c, s, handled, nullptr);
     if (rc20 || *handled) return rc20;
+  }
+  if (s.K == 320 || s.K == 480 || s.K == 640 || s.K == 960) {  // A x B native kernels (kernels_wave_rab.hip)
+    int rcab = launch_stft_rab(c, s, handled);
+    if (rcab || *handled) return rcab;
   }
   if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !tune(c, kT_DISABLE_BLUE_WAVE, 0)) {
     *handled = true;  // non-power-of-two: Bluestein through the 1024- (Kb <= 512) or 2048-point core

@@ -11,7 +11,7 @@
 //   20 x 20 transpose through LDS (row stride 21: conflict-free both ways)
 //   pass B   lane k1: DFT20 over n2 -> U[k1 + 20 k2]
 //   natural-order U in LDS -> untangle XA = (U + conj U')/2, XB = -i (U - conj U')/2 -> 16-byte stores (:129)
-#include "wave_stft.hpp"
+#include "small_dft.hpp"   // dft5 / dft20 codelets (shared with kernels_wave_rab.hip)
 
 namespace nxsig {
 
@@ -30,34 +30,6 @@ struct R20Args {
   int* gmax;
   int32_t mag_kind;
 };
-
-// 5-point DFT, forward (e^{-2 pi i ..})
-__device__ __forceinline__ void dft5(v2f& x0, v2f& x1, v2f& x2, v2f& x3, v2f& x4) {
-  const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f, s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
-  const v2f a1 = x1 + x4, a2 = x2 + x3, b1 = x1 - x4, b2 = x2 - x3;
-  const v2f t1 = x0 + a1 * c1 + a2 * c2, t2 = x0 + a1 * c2 + a2 * c1;
-  const v2f u1 = b1 * s1 + b2 * s2, u2 = b1 * s2 - b2 * s1;
-  x0 = x0 + a1 + a2;
-  x1 = add_mi(t1, u1); x4 = add_pi(t1, u1);
-  x2 = add_mi(t2, u2); x3 = add_pi(t2, u2);
-}
-
-// 20-point DFT in natural order, prime-factor 4 x 5: n = (5 n1 + 4 n2) mod 20, k = (5 k1 + 16 k2) mod 20, no twiddles
-__device__ __forceinline__ void dft20(v2f* v) {
-  v2f A[4][5];
-#pragma unroll
-  for (int n2 = 0; n2 < 5; ++n2) {
-    v2f c0 = v[(4 * n2) % 20], c1 = v[(5 + 4 * n2) % 20], c2 = v[(10 + 4 * n2) % 20], c3 = v[(15 + 4 * n2) % 20];
-    dft4<false>(c0, c1, c2, c3);
-    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2; A[3][n2] = c3;
-  }
-#pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1) {
-    dft5(A[k1][0], A[k1][1], A[k1][2], A[k1][3], A[k1][4]);
-#pragma unroll
-    for (int k2 = 0; k2 < 5; ++k2) v[(5 * k1 + 16 * k2) % 20] = A[k1][k2];
-  }
-}
 
 // SINK: kSinkSpectrum (c64 rows of 400 bins), kSinkMel (log-mel of the bins below 200), kSinkMag (|X| / |X|^2 of them)
 template <bool SCALE, int W, int SINK>

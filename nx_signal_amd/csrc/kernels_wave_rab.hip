@@ -1,0 +1,266 @@
+// Wave kernels, part 5 (round 5): composite fft lengths A x B computed natively — 320 = 16 x 20, 480 = 24 x 20, 640 = 32 x 20,
+// 960 = 32 x 30: the 10 / 20 / 30 / 40 ms frames of 16 / 32 / 48 kHz audio (NxSignal.stft, lib/nx_signal.ex:94-102 with
+// fft_length: 320 ...).  The Bluestein kernel pays two 1024- or 2048-point transforms per frame pair for these lengths (0.14 of the
+// HBM roofline); this is kernels_wave_r20.hip's two-pass scheme with the two factors free:
+//
+//   one K = A B point complex FFT on max(A, B) lanes: Cooley-Tukey n = B n1 + n2, k = k1 + A k2
+//   raw samples of the unit's 2 T frames (one contiguous span) -> LDS                       16-byte loads when aligned and inside
+//   pass A   lane n2 < B: DFT_A over n1 of u[B n1 + n2] (frame slice x window fused, :94-101), x W_K^(n2 k1)
+//   A x B transpose through LDS (row stride B + 1)
+//   pass B   lane k1 < A: DFT_B over n2 -> U[k1 + A k2]
+//   natural-order U in LDS -> untangle XA = (U + conj U') / 2, XB = -i (U - conj U') / 2 -> 16-byte stores (:129)
+//
+// T = 64 / max(A, B) transforms per wave (3, 2, 2, 2), two real frames per transform as re / im, the small DFTs are register codelets
+// without internal twiddles (small_dft.hpp: 16 = 4 x 4, 20 = 4 x 5, 24 = 3 x 8 and 30 = 5 x 6 prime-factor, 32 = 2 x 16).
+// Measured (tools/bench_configs.py gen<N>, 16 rows, 1.7 GB of output): 0.52 / 0.53 / 0.49 / 0.49 of 8 TB/s against 0.14 through
+// Bluestein; two waves per SIMD (216 ... 256 registers: the 30- / 32-point codelets), LDS-bound on the staging and transposes.  Complex spectrum sink
+// only: the log-mel / magnitude sinks and the inverse of these lengths keep the Bluestein / generic kernels.
+#include "small_dft.hpp"
+
+namespace nxsig {
+
+struct RabArgs {
+  WaveArgs w;              // framing, window (f32[K], zero beyond N), div / has_scale, z; pairs_per_row = ceil(M / 2)
+  const v2f* tw;           // c64[B][A]: W_K^(n2 k1) at [n2 * A + k1]
+  int64_t units_per_row;   // ceil(pairs_per_row / T): a unit = T frame pairs = 2 T frames
+  int64_t total_units;
+};
+
+template <int A, int B, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_stft_rab(RabArgs b) {
+  const WaveArgs& a = b.w;
+  constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT;
+  constexpr int TRS = A * (B + 1);                          // one transform's transposed block (row stride B + 1)
+  constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;   // complex cells per wave: staging (<= 2 BUF floats) / T x TRS / T x KB
+  constexpr int NRS = 10;                                   // 16-byte loads per lane that prefetch a unit's span (<= 2560 floats)
+  float* s_w = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
+  v2f* s_x = s_tw + KB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = b.tw[i]; }
+  __syncthreads();
+  v2f* buf = s_x + wave * BUF;
+  float* S = reinterpret_cast<float*>(buf);
+  const int g = lane / LT, l = lane % LT;         // transform of the unit (g >= T: idle lanes), lane inside it
+  const int nuse = a.N < KB ? a.N : KB;
+  const int span = (2 * T - 1) * a.hop + nuse;
+  const int span4 = (span + 3) & ~3;
+
+  const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
+  int64_t p_end = p_begin + a.chunk;
+  if (p_end > b.total_units) p_end = b.total_units;
+  // the span of a unit that lies inside the stored row (and is 16-byte aligned) is fetched one unit ahead into registers
+  v4f rs[NRS];
+  auto prefetch = [&](int64_t ui) -> bool {
+    const int64_t row = ui / b.units_per_row;
+    const int64_t u = ui - row * b.units_per_row;
+    const int64_t start = 2 * T * u * (int64_t)a.hop - a.lo;
+    const float* p = a.x + (size_t)row * a.batch_stride + start;
+    const bool inside = a.reflect == 0 && start >= 0 && start + span4 <= a.L && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    if (inside) {
+      const v4f* p4 = reinterpret_cast<const v4f*>(p) + lane;
+#pragma unroll
+      for (int c = 0; c < NRS; ++c)
+        if (256 * c + 4 * lane < span4) rs[c] = p4[64 * c];
+    }
+    return inside;
+  };
+  auto stage_slow = [&](const float* xr, int64_t q0) {
+    const int64_t start = q0 - a.lo;
+    if (a.reflect == 0 && start >= 0 && start + span <= a.L) {   // inside the row but not 16-byte aligned: 4-byte loads
+      for (int i = lane; i < span; i += 64) S[i] = xr[start + i];
+    } else {                                                      // padding / mirror / row end: per-sample bounds
+      for (int i = lane; i < span; i += 64) S[i] = fetch_any(xr, a, q0 + i);
+    }
+  };
+  constexpr bool PF = LT < 30;   // register prefetch of the next unit's span (the 30- / 32-point codelets need the registers)
+  bool have = (PF && p_begin + wave < p_end) ? prefetch(p_begin + wave) : false;
+  for (int64_t ui = p_begin + wave; ui < p_end; ui += W) {
+    const int64_t row = ui / b.units_per_row;
+    const int64_t u = ui - row * b.units_per_row;
+    const float* xr = a.x + (size_t)row * a.batch_stride;
+    const int64_t q0 = 2 * T * u * (int64_t)a.hop;    // padded-signal index of the unit's first sample
+    // ---- the unit's raw samples -> LDS
+    if (have) {
+#pragma unroll
+      for (int c = 0; c < NRS; ++c)
+        if (256 * c + 4 * lane < span4) *reinterpret_cast<v4f*>(&S[256 * c + 4 * lane]) = rs[c];
+    } else {
+      stage_slow(xr, q0);
+    }
+    wave_lds_fence();
+    have = (PF && ui + W < p_end) ? prefetch(ui + W) : false;   // next unit's samples travel during this unit's transforms
+    const int64_t pair = T * u + g;
+    const bool active = g < T && pair < a.pairs_per_row;
+    const int64_t mA = 2 * pair;
+    const bool haveB = active && (mA + 1 < a.M);
+    v2f v[NV];
+    // pass A input of lane n2 = l: u[B n1 + n2], n1 < A.  sel < 0: the pair rides as frame A + i frame B; sel = 0 / 1: frame A / frame B
+    // ALONE as the real part (solo route of a unit that holds a non-finite sample, see k_stft_r20)
+    auto build = [&](int sel) {
+      const float* fa = S + (2 * (g < T ? g : 0)) * a.hop + l;
+      const float* fb = fa + a.hop;
+#pragma unroll
+      for (int n1 = 0; n1 < A; ++n1) {
+        const int n = B * n1 + l;
+        v2f t = v2f{0.f, 0.f};
+        if (active && l < B && n < nuse) {
+          const float w = s_w[n];
+          const float pa = fa[B * n1] * w, pb = haveB ? fb[B * n1] * w : 0.0f;  // exact f32 products like the reference (:101)
+          t = sel < 0 ? v2f{pa, pb} : v2f{sel == 0 ? pa : pb, 0.0f};
+        }
+        v[n1] = t;
+      }
+    };
+    auto xform_sink = [&](const int sel) {
+      dft_n<A>(v);
+      if (l < B) {
+#pragma unroll
+        for (int k1 = 1; k1 < A; ++k1) {
+          v[k1] = wcmul(v[k1], s_tw[l * A + k1]);
+          if (A > 16 && (k1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      wave_lds_fence();                               // every lane has read its samples: the buffer becomes the exchange
+      if (g < T && l < B) {
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) buf[g * TRS + k1 * (B + 1) + l] = v[k1];
+      }
+      wave_lds_fence();
+      // ---- pass B: lane k1 = l < A: DFT_B over n2
+      if (g < T && l < A) {
+#pragma unroll
+        for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[g * TRS + l * (B + 1) + n2];
+      }
+      dft_n<B>(v);
+      wave_lds_fence();
+      if (g < T && l < A) {
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2) buf[g * KB + l + A * k2] = v[k2];   // U[k1 + A k2] in natural order
+      }
+      wave_lds_fence();
+      // ---- untangle + store.  All 64 lanes walk the T transforms one after the other: lane takes the bin pairs p = lane + 64 i
+      //      (bins 2 p, 2 p + 1), so a wave instruction stores 1 KiB of one frame's row contiguously
+      constexpr int NP = KB / 2, NI = (NP + 63) / 64;
+#pragma unroll
+      for (int gg = 0; gg < T; ++gg) {
+        const int64_t pr = T * u + gg;
+        const bool act = pr < a.pairs_per_row;                 // wave-uniform
+        const int64_t m0 = 2 * pr;
+        const bool hb = act && (m0 + 1 < a.M);
+        const v2f* U = buf + gg * KB;
+        v2f* zA = a.z + ((size_t)row * a.M + m0) * KB;
+        v2f* zB = zA + KB;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int pi = lane + 64 * i;
+          if (act && pi < NP) {
+            const int k = 2 * pi;
+            const v4f uu = *reinterpret_cast<const v4f*>(&U[k]);
+            const v2f p0 = U[k == 0 ? 0 : KB - k], p1 = U[KB - 1 - k];
+            v4f xa = fft_eps0(v4f{uu.x + p0.x, uu.y - p0.y, uu.z + p1.x, uu.w - p1.y} * 0.5f);  // Nx.fft's clean-up (:102)
+            v4f xv = fft_eps0(v4f{uu.y + p0.y, p0.x - uu.x, uu.w + p1.y, p1.x - uu.z} * 0.5f);
+            if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
+            const bool stA = sel <= 0, stB = hb && sel != 0;      // solo rounds: the transform's real part is frame A (sel 0) / B (sel 1)
+            if (sel == 1) xv = xa;
+            if (stA) __builtin_nontemporal_store(xa, (gv4f*)(zA + k));
+            if (stB) __builtin_nontemporal_store(xv, (gv4f*)(zB + k));
+          }
+        }
+      }
+    };
+    // ---- non-finite samples: the reference transforms every frame alone (lib/nx_signal.ex:94-102), so an Inf / NaN reaches only the
+    // frames that contain it.  A unit whose windowed samples are not all finite leaves the paired route: its frames A, then (samples
+    // re-staged) its frames B, ride alone as real parts.
+    build(-1);
+    bool solo = false;
+    {
+      v2f t = v[0];
+#pragma unroll
+      for (int n1 = 1; n1 < A; ++n1) t += v[n1];
+      const bool nf = ((__float_as_uint(t.x) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(t.y) & 0x7f800000u) == 0x7f800000u);
+      solo = __builtin_amdgcn_ballot_w64(nf) != 0;
+    }
+    if (solo) {
+#pragma nounroll
+      for (int sel = 0; sel < 2; ++sel) {
+        if (sel == 1) {
+          wave_lds_fence();      // round A's partner reads are done
+          stage_slow(xr, q0);    // the exchange overwrote the samples
+          wave_lds_fence();
+        }
+        build(sel);
+        xform_sink(sel);
+      }
+    } else {
+      xform_sink(-1);
+    }
+    wave_lds_fence();  // all reads of the buffer are done before the next unit's samples overwrite it
+  }
+}
+
+template <int A, int B>
+static int launch_rab(Ctx* c, const StftLaunch& s, bool* handled) {
+  constexpr int W = 4, KB = A * B, LT = A > B ? A : B, T = 64 / LT;
+  constexpr int TRS = A * (B + 1);
+  constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
+  const int nuse = s.fr.N < KB ? s.fr.N : KB;
+  const int64_t span = (2 * T - 1) * (int64_t)s.fr.hop + nuse;
+  if (span + 3 > 2 * BUF || span + 3 > 2560) return NXSIG_OK;   // the unit's span must fit the wave's buffer and the prefetch registers
+  *handled = true;
+  RabArgs b;
+  WaveArgs& a = b.w;
+  a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
+  a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
+  a.pairs_per_row = (s.fr.M + 1) / 2;
+  a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
+  a.twB = a.twC = a.twR = nullptr; a.dummy = nullptr; a.wtab = s.window_padK;
+  a.units_per_row = 0; a.u_split = 0; a.u_add0 = 0; a.u_add1 = 0;
+  b.units_per_row = (a.pairs_per_row + T - 1) / T;
+  b.total_units = b.units_per_row * s.batch;
+  a.total_pairs = b.total_units;
+  const uint64_t key = 0x2AB000000000ull ^ ((uint64_t)A << 16) ^ (uint64_t)B;
+  auto hit = c->memo.find(key);
+  if (hit != c->memo.end()) b.tw = reinterpret_cast<const v2f*>(hit->second[0]);
+  else {
+    std::vector<float2> tw((size_t)KB);
+    for (int n2 = 0; n2 < B; ++n2)
+      for (int k1 = 0; k1 < A; ++k1) {
+        const double ang = -6.283185307179586476925286766559 * (double)(n2 * k1) / (double)KB;
+        tw[(size_t)n2 * A + k1] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      }
+    const void* dt = nullptr;
+    int rc = ctx_table(c, 0x2AB0ull ^ ((uint64_t)A << 16) ^ (uint64_t)B, tw.data(), tw.size() * sizeof(float2), &dt);
+    if (rc) return rc;
+    c->memo[key] = {reinterpret_cast<uint64_t>(dt)};
+    b.tw = reinterpret_cast<const v2f*>(dt);
+  }
+  a.chunk = (int64_t)W * 4;   // four units per wave (two: -1 ... -3 %), short-lived workgroups (the geometry of kernels_wave_r20.hip)
+  const int64_t blocks = (b.total_units + a.chunk - 1) / a.chunk;
+  if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
+  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)W * BUF * 8;
+  auto go = [&](auto kernel) -> int {
+    if (lds > 64 * 1024)
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, b);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  };
+  return s.has_scale ? go(k_stft_rab<A, B, true, W>) : go(k_stft_rab<A, B, false, W>);
+}
+
+// fft_length 320 / 480 / 640 / 960 (complex spectrum sink); handled = false: the caller falls through to the Bluestein kernel
+int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled) {
+  *handled = false;
+  if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_RAB, 0) || tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
+  switch (s.K) {
+    case 320: return launch_rab<16, 20>(c, s, handled);
+    case 480: return launch_rab<24, 20>(c, s, handled);   // (16 x 30 measured 0.45 of the roofline against 0.51: half of its pass-B lanes idle)
+    case 640: return launch_rab<32, 20>(c, s, handled);
+    case 960: return launch_rab<32, 30>(c, s, handled);
+    default: return NXSIG_OK;
+  }
+}
+
+}  // namespace nxsig

@@ -1,0 +1,128 @@
+// Small natural-order DFT codelets on registers (forward transform, e^{-2 pi i ..}) for the two-pass wave kernels of composite
+// fft lengths (kernels_wave_r20.hip: 400 = 20 x 20; kernels_wave_rab.hip: 320 = 16 x 20, 480 = 24 x 20, 640 = 32 x 20, 960 = 32 x 30).
+// Coprime factors are joined by the prime-factor (Good-Thomas) index maps — n = (N2 n1 + N1 n2) mod N in, k = (N2 (N2^-1 mod N1) k1
+// + N1 (N1^-1 mod N2) k2) mod N out, no twiddles in between; dft32 is one radix-2 step over two dft16 (wave_stft.hpp).  Index maps
+// checked against numpy in tools/emulate_wave_fft.py-style scripts (round 5) and end to end by the parity tests of the kernels.
+#pragma once
+#include "wave_stft.hpp"
+
+namespace nxsig {
+
+// 3-point DFT: X1 = m - i s (x1 - x2), X2 = m + i s (x1 - x2), m = x0 - (x1 + x2) / 2, s = sin(2 pi / 3)
+__device__ __forceinline__ void dft3(v2f& x0, v2f& x1, v2f& x2) {
+  const float s = 0.86602540378443865f;
+  const v2f t = x1 + x2, u = (x1 - x2) * s;
+  const v2f m = x0 - t * 0.5f;
+  x0 = x0 + t;
+  x1 = add_mi(m, u);
+  x2 = add_pi(m, u);
+}
+
+// 5-point DFT
+__device__ __forceinline__ void dft5(v2f& x0, v2f& x1, v2f& x2, v2f& x3, v2f& x4) {
+  const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f, s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+  const v2f a1 = x1 + x4, a2 = x2 + x3, b1 = x1 - x4, b2 = x2 - x3;
+  const v2f t1 = x0 + a1 * c1 + a2 * c2, t2 = x0 + a1 * c2 + a2 * c1;
+  const v2f u1 = b1 * s1 + b2 * s2, u2 = b1 * s2 - b2 * s1;
+  x0 = x0 + a1 + a2;
+  x1 = add_mi(t1, u1); x4 = add_pi(t1, u1);
+  x2 = add_mi(t2, u2); x3 = add_pi(t2, u2);
+}
+
+// 6-point DFT, prime-factor 2 x 3: n = (3 n1 + 2 n2) mod 6, k = (3 k1 + 4 k2) mod 6
+__device__ __forceinline__ void dft6(v2f* v) {
+  v2f A0[3], A1[3];
+#pragma unroll
+  for (int n2 = 0; n2 < 3; ++n2) {
+    const v2f a = v[(2 * n2) % 6], b = v[(3 + 2 * n2) % 6];
+    A0[n2] = a + b; A1[n2] = a - b;
+  }
+  dft3(A0[0], A0[1], A0[2]);
+  dft3(A1[0], A1[1], A1[2]);
+#pragma unroll
+  for (int k2 = 0; k2 < 3; ++k2) { v[(4 * k2) % 6] = A0[k2]; v[(3 + 4 * k2) % 6] = A1[k2]; }
+}
+
+// 20-point DFT, prime-factor 4 x 5: n = (5 n1 + 4 n2) mod 20, k = (5 k1 + 16 k2) mod 20
+__device__ __forceinline__ void dft20(v2f* v) {
+  v2f A[4][5];
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) {
+    v2f c0 = v[(4 * n2) % 20], c1 = v[(5 + 4 * n2) % 20], c2 = v[(10 + 4 * n2) % 20], c3 = v[(15 + 4 * n2) % 20];
+    dft4<false>(c0, c1, c2, c3);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2; A[3][n2] = c3;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    dft5(A[k1][0], A[k1][1], A[k1][2], A[k1][3], A[k1][4]);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) v[(5 * k1 + 16 * k2) % 20] = A[k1][k2];
+  }
+}
+
+// 24-point DFT, prime-factor 3 x 8: n = (8 n1 + 3 n2) mod 24, k = (16 k1 + 9 k2) mod 24
+__device__ __forceinline__ void dft24(v2f* v) {
+  v2f A[3][8];
+#pragma unroll
+  for (int n2 = 0; n2 < 8; ++n2) {
+    v2f c0 = v[(3 * n2) % 24], c1 = v[(8 + 3 * n2) % 24], c2 = v[(16 + 3 * n2) % 24];
+    dft3(c0, c1, c2);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    dft8<false>(A[k1]);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) v[(16 * k1 + 9 * k2) % 24] = A[k1][k2];
+  }
+}
+
+// 30-point DFT, prime-factor 5 x 6: n = (6 n1 + 5 n2) mod 30, k = (6 k1 + 25 k2) mod 30
+__device__ __forceinline__ void dft30(v2f* v) {
+  v2f A[5][6];
+#pragma unroll
+  for (int n2 = 0; n2 < 6; ++n2) {
+    v2f c0 = v[(5 * n2) % 30], c1 = v[(6 + 5 * n2) % 30], c2 = v[(12 + 5 * n2) % 30], c3 = v[(18 + 5 * n2) % 30], c4 = v[(24 + 5 * n2) % 30];
+    dft5(c0, c1, c2, c3, c4);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2; A[3][n2] = c3; A[4][n2] = c4;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 5; ++k1) {
+    dft6(A[k1]);
+#pragma unroll
+    for (int k2 = 0; k2 < 6; ++k2) v[(6 * k1 + 25 * k2) % 30] = A[k1][k2];
+  }
+}
+
+// 32-point DFT: one radix-2 step over the 16-point transforms of the even and the odd samples, X[k] = E[k] + W_32^k O[k]
+__device__ __forceinline__ void dft32(v2f* v) {
+  constexpr float kC[16] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f, 0.55557023301960218f,
+                            0.38268343236508977f, 0.19509032201612825f, 0.0f, -0.19509032201612825f, -0.38268343236508977f, -0.55557023301960218f,
+                            -0.70710678118654752f, -0.83146961230254524f, -0.92387953251128674f, -0.98078528040323043f};
+  constexpr float kS[16] = {0.0f, 0.19509032201612825f, 0.38268343236508977f, 0.55557023301960218f, 0.70710678118654752f, 0.83146961230254524f,
+                            0.92387953251128674f, 0.98078528040323043f, 1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+                            0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f};
+  v2f e[16], o[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { e[j] = v[2 * j]; o[j] = v[2 * j + 1]; }
+  dft16<false>(e);
+  dft16<false>(o);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const v2f t = k == 0 ? o[0] : (k == 8 ? rot90<false>(o[8]) : cmulc<false>(o[k], kC[k], -kS[k]));   // W_32^k = (cos, -sin)
+    v[k] = e[k] + t;
+    v[k + 16] = e[k] - t;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void dft_n(v2f* v) {
+  static_assert(N == 16 || N == 20 || N == 24 || N == 30 || N == 32, "no codelet for this length");
+  if constexpr (N == 16) dft16<false>(v);
+  else if constexpr (N == 20) dft20(v);
+  else if constexpr (N == 24) dft24(v);
+  else if constexpr (N == 30) dft30(v);
+  else dft32(v);
+}
+
+}  // namespace nxsig

@@ -27,6 +27,7 @@ CASES = [
     ("NXSIG_DISABLE_WAVE_ROWS=1", ("tests/test_gpu_parity.py tests/test_gpu_nd.py", "fft_rows or wave_core_row or generic_istft")),
     ("NXSIG_DISABLE_BLUE_WAVE=1", ("tests/test_gpu_parity.py tests/test_gpu_tuned_kernels.py", "non_power_of_two or bluestein")),
     ("NXSIG_DISABLE_R20=1", ("tests/test_gpu_parity.py tests/test_gpu_tuned_kernels.py", "non_power_of_two or r20")),
+    ("NXSIG_DISABLE_RAB=1", ("tests/test_gpu_parity.py tests/test_gpu_tuned_kernels.py", "non_power_of_two or composite")),
     ("NXSIG_DISABLE_8K=1", ("tests/test_gpu_tuned_kernels.py", "8192")),
     ("NXSIG_DISABLE_4K=1", ("tests/test_gpu_tuned_kernels.py", "4096")),
     ("NXSIG_DISABLE_FUSED_FILTER=1", ISTFT),

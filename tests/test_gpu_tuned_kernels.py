@@ -423,3 +423,63 @@ def test_stft_onesided_equals_the_first_half_of_stft_bit_for_bit(K, N, hop, pad,
     assert np.array_equal(h.view(np.uint32), np.ascontiguousarray(z[..., : K // 2]).view(np.uint32))
     hd, _, _ = S.stft_onesided(S.default_context().to_device(x), w, **opts)
     assert np.array_equal(hd.numpy().view(np.uint32), h.view(np.uint32))
+
+
+@pytest.mark.parametrize("K", [320, 480, 640, 960])
+@pytest.mark.parametrize("shape", ["full", "short_frame", "long_frame", "reflect", "odd_hop", "ragged"])
+def test_stft_composite_lengths_native_kernels(K, shape):
+    """kernels_wave_rab.hip (round 5): fft_length 320 = 16 x 20, 480 = 16 x 30, 640 = 32 x 20, 960 = 32 x 30 on two-pass wave kernels
+    instead of Bluestein.  Against the oracle for: N == K at 75 % overlap, a shorter frame (zero-padded), a longer frame (truncated,
+    lib/nx_signal.ex:102), :reflect padding (edge units through the bounds-checked staging), an odd hop (unaligned spans: 4-byte
+    staging) and ragged frame counts (phantom frames of the last unit); every scaling; and the switch back to Bluestein agrees."""
+    import nx_signal_amd as S
+    from oracle import nx_oracle as O
+
+    rng = np.random.default_rng(K)
+    N, hop, pad, L = K, K // 4, "valid", 7 * K + 13
+    if shape == "short_frame":
+        N = K - 80
+    elif shape == "long_frame":
+        N = K + 64
+    elif shape == "reflect":
+        pad = "reflect"
+    elif shape == "odd_hop":
+        hop = K // 4 + 1
+    elif shape == "ragged":
+        L = 3 * K + hop * 5 + 1
+    x = rng.standard_normal((3, L)).astype(np.float32)
+    w = S.windows.hamming(N)
+    for scaling in (None, "spectrum", "psd"):
+        opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=16000)
+        z, t, f = S.stft(x, w, **opts)
+        zo, to, fo = O.stft(x, w, **opts)
+        assert z.shape == zo.shape
+        assert float(np.max(np.abs(z - zo)) / np.max(np.abs(zo))) < 1e-5, (K, shape, scaling)
+        assert np.array_equal(t, to) and np.array_equal(f, fo)
+    ctx = S.Context(0)
+    native = not ctx.get_tuning("DISABLE_RAB")[0] and not ctx.get_tuning("DISABLE_WAVE")[0]   # (the switch matrix runs this test under them)
+    zt = S.stft(ctx.to_device(x), w, ctx=ctx, **opts)[0].numpy()
+    ctx.set_tuning("NXSIG_DISABLE_RAB", 1)
+    zb = S.stft(ctx.to_device(x), w, ctx=ctx, **opts)[0].numpy()
+    assert not native or not np.array_equal(zt.view(np.uint32), zb.view(np.uint32))        # two different kernels really ran
+    assert float(np.max(np.abs(zt - zb)) / np.max(np.abs(zb))) < 1e-5
+
+
+def test_stft_composite_lengths_non_finite_samples_stay_in_their_frames():
+    """a NaN / Inf sample reaches exactly the frames that contain it (the reference transforms frame by frame): the solo route of the
+    A x B kernels, against the oracle's finite / non-finite pattern"""
+    import nx_signal_amd as S
+    from oracle import nx_oracle as O
+
+    for K in (320, 480, 640, 960):
+        hop = K // 4
+        x = np.random.default_rng(K + 1).standard_normal(12 * K).astype(np.float32)
+        x[5 * K + 7] = np.nan
+        x[9 * K + 1] = np.inf
+        w = S.windows.hann(K)
+        opts = dict(overlap_length=K - hop, fft_length=K, sampling_rate=16000)
+        z = S.stft(x, w, **opts)[0]
+        zo = O.stft(x, w, **opts)[0]
+        bad = ~np.isfinite(zo).all(axis=1)
+        assert bad.sum() >= 6 and np.array_equal(~np.isfinite(z).all(axis=1), bad), K
+        assert float(np.max(np.abs(z[~bad] - zo[~bad])) / np.max(np.abs(zo[~bad]))) < 1e-5

@@ -243,7 +243,9 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
     launched until the clocks have settled (`settle` / `settled_tail`, the headline's rule; at most `settle_cap`
     launches; the first 20 laps are reported as `cold20`), then kernel and no-math traffic model (`mix_ceiling`, tools/diag_mix.hip: the
     same traffic in the kernel's launch geometry) are timed INTERLEAVED — A B A B, 10 laps each after 2 untimed launches — so that
-    `kernel_over_ceiling` compares two series taken under the same clocks.
+    `kernel_over_ceiling` compares two series taken under the same clocks.  The block's own figure (`achieved`, `frac`) is the series of
+    40 laps taken right after the settle loop, before any model launch: the model draws less power than the kernel, and kernel laps that
+    follow it pay a clock excursion of their own (`mix_ceiling.kernel_interleaved` shows them).
     Under a launcher EVERY rank runs this on its own shard (`barrier` lines the ranks up before each of the two blocks so the GPUs
     of the node work at the same time); main() reduces the per-rank kernel times with max-over-ranks."""
     out = {}
@@ -291,6 +293,12 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
     except Exception:
         traffic_tab = {}
 
+    def timed_after_settle(kernel_fn):
+        """the block's number of record: 40 laps right after its own settle loop, nothing else launched in between.  Forty, because the
+        power management of a loaded MI355X hunts with a period of about 20 launches of these kernels (config 4's laps of one run:
+        1425 .. 1539 .. 1423 us over 20 launches, profiles/r05/README.md): a 20-lap window catches an arbitrary part of one cycle."""
+        return measure(kernel_fn, 1 if dry else 40, 0)
+
     def block(workload, kernel, nbytes, laps, extra, pre, traffic_key=None):
         ms, stalled = lap_mean(laps)
         ms_all = float(np.mean(laps))
@@ -300,20 +308,24 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
              "traffic_source": "profiles/traffic.json (PMC passes of tools/profile_bench.sh, not measured in this run)",
              "kernel_ms": ms, "kernel_ms_all_laps": ms_all, "frac_all_laps": nbytes / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
-             "stalled_laps": stalled, "kernel_us": lap_us(laps), "settled": bool(pre.get("settled")), "precondition": pre,
+             "stalled_laps": stalled, "kernel_us": lap_us(laps), "laps_us": [round(v * 1e3, 1) for v in laps], "settled": bool(pre.get("settled")), "precondition": pre,
              "cold20": pre.get("cold20"), "workload": workload, "kernel": kernel, "algorithmic_bytes": nbytes}
         d.update(extra)
         return d
 
-    def ceiling(d, nbytes, mlaps, what, plain_key=None):
-        """the no-math traffic model, timed interleaved with the kernel: same buffers, same stream, same clocks"""
+    def ceiling(d, nbytes, klaps, mlaps, what, plain_key=None):
+        """the no-math traffic model, timed INTERLEAVED with the kernel (A B A B: same buffers, same stream, same clocks): the ratio
+        `kernel_over_ceiling` compares the two interleaved series; `frac` above stays the kernel's own settled series"""
         if not mlaps:
             d["mix_ceiling"] = None
         else:
             ms, stalled = lap_mean(mlaps)
+            kms, kst = lap_mean(klaps)
             gbs = nbytes / (ms * 1e-3) / 1e9
-            d["mix_ceiling"] = {"GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "kernel_over_ceiling": d["achieved"] / gbs, "what": what,
-                                "laps_us": lap_us(mlaps), "stalled_laps": stalled, "interleaved": "A B A B, 10 laps each"}
+            kgbs = nbytes / (kms * 1e-3) / 1e9
+            d["mix_ceiling"] = {"GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "kernel_over_ceiling": kgbs / gbs, "what": what,
+                                "laps_us": lap_us(mlaps), "stalled_laps": stalled, "interleaved": "A B A B, 10 laps each",
+                                "kernel_interleaved": {"frac_of_peak": kgbs / HBM_PEAK_GBS, "laps_us": lap_us(klaps), "stalled_laps": kst}}
         if plain_key and yard.get(plain_key):
             # the geometry-free yardstick of the same read : write ratio, timed in this process by yardsticks()
             d["plain_" + plain_key] = {k: yard[plain_key][k] for k in ("GBps", "frac_of_peak", "what") if k in yard[plain_key]}
@@ -345,11 +357,12 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         ref = np.empty(4096, np.float32)
         _lib.check(lib.nxsig_download(ctx.handle, ref.ctypes.data_as(C.c_void_p), C.c_void_p(x3.ptr + 4 * 100000), ref.nbytes))
         m3 = (lambda: diag.nxdiag_istft_mix(stream, C.c_void_p(z3.ptr), C.c_void_p(y3.ptr), B3 * M3, 8, 3)) if diag is not None else None
-        laps, mlaps = interleaved(k3, m3)
+        laps = timed_after_settle(k3)
+        klaps, mlaps = interleaved(k3, m3)
         out["roofline_istft"] = block(f"config 3: istft N=1024 hop=256, {B3} x {seconds3} s mono 48 kHz, c64 out", "k_istft_wave<1024> (+ k_istft_edge_fix)",
                                       nb3, laps, {"bytes_per_frame": N_FFT * 8 + HOP * 8, "frames": B3 * M3, "frames_per_s": B3 * M3 / (lap_mean(laps)[0] * 1e-3)}, pre, "istft")
         out["roofline_istft"]["roundtrip_max_err"] = float(np.max(np.abs(chk.real - ref)) / np.max(np.abs(ref)))
-        ceiling(out["roofline_istft"], nb3, mlaps,
+        ceiling(out["roofline_istft"], nb3, klaps, mlaps,
                 "tools/diag_mix.hip k_istft_mix: 8 KiB nt-read + 2 KiB nt-written per frame, no math, 8 runs per CU, two frames ahead, 3 halo frames per run", "mix_4to1")
         for b in (x3, z3, y3):
             b.free()
@@ -374,10 +387,11 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         pre = settle(ctx, k4, settle_cap, nb4) if not dry else {"launches": 0, "settled": False, "dry": True}
         tab4 = ctx.to_device(np.zeros(3072, np.float32)) if diag is not None else None
         m4 = (lambda: diag.nxdiag_stft2048_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(z4.ptr), C.c_void_p(tab4.ptr), B4, L4, H4, 8)) if diag is not None else None
-        laps, mlaps = interleaved(k4, m4)
+        laps = timed_after_settle(k4)
+        klaps, mlaps = interleaved(k4, m4)
         out["roofline_stft2048"] = block(f"config 4 (one GPU's shard of 64 channels): stft N=2048 hop=512, {B4} ch x {seconds45} s @48 kHz", "k_stft_wave<1024, real-2x>",
                                          nb4, laps, {"bytes_per_frame": H4 * 4 + N4 * 8, "frames": B4 * M4, "frames_per_s": B4 * M4 / (lap_mean(laps)[0] * 1e-3)}, pre, "stft2048")
-        ceiling(out["roofline_stft2048"], nb4, mlaps,
+        ceiling(out["roofline_stft2048"], nb4, klaps, mlaps,
                 "tools/diag_mix.hip k_stft2048_mix: the real-2x kernel's loads and stores in its launch geometry (8 frames per wave), no math", "mix_1to8")
         if tab4 is not None:
             tab4.free()
@@ -394,10 +408,11 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
             mem.sample("config 5 buffers")
         pre = settle(ctx, k5, settle_cap, B4 * L4 * 8) if not dry else {"launches": 0, "settled": False, "dry": True}
         m5 = (lambda: diag.nxdiag_fir_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(y5.ptr), B4, L4, 8)) if diag is not None else None
-        laps, mlaps = interleaved(k5, m5)
+        laps = timed_after_settle(k5)
+        klaps, mlaps = interleaved(k5, m5)
         out["roofline_fir"] = block(f"config 5 (one GPU's shard): fir 257 taps :same, {B4} ch x {seconds45} s @48 kHz", "nxsig_fir_f32 (stream + edge + poison pass)",
                                     B4 * L4 * 8, laps, {"bytes_per_sample": 8, "samples": B4 * L4, "samples_per_s": B4 * L4 / (lap_mean(laps)[0] * 1e-3)}, pre, "fir")
-        ceiling(out["roofline_fir"], B4 * L4 * 8, mlaps,
+        ceiling(out["roofline_fir"], B4 * L4 * 8, klaps, mlaps,
                 "tools/diag_mix.hip k_fir_mix: the overlap-save stream of k_fir_wave<1024> (two 1024-sample blocks read per 1536 outputs, 8-byte accesses, sc1 nt stores), no math",
                 "mix_1to1")
         x4.free()

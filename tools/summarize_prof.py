@@ -31,7 +31,7 @@ for f in find("trace", "*kernel_trace.csv"):
         by[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         meta[key] = r
     print(f"\n## kernel durations by launch shape ({os.path.relpath(f, root)})")
-    for key, v in sorted(by.items(), key=lambda kv: -sum(kv[1]))[:10]:
+    for key, v in sorted(by.items(), key=lambda kv: ('nxsig::' not in kv[0][0], -sum(kv[1])))[:24]:   # product kernels first, then the models / yardsticks
         v2 = sorted(v)
         r0 = meta[key]
         print(f"  {short(key[0]):64s} grid={key[1]} wg={key[2]} n={len(v)} mean_us={sum(v)/len(v)/1e3:.2f} median_us={v2[len(v2)//2]/1e3:.2f} min_us={v2[0]/1e3:.2f}"
@@ -54,6 +54,6 @@ for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
             if r.get("Counter_Name") == cname:
                 by[(r["Kernel_Name"], r.get("Grid_Size"))].append(float(r["Counter_Value"]))
         print(f"\n## {cname} per dispatch, raw counter (KiB) by launch shape ({os.path.relpath(f, root)})")
-        for key, v in sorted(by.items(), key=lambda kv: -sum(kv[1]))[:8]:
+        for key, v in sorted(by.items(), key=lambda kv: ('nxsig::' not in kv[0][0], -sum(kv[1])))[:24]:
             v2 = sorted(v)
             print(f"  {short(key[0]):64s} grid={key[1]} n={len(v)} median={v2[len(v2)//2]:.1f} KiB  min={v2[0]:.1f} max={v2[-1]:.1f}")

@@ -468,7 +468,8 @@ int nxsig_group_allgather(nxsig_group* g, const void* const* send, const int64_t
  *   mem == NXSIG_HOST  : x[0] is the whole host tensor f32[batch][length], z[0] the whole host result c64[batch][M][K];
  *                        every local member uploads its part, computes it, and the result is assembled either by per-shard
  *                        downloads (gather == 0) or by the RCCL all-gather followed by one download (gather == 1).
- *                        LOCAL groups only.
+ *                        RANKED groups (one process per GPU): every process passes the whole tensor and a full-size result;
+ *                        gather == 0 writes only the process' own part of it, gather == 1 the whole result in every process.
  *   mem == NXSIG_DEVICE: x[i] is local member i's INPUT SHARD on its own device — rows [c0, c1) of the tensor
  *                        (channels axis: f32[c1 - c0][length], rows batch_stride apart) or the sample span [s0, s1) of
  *                        every row (frames axis: f32[batch][s1 - s0]).  batch_stride == 0 means DENSE per-member shards

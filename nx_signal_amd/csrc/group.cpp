@@ -662,7 +662,11 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
     return allgather_locked(g, send.data(), pl.count.data(), out);
   }
   // ---- host tensors: LOCAL groups only (one process sees the whole tensor); one thread per member keeps every GPU busy
-  if (g->ranked && g->world > 1) return set_error(NXSIG_ERR_UNSUPPORTED, "sharded: host tensors need a LOCAL group (one process, all GPUs)");
+  // RANKED groups (round 5): every process holds the WHOLE host tensor and a full-size host result; it computes its own member's part
+  // — without `gather` only that part of its result is written, with it the shards are assembled over RCCL and every process
+  // downloads the whole tensor.  (The reference's vectorised axes know no process boundary: lib/nx_signal.ex:358-363.)
+  if (g->ranked && g->world > 1 && gather && !g->has_rccl)
+    return set_error(NXSIG_ERR_UNSUPPORTED, "sharded: a ranked group without RCCL cannot assemble host tensors");
   if (!x[0] || !out[0]) return set_error(NXSIG_ERR_INVALID_ARG, "sharded: null tensor pointer");
   const float* xh = static_cast<const float*>(x[0]);
   char* oh = static_cast<char*>(out[0]);
@@ -727,14 +731,20 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
   };
   if constexpr (kExchange) {
     on_every_member(work);
-    if ((rc = first_failure())) return rc;
+    int local_rc = NXSIG_OK;
+    std::string local_msg;
+    for (size_t i = 0; i < nl && !local_rc; ++i)
+      if (rcs[i]) { local_rc = rcs[i]; local_msg = msgs[i]; }
     {
+      // the exchange is a collective of the whole group: a process whose work failed still joins it (status word), see device mode
       std::vector<void*> dsts(nl);
       for (size_t i = 0; i < nl; ++i) {
         const Part& p = pl.part[g->m[i].rank];
-        dsts[i] = (p.rows > 0 && p.out_len > 0) ? const_cast<void*>(send[i]) : nullptr;
+        dsts[i] = (!local_rc && p.rows > 0 && p.out_len > 0) ? const_cast<void*>(send[i]) : nullptr;
       }
-      if ((rc = exchange(dsts, NXSIG_OK))) { std::string keep = nxsig_last_error(); cleanup(); return set_error(rc, keep); }
+      rc = exchange(dsts, local_rc);
+      if (local_rc) { cleanup(); return set_error(local_rc, local_msg); }
+      if (rc) { std::string keep = nxsig_last_error(); cleanup(); return set_error(rc, keep); }
     }
     on_every_member(fetch);
   } else {

@@ -173,7 +173,8 @@ def stft_sharded(group: Group, data, window, axis: str = "channels", gather: boo
     """NxSignal.stft(data, window, **opts) sharded over `group` (window_padding must be "valid").
 
     data: host array [channels, L] / [L]  -> returns the assembled host spectrum c64[channels, M, K] / [M, K]
-          (per-shard downloads, or with gather=True the RCCL all-gather followed by one download; LOCAL groups), or
+          (per-shard downloads, or with gather=True the RCCL all-gather followed by one download; on a RANKED group every
+          process passes the whole tensor and gets its own part — gather=False — or the whole result — gather=True), or
           a list with one DeviceBuffer per LOCAL member holding that member's input shard (rows [c0, c1) or the sample
           span [s0, s1) of every row; see shard_channels / shard_frames) together with `length=` and `batch=` of the
           whole tensor -> returns the list of per-member output DeviceBuffers (shards, or full tensors with gather=True).

@@ -63,6 +63,15 @@ def main():
     lo, hi = m0 + (m0 & 1), m1 - ((m1 - m0 - (m0 & 1)) & 1)  # own frames whose frame PAIR (2j, 2j + 1) lies inside the shard
     if m0 % 2 == 0 and hi > lo:                                 # ... ride the same transform as in the unsharded launch: bit-identical
         assert np.array_equal(got[lo:hi].view(np.uint32), full[0][lo:hi].view(np.uint32))
+    # HOST tensors on a ranked group (round 5): every process holds the whole tensor; gather=True assembles the whole result in every
+    # process, gather=False fills only the own part (channels c0:c1)
+    zh = sharding.stft_sharded(g, x, w, axis="channels", gather=True, **opts)
+    assert np.array_equal(zh.view(np.uint32), full.view(np.uint32)), "host tensors, ranked group, assembled"
+    zo = sharding.stft_sharded(g, x, w, axis="channels", gather=False, **opts)
+    assert np.array_equal(zo[c0:c1].view(np.uint32), full[c0:c1].view(np.uint32)), "host tensors, ranked group, own part"
+    yh = sharding.fir_sharded(g, x[:3], S.filters.firwin(257, [4000.0], sampling_rate=48000), mode="same", axis="samples", gather=True)
+    yf3 = np.asarray(S.filters.fir(x[:3], S.filters.firwin(257, [4000.0], sampling_rate=48000), mode="same", ctx=ctx))
+    assert float(np.max(np.abs(yh - yf3)) / np.max(np.abs(yf3))) < 1e-6, "host tensors, ranked group, sample shards of 3 rows assembled"
     # frame shards of a MULTI-ROW tensor, assembled on every rank: one ncclBroadcast per (rank, row)
     xs3 = np.ascontiguousarray(x[:3, s0:s1])
     outs = sharding.stft_sharded(g, [ctx.to_device(xs3)], w, axis="frames", gather=True, length=L, batch=3, **opts)

@@ -233,7 +233,7 @@ def settle(ctx, fn, cap, nbytes=None):
 
 
 def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, seconds45=600, streams3=16, channels45=8, keep_z4=False,
-                        settle_cap=300, yard=None, dry=False, mem=None):
+                        settle_cap=300, yard=None, dry=False, mem=None, check=True):
     """Rooflines of the other BASELINE configs at their FULL per-GPU shard, measured like the headline (HIP events on the
     library's stream, one interval per launch, device-resident data; algorithmic bytes per SURVEY 8d):
       config 3  istft N=1024 hop=256, 16 x 60 s            10 240 B/frame  (K*8 read + hop*8 written, c64 out)
@@ -260,6 +260,7 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         for r in range(rows):  # one full-entropy stream, rolled per row
             xr = np.roll(chunk, 977 * r)
             _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(buf.ptr + r * n * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
+        return chunk   # row r of the buffer is np.roll(chunk, 977 * r): the in-run checks rebuild the slices they need from it
 
     def measure(fn, reps, warm):
         import gc
@@ -375,7 +376,7 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         B4, L4, N4, H4 = channels45, SR * seconds45, 2048, 512
         M4 = (L4 - N4) // H4 + 1
         x4 = ctx.empty((B4, L4), np.float32)
-        fill(x4, B4, L4)
+        chunk4 = fill(x4, B4, L4)
         w4 = S.windows.hann(N4)
         z4 = ctx.empty((B4, M4, N4), np.complex64)
         p4 = _lib.StftParams(N4, H4, N4, 0, 0, 0, _lib.SCALE_NONE, 0, float(SR))
@@ -388,9 +389,24 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         tab4 = ctx.to_device(np.zeros(3072, np.float32)) if diag is not None else None
         m4 = (lambda: diag.nxdiag_stft2048_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(z4.ptr), C.c_void_p(tab4.ptr), B4, L4, H4, 8)) if diag is not None else None
         laps = timed_after_settle(k4)
+        # in-run check of config 4 (before the model overwrites the spectrum): first frame of the first channel, a mid frame, the last
+        # frame of the last channel against the oracle on the matching input slices
+        err4 = None
+        if check:
+            from oracle import nx_oracle as O
+            worst, ref = 0.0, 0.0
+            for (r, m) in ((0, 0), (B4 // 2, M4 // 2), (B4 - 1, M4 - 1)):
+                zg = np.empty((1, N4), np.complex64)
+                _lib.check(lib.nxsig_download(ctx.handle, zg.ctypes.data_as(C.c_void_p), C.c_void_p(z4.ptr + (r * M4 + m) * N4 * 8), zg.nbytes))
+                xs = np.roll(chunk4, 977 * r)[m * H4: m * H4 + N4]
+                zo = O.stft(xs, w4, overlap_length=N4 - H4, fft_length=N4, sampling_rate=SR)[0]
+                worst = max(worst, float(np.max(np.abs(zg - zo))))
+                ref = max(ref, float(np.max(np.abs(zo))))
+            err4 = worst / ref
         klaps, mlaps = interleaved(k4, m4)
         out["roofline_stft2048"] = block(f"config 4 (one GPU's shard of 64 channels): stft N=2048 hop=512, {B4} ch x {seconds45} s @48 kHz", "k_stft_wave<1024, real-2x>",
                                          nb4, laps, {"bytes_per_frame": H4 * 4 + N4 * 8, "frames": B4 * M4, "frames_per_s": B4 * M4 / (lap_mean(laps)[0] * 1e-3)}, pre, "stft2048")
+        out["roofline_stft2048"]["max_norm_err_vs_oracle"] = err4
         ceiling(out["roofline_stft2048"], nb4, klaps, mlaps,
                 "tools/diag_mix.hip k_stft2048_mix: the real-2x kernel's loads and stores in its launch geometry (8 frames per wave), no math", "mix_1to8")
         if tab4 is not None:
@@ -409,9 +425,28 @@ def secondary_rooflines(ctx, lib, S, _lib, C, barrier=None, seconds3=SECONDS, se
         pre = settle(ctx, k5, settle_cap, B4 * L4 * 8) if not dry else {"launches": 0, "settled": False, "dry": True}
         m5 = (lambda: diag.nxdiag_fir_mix(stream, C.c_void_p(x4.ptr), C.c_void_p(y5.ptr), B4, L4, 8)) if diag is not None else None
         laps = timed_after_settle(k5)
+        # in-run check of config 5: three 2 048-sample slices (row start, mid stream, row end) against the direct f64 convolution of
+        # the matching input samples (`:same`: y[n] = sum_k h[k] x[n + 128 - k], zero beyond the stream)
+        err5 = None
+        if check:
+            worst, ref = 0.0, 0.0
+            hh = np.asarray(h, np.float64)
+            for (r, n0) in ((0, 0), (B4 // 2, L4 // 2), (B4 - 1, L4 - 2048)):
+                yg = np.empty(2048, np.float32)
+                _lib.check(lib.nxsig_download(ctx.handle, yg.ctypes.data_as(C.c_void_p), C.c_void_p(y5.ptr + (r * L4 + n0) * 4), yg.nbytes))
+                xr = np.roll(chunk4, 977 * r).astype(np.float64)
+                lo, hi = n0 - 128, n0 + 2048 + 128
+                seg = np.zeros(hi - lo)
+                a, b = max(lo, 0), min(hi, L4)
+                seg[a - lo: b - lo] = xr[a:b]
+                yo = np.convolve(seg, hh, mode="valid")     # yo[i] = sum_k h[k] seg[i + 256 - k] = y[n0 + i]
+                worst = max(worst, float(np.max(np.abs(yg - yo[:2048]))))
+                ref = max(ref, float(np.max(np.abs(yo))))
+            err5 = worst / ref
         klaps, mlaps = interleaved(k5, m5)
         out["roofline_fir"] = block(f"config 5 (one GPU's shard): fir 257 taps :same, {B4} ch x {seconds45} s @48 kHz", "nxsig_fir_f32 (stream + edge + poison pass)",
                                     B4 * L4 * 8, laps, {"bytes_per_sample": 8, "samples": B4 * L4, "samples_per_s": B4 * L4 / (lap_mean(laps)[0] * 1e-3)}, pre, "fir")
+        out["roofline_fir"]["max_norm_err_vs_direct_f64"] = err5
         ceiling(out["roofline_fir"], B4 * L4 * 8, klaps, mlaps,
                 "tools/diag_mix.hip k_fir_mix: the overlap-save stream of k_fir_wave<1024> (two 1024-sample blocks read per 1536 outputs, 8-byte accesses, sc1 nt stores), no math",
                 "mix_1to1")
@@ -989,7 +1024,8 @@ def main():
     if not args.no_secondary:
         sec = secondary_rooflines(ctx, lib, S, _lib, C, barrier=barrier if world > 1 else None, seconds3=args.istft_seconds,
                                   seconds45=args.secondary_seconds, channels45=args.secondary_channels, settle_cap=args.precondition,
-                                  yard=yard if isinstance(yard, dict) and "error" not in yard else None, dry=args.dry, mem=mem)
+                                  yard=yard if isinstance(yard, dict) and "error" not in yard else None, dry=args.dry, mem=mem,
+                                  check=(not args.no_verify and rank == 0))
         sec.pop("_z4", None)
         if world > 1:
             try:

@@ -387,6 +387,7 @@ static bool tuning_in_range(int k, long v, long* lo, long* hi) {
     case kT_FFT_TILE_NT: a = 64; b = 1024; break;
     case kT_FFT_TILED_MIN: a = 2; break;
     case kT_STORE_POLICY: a = 0; b = 2; break;
+    case kT_FIR_R2K: a = 0; b = 2; break;
     default: break;
   }
   if (lo) *lo = a;

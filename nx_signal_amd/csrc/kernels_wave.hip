@@ -855,6 +855,8 @@ struct FirWaveArgs {
   const v2f* twC;
   float* y;                            // f32[batch][out_len]
   int* row_flags;                      // FirLaunch::row_flags: a non-finite sample poisons its whole row, like the reference's one transform
+  const v2f* coefA = nullptr;          // k_fir_r2k: c64[1024] each, W[k] = A[k] Z[k] + B[k] conj Z[(1024 - k) mod 1024]
+  const v2f* coefB = nullptr;
 };
 
 int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, int32_t taps, int64_t first_block, int64_t pb_lo,
@@ -1008,6 +1010,101 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
           }
         }
     }
+  }
+}
+
+// ---- round 5: ONE real block of 2048 samples per 1024-point complex transform.  z[m] = x[2m] + i x[2m + 1],
+// Z = FFT_1024(z); the Hermitian untangle of the 2048-point real spectrum, the product with H and the re-tangle of the result fuse
+// into  W[k] = A[k] Z[k] + B[k] conj Z[(1024 - k) mod 1024],  A = (S - D sin th) / 1024,  B = i D cos th / 1024,  S / D = (H[k] +-
+// H[k + 1024]) / 2,  th = 2 pi k / 2048  (tables computed on the host in double), and IFFT_1024(W)[m] = y[2m] + i y[2m + 1].  Against
+// the pair form (two 1024-sample blocks as re / im: k_fir_wave): 1 792 instead of 1 536 outputs per two transforms, 16-byte loads AND
+// stores (a lane owns 4 consecutive samples per 256-sample slot), at the price of the partner fetch (32 ds_bpermute per block), a
+// second complex multiply per bin and the B table (LDS; A rides in the registers H used).  STREAM blocks only (taps - 1 a multiple of
+// 256 <= 1024, 16-byte aligned rows); the edge blocks of a row stay with k_fir_wave<2048, false> (same block grid: V = 2048 - taps + 1).
+// TQ2: taps - 1 == 256 TQ2.
+template <int W, int TQ2>
+__global__ __launch_bounds__(64 * W) void k_fir_r2k(FirWaveArgs a) {
+  constexpr int K = 1024, P = 16, R3 = 4, NQ = 8, XCH = K + K / 16 + 16, TM1 = 256 * TQ2;
+  v2f* s_twB = reinterpret_cast<v2f*>(g_wave_smem);
+  v2f* s_twC = s_twB + 256;
+  v2f* s_B = s_twC + R3 * 256;
+  v2f* s_x = s_B + K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
+  for (int i = tid; i < R3 * 256; i += 64 * W) s_twC[i] = a.twC[i];
+  for (int i = tid; i < K; i += 64 * W) s_B[i] = a.coefB[i];
+  v2f av[P];   // this lane's A values (k = lane + 64 s)
+#pragma unroll
+  for (int s = 0; s < P; ++s) av[s] = a.coefA[lane + 64 * s];
+  __syncthreads();
+  v2f* xb = s_x + wave * XCH;
+  const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
+  int64_t p_end = p_begin + a.chunk;
+  if (p_end > a.total_units) p_end = a.total_units;
+  // unit u of a row = block first_block + 2 pb_lo + u (the interior PAIRS of the 2048-block grid, one block per unit)
+  int64_t row = (p_begin + wave) / a.units_per_row;
+  int64_t uin = (p_begin + wave) - row * a.units_per_row;
+  int64_t nrow = row, nuin = uin;
+  auto advance = [&](int64_t& r, int64_t& q) {
+    q += W;
+    while (q >= a.units_per_row) { q -= a.units_per_row; ++r; }
+  };
+  advance(nrow, nuin);
+  v4f r4[NQ];
+  auto issue_loads = [&](int64_t rw, int64_t ui) {
+    const int64_t b = a.first_block + 2 * a.pb_lo + ui;
+    const v4f* p = reinterpret_cast<const v4f*>(a.x + (size_t)rw * a.batch_stride + (b * a.V - TM1)) + lane;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) r4[q] = p[64 * q];   // samples 4 lane + 256 q .. + 3: z[2 lane + 128 q], z[2 lane + 1 + 128 q]
+  };
+  v2f zz[2][NQ];
+  auto pack = [&]() {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { zz[0][q] = v2f{r4[q].x, r4[q].y}; zz[1][q] = v2f{r4[q].z, r4[q].w}; }
+  };
+  if (p_begin + wave < p_end) { issue_loads(row, uin); pack(); }
+  const int src = ((64 - lane) & 63) << 2;
+  for (int64_t pr = p_begin + wave; pr < p_end; pr += W) {
+    const bool more = pr + W < p_end;
+    issue_loads(more ? nrow : row, more ? nuin : uin);  // unconditional prefetch: branch-free loop
+    __builtin_amdgcn_sched_barrier(0);
+    v2f d[P];
+    wave_fft_core_T<K>(zz, d, xb, s_twB, s_twC, lane);   // d[s] = Z[lane + 64 s]
+    // partner conj Z[(1024 - k) mod 1024], k = lane + 64 s: lane (64 - lane) & 63, register 15 - s (lane 0: its own (16 - s) mod 16)
+    v2f wv[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+      v2f pz;
+      pz.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d[P - 1 - s].x)));
+      pz.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d[P - 1 - s].y)));
+      if (lane == 0) pz = d[(P - s) % P];
+      const v2f t = wcmul(d[s], av[s]);
+      wv[s] = t + wcmul_conj(s_B[lane + 64 * s], pz);   // B conj(pz): wcmul_conj(a, b) = a conj(b)
+    }
+    v2f u[2][NQ];
+    wave_fft_core<K, true, true>(wv, u, xb, s_twB, s_twC, lane);  // unscaled inverse: u[par][q] = (y[2m], y[2m + 1]), m = 2 lane + par + 128 q
+    __builtin_amdgcn_sched_barrier(0);
+    pack();  // next block (its samples landed during the two transforms)
+    __builtin_amdgcn_sched_barrier(0);
+    // non-finite samples: every output of a block depends on every sample of the block (see k_fir_wave)
+    if (wave_any_nonfinite(u[0][NQ - 1].x, u[0][NQ - 1].y) && lane == 0) atomicOr(a.row_flags + row, 1);
+    float amin = 3.0e38f;
+#pragma unroll
+    for (int q = TQ2; q < NQ; ++q) {
+      amin = min3abs(u[0][q].x, u[0][q].y, amin);
+      amin = min3abs(u[1][q].x, u[1][q].y, amin);
+    }
+    if (__builtin_amdgcn_ballot_w64(amin <= kFftEps) != 0) {   // cold: Nx.ifft's clean-up (convolution.ex:282)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { u[0][q] = fft_eps0(u[0][q]); u[1][q] = fft_eps0(u[1][q]); }
+    }
+    const int64_t b = a.first_block + 2 * a.pb_lo + uin;
+    const StreamRow ys(a.y + (size_t)row * a.out_len + (b * a.V - a.out_start), (uint32_t)a.V * 4);
+#pragma unroll
+    for (int q = TQ2; q < NQ; ++q)
+      ys.st16(v4f{u[0][q].x, u[0][q].y, u[1][q].x, u[1][q].y}, lane * 16 + 1024 * q - TM1 * 4);
+    row = nrow; uin = nuin;
+    advance(nrow, nuin);
   }
 }
 
@@ -1402,7 +1499,7 @@ static void host_fft1024_f64(std::vector<double>& re, std::vector<double>& im) {
   }
 }
 
-template <int W, int K = 1024>
+template <int W, int K = 1024, bool R2K = false>
 static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   *handled = false;
   constexpr int R3 = K / 256, XCH = K + K / 16 + 16;
@@ -1415,7 +1512,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   const int taps_h = s_in.taps;
   FirLaunch s = s_in;
   {
-    const int q = K == 1024 ? 32 : 128;
+    const int q = R2K ? 256 : (K == 1024 ? 32 : 128);   // (R2K: whole 256-sample slots of the real-block kernel)
     const int eff = ((s_in.taps - 1 + q - 1) / q) * q + 1;
     if (eff <= K / 2 + 1 && tune(c, kT_FIR_PAD_TAPS, 1)) s.taps = eff;
   }
@@ -1424,9 +1521,11 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   *handled = true;
   const void* Hd = nullptr;
   const uint64_t hkey = fnv1a(0xF1B0ull ^ ((uint64_t)K << 32), s.h_host, (size_t)taps_h * sizeof(float)) ^ (uint64_t)taps_h;
+  const void *Ad = nullptr, *Bd = nullptr;
   auto hit = c->memo.find(hkey);
-  if (hit != c->memo.end()) {
+  if (hit != c->memo.end() && (!R2K || hit->second.size() >= 3)) {
     Hd = reinterpret_cast<const void*>(hit->second[0]);  // same taps as an earlier call: no host FFT
+    if (R2K) { Ad = reinterpret_cast<const void*>(hit->second[1]); Bd = reinterpret_cast<const void*>(hit->second[2]); }
   } else {
     std::vector<double> re(K, 0.0), im(K, 0.0);
     for (int i = 0; i < taps_h; ++i) re[i] = (double)s.h_host[i];
@@ -1436,6 +1535,19 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     rc = ctx_table(c, 0xF1A1ull ^ (uint64_t)K, H.data(), H.size() * sizeof(float2), &Hd);
     if (rc) return rc;
     c->memo[hkey] = {reinterpret_cast<uint64_t>(Hd)};
+    if constexpr (R2K) {   // fused untangle x H x re-tangle coefficients of k_fir_r2k (K == 2048 here), in double
+      std::vector<float2> A(1024), B(1024);
+      for (int k = 0; k < 1024; ++k) {
+        const double sr = 0.5 * (re[k] + re[k + 1024]), si = 0.5 * (im[k] + im[k + 1024]);
+        const double dr = 0.5 * (re[k] - re[k + 1024]), di = 0.5 * (im[k] - im[k + 1024]);
+        const double th = 6.283185307179586476925286766559 * (double)k / 2048.0, sn = std::sin(th), cs = std::cos(th);
+        A[k] = make_float2((float)((sr - dr * sn) / 1024.0), (float)((si - di * sn) / 1024.0));
+        B[k] = make_float2((float)(-di * cs / 1024.0), (float)(dr * cs / 1024.0));   // i D cos th
+      }
+      if ((rc = ctx_table(c, 0xF1A2ull, A.data(), A.size() * sizeof(float2), &Ad))) return rc;
+      if ((rc = ctx_table(c, 0xF1A3ull, B.data(), B.size() * sizeof(float2), &Bd))) return rc;
+      c->memo[hkey] = {reinterpret_cast<uint64_t>(Hd), reinterpret_cast<uint64_t>(Ad), reinterpret_cast<uint64_t>(Bd)};
+    }
   }
   FirWaveArgs a;
   a.V = K - (s.taps - 1);
@@ -1528,6 +1640,35 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
+  if constexpr (R2K) {
+    // interior pairs of the 2048-block grid, ONE block per unit, on the real-block kernel (16-byte accesses: rows, offsets and V
+    // multiples of 4 samples); anything else falls back to this grid's pair kernel below
+    const bool al16 = fast8 && (s.taps - 1) % 256 == 0 && (s.batch_stride % 4 == 0) && (s.out_len % 4 == 0) && (out_start % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 15) == 0) && a.pb_hi > a.pb_lo;
+    if (al16) {
+      int rc1 = ensure_wave_tables(c, 1024);
+      if (rc1) return rc1;
+      Ctx::WaveTables& w1 = c->wave_tables[1024];
+      FirWaveArgs b = a;
+      b.twB = reinterpret_cast<const v2f*>(w1.twB); b.twC = reinterpret_cast<const v2f*>(w1.twC);
+      b.coefA = reinterpret_cast<const v2f*>(Ad); b.coefB = reinterpret_cast<const v2f*>(Bd);
+      constexpr int W4 = 4;
+      b.units_per_row = 2 * (a.pb_hi - a.pb_lo);
+      b.total_units = b.units_per_row * s.batch;
+      b.chunk = (int64_t)W4 * tune(c, kT_FIR_UNITS_PER_WAVE, 8);
+      const int64_t blocks = (b.total_units + b.chunk - 1) / b.chunk;
+      if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: signal too long for one launch");
+      const size_t lds4 = 256 * 8 + (size_t)4 * 256 * 8 + (size_t)1024 * 8 + (size_t)W4 * (1024 + 64 + 16) * 8;
+      switch ((s.taps - 1) / 256) {
+        case 1: hipLaunchKernelGGL((k_fir_r2k<W4, 1>), dim3((unsigned)blocks), dim3(64 * W4), lds4, c->stream, b); break;
+        case 2: hipLaunchKernelGGL((k_fir_r2k<W4, 2>), dim3((unsigned)blocks), dim3(64 * W4), lds4, c->stream, b); break;
+        case 3: hipLaunchKernelGGL((k_fir_r2k<W4, 3>), dim3((unsigned)blocks), dim3(64 * W4), lds4, c->stream, b); break;
+        default: hipLaunchKernelGGL((k_fir_r2k<W4, 4>), dim3((unsigned)blocks), dim3(64 * W4), lds4, c->stream, b); break;
+      }
+      NXSIG_HIP_TRY(hipGetLastError());
+      return launch(false, a.pairs_per_row - (a.pb_hi - a.pb_lo));
+    }
+  }
   if (use32) {  // interior pairs two at a time on the 32 x 32 kernel (kernels_wave_fir32.hip); an odd leftover joins the edge pairs
     a.pb_hi -= (a.pb_hi - a.pb_lo) & 1;
     rc = launch_fir_wave32(c, a.x, s.batch_stride, s.batch, s.taps, a.first_block, a.pb_lo, (a.pb_hi - a.pb_lo) / 2, a.out_start, s.out_len,
@@ -1542,6 +1683,11 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
 int launch_fir_wave(Ctx* c, const FirLaunch& s, bool* handled) {
   // 2048-sample blocks (32 points per lane, six waves per workgroup) for 514..1025 taps; four-wave workgroups on 1024-sample
   // blocks otherwise (7- and 14-wave workgroups measured slower in round 2 and went with their switch in round 4)
+  // real 2048-sample blocks on the 1024-point core (k_fir_r2k, round 5) from 386 taps on: interleaved A/B on config 5's shard
+  // (tools/sweep_fir.py NXSIG_FIR_R2K 0 2 with SWEEP_TAPS): 129 / 193 / 257 taps -11 / -2 / -5 %, 289 / 321 / 385 +2 / +3 / -1 %,
+  // 449 / 513 / 641 / 769 / 1025 taps +20 / +15 / +9 / +22 / +22 %.  NXSIG_FIR_R2K: 0 never, 1 (default) from 386 taps, 2 whenever it applies
+  const int r2k = tune(c, kT_FIR_R2K, 1);
+  if (s.taps <= 1025 && (r2k == 2 || (r2k == 1 && s.taps > 385))) return launch_fir_wave_W<6, 2048, true>(c, s, handled);
   if (s.taps > 513) return launch_fir_wave_W<6, 2048>(c, s, handled);
   return launch_fir_wave_W<4>(c, s, handled);
 }

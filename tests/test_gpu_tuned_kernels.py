@@ -483,3 +483,35 @@ def test_stft_composite_lengths_non_finite_samples_stay_in_their_frames():
         bad = ~np.isfinite(zo).all(axis=1)
         assert bad.sum() >= 6 and np.array_equal(~np.isfinite(z).all(axis=1), bad), K
         assert float(np.max(np.abs(z[~bad] - zo[~bad])) / np.max(np.abs(zo[~bad]))) < 1e-5
+
+
+@pytest.mark.parametrize("taps", [257, 386, 449, 513, 700, 769, 1000, 1025])
+@pytest.mark.parametrize("mode", ["same", "full", "valid"])
+def test_fir_real_block_kernel(taps, mode):
+    """k_fir_r2k (round 5): one real 2048-sample block per 1024-point complex transform, W[k] = A[k] Z[k] + B[k] conj Z[-k].  Every tap
+    count it serves by default (>= 386) and 257 under NXSIG_FIR_R2K=2, all modes, several rows, against the direct f64 convolution;
+    unaligned rows (odd length / odd stride) fall back to the pair kernels and agree; a NaN poisons exactly its row."""
+    import nx_signal_amd as S
+
+    rng = np.random.default_rng(taps)
+    L = 60000
+    x = rng.standard_normal((3, L)).astype(np.float32)
+    h = S.filters.firwin(taps if taps % 2 else taps + 1, [4000.0], sampling_rate=48000)[:taps].copy()
+    ctx = S.Context(0)
+    ctx.set_tuning("NXSIG_FIR_R2K", 2)
+    y = S.filters.fir(ctx.to_device(x), h, mode=mode, ctx=ctx).numpy()
+    ref = np.stack([np.convolve(r.astype(np.float64), h.astype(np.float64), mode=mode) for r in x])
+    assert y.shape == ref.shape
+    assert float(np.max(np.abs(y - ref)) / np.max(np.abs(ref))) < 1e-5, (taps, mode)
+    ctx.set_tuning("NXSIG_FIR_R2K", 0)
+    y0 = S.filters.fir(ctx.to_device(x), h, mode=mode, ctx=ctx).numpy()
+    assert float(np.max(np.abs(y - y0)) / np.max(np.abs(ref))) < 2e-6
+    ctx.set_tuning("NXSIG_FIR_R2K", 2)
+    xo = np.ascontiguousarray(x[:, : L - 3])                      # 59 997 samples per row: rows not 16-byte aligned
+    yo = S.filters.fir(ctx.to_device(xo), h, mode=mode, ctx=ctx).numpy()
+    refo = np.stack([np.convolve(r.astype(np.float64), h.astype(np.float64), mode=mode) for r in xo])
+    assert float(np.max(np.abs(yo - refo)) / np.max(np.abs(refo))) < 1e-5
+    xn = x.copy()
+    xn[1, 31000] = np.nan
+    yn = S.filters.fir(ctx.to_device(xn), h, mode=mode, ctx=ctx).numpy()
+    assert np.isfinite(yn[0]).all() and np.isfinite(yn[2]).all() and not np.isfinite(yn[1]).any()

@@ -10,7 +10,7 @@ import nx_signal_amd as S
 
 pytestmark = pytest.mark.gpu
 
-FFT_LENGTHS = [8, 32, 64, 128, 256, 512, 1024, 2048, 4096, 100, 400, 640, 1000, 48, 3000, 8192]
+FFT_LENGTHS = [8, 32, 64, 128, 256, 512, 1024, 2048, 4096, 100, 400, 640, 1000, 48, 3000, 8192, 320, 480, 960]
 WINDOWS = ["hann", "hamming", "blackman", "bartlett", "triangular", "kaiser", "rectangular"]
 
 
@@ -49,6 +49,36 @@ def test_fuzz_stft(seed):
     zo, to, fo = O.stft(x, w, **opts)
     assert z.shape == zo.shape, (opts, L)
     assert np.all(np.isfinite(z.view(np.float32)))
+    assert nerr(z, zo) < 1e-5, (K, N, hop, L, pad, scaling, bshape, nerr(z, zo))
+    assert np.array_equal(t, to, equal_nan=True) and np.array_equal(f, fo)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_stft_of_complex_samples(seed):
+    """round 5: c64 IQ data through nxsig_stft_c64 — the fused framed row kernels (1024 / 2048 / 4096) and the two-step path (every other
+    length), random frame lengths, hops, paddings, scalings, batch shapes; host and device-resident"""
+    rng = np.random.default_rng(7000 + seed)
+    K = [1024, 1024, 2048, 4096, 512, 256, 100, 400, 1000, 3000, 8192, 48, 960][rng.integers(13)]
+    N = int(rng.choice([K, K, max(2, K // 2), max(2, int(K * 0.8)), min(K + K // 4, 5000)]))
+    hop = int(rng.integers(1, N + 1))
+    bshape = [(), (), (2,), (3,), (2, 2)][rng.integers(5)]
+    pad = ["valid", "valid", "reflect", "same", [(int(rng.integers(0, N)), int(rng.integers(0, N)))]][rng.integers(5)]
+    M_target = int(rng.integers(1, 30))
+    L = max(N + (M_target - 1) * hop + int(rng.integers(0, hop)), 2 if pad == "reflect" else 1)
+    if pad == "reflect":
+        L = max(L, N // 2 + 2)
+    scaling = [None, None, "spectrum", "psd"][rng.integers(4)]
+    fs = float(rng.choice([100, 8000, 48000]))
+    x = (rng.standard_normal(bshape + (L,)) + 1j * rng.standard_normal(bshape + (L,))).astype(np.complex64)
+    w = make_window(rng, N)
+    opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=fs)
+    zo, to, fo = O.stft(x, w, **opts)
+    if seed % 2:
+        z, t, f = S.stft(x, w, **opts)
+    else:
+        zd, t, f = S.stft(S.default_context(0).to_device(x), w, **opts)
+        z = zd.numpy()
+    assert z.shape == zo.shape, (opts, L)
     assert nerr(z, zo) < 1e-5, (K, N, hop, L, pad, scaling, bshape, nerr(z, zo))
     assert np.array_equal(t, to, equal_nan=True) and np.array_equal(f, fo)
 

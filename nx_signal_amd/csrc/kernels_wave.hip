@@ -1390,6 +1390,7 @@ static int launch_istft_wave_4k(Ctx* c, const IstftLaunch& s, const float* windo
 }
 
 int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);  // kernels_wave_r20.hip
+int launch_istft_rab(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);  // kernels_wave_rab.hip
 
 int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   *handled = false;
@@ -1414,6 +1415,10 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
   if (s.K == 400 && s.N == 400) {  // native 20 x 20 inverse (kernels_wave_r20.hip); declines odd hops / short inputs
     int rc20 = launch_istft_r20(c, s, window_host, handled);
     if (rc20 || *handled) return rc20;
+  }
+  if (s.K == s.N && (s.K == 320 || s.K == 480 || s.K == 640 || s.K == 960)) {  // A x B inverses (kernels_wave_rab.hip), same conditions
+    int rcab = launch_istft_rab(c, s, window_host, handled);
+    if (rcab || *handled) return rcab;
   }
   if ((s.K == 256 && s.N == 256) || (s.K == 128 && s.N == 128)) {  // 4 / 8 frames per 1024-point inverse FFT
     const int R = s.N / s.hop;

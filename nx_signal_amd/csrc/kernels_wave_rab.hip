@@ -263,4 +263,266 @@ int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled) {
   }
 }
 
+// ============================================================================================ iSTFT, N = fft_length = A x B
+// NxSignal.istft/3 (lib/nx_signal.ex:609-637) for 320 / 480 / 640 / 960-point frames, any even hop: k_istft_r20's scheme with the two
+// factors free.  The same two-pass transform in inverse direction (IDFT(z) = conj(DFT(conj z)) / K: the conjugations ride on the LDS
+// reads and the epilogue), ONE complex frame per max(A, B)-lane group, T consecutive frames per wave iteration, a run of such units
+// per wave.  The T spectra are one contiguous span (16-byte loads one unit ahead).  The windowed frames are parked in LDS in natural
+// order and every lane gathers its output positions: carry of the earlier units + the frames that cover the position, in ascending
+// frame order (deterministic; sharded = unsharded), x reciprocal of the guarded normaliser (:630-637), 16-byte stores; the following
+// K - hop positions become the carry strip of the next unit.
+struct IstftRabArgs {
+  const v2f* z;               // c64[batch][M][K]
+  int64_t M;
+  int32_t batch, hop, RP;     // RP = ceil(K / hop): frames that cover one output sample
+  int64_t out_len;            // (M - 1) hop + K
+  int64_t units_per_row, run_len, runs_per_row, total_runs;
+  const float* wtab;          // f32[K]
+  const v2f* tw;              // c64[B][A] forward twiddles W_K^(n2 k1)
+  float scale;
+  const float* den;           // f32[2 RP - 1][hop]: reciprocal of the guarded normaliser: head segments, interior, tail segments
+  v2f* y;                     // c64[batch][out_len]
+  v2f* dummy;
+};
+
+template <int A, int B, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_istft_rab(IstftRabArgs a) {
+  constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT, CMAX = KB;
+  constexpr int TRS = A * (B + 1);
+  constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
+  constexpr int N4 = T * KB / 2;                 // 16-byte pieces of a unit's T spectra
+  constexpr int NRS = (N4 + 63) / 64;
+  float* s_w = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
+  v2f* s_x = s_tw + KB;
+  v2f* s_carry = s_x + W * BUF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = a.tw[i]; }
+  __syncthreads();
+  v2f* buf = s_x + wave * BUF;
+  v2f* carry = s_carry + wave * CMAX;
+  const int g = lane / LT, l = lane % LT;
+  const int hop = a.hop;
+  const int CARRY = KB - hop;             // positions handed to the next unit
+  const int OUTN = T * hop;               // positions finished per unit
+  const int64_t run = (int64_t)blockIdx.x * W + wave;
+  if (run >= a.total_runs) return;
+  const int64_t row = run / a.runs_per_row;
+  const int64_t u0 = (run - row * a.runs_per_row) * a.run_len;
+  int64_t u1 = u0 + a.run_len;
+  if (u1 > a.units_per_row) u1 = a.units_per_row;
+  const int halo = (a.RP - 1 + T - 1) / T;    // earlier units whose frames reach into this run
+  const int64_t us = u0 >= halo ? u0 - halo : 0;
+  for (int i = lane; i < CARRY; i += 64) carry[i] = v2f{0.f, 0.f};
+  const float invK = 1.0f / (float)KB;
+  const v2f* zrow = a.z + (size_t)row * a.M * KB;
+
+  v4f rs[NRS];
+  auto prefetch = [&](int64_t u) {
+    const int64_t m0 = T * u;
+    const v4f* p4 = reinterpret_cast<const v4f*>(zrow + (size_t)m0 * KB) + lane;
+    const int64_t avail4 = (a.M - m0) * (KB / 2);   // float4s that exist from frame m0 on (frames past the end: zeros)
+#pragma unroll
+    for (int c = 0; c < NRS; ++c) {
+      const int i4 = lane + 64 * c;
+      rs[c] = (i4 < N4 && i4 < avail4) ? p4[64 * c] : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  prefetch(us);
+  for (int64_t u = us; u < u1; ++u) {
+    // ---- the unit's T spectra -> LDS
+#pragma unroll
+    for (int c = 0; c < NRS; ++c) {
+      const int i4 = lane + 64 * c;
+      if (i4 < N4) *reinterpret_cast<v4f*>(&buf[2 * i4]) = rs[c];
+    }
+    wave_lds_fence();
+    prefetch(u + 1 < u1 ? u + 1 : u);
+    // ---- pass A on conj(z): lane n2 = l < B of frame g takes conj z[B n1 + n2]
+    v2f v[NV];
+#pragma unroll
+    for (int n1 = 0; n1 < A; ++n1) {
+      const v2f t = (g < T && l < B) ? buf[g * KB + B * n1 + l] : v2f{0.f, 0.f};
+      v[n1] = v2f{t.x, -t.y};
+      if (A > 16 && (n1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    dft_n<A>(v);
+    if (l < B) {
+#pragma unroll
+      for (int k1 = 1; k1 < A; ++k1) {
+        v[k1] = wcmul(v[k1], s_tw[l * A + k1]);
+        if (A > 16 && (k1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    wave_lds_fence();
+    if (g < T && l < B) {
+#pragma unroll
+      for (int k1 = 0; k1 < A; ++k1) buf[g * TRS + k1 * (B + 1) + l] = v[k1];
+    }
+    wave_lds_fence();
+    if (g < T && l < A) {
+#pragma unroll
+      for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[g * TRS + l * (B + 1) + n2];
+    }
+    dft_n<B>(v);
+    wave_lds_fence();
+    // ---- x[n] = conj(T[n]) / K, x scale, x window (lib/nx_signal.ex:611-628), n = l + A k2; parked frame-major
+    if (g < T && l < A) {
+      const float live = (T * u + g) < a.M ? 1.0f : 0.0f;
+#pragma unroll
+      for (int k2 = 0; k2 < B; ++k2) {
+        const int n = l + A * k2;
+        v2f x = fft_eps0(v2f{v[k2].x, -v[k2].y} * invK);  // Nx.ifft's clean-up (:609) precedes scale and window
+        if (SCALE) x = x * a.scale;
+        buf[g * KB + n] = x * (s_w[n] * live);
+      }
+    }
+    wave_lds_fence();
+    // position t of the unit (t = 0 is sample T u hop of the row): carry + covering frames in ascending order
+    auto gather = [&](int t) -> v4f {
+      v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+      if (t < CARRY) acc = *reinterpret_cast<const v4f*>(&carry[t]);
+#pragma unroll
+      for (int f = 0; f < T; ++f) {
+        const int off = t - f * hop;
+        if (off >= 0 && off < KB) acc += *reinterpret_cast<const v4f*>(&buf[f * KB + off]);
+      }
+      return acc;
+    };
+    const int64_t t_unit = u * OUTN;
+    v2f* yrow = a.y + (size_t)row * a.out_len;
+    for (int t = 2 * lane; t < OUTN; t += 128) {
+      const v4f acc = gather(t);
+      const int64_t tabs = t_unit + t;
+      const bool inside = u >= u0 && tabs < a.out_len;
+      v2f rd = v2f{0.f, 0.f};
+      if (inside) {
+        const int64_t seg = tabs / hop;
+        const int pos = (int)(tabs - seg * hop);
+        const int64_t trow = seg < a.RP - 1 ? seg : (seg >= a.M ? a.RP + (seg - a.M) : a.RP - 1);
+        rd = *reinterpret_cast<const v2f*>(a.den + trow * hop + pos);
+      }
+      const v4f o = v4f{acc.x * rd.x, acc.y * rd.x, acc.z * rd.y, acc.w * rd.y};
+      v2f* yp = inside ? yrow + tabs : a.dummy + 2 * lane;
+      __builtin_nontemporal_store(o, (gv4f*)yp);
+    }
+    // ---- carry for the next unit (all reads first, then the writes)
+    constexpr int NC = (CMAX + 127) / 128;
+    v4f nc[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int t = 2 * lane + 128 * i;
+      nc[i] = t < CARRY ? gather(OUTN + t) : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int t = 2 * lane + 128 * i;
+      if (t < CARRY) *reinterpret_cast<v4f*>(&carry[t]) = nc[i];
+    }
+    wave_lds_fence();
+  }
+}
+
+template <int A, int B>
+static int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
+  constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, CMAX = KB;
+  constexpr int W = KB >= 640 ? 2 : 4;   // 640 / 960: 24 KB of LDS per wave (exchange + carry strip): two waves per workgroup, two workgroups per CU
+  constexpr int TRS = A * (B + 1);
+  constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
+  const int hop = s.hop;
+  if (hop < 2 || (hop & 1) || hop > KB) return NXSIG_OK;            // 16-byte LDS gathers need an even hop
+  const int RP = (KB + hop - 1) / hop;
+  if (s.M < 2 * RP - 1) return NXSIG_OK;                            // head and tail rows of the normaliser must not overlap
+  if ((reinterpret_cast<uintptr_t>(s.z) & 15) || (reinterpret_cast<uintptr_t>(s.y) & 15)) return NXSIG_OK;
+  *handled = true;
+  IstftRabArgs a;
+  a.z = reinterpret_cast<const v2f*>(s.z); a.M = s.M; a.batch = s.batch; a.hop = hop; a.RP = RP;
+  a.out_len = (s.M - 1) * (int64_t)hop + KB;
+  a.wtab = s.window; a.scale = s.scale_mul; a.y = reinterpret_cast<v2f*>(s.y);
+  {  // forward twiddles (shared with the stft kernel of the same factors)
+    const uint64_t key = 0x2AB000000000ull ^ ((uint64_t)A << 16) ^ (uint64_t)B;
+    auto hit = c->memo.find(key);
+    if (hit != c->memo.end()) a.tw = reinterpret_cast<const v2f*>(hit->second[0]);
+    else {
+      std::vector<float2> tw((size_t)KB);
+      for (int n2 = 0; n2 < B; ++n2)
+        for (int k1 = 0; k1 < A; ++k1) {
+          const double ang = -6.283185307179586476925286766559 * (double)(n2 * k1) / (double)KB;
+          tw[(size_t)n2 * A + k1] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+      const void* dt = nullptr;
+      int rc = ctx_table(c, 0x2AB0ull ^ ((uint64_t)A << 16) ^ (uint64_t)B, tw.data(), tw.size() * sizeof(float2), &dt);
+      if (rc) return rc;
+      c->memo[key] = {reinterpret_cast<uint64_t>(dt)};
+      a.tw = reinterpret_cast<const v2f*>(dt);
+    }
+  }
+  {  // reciprocal of the guarded normaliser (:630-635): head segments j = 0..RP-2, the interior, tail segments j = M..M+RP-2
+    const uint64_t dkey = fnv1a(0xDE2Bull ^ ((uint64_t)hop << 8) ^ ((uint64_t)KB << 40), window_host, (size_t)KB * sizeof(float));
+    auto hit = c->memo.find(dkey);
+    if (hit != c->memo.end()) {
+      a.den = reinterpret_cast<const float*>(hit->second[0]);
+    } else {
+      std::vector<float> den((size_t)(2 * RP - 1) * hop);
+      auto w2 = [&](int idx) { const float w = std::fabs(window_host[idx]); return (double)(w * w); };
+      for (int rowi = 0; rowi < 2 * RP - 1; ++rowi)
+        for (int pos = 0; pos < hop; ++pos) {
+          double acc = 0.0;
+          for (int rr = RP - 1; rr >= 0; --rr) {   // ascending frame order
+            if (rr * hop + pos >= KB) continue;
+            bool have;
+            if (rowi < RP - 1) have = rr <= rowi;
+            else if (rowi == RP - 1) have = true;
+            else have = rr >= rowi - RP + 1;
+            if (have) acc += w2(rr * hop + pos);
+          }
+          const float d = (float)acc;
+          den[(size_t)rowi * hop + pos] = (float)(1.0 / (double)(d > 1.0e-10f ? d : 1.0f));
+        }
+      const void* dd = nullptr;
+      int rc = ctx_table(c, 0xDE2Cull ^ ((uint64_t)hop << 8) ^ ((uint64_t)KB << 40), den.data(), den.size() * sizeof(float), &dd);
+      if (rc) return rc;
+      a.den = reinterpret_cast<const float*>(dd);
+      c->memo[dkey] = {reinterpret_cast<uint64_t>(dd)};
+    }
+  }
+  void* dummy = nullptr;
+  { int rc2 = ctx_scratch(c, 3, (size_t)8192 * sizeof(float2), &dummy); if (rc2) return rc2; }
+  a.dummy = reinterpret_cast<v2f*>(dummy);
+  const int64_t segs = (a.out_len + hop - 1) / hop;              // hop segments of the output (the last may be partial)
+  a.units_per_row = (segs + T - 1) / T;
+  const int64_t total_units = a.units_per_row * s.batch;
+  const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, KB >= 640 ? 4 : 8);  // = resident waves per CU
+  int64_t run_len = (total_units + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
+  if (run_len < 8) run_len = 8;
+  a.run_len = run_len;
+  a.runs_per_row = (a.units_per_row + run_len - 1) / run_len;
+  a.total_runs = a.runs_per_row * s.batch;
+  const int64_t blocks = (a.total_runs + W - 1) / W;
+  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)W * BUF * 8 + (size_t)W * CMAX * 8;
+  auto go = [&](auto kernel) -> int {
+    if (lds > 64 * 1024)
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  };
+  return s.has_scale ? go(k_istft_rab<A, B, true, W>) : go(k_istft_rab<A, B, false, W>);
+}
+
+// N = fft_length 320 / 480 / 640 / 960; handled = false: the generic inverse path
+int launch_istft_rab(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
+  *handled = false;
+  if (s.K != s.N || s.M == 0 || s.batch == 0 || window_host == nullptr || s.filt != nullptr) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_RAB, 0) || tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
+  switch (s.K) {
+    case 320: return launch_istft_rab_AB<16, 20>(c, s, window_host, handled);
+    case 480: return launch_istft_rab_AB<24, 20>(c, s, window_host, handled);
+    case 640: return launch_istft_rab_AB<32, 20>(c, s, window_host, handled);
+    case 960: return launch_istft_rab_AB<32, 30>(c, s, window_host, handled);
+    default: return NXSIG_OK;
+  }
+}
+
 }  // namespace nxsig

@@ -515,3 +515,61 @@ def test_fir_real_block_kernel(taps, mode):
     xn[1, 31000] = np.nan
     yn = S.filters.fir(ctx.to_device(xn), h, mode=mode, ctx=ctx).numpy()
     assert np.isfinite(yn[0]).all() and np.isfinite(yn[2]).all() and not np.isfinite(yn[1]).any()
+
+
+@pytest.mark.parametrize("K", [320, 480, 640, 960])
+@pytest.mark.parametrize("hopsel", ["quarter", "half", "full", "eighth", "uneven"])
+def test_istft_composite_lengths_native_kernels(K, hopsel):
+    """k_istft_rab (round 5): the inverse of the A x B kernels — one frame per lane group, overlap-add through LDS with a carry strip,
+    any even hop.  Non-Hermitian spectra, every scaling, several rows, frame counts that leave the last unit ragged; against the oracle
+    (1e-5), bit-identical to itself across run alignments (two batch sizes change the run length) and against the generic path."""
+    import nx_signal_amd as S
+    from oracle import nx_oracle as O
+
+    hop = {"quarter": K // 4, "half": K // 2, "full": K, "eighth": K // 8, "uneven": K // 4 + 6}[hopsel]
+    rng = np.random.default_rng(K + hop)
+    M = 57
+    w = S.windows.hann(K)
+    z = (rng.standard_normal((3, M, K)) + 1j * rng.standard_normal((3, M, K))).astype(np.complex64)
+    for scaling in (None, "spectrum", "psd"):
+        opts = dict(overlap_length=K - hop, fft_length=K, scaling=scaling, sampling_rate=16000)
+        y = S.istft(z, w, **opts)
+        yo = O.istft(z, w, **opts)
+        assert y.shape == yo.shape and y.dtype == np.complex64
+        assert float(np.max(np.abs(y - yo)) / np.max(np.abs(yo))) < 1e-5, (K, hop, scaling)
+    ctx = S.Context(0)
+    opts = dict(overlap_length=K - hop, fft_length=K, sampling_rate=16000)
+    native = not ctx.get_tuning("DISABLE_RAB")[0] and not ctx.get_tuning("DISABLE_WAVE")[0]
+    y3 = S.istft(ctx.to_device(z), w, ctx=ctx, **opts).numpy()
+    y1 = S.istft(ctx.to_device(z[1:2]), w, ctx=ctx, **opts).numpy()
+    assert np.array_equal(y3[1].view(np.uint32), y1[0].view(np.uint32))          # deterministic whatever the launch geometry
+    ctx.set_tuning("NXSIG_DISABLE_RAB", 1)
+    yg = S.istft(ctx.to_device(z), w, ctx=ctx, **opts).numpy()
+    assert not native or not np.array_equal(yg.view(np.uint32), y3.view(np.uint32))   # two different kernels really ran
+    assert float(np.max(np.abs(yg - y3)) / np.max(np.abs(y3))) < 1e-5
+    # round trip of a real signal on interior samples
+    x = rng.standard_normal(40 * hop + K).astype(np.float32)
+    ctx.clear_tuning("DISABLE_RAB")
+    zz = S.stft(x, w, **opts)[0]
+    xr = S.istft(zz, w, **opts)
+    if hop <= K // 2:   # a Hann window needs >= 50 % overlap for the normaliser to be well conditioned
+        assert float(np.max(np.abs(xr.real[K: -K] - x[K: len(xr) - K]))) < 1e-4
+
+
+def test_istft_composite_lengths_non_finite_bins_stay_in_their_frames():
+    import nx_signal_amd as S
+    from oracle import nx_oracle as O
+
+    for K in (320, 480, 640, 960):
+        hop = K // 4
+        rng = np.random.default_rng(K + 3)
+        z = (rng.standard_normal((2, 40, K)) + 1j * rng.standard_normal((2, 40, K))).astype(np.complex64)
+        z[0, 17, 5] = np.nan
+        z[1, 30, K - 1] = np.inf
+        w = S.windows.hann(K)
+        opts = dict(overlap_length=K - hop, fft_length=K, sampling_rate=16000)
+        y = S.istft(z, w, **opts)
+        yo = O.istft(z, w, **opts)
+        assert np.array_equal(np.isfinite(y), np.isfinite(yo)), K
+        ok = np.isfinite(yo)
+        assert float(np.max(np.abs(y[ok] - yo[ok])) / np.max(np.abs(yo[ok]))) < 1e-5

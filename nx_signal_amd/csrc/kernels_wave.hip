@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_r2k(FirWaveArgs a) {
 }
 
 int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_r20.hip
-int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled);                           // kernels_wave_rab.hip
+int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);    // kernels_wave_rab.hip
 int launch_stft_wave_8k(Ctx* c, const StftLaunch& s, bool* handled);                      // kernels_wave_8k.hip
 
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
@@ -1136,7 +1136,7 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
     if (rc20 || *handled) return rc20;
   }
   if (s.K == 320 || s.K == 480 || s.K == 640 || s.K == 960) {  // A x B native kernels (kernels_wave_rab.hip)
-    int rcab = launch_stft_rab(c, s, handled);
+    int rcab = launch_stft_rab(c, s, handled, nullptr);
     if (rcab || *handled) return rcab;
   }
   if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !tune(c, kT_DISABLE_BLUE_WAVE, 0)) {

@@ -4,6 +4,7 @@
 namespace nxsig {
 
 int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_r20.hip
+int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_rab.hip
 
 // fused stft -> magnitude / power / dBFS spectrogram of the bins below fft_length / 2
 int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool* handled) {
@@ -23,12 +24,18 @@ int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool
                                        // the one-sided form keeps its "same bits as stft" promise through the two-step path
       return launch_wave<2048, kModeReal2x, 4, 2, kSinkMag>(c, s, &mel);
     default:
-      if (kind == 3 && s.K != 400) return NXSIG_OK;  // one-sided complex output: the power-of-two front-ends above and the
-                                                     // 20 x 20 kernel store it; the rest slice the full spectrum
+      const bool ab = s.K == 320 || s.K == 480 || s.K == 640 || s.K == 960;
+      if (kind == 3 && s.K != 400 && !ab) return NXSIG_OK;  // one-sided complex output: the power-of-two front-ends above, the 20 x 20
+                                                            // and the A x B kernels store it; the rest slice the full spectrum
       if (s.K == 400) {  // native 20 x 20 kernel
         bool h20 = false;
         int rc20 = launch_stft_r20(c, s, &h20, &mel);
         if (rc20 || h20) return rc20;
+      }
+      if (ab) {  // native A x B kernels (round 5)
+        bool hab = false;
+        int rcab = launch_stft_rab(c, s, &hab, &mel);
+        if (rcab || hab) return rcab;
       }
       if (kind == 3) return NXSIG_OK;
       if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !tune(c, kT_DISABLE_BLUE_WAVE, 0))

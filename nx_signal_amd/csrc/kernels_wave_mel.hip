@@ -4,6 +4,7 @@
 namespace nxsig {
 
 int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_r20.hip
+int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_rab.hip
 
 // fused stft -> log-mel; *handled = false when the shape is not covered (the caller falls back to stft + stft_to_mel)
 int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled) {
@@ -23,6 +24,11 @@ int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float*
         bool h20 = false;
         int rc20 = launch_stft_r20(c, s, &h20, &mel);
         if (rc20 || h20) return rc20;
+      }
+      if (s.K == 320 || s.K == 480 || s.K == 640 || s.K == 960) {  // native A x B kernels (round 5)
+        bool hab = false;
+        int rcab = launch_stft_rab(c, s, &hab, &mel);
+        if (rcab || hab) return rcab;
       }
       if ((s.K & (s.K - 1)) != 0 && s.K > 16 && s.K <= 1024 && !tune(c, kT_DISABLE_BLUE_WAVE, 0))
         return s.K <= 512 ? launch_blue_wave<1024, kSinkMel>(c, s, &mel) : launch_blue_wave<2048, kSinkMel>(c, s, &mel);

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
       const v2f* U = buf + gg * KB;
       v2f* zA = a.z + ((size_t)row * a.M + m0) * KB;
       v2f* zB = zA + KB;
-#pragma unroll
+#pragma unroll 2
       for (int i = 0; i < NI; ++i) {
         const int pi = lane + 64 * i;
         if (MEL) { pw[gg][0][i] = v2f{0.f, 0.f}; pw[gg][1][i] = v2f{0.f, 0.f}; }
@@ -216,19 +216,21 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
       solo = __builtin_amdgcn_ballot_w64(nf) != 0;
       if (MEL) { melbad |= solo; solo = false; }   // log-mel: the whole tensor is poisoned instead (gmax[1], see stft_wave_body)
     }
-    if (solo) {
+    // one inlined copy of the transform + sink (round 5: two copies — the paired call and the solo loop — cost the spectrum sink 70
+    // registers and its third wave per SIMD): the paired route is pass 0 with sel = -1; a non-finite unit takes two passes (sel 0, 1)
+    const int npass = solo ? 2 : 1;
 #pragma nounroll
-      for (int sel = 0; sel < 2; ++sel) {
-        if (sel == 1) {
+    for (int ps = 0; ps < npass; ++ps) {
+      const int sel = solo ? ps : -1;
+      if (solo) {
+        if (ps == 1) {
           wave_lds_fence();      // round A's partner reads are done
           stage_slow(xr, q0);    // the exchange overwrote the samples
           wave_lds_fence();
         }
         build(sel);
-        xform_sink(sel);
       }
-    } else {
-      xform_sink(-1);
+      xform_sink(sel);
     }
     // (MEL: pw[][][] is filled by xform_sink(-1))
     if (MEL) {

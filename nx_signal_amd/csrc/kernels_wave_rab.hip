@@ -11,10 +11,10 @@
 //   natural-order U in LDS -> untangle XA = (U + conj U') / 2, XB = -i (U - conj U') / 2 -> 16-byte stores (:129)
 //
 // T = 64 / max(A, B) transforms per wave (3, 2, 2, 2), two real frames per transform as re / im, the small DFTs are register codelets
-// without internal twiddles (small_dft.hpp: 16 = 4 x 4, 20 = 4 x 5, 24 = 3 x 8 and 30 = 5 x 6 prime-factor, 32 = 2 x 16).
-// Measured (tools/bench_configs.py gen<N>, 16 rows, 1.7 GB of output): 0.52 / 0.53 / 0.49 / 0.49 of 8 TB/s against 0.14 through
-// Bluestein; two waves per SIMD (216 ... 256 registers: the 30- / 32-point codelets), LDS-bound on the staging and transposes.  Complex spectrum sink
-// only: the log-mel / magnitude sinks and the inverse of these lengths keep the Bluestein / generic kernels.
+// without internal twiddles (small_dft.hpp: 16 = 4 x 4, 20 = 4 x 5, 24 = 3 x 8 and 30 = 5 x 6 prime-factor, 32 = 2 x 16).  Sinks as in
+// kernels_wave_r20.hip: complex spectrum, fused log-mel, magnitude / power / dBFS / one-sided rows.
+// Measured (tools/bench_configs.py gen<N>, 16 rows, 1.7 GB of output): 0.56 / 0.56 / 0.51-0.53 / 0.48-0.49 of 8 TB/s against 0.14 through
+// Bluestein.  The inverses: k_istft_rab below.
 #include "small_dft.hpp"
 
 namespace nxsig {
@@ -24,11 +24,26 @@ struct RabArgs {
   const v2f* tw;           // c64[B][A]: W_K^(n2 k1) at [n2 * A + k1]
   int64_t units_per_row;   // ceil(pairs_per_row / T): a unit = T frame pairs = 2 T frames
   int64_t total_units;
+  // sinks other than the complex spectrum (same fields as MelWaveArgs / R20Args)
+  int32_t mel_bins = 0, nnz = 0;
+  const float* csr_w = nullptr;
+  const int* csr_off = nullptr;
+  const int* csr_lo = nullptr;
+  float* out = nullptr;
+  int* gmax = nullptr;
+  int32_t mag_kind = -1;
 };
 
-template <int A, int B, bool SCALE, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_stft_rab(RabArgs b) {
+// SINK: kSinkSpectrum (c64 rows of K bins), kSinkMel (log-mel of the bins below K / 2), kSinkMag (|X| / |X|^2 / one-sided rows of them)
+// Three waves per SIMD where the registers allow it without scratch (spectrum sink of 320 / 480 / 640, log-mel of 320 / 480): 0.56 / 0.56 /
+// 0.51-0.53 of the roofline against 0.52 / 0.53 / 0.49 at two; 960 is held at two by its 75 KB of LDS per workgroup either way (0.48-0.49).
+// What made the third wave possible: ONE inlined copy of the transform + sink (the solo route re-enters it with sel = 0, 1) and the
+// untangle loop unrolled by 2 instead of fully — 216-256 registers became 145-167
+template <int A, int B, bool SCALE, int W, int SINK = kSinkSpectrum>
+__global__ __launch_bounds__(64 * W)
+__attribute__((amdgpu_waves_per_eu(((SINK == kSinkSpectrum && A * B != 960) || (SINK == kSinkMel && A * B <= 480)) ? 3 : 2, 3))) void k_stft_rab(RabArgs b) {
   const WaveArgs& a = b.w;
+  constexpr bool MEL = SINK == kSinkMel, MAG = SINK == kSinkMag;
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT;
   constexpr int TRS = A * (B + 1);                          // one transform's transposed block (row stride B + 1)
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;   // complex cells per wave: staging (<= 2 BUF floats) / T x TRS / T x KB
@@ -38,7 +53,18 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
   v2f* s_x = s_tw + KB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = b.tw[i]; }
+  float* s_csr = reinterpret_cast<float*>(s_x + W * BUF);
+  int* s_off = reinterpret_cast<int*>(s_csr + (MEL ? b.nnz : 0));
+  int* s_lo = s_off + (MEL ? b.mel_bins + 1 : 0);
+  if (MEL) {
+    for (int i = tid; i < b.nnz; i += 64 * W) s_csr[i] = b.csr_w[i];
+    for (int i = tid; i <= b.mel_bins; i += 64 * W) s_off[i] = b.csr_off[i];
+    for (int i = tid; i < b.mel_bins; i += 64 * W) s_lo[i] = b.csr_lo[i];
+  }
   __syncthreads();
+  float vmax = -3.0e38f;
+  bool melbad = false;
+  constexpr int HALF = KB / 2;
   v2f* buf = s_x + wave * BUF;
   float* S = reinterpret_cast<float*>(buf);
   const int g = lane / LT, l = lane % LT;         // transform of the unit (g >= T: idle lanes), lane inside it
@@ -112,6 +138,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
         v[n1] = t;
       }
     };
+    constexpr int NP = SINK == kSinkSpectrum ? KB / 2 : KB / 4;    // bin pairs per frame that reach the sink
+    constexpr int NI = (NP + 63) / 64;
+    v2f pw[T][2][NI];  // MEL: |XA|^2, |XB|^2 of the lane's bin pairs, parked in registers until every lane has read U
     auto xform_sink = [&](const int sel) {
       dft_n<A>(v);
       if (l < B) {
@@ -141,7 +170,6 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
       wave_lds_fence();
       // ---- untangle + store.  All 64 lanes walk the T transforms one after the other: lane takes the bin pairs p = lane + 64 i
       //      (bins 2 p, 2 p + 1), so a wave instruction stores 1 KiB of one frame's row contiguously
-      constexpr int NP = KB / 2, NI = (NP + 63) / 64;
 #pragma unroll
       for (int gg = 0; gg < T; ++gg) {
         const int64_t pr = T * u + gg;
@@ -151,9 +179,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
         const v2f* U = buf + gg * KB;
         v2f* zA = a.z + ((size_t)row * a.M + m0) * KB;
         v2f* zB = zA + KB;
-#pragma unroll
+#pragma unroll 2
         for (int i = 0; i < NI; ++i) {
           const int pi = lane + 64 * i;
+          if (MEL) { pw[gg][0][i] = v2f{0.f, 0.f}; pw[gg][1][i] = v2f{0.f, 0.f}; }
           if (act && pi < NP) {
             const int k = 2 * pi;
             const v4f uu = *reinterpret_cast<const v4f*>(&U[k]);
@@ -163,8 +192,27 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
             if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
             const bool stA = sel <= 0, stB = hb && sel != 0;      // solo rounds: the transform's real part is frame A (sel 0) / B (sel 1)
             if (sel == 1) xv = xa;
-            if (stA) __builtin_nontemporal_store(xa, (gv4f*)(zA + k));
-            if (stB) __builtin_nontemporal_store(xv, (gv4f*)(zB + k));
+            if (SINK == kSinkSpectrum) {
+              if (stA) __builtin_nontemporal_store(xa, (gv4f*)(zA + k));
+              if (stB) __builtin_nontemporal_store(xv, (gv4f*)(zB + k));
+            } else {
+              const v2f pa = v2f{xa.x * xa.x + xa.y * xa.y, xa.z * xa.z + xa.w * xa.w};
+              const v2f pb = v2f{xv.x * xv.x + xv.y * xv.y, xv.z * xv.z + xv.w * xv.w};
+              if (MEL) { pw[gg][0][i] = pa; pw[gg][1][i] = pb; }
+              else if (b.mag_kind == 3) {   // one-sided complex rows: the same values the spectrum sink stores, bins below K / 2 only
+                float* o = b.out + (((size_t)row * a.M + m0) * HALF + k) * 2;
+                if (stA) __builtin_nontemporal_store(xa, (gv4f*)o);
+                if (stB) __builtin_nontemporal_store(xv, (gv4f*)(o + 2 * HALF));
+              } else {
+                const v2f va = b.mag_kind == 1 ? pa : v2f{__builtin_sqrtf(pa.x), __builtin_sqrtf(pa.y)};
+                const v2f vb = b.mag_kind == 1 ? pb : v2f{__builtin_sqrtf(pb.x), __builtin_sqrtf(pb.y)};
+                float* o = b.out + ((size_t)row * a.M + m0) * HALF + k;
+                float mx = -3.0e38f;
+                if (stA) { __builtin_nontemporal_store(va, (gv2f*)o); mx = va.x > va.y ? va.x : va.y; }
+                if (stB) { __builtin_nontemporal_store(vb, (gv2f*)(o + HALF)); mx = vb.x > mx ? vb.x : mx; mx = vb.y > mx ? vb.y : mx; }
+                vmax = mx > vmax ? mx : vmax;
+              }
+            }
           }
         }
       }
@@ -180,35 +228,117 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
       for (int n1 = 1; n1 < A; ++n1) t += v[n1];
       const bool nf = ((__float_as_uint(t.x) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(t.y) & 0x7f800000u) == 0x7f800000u);
       solo = __builtin_amdgcn_ballot_w64(nf) != 0;
+      if (MEL) { melbad |= solo; solo = false; }   // log-mel: the whole tensor is poisoned instead (gmax[1], see stft_wave_body)
     }
-    if (solo) {
+    // one inlined copy of the transform + sink: the paired route is pass 0 with sel = -1; a non-finite unit takes two passes (sel 0, 1)
+    const int npass = solo ? 2 : 1;
 #pragma nounroll
-      for (int sel = 0; sel < 2; ++sel) {
-        if (sel == 1) {
+    for (int ps = 0; ps < npass; ++ps) {
+      const int sel = solo ? ps : -1;
+      if (solo) {
+        if (ps == 1) {
           wave_lds_fence();      // round A's partner reads are done
           stage_slow(xr, q0);    // the exchange overwrote the samples
           wave_lds_fence();
         }
         build(sel);
-        xform_sink(sel);
       }
-    } else {
-      xform_sink(-1);
+      xform_sink(sel);
+    }
+    if (MEL) {   // (pw[][][] was filled by xform_sink(-1))
+      wave_lds_fence();                          // every partner read of U is done: the buffer becomes the power spectra
+      float* mags = reinterpret_cast<float*>(buf);  // frame f of the unit (f = 2 g + {0, 1}) at mags[f * HALF + k]
+#pragma unroll
+      for (int gg = 0; gg < T; ++gg)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int pi = lane + 64 * i;
+          if (pi < NP) {
+            *reinterpret_cast<v2f*>(&mags[(2 * gg) * HALF + 2 * pi]) = pw[gg][0][i];
+            *reinterpret_cast<v2f*>(&mags[(2 * gg + 1) * HALF + 2 * pi]) = pw[gg][1][i];
+          }
+        }
+      wave_lds_fence();
+      // sparse filterbank + log10: one band per lane, the unit's 2 T frames share every weight
+      for (int mb = lane; mb < b.mel_bins; mb += 64) {
+        const int o0 = s_off[mb], o1 = s_off[mb + 1], k0 = s_lo[mb];
+        float acc[2 * T];
+#pragma unroll
+        for (int f = 0; f < 2 * T; ++f) acc[f] = 0.0f;
+        for (int jj = o0; jj < o1; ++jj) {
+          const float wv = s_csr[jj];
+#pragma unroll
+          for (int f = 0; f < 2 * T; ++f) acc[f] = fmaf(mags[f * HALF + k0 + (jj - o0)], wv, acc[f]);
+        }
+#pragma unroll
+        for (int f = 0; f < 2 * T; ++f) {
+          const int64_t m = 2 * T * u + f;
+          melbad |= (m < a.M) && !(acc[f] < INFINITY);
+          const float av = acc[f] > 1.0e-10f ? acc[f] : 1.0e-10f;
+          const float vv = __log2f(av) * 0.30102999566398120f;
+          if (m < a.M) { b.out[((size_t)row * a.M + m) * b.mel_bins + mb] = vv; vmax = vv > vmax ? vv : vmax; }
+        }
+      }
     }
     wave_lds_fence();  // all reads of the buffer are done before the next unit's samples overwrite it
+  }
+  if (MEL || (MAG && b.mag_kind == 2)) {  // one atomic per wave: running maximum in ordered-int encoding
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(vmax, off); vmax = o > vmax ? o : vmax; }
+    if (lane == 0 && p_begin + wave < p_end) {
+      const int i = __float_as_int(vmax);
+      atomicMax(b.gmax, i >= 0 ? i : i ^ 0x7fffffff);
+    }
+    if (MEL && __builtin_amdgcn_ballot_w64(melbad) != 0 && lane == 0) atomicOr(b.gmax + 1, 1);
   }
 }
 
 template <int A, int B>
-static int launch_rab(Ctx* c, const StftLaunch& s, bool* handled) {
+static int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel) {
   constexpr int W = 4, KB = A * B, LT = A > B ? A : B, T = 64 / LT;
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   const int nuse = s.fr.N < KB ? s.fr.N : KB;
   const int64_t span = (2 * T - 1) * (int64_t)s.fr.hop + nuse;
   if (span + 3 > 2 * BUF || span + 3 > 2560) return NXSIG_OK;   // the unit's span must fit the wave's buffer and the prefetch registers
-  *handled = true;
   RabArgs b;
+  int sink = kSinkSpectrum;
+  size_t lds_extra = 0;
+  if (mel && mel->mag_kind >= 0) {
+    sink = kSinkMag;
+    b.out = mel->out; b.mag_kind = mel->mag_kind;
+    int rcm = launch_mel_init(c, &b.gmax);
+    if (rcm) return rcm;
+  } else if (mel) {  // CSR of the triangular filter rows restricted to bins < K / 2
+    sink = kSinkMel;
+    std::vector<float> cw;
+    std::vector<int> off(mel->mel_bins + 1, 0), lo(mel->mel_bins, 0);
+    const int half = KB / 2;
+    for (int mb = 0; mb < mel->mel_bins; ++mb) {
+      const float* fr = mel->filters_host + (size_t)mb * KB;
+      int l = half, h = 0;
+      for (int k = 0; k < half; ++k)
+        if (fr[k] != 0.0f) { if (k < l) l = k; h = k + 1; }
+      if (h <= l) { l = 0; h = 0; }
+      lo[mb] = l;
+      for (int k = l; k < h; ++k) cw.push_back(fr[k]);
+      off[mb + 1] = (int)cw.size();
+    }
+    if (cw.empty()) cw.push_back(0.0f);
+    if (cw.size() > 6144 || mel->mel_bins > 1024) return NXSIG_OK;  // Bluestein / two-step path
+    const void *dw = nullptr, *doff = nullptr, *dlo = nullptr;
+    int rcm;
+    if ((rcm = ctx_table(c, 0xC5A1ull, cw.data(), cw.size() * sizeof(float), &dw))) return rcm;
+    if ((rcm = ctx_table(c, 0xC5A2ull, off.data(), off.size() * sizeof(int), &doff))) return rcm;
+    if ((rcm = ctx_table(c, 0xC5A3ull, lo.data(), lo.size() * sizeof(int), &dlo))) return rcm;
+    b.mel_bins = mel->mel_bins; b.nnz = (int)cw.size();
+    b.csr_w = reinterpret_cast<const float*>(dw); b.csr_off = reinterpret_cast<const int*>(doff); b.csr_lo = reinterpret_cast<const int*>(dlo);
+    b.out = mel->out;
+    if ((rcm = launch_mel_init(c, &b.gmax))) return rcm;
+    lds_extra = (size_t)b.nnz * 4 + (size_t)(2 * mel->mel_bins + 1) * 4;
+  }
+  *handled = true;
+  if (mel) *mel->handled = true;
   WaveArgs& a = b.w;
   a.x = s.x; a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
   a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
@@ -235,10 +365,10 @@ static int launch_rab(Ctx* c, const StftLaunch& s, bool* handled) {
     c->memo[key] = {reinterpret_cast<uint64_t>(dt)};
     b.tw = reinterpret_cast<const v2f*>(dt);
   }
-  a.chunk = (int64_t)W * 4;   // four units per wave (two: -1 ... -3 %), short-lived workgroups (the geometry of kernels_wave_r20.hip)
+  a.chunk = (int64_t)W * (sink == kSinkMel ? 8 : 4);   // four units per wave (two: -1 ... -3 %), short-lived workgroups; the mel sink amortises its CSR preload
   const int64_t blocks = (b.total_units + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
-  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)W * BUF * 8;
+  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)W * BUF * 8 + lds_extra;
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -246,19 +376,30 @@ static int launch_rab(Ctx* c, const StftLaunch& s, bool* handled) {
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
-  return s.has_scale ? go(k_stft_rab<A, B, true, W>) : go(k_stft_rab<A, B, false, W>);
+  int rc;
+  if (sink == kSinkMel) rc = s.has_scale ? go(k_stft_rab<A, B, true, W, kSinkMel>) : go(k_stft_rab<A, B, false, W, kSinkMel>);
+  else if (sink == kSinkMag) rc = s.has_scale ? go(k_stft_rab<A, B, true, W, kSinkMag>) : go(k_stft_rab<A, B, false, W, kSinkMag>);
+  else rc = s.has_scale ? go(k_stft_rab<A, B, true, W>) : go(k_stft_rab<A, B, false, W>);
+  if (rc) return rc;
+  if (sink == kSinkMel) return launch_mel_finish(c, mel->out, (int64_t)s.batch * s.fr.M * mel->mel_bins, b.gmax);
+  if (sink == kSinkMag && mel->mag_kind == 2) {
+    const int64_t n = (int64_t)s.batch * s.fr.M * (KB / 2);
+    hipLaunchKernelGGL(k_mag_db_pass2, dim3(mag_db_blocks(c, n)), dim3(256), 0, c->stream, mel->out, n, b.gmax);
+    NXSIG_HIP_TRY(hipGetLastError());
+  }
+  return NXSIG_OK;
 }
 
-// fft_length 320 / 480 / 640 / 960 (complex spectrum sink); handled = false: the caller falls through to the Bluestein kernel
-int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled) {
+// fft_length 320 / 480 / 640 / 960, every sink; handled = false: the caller falls through to the Bluestein kernel
+int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel) {
   *handled = false;
   if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
   if (tune(c, kT_DISABLE_RAB, 0) || tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   switch (s.K) {
-    case 320: return launch_rab<16, 20>(c, s, handled);
-    case 480: return launch_rab<24, 20>(c, s, handled);   // (16 x 30 measured 0.45 of the roofline against 0.51: half of its pass-B lanes idle)
-    case 640: return launch_rab<32, 20>(c, s, handled);
-    case 960: return launch_rab<32, 30>(c, s, handled);
+    case 320: return launch_rab<16, 20>(c, s, handled, mel);
+    case 480: return launch_rab<24, 20>(c, s, handled, mel);   // (16 x 30 measured 0.45 of the roofline against 0.51: half of its pass-B lanes idle)
+    case 640: return launch_rab<32, 20>(c, s, handled, mel);
+    case 960: return launch_rab<32, 30>(c, s, handled, mel);
     default: return NXSIG_OK;
   }
 }

@@ -573,3 +573,28 @@ def test_istft_composite_lengths_non_finite_bins_stay_in_their_frames():
         assert np.array_equal(np.isfinite(y), np.isfinite(yo)), K
         ok = np.isfinite(yo)
         assert float(np.max(np.abs(y[ok] - yo[ok])) / np.max(np.abs(yo[ok]))) < 1e-5
+
+
+@pytest.mark.parametrize("K,N,hop,pad", [(320, 320, 160, "reflect"), (480, 400, 160, "valid"), (640, 640, 160, "reflect"), (960, 960, 240, "valid")])
+def test_composite_lengths_fused_sinks(K, N, hop, pad):
+    """the log-mel, magnitude / power / dBFS and one-sided sinks of kernels_wave_rab.hip (round 5): bit-identical to the same sinks on the
+    Bluestein kernels' INPUT (same oracle), i.e. against the oracle to the tolerances the other front-ends' sink tests use"""
+    import nx_signal_amd as S
+    from oracle import nx_oracle as O
+
+    rng = np.random.default_rng(K + N)
+    x = rng.standard_normal((2, 30 * hop + N)).astype(np.float32)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, sampling_rate=16000)
+    zo = np.stack([O.stft(r, w, **opts)[0] for r in x])
+    mel = S.mel_spectrogram(x, w, mel_bins=80, **opts)
+    # reduce_max is over the WHOLE tensor (both rows): the oracle on the stacked spectrogram
+    melo = O.stft_to_mel(zo.reshape(-1, K), 16000, K, 80).reshape(2, -1, 80)
+    assert mel.shape == melo.shape and float(np.max(np.abs(mel - melo))) < 1e-4
+    for kind in ("magnitude", "power"):
+        g, _, _ = S.spectrogram(x, w, kind=kind, **opts)
+        ref = np.abs(zo[..., : K // 2]) if kind == "magnitude" else np.abs(zo[..., : K // 2].astype(np.complex128)) ** 2
+        assert g.shape == ref.shape and float(np.max(np.abs(g - ref)) / np.max(np.abs(ref))) < 1e-5, kind
+    z1, _, _ = S.stft_onesided(S.default_context(0).to_device(x), w, **opts)
+    zf, _, _ = S.stft(x, w, **opts)
+    assert np.array_equal(z1.numpy().view(np.uint32), np.ascontiguousarray(zf[..., : K // 2]).view(np.uint32))   # the same bits as stft's first half

@@ -1075,13 +1075,19 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
     const int64_t mA = 2 * pin, mB = mA + 1;
     const bool haveB = mB < a.M;
     const float* xr = a.x + (size_t)row * a.batch_stride;
-    const int64_t qA = mA * a.hop, qB = qA + a.hop;
-    // every sample of both frames inside the signal: plain loads; otherwise per-sample padding / mirror math
-    const bool inside = a.reflect == 0 && qA - a.lo >= 0 && (haveB ? qB : qA) - a.lo + nuse <= a.L;
     v2f zz[2][NQ];
-    // sel < 0: the pair rides as frame A + i frame B; sel = 0 / 1: frame A / B ALONE as the real part (solo route, below).
-    // Returns whether a windowed sample of the unit is not finite (wave-uniform).
-    auto load_unit = [&](const int sel) -> bool {
+    // One pass = frames (m0, m0 + 1 if two) as re / im of one transform pair.  The paired route is (mA, haveB).  The reference transforms
+    // every frame alone (lib/nx_signal.ex:94-102): a pair whose windowed samples are not all finite is redone as (mA, alone) and
+    // (mB, alone) — the SAME code with the second frame absent: the imaginary slot is zero and only slot 0 is stored (round 5: the
+    // earlier `sel` selector inside load and sink doubled the kernel's registers: 234 -> 121 at C = 1024, 556 B of scratch -> 0 at 2048)
+    int64_t m0 = mA;
+    bool two = haveB;
+    int stage = 0;   // 0: paired, 1: frame A alone, 2: frame B alone
+#pragma nounroll
+    for (;;) {
+      const int64_t qA = m0 * a.hop, qB = qA + a.hop;
+      // every sample of the pass's frames inside the signal: plain loads; otherwise per-sample padding / mirror math
+      const bool inside = a.reflect == 0 && qA - a.lo >= 0 && (two ? qB : qA) - a.lo + nuse <= a.L;
       v2f sum = v2f{0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
@@ -1091,78 +1097,67 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
           v2f v = v2f{0.f, 0.f};
           if (128 * q < nuse && n < nuse) {
             float va, vb;
-            if (inside) { va = xr[qA - a.lo + n]; vb = haveB ? xr[qB - a.lo + n] : 0.0f; }
-            else { va = fetch_any(xr, a, qA + n); vb = haveB ? fetch_any(xr, a, qB + n) : 0.0f; }
+            if (inside) { va = xr[qA - a.lo + n]; vb = two ? xr[qB - a.lo + n] : 0.0f; }
+            else { va = fetch_any(xr, a, qA + n); vb = two ? fetch_any(xr, a, qB + n) : 0.0f; }
             const float w = s_w[n];
-            const v2f u = sel < 0 ? v2f{va * w, vb * w} : v2f{(sel == 0 ? va : vb) * w, 0.0f};
+            const v2f u = v2f{va * w, vb * w};
             sum += u;
             v = wcmul(u, s_ch[n]);   // windowed samples (exact f32 products, :101) times the chirp
           }
           zz[e][q] = v;
         }
-      const bool nf = ((__float_as_uint(sum.x) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(sum.y) & 0x7f800000u) == 0x7f800000u);
-      return __builtin_amdgcn_ballot_w64(nf) != 0;
-    };
-    auto xform_sink = [&](const int sel) {
-    v2f d[P];
-    wave_fft_core_T<C>(zz, d, xb, s_twB, s_twC, lane);
-#pragma unroll
-    for (int s = 0; s < P; ++s) d[s] = wcmul(d[s], s_Bf[lane + 64 * s]);
-    v2f y[2][NQ];
-    wave_fft_core<C, true>(d, y, xb, s_twBi, s_twCi, lane);
-    // U[k] = y[k] c[k] = XA[k] + i XB[k], k < Kb: park it in the exchange buffer for the partner read
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int k = 2 * lane + e + 128 * q;
-        if (128 * q < Kb && k < Kb) { y[e][q] = wcmul(y[e][q], s_ch[k]); xb[k] = y[e][q]; }
+      const bool nfl = ((__float_as_uint(sum.x) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(sum.y) & 0x7f800000u) == 0x7f800000u);
+      const bool unit_nf = __builtin_amdgcn_ballot_w64(nfl) != 0;
+      if (stage == 0 && unit_nf) {
+        if (MEL) melbad = true;                                   // log-mel: the whole tensor is poisoned instead (see stft_wave_body)
+        else if (haveB) { stage = 1; two = false; continue; }     // leave the paired route
       }
-    wave_lds_fence();
-    v2f* zA = a.z + ((size_t)row * a.M + mA) * Kb;
-    v2f* zB = zA + Kb;
+      v2f d[P];
+      wave_fft_core_T<C>(zz, d, xb, s_twB, s_twC, lane);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+      for (int s = 0; s < P; ++s) d[s] = wcmul(d[s], s_Bf[lane + 64 * s]);
+      v2f y[2][NQ];
+      wave_fft_core<C, true>(d, y, xb, s_twBi, s_twCi, lane);
+      // U[k] = y[k] c[k] = XA[k] + i XB[k], k < Kb: park it in the exchange buffer for the partner read
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int k = 2 * lane + e + 128 * q;
-        if (128 * q < Kb && k < Kb) {
-          const v2f u = y[e][q];
-          const v2f p = xb[k == 0 ? 0 : Kb - k];
-          v2f xa = fft_eps0(v2f{u.x + p.x, u.y - p.y} * 0.5f);
-          v2f xv = fft_eps0(v2f{u.y + p.y, p.x - u.x} * 0.5f);
-          if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
-          const bool stA = sel <= 0, stB = haveB && sel != 0;   // solo rounds: the real part is frame A (sel 0) / frame B (sel 1)
-          if (sel == 1) xv = xa;
-          if (SINK == kSinkSpectrum) {
-            if (stA) __builtin_nontemporal_store(xa, (gv2f*)(zA + k));
-            if (stB) __builtin_nontemporal_store(xv, (gv2f*)(zB + k));
-          } else if (k < half) {
-            const float pa = xa.x * xa.x + xa.y * xa.y, pb = xv.x * xv.x + xv.y * xv.y;
-            if (MEL) { mags[k] = pa; mags[half + k] = pb; }
-            else {
-              const float va = b.mag_kind == 1 ? pa : __builtin_sqrtf(pa), vb = b.mag_kind == 1 ? pb : __builtin_sqrtf(pb);
-              float* o = b.out + ((size_t)row * a.M + mA) * half + k;
-              if (stA) { o[0] = va; vmax = va > vmax ? va : vmax; }
-              if (stB) { o[half] = vb; vmax = vb > vmax ? vb : vmax; }
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int k = 2 * lane + e + 128 * q;
+          if (128 * q < Kb && k < Kb) { y[e][q] = wcmul(y[e][q], s_ch[k]); xb[k] = y[e][q]; }
+        }
+      wave_lds_fence();
+      v2f* zA = a.z + ((size_t)row * a.M + m0) * Kb;
+      v2f* zB = zA + Kb;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int k = 2 * lane + e + 128 * q;
+          if (128 * q < Kb && k < Kb) {
+            const v2f u = y[e][q];
+            const v2f p = xb[k == 0 ? 0 : Kb - k];
+            v2f xa = fft_eps0(v2f{u.x + p.x, u.y - p.y} * 0.5f);
+            v2f xv = fft_eps0(v2f{u.y + p.y, p.x - u.x} * 0.5f);
+            if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
+            if (SINK == kSinkSpectrum) {
+              __builtin_nontemporal_store(xa, (gv2f*)(zA + k));
+              if (two) __builtin_nontemporal_store(xv, (gv2f*)(zB + k));
+            } else if (k < half) {
+              const float pa = xa.x * xa.x + xa.y * xa.y, pb = xv.x * xv.x + xv.y * xv.y;
+              if (MEL) { mags[k] = pa; mags[half + k] = pb; }
+              else {
+                const float va = b.mag_kind == 1 ? pa : __builtin_sqrtf(pa), vb = b.mag_kind == 1 ? pb : __builtin_sqrtf(pb);
+                float* o = b.out + ((size_t)row * a.M + m0) * half + k;
+                o[0] = va; vmax = va > vmax ? va : vmax;
+                if (two) { o[half] = vb; vmax = vb > vmax ? vb : vmax; }
+              }
             }
           }
         }
-      }
-    };  // xform_sink
-    // non-finite samples: the reference transforms every frame alone (lib/nx_signal.ex:94-102); a pair whose windowed samples
-    // are not all finite leaves the paired route and its frames ride alone, one after the other (same scheme as stft_wave_body)
-    const bool unit_nf = load_unit(-1);
-    if (MEL && unit_nf) melbad = true;
-    if (unit_nf && !MEL && haveB) {
-#pragma nounroll
-      for (int sel = 0; sel < 2; ++sel) {
-        load_unit(sel);
-        xform_sink(sel);
-        wave_lds_fence();
-      }
-    } else {
-      xform_sink(-1);
+      if (stage != 1) break;
+      wave_lds_fence();   // the partner reads of this pass are done before the next pass parks its spectrum
+      stage = 2; m0 = mB;
     }
     if (MEL) {
       wave_lds_fence();

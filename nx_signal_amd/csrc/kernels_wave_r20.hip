@@ -17,7 +17,7 @@ namespace nxsig {
 
 struct R20Args {
   WaveArgs w;              // framing, window (f32[400], zero beyond N), div / has_scale, z; pairs_per_row = ceil(M / 2)
-  const v2f* tw;           // c64[20][20]: W_400^(n2 k1) at [n2 * 20 + k1]
+  const v2f* tw;           // c64[20][20]: W_400^(n2 k1) at [k1 * 20 + n2] (symmetric; read with the lane index last: no LDS bank conflict)
   int64_t units_per_row;   // ceil(pairs_per_row / 3): a unit = three frame pairs = six frames
   int64_t total_units;
   int32_t fast_ok;         // prefetch aligned, in-bounds spans with 16-byte loads one unit ahead
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
     auto xform_sink = [&](const int sel) {
     dft20(v);
 #pragma unroll
-    for (int k1 = 1; k1 < 20; ++k1) v[k1] = wcmul(v[k1], s_tw[l20 * 20 + k1]);
+    for (int k1 = 1; k1 < 20; ++k1) v[k1] = wcmul(v[k1], s_tw[k1 * 20 + l20]);
     wave_lds_fence();                               // every lane has read its samples: the buffer becomes the exchange
     if (g < 3) {
 #pragma unroll
@@ -343,7 +343,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   for (int n2 = 0; n2 < 20; ++n2)
     for (int k1 = 0; k1 < 20; ++k1) {
       const double ang = -6.283185307179586476925286766559 * (double)(n2 * k1) / (double)KB;
-      tw[(size_t)n2 * 20 + k1] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      tw[(size_t)k1 * 20 + n2] = make_float2((float)std::cos(ang), (float)std::sin(ang));
     }
   const void* dt = nullptr;
   int rc = ctx_table(c, 0x20A20ull, tw.data(), tw.size() * sizeof(float2), &dt);
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_r20(IstftR20Args a) {
     }
     dft20(v);
 #pragma unroll
-    for (int k1 = 1; k1 < 20; ++k1) v[k1] = wcmul(v[k1], s_tw[l20 * 20 + k1]);
+    for (int k1 = 1; k1 < 20; ++k1) v[k1] = wcmul(v[k1], s_tw[k1 * 20 + l20]);
     wave_lds_fence();
     if (g < 3) {
 #pragma unroll
@@ -546,7 +546,7 @@ int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, boo
     for (int n2 = 0; n2 < 20; ++n2)
       for (int k1 = 0; k1 < 20; ++k1) {
         const double ang = -6.283185307179586476925286766559 * (double)(n2 * k1) / (double)KB;
-        tw[(size_t)n2 * 20 + k1] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        tw[(size_t)k1 * 20 + n2] = make_float2((float)std::cos(ang), (float)std::sin(ang));
       }
     const void* dt = nullptr;
     int rc = ctx_table(c, 0x20A20ull, tw.data(), tw.size() * sizeof(float2), &dt);

@@ -21,7 +21,8 @@ namespace nxsig {
 
 struct RabArgs {
   WaveArgs w;              // framing, window (f32[K], zero beyond N), div / has_scale, z; pairs_per_row = ceil(M / 2)
-  const v2f* tw;           // c64[B][A]: W_K^(n2 k1) at [n2 * A + k1]
+  const v2f* tw;           // c64[A][B]: W_K^(n2 k1) at [k1 * B + n2]: the lanes n2 of pass A read consecutive cells (at [n2 * A + k1]
+                           // every lane of a group hit the same LDS bank: 67 % of the LDS cycles of the 960-point kernel were bank conflicts)
   int64_t units_per_row;   // ceil(pairs_per_row / T): a unit = T frame pairs = 2 T frames
   int64_t total_units;
   // sinks other than the complex spectrum (same fields as MelWaveArgs / R20Args)
@@ -51,7 +52,7 @@ __attribute__((amdgpu_waves_per_eu(((SINK == kSinkSpectrum && A * B != 960) || (
   float* s_w = reinterpret_cast<float*>(g_wave_smem);
   v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
   v2f* s_x = s_tw + KB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: unit arithmetic on the scalar unit
   for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = b.tw[i]; }
   float* s_csr = reinterpret_cast<float*>(s_x + W * BUF);
   int* s_off = reinterpret_cast<int*>(s_csr + (MEL ? b.nnz : 0));
@@ -77,9 +78,7 @@ __attribute__((amdgpu_waves_per_eu(((SINK == kSinkSpectrum && A * B != 960) || (
   if (p_end > b.total_units) p_end = b.total_units;
   // the span of a unit that lies inside the stored row (and is 16-byte aligned) is fetched one unit ahead into registers
   v4f rs[NRS];
-  auto prefetch = [&](int64_t ui) -> bool {
-    const int64_t row = ui / b.units_per_row;
-    const int64_t u = ui - row * b.units_per_row;
+  auto prefetch = [&](int64_t row, int64_t u) -> bool {
     const int64_t start = 2 * T * u * (int64_t)a.hop - a.lo;
     const float* p = a.x + (size_t)row * a.batch_stride + start;
     const bool inside = a.reflect == 0 && start >= 0 && start + span4 <= a.L && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
@@ -100,10 +99,13 @@ __attribute__((amdgpu_waves_per_eu(((SINK == kSinkSpectrum && A * B != 960) || (
     }
   };
   constexpr bool PF = LT < 30;   // register prefetch of the next unit's span (the 30- / 32-point codelets need the registers)
-  bool have = (PF && p_begin + wave < p_end) ? prefetch(p_begin + wave) : false;
+  // (row, unit inside the row) of the wave's units: one division per wave, then increments
+  int64_t row = (p_begin + wave) / b.units_per_row;
+  int64_t u = (p_begin + wave) - row * b.units_per_row;
+  bool have = (PF && p_begin + wave < p_end) ? prefetch(row, u) : false;
   for (int64_t ui = p_begin + wave; ui < p_end; ui += W) {
-    const int64_t row = ui / b.units_per_row;
-    const int64_t u = ui - row * b.units_per_row;
+    int64_t nrow = row, nu = u + W;
+    while (nu >= b.units_per_row) { nu -= b.units_per_row; ++nrow; }
     const float* xr = a.x + (size_t)row * a.batch_stride;
     const int64_t q0 = 2 * T * u * (int64_t)a.hop;    // padded-signal index of the unit's first sample
     // ---- the unit's raw samples -> LDS
@@ -115,7 +117,7 @@ __attribute__((amdgpu_waves_per_eu(((SINK == kSinkSpectrum && A * B != 960) || (
       stage_slow(xr, q0);
     }
     wave_lds_fence();
-    have = (PF && ui + W < p_end) ? prefetch(ui + W) : false;   // next unit's samples travel during this unit's transforms
+    have = (PF && ui + W < p_end) ? prefetch(nrow, nu) : false;   // next unit's samples travel during this unit's transforms
     const int64_t pair = T * u + g;
     const bool active = g < T && pair < a.pairs_per_row;
     const int64_t mA = 2 * pair;
@@ -126,17 +128,23 @@ __attribute__((amdgpu_waves_per_eu(((SINK == kSinkSpectrum && A * B != 960) || (
     auto build = [&](int sel) {
       const float* fa = S + (2 * (g < T ? g : 0)) * a.hop + l;
       const float* fb = fa + a.hop;
+      const bool on = active && l < B, onB = on && haveB;
+      // unconditional LDS reads + selects (a branch per element cost more than the selects; the reads of idle lanes and of n >= nuse stay
+      // inside the wave's buffer, launch_rab checks it, and are discarded, never multiplied by zero: Inf x 0 would be NaN).  SHORT: the
+      // window is shorter than the transform (wave-uniform): only then does an element need its own compare
+      auto fill = [&](auto short_window) {
+        constexpr bool SHORT = decltype(short_window)::value;
 #pragma unroll
-      for (int n1 = 0; n1 < A; ++n1) {
-        const int n = B * n1 + l;
-        v2f t = v2f{0.f, 0.f};
-        if (active && l < B && n < nuse) {
+        for (int n1 = 0; n1 < A; ++n1) {
+          const int n = B * n1 + l;
+          const bool in = !SHORT || n < nuse;
           const float w = s_w[n];
-          const float pa = fa[B * n1] * w, pb = haveB ? fb[B * n1] * w : 0.0f;  // exact f32 products like the reference (:101)
-          t = sel < 0 ? v2f{pa, pb} : v2f{sel == 0 ? pa : pb, 0.0f};
+          const float pa = fa[B * n1] * w, pb = fb[B * n1] * w;  // exact f32 products like the reference (:101)
+          const float qa = (on && in) ? pa : 0.0f, qb = (onB && in) ? pb : 0.0f;
+          v[n1] = sel < 0 ? v2f{qa, qb} : v2f{sel == 0 ? qa : qb, 0.0f};
         }
-        v[n1] = t;
-      }
+      };
+      if (nuse == KB) fill(std::false_type{}); else fill(std::true_type{});
     };
     constexpr int NP = SINK == kSinkSpectrum ? KB / 2 : KB / 4;    // bin pairs per frame that reach the sink
     constexpr int NI = (NP + 63) / 64;
@@ -146,7 +154,7 @@ __attribute__((amdgpu_waves_per_eu(((SINK == kSinkSpectrum && A * B != 960) || (
       if (l < B) {
 #pragma unroll
         for (int k1 = 1; k1 < A; ++k1) {
-          v[k1] = wcmul(v[k1], s_tw[l * A + k1]);
+          v[k1] = wcmul(v[k1], s_tw[k1 * B + l]);
           if (A > 16 && (k1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -281,6 +289,7 @@ __attribute__((amdgpu_waves_per_eu(((SINK == kSinkSpectrum && A * B != 960) || (
       }
     }
     wave_lds_fence();  // all reads of the buffer are done before the next unit's samples overwrite it
+    row = nrow; u = nu;
   }
   if (MEL || (MAG && b.mag_kind == 2)) {  // one atomic per wave: running maximum in ordered-int encoding
 #pragma unroll
@@ -300,7 +309,8 @@ static int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   const int nuse = s.fr.N < KB ? s.fr.N : KB;
   const int64_t span = (2 * T - 1) * (int64_t)s.fr.hop + nuse;
-  if (span + 3 > 2 * BUF || span + 3 > 2560) return NXSIG_OK;   // the unit's span must fit the wave's buffer and the prefetch registers
+  if (span + 3 > 2560) return NXSIG_OK;   // the unit's span must fit the prefetch registers
+  if ((2 * T - 1) * (int64_t)s.fr.hop + KB + LT > 2 * BUF) return NXSIG_OK;   // ... and every lane's reads (idle lanes included) the wave's buffer
   RabArgs b;
   int sink = kSinkSpectrum;
   size_t lds_extra = 0;
@@ -357,7 +367,7 @@ static int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
     for (int n2 = 0; n2 < B; ++n2)
       for (int k1 = 0; k1 < A; ++k1) {
         const double ang = -6.283185307179586476925286766559 * (double)(n2 * k1) / (double)KB;
-        tw[(size_t)n2 * A + k1] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        tw[(size_t)k1 * B + n2] = make_float2((float)std::cos(ang), (float)std::sin(ang));
       }
     const void* dt = nullptr;
     int rc = ctx_table(c, 0x2AB0ull ^ ((uint64_t)A << 16) ^ (uint64_t)B, tw.data(), tw.size() * sizeof(float2), &dt);
@@ -419,7 +429,7 @@ struct IstftRabArgs {
   int64_t out_len;            // (M - 1) hop + K
   int64_t units_per_row, run_len, runs_per_row, total_runs;
   const float* wtab;          // f32[K]
-  const v2f* tw;              // c64[B][A] forward twiddles W_K^(n2 k1)
+  const v2f* tw;              // c64[A][B] forward twiddles W_K^(n2 k1) at [k1 * B + n2]
   float scale;
   const float* den;           // f32[2 RP - 1][hop]: reciprocal of the guarded normaliser: head segments, interior, tail segments
   v2f* y;                     // c64[batch][out_len]
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
     if (l < B) {
 #pragma unroll
       for (int k1 = 1; k1 < A; ++k1) {
-        v[k1] = wcmul(v[k1], s_tw[l * A + k1]);
+        v[k1] = wcmul(v[k1], s_tw[k1 * B + l]);
         if (A > 16 && (k1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -590,7 +600,7 @@ static int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
       for (int n2 = 0; n2 < B; ++n2)
         for (int k1 = 0; k1 < A; ++k1) {
           const double ang = -6.283185307179586476925286766559 * (double)(n2 * k1) / (double)KB;
-          tw[(size_t)n2 * A + k1] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+          tw[(size_t)k1 * B + n2] = make_float2((float)std::cos(ang), (float)std::sin(ang));
         }
       const void* dt = nullptr;
       int rc = ctx_table(c, 0x2AB0ull ^ ((uint64_t)A << 16) ^ (uint64_t)B, tw.data(), tw.size() * sizeof(float2), &dt);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
   float* s_w = reinterpret_cast<float*>(g_wave_smem);
   v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
   v2f* s_x = s_tw + KB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: unit arithmetic on the scalar unit
   for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = b.tw[i]; }
   float* s_csr = reinterpret_cast<float*>(s_x + W * BUF);
   int* s_off = reinterpret_cast<int*>(s_csr + (MEL ? b.nnz : 0));
@@ -66,9 +66,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
   if (p_end > b.total_units) p_end = b.total_units;
   // the span of a unit that lies inside the stored row (and is 16-byte aligned) is fetched one unit ahead into registers
   v4f rs[10];
-  auto prefetch = [&](int64_t ui) -> bool {
-    const int64_t row = ui / b.units_per_row;
-    const int64_t u = ui - row * b.units_per_row;
+  auto prefetch = [&](int64_t row, int64_t u) -> bool {
     const int64_t start = 6 * u * (int64_t)a.hop - a.lo;
     const float* p = a.x + (size_t)row * a.batch_stride + start;
     const bool inside = b.fast_ok && a.reflect == 0 && start >= 0 && start + span4 <= a.L && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
@@ -88,10 +86,13 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
       for (int i = lane; i < span; i += 64) S[i] = fetch_any(xr, a, q0 + i);
     }
   };
-  bool have = (p_begin + wave < p_end) ? prefetch(p_begin + wave) : false;
+  // (row, unit inside the row) of the wave's units: one division per wave, then increments
+  int64_t row = (p_begin + wave) / b.units_per_row;
+  int64_t u = (p_begin + wave) - row * b.units_per_row;
+  bool have = (p_begin + wave < p_end) ? prefetch(row, u) : false;
   for (int64_t ui = p_begin + wave; ui < p_end; ui += W) {
-    const int64_t row = ui / b.units_per_row;
-    const int64_t u = ui - row * b.units_per_row;
+    int64_t nrow = row, nu = u + W;
+    while (nu >= b.units_per_row) { nu -= b.units_per_row; ++nrow; }
     const float* xr = a.x + (size_t)row * a.batch_stride;
     const int64_t q0 = 6 * u * (int64_t)a.hop;    // padded-signal index of the unit's first sample
     // ---- the unit's raw samples -> LDS
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
       stage_slow(xr, q0);
     }
     wave_lds_fence();
-    have = (ui + W < p_end) ? prefetch(ui + W) : false;   // next unit's samples travel during this unit's transforms
+    have = (ui + W < p_end) ? prefetch(nrow, nu) : false;   // next unit's samples travel during this unit's transforms
     // ---- pass A: lane n2 = l20 of transform g: u[20 n1 + n2] = (frame A + i frame B) x window
     const int64_t pair = 3 * u + g;
     const bool active = g < 3 && pair < a.pairs_per_row;
@@ -114,17 +115,23 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
     auto build = [&](int sel) {
       const float* fa = S + (2 * (g < 3 ? g : 0)) * a.hop + l20;
       const float* fb = fa + a.hop;
+      const bool onB = active && haveB;
+      // unconditional LDS reads + selects instead of a branch per element (the reads stay inside the wave's buffer, launch_stft_r20
+      // checks it; what is not wanted is discarded, never multiplied by zero: Inf x 0 would be NaN).  SHORT: the window is shorter
+      // than the transform (wave-uniform): only then does an element need its own compare
+      auto fill = [&](auto short_window) {
+        constexpr bool SHORT = decltype(short_window)::value;
 #pragma unroll
-      for (int n1 = 0; n1 < 20; ++n1) {
-        const int n = 20 * n1 + l20;
-        v2f t = v2f{0.f, 0.f};
-        if (active && n < nuse) {
+        for (int n1 = 0; n1 < 20; ++n1) {
+          const int n = 20 * n1 + l20;
+          const bool in = !SHORT || n < nuse;
           const float w = s_w[n];
-          const float pa = fa[20 * n1] * w, pb = haveB ? fb[20 * n1] * w : 0.0f;  // exact f32 products like the reference (:101)
-          t = sel < 0 ? v2f{pa, pb} : v2f{sel == 0 ? pa : pb, 0.0f};
+          const float pa = fa[20 * n1] * w, pb = fb[20 * n1] * w;  // exact f32 products like the reference (:101)
+          const float qa = (active && in) ? pa : 0.0f, qb = (onB && in) ? pb : 0.0f;
+          v[n1] = sel < 0 ? v2f{qa, qb} : v2f{sel == 0 ? qa : qb, 0.0f};
         }
-        v[n1] = t;
-      }
+      };
+      if (nuse == KB) fill(std::false_type{}); else fill(std::true_type{});
     };
     constexpr int NP = SINK == kSinkSpectrum ? 200 : 100;    // bin pairs per frame that reach the sink
     constexpr int NI = (NP + 63) / 64;
@@ -269,6 +276,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
       }
     }
     wave_lds_fence();  // all reads of the buffer are done before the next unit's samples overwrite it
+    row = nrow; u = nu;
   }
   if (MEL || (MAG && b.mag_kind == 2)) {  // one atomic per wave: running maximum in ordered-int encoding
 #pragma unroll
@@ -287,7 +295,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   if (s.K != KB || s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
   if (tune(c, kT_DISABLE_R20, 0) || tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   const int nuse = s.fr.N < KB ? s.fr.N : KB;
-  if (5 * (int64_t)s.fr.hop + nuse > 2 * BUF) return NXSIG_OK;  // the unit's span must fit the wave's buffer
+  if (5 * (int64_t)s.fr.hop + KB + 4 > 2 * BUF) return NXSIG_OK;  // every lane's reads of the unit's span (idle lanes included) must fit the wave's buffer
   R20Args b;
   b.mel_bins = 0; b.nnz = 0; b.csr_w = nullptr; b.csr_off = nullptr; b.csr_lo = nullptr; b.out = nullptr; b.gmax = nullptr;
   b.mag_kind = -1;
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_r20(IstftR20Args a) {
   v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
   v2f* s_x = s_tw + KB;
   v2f* s_carry = s_x + W * BUF;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = a.tw[i]; }
   __syncthreads();
   v2f* buf = s_x + wave * BUF;
@@ -500,8 +508,11 @@ __global__ __launch_bounds__(64 * W) void k_istft_r20(IstftR20Args a) {
       const bool inside = u >= u0 && tabs < a.out_len;
       v2f rd = v2f{0.f, 0.f};
       if (inside) {
-        const int64_t seg = tabs / hop;
-        const int pos = (int)(tabs - seg * hop);
+        int f = 0;                        // hop segment of the unit that holds t (a 64-bit division per lane and iteration until round 5)
+#pragma unroll
+        for (int j = 1; j < 3; ++j) f += t >= j * hop ? 1 : 0;
+        const int64_t seg = (int64_t)3 * u + f;
+        const int pos = t - f * hop;
         const int64_t trow = seg < a.RP - 1 ? seg : (seg >= a.M ? a.RP + (seg - a.M) : a.RP - 1);
         rd = *reinterpret_cast<const v2f*>(a.den + trow * hop + pos);
       }
@@ -528,7 +539,7 @@ __global__ __launch_bounds__(64 * W) void k_istft_r20(IstftR20Args a) {
 
 int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   *handled = false;
-  constexpr int W = 4, KB = 400, BUF = 1280, CMAX = 400;
+  constexpr int W = 11, KB = 400, BUF = 1280, CMAX = 400;   // one workgroup of 11 waves per CU: 153 KB of LDS (13.4 KB per wave + the tables once)
   if (s.K != KB || s.N != KB || s.M == 0 || s.batch == 0 || window_host == nullptr) return NXSIG_OK;
   if (tune(c, kT_DISABLE_R20, 0) || tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
   const int hop = s.hop;
@@ -589,7 +600,7 @@ int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, boo
   const int64_t segs = (a.out_len + hop - 1) / hop;              // hop segments of the output (the last may be partial)
   a.units_per_row = (segs + 2) / 3;
   const int64_t total_units = a.units_per_row * s.batch;
-  const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, 8);  // = resident waves per CU (58 KB of LDS per workgroup)
+  const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, W);  // = resident waves per CU
   int64_t run_len = (total_units + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   if (run_len < 8) run_len = 8;
   a.run_len = run_len;

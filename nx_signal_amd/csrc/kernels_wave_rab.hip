@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
   v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
   v2f* s_x = s_tw + KB;
   v2f* s_carry = s_x + W * BUF;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = a.tw[i]; }
   __syncthreads();
   v2f* buf = s_x + wave * BUF;
@@ -548,8 +548,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
       const bool inside = u >= u0 && tabs < a.out_len;
       v2f rd = v2f{0.f, 0.f};
       if (inside) {
-        const int64_t seg = tabs / hop;
-        const int pos = (int)(tabs - seg * hop);
+        int f = 0;                        // hop segment of the unit that holds t (a 64-bit division per lane and iteration until round 5)
+#pragma unroll
+        for (int j = 1; j < T; ++j) f += t >= j * hop ? 1 : 0;
+        const int64_t seg = (int64_t)T * u + f;
+        const int pos = t - f * hop;
         const int64_t trow = seg < a.RP - 1 ? seg : (seg >= a.M ? a.RP + (seg - a.M) : a.RP - 1);
         rd = *reinterpret_cast<const v2f*>(a.den + trow * hop + pos);
       }
@@ -578,7 +581,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
 template <int A, int B>
 static int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, CMAX = KB;
-  constexpr int W = KB >= 640 ? 2 : 4;   // 640 / 960: 24 KB of LDS per wave (exchange + carry strip): two waves per workgroup, two workgroups per CU
+  // ONE workgroup per CU with as many waves as the LDS (exchange + carry strip per wave: 11 / 12 / 16 / 24 KB, the tables once) and the
+  // registers allow: 12 / 12 / 8 / 6 waves.  (Round 5, until then 2 workgroups of 4 / 4 / 2 / 2 waves: 0.25 -> 0.42 of the roofline for 640)
+  constexpr int W = KB >= 960 ? 6 : (KB >= 640 ? 8 : 12);
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   const int hop = s.hop;
@@ -644,7 +649,7 @@ static int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   const int64_t segs = (a.out_len + hop - 1) / hop;              // hop segments of the output (the last may be partial)
   a.units_per_row = (segs + T - 1) / T;
   const int64_t total_units = a.units_per_row * s.batch;
-  const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, KB >= 640 ? 4 : 8);  // = resident waves per CU
+  const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, W);  // = resident waves per CU
   int64_t run_len = (total_units + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   if (run_len < 8) run_len = 8;
   a.run_len = run_len;

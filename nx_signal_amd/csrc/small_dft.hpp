@@ -1,5 +1,5 @@
 // Small natural-order DFT codelets on registers (forward transform, e^{-2 pi i ..}) for the two-pass wave kernels of composite
-// fft lengths (kernels_wave_r20.hip: 400 = 20 x 20; kernels_wave_rab.hip: 320 = 16 x 20, 480 = 24 x 20, 640 = 32 x 20, 960 = 32 x 30).
+// fft lengths (kernels_wave_r20.hip: 400 = 20 x 20; kernels_wave_rab.hip: 320 = 16 x 20, 480 = 24 x 20, 640 = 32 x 20, 960 = 32 x 30, ...).
 // Coprime factors are joined by the prime-factor (Good-Thomas) index maps — n = (N2 n1 + N1 n2) mod N in, k = (N2 (N2^-1 mod N1) k1
 // + N1 (N1^-1 mod N2) k2) mod N out, no twiddles in between; dft32 is one radix-2 step over two dft16 (wave_stft.hpp).  Index maps
 // checked against numpy in tools/emulate_wave_fft.py-style scripts (round 5) and end to end by the parity tests of the kernels.
@@ -115,14 +115,64 @@ __device__ __forceinline__ void dft32(v2f* v) {
   }
 }
 
+// 25-point DFT, Cooley-Tukey 5 x 5: n = 5 n1 + n2, k = k1 + 5 k2, twiddles W_25^(n2 k1) between the two rounds of dft5
+__device__ __forceinline__ void dft25(v2f* v) {
+  // (cos, sin)(2 pi j / 25) for j = n2 k1, n2, k1 = 1..4
+  constexpr float kC[5][5] = {{1.f, 1.f, 1.f, 1.f, 1.f},
+                              {1.f, 0.96858316112863108f, 0.87630668004386358f, 0.72896862742141155f, 0.53582679497899666f},
+                              {1.f, 0.87630668004386358f, 0.53582679497899666f, 0.06279051952931337f, -0.42577929156507272f},
+                              {1.f, 0.72896862742141155f, 0.06279051952931337f, -0.63742398974868975f, -0.99211470131447788f},
+                              {1.f, 0.53582679497899666f, -0.42577929156507272f, -0.99211470131447788f, -0.63742398974868975f}};
+  constexpr float kS[5][5] = {{0.f, 0.f, 0.f, 0.f, 0.f},
+                              {0.f, 0.24868988716485479f, 0.48175367410171532f, 0.68454710592868873f, 0.84432792550201508f},
+                              {0.f, 0.48175367410171532f, 0.84432792550201508f, 0.99802672842827156f, 0.90482705246601958f},
+                              {0.f, 0.68454710592868873f, 0.99802672842827156f, 0.77051324277578925f, 0.12533323356430426f},
+                              {0.f, 0.84432792550201508f, 0.90482705246601958f, 0.12533323356430426f, -0.77051324277578925f}};
+  v2f Y[5][5];
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) {
+    v2f c0 = v[n2], c1 = v[5 + n2], c2 = v[10 + n2], c3 = v[15 + n2], c4 = v[20 + n2];
+    dft5(c0, c1, c2, c3, c4);
+    Y[0][n2] = c0; Y[1][n2] = c1; Y[2][n2] = c2; Y[3][n2] = c3; Y[4][n2] = c4;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 5; ++k1) {
+#pragma unroll
+    for (int n2 = 1; n2 < 5; ++n2)
+      if (k1 > 0) Y[k1][n2] = cmulc<false>(Y[k1][n2], kC[k1][n2], -kS[k1][n2]);
+    dft5(Y[k1][0], Y[k1][1], Y[k1][2], Y[k1][3], Y[k1][4]);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) v[k1 + 5 * k2] = Y[k1][k2];
+  }
+}
+
+// 40-point DFT, prime-factor 5 x 8: n = (8 n1 + 5 n2) mod 40, k = (16 k1 + 25 k2) mod 40
+__device__ __forceinline__ void dft40(v2f* v) {
+  v2f A[5][8];
+#pragma unroll
+  for (int n2 = 0; n2 < 8; ++n2) {
+    v2f c0 = v[(5 * n2) % 40], c1 = v[(8 + 5 * n2) % 40], c2 = v[(16 + 5 * n2) % 40], c3 = v[(24 + 5 * n2) % 40], c4 = v[(32 + 5 * n2) % 40];
+    dft5(c0, c1, c2, c3, c4);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2; A[3][n2] = c3; A[4][n2] = c4;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 5; ++k1) {
+    dft8<false>(A[k1]);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) v[(16 * k1 + 25 * k2) % 40] = A[k1][k2];
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void dft_n(v2f* v) {
-  static_assert(N == 16 || N == 20 || N == 24 || N == 30 || N == 32, "no codelet for this length");
+  static_assert(N == 16 || N == 20 || N == 24 || N == 25 || N == 30 || N == 32 || N == 40, "no codelet for this length");
   if constexpr (N == 16) dft16<false>(v);
   else if constexpr (N == 20) dft20(v);
   else if constexpr (N == 24) dft24(v);
+  else if constexpr (N == 25) dft25(v);
   else if constexpr (N == 30) dft30(v);
-  else dft32(v);
+  else if constexpr (N == 32) dft32(v);
+  else dft40(v);
 }
 
 }  // namespace nxsig

@@ -32,7 +32,10 @@ UNITS = [
     ("kernels_wave_mel.hip", []),
     ("kernels_wave_mag.hip", []),
     ("kernels_wave_r20.hip", []),
-    ("kernels_wave_rab.hip", []),   # composite fft lengths 320 / 480 / 640 / 960 (round 5)
+    ("kernels_wave_rab.hip", []),   # composite fft lengths A x B (round 5): 320 / 480 / 640 / 960 + the dispatchers
+    ("kernels_wave_rab_p1.hip", []),  # 100 ... 384
+    ("kernels_wave_rab_p2.hip", []),  # 500 ... 900
+    ("kernels_wave_rab_p3.hip", []),  # 1000 ... 1600
     ("kernels_wave_8k.hip", []),
     ("kernels_wave_rows.hip", []),
     ("kernels_wave_fir32.hip", []),

@@ -1110,6 +1110,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_r2k(FirWaveArgs a) {
 
 int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_r20.hip
 int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);    // kernels_wave_rab.hip
+int rab_length_part(int K);                                                               // >= 0: a native A x B kernel exists for fft length K
 int launch_stft_wave_8k(Ctx* c, const StftLaunch& s, bool* handled);                      // kernels_wave_8k.hip
 
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
@@ -1135,7 +1136,7 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
     int rc20 = launch_stft_r20(c, s, handled, nullptr);
     if (rc20 || *handled) return rc20;
   }
-  if (s.K == 320 || s.K == 480 || s.K == 640 || s.K == 960) {  // A x B native kernels (kernels_wave_rab.hip)
+  if (rab_length_part(s.K) >= 0) {  // A x B native kernels (kernels_wave_rab*.hip): 100 ... 1600, see wave_rab.hpp
     int rcab = launch_stft_rab(c, s, handled, nullptr);
     if (rcab || *handled) return rcab;
   }
@@ -1416,7 +1417,7 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
     int rc20 = launch_istft_r20(c, s, window_host, handled);
     if (rc20 || *handled) return rc20;
   }
-  if (s.K == s.N && (s.K == 320 || s.K == 480 || s.K == 640 || s.K == 960)) {  // A x B inverses (kernels_wave_rab.hip), same conditions
+  if (s.K == s.N && rab_length_part(s.K) >= 0) {  // A x B inverses (kernels_wave_rab*.hip), same conditions
     int rcab = launch_istft_rab(c, s, window_host, handled);
     if (rcab || *handled) return rcab;
   }

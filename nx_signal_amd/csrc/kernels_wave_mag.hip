@@ -5,6 +5,7 @@ namespace nxsig {
 
 int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_r20.hip
 int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_rab.hip
+int rab_length_part(int K);
 
 // fused stft -> magnitude / power / dBFS spectrogram of the bins below fft_length / 2
 int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool* handled) {
@@ -24,7 +25,7 @@ int launch_stft_mag_wave(Ctx* c, const StftLaunch& s, int kind, float* out, bool
                                        // the one-sided form keeps its "same bits as stft" promise through the two-step path
       return launch_wave<2048, kModeReal2x, 4, 2, kSinkMag>(c, s, &mel);
     default:
-      const bool ab = s.K == 320 || s.K == 480 || s.K == 640 || s.K == 960;
+      const bool ab = rab_length_part(s.K) >= 0;
       if (kind == 3 && s.K != 400 && !ab) return NXSIG_OK;  // one-sided complex output: the power-of-two front-ends above, the 20 x 20
                                                             // and the A x B kernels store it; the rest slice the full spectrum
       if (s.K == 400) {  // native 20 x 20 kernel

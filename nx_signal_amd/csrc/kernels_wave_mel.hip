@@ -5,6 +5,7 @@ namespace nxsig {
 
 int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_r20.hip
 int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);  // kernels_wave_rab.hip
+int rab_length_part(int K);
 
 // fused stft -> log-mel; *handled = false when the shape is not covered (the caller falls back to stft + stft_to_mel)
 int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float* filters_host, float* out, bool* handled) {
@@ -25,7 +26,7 @@ int launch_stft_mel_wave(Ctx* c, const StftLaunch& s, int mel_bins, const float*
         int rc20 = launch_stft_r20(c, s, &h20, &mel);
         if (rc20 || h20) return rc20;
       }
-      if (s.K == 320 || s.K == 480 || s.K == 640 || s.K == 960) {  // native A x B kernels (round 5)
+      if (rab_length_part(s.K) >= 0) {  // native A x B kernels (round 5)
         bool hab = false;
         int rcab = launch_stft_rab(c, s, &hab, &mel);
         if (rcab || hab) return rcab;

@@ -163,10 +163,61 @@ __device__ __forceinline__ void dft40(v2f* v) {
   }
 }
 
+// 10-point DFT, prime-factor 2 x 5: n = (5 n1 + 2 n2) mod 10, k = (5 k1 + 6 k2) mod 10
+__device__ __forceinline__ void dft10(v2f* v) {
+  v2f A0[5], A1[5];
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) {
+    const v2f a = v[(2 * n2) % 10], b = v[(5 + 2 * n2) % 10];
+    A0[n2] = a + b; A1[n2] = a - b;
+  }
+  dft5(A0[0], A0[1], A0[2], A0[3], A0[4]);
+  dft5(A1[0], A1[1], A1[2], A1[3], A1[4]);
+#pragma unroll
+  for (int k2 = 0; k2 < 5; ++k2) { v[(6 * k2) % 10] = A0[k2]; v[(5 + 6 * k2) % 10] = A1[k2]; }
+}
+
+// 12-point DFT, prime-factor 3 x 4: n = (4 n1 + 3 n2) mod 12, k = (4 k1 + 9 k2) mod 12
+__device__ __forceinline__ void dft12(v2f* v) {
+  v2f A[3][4];
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) {
+    v2f c0 = v[(3 * n2) % 12], c1 = v[(4 + 3 * n2) % 12], c2 = v[(8 + 3 * n2) % 12];
+    dft3(c0, c1, c2);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    dft4<false>(A[k1][0], A[k1][1], A[k1][2], A[k1][3]);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) v[(4 * k1 + 9 * k2) % 12] = A[k1][k2];
+  }
+}
+
+// 15-point DFT, prime-factor 3 x 5: n = (5 n1 + 3 n2) mod 15, k = (10 k1 + 6 k2) mod 15
+__device__ __forceinline__ void dft15(v2f* v) {
+  v2f A[3][5];
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) {
+    v2f c0 = v[(3 * n2) % 15], c1 = v[(5 + 3 * n2) % 15], c2 = v[(10 + 3 * n2) % 15];
+    dft3(c0, c1, c2);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    dft5(A[k1][0], A[k1][1], A[k1][2], A[k1][3], A[k1][4]);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) v[(10 * k1 + 6 * k2) % 15] = A[k1][k2];
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void dft_n(v2f* v) {
-  static_assert(N == 16 || N == 20 || N == 24 || N == 25 || N == 30 || N == 32 || N == 40, "no codelet for this length");
-  if constexpr (N == 16) dft16<false>(v);
+  static_assert(N == 10 || N == 12 || N == 15 || N == 16 || N == 20 || N == 24 || N == 25 || N == 30 || N == 32 || N == 40, "no codelet for this length");
+  if constexpr (N == 10) dft10(v);
+  else if constexpr (N == 12) dft12(v);
+  else if constexpr (N == 15) dft15(v);
+  else if constexpr (N == 16) dft16<false>(v);
   else if constexpr (N == 20) dft20(v);
   else if constexpr (N == 24) dft24(v);
   else if constexpr (N == 25) dft25(v);

@@ -10,7 +10,7 @@ import nx_signal_amd as S
 
 pytestmark = pytest.mark.gpu
 
-FFT_LENGTHS = [8, 32, 64, 128, 256, 512, 1024, 2048, 4096, 100, 400, 640, 1000, 48, 3000, 8192, 320, 480, 960]
+FFT_LENGTHS = [8, 32, 64, 128, 256, 512, 1024, 2048, 4096, 100, 400, 640, 1000, 48, 3000, 8192, 320, 480, 960, 200, 600, 1200, 1100]
 WINDOWS = ["hann", "hamming", "blackman", "bartlett", "triangular", "kaiser", "rectangular"]
 
 

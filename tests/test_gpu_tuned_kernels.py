@@ -425,11 +425,15 @@ def test_stft_onesided_equals_the_first_half_of_stft_bit_for_bit(K, N, hop, pad,
     assert np.array_equal(hd.numpy().view(np.uint32), h.view(np.uint32))
 
 
-@pytest.mark.parametrize("K", [320, 480, 640, 960])
+# every fft length with a native A x B kernel (wave_rab.hpp: four lists, four translation units)
+RAB_LENGTHS = [100, 120, 160, 200, 240, 300, 360, 384, 320, 480, 640, 960, 500, 600, 720, 768, 800, 900, 1000, 1200, 1280, 1600]
+
+
+@pytest.mark.parametrize("K", RAB_LENGTHS)
 @pytest.mark.parametrize("shape", ["full", "short_frame", "long_frame", "reflect", "odd_hop", "ragged"])
 def test_stft_composite_lengths_native_kernels(K, shape):
-    """kernels_wave_rab.hip (round 5): fft_length 320 = 16 x 20, 480 = 16 x 30, 640 = 32 x 20, 960 = 32 x 30 on two-pass wave kernels
-    instead of Bluestein.  Against the oracle for: N == K at 75 % overlap, a shorter frame (zero-padded), a longer frame (truncated,
+    """kernels_wave_rab*.hip (round 5): fft_length 320 = 16 x 20, 480 = 24 x 20, 640 = 32 x 20, 960 = 32 x 30 ... 1600 = 40 x 40 on two-pass
+    wave kernels instead of Bluestein (<= 1024) or the generic kernels (above).  Against the oracle for: N == K at 75 % overlap, a shorter frame (zero-padded), a longer frame (truncated,
     lib/nx_signal.ex:102), :reflect padding (edge units through the bounds-checked staging), an odd hop (unaligned spans: 4-byte
     staging) and ragged frame counts (phantom frames of the last unit); every scaling; and the switch back to Bluestein agrees."""
     import nx_signal_amd as S
@@ -438,7 +442,7 @@ def test_stft_composite_lengths_native_kernels(K, shape):
     rng = np.random.default_rng(K)
     N, hop, pad, L = K, K // 4, "valid", 7 * K + 13
     if shape == "short_frame":
-        N = K - 80
+        N = K - K // 4
     elif shape == "long_frame":
         N = K + 64
     elif shape == "reflect":
@@ -471,7 +475,7 @@ def test_stft_composite_lengths_non_finite_samples_stay_in_their_frames():
     import nx_signal_amd as S
     from oracle import nx_oracle as O
 
-    for K in (320, 480, 640, 960):
+    for K in RAB_LENGTHS:
         hop = K // 4
         x = np.random.default_rng(K + 1).standard_normal(12 * K).astype(np.float32)
         x[5 * K + 7] = np.nan
@@ -517,11 +521,11 @@ def test_fir_real_block_kernel(taps, mode):
     assert np.isfinite(yn[0]).all() and np.isfinite(yn[2]).all() and not np.isfinite(yn[1]).any()
 
 
-@pytest.mark.parametrize("K", [320, 480, 640, 960])
+@pytest.mark.parametrize("K", RAB_LENGTHS)
 @pytest.mark.parametrize("hopsel", ["quarter", "half", "full", "eighth", "uneven"])
 def test_istft_composite_lengths_native_kernels(K, hopsel):
     """k_istft_rab (round 5): the inverse of the A x B kernels — one frame per lane group, overlap-add through LDS with a carry strip,
-    any even hop.  Non-Hermitian spectra, every scaling, several rows, frame counts that leave the last unit ragged; against the oracle
+    any hop (16-byte gathers for an even one, 8-byte for an odd one).  Non-Hermitian spectra, every scaling, several rows, frame counts that leave the last unit ragged; against the oracle
     (1e-5), bit-identical to itself across run alignments (two batch sizes change the run length) and against the generic path."""
     import nx_signal_amd as S
     from oracle import nx_oracle as O
@@ -560,8 +564,8 @@ def test_istft_composite_lengths_non_finite_bins_stay_in_their_frames():
     import nx_signal_amd as S
     from oracle import nx_oracle as O
 
-    for K in (320, 480, 640, 960):
-        hop = K // 4
+    for K in RAB_LENGTHS:
+        hop = K // 4   # (odd for 100 / 300 / 500 / 900: the 8-byte gathers)
         rng = np.random.default_rng(K + 3)
         z = (rng.standard_normal((2, 40, K)) + 1j * rng.standard_normal((2, 40, K))).astype(np.complex64)
         z[0, 17, 5] = np.nan
@@ -575,7 +579,9 @@ def test_istft_composite_lengths_non_finite_bins_stay_in_their_frames():
         assert float(np.max(np.abs(y[ok] - yo[ok])) / np.max(np.abs(yo[ok]))) < 1e-5
 
 
-@pytest.mark.parametrize("K,N,hop,pad", [(320, 320, 160, "reflect"), (480, 400, 160, "valid"), (640, 640, 160, "reflect"), (960, 960, 240, "valid")])
+@pytest.mark.parametrize("K,N,hop,pad", [(320, 320, 160, "reflect"), (480, 400, 160, "valid"), (640, 640, 160, "reflect"), (960, 960, 240, "valid"),
+                                         (100, 100, 50, "valid"), (240, 200, 80, "reflect"), (500, 500, 125, "valid"), (768, 768, 192, "reflect"),
+                                         (1000, 800, 250, "valid"), (1200, 1200, 300, "valid"), (1600, 1600, 400, "reflect")])
 def test_composite_lengths_fused_sinks(K, N, hop, pad):
     """the log-mel, magnitude / power / dBFS and one-sided sinks of kernels_wave_rab.hip (round 5): bit-identical to the same sinks on the
     Bluestein kernels' INPUT (same oracle), i.e. against the oracle to the tolerances the other front-ends' sink tests use"""

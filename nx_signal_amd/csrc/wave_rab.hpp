@@ -319,7 +319,10 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
 
 template <int A, int B>
 inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel) {
-  constexpr int W = 4, KB = A * B, LT = A > B ? A : B, T = 64 / LT;
+  // four waves per workgroup, short-lived workgroups.  (ONE workgroup per CU sized to fill the LDS — 6 ... 12 waves for 720 ... 960, what
+  // the persistent inverse kernels gain 40-70 % from — measured 0.46 / 0.59 / 0.55 / 0.50 / 0.56 against 0.52 / 0.56 / 0.55 / 0.50 / 0.60
+  // here for 720 / 768 / 800 / 900 / 960: the blocks retire together and the CU idles between them)
+  constexpr int W = 4, WM = 4, KB = A * B, LT = A > B ? A : B, T = 64 / LT;   // WM: the log-mel sink
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   const int nuse = s.fr.N < KB ? s.fr.N : KB;
@@ -390,19 +393,20 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
     c->memo[key] = {reinterpret_cast<uint64_t>(dt)};
     b.tw = reinterpret_cast<const v2f*>(dt);
   }
-  a.chunk = (int64_t)W * (sink == kSinkMel ? 8 : 4);   // four units per wave (two: -1 ... -3 %), short-lived workgroups; the mel sink amortises its CSR preload
+  const int w = sink == kSinkMel ? WM : W;
+  a.chunk = (int64_t)w * (sink == kSinkMel ? 8 : 4);   // four units per wave (two: -1 ... -3 %), short-lived workgroups; the mel sink amortises its CSR preload
   const int64_t blocks = (b.total_units + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
-  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)W * BUF * 8 + lds_extra;
+  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)w * BUF * 8 + lds_extra;
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, b);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * w), lds, c->stream, b);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
   int rc;
-  if (sink == kSinkMel) rc = s.has_scale ? go(k_stft_rab<A, B, true, W, kSinkMel>) : go(k_stft_rab<A, B, false, W, kSinkMel>);
+  if (sink == kSinkMel) rc = s.has_scale ? go(k_stft_rab<A, B, true, WM, kSinkMel>) : go(k_stft_rab<A, B, false, WM, kSinkMel>);
   else if (sink == kSinkMag) rc = s.has_scale ? go(k_stft_rab<A, B, true, W, kSinkMag>) : go(k_stft_rab<A, B, false, W, kSinkMag>);
   else rc = s.has_scale ? go(k_stft_rab<A, B, true, W>) : go(k_stft_rab<A, B, false, W>);
   if (rc) return rc;

@@ -1392,8 +1392,9 @@ static int launch_istft_wave_4k(Ctx* c, const IstftLaunch& s, const float* windo
 
 int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);  // kernels_wave_r20.hip
 int launch_istft_rab(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);  // kernels_wave_rab.hip
+bool rab_inverse_only(int K);                                                                  // kernels_wave_rab.hip
 
-int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
+static int launch_istft_wave_tuned(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   *handled = false;
   if (s.M == 0 || s.batch == 0) return NXSIG_OK;
   if (tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
@@ -1483,6 +1484,17 @@ int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bo
     default: return launch_istft_wave_R<8, 4>(c, s, s.window, window_host);
   }
 }
+
+// the tuned inverse kernels; power-of-two frame lengths whose hop they do not take (N / hop not in {1, 2, 4, 8}, e.g. 512-sample frames
+// every 160 samples) go to the two-pass A x B inverses instead of the generic path
+int launch_istft_wave(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
+  int rc = launch_istft_wave_tuned(c, s, window_host, handled);
+  if (rc || *handled) return rc;
+  if (s.M == 0 || s.batch == 0 || window_host == nullptr || s.filt) return NXSIG_OK;
+  if (s.K == s.N && rab_inverse_only(s.K)) return launch_istft_rab(c, s, window_host, handled);
+  return NXSIG_OK;
+}
+
 // spectrum of the zero-padded taps in double (radix-2, 1024 points, once per distinct filter)
 static void host_fft1024_f64(std::vector<double>& re, std::vector<double>& im) {
   const size_t n = re.size();

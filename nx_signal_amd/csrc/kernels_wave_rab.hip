@@ -10,6 +10,7 @@ int launch_stft_rab_p3(Ctx* c, const StftLaunch& s, bool* handled, const MelLaun
 int launch_istft_rab_p1(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p2(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p3(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
+int launch_istft_rab_p4(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 
 // 0..3: the list that holds fft length K, -1: none
 int rab_length_part(int K) {
@@ -21,6 +22,16 @@ int rab_length_part(int K) {
     NXSIG_RAB_PART3(X) return 3;
 #undef X
     default: return -1;
+  }
+}
+
+// frame lengths that have an INVERSE kernel only (the forward direction has the power-of-two front ends)
+bool rab_inverse_only(int K) {
+  switch (K) {
+#define X(KK, A, B) case KK:
+    NXSIG_RAB_INVERSE_ONLY(X) return true;
+#undef X
+    default: return false;
   }
 }
 
@@ -47,6 +58,7 @@ int launch_istft_rab(Ctx* c, const IstftLaunch& s, const float* window_host, boo
   *handled = false;
   if (s.K != s.N || s.M == 0 || s.batch == 0 || window_host == nullptr || s.filt != nullptr) return NXSIG_OK;
   if (tune(c, kT_DISABLE_RAB, 0) || tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
+  if (rab_inverse_only(s.K)) return launch_istft_rab_p4(c, s, window_host, handled);
   switch (rab_length_part(s.K)) {
     case 1: return launch_istft_rab_p1(c, s, window_host, handled);
     case 2: return launch_istft_rab_p2(c, s, window_host, handled);

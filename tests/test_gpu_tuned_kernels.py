@@ -604,3 +604,37 @@ def test_composite_lengths_fused_sinks(K, N, hop, pad):
     z1, _, _ = S.stft_onesided(S.default_context(0).to_device(x), w, **opts)
     zf, _, _ = S.stft(x, w, **opts)
     assert np.array_equal(z1.numpy().view(np.uint32), np.ascontiguousarray(zf[..., : K // 2]).view(np.uint32))   # the same bits as stft's first half
+
+
+@pytest.mark.parametrize("K,hop", [(128, 40), (128, 100), (256, 80), (256, 37), (512, 160), (512, 200), (512, 441), (1024, 160), (1024, 300), (1024, 441)])
+def test_istft_power_of_two_frames_any_hop(K, hop):
+    """power-of-two frame lengths whose hop the N / hop in {1, 2, 4, 8} kernels do not take (e.g. 512-sample frames every 160 samples,
+    lib/nx_signal.ex:609-637) run on the two-pass A x B inverses (kernels_wave_rab_p4.hip) instead of the generic path: against the
+    oracle, every scaling, non-Hermitian spectra; deterministic across launch geometries; agrees with the generic path"""
+    import nx_signal_amd as S
+    from oracle import nx_oracle as O
+
+    rng = np.random.default_rng(K * 7 + hop)
+    M = 61
+    w = S.windows.hann(K)
+    z = (rng.standard_normal((3, M, K)) + 1j * rng.standard_normal((3, M, K))).astype(np.complex64)
+    for scaling in (None, "spectrum", "psd"):
+        opts = dict(overlap_length=K - hop, fft_length=K, scaling=scaling, sampling_rate=16000)
+        y = S.istft(z, w, **opts)
+        yo = O.istft(z, w, **opts)
+        assert y.shape == yo.shape and y.dtype == np.complex64
+        assert float(np.max(np.abs(y - yo)) / np.max(np.abs(yo))) < 1e-5, (K, hop, scaling)
+    ctx = S.Context(0)
+    opts = dict(overlap_length=K - hop, fft_length=K, sampling_rate=16000)
+    native = not ctx.get_tuning("DISABLE_RAB")[0] and not ctx.get_tuning("DISABLE_WAVE")[0]
+    y3 = S.istft(ctx.to_device(z), w, ctx=ctx, **opts).numpy()
+    y1 = S.istft(ctx.to_device(z[1:2]), w, ctx=ctx, **opts).numpy()
+    assert np.array_equal(y3[1].view(np.uint32), y1[0].view(np.uint32))
+    ctx.set_tuning("NXSIG_DISABLE_RAB", 1)
+    yg = S.istft(ctx.to_device(z), w, ctx=ctx, **opts).numpy()
+    assert not native or not np.array_equal(yg.view(np.uint32), y3.view(np.uint32))   # two different kernels really ran
+    assert float(np.max(np.abs(yg - y3)) / np.max(np.abs(y3))) < 1e-5
+    zn = z.copy()
+    zn[0, 20, 3] = np.nan
+    yn = S.istft(zn, w, **opts)
+    assert np.array_equal(np.isfinite(yn), np.isfinite(O.istft(zn, w, **opts)))

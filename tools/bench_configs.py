@@ -106,7 +106,8 @@ def main():
             stft_case(ctx, n, n // 4, Lg, b, f"stft N={n} hop={n // 4}, {b} rows (tuned wave kernel if the size has one, else generic)")
     for name in which:
         if name.startswith("ist") and name != "istft":  # e.g. ist512: generic-path istft sizes
-            n = int(name[3:]); hop = n // 4; b = 8
+            n, _, hp = name[3:].partition("h")   # ist512 or ist512h160 (any hop)
+            n = int(n); hop = int(hp) if hp else n // 4; b = 8
             Mi = (900 * 1024 * 1024 // (b * n * 8))
             w = S.windows.hann(n)
             rng = np.random.Generator(np.random.PCG64(5))

@@ -241,9 +241,78 @@ static int launch_fir_long(Ctx* c, const FirLaunch& a) {
   return NXSIG_OK;
 }
 
+int launch_fir_partition_sum(Ctx* c, int n, const float* const* src, const int64_t* i0, const int64_t* len, bool accumulate, bool clean, float scale,
+                             float* y, int32_t batch, int64_t out_len);   // kernels_generic.hip
+
+// 1 026 ... 32 768 taps (round 5): the filter is cut into P partitions of <= 1 025 taps (stride 256 ... 1 024), each one a FIR call of the tuned overlap-save
+// kernels into a scratch tensor (full convolution of x with h[p S .. p S + taps_p), delayed by p S samples), and one pass sums them into
+// y.  P x (8 B per sample at the 1 025-tap kernel's rate) + one (4 P + 4) B pass instead of the 8192-point workgroup kernel (0.05 of
+// the roofline) or one 2^k-point transform per row (> 4 096 taps: 0.009).  Non-finite samples poison their row like everywhere else
+// (FirLaunch::row_flags, shared by the partitions).  Scratch: at most ~4 GB per round of partitions; later rounds add to y.
+// The reference's result is ONE Nx.ifft output: samples with |y| <= 1e-10 are exact zeros (convolution.ex:282).  The overlap-save
+// kernels apply that clean-up to what they store — here partial sums, where it does not belong.  So the partitions run with h x 2^20
+// (exact: the kernels' threshold then sits at 1e-16 of the true scale, far below what decides a sample of y), the summing pass
+// multiplies by 2^-20 and cleans the finished sums.
+static int launch_fir_partitioned(Ctx* c, const FirLaunch& a_in) {
+  FirLaunch a = a_in;
+  int rc = fir_row_flags(c, a.batch, &a.row_flags);
+  if (rc) return rc;
+  constexpr float kUp = 1048576.0f, kDown = 1.0f / 1048576.0f;
+  std::vector<float> hs((size_t)a.taps);
+  for (int i = 0; i < a.taps; ++i) hs[i] = a.h_host[i] * kUp;
+  // partition stride S: a multiple of 256 (the delays p S keep the rows' 16-byte alignment: the stream kernels decline unaligned
+  // spans; and taps_p - 1 is what the real-block kernel pads to a multiple of 256 anyway); the last partition takes up to S + 1 taps
+  const int P = (a.taps - 1 + 1023) / 1024;
+  int S = ((a.taps - 1 + P - 1) / P + 255) / 256 * 256;
+  if (S > 1024) S = 1024;
+  const int64_t row_bytes = (int64_t)a.batch * (a.out_len + 4) * 4;
+  int per_round = (int)(((int64_t)4 << 30) / (row_bytes > 0 ? row_bytes : 1));
+  if (per_round < 1) per_round = 1;
+  if (per_round > 8) per_round = 8;
+  void* tmp = nullptr;
+  const int n_parts = (a.taps - 1 + S - 1) / S;
+  const int first_round = n_parts < per_round ? n_parts : per_round;
+  if ((rc = ctx_scratch(c, 21, (size_t)first_round * (size_t)row_bytes, &tmp))) return rc;
+  bool any = false;
+  for (int p0 = 0; p0 < n_parts; p0 += per_round) {
+    const float* src[8];
+    int64_t i0s[8], lens[8];
+    int n = 0;
+    size_t off = 0;
+    for (int p = p0; p < n_parts && p < p0 + per_round; ++p) {
+      const int64_t delay = (int64_t)p * S;
+      const int32_t taps_p = p == n_parts - 1 ? a.taps - p * S : S;
+      const int64_t full_p = a.L + taps_p - 1;                       // length of x * h_p
+      int64_t i0 = delay - a.out_start;                              // first output of y this partition reaches
+      if (i0 < 0) i0 = 0;
+      int64_t i1 = full_p - 1 + delay - a.out_start;                 // last one
+      if (i1 > a.out_len - 1) i1 = a.out_len - 1;
+      if (i1 < i0) continue;
+      FirLaunch q = a;
+      q.h_host = hs.data() + (size_t)p * S; q.taps = taps_p;
+      q.out_start = a.out_start + i0 - delay;
+      q.out_len = (i1 - i0 + 1 + 3) & ~(int64_t)3;   // whole 16-byte groups per row (the stream kernels decline unaligned rows); what lies
+                                                      // beyond the partition's full convolution comes out as zeros
+      q.y = reinterpret_cast<float*>(static_cast<char*>(tmp) + off);
+      off += (size_t)a.batch * (size_t)q.out_len * 4;
+      bool handled = false;
+      if ((rc = launch_fir_wave(c, q, &handled))) return rc;
+      if (!handled && (rc = launch_fir_generic(c, q))) return rc;
+      src[n] = q.y; i0s[n] = i0; lens[n] = q.out_len; ++n;
+    }
+    const bool last = p0 + per_round >= n_parts;
+    if (n == 0 && any && !last) continue;
+    if ((rc = launch_fir_partition_sum(c, n, src, i0s, lens, any, last, kDown, a.y, a.batch, a.out_len))) return rc;
+    any = true;
+  }
+  return launch_fir_poison(c, a);
+}
+
 int launch_fir(Ctx* c, const FirLaunch& a_in) {
-  if (a_in.taps > 4096) return launch_fir_long(c, a_in);   // one transform per row, like the reference: non-finite rows come out NaN
   if (a_in.out_len <= 0 || a_in.batch == 0) return NXSIG_OK;
+  if (a_in.taps > 32768) return launch_fir_long(c, a_in);   // one transform per row, like the reference: non-finite rows come out NaN
+  if (a_in.taps > 1025 && !tune(c, kT_DISABLE_WAVE, 0)) return launch_fir_partitioned(c, a_in);
+  if (a_in.taps > 4096) return launch_fir_long(c, a_in);
   FirLaunch a = a_in;
   int rc = fir_row_flags(c, a.batch, &a.row_flags);
   if (rc) return rc;

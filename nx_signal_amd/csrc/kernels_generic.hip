@@ -658,6 +658,67 @@ int launch_fir_flags_from_output(Ctx* c, const float* y, int32_t rows, int64_t o
   return NXSIG_OK;
 }
 
+// ---- filters longer than one overlap-save block takes (launch_fir_partitioned, api.cpp): y[row][i] = sum over the partitions p that
+// reach output i of part_p[row][i - i0_p].  Partition p is x * h[p S .. p S + taps_p) — a plain FIR call of the tuned kernels —
+// and enters the full convolution p S samples late.  Up to eight partitions per pass; later passes add to y.
+struct FirSumArgs {
+  const float* src[8];
+  int64_t i0[8], len[8];     // output indices [i0, i0 + len) of y that partition p reaches; its rows are len floats apart
+  int32_t n, accumulate, clean;   // clean: last pass — Nx.ifft's clean-up of fftconvolve's result (convolution.ex:282) on the finished sums
+  float scale;                    // the partitions were computed with h x 2^20 (see launch_fir_partitioned): x 2^-20 here, exact
+  float* y;
+  int64_t out_len;
+};
+
+__global__ __launch_bounds__(256) void k_fir_partition_sum(FirSumArgs a) {
+  const int64_t row = blockIdx.y;
+  const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  float* __restrict__ yr = a.y + (size_t)row * a.out_len;
+  // 4-byte accesses, a wave on 256 consecutive bytes (the partitions' rows start at arbitrary offsets); all loads of a thread's four
+  // outputs are issued before the sums
+  float acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = base + 256 * e;
+    acc[e] = 0.0f;
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    if (p < a.n) {   // uniform
+      const float* __restrict__ sp = a.src[p] + (size_t)row * a.len[p] - a.i0[p];
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t i = base + 256 * e, j = i - a.i0[p];
+        v[e] = (j >= 0 && j < a.len[p]) ? __builtin_nontemporal_load(sp + i) : 0.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = base + 256 * e;
+    if (i < a.out_len) {
+      float v = acc[e] * a.scale;
+      if (a.accumulate) v += yr[i];
+      yr[i] = a.clean ? fft_eps0(v) : v;
+    }
+  }
+}
+
+int launch_fir_partition_sum(Ctx* c, int n, const float* const* src, const int64_t* i0, const int64_t* len, bool accumulate, bool clean, float scale,
+                             float* y, int32_t batch, int64_t out_len) {
+  FirSumArgs a;
+  for (int p = 0; p < 8; ++p) { a.src[p] = p < n ? src[p] : nullptr; a.i0[p] = p < n ? i0[p] : 0; a.len[p] = p < n ? len[p] : 0; }
+  a.n = n; a.accumulate = accumulate ? 1 : 0; a.clean = clean ? 1 : 0; a.scale = scale; a.y = y; a.out_len = out_len;
+  const int64_t bx = (out_len + 1023) / 1024;
+  if (bx > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: output too long for one launch");
+  hipLaunchKernelGGL(k_fir_partition_sum, dim3((unsigned)bx, (unsigned)batch), dim3(256), 0, c->stream, a);
+  NXSIG_HIP_TRY(hipGetLastError());
+  return NXSIG_OK;
+}
+
 int launch_fir_poison(Ctx* c, const FirLaunch& s) {
   if (!s.row_flags || s.batch == 0 || s.out_len <= 0) return NXSIG_OK;
   hipLaunchKernelGGL(k_fir_poison, dim3((unsigned)s.batch), dim3(kThreads), 0, c->stream, s.row_flags, s.y, s.out_len);

@@ -638,3 +638,37 @@ def test_istft_power_of_two_frames_any_hop(K, hop):
     zn[0, 20, 3] = np.nan
     yn = S.istft(zn, w, **opts)
     assert np.array_equal(np.isfinite(yn), np.isfinite(O.istft(zn, w, **opts)))
+
+
+@pytest.mark.parametrize("taps", [1026, 1500, 2049, 4097, 5000, 9001])
+@pytest.mark.parametrize("mode", ["same", "full", "valid"])
+def test_fir_long_filters_partitioned(taps, mode):
+    """filters of more than 1 025 taps (round 5): partitions of <= 1 025 taps through the tuned overlap-save kernels, summed with their
+    delays (api.cpp launch_fir_partitioned) — against the direct f64 convolution (Convolution.convolve method: :fft,
+    lib/nx_signal/convolution.ex:252-329, to fp32 rounding), several rows, every mode; a NaN poisons exactly its row; the path behind
+    NXSIG_DISABLE_WAVE (8192-point workgroup kernel / one transform per row) agrees"""
+    import nx_signal_amd as S
+
+    rng = np.random.default_rng(taps)
+    L = 40000
+    x = rng.standard_normal((3, L)).astype(np.float32)
+    h = (rng.standard_normal(taps) * np.hanning(taps)).astype(np.float32)
+    ctx = S.Context(0)
+    y = S.filters.fir(ctx.to_device(x), h, mode=mode, ctx=ctx).numpy()
+    ref = np.stack([np.convolve(r.astype(np.float64), h.astype(np.float64), mode=mode) for r in x])
+    assert y.shape == ref.shape
+    assert float(np.max(np.abs(y - ref)) / np.max(np.abs(ref))) < 1e-5, (taps, mode)
+    yh = S.filters.fir(x, h, mode=mode)                          # host tensors through the same path
+    assert np.array_equal(yh.view(np.uint32), y.view(np.uint32))
+    ctx.set_tuning("NXSIG_DISABLE_WAVE", 1)
+    y0 = S.filters.fir(ctx.to_device(x), h, mode=mode, ctx=ctx).numpy()
+    assert float(np.max(np.abs(y - y0)) / np.max(np.abs(ref))) < 1e-5
+    ctx.clear_tuning("DISABLE_WAVE")
+    xn = x.copy()
+    xn[1, 17000] = np.inf
+    yn = S.filters.fir(ctx.to_device(xn), h, mode=mode, ctx=ctx).numpy()
+    assert np.isfinite(yn[0]).all() and np.isfinite(yn[2]).all() and not np.isfinite(yn[1]).any()
+    xs = x[:, :700]                                              # rows shorter than the filter
+    ys = S.filters.fir(xs, h, mode="full")
+    refs = np.stack([np.convolve(r.astype(np.float64), h.astype(np.float64), mode="full") for r in xs])
+    assert float(np.max(np.abs(ys - refs)) / np.max(np.abs(refs))) < 1e-5

@@ -676,12 +676,7 @@ __global__ __launch_bounds__(256) void k_fir_partition_sum(FirSumArgs a) {
   float* __restrict__ yr = a.y + (size_t)row * a.out_len;
   // 4-byte accesses, a wave on 256 consecutive bytes (the partitions' rows start at arbitrary offsets); all loads of a thread's four
   // outputs are issued before the sums
-  float acc[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int64_t i = base + 256 * e;
-    acc[e] = 0.0f;
-  }
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     if (p < a.n) {   // uniform

@@ -588,6 +588,121 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a, int6
   }
 }
 
+// ---- the edge role for N = A SP, SP in {2, 4, 8, 16, 32}, A <= 64 lanes (round 5; the text below says 64 for A).  k_istft_edge_fix spends N / 64 complex multiply-adds plus a
+// twiddle recurrence per lane on EVERY candidate sample; with thousands of short rows (2 048 rows of 184 frames: 280 candidates per
+// row) that pass took longer than the istft kernel itself (0.84 against 0.70 ms).  Here one wave takes a CHUNK of SP consecutive
+// output positions n0 .. n0 + SP - 1 (n0 a multiple of SP) that share their frame range:
+//   x_m[j] = 1/N sum_lane w_N^(j lane) sum_s Z_m[lane + 64 s] e^(2 pi i j s / SP),   j = n - m hop
+// the inner sum has period SP in j: ONE lane-local SP-point transform per frame (radix-2 Stockham in double, static register indices)
+// yields it for all SP positions of the chunk (a frame whose j0 = n0 - m hop is not a multiple of SP is rotated first), the outer sums
+// of the SP positions are reduced together (butterfly reduction: SP - 1 + 6 - log2 SP exchanges instead of 6 SP), and the lane group
+// that ends up with position g carries it through the reference's chain (divide by N, clean-up, round to f32, x scale, x window, sum
+// over the frames in double, divide by the normaliser: lib/nx_signal.ex:609-637).  Same roundings as istft_sample_body except for the
+// order of the double sums.  Chunk entry (20 x int64, host-built): n0, m_lo, m_hi, mask of the flagged positions, then the bits of the
+// f32 normalisers, two per int64.
+template <int SP>
+__global__ __launch_bounds__(kThreads) void k_istft_edge_chunks(EdgeFixArgs a, int64_t chunk_blocks) {
+  constexpr int LOG = SP == 2 ? 1 : SP == 4 ? 2 : SP == 8 ? 3 : SP == 16 ? 4 : 5;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = blockIdx.x;
+  const int64_t row = b / chunk_blocks;
+  const int64_t ci = (b - row * chunk_blocks) * kFixWaves + wave;
+  if (ci >= a.n_idx) return;
+  const int64_t* e = a.idx + 20 * ci;
+  const int64_t n0 = e[0], m_lo = e[1], m_hi = e[2];
+  const uint32_t mask = (uint32_t)e[3];
+  const int g = lane >> (6 - LOG);                       // the position this lane group finishes
+  const bool mine = ((mask >> g) & 1u) != 0;
+  const int N = a.N, rowlen = a.onesided ? (N >> 1) : N;
+  const int A = N / SP;                                  // active lanes: bin k = lane + A s
+  const float2* zb = a.z + (size_t)row * a.M * rowlen;
+  double acc_re = 0.0, acc_im = 0.0;
+  for (int64_t m = m_lo; m <= m_hi; ++m) {
+    const int64_t j0 = n0 - m * a.hop;                   // may be negative for positions outside the mask
+    const int rot = (int)(((j0 % SP) + SP) % SP);        // uniform
+    const float2* zr = zb + (size_t)m * rowlen;
+    double2 x[SP], y[SP];
+#pragma unroll
+    for (int s = 0; s < SP; ++s) {
+      float2 v = lane < A ? istft_bin(a, zr, lane + A * s) : make_float2(0.0f, 0.0f);
+      if (a.filt && lane < A) {
+        const float2 h = a.filt[lane + A * s];
+        v = make_float2((float)((double)v.x * (double)h.x - (double)v.y * (double)h.y),
+                        (float)((double)v.x * (double)h.y + (double)v.y * (double)h.x));
+      }
+      x[s] = make_double2((double)v.x, (double)v.y);
+    }
+    if (rot != 0) {   // x_s *= e^(2 pi i rot s / SP) = w_N^(64 rot s)
+#pragma unroll
+      for (int s = 1; s < SP; ++s) {
+        const double2 t = a.tw[A * ((rot * s) % SP)];
+        x[s] = make_double2(x[s].x * t.x - x[s].y * t.y, x[s].x * t.y + x[s].y * t.x);
+      }
+    }
+    // SP-point transform with the + sign, natural order in and out: radix-2 Stockham, every index a compile-time constant
+#pragma unroll
+    for (int Ns = 1; Ns < SP; Ns *= 2) {
+#pragma unroll
+      for (int j = 0; j < SP / 2; ++j) {
+        const int k = j % Ns;
+        const double2 u = x[j];
+        double2 v = x[j + SP / 2];
+        if (k != 0) {
+          const double2 t = a.tw[A * (k * (SP / (2 * Ns)))];   // e^(2 pi i k / (2 Ns))
+          v = make_double2(v.x * t.x - v.y * t.y, v.x * t.y + v.y * t.x);
+        }
+        const int d0 = (j / Ns) * 2 * Ns + k;
+        y[d0] = make_double2(u.x + v.x, u.y + v.y);
+        y[d0 + Ns] = make_double2(u.x - v.x, u.y - v.y);
+      }
+#pragma unroll
+      for (int s = 0; s < SP; ++s) x[s] = y[s];
+    }
+    // x[c] = inner sum for the positions with (j - rot) mod SP == c, i.e. position gg <-> x[gg] after the rotation above.
+    // outer products with w_N^(j lane), j = j0 + gg
+    int tix = (int)((uint32_t)((int)(((j0 % N) + N) % N) * lane) % (uint32_t)N);   // (j0 lane) mod N, then + lane per position (lane < N)
+#pragma unroll
+    for (int gg = 0; gg < SP; ++gg) {
+      const double2 t = a.tw[tix];
+      x[gg] = make_double2(x[gg].x * t.x - x[gg].y * t.y, x[gg].x * t.y + x[gg].y * t.x);
+      tix += lane;
+      if (tix >= N) tix -= N;
+    }
+    // butterfly reduction: after step q the lane holds SP >> (q + 1) partial sums over 2^(q + 1) lanes
+#pragma unroll
+    for (int q = 0; q < LOG; ++q) {
+      const int half = SP >> (q + 1), off = 32 >> q;
+      const bool up = (lane & off) != 0;
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        const double2 keep = up ? x[i + half] : x[i];
+        const double2 send = up ? x[i] : x[i + half];
+        x[i] = make_double2(keep.x + __shfl_xor(send.x, off), keep.y + __shfl_xor(send.y, off));
+      }
+    }
+    double sr = x[0].x, si = x[0].y;
+#pragma unroll
+    for (int off = 32 >> LOG; off > 0; off >>= 1) { sr += __shfl_xor(sr, off); si += __shfl_xor(si, off); }
+    const int64_t j = j0 + g;
+    if (mine && j >= 0 && j < N) {
+      double dr = sr / (double)N, di = si / (double)N;
+      if (fabs(dr) <= 1.0e-10) dr = 0.0;   // Nx.ifft's eps clean-up, on the double result like the reference
+      if (fabs(di) <= 1.0e-10) di = 0.0;
+      float fr = (float)dr, fi = (float)di;
+      if (a.has_scale) { fr *= a.scale; fi *= a.scale; }
+      const float w = a.window[j];
+      fr *= w; fi *= w;
+      acc_re += (double)fr; acc_im += (double)fi;
+    }
+  }
+  if (mine && (lane & ((64 >> LOG) - 1)) == 0) {
+    const float d = __int_as_float((int)(((uint64_t)e[4 + (g >> 1)] >> (32 * (g & 1))) & 0xffffffffu));
+    const int64_t n = n0 + g;
+    if (a.onesided) reinterpret_cast<float*>(a.y)[(size_t)row * a.out_len + n] = (float)acc_re / d;
+    else a.y[(size_t)row * a.out_len + n] = make_float2((float)acc_re / d, (float)acc_im / d);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ framing
 __global__ __launch_bounds__(kThreads) void k_as_windowed(const float* __restrict__ x, int64_t batch_stride, FrameGeom g,
                                                          float* __restrict__ out) {
@@ -1582,7 +1697,33 @@ int launch_istft_fix(Ctx* c, const IstftLaunch& s, const float* window_host) {
         };
         for (int64_t n = 0; n < head_cnt; ++n) consider(n);
         for (int64_t n = tail_start; n < out_len; ++n) consider(n);
-        if (!idx.empty()) {
+        int SP = 0;   // smallest power of two <= 32 that divides N with N / SP <= 64 lanes
+        for (int q = 2; q <= 32 && !SP; q *= 2)
+          if (N % q == 0 && N / q <= 64) SP = q;
+        const bool chunked = SP != 0 && N < (1 << 20) && !tune(c, kT_DISABLE_WAVE, 0);
+        if (!idx.empty() && chunked) {
+          // k_istft_edge_chunks: candidates grouped by (n / SP, frame range) -> {n0, m_lo, m_hi, mask, SP normalisers (f32 bits, two per word)}
+          std::vector<int64_t> ch;
+          for (size_t i = 0; i < idx.size(); i += 4) {
+            const int64_t n = idx[i], n0 = n - n % SP;   // (n >= 0)
+            const size_t last = ch.size() >= 20 ? ch.size() - 20 : 0;
+            if (ch.empty() || ch[last] != n0 || ch[last + 1] != idx[i + 1] || ch[last + 2] != idx[i + 2]) {
+              ch.resize(ch.size() + 20, 0);
+              const size_t q = ch.size() - 20;
+              ch[q] = n0; ch[q + 1] = idx[i + 1]; ch[q + 2] = idx[i + 2];
+            }
+            const size_t q = ch.size() - 20;
+            const int g = (int)(n - n0);
+            ch[q + 3] |= (int64_t)1 << g;
+            ch[q + 4 + (g >> 1)] |= (int64_t)((uint64_t)(uint32_t)idx[i + 3] << (32 * (g & 1)));
+          }
+          const void* d = nullptr;
+          int rc = ctx_table(c, 0x1DAull, ch.data(), ch.size() * sizeof(int64_t), &d);
+          if (rc) return rc;
+          a.idx = reinterpret_cast<const int64_t*>(d);
+          a.n_idx = (int64_t)ch.size() / 20;
+          mode = 3 + (uint64_t)SP * 16;   // 3 | SP << 4
+        } else if (!idx.empty()) {
           const void* d = nullptr;
           int rc = ctx_table(c, 0x1D9ull, idx.data(), idx.size() * sizeof(int64_t), &d);
           if (rc) return rc;
@@ -1600,6 +1741,22 @@ int launch_istft_fix(Ctx* c, const IstftLaunch& s, const float* window_host) {
   }
   if (mode == 0 && !s.nf_list) return NXSIG_OK;
   { int rc = edge_fix_twiddles(c, N, &a.tw); if (rc) return rc; }
+  if ((mode & 15) == 3) {   // chunks of SP positions per wave (k_istft_edge_chunks); the non-finite role, if any, follows on its own
+    const int64_t chunk_blocks = (a.n_idx + kFixWaves - 1) / kFixWaves;
+    const int64_t blocks = chunk_blocks * s.batch;
+    if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "istft: signal too long for the edge fix-up grid");
+    switch ((int)(mode >> 4)) {
+      case 2: hipLaunchKernelGGL(k_istft_edge_chunks<2>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
+      case 4: hipLaunchKernelGGL(k_istft_edge_chunks<4>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
+      case 8: hipLaunchKernelGGL(k_istft_edge_chunks<8>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
+      case 16: hipLaunchKernelGGL(k_istft_edge_chunks<16>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
+      default: hipLaunchKernelGGL(k_istft_edge_chunks<32>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
+    }
+    NXSIG_HIP_TRY(hipGetLastError());
+    if (!s.nf_list) return NXSIG_OK;
+    mode = 0;   // what is left for k_istft_edge_fix: the non-finite units
+    a.idx = nullptr; a.n_idx = 0;
+  }
   const int64_t edge_blocks = mode == 0 ? 0 : ((mode == 1 ? a.n_idx : out_len) + kFixWaves - 1) / kFixWaves;
   const int32_t nf_blocks = s.nf_list ? c->num_cus * 2 : 0;
   const int64_t blocks = edge_blocks * s.batch + nf_blocks;

@@ -1626,7 +1626,13 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
     // the edge launch has few, slow (bounds-checked) units: one per wave so that they all run concurrently, unless every pair
     // goes through it (filters whose taps - 1 is not a multiple of 128)
-    if (!stream && a.total_units <= (int64_t)c->num_cus * W) a.chunk = W;
+    // (many short rows: up to two such workgroups per CU before a wave takes a second unit — 4 096 edge pairs of 2 048 one-second rows
+    // ran as 128 workgroups of 8 units per wave)
+    if (!stream) {
+      int64_t per_wave = (a.total_units + (int64_t)c->num_cus * W * 2 - 1) / ((int64_t)c->num_cus * W * 2);
+      if (per_wave < 1) per_wave = 1;
+      if (per_wave < units_per_wave) a.chunk = (int64_t)W * per_wave;
+    }
     const int64_t blocks = (a.total_units + a.chunk - 1) / a.chunk;
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: signal too long for one launch");
     hipError_t attr_rc = hipSuccess;

@@ -73,6 +73,19 @@ def make(side):
         p = _lib.StftParams(N, hop, N, 0, 0, 0, 0, 0, float(SR))
         side.keep = (w, p)
         return (lambda: lib.nxsig_stft_f32(ctx, x, L, B, L, w.ctypes.data_as(C.c_void_p), C.byref(p), z, None, 1)), B * M * (hop * 4 + N * 8)
+    if which.startswith("mel"):   # mel1024: N = K = 1024 hop 256, 128 bands, 32 x 60 s @48k; mel400 / mel512: N = 400 hop 160 K = 400 / 512 :reflect, 80 bands, 32 x 10 min @16k
+        import nx_signal_amd as S
+        K = int(which[3:] or 1024)
+        N, hop, B, L, mb, sr, pad = (1024, 256, 32, SR * 60, 128, 48000.0, 0) if K == 1024 else (400, 160, 32, 16000 * 600, 80, 16000.0, 1)
+        Lp = L + (N // 2) * 2 if pad else L
+        M = (Lp - N) // hop + 1
+        x = side.alloc(B * L * 4); o = side.alloc(B * M * mb * 4)
+        side.upload_rows(x, B, L, rng.standard_normal(L, dtype=np.float32))
+        w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(N) / N)).astype(np.float32)
+        filt = np.ascontiguousarray(S.mel_filters(K, mb, sr), dtype=np.float32)
+        p = _lib.StftParams(N, hop, K, pad, 0, 0, 0, 0, sr)
+        side.keep = (w, p, filt)
+        return (lambda: lib.nxsig_stft_mel_f32(ctx, x, L, B, L, w.ctypes.data_as(C.c_void_p), C.byref(p), mb, filt.ctypes.data_as(C.c_void_p), o, None, 1)), B * M * (hop * 4 + mb * 4)
     if which.startswith("istft"):
         N = int(which[5:] or 1024)
         hop, B, L = N // 4, 16, SR * 60

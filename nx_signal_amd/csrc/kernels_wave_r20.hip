@@ -294,7 +294,6 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   constexpr int W = 4, KB = 400, BUF = 1280;
   if (s.K != KB || s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
   if (tune(c, kT_DISABLE_R20, 0) || tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
-  const int nuse = s.fr.N < KB ? s.fr.N : KB;
   if (5 * (int64_t)s.fr.hop + KB + 4 > 2 * BUF) return NXSIG_OK;  // every lane's reads of the unit's span (idle lanes included) must fit the wave's buffer
   R20Args b;
   b.mel_bins = 0; b.nnz = 0; b.csr_w = nullptr; b.csr_off = nullptr; b.csr_lo = nullptr; b.out = nullptr; b.gmax = nullptr;

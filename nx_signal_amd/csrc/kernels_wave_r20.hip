@@ -82,8 +82,15 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
     const int64_t start = q0 - a.lo;
     if (a.reflect == 0 && start >= 0 && start + span <= a.L) {   // inside the row but not 16-byte aligned: 4-byte loads
       for (int i = lane; i < span; i += 64) S[i] = xr[start + i];
-    } else {                                                      // padding / mirror / row end: per-sample bounds
-      for (int i = lane; i < span; i += 64) S[i] = fetch_any(xr, a, q0 + i);
+    } else {                                                      // padding / mirror / row end: per-sample bounds, eight loads in flight
+      for (int i0 = lane; i0 < span; i0 += 512) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (i0 + 64 * k < span) ? fetch_any(xr, a, q0 + i0 + 64 * k) : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (i0 + 64 * k < span) S[i0 + 64 * k] = t[k];
+      }
     }
   };
   // (row, unit inside the row) of the wave's units: one division per wave, then increments

@@ -384,9 +384,15 @@ __device__ __forceinline__ float fetch_any(const float* __restrict__ x, const Wa
   if (a.reflect) {
     if (a.L == 1) return x[0];
     const int64_t period = 2 * (a.L - 1);
-    pos %= period;
-    if (pos < 0) pos += period;
+    // one mirror on either side covers every padding shorter than the signal (the usual case) without the 64-bit modulo, which costs
+    // more than a hundred instructions per sample; anything farther out takes it
+    if (pos < 0) pos = -pos;
     if (pos >= a.L) pos = period - pos;
+    if (pos < 0 || pos >= a.L) {
+      pos %= period;
+      if (pos < 0) pos += period;
+      if (pos >= a.L) pos = period - pos;
+    }
     return x[pos];
   }
   return (pos >= 0 && pos < a.L) ? x[pos] : 0.0f;

@@ -674,8 +674,8 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   a.units_per_row = (segs + T - 1) / T;
   const int64_t total_units = a.units_per_row * s.batch;
   const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, W);  // = resident waves per CU
-  int64_t run_len = (total_units + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
-  if (run_len < 8) run_len = 8;
+  (void)total_units;
+  const int64_t run_len = istft_balanced_run_len(a.units_per_row, s.batch, (int64_t)c->num_cus * waves_per_cu, (RP - 1 + T - 1) / T, 8);
   a.run_len = run_len;
   a.runs_per_row = (a.units_per_row + run_len - 1) / run_len;
   a.total_runs = a.runs_per_row * s.batch;

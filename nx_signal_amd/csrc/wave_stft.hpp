@@ -80,6 +80,28 @@ __device__ __forceinline__ void ifft_eps_cold(v2f (*zz)[NQ], const float thr) {
   }
 }
 
+// Run length of the persistent inverse kernels (runs never cross rows; every run recomputes `halo` units of the previous one).  The
+// plain rule — total / wave slots — leaves thousands of short rows with ONE run per row, i.e. ceil(rows / slots) rounds of whole rows
+// (4 096 rows on 2 816 slots: two rounds, the second 45 % full).  Here: among 1 ... 8 equal runs per row and the plain rule, the length
+// with the smallest  rounds x (run + halo).
+inline int64_t istft_balanced_run_len(int64_t units_per_row, int64_t rows, int64_t slots, int64_t halo, int64_t min_run) {
+  auto cdiv = [](int64_t a, int64_t b) { return (a + b - 1) / b; };
+  auto cost = [&](int64_t len) {
+    const int64_t rpr = cdiv(units_per_row, len);
+    return cdiv(rpr * rows, slots) * ((len < units_per_row ? len : units_per_row) + halo);
+  };
+  int64_t best = cdiv(units_per_row * rows, slots);
+  if (best < min_run) best = min_run;
+  int64_t best_cost = cost(best);
+  for (int r = 1; r <= 8; ++r) {
+    int64_t len = cdiv(units_per_row, r);
+    if (len < min_run) len = min_run;
+    const int64_t c = cost(len);
+    if (c < best_cost || (c == best_cost && len > best)) { best = len; best_cost = c; }
+  }
+  return best;
+}
+
 // front-ends of the C-point complex core
 enum : int {
   kModePair = 0,    // two adjacent real frames of length C as re / im          (fft_length == C)

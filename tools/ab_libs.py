@@ -86,6 +86,17 @@ def make(side):
         p = _lib.StftParams(N, hop, K, pad, 0, 0, 0, 0, sr)
         side.keep = (w, p, filt)
         return (lambda: lib.nxsig_stft_mel_f32(ctx, x, L, B, L, w.ctypes.data_as(C.c_void_p), C.byref(p), mb, filt.ctypes.data_as(C.c_void_p), o, None, 1)), B * M * (hop * 4 + mb * 4)
+    if which.startswith("ishort"):   # ishort400: thousands of short rows (4096 rows x ~100 frames, hop = 0.4 N rounded to 16)
+        N = int(which[6:] or 400)
+        hop, B, M = max(16, int(0.4 * N) // 16 * 16), 4096, 98
+        z = side.alloc(B * M * N * 8); y = side.alloc(B * (M * hop + N - hop) * 8)
+        zr = (rng.standard_normal((M, N), dtype=np.float32) + 1j * rng.standard_normal((M, N), dtype=np.float32)).astype(np.complex64)
+        for r in range(B):
+            assert lib.nxsig_upload(ctx, C.c_void_p(z.value + r * M * N * 8), zr.ctypes.data_as(C.c_void_p), zr.nbytes) == 0
+        w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(N) / N)).astype(np.float32)
+        p = _lib.StftParams(N, hop, N, 0, 0, 0, 0, 0, float(SR))
+        side.keep = (w, p)
+        return (lambda: lib.nxsig_istft_c64(ctx, z, M, B, w.ctypes.data_as(C.c_void_p), C.byref(p), y, 1)), B * M * (N * 8 + hop * 8)
     if which.startswith("istft"):
         N = int(which[5:] or 1024)
         hop, B, L = N // 4, 16, SR * 60

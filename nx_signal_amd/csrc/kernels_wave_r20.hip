@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
   auto prefetch = [&](int64_t row, int64_t u) -> bool {
     const int64_t start = 6 * u * (int64_t)a.hop - a.lo;
     const float* p = a.x + (size_t)row * a.batch_stride + start;
-    const bool inside = b.fast_ok && a.reflect == 0 && start >= 0 && start + span4 <= a.L && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    const bool inside = b.fast_ok && start >= 0 && start + span4 <= a.L && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
     if (inside) {
       const v4f* p4 = reinterpret_cast<const v4f*>(p) + lane;
 #pragma unroll
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
   };
   auto stage_slow = [&](const float* xr, int64_t q0) {
     const int64_t start = q0 - a.lo;
-    if (a.reflect == 0 && start >= 0 && start + span <= a.L) {   // inside the row but not 16-byte aligned: 4-byte loads
+    if (start >= 0 && start + span <= a.L) {   // inside the row (whatever the padding mode) but not 16-byte aligned: 4-byte loads
       for (int i = lane; i < span; i += 64) S[i] = xr[start + i];
     } else {                                                      // padding / mirror / row end: per-sample bounds, eight loads in flight
       for (int i0 = lane; i0 < span; i0 += 512) {

@@ -98,7 +98,7 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
   auto prefetch = [&](int64_t row, int64_t u) -> bool {
     const int64_t start = 2 * T * u * (int64_t)a.hop - a.lo;
     const float* p = a.x + (size_t)row * a.batch_stride + start;
-    const bool inside = a.reflect == 0 && start >= 0 && start + span4 <= a.L && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    const bool inside = start >= 0 && start + span4 <= a.L && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
     if (inside) {
       const v4f* p4 = reinterpret_cast<const v4f*>(p) + lane;
 #pragma unroll
@@ -109,7 +109,7 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
   };
   auto stage_slow = [&](const float* xr, int64_t q0) {
     const int64_t start = q0 - a.lo;
-    if (a.reflect == 0 && start >= 0 && start + span <= a.L) {   // inside the row but not 16-byte aligned: 4-byte loads
+    if (start >= 0 && start + span <= a.L) {   // inside the row (whatever the padding mode) but not 16-byte aligned: 4-byte loads
       for (int i = lane; i < span; i += 64) S[i] = xr[start + i];
     } else {                                                      // padding / mirror / row end: per-sample bounds, eight loads in flight
       for (int i0 = lane; i0 < span; i0 += 512) {

@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
     for (;;) {
       const int64_t qA = m0 * a.hop, qB = qA + a.hop;
       // every sample of the pass's frames inside the signal: plain loads; otherwise per-sample padding / mirror math
-      const bool inside = a.reflect == 0 && qA - a.lo >= 0 && (two ? qB : qA) - a.lo + nuse <= a.L;
+      const bool inside = qA - a.lo >= 0 && (two ? qB : qA) - a.lo + nuse <= a.L;
       v2f sum = v2f{0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)

@@ -577,11 +577,17 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   float ra[STAGED ? 1 : P], rb[STAGED ? 1 : P];
   v4f rs[STAGED ? NST : 1];
   constexpr int FPU_IN = MODE == kModeQuad ? 2 * J : 2;  // frames per unit
-  const int span4 = STAGED ? (((FPU_IN - 1) * a.hop + KOUT + 3) & ~3) : 0;  // floats of one unit's input span, 16-byte multiple
+  // floats of one unit's input span, 16-byte multiple; the unpadded form also takes spans that do not START on a 16-byte boundary (rows of
+  // odd length, host slices): the loads begin `mis` floats early and the reads out of the parked span skip them (round 5: such rows fell
+  // back to strided 4-byte gathers, 0.49 against 0.61-0.68 of the roofline for N = 512 / 256 / 128)
+  const int span4 = STAGED ? ((((FPU_IN - 1) * a.hop + KOUT + 3) & ~3) + (HQP ? 0 : 4)) : 0;
+  int mis = 0;
   auto issue_loads = [&](int64_t row, int64_t pin) {
     if (STAGED) {
-      // the unit's frames 2J pin .. 2J pin + 2J - 1 read x[unit start .. + span): one contiguous, 16-byte aligned run
-      const v4f* p4 = reinterpret_cast<const v4f*>(a.x + (size_t)row * a.batch_stride + (pin * FPU_IN * (int64_t)a.hop - a.lo)) + lane;
+      // the unit's frames 2J pin .. 2J pin + 2J - 1 read x[unit start .. + span): one contiguous run
+      const float* pu = a.x + (size_t)row * a.batch_stride + (pin * FPU_IN * (int64_t)a.hop - a.lo);
+      if (!HQP) mis = (int)((reinterpret_cast<uintptr_t>(pu) >> 2) & 3);   // wave-uniform
+      const v4f* p4 = reinterpret_cast<const v4f*>(pu - mis) + lane;
 #pragma unroll
       for (int c = 0; c < (STAGED ? NST : 0); ++c)
         rs[c] = (256 * c + 4 * lane < span4) ? p4[64 * c] : v4f{0.f, 0.f, 0.f, 0.f};
@@ -637,7 +643,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
         wave_lds_fence();
         return;
       }
-      const float* fa = xsf + (2 * (lane % JJ)) * a.hop + (lane / JJ);
+      const float* fa = xsf + mis + (2 * (lane % JJ)) * a.hop + (lane / JJ);
       const float* fb = fa + a.hop;
 #pragma unroll
       for (int s = 0; s < P; ++s) {
@@ -1379,14 +1385,17 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
   int64_t u_hi = m_hi >= M ? a.pairs_per_row : m_hi / F;  // the last (possibly ragged) unit is interior iff frame M-1 is
   if (u_lo > a.pairs_per_row) u_lo = a.pairs_per_row;
   if (u_hi < u_lo) u_hi = u_lo;
-  // quad front-ends: staged input (16-byte loads of the unit's contiguous span, re-distributed through LDS) when the span
-  // is 16-byte aligned; units must then be complete (no phantom frames) and have 3 floats of slack behind the span
+  // quad front-ends: staged input (16-byte loads of the unit's contiguous span, re-distributed through LDS); units must then be
+  // complete (no phantom frames) and have 3 floats of slack behind the span — 7 when the spans are not 16-byte aligned (the kernel
+  // then starts its loads up to 3 floats early, which stays inside the allocation: an unaligned address is not its first)
   int stg = 0;
+  const bool stage_aligned = (reinterpret_cast<uintptr_t>(s.x) & 15) == 0 && (s.batch_stride & 3) == 0 && (lo & 3) == 0;
   if (MODE == kModeQuad && !tune(c, kT_NO_STAGE, 0) && s.fr.hop <= KOUT &&
-      (reinterpret_cast<uintptr_t>(s.x) & 15) == 0 && (s.batch_stride & 3) == 0 && (lo & 3) == 0) {
-    const int span4 = ((F - 1) * s.fr.hop + KOUT + 3) & ~3;
+      (stage_aligned || (((F - 1) * s.fr.hop + KOUT + 3) & ~3) + 4 <= 2048)) {
+    const int slack = 4;   // the unpadded kernels load 4 floats more than the span (room for the `mis` floats they may start early)
+    const int span4 = (((F - 1) * s.fr.hop + KOUT + 3) & ~3) + 4;   // (+ 4: what the unpadded kernels load, see stft_wave_body)
     stg = (span4 + 255) / 256 <= 4 ? 4 : 8;
-    int64_t mh = (s.fr.L + lo - (KOUT + 3) >= 0) ? (s.fr.L + lo - (KOUT + 3)) / hop + 1 : 0;
+    int64_t mh = (s.fr.L + lo - (KOUT + 3 + slack) >= 0) ? (s.fr.L + lo - (KOUT + 3 + slack)) / hop + 1 : 0;
     if (mh > M) mh = M;
     if (mh < m_lo) mh = m_lo;
     u_hi = mh / F;  // complete units only
@@ -1501,7 +1510,7 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
       if (stg == 4) {
         done = true;
         // hop == fft_length / 4 (the default 75 % overlap): the instantiation whose parked span is padded against bank conflicts
-        if (!npred && 4 * s.fr.hop == KOUT && tune(c, kT_STAGE_PAD, 1))
+        if (!npred && 4 * s.fr.hop == KOUT && stage_aligned && tune(c, kT_STAGE_PAD, 1))
           rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 5>, upr, big, u_lo, u_lo)
                      : go(k_stft_wave<C, MODE, false, false, W, J, false, 5>, upr, big, u_lo, u_lo);
         else if (!npred) rc = scale ? go(k_stft_wave<C, MODE, false, true, W, J, false, 4>, upr, big, u_lo, u_lo)

@@ -672,3 +672,42 @@ def test_fir_long_filters_partitioned(taps, mode):
     ys = S.filters.fir(xs, h, mode="full")
     refs = np.stack([np.convolve(r.astype(np.float64), h.astype(np.float64), mode="full") for r in xs])
     assert float(np.max(np.abs(ys - refs)) / np.max(np.abs(refs))) < 1e-5
+
+
+@pytest.mark.parametrize("K,N,hop", [(512, 512, 128), (512, 400, 160), (256, 256, 64), (128, 128, 32), (512, 512, 200), (256, 256, 256)])
+@pytest.mark.parametrize("L", [30001, 30002, 30003])
+def test_stft_quad_front_ends_rows_that_do_not_start_on_16_bytes(K, N, hop, L):
+    """rows of a length that is not a multiple of 4 (every row but the first starts off a 16-byte boundary) and a device tensor sliced at an
+    odd offset: the staged quad input (round 5) starts its 16-byte loads up to 3 floats early and skips them when it reads the parked span.
+    Spectrum, log-mel and magnitude sinks against the oracle; a NaN in the last sample of a row (right before the next row's first
+    span) stays in its own frames."""
+    import nx_signal_amd as S
+    from oracle import nx_oracle as O
+
+    rng = np.random.default_rng(K + hop + L)
+    x = rng.standard_normal((5, L)).astype(np.float32)
+    x[1, L - 1] = np.nan
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=K, sampling_rate=16000)
+    ctx = S.Context(0)
+    z = S.stft(ctx.to_device(x), w, ctx=ctx, **opts)[0].numpy()
+    zo = O.stft(x, w, **opts)[0]
+    ok = np.isfinite(zo)
+    assert np.array_equal(np.isfinite(z), ok)
+    assert float(np.max(np.abs(z[ok] - zo[ok])) / np.max(np.abs(zo[ok]))) < 1e-5
+    x[1, L - 1] = 0.25
+    zo = O.stft(x, w, **opts)[0]
+    flat = ctx.to_device(np.concatenate([np.zeros(1, np.float32), x.reshape(-1)]))     # the same rows, one float into the allocation
+    lib = S._lib.load()
+    import ctypes as C
+    M = zo.shape[1]
+    zd = ctx.empty((5, M, K), np.complex64)
+    p = S._lib.StftParams(N, hop, K, S._lib.PAD_VALID, 0, 0, S._lib.SCALE_NONE, 0, 16000.0)
+    S._lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(flat.ptr + 4), L, 5, L, w.ctypes.data_as(C.c_void_p), C.byref(p), C.c_void_p(zd.ptr), None, S._lib.DEVICE))
+    z2 = zd.numpy()
+    assert float(np.max(np.abs(z2 - zo)) / np.max(np.abs(zo))) < 1e-5
+    mel = S.mel_spectrogram(x, w, mel_bins=40, **opts)
+    melo = O.stft_to_mel(zo.reshape(-1, K), 16000, K, 40).reshape(5, -1, 40)
+    assert float(np.max(np.abs(mel - melo))) < 1e-4
+    g, _, _ = S.spectrogram(x, w, kind="magnitude", **opts)
+    assert float(np.max(np.abs(g - np.abs(zo[..., : K // 2]))) / np.max(np.abs(zo))) < 1e-5

@@ -857,10 +857,18 @@ struct FirWaveArgs {
   int* row_flags;                      // FirLaunch::row_flags: a non-finite sample poisons its whole row, like the reference's one transform
   const v2f* coefA = nullptr;          // k_fir_r2k: c64[1024] each, W[k] = A[k] Z[k] + B[k] conj Z[(1024 - k) mod 1024]
   const v2f* coefB = nullptr;
+  // per-row grid phase (round 5): rows whose length is not a multiple of 32 samples start off a 128-byte boundary, every row at a
+  // different offset, and one common phase aligns the first row only (the other rows' streaming stores then hit partial lines: 2 x
+  // slower).  row_mod = out_len mod 32 (0: off): row r shifts its block grid by fir_row_shift(r) = (-r out_len) mod 32 further
+  // samples, i.e. x'' = x' + shift, [xlo, xhi) and out_start move down by shift, so that every block of every row starts a line of y.
+  int32_t row_mod = 0;
 };
+__device__ __forceinline__ int fir_row_shift(const int32_t row_mod, const int64_t row) {
+  return row_mod ? (int)((32 - (int)((row * row_mod) & 31)) & 31) : 0;
+}
 
 int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, int32_t taps, int64_t first_block, int64_t pb_lo,
-                      int64_t dp_per_row, int64_t out_start, int64_t out_len, const float2* H_dev, float* y, int* row_flags);  // kernels_wave_fir32.hip
+                      int64_t dp_per_row, int64_t out_start, int64_t out_len, const float2* H_dev, float* y, int* row_flags, int row_mod);  // kernels_wave_fir32.hip
 
 // STREAM = true : interior pairs only, 8-byte vector access, branch-free and software-pipelined like k_stft_wave
 //                 (requires (taps-1) % 128 == 0 and even offsets — checked by the launcher)
@@ -908,7 +916,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
     v2f r1[NQ], r2[NQ];
     auto issue_loads = [&](int64_t rw, int64_t pi) {
       const int64_t b1 = a.first_block + 2 * (a.pb_lo + pi);
-      const float* p1 = a.x + (size_t)rw * a.batch_stride + (b1 * a.V - tm1) + 2 * lane;
+      const float* p1 = a.x + (size_t)rw * a.batch_stride + (b1 * a.V - tm1 + fir_row_shift(a.row_mod, rw)) + 2 * lane;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         r1[q] = *reinterpret_cast<const v2f*>(p1 + 128 * q);   // default cache policy: the pair's blocks overlap and neighbours re-read
@@ -955,7 +963,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       }
       const int64_t b1 = a.first_block + 2 * (a.pb_lo + pin);
       // the pair's two valid parts are one contiguous run of 2 V outputs: streaming stores (sc1 nt) through a row descriptor
-      const StreamRow ys(a.y + (size_t)row * a.out_len + (b1 * a.V - a.out_start), (uint32_t)(2 * a.V) * 4);
+      const StreamRow ys(a.y + (size_t)row * a.out_len + (b1 * a.V - a.out_start + fir_row_shift(a.row_mod, row)), (uint32_t)(2 * a.V) * 4);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (128 * q >= tm1) {  // uniform: (taps-1) % 128 == 0
@@ -975,10 +983,12 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
       (void)n_hi;
       const int64_t b1 = a.first_block + 2 * pb, b2 = b1 + 1;
       const bool have2 = (b2 - a.first_block) < a.nblocks;
-      const float* xr = a.x + (size_t)row * a.batch_stride;
+      const int rsh = fir_row_shift(a.row_mod, row);
+      const float* xr = a.x + (size_t)row * a.batch_stride + rsh;
+      const int64_t xlo = a.xlo - rsh, xhi = a.xhi - rsh;
       float* yr = a.y + (size_t)row * a.out_len;
       const int64_t s1 = b1 * a.V - tm1, s2 = s1 + a.V;
-      const int64_t o1 = b1 * a.V - a.out_start - tm1;  // y index of block-1 sample n is o1 + n (n >= taps-1)
+      const int64_t o1 = b1 * a.V - a.out_start + rsh - tm1;  // y index of block-1 sample n is o1 + n (n >= taps-1)
       v2f zz[2][NQ];
       v2f nfs = v2f{0.f, 0.f};
 #pragma unroll
@@ -987,8 +997,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_wave(FirWaveArgs a) {
         for (int e2 = 0; e2 < 2; ++e2) {
           const int n = 2 * lane + e2 + 128 * q;
           const int64_t p1 = s1 + n, p2 = s2 + n;
-          const float v1 = (p1 >= a.xlo && p1 < a.xhi) ? xr[p1] : 0.0f;
-          const float v2 = (have2 && p2 >= a.xlo && p2 < a.xhi) ? xr[p2] : 0.0f;
+          const float v1 = (p1 >= xlo && p1 < xhi) ? xr[p1] : 0.0f;
+          const float v2 = (have2 && p2 >= xlo && p2 < xhi) ? xr[p2] : 0.0f;
           zz[e2][q] = v2f{v1, v2};
           nfs += zz[e2][q];
         }
@@ -1053,7 +1063,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_r2k(FirWaveArgs a) {
   v4f r4[NQ];
   auto issue_loads = [&](int64_t rw, int64_t ui) {
     const int64_t b = a.first_block + 2 * a.pb_lo + ui;
-    const v4f* p = reinterpret_cast<const v4f*>(a.x + (size_t)rw * a.batch_stride + (b * a.V - TM1)) + lane;
+    const v4f* p = reinterpret_cast<const v4f*>(a.x + (size_t)rw * a.batch_stride + (b * a.V - TM1 + fir_row_shift(a.row_mod, rw))) + lane;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) r4[q] = p[64 * q];   // samples 4 lane + 256 q .. + 3: z[2 lane + 128 q], z[2 lane + 1 + 128 q]
   };
@@ -1099,7 +1109,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_r2k(FirWaveArgs a) {
       for (int q = 0; q < NQ; ++q) { u[0][q] = fft_eps0(u[0][q]); u[1][q] = fft_eps0(u[1][q]); }
     }
     const int64_t b = a.first_block + 2 * a.pb_lo + uin;
-    const StreamRow ys(a.y + (size_t)row * a.out_len + (b * a.V - a.out_start), (uint32_t)a.V * 4);
+    const StreamRow ys(a.y + (size_t)row * a.out_len + (b * a.V - a.out_start + fir_row_shift(a.row_mod, row)), (uint32_t)a.V * 4);
 #pragma unroll
     for (int q = TQ2; q < NQ; ++q)
       ys.st16(v4f{u[0][q].x, u[0][q].y, u[1][q].x, u[1][q].y}, lane * 16 + 1024 * q - TM1 * 4);
@@ -1578,7 +1588,13 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   const int64_t out_start = s.out_start - phase;
   a.x = s.x + phase; a.xlo = -phase; a.xhi = s.L - phase;
   a.L = s.L; a.batch_stride = s.batch_stride; a.batch = s.batch; a.taps = s.taps;
-  a.first_block = out_start / a.V;
+  // rows that do not start on a 128-byte boundary of y (row length not a multiple of 32, more than one row): per-row grid phase, see
+  // FirWaveArgs::row_mod.  A row's grid moves by up to 31 samples: the block range of the launch covers every shift (one more block in
+  // front), and a pair is interior only if it is so for every shift
+  const int row_mod = (tune(c, kT_FIR_PHASE, 1) && s.batch > 1) ? (int)(s.out_len % 32) : 0;
+  const int64_t margin = row_mod ? 31 : 0;
+  a.row_mod = row_mod;
+  a.first_block = out_start - margin >= 0 ? (out_start - margin) / a.V : -1;
   const int64_t last_block = (out_start + s.out_len - 1) / a.V;
   a.nblocks = last_block - a.first_block + 1;
   a.pairs_per_row = (a.nblocks + 1) / 2;
@@ -1589,7 +1605,10 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   a.twC = reinterpret_cast<const v2f*>(wt.twC);
   a.y = s.y; a.row_flags = s.row_flags;
   // 8-byte vector access needs every offset even: taps-1 multiple of 128 (=> V even), even strides, aligned bases
-  const bool fast8 = ((s.taps - 1) % 128 == 0) && (s.batch_stride % 2 == 0) && (s.out_len % 2 == 0) && (out_start % 2 == 0) &&
+  // (with the per-row phase every row of y starts a line, and row r of x sits r (stride - out_len) samples off one)
+  const bool rows2 = row_mod ? (s.batch_stride - s.out_len) % 2 == 0 : (s.batch_stride % 2 == 0 && s.out_len % 2 == 0);
+  const bool rows4 = row_mod ? (s.batch_stride - s.out_len) % 4 == 0 : (s.batch_stride % 4 == 0 && s.out_len % 4 == 0);
+  const bool fast8 = ((s.taps - 1) % 128 == 0) && rows2 && (out_start % 2 == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 7) == 0);
   // the 32 x 32 kernel (kernels_wave_fir32.hip, 4-byte accesses: no alignment conditions) takes what the 8-byte kernel cannot;
   // where both apply the 8-byte kernel is ~4 % faster (NXSIG_FIR32: 0 never, 1 when needed, 2 always)
@@ -1611,7 +1630,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     while (hi > lo) {
       const int64_t b1 = a.first_block + 2 * (hi - 1);
       const bool have2 = (b1 + 1 - a.first_block) < a.nblocks;
-      if (have2 && b1 * a.V - tm1 + a.V + K <= a.xhi && b1 * a.V - a.out_start + 2 * a.V <= s.out_len) break;
+      if (have2 && b1 * a.V - tm1 + a.V + K <= a.xhi - margin && b1 * a.V - a.out_start + 2 * a.V + margin <= s.out_len) break;
       --hi;
     }
     a.pb_lo = lo; a.pb_hi = hi;
@@ -1667,7 +1686,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   if constexpr (R2K) {
     // interior pairs of the 2048-block grid, ONE block per unit, on the real-block kernel (16-byte accesses: rows, offsets and V
     // multiples of 4 samples); anything else falls back to this grid's pair kernel below
-    const bool al16 = fast8 && (s.taps - 1) % 256 == 0 && (s.batch_stride % 4 == 0) && (s.out_len % 4 == 0) && (out_start % 4 == 0) &&
+    const bool al16 = fast8 && (s.taps - 1) % 256 == 0 && s.taps - 1 >= 256 && s.taps - 1 <= 1024 && rows4 && (out_start % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(s.y) & 15) == 0) && a.pb_hi > a.pb_lo;
     if (al16) {
       int rc1 = ensure_wave_tables(c, 1024);
@@ -1696,7 +1715,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   if (use32) {  // interior pairs two at a time on the 32 x 32 kernel (kernels_wave_fir32.hip); an odd leftover joins the edge pairs
     a.pb_hi -= (a.pb_hi - a.pb_lo) & 1;
     rc = launch_fir_wave32(c, a.x, s.batch_stride, s.batch, s.taps, a.first_block, a.pb_lo, (a.pb_hi - a.pb_lo) / 2, a.out_start, s.out_len,
-                           reinterpret_cast<const float2*>(Hd), s.y, s.row_flags);
+                           reinterpret_cast<const float2*>(Hd), s.y, s.row_flags, row_mod);
   } else {
     rc = launch(true, a.pb_hi - a.pb_lo);
   }

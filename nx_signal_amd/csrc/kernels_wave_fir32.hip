@@ -121,7 +121,11 @@ struct Fir32Args {
   const v2f* tw;                       // c64[32][32]: w_1024^(k1 n2)
   float* y;
   int* row_flags;                      // FirLaunch::row_flags
+  int32_t row_mod = 0;                 // per-row grid phase, see FirWaveArgs::row_mod (kernels_wave.hip)
 };
+__device__ __forceinline__ int fir32_row_shift(const int32_t row_mod, const int64_t row) {
+  return row_mod ? (int)((32 - (int)((row * row_mod) & 31)) & 31) : 0;
+}
 
 // RLO = (taps - 1) / 32 as a compile-time constant for the common filter lengths (the stores of registers below it vanish at
 // compile time), or -1: decided at run time by pushing the unwanted stores' offsets out of the descriptor's range
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fir_wave32(Fir32Args a) {
   const int lane_off = h * 2 * a.V + l;
   auto src_of = [&](int64_t rw, int64_t qq) -> const float* {
     const int64_t b1 = a.first_block + 2 * (a.pb_lo + 2 * qq);
-    return a.x + (size_t)rw * a.batch_stride + (b1 * (int64_t)a.V - a.tm1) + lane_off;
+    return a.x + (size_t)rw * a.batch_stride + (b1 * (int64_t)a.V - a.tm1 + fir32_row_shift(a.row_mod, rw)) + lane_off;
   };
   v2f nd[32];   // the next double pair's samples land straight in (re, im) position
   auto issue_loads = [&](const float* s) {
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_fir_wave32(Fir32Args a) {
     __builtin_amdgcn_sched_barrier(0);
     // the double pair's valid outputs are one contiguous run of 4 V samples: streaming stores through one row descriptor
     const int64_t b1 = a.first_block + 2 * (a.pb_lo + 2 * q);
-    const StreamRow ys(a.y + (size_t)row * a.out_len + (b1 * (int64_t)a.V - a.out_start), (uint32_t)(4 * a.V) * 4);
+    const StreamRow ys(a.y + (size_t)row * a.out_len + (b1 * (int64_t)a.V - a.out_start + fir32_row_shift(a.row_mod, row)), (uint32_t)(4 * a.V) * 4);
     const int base = (h * 2 * a.V + l - a.tm1) * 4, base2 = base + a.V * 4;
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
@@ -201,13 +205,13 @@ __global__ __launch_bounds__(64 * W, 2) void k_fir_wave32(Fir32Args a) {
 
 // stream part of launch_fir_wave_W (kernels_wave.hip): interior pairs [pb_lo, pb_lo + 2 dp_per_row) of every row
 int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batch, int32_t taps, int64_t first_block, int64_t pb_lo,
-                      int64_t dp_per_row, int64_t out_start, int64_t out_len, const float2* H_dev, float* y, int* row_flags) {
+                      int64_t dp_per_row, int64_t out_start, int64_t out_len, const float2* H_dev, float* y, int* row_flags, int row_mod) {
   if (dp_per_row <= 0 || batch <= 0) return NXSIG_OK;
   constexpr int W = 4;
   Fir32Args a;
   a.x = x; a.batch_stride = batch_stride; a.V = 1024 - (taps - 1); a.tm1 = taps - 1; a.r_lo = (taps - 1) / 32; a.first_block = first_block; a.pb_lo = pb_lo;
   a.dp_per_row = dp_per_row; a.total_dp = dp_per_row * batch;
-  a.out_start = out_start; a.out_len = out_len; a.H = reinterpret_cast<const v2f*>(H_dev); a.y = y; a.row_flags = row_flags;
+  a.out_start = out_start; a.out_len = out_len; a.H = reinterpret_cast<const v2f*>(H_dev); a.y = y; a.row_flags = row_flags; a.row_mod = row_mod;
   {
     const uint64_t key = 0xF1320000ull;
     auto hit = c->memo.find(key);

@@ -711,3 +711,42 @@ def test_stft_quad_front_ends_rows_that_do_not_start_on_16_bytes(K, N, hop, L):
     assert float(np.max(np.abs(mel - melo))) < 1e-4
     g, _, _ = S.spectrogram(x, w, kind="magnitude", **opts)
     assert float(np.max(np.abs(g - np.abs(zo[..., : K // 2]))) / np.max(np.abs(zo))) < 1e-5
+
+
+@pytest.mark.parametrize("taps", [33, 101, 257, 513, 1025])
+@pytest.mark.parametrize("mode", ["same", "full", "valid"])
+def test_fir_rows_that_do_not_start_on_a_cache_line(taps, mode):
+    """more than 32 rows of a length that is not a multiple of 32 samples: every row starts at a different offset inside a 128-byte line
+    and gets its own grid phase (round 5, FirWaveArgs::row_mod: one common phase left the other rows' streaming stores on partial lines,
+    0.26 instead of 0.50 of the roofline).  Against the direct f64 convolution; rows padded apart (batch_stride > length) through the C
+    ABI; a NaN poisons exactly its row; NXSIG_FIR_PHASE=0 (no phase at all) agrees."""
+    import ctypes as C
+    import nx_signal_amd as S
+
+    rng = np.random.default_rng(taps + len(mode))
+    rows, L = 37, 9003
+    x = rng.standard_normal((rows, L)).astype(np.float32)
+    h = (rng.standard_normal(taps) / taps ** 0.5).astype(np.float32)
+    ref = np.stack([np.convolve(r.astype(np.float64), h.astype(np.float64), mode=mode) for r in x])
+    ctx = S.Context(0)
+    y = S.filters.fir(ctx.to_device(x), h, mode=mode, ctx=ctx).numpy()
+    assert y.shape == ref.shape and float(np.max(np.abs(y - ref)) / np.max(np.abs(ref))) < 1e-5, (taps, mode)
+    ctx.set_tuning("NXSIG_FIR_PHASE", 0)
+    y0 = S.filters.fir(ctx.to_device(x), h, mode=mode, ctx=ctx).numpy()
+    ctx.clear_tuning("FIR_PHASE")
+    assert float(np.max(np.abs(y - y0)) / np.max(np.abs(ref))) < 2e-6
+    xn = x.copy()
+    xn[20, 4000] = np.nan
+    yn = S.filters.fir(ctx.to_device(xn), h, mode=mode, ctx=ctx).numpy()
+    bad = ~np.isfinite(yn).all(axis=1)
+    assert bad[20] and bad.sum() == 1 and not np.isfinite(yn[20]).any()
+    # rows 9 007 floats apart
+    stride = L + 4
+    xs = np.zeros((rows, stride), np.float32)
+    xs[:, :L] = x
+    xd = ctx.to_device(xs)
+    yd = ctx.empty(ref.shape, np.float32)
+    lib = S._lib.load()
+    cm = {"full": S._lib.CONV_FULL, "same": S._lib.CONV_SAME, "valid": S._lib.CONV_VALID}[mode]
+    S._lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(xd.ptr), L, rows, stride, h.ctypes.data_as(C.c_void_p), taps, cm, C.c_void_p(yd.ptr), S._lib.DEVICE))
+    assert float(np.max(np.abs(yd.numpy() - ref)) / np.max(np.abs(ref))) < 1e-5

@@ -1539,16 +1539,28 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   // (128 on the 2048-point blocks) gives EVERY filter length the streaming kernels instead of the bounds-checked edge path.
   const int taps_h = s_in.taps;
   FirLaunch s = s_in;
+  // ... and LEADING zero taps delay the result by their number: the filter is treated as `lead` zeros + h and the requested slice
+  // starts `lead` outputs later.  On the 2048-point blocks (no 4-byte kernel there) this makes out_start a multiple of 4 — the grid
+  // phase then keeps x 16-byte aligned — for the tap counts whose :same / :valid offset is not: every even count (400, 512, 600, 900
+  // taps ran on the bounds-checked kernel throughout: 0.19-0.26 of the roofline against 0.45-0.51 for 449 / 513 / 769)
+  int lead = 0;
+  if (K == 2048 && tune(c, kT_FIR_PAD_TAPS, 1)) {
+    lead = (int)((4 - s_in.out_start % 4) % 4);
+    const int q0 = R2K ? 256 : 128;
+    if (((s_in.taps + lead - 1 + q0 - 1) / q0) * q0 + 1 > K / 2 + 1) lead = 0;
+  }
+  s.taps = s_in.taps + lead;
+  s.out_start = s_in.out_start + lead;
   {
     const int q = R2K ? 256 : (K == 1024 ? 32 : 128);   // (R2K: whole 256-sample slots of the real-block kernel)
-    const int eff = ((s_in.taps - 1 + q - 1) / q) * q + 1;
+    const int eff = ((s.taps - 1 + q - 1) / q) * q + 1;
     if (eff <= K / 2 + 1 && tune(c, kT_FIR_PAD_TAPS, 1)) s.taps = eff;
   }
   int rc = ensure_wave_tables(c, K);
   if (rc) return rc;
   *handled = true;
   const void* Hd = nullptr;
-  const uint64_t hkey = fnv1a(0xF1B0ull ^ ((uint64_t)K << 32), s.h_host, (size_t)taps_h * sizeof(float)) ^ (uint64_t)taps_h;
+  const uint64_t hkey = fnv1a(0xF1B0ull ^ ((uint64_t)K << 32), s.h_host, (size_t)taps_h * sizeof(float)) ^ (uint64_t)taps_h ^ ((uint64_t)lead << 20);
   const void *Ad = nullptr, *Bd = nullptr;
   auto hit = c->memo.find(hkey);
   if (hit != c->memo.end() && (!R2K || hit->second.size() >= 3)) {
@@ -1556,7 +1568,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     if (R2K) { Ad = reinterpret_cast<const void*>(hit->second[1]); Bd = reinterpret_cast<const void*>(hit->second[2]); }
   } else {
     std::vector<double> re(K, 0.0), im(K, 0.0);
-    for (int i = 0; i < taps_h; ++i) re[i] = (double)s.h_host[i];
+    for (int i = 0; i < taps_h; ++i) re[lead + i] = (double)s.h_host[i];
     host_fft1024_f64(re, im);
     std::vector<float2> H(K);
     for (int i = 0; i < K; ++i) H[i] = make_float2((float)(re[i] / K), (float)(im[i] / K));

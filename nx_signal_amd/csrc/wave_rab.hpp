@@ -672,9 +672,7 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t segs = (a.out_len + hop - 1) / hop;              // hop segments of the output (the last may be partial)
   a.units_per_row = (segs + T - 1) / T;
-  const int64_t total_units = a.units_per_row * s.batch;
   const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, W);  // = resident waves per CU
-  (void)total_units;
   const int64_t run_len = istft_balanced_run_len(a.units_per_row, s.batch, (int64_t)c->num_cus * waves_per_cu, (RP - 1 + T - 1) / T, 8);
   a.run_len = run_len;
   a.runs_per_row = (a.units_per_row + run_len - 1) / run_len;

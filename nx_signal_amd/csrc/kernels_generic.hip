@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_fix(EdgeFixArgs a, int6
 // order of the double sums.  Chunk entry (20 x int64, host-built): n0, m_lo, m_hi, mask of the flagged positions, then the bits of the
 // f32 normalisers, two per int64.
 template <int SP>
-__global__ __launch_bounds__(kThreads) void k_istft_edge_chunks(EdgeFixArgs a, int64_t chunk_blocks) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(SP >= 32 ? 1 : 2, 8))) void k_istft_edge_chunks(EdgeFixArgs a, int64_t chunk_blocks) {
   constexpr int LOG = SP == 2 ? 1 : SP == 4 ? 2 : SP == 8 ? 3 : SP == 16 ? 4 : 5;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t b = blockIdx.x;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_chunks(EdgeFixArgs a, i
     const int64_t j0 = n0 - m * a.hop;                   // may be negative for positions outside the mask
     const int rot = (int)(((j0 % SP) + SP) % SP);        // uniform
     const float2* zr = zb + (size_t)m * rowlen;
-    double2 x[SP], y[SP];
+    double2 x[SP];
 #pragma unroll
     for (int s = 0; s < SP; ++s) {
       float2 v = lane < A ? istft_bin(a, zr, lane + A * s) : make_float2(0.0f, 0.0f);
@@ -639,44 +639,50 @@ __global__ __launch_bounds__(kThreads) void k_istft_edge_chunks(EdgeFixArgs a, i
         x[s] = make_double2(x[s].x * t.x - x[s].y * t.y, x[s].x * t.y + x[s].y * t.x);
       }
     }
-    // SP-point transform with the + sign, natural order in and out: radix-2 Stockham, every index a compile-time constant
+    // SP-point transform with the + sign IN PLACE: radix-2 decimation in frequency, every index a compile-time constant; the result is
+    // in bit-reversed order, X[c] sits in x[rev(c)] (a natural-order Stockham form with a second array held 242 VGPRs for SP = 16)
 #pragma unroll
-    for (int Ns = 1; Ns < SP; Ns *= 2) {
+    for (int half = SP / 2; half >= 1; half /= 2) {
 #pragma unroll
-      for (int j = 0; j < SP / 2; ++j) {
-        const int k = j % Ns;
-        const double2 u = x[j];
-        double2 v = x[j + SP / 2];
-        if (k != 0) {
-          const double2 t = a.tw[A * (k * (SP / (2 * Ns)))];   // e^(2 pi i k / (2 Ns))
-          v = make_double2(v.x * t.x - v.y * t.y, v.x * t.y + v.y * t.x);
+      for (int blk = 0; blk < SP; blk += 2 * half) {
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+          const double2 u = x[blk + j], v = x[blk + j + half];
+          x[blk + j] = make_double2(u.x + v.x, u.y + v.y);
+          double2 d = make_double2(u.x - v.x, u.y - v.y);
+          if (j != 0) {
+            const double2 t = a.tw[A * (j * (SP / (2 * half)))];   // e^(2 pi i j / (2 half))
+            d = make_double2(d.x * t.x - d.y * t.y, d.x * t.y + d.y * t.x);
+          }
+          x[blk + j + half] = d;
         }
-        const int d0 = (j / Ns) * 2 * Ns + k;
-        y[d0] = make_double2(u.x + v.x, u.y + v.y);
-        y[d0 + Ns] = make_double2(u.x - v.x, u.y - v.y);
       }
-#pragma unroll
-      for (int s = 0; s < SP; ++s) x[s] = y[s];
     }
-    // x[c] = inner sum for the positions with (j - rot) mod SP == c, i.e. position gg <-> x[gg] after the rotation above.
-    // outer products with w_N^(j lane), j = j0 + gg
-    int tix = (int)((uint32_t)((int)(((j0 % N) + N) % N) * lane) % (uint32_t)N);   // (j0 lane) mod N, then + lane per position (lane < N)
+    // position gg <-> inner sum with index gg (after the rotation above) = x[rev(gg)]; outer products with w_N^(j lane), j = j0 + gg, in place
+    {
+      int tix = (int)((uint32_t)((int)(((j0 % N) + N) % N) * lane) % (uint32_t)N);   // (j0 lane) mod N, then + lane per position (lane < N)
 #pragma unroll
-    for (int gg = 0; gg < SP; ++gg) {
-      const double2 t = a.tw[tix];
-      x[gg] = make_double2(x[gg].x * t.x - x[gg].y * t.y, x[gg].x * t.y + x[gg].y * t.x);
-      tix += lane;
-      if (tix >= N) tix -= N;
+      for (int gg = 0; gg < SP; ++gg) {
+        int rv = 0;
+#pragma unroll
+        for (int bit = 0; bit < LOG; ++bit) rv |= ((gg >> bit) & 1) << (LOG - 1 - bit);
+        const double2 t = a.tw[tix];
+        const double2 xv = x[rv];
+        x[rv] = make_double2(xv.x * t.x - xv.y * t.y, xv.x * t.y + xv.y * t.x);
+        tix += lane;
+        if (tix >= N) tix -= N;
+      }
     }
-    // butterfly reduction: after step q the lane holds SP >> (q + 1) partial sums over 2^(q + 1) lanes
+    // butterfly reduction on the bit-reversed storage: step q folds position bit LOG - 1 - q = storage bit q (stride 2^q) and lane bit
+    // 5 - q; after it the lane holds SP >> (q + 1) partial sums over 2^(q + 1) lanes, the last one in x[0]
 #pragma unroll
     for (int q = 0; q < LOG; ++q) {
-      const int half = SP >> (q + 1), off = 32 >> q;
+      const int stride = 1 << q, off = 32 >> q;
       const bool up = (lane & off) != 0;
 #pragma unroll
-      for (int i = 0; i < half; ++i) {
-        const double2 keep = up ? x[i + half] : x[i];
-        const double2 send = up ? x[i] : x[i + half];
+      for (int i = 0; i < SP; i += 2 * stride) {
+        const double2 keep = up ? x[i + stride] : x[i];
+        const double2 send = up ? x[i] : x[i + stride];
         x[i] = make_double2(keep.x + __shfl_xor(send.x, off), keep.y + __shfl_xor(send.y, off));
       }
     }

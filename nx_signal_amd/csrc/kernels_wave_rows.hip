@@ -97,6 +97,18 @@ __global__ __launch_bounds__(64 * W) void k_fft_rows_wave(RowsWaveArgs a) {
     if (!INV && a.fM > 0) {   // wave-uniform
       const int64_t b = r / a.fM, m = r - b * a.fM;
       const v2f* sig = static_cast<const v2f*>(a.in) + (size_t)b * a.fstride;
+      const int64_t p0 = m * a.fhop - a.flo;
+      if (p0 >= 0 && p0 + a.n_in <= a.fL) {   // wave-uniform: the frame lies inside the signal (all but the edge frames): plain loads
+        const v2f* fp = sig + p0 + lane;
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+          const bool in = lane + 64 * s < a.n_in;
+          const v2f v = in ? fp[64 * s] : v2f{0.f, 0.f};
+          const float w = in ? a.pre_window[lane + 64 * s] : 0.0f;
+          nx[s] = v2f{v.x * w, v.y * w};
+        }
+        return;
+      }
 #pragma unroll
       for (int s = 0; s < P; ++s) nx[s] = rows_fetch_framed(a, sig, m * a.fhop, lane + 64 * s);
       return;
@@ -154,6 +166,17 @@ __global__ __launch_bounds__(64 * W) void k_fft_rows_wave_4k(RowsWaveArgs a) {
         const v4f* p4 = reinterpret_cast<const v4f*>(row) + 2 * lane + h;
 #pragma unroll
         for (int s = 0; s < P; ++s) { const v4f t = p4[128 * s]; d0[s] = v2f{t.x, t.y}; d1[s] = v2f{t.z, t.w}; }
+      } else if (!INV && a.fM > 0 && fq0 - a.flo >= 0 && fq0 - a.flo + a.n_in <= a.fL) {   // wave-uniform: a frame inside the signal
+        const v2f* fp = fsig + (fq0 - a.flo);
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+          const int i0 = 4 * (lane + 64 * s) + 2 * h;
+          const bool in0 = i0 < a.n_in, in1 = i0 + 1 < a.n_in;
+          const v2f v0 = in0 ? fp[i0] : v2f{0.f, 0.f}, v1 = in1 ? fp[i0 + 1] : v2f{0.f, 0.f};
+          const float w0 = in0 ? a.pre_window[i0] : 0.0f, w1 = in1 ? a.pre_window[i0 + 1] : 0.0f;
+          d0[s] = v2f{v0.x * w0, v0.y * w0};
+          d1[s] = v2f{v1.x * w1, v1.y * w1};
+        }
       } else {
 #pragma unroll
         for (int s = 0; s < P; ++s) {

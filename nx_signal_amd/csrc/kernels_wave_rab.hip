@@ -11,6 +11,10 @@ int launch_istft_rab_p1(Ctx* c, const IstftLaunch& s, const float* window_host, 
 int launch_istft_rab_p2(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p3(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p4(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
+int launch_stft_rab_c64_p1(Ctx* c, const StftLaunch& s, bool* handled);
+int launch_stft_rab_c64_p2(Ctx* c, const StftLaunch& s, bool* handled);
+int launch_stft_rab_c64_p3(Ctx* c, const StftLaunch& s, bool* handled);
+int launch_stft_rab_c64_p4(Ctx* c, const StftLaunch& s, bool* handled);
 
 // 0..3: the list that holds fft length K, -1: none
 int rab_length_part(int K) {
@@ -48,6 +52,27 @@ int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   }
   switch (s.K) {
 #define X(KK, A, B) case KK: return launch_rab<A, B>(c, s, handled, mel);   // (480 as 16 x 30 measured 0.45 against 0.51: half of its pass-B lanes idle)
+    NXSIG_RAB_PART0(X)
+#undef X
+    default: return NXSIG_OK;
+  }
+}
+
+// stft of complex samples: every length of the four lists + the power-of-two lengths of the inverse-only list (128 ... 1024)
+int launch_stft_rab_c64(Ctx* c, const StftLaunch& s, bool* handled) {
+  *handled = false;
+  if (s.fr.M == 0 || s.batch == 0 || s.window_padK == nullptr) return NXSIG_OK;
+  if (tune(c, kT_DISABLE_RAB, 0) || tune(c, kT_DISABLE_WAVE, 0)) return NXSIG_OK;
+  if (rab_inverse_only(s.K)) return launch_stft_rab_c64_p4(c, s, handled);
+  switch (rab_length_part(s.K)) {
+    case 1: return launch_stft_rab_c64_p1(c, s, handled);
+    case 2: return launch_stft_rab_c64_p2(c, s, handled);
+    case 3: return launch_stft_rab_c64_p3(c, s, handled);
+    case 0: break;
+    default: return NXSIG_OK;
+  }
+  switch (s.K) {
+#define X(KK, A, B) case KK: return launch_rab_c64<A, B>(c, s, handled);
     NXSIG_RAB_PART0(X)
 #undef X
     default: return NXSIG_OK;

@@ -21,4 +21,13 @@ int launch_istft_rab_p3(Ctx* c, const IstftLaunch& s, const float* window_host, 
   }
 }
 
+int launch_stft_rab_c64_p3(Ctx* c, const StftLaunch& s, bool* handled) {
+  switch (s.K) {
+#define X(KK, A, B) case KK: return launch_rab_c64<A, B>(c, s, handled);
+    NXSIG_RAB_PART3(X)
+#undef X
+    default: return NXSIG_OK;
+  }
+}
+
 }  // namespace nxsig

@@ -428,6 +428,191 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   return NXSIG_OK;
 }
 
+// ============================================================================================ STFT of COMPLEX samples, fft_length = A x B
+// NxSignal.stft/3 on a c64 signal (lib/nx_signal.ex:94-102: the same slices x window -> Nx.fft(length: K), one complex frame per
+// transform, nothing to untangle): the two-pass transform of k_stft_rab with ONE frame per max(A, B)-lane group, T frames per wave
+// iteration.  The unit's c64 span is staged in LDS (8-byte loads), pass A multiplies by the real window, the natural-order result leaves
+// with 16-byte stores after Nx.fft's clean-up and the scaling.  Frames are independent, so a non-finite sample needs no special route.
+struct RabCArgs {
+  const v2f* x;            // c64[batch][...], rows batch_stride cells apart
+  int64_t batch_stride, L, lo, M;
+  int32_t N, hop, reflect, batch;
+  const float* wtab;       // f32[K], zero beyond N
+  const v2f* tw;           // c64[A][B]: W_K^(n2 k1) at [k1 * B + n2]
+  float div;
+  int32_t has_scale;
+  v2f* z;                  // c64[batch][M][K]
+  int64_t units_per_row, total_units, chunk;   // a unit = T frames
+};
+
+__device__ __forceinline__ v2f fetch_any_c64(const v2f* __restrict__ x, const RabCArgs& a, int64_t q) {
+  int64_t pos = q - a.lo;
+  if (a.reflect) {
+    if (a.L == 1) return x[0];
+    const int64_t period = 2 * (a.L - 1);
+    if (pos < 0) pos = -pos;
+    if (pos >= a.L) pos = period - pos;
+    if (pos < 0 || pos >= a.L) {
+      pos %= period;
+      if (pos < 0) pos += period;
+      if (pos >= a.L) pos = period - pos;
+    }
+    return x[pos];
+  }
+  return (pos >= 0 && pos < a.L) ? x[pos] : v2f{0.f, 0.f};
+}
+
+template <int A, int B, bool SCALE, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_stft_rab_c64(RabCArgs a) {
+  constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT;
+  constexpr int TRS = A * (B + 1);
+  constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
+  float* s_w = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
+  v2f* s_x = s_tw + KB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = a.tw[i]; }
+  __syncthreads();
+  v2f* buf = s_x + wave * BUF;
+  const int g = lane / LT, l = lane % LT;
+  const int nuse = a.N < KB ? a.N : KB;
+  const int span = (T - 1) * a.hop + nuse;   // cells
+  const int64_t p_begin = (int64_t)blockIdx.x * a.chunk;
+  int64_t p_end = p_begin + a.chunk;
+  if (p_end > a.total_units) p_end = a.total_units;
+  int64_t row = (p_begin + wave) / a.units_per_row;
+  int64_t u = (p_begin + wave) - row * a.units_per_row;
+  for (int64_t ui = p_begin + wave; ui < p_end; ui += W) {
+    const v2f* xr = a.x + (size_t)row * a.batch_stride;
+    const int64_t q0 = (int64_t)T * u * a.hop;          // padded-signal index of the unit's first sample
+    const int64_t start = q0 - a.lo;
+    // ---- the unit's samples -> LDS, eight loads in flight per lane
+    const bool inside = start >= 0 && start + span <= a.L;   // wave-uniform
+    for (int i0 = lane; i0 < span; i0 += 512) {
+      v2f t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = i0 + 64 * k;
+        t[k] = i < span ? (inside ? xr[start + i] : fetch_any_c64(xr, a, q0 + i)) : v2f{0.f, 0.f};
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + 64 * k < span) buf[i0 + 64 * k] = t[k];
+    }
+    wave_lds_fence();
+    const int64_t m = (int64_t)T * u + g;
+    const bool active = g < T && m < a.M;
+    v2f v[NV];
+    {
+      const v2f* fa = buf + (g < T ? g : 0) * a.hop + l;
+      const bool on = active && l < B;
+      auto fill = [&](auto short_window) {
+        constexpr bool SHORT = decltype(short_window)::value;
+#pragma unroll
+        for (int n1 = 0; n1 < A; ++n1) {
+          const int n = B * n1 + l;
+          const bool in = on && (!SHORT || n < nuse);
+          const float w = s_w[n];
+          const v2f t = fa[B * n1];
+          v[n1] = in ? v2f{t.x * w, t.y * w} : v2f{0.f, 0.f};   // (selected, never multiplied by zero: Inf x 0 would be NaN)
+        }
+      };
+      if (nuse == KB) fill(std::false_type{}); else fill(std::true_type{});
+    }
+    dft_n<A>(v);
+    if (l < B) {
+#pragma unroll
+      for (int k1 = 1; k1 < A; ++k1) {
+        v[k1] = wcmul(v[k1], s_tw[k1 * B + l]);
+        if (A > 16 && (k1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    wave_lds_fence();
+    if (g < T && l < B) {
+#pragma unroll
+      for (int k1 = 0; k1 < A; ++k1) buf[g * TRS + k1 * (B + 1) + l] = v[k1];
+    }
+    wave_lds_fence();
+    if (g < T && l < A) {
+#pragma unroll
+      for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[g * TRS + l * (B + 1) + n2];
+    }
+    dft_n<B>(v);
+    wave_lds_fence();
+    if (g < T && l < A) {
+#pragma unroll
+      for (int k2 = 0; k2 < B; ++k2) buf[g * KB + l + A * k2] = v[k2];   // X[k1 + A k2] in natural order
+    }
+    wave_lds_fence();
+    // ---- clean-up (:102), scaling, 16-byte stores: all 64 lanes walk the T frames one after the other
+    constexpr int NI = (KB / 2 + 63) / 64;
+#pragma unroll
+    for (int gg = 0; gg < T; ++gg) {
+      const int64_t mm = (int64_t)T * u + gg;
+      if (mm < a.M) {   // wave-uniform
+        const v2f* U = buf + gg * KB;
+        v2f* zr = a.z + ((size_t)row * a.M + mm) * KB;
+#pragma unroll 2
+        for (int i = 0; i < NI; ++i) {
+          const int k = 2 * (lane + 64 * i);
+          if (k < KB) {
+            v4f xv = fft_eps0(*reinterpret_cast<const v4f*>(&U[k]));
+            if (SCALE) xv = xv / a.div;
+            __builtin_nontemporal_store(xv, (gv4f*)(zr + k));
+          }
+        }
+      }
+    }
+    wave_lds_fence();
+    u += W;
+    while (u >= a.units_per_row) { u -= a.units_per_row; ++row; }
+  }
+}
+
+template <int A, int B>
+inline int launch_rab_c64(Ctx* c, const StftLaunch& s, bool* handled) {
+  constexpr int W = 4, KB = A * B, LT = A > B ? A : B, T = 64 / LT;
+  constexpr int TRS = A * (B + 1);
+  constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
+  if ((int64_t)(T - 1) * s.fr.hop + KB + LT > BUF) return NXSIG_OK;   // the unit's span (idle lanes' reads included) must fit the wave's buffer
+  if ((reinterpret_cast<uintptr_t>(s.z) & 15) != 0) return NXSIG_OK;
+  *handled = true;
+  RabCArgs a;
+  a.x = reinterpret_cast<const v2f*>(s.x); a.batch_stride = s.batch_stride; a.L = s.fr.L; a.lo = s.fr.lo; a.M = s.fr.M;
+  a.N = s.fr.N; a.hop = s.fr.hop; a.reflect = s.fr.reflect; a.batch = s.batch;
+  a.wtab = s.window_padK; a.div = s.inv_scale_div; a.has_scale = s.has_scale; a.z = reinterpret_cast<v2f*>(s.z);
+  a.units_per_row = (s.fr.M + T - 1) / T;
+  a.total_units = a.units_per_row * s.batch;
+  const uint64_t key = 0x2AB000000000ull ^ ((uint64_t)A << 16) ^ (uint64_t)B;
+  auto hit = c->memo.find(key);
+  if (hit != c->memo.end()) a.tw = reinterpret_cast<const v2f*>(hit->second[0]);
+  else {
+    std::vector<float2> tw((size_t)KB);
+    for (int n2 = 0; n2 < B; ++n2)
+      for (int k1 = 0; k1 < A; ++k1) {
+        const double ang = -6.283185307179586476925286766559 * (double)(n2 * k1) / (double)KB;
+        tw[(size_t)k1 * B + n2] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      }
+    const void* dt = nullptr;
+    int rc = ctx_table(c, 0x2AB0ull ^ ((uint64_t)A << 16) ^ (uint64_t)B, tw.data(), tw.size() * sizeof(float2), &dt);
+    if (rc) return rc;
+    c->memo[key] = {reinterpret_cast<uint64_t>(dt)};
+    a.tw = reinterpret_cast<const v2f*>(dt);
+  }
+  a.chunk = (int64_t)W * 4;
+  const int64_t blocks = (a.total_units + a.chunk - 1) / a.chunk;
+  if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
+  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)W * BUF * 8;
+  auto go = [&](auto kernel) -> int {
+    if (lds > 64 * 1024)
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+    NXSIG_HIP_TRY(hipGetLastError());
+    return NXSIG_OK;
+  };
+  return s.has_scale ? go(k_stft_rab_c64<A, B, true, W>) : go(k_stft_rab_c64<A, B, false, W>);
+}
+
 // ============================================================================================ iSTFT, N = fft_length = A x B
 // NxSignal.istft/3 (lib/nx_signal.ex:609-637) for 320 / 480 / 640 / 960-point frames, any even hop: k_istft_r20's scheme with the two
 // factors free.  The same two-pass transform in inverse direction (IDFT(z) = conj(DFT(conj z)) / K: the conjugations ride on the LDS

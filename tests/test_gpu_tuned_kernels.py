@@ -750,3 +750,35 @@ def test_fir_rows_that_do_not_start_on_a_cache_line(taps, mode):
     cm = {"full": S._lib.CONV_FULL, "same": S._lib.CONV_SAME, "valid": S._lib.CONV_VALID}[mode]
     S._lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(xd.ptr), L, rows, stride, h.ctypes.data_as(C.c_void_p), taps, cm, C.c_void_p(yd.ptr), S._lib.DEVICE))
     assert float(np.max(np.abs(yd.numpy() - ref)) / np.max(np.abs(ref))) < 1e-5
+
+
+@pytest.mark.parametrize("K", RAB_LENGTHS + [128, 256, 512, 1024])
+def test_stft_of_complex_samples_on_the_two_pass_kernels(K):
+    """k_stft_rab_c64 (round 5): c64 signals, one complex frame per transform, every composite length and the power-of-two lengths to 1024
+    — against the oracle for N == K, a shorter frame, :reflect padding, every scaling, a ragged frame count; a NaN stays in its frames;
+    NXSIG_DISABLE_RAB (two-step path / framed row kernels) agrees"""
+    import nx_signal_amd as S
+    from oracle import nx_oracle as O
+
+    rng = np.random.default_rng(K + 5)
+    hop = K // 4
+    for N, pad, L in ((K, "valid", 9 * K + 7), (K - K // 4, "reflect", 5 * K + 3), (K, "reflect", 6 * K)):
+        x = (rng.standard_normal((3, L)) + 1j * rng.standard_normal((3, L))).astype(np.complex64)
+        w = S.windows.hamming(N)
+        for scaling in (None, "spectrum", "psd"):
+            opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=16000)
+            z = S.stft(x, w, **opts)[0]
+            zo = O.stft(x, w, **opts)[0]
+            assert z.shape == zo.shape and float(np.max(np.abs(z - zo)) / np.max(np.abs(zo))) < 1e-5, (K, N, pad, scaling)
+    ctx = S.Context(0)
+    opts = dict(overlap_length=K - hop, fft_length=K, sampling_rate=16000)
+    w = S.windows.hann(K)
+    x = (rng.standard_normal((2, 8 * K)) + 1j * rng.standard_normal((2, 8 * K))).astype(np.complex64)
+    x[1, 3 * K + 5] = np.nan
+    z = S.stft(ctx.to_device(x), w, ctx=ctx, **opts)[0].numpy()
+    zo = O.stft(x, w, **opts)[0]
+    assert np.array_equal(np.isfinite(z).all(axis=-1), np.isfinite(zo).all(axis=-1))
+    ctx.set_tuning("NXSIG_DISABLE_RAB", 1)
+    zb = S.stft(ctx.to_device(x), w, ctx=ctx, **opts)[0].numpy()
+    ok = np.isfinite(zo)
+    assert float(np.max(np.abs(z[ok] - zb[ok])) / np.max(np.abs(zo[ok]))) < 1e-5

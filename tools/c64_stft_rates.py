@@ -1,5 +1,5 @@
 """Rates of the complex-sample stft (nxsig_stft_c64) per frame length (tools only).  Round 5: N = 1024 / 2048 / 4096 on the framed row kernels
-0.25 / 0.12 / 0.15 -> 0.38 / 0.28 / 0.25 of the roofline (interior frames load without per-element bounds and mirror math); other lengths two-step, 0.05-0.17."""
+0.25 / 0.12 / 0.15 -> 0.38 / 0.28 / 0.25 of the roofline (interior frames load without per-element bounds and mirror math); the two-pass A x B kernels (k_stft_rab_c64) for 100 ... 1600: 0.33-0.55 (two-step before: 0.05-0.17)."""
 import sys, os, ctypes as C, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nx_signal_amd as S

@@ -1545,7 +1545,9 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
   // taps ran on the bounds-checked kernel throughout: 0.19-0.26 of the roofline against 0.45-0.51 for 449 / 513 / 769)
   int lead = 0;
   if (K == 2048 && tune(c, kT_FIR_PAD_TAPS, 1)) {
-    lead = (int)((4 - s_in.out_start % 4) % 4);
+    // (x itself may start off a 16-byte boundary — a sliced tensor: its offset joins the slice offset)
+    const int64_t xoff = (int64_t)((reinterpret_cast<uintptr_t>(s_in.x) >> 2) & 3);
+    lead = (int)((4 - (s_in.out_start + xoff) % 4) % 4);
     const int q0 = R2K ? 256 : 128;
     if (((s_in.taps + lead - 1 + q0 - 1) / q0) * q0 + 1 > K / 2 + 1) lead = 0;
   }

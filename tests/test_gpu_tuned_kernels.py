@@ -782,3 +782,24 @@ def test_stft_of_complex_samples_on_the_two_pass_kernels(K):
     zb = S.stft(ctx.to_device(x), w, ctx=ctx, **opts)[0].numpy()
     ok = np.isfinite(zo)
     assert float(np.max(np.abs(z[ok] - zb[ok])) / np.max(np.abs(zo[ok]))) < 1e-5
+
+
+@pytest.mark.parametrize("taps", [257, 512, 513, 1000])
+@pytest.mark.parametrize("off", [1, 2, 3])
+def test_fir_of_a_tensor_sliced_at_an_odd_sample(taps, off):
+    """x starts `off` floats into its allocation: the leading-zero-tap shift of the 2048-point blocks takes the offset into account, the
+    1024-point blocks fall to the 4-byte kernel; results against the direct f64 convolution"""
+    import ctypes as C
+    import nx_signal_amd as S
+
+    rng = np.random.default_rng(taps + off)
+    rows, L = 3, 50000
+    x = rng.standard_normal((rows, L)).astype(np.float32)
+    h = (rng.standard_normal(taps) / taps ** 0.5).astype(np.float32)
+    ref = np.stack([np.convolve(r.astype(np.float64), h.astype(np.float64), mode="same") for r in x])
+    ctx = S.Context(0)
+    flat = ctx.to_device(np.concatenate([np.zeros(off, np.float32), x.reshape(-1)]))
+    yd = ctx.empty((rows, L), np.float32)
+    lib = S._lib.load()
+    S._lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(flat.ptr + 4 * off), L, rows, L, h.ctypes.data_as(C.c_void_p), taps, S._lib.CONV_SAME, C.c_void_p(yd.ptr), S._lib.DEVICE))
+    assert float(np.max(np.abs(yd.numpy() - ref)) / np.max(np.abs(ref))) < 1e-5

@@ -176,7 +176,23 @@ int launch_stft_wave(Ctx* c, const StftLaunch& a, bool* handled);
 int launch_istft_wave(Ctx* c, const IstftLaunch& a, const float* window_host, bool* handled);
 int launch_fir_wave(Ctx* c, const FirLaunch& a, bool* handled);
 
+// More rows than one launch takes (the bounds-checked and generic kernels put the row on gridDim.y, <= 65 535) run as slabs of 65 504
+// rows — a multiple of 32, so that every slab's rows keep the first slab's alignment (FirWaveArgs::row_mod).  Rows are independent in
+// stft / istft / fir; the sinks whose result depends on the whole tensor (log-mel, dBFS) keep the 65 535-row limit.
+static constexpr int32_t kSlabRows = 65504;
+
 int launch_stft(Ctx* c, const StftLaunch& a) {
+  if (a.batch > kSlabRows) {
+    for (int32_t r0 = 0; r0 < a.batch; r0 += kSlabRows) {
+      StftLaunch b = a;
+      b.batch = a.batch - r0 < kSlabRows ? a.batch - r0 : kSlabRows;
+      b.x = a.x + (size_t)r0 * a.batch_stride;
+      b.z = a.z + (size_t)r0 * a.fr.M * a.K;
+      int rc = launch_stft(c, b);
+      if (rc) return rc;
+    }
+    return NXSIG_OK;
+  }
   bool handled = false;
   int rc = launch_stft_wave(c, a, &handled);
   if (rc || handled) return rc;
@@ -184,6 +200,18 @@ int launch_stft(Ctx* c, const StftLaunch& a) {
 }
 int launch_istft_packed_wave(Ctx* c, const IstftLaunch& a, const float* window_host, bool* handled);
 int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
+  if (a.batch > kSlabRows && !a.onesided) {
+    const int64_t out_len = a.M * a.hop + (a.N - a.hop);
+    for (int32_t r0 = 0; r0 < a.batch; r0 += kSlabRows) {
+      IstftLaunch b = a;
+      b.batch = a.batch - r0 < kSlabRows ? a.batch - r0 : kSlabRows;
+      b.z = a.z + (size_t)r0 * a.M * a.K;
+      b.y = a.y + (size_t)r0 * out_len;
+      int rc2 = launch_istft(c, b, window_host);
+      if (rc2) return rc2;
+    }
+    return NXSIG_OK;
+  }
   bool handled = false;
   int rc;
   if (a.onesided) {  // packed half spectrum in, real signal out (nxsig_istft_packed_f32)
@@ -310,6 +338,17 @@ static int launch_fir_partitioned(Ctx* c, const FirLaunch& a_in) {
 
 int launch_fir(Ctx* c, const FirLaunch& a_in) {
   if (a_in.out_len <= 0 || a_in.batch == 0) return NXSIG_OK;
+  if (a_in.batch > kSlabRows) {
+    for (int32_t r0 = 0; r0 < a_in.batch; r0 += kSlabRows) {
+      FirLaunch b = a_in;
+      b.batch = a_in.batch - r0 < kSlabRows ? a_in.batch - r0 : kSlabRows;
+      b.x = a_in.x + (size_t)r0 * a_in.batch_stride;
+      b.y = a_in.y + (size_t)r0 * a_in.out_len;
+      int rc = launch_fir(c, b);
+      if (rc) return rc;
+    }
+    return NXSIG_OK;
+  }
   if (a_in.taps > 32768) return launch_fir_long(c, a_in);   // one transform per row, like the reference: non-finite rows come out NaN
   if (a_in.taps > 1025 && !tune(c, kT_DISABLE_WAVE, 0)) return launch_fir_partitioned(c, a_in);
   if (a_in.taps > 4096) return launch_fir_long(c, a_in);
@@ -863,7 +902,7 @@ int nxsig_stft_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch
   if (!x || !window || !p || !z) return set_error(NXSIG_ERR_INVALID_ARG, "stft: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
-  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch must be in [1, 65535]");
+  if (batch < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch must be >= 1");   // (more than 65 504 rows: slabs, see launch_stft)
   if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch_stride < length");
   if (p->fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft: fft_length must be >= 1");
   rc = check_scaling(p->scaling);
@@ -939,7 +978,8 @@ static int istft_common(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, 
   if (!z || !window || !p || !y) return set_error(NXSIG_ERR_INVALID_ARG, "istft: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
-  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "istft: batch must be in [1, 65535]");
+  if (batch < 1 || (batch > 65535 && (onesided || h)))
+    return set_error(NXSIG_ERR_INVALID_ARG, "istft: batch must be >= 1 (and <= 65535 for the packed and the filtered forms)");
   if (num_frames < 1) return set_error(NXSIG_ERR_INVALID_ARG, "istft: num_frames must be >= 1");
   rc = check_scaling(p->scaling);
   if (rc) return rc;
@@ -1084,7 +1124,7 @@ static int fir_common(nxsig_ctx* ctx, const float* x, int64_t length, int32_t ba
   if (!x || !h || !y) return set_error(NXSIG_ERR_INVALID_ARG, "fir: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
-  if (batch < 1 || batch > 65535 || length < 1 || num_taps < 1)
+  if (batch < 1 || length < 1 || num_taps < 1)   // (more than 65 504 rows: slabs, see launch_fir)
     return set_error(NXSIG_ERR_INVALID_ARG, "fir: batch, length and num_taps must be >= 1");
   if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "fir: batch_stride < length");
   if (start < 0 || out_len < 1 || start + out_len > length + num_taps - 1)

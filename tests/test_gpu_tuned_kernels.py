@@ -803,3 +803,29 @@ def test_fir_of_a_tensor_sliced_at_an_odd_sample(taps, off):
     lib = S._lib.load()
     S._lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(flat.ptr + 4 * off), L, rows, L, h.ctypes.data_as(C.c_void_p), taps, S._lib.CONV_SAME, C.c_void_p(yd.ptr), S._lib.DEVICE))
     assert float(np.max(np.abs(yd.numpy() - ref)) / np.max(np.abs(ref))) < 1e-5
+
+
+def test_more_rows_than_one_launch_takes():
+    """stft / istft / fir of more than 65 535 rows run as slabs of 65 504 rows (api.cpp launch_stft / launch_istft / launch_fir): every
+    row equals the same row computed alone"""
+    import nx_signal_amd as S
+
+    rng = np.random.default_rng(77)
+    rows, L, N, hop = 70000, 700, 256, 64
+    x = rng.standard_normal((rows, L)).astype(np.float32)
+    w = S.windows.hann(N)
+    opts = dict(overlap_length=N - hop, fft_length=N, sampling_rate=16000)
+    ctx = S.Context(0)
+    xd = ctx.to_device(x)
+    z = S.stft(xd, w, ctx=ctx, **opts)[0]
+    zh = z.numpy()
+    pick = [0, 1, 65503, 65504, 65505, 65535, 65536, rows - 1]
+    zs = S.stft(ctx.to_device(np.ascontiguousarray(x[pick])), w, ctx=ctx, **opts)[0].numpy()
+    assert np.array_equal(zh[pick].view(np.uint32), zs.view(np.uint32))
+    y = S.istft(z, w, ctx=ctx, **opts).numpy()
+    ys = S.istft(ctx.to_device(np.ascontiguousarray(zh[pick])), w, ctx=ctx, **opts).numpy()
+    assert np.array_equal(y[pick].view(np.uint32), ys.view(np.uint32))
+    h = S.filters.firwin(65, [0.2])
+    f = S.filters.fir(xd, h, mode="same", ctx=ctx).numpy()
+    fs = S.filters.fir(ctx.to_device(np.ascontiguousarray(x[pick])), h, mode="same", ctx=ctx).numpy()
+    assert float(np.max(np.abs(f[pick] - fs))) < 1e-6

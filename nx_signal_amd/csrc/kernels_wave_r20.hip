@@ -262,7 +262,9 @@ __global__ __launch_bounds__(64 * W) void k_stft_r20(R20Args b) {
         }
       wave_lds_fence();
       // sparse filterbank + log10: one band per lane, the unit's six frames share every weight (six independent sums)
-      for (int mb = lane; mb < b.mel_bins; mb += 64) {
+      const int rot = b.mel_bins & 63;   // the partial pass takes the narrowest bands (see stft_wave_body, wave_stft.hpp)
+      for (int mb0 = lane; mb0 < b.mel_bins; mb0 += 64) {
+        const int mb = mb0 + rot < b.mel_bins ? mb0 + rot : mb0 + rot - b.mel_bins;
         const int o0 = s_off[mb], o1 = s_off[mb + 1], k0 = s_lo[mb];
         float acc[6];
 #pragma unroll

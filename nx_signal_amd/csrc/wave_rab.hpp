@@ -292,7 +292,9 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
         }
       wave_lds_fence();
       // sparse filterbank + log10: one band per lane, the unit's 2 T frames share every weight
-      for (int mb = lane; mb < b.mel_bins; mb += 64) {
+      const int rot = b.mel_bins & 63;   // the partial pass takes the narrowest bands (see stft_wave_body, wave_stft.hpp)
+      for (int mb0 = lane; mb0 < b.mel_bins; mb0 += 64) {
+        const int mb = mb0 + rot < b.mel_bins ? mb0 + rot : mb0 + rot - b.mel_bins;
         const int o0 = s_off[mb], o1 = s_off[mb + 1], k0 = s_lo[mb];
         float acc[2 * T];
 #pragma unroll

@@ -533,7 +533,11 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
     wave_lds_fence();
     // ---- sparse filterbank + log10
     float* o0p = mp->out + ((size_t)crow * a.M + mA) * mp->mel_bins;
-    for (int b = lane; b < mp->mel_bins; b += 64) {
+    // the partial pass (mel_bins mod 64 lanes) takes the NARROWEST bands 0 .. rot - 1, the full passes the rest: a wave instruction
+    // costs its widest lane, and with 80 bands the partial pass otherwise holds the 16 widest ones
+    const int rot = mp->mel_bins & 63;
+    for (int b0 = lane; b0 < mp->mel_bins; b0 += 64) {
+      const int b = b0 + rot < mp->mel_bins ? b0 + rot : b0 + rot - mp->mel_bins;
       const int o0 = s_off[b], o1 = s_off[b + 1], k0 = s_lo[b];
       float acc[FPU];
 #pragma unroll
@@ -1196,7 +1200,9 @@ __global__ __launch_bounds__(64 * W) void k_stft_blue_wave(BlueWaveArgs b) {
     if (MEL) {
       wave_lds_fence();
       float* o0p = b.out + ((size_t)row * a.M + mA) * b.mel_bins;
-      for (int mb = lane; mb < b.mel_bins; mb += 64) {
+      const int rot = b.mel_bins & 63;   // the partial pass takes the narrowest bands (see stft_wave_body)
+      for (int mb0 = lane; mb0 < b.mel_bins; mb0 += 64) {
+        const int mb = mb0 + rot < b.mel_bins ? mb0 + rot : mb0 + rot - b.mel_bins;
         const int o0 = s_off[mb], o1 = s_off[mb + 1], k0 = s_lo[mb];
         float accA = 0.0f, accB = 0.0f;
         for (int j = o0; j < o1; ++j) {

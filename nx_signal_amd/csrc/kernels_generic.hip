@@ -659,6 +659,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(SP >= 
       }
     }
     // position gg <-> inner sum with index gg (after the rotation above) = x[rev(gg)]; outer products with w_N^(j lane), j = j0 + gg, in place
+    if (SP >= 16) __builtin_amdgcn_sched_barrier(0);
     {
       int tix = (int)((uint32_t)((int)(((j0 % N) + N) % N) * lane) % (uint32_t)N);   // (j0 lane) mod N, then + lane per position (lane < N)
 #pragma unroll
@@ -671,6 +672,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(SP >= 
         x[rv] = make_double2(xv.x * t.x - xv.y * t.y, xv.x * t.y + xv.y * t.x);
         tix += lane;
         if (tix >= N) tix -= N;
+        if (SP >= 16 && (gg & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // eight table gathers in flight, not SP (registers)
       }
     }
     // butterfly reduction on the bit-reversed storage: step q folds position bit LOG - 1 - q = storage bit q (stride 2^q) and lane bit

@@ -213,8 +213,9 @@ __device__ __forceinline__ void dft15(v2f* v) {
 
 template <int N>
 __device__ __forceinline__ void dft_n(v2f* v) {
-  static_assert(N == 8 || N == 10 || N == 12 || N == 15 || N == 16 || N == 20 || N == 24 || N == 25 || N == 30 || N == 32 || N == 40, "no codelet for this length");
-  if constexpr (N == 8) dft8<false>(v);
+  static_assert(N == 4 || N == 8 || N == 10 || N == 12 || N == 15 || N == 16 || N == 20 || N == 24 || N == 25 || N == 30 || N == 32 || N == 40, "no codelet for this length");
+  if constexpr (N == 4) dft4<false>(v[0], v[1], v[2], v[3]);
+  else if constexpr (N == 8) dft8<false>(v);
   else if constexpr (N == 10) dft10(v);
   else if constexpr (N == 12) dft12(v);
   else if constexpr (N == 15) dft15(v);

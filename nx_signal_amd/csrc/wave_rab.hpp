@@ -21,7 +21,7 @@
 
 // (K, A, B) of every native composite length, one list per translation unit.  K % 4 == 0 (bin pairs of the one-sided sinks).
 #define NXSIG_RAB_PART0(X) X(320, 16, 20) X(480, 24, 20) X(640, 32, 20) X(960, 32, 30)
-#define NXSIG_RAB_PART1(X) X(64, 8, 8) X(100, 10, 10) X(120, 12, 10) X(160, 16, 10) X(200, 20, 10) X(240, 16, 15) X(300, 20, 15) X(360, 24, 15) X(384, 24, 16)
+#define NXSIG_RAB_PART1(X) X(32, 8, 4) X(64, 8, 8) X(100, 10, 10) X(120, 12, 10) X(160, 16, 10) X(200, 20, 10) X(240, 16, 15) X(300, 20, 15) X(360, 24, 15) X(384, 24, 16)
 #define NXSIG_RAB_PART2(X) X(500, 25, 20) X(600, 30, 20) X(720, 30, 24) X(768, 32, 24) X(800, 32, 25) X(900, 30, 30)
 #define NXSIG_RAB_PART3(X) X(1000, 40, 25) X(1200, 40, 30) X(1280, 40, 32) X(1600, 40, 40)
 // inverse only: power-of-two frame lengths with a hop the N / hop in {1, 2, 4, 8} kernels of kernels_wave.hip do not take (e.g. 512 / 160)

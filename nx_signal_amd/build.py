@@ -36,6 +36,7 @@ UNITS = [
     ("kernels_wave_rab_p1.hip", []),  # 100 ... 384
     ("kernels_wave_rab_p2.hip", []),  # 500 ... 900
     ("kernels_wave_rab_p3.hip", []),  # 1000 ... 1600
+    ("kernels_wave_rab_p5.hip", []),  # 192 ... 1920 (12- and 48-point codelets)
     ("kernels_wave_rab_p4.hip", []),  # inverse only: 128 / 256 / 512 / 1024 at any hop
     ("kernels_wave_8k.hip", []),
     ("kernels_wave_rows.hip", []),

@@ -7,16 +7,19 @@ namespace nxsig {
 int launch_stft_rab_p1(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);   // kernels_wave_rab_p1.hip ...
 int launch_stft_rab_p2(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);
 int launch_stft_rab_p3(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);
+int launch_stft_rab_p5(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);
 int launch_istft_rab_p1(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p2(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p3(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
+int launch_istft_rab_p5(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p4(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_stft_rab_c64_p1(Ctx* c, const StftLaunch& s, bool* handled);
 int launch_stft_rab_c64_p2(Ctx* c, const StftLaunch& s, bool* handled);
 int launch_stft_rab_c64_p3(Ctx* c, const StftLaunch& s, bool* handled);
+int launch_stft_rab_c64_p5(Ctx* c, const StftLaunch& s, bool* handled);
 int launch_stft_rab_c64_p4(Ctx* c, const StftLaunch& s, bool* handled);
 
-// 0..3: the list that holds fft length K, -1: none
+// 0..3, 5: the list that holds fft length K, -1: none
 int rab_length_part(int K) {
   switch (K) {
 #define X(KK, A, B) case KK:
@@ -24,6 +27,7 @@ int rab_length_part(int K) {
     NXSIG_RAB_PART1(X) return 1;
     NXSIG_RAB_PART2(X) return 2;
     NXSIG_RAB_PART3(X) return 3;
+    NXSIG_RAB_PART5(X) return 5;
 #undef X
     default: return -1;
   }
@@ -47,6 +51,7 @@ int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
     case 1: return launch_stft_rab_p1(c, s, handled, mel);
     case 2: return launch_stft_rab_p2(c, s, handled, mel);
     case 3: return launch_stft_rab_p3(c, s, handled, mel);
+    case 5: return launch_stft_rab_p5(c, s, handled, mel);
     case 0: break;
     default: return NXSIG_OK;
   }
@@ -68,6 +73,7 @@ int launch_stft_rab_c64(Ctx* c, const StftLaunch& s, bool* handled) {
     case 1: return launch_stft_rab_c64_p1(c, s, handled);
     case 2: return launch_stft_rab_c64_p2(c, s, handled);
     case 3: return launch_stft_rab_c64_p3(c, s, handled);
+    case 5: return launch_stft_rab_c64_p5(c, s, handled);
     case 0: break;
     default: return NXSIG_OK;
   }
@@ -88,6 +94,7 @@ int launch_istft_rab(Ctx* c, const IstftLaunch& s, const float* window_host, boo
     case 1: return launch_istft_rab_p1(c, s, window_host, handled);
     case 2: return launch_istft_rab_p2(c, s, window_host, handled);
     case 3: return launch_istft_rab_p3(c, s, window_host, handled);
+    case 5: return launch_istft_rab_p5(c, s, window_host, handled);
     case 0: break;
     default: return NXSIG_OK;
   }

@@ -211,9 +211,26 @@ __device__ __forceinline__ void dft15(v2f* v) {
   }
 }
 
+// 48-point DFT, prime-factor 3 x 16: n = (16 n1 + 3 n2) mod 48, k = (16 k1 + 33 k2) mod 48
+__device__ __forceinline__ void dft48(v2f* v) {
+  v2f A[3][16];
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) {
+    v2f c0 = v[(3 * n2) % 48], c1 = v[(16 + 3 * n2) % 48], c2 = v[(32 + 3 * n2) % 48];
+    dft3(c0, c1, c2);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    dft16<false>(A[k1]);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) v[(16 * k1 + 33 * k2) % 48] = A[k1][k2];
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void dft_n(v2f* v) {
-  static_assert(N == 4 || N == 8 || N == 10 || N == 12 || N == 15 || N == 16 || N == 20 || N == 24 || N == 25 || N == 30 || N == 32 || N == 40, "no codelet for this length");
+  static_assert(N == 4 || N == 8 || N == 10 || N == 12 || N == 15 || N == 16 || N == 20 || N == 24 || N == 25 || N == 30 || N == 32 || N == 40 || N == 48, "no codelet for this length");
   if constexpr (N == 4) dft4<false>(v[0], v[1], v[2], v[3]);
   else if constexpr (N == 8) dft8<false>(v);
   else if constexpr (N == 10) dft10(v);
@@ -225,7 +242,8 @@ __device__ __forceinline__ void dft_n(v2f* v) {
   else if constexpr (N == 25) dft25(v);
   else if constexpr (N == 30) dft30(v);
   else if constexpr (N == 32) dft32(v);
-  else dft40(v);
+  else if constexpr (N == 40) dft40(v);
+  else dft48(v);
 }
 
 }  // namespace nxsig

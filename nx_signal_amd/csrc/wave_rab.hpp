@@ -24,6 +24,7 @@
 #define NXSIG_RAB_PART1(X) X(32, 8, 4) X(64, 8, 8) X(100, 10, 10) X(120, 12, 10) X(160, 16, 10) X(200, 20, 10) X(240, 16, 15) X(300, 20, 15) X(360, 24, 15) X(384, 24, 16)
 #define NXSIG_RAB_PART2(X) X(500, 25, 20) X(600, 30, 20) X(720, 30, 24) X(768, 32, 24) X(800, 32, 25) X(900, 30, 30)
 #define NXSIG_RAB_PART3(X) X(1000, 40, 25) X(1200, 40, 30) X(1280, 40, 32) X(1600, 40, 40)
+#define NXSIG_RAB_PART5(X) X(192, 16, 12) X(288, 24, 12) X(576, 24, 24) X(1152, 48, 24) X(1440, 48, 30) X(1536, 48, 32) X(1920, 48, 40)
 // inverse only: power-of-two frame lengths with a hop the N / hop in {1, 2, 4, 8} kernels of kernels_wave.hip do not take (e.g. 512 / 160)
 #define NXSIG_RAB_INVERSE_ONLY(X) X(128, 16, 8) X(256, 16, 16) X(512, 32, 16) X(1024, 32, 32)
 
@@ -338,7 +339,7 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   const int nuse = s.fr.N < KB ? s.fr.N : KB;
   const int64_t span = (2 * T - 1) * (int64_t)s.fr.hop + nuse;
-  if (span + 3 > 2560) return NXSIG_OK;   // the unit's span must fit the prefetch registers
+  if (LT < 30 && span + 3 > 2560) return NXSIG_OK;   // the unit's span must fit the prefetch registers (used below 30-point codelets only)
   if ((2 * T - 1) * (int64_t)s.fr.hop + KB + LT > 2 * BUF) return NXSIG_OK;   // ... and every lane's reads (idle lanes included) the wave's buffer
   RabArgs b;
   int sink = kSinkSpectrum;

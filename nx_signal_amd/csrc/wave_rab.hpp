@@ -334,9 +334,11 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   // four waves per workgroup, short-lived workgroups.  (ONE workgroup per CU sized to fill the LDS — 6 ... 12 waves for 720 ... 960, what
   // the persistent inverse kernels gain 40-70 % from — measured 0.46 / 0.59 / 0.55 / 0.50 / 0.56 against 0.52 / 0.56 / 0.55 / 0.50 / 0.60
   // here for 720 / 768 / 800 / 900 / 960: the blocks retire together and the CU idles between them)
-  constexpr int W = 4, WM = 4, KB = A * B, LT = A > B ? A : B, T = 64 / LT;   // WM: the log-mel sink
+  constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT;
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
+  // (1920: four waves would need 87 KB — one workgroup, four waves per CU; eight share the tables in 150 KB)
+  constexpr int W = (KB * 12 + 4 * BUF * 8 > 80 * 1024) ? 8 : 4, WM = W;   // WM: the log-mel sink
   const int nuse = s.fr.N < KB ? s.fr.N : KB;
   const int64_t span = (2 * T - 1) * (int64_t)s.fr.hop + nuse;
   if (LT < 30 && span + 3 > 2560) return NXSIG_OK;   // the unit's span must fit the prefetch registers (used below 30-point codelets only)

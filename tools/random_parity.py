@@ -9,7 +9,7 @@ from oracle import nx_oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-LENGTHS = [64, 100, 120, 128, 160, 200, 240, 256, 300, 320, 360, 384, 400, 480, 500, 512, 600, 640, 720, 768, 800, 900, 960, 1000, 1024, 1200, 1280, 1600, 2048, 333, 441, 48]
+LENGTHS = [32, 192, 288, 576, 1152, 1440, 1536, 1920, 64, 100, 120, 128, 160, 200, 240, 256, 300, 320, 360, 384, 400, 480, 500, 512, 600, 640, 720, 768, 800, 900, 960, 1000, 1024, 1200, 1280, 1600, 2048, 333, 441, 48]
 ctx = S.Context(0)
 t0 = time.time(); n = 0; worst = {}
 def note(kind, err, what):

@@ -1123,6 +1123,12 @@ int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
 int rab_length_part(int K);                                                               // >= 0: a native A x B kernel exists for fft length K
 int launch_stft_wave_8k(Ctx* c, const StftLaunch& s, bool* handled);                      // kernels_wave_8k.hip
 
+#ifdef NXSIG_TRACE
+extern "C" int nxsig_diag_set_trace(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_trace), &p, sizeof(p));
+}
+#endif
+
 int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   *handled = false;
   if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
@@ -1130,7 +1136,29 @@ int launch_stft_wave(Ctx* c, const StftLaunch& s, bool* handled) {
   if (s.window_padK == nullptr) return NXSIG_OK;
   // 4 waves per workgroup everywhere: 8 / 12 / 16 measured equal or slower (tables are re-read from L2 either way)
   switch (s.K) {
-    case 1024: *handled = true; return launch_wave<1024, kModePair, 4>(c, s);      // two frames per 1024-point complex FFT
+    case 1024: {                                                                   // two frames per 1024-point complex FFT
+      *handled = true;
+      // ONE-ROUND geometry (round 6): a launch whose workgroups all fit on the chip at once (BASELINE config 1, and config 2 as
+      // written: one 60 s stream = 5 624 frame pairs) is one round of start-up latencies; 4-wave workgroups of 12 pairs land 2 + 2 +
+      // ... + 1 on the CUs (469 on 256) and a 1 s stream fills 24 of them.  Here ONE 12-wave workgroup per CU (120 KB of LDS exclude
+      // a second one; the dispatcher places them one per CU, tools/wg_census.hip) on 11/16 of the CUs, the chunk a multiple of four
+      // pairs: measured optimum of interleaved sweeps over chunk sizes and stream lengths (tools/sweep_small.py,
+      // profiles/r06/one_round_geometry.txt): 1 s ... 30 s streams 2.2 ... 1.2 x the many-round geometry, 60 s +1 ... 7 %
+      // (box-dependent).  NXSIG_WAVE_SMALL_W=0 keeps the old geometry, NXSIG_WAVE_SMALL_CHUNK forces a chunk.
+      const int64_t pairs = (int64_t)s.batch * ((s.fr.M + 1) / 2);
+      int64_t chunk = tune(c, kT_WAVE_SMALL_CHUNK, 0);
+      const bool forced = chunk > 0;
+      if (tune(c, kT_WAVE_SMALL_W, 12) >= 12 && (forced || pairs <= (int64_t)c->num_cus * 24)) {
+        if (!forced) {
+          const int64_t wgs = ((int64_t)c->num_cus * 11) / 16;
+          chunk = (pairs + wgs - 1) / wgs;
+          if (chunk >= 16) chunk = (chunk + 3) & ~(int64_t)3;
+        }
+        return launch_wave<1024, kModePair, 12>(c, s, nullptr, chunk);
+      }
+      if (forced && pairs <= (int64_t)c->num_cus * 24) return launch_wave<1024, kModePair, 4>(c, s, nullptr, chunk);
+      return launch_wave<1024, kModePair, 4>(c, s);
+    }
     case 512: *handled = true; return launch_wave<1024, kModeQuad, 4, 2>(c, s);    // 4 frames interleaved into one transform
     case 256: *handled = true; return launch_wave<1024, kModeQuad, 4, 4>(c, s);    // 8 frames
     case 128: *handled = true; return launch_wave<1024, kModeQuad, 4, 8>(c, s);    // 16 frames

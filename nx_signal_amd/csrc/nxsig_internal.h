@@ -70,7 +70,7 @@ int make_framing(int64_t L, int32_t N, int32_t hop, int32_t pad_mode, int64_t pa
 #define NXSIG_TUNABLES(X)                                                                                                      \
   X(DISABLE_WAVE) X(DISABLE_WAVE_ROWS) X(DISABLE_BLUE_WAVE) X(DISABLE_R20) X(DISABLE_RAB) X(DISABLE_8K) X(DISABLE_4K) X(DISABLE_FUSED_FILTER) \
   X(ISTFT_DEEP) X(ISTFT_HALF_DEEP) X(ISTFT_RUNS_PER_CU) X(ISTFT_MIN_RUN) X(ISTFT_REGOLA)                                                    \
-  X(STORE_POLICY) X(WAVE_NO_SPLIT) X(NO_AL8) X(NO_STAGE) X(WAVE_UNITS_PER_WAVE) X(STAGE_PAD)                                              \
+  X(STORE_POLICY) X(WAVE_NO_SPLIT) X(NO_AL8) X(NO_STAGE) X(WAVE_UNITS_PER_WAVE) X(STAGE_PAD) X(WAVE_SMALL_W) X(WAVE_SMALL_CHUNK) \
   X(FIR32) X(FIR_PAD_TAPS) X(FIR_PHASE) X(FIR_HREG) X(FIR_UNITS_PER_WAVE) X(FIR_R2K)                                                      \
   X(MEL_TILE) X(MEL_LDS_KB) X(FFT_TILED) X(FFT_TILE_ELEMS) X(FFT_TILE_NT) X(FFT_COLUMNS) X(FFT_TILED_MIN) X(CONV_POW2)          \
   X(DIRECT_FAST) X(POOL_MAX_MB) X(NO_PREFAULT)

@@ -421,6 +421,9 @@ __device__ __forceinline__ float fetch_any(const float* __restrict__ x, const Wa
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_wave_smem[];
+#ifdef NXSIG_TRACE   // diagnostic builds only (tools/trace_small.py): per-wave time stamps of the pair-mode kernel's phases
+static __device__ unsigned long long* g_wave_trace = nullptr;
+#endif
 
 typedef __attribute__((address_space(1))) v4f gv4f;
 typedef __attribute__((address_space(1))) v2f gv2f;
@@ -492,6 +495,13 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   v2f* s_twR = s_twC + R3 * 256;
   v2f* s_x = s_twR + (MODE == kModeReal2x ? K : (MODE == kModeQuad ? TWQ : 0));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef NXSIG_TRACE
+  unsigned long long* tr = g_wave_trace ? g_wave_trace + ((size_t)blockIdx.x * W + wave) * 8 : nullptr;
+  int tri = 0;
+  auto stamp = [&]() { if (tr && lane == 0 && tri < 8) tr[tri] = wall_clock64(); ++tri; };
+#else
+  auto stamp = [] {};
+#endif
   // the tables are staged (and the workgroup's only barrier passed) AFTER the first unit's sample loads have been issued, see
   // below: the two memory round trips of a workgroup's start-up overlap (a short launch is mostly start-up: config 2 as written)
   float* s_csr = reinterpret_cast<float*>(s_x + W * XCH);
@@ -693,9 +703,12 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
   advance(nrow, nuin);
   v2f d[P];  // windowed samples of the current pair: re = frame A, im = frame B (exact f32 products, :101)
   const bool have_first = !GENERAL && p_begin + wave < p_end;
+  stamp();
   stage_tables();
+  stamp();
   if (have_first) issue_loads(row, pinof(uin));
   if (have_first) window_mul(d);
+  stamp();
 
   // ---- Nx.fft's clean-up (SURVEY App. A rule 7; call site lib/nx_signal.ex:102): every component of the finished spectrum
   // with |x| <= eps = 1e-10 becomes +0, BEFORE the :spectrum / :psd division (:113-127).  NaN compares false and stays.
@@ -993,6 +1006,7 @@ __device__ __forceinline__ void stft_wave_body(const WaveArgs& a, const MelWaveA
     }
     row = nrow; uin = nuin;
     advance(nrow, nuin);
+    stamp();
   }
   if (MEL || (MAG && mp->mag_kind == 2)) {  // one atomic per wave: running maximum in ordered-int encoding
 #pragma unroll
@@ -1296,7 +1310,7 @@ struct MelLaunch {
 
 // SINK selects the kernel family this translation unit instantiates (spectrum / log-mel / magnitude: one TU each)
 template <int C, int MODE, int W, int J = 2, int SINK = kSinkSpectrum>
-static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullptr) {
+static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullptr, const int64_t small_chunk = 0) {
   constexpr int R3 = C / 256;
   constexpr int XCH = C + C / 16 + 16;
   constexpr int KOUT = MODE == kModeReal2x ? 2 * C : (MODE == kModeQuad ? C / J : C);
@@ -1377,6 +1391,8 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
   if (MODE == kModePair && !mel && units_per_wave == 2 && !c->tuning.set[kT_WAVE_UNITS_PER_WAVE] &&
       (a.total_pairs + 2 * W - 1) / (2 * W) <= (int64_t)c->num_cus * 3)
     a.chunk = (int64_t)W * 3;
+  // small_chunk > 0 (launch_stft_wave's one-round geometry): the caller sized the chunk so that every CU holds ONE workgroup of W waves
+  if (small_chunk > 0) a.chunk = small_chunk;
   // Interior frames [m_lo, m_hi): every one of the KOUT samples the streaming front-end reads lies inside the signal,
   // whatever the padding mode (window_padding :reflect / :same / explicit only touch the first and last few frames).
   // Interior units go to the branch-free software-pipelined kernel; the edge units to the bounds-checked one.

@@ -35,6 +35,16 @@ defmodule NxSignalAMD do
   end
 
   @doc """
+  Which kernel families did the last compute call on this context launch?  A `"+"`-separated string such as `"stft.pair"`,
+  `"istft.wave.deep+istft.edge_chunks"`, `"fir.pair+fir.pair.edge"` or `"stft.generic.pow2"` (`nxsig_ctx_last_dispatch`,
+  include/nxsig.h).  Diagnostic: a shape that silently leaves the tuned kernels shows up here.
+  """
+  def last_dispatch(ctx \\ context()) do
+    {:ok, families} = NIF.last_dispatch(ctx) |> unwrap!()
+    families
+  end
+
+  @doc """
   See `NxSignal.stft/3`. Returns `{z, times, frequencies}` with `z :: c64[frames: M][frequencies: K]`.
 
   `data` may be an `Nx.Tensor` (vectorized axes = channels, re-applied to `z`) or a `NxSignalAMD.DeviceTensor`

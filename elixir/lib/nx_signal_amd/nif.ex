@@ -13,6 +13,7 @@ defmodule NxSignalAMD.NIF do
   def device_count(), do: :erlang.nif_error(:nif_not_loaded)
   def ctx_create(_device), do: :erlang.nif_error(:nif_not_loaded)
   def sync(_ctx), do: :erlang.nif_error(:nif_not_loaded)
+  def last_dispatch(_ctx), do: :erlang.nif_error(:nif_not_loaded)
   def window(_kind, _n, _periodic, _beta, _eps), do: :erlang.nif_error(:nif_not_loaded)
   def firwin(_taps, _cutoff, _kind, _beta, _pass_zero, _scale, _fs), do: :erlang.nif_error(:nif_not_loaded)
   def fft_frequencies(_fs, _fft_length, _endpoint), do: :erlang.nif_error(:nif_not_loaded)

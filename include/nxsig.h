@@ -106,6 +106,15 @@ int nxsig_ctx_set_tuning(nxsig_ctx* ctx, const char* name, int32_t value);
 int nxsig_ctx_get_tuning(nxsig_ctx* ctx, const char* name, int32_t* value, int32_t* is_set);
 int nxsig_ctx_clear_tuning(nxsig_ctx* ctx, const char* name);
 const char* nxsig_last_error(void); /* thread-local, valid until the next call on this thread */
+/* Which kernel families did the calling thread's LAST compute call (stft / istft / fir / fft / convolve / mel ...) launch?  A
+ * '+'-separated list in launch order, each family once, e.g. "stft.pair", "stft.pair.1r+stft.pair.edge", "istft.wave+istft.edge_chunks",
+ * "fir.pair+fir.poison", "stft.generic".  The names are the kernel families of DESIGN.md section 3; a shape that silently falls from a tuned
+ * kernel to the generic ones shows here (tests/test_gpu_dispatch_table.py pins the family of every documented shape).  Thread-local,
+ * valid until the next compute call on this thread; "" before the first one.  Diagnostic only: nothing in the library reads it. */
+const char* nxsig_last_dispatch(void);
+/* the same record of the last compute call made on THIS CONTEXT by any thread, copied into buf (truncated to buflen - 1 characters): what a
+ * host whose calls hop between threads (the BEAM's dirty schedulers) reads */
+int nxsig_ctx_last_dispatch(nxsig_ctx* ctx, char* buf, size_t buflen);
 /* human readable device line ("AMD Instinct MI355X gfx950 256 CUs") into buf */
 int nxsig_device_name(nxsig_ctx* ctx, char* buf, size_t buflen);
 

@@ -182,6 +182,22 @@ static ERL_NIF_TERM nif_sync(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]
   return rc ? mk_error(env, rc) : mk_atom(env, "ok");
 }
 
+/* last_dispatch(ctx) -> {:ok, binary}: the kernel families of the last compute call on this context ("stft.pair", "istft.wave.deep+
+ * istft.edge_chunks" ...; include/nxsig.h: nxsig_ctx_last_dispatch — the per-context copy, because two NIF calls of one Erlang process
+ * may run on different scheduler threads).  Diagnostic: NxSignalAMD.last_dispatch/1 */
+static ERL_NIF_TERM nif_last_dispatch(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  if (argc != 1 || !get_ctx(env, argv[0], &c)) return enif_make_badarg(env);
+  char buf[512];
+  int rc = nxsig_ctx_last_dispatch(c->ctx, buf, sizeof buf);
+  if (rc) return mk_error(env, rc);
+  ErlNifBinary b;
+  const size_t n = strlen(buf);
+  if (!enif_alloc_binary(n, &b)) return mk_oom(env);
+  memcpy(b.data, buf, n);
+  return mk_ok(env, enif_make_binary(env, &b));
+}
+
 /* ------------------------------------------------------------------------------------------------ host generators */
 /* window(kind, n, periodic, beta, eps) -> {:ok, f32 binary}   (NxSignal.Windows.*, BinaryBackend rounding) */
 static ERL_NIF_TERM nif_window(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
@@ -1442,6 +1458,7 @@ static ErlNifFunc funcs[] = {
     {"device_count", 0, nif_device_count, 0},
     {"ctx_create", 1, nif_ctx_create, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"sync", 1, nif_sync, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"last_dispatch", 1, nif_last_dispatch, ERL_NIF_DIRTY_JOB_IO_BOUND},   /* takes the context mutex: may wait behind a running call */
     {"window", 5, nif_window, 0},
     {"firwin", 7, nif_firwin, 0},
     {"fft_frequencies", 3, nif_fft_frequencies, 0},

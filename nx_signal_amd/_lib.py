@@ -66,6 +66,8 @@ SIGNATURES = {
     "nxsig_ctx_get_tuning": (C.c_int, [_p, C.c_char_p, C.POINTER(_i32), C.POINTER(_i32)]),
     "nxsig_ctx_clear_tuning": (C.c_int, [_p, C.c_char_p]),
     "nxsig_last_error": (C.c_char_p, []),
+    "nxsig_last_dispatch": (C.c_char_p, []),
+    "nxsig_ctx_last_dispatch": (_i32, [_p, C.c_char_p, _sz]),
     "nxsig_device_name": (C.c_int, [_p, C.c_char_p, _sz]),
     "nxsig_alloc": (C.c_int, [_p, _sz, C.POINTER(_p)]),
     "nxsig_free": (C.c_int, [_p, _p]),
@@ -172,6 +174,12 @@ def load() -> C.CDLL:
         raise NxSignalLibraryError("libnxsig.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def last_dispatch() -> str:
+    """Kernel families the calling thread's last compute call launched ('+'-separated, include/nxsig.h: nxsig_last_dispatch)."""
+    msg = load().nxsig_last_dispatch()
+    return msg.decode() if msg else ""
 
 
 def last_error() -> str:

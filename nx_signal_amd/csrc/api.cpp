@@ -27,6 +27,28 @@ int set_error(int code, const std::string& msg) {
 }
 const char* last_error_cstr() { return g_last_error.c_str(); }
 
+static thread_local std::string g_dispatch;
+void dispatch_reset() { g_dispatch.clear(); }
+void dispatch_note(const char* family) {
+  const std::string f(family);
+  size_t at = 0;
+  while ((at = g_dispatch.find(f, at)) != std::string::npos) {   // already noted (as a whole '+'-separated item)?
+    const bool l = at == 0 || g_dispatch[at - 1] == '+', r = at + f.size() == g_dispatch.size() || g_dispatch[at + f.size()] == '+';
+    if (l && r) return;
+    at += f.size();
+  }
+  if (!g_dispatch.empty()) g_dispatch += '+';
+  g_dispatch += f;
+}
+const char* dispatch_cstr() { return g_dispatch.c_str(); }
+// one per compute entry point of the C ABI: resets the calling thread's record, and leaves a copy in the context on the way out (the
+// BEAM's dirty schedulers move between threads from call to call: the NIF reads the context's copy)
+struct DispatchScope {
+  Ctx* c;
+  explicit DispatchScope(Ctx* ctx) : c(ctx) { dispatch_reset(); }
+  ~DispatchScope() { c->last_dispatch = g_dispatch; }
+};
+
 // In-process cache key (never persisted): FNV-1a over the tail bytes, and for the bulk four independent multiply-xor lanes over
 // 8-byte words — a byte-at-a-time FNV costs one dependent multiply per byte, 0.7 ms for the 512 KB mel filterbank that
 // stft_to_mel / mel_spectrogram look up on every call.
@@ -252,6 +274,7 @@ int launch_istft(Ctx* c, const IstftLaunch& a, const float* window_host) {
 // next_pow2(L + taps - 1) points per row, the way the reference's fftconvolve does it (lib/nx_signal/convolution.ex:252-329),
 // through the device-side fft_nd fold (four-step rows up to 2^26 points); the requested slice is copied out of the full result
 static int launch_fir_long(Ctx* c, const FirLaunch& a) {
+  dispatch_note("fir.long");
   const int64_t full = a.L + a.taps - 1;
   if (full > ((int64_t)1 << 26))
     return set_error(NXSIG_ERR_UNSUPPORTED, "fir: more than 4096 taps with length + taps - 1 > 2^26 is not supported");
@@ -282,6 +305,7 @@ int launch_fir_partition_sum(Ctx* c, int n, const float* const* src, const int64
 // (exact: the kernels' threshold then sits at 1e-16 of the true scale, far below what decides a sample of y), the summing pass
 // multiplies by 2^-20 and cleans the finished sums.
 static int launch_fir_partitioned(Ctx* c, const FirLaunch& a_in) {
+  dispatch_note("fir.partitioned");
   FirLaunch a = a_in;
   int rc = fir_row_flags(c, a.batch, &a.row_flags);
   if (rc) return rc;
@@ -538,6 +562,7 @@ extern "C" {
 int nxsig_abi_version(void) { return NXSIG_ABI_VERSION; }
 
 const char* nxsig_last_error(void) { return last_error_cstr(); }
+const char* nxsig_last_dispatch(void) { return dispatch_cstr(); }
 
 int nxsig_device_count(int* count) {
   NXSIG_API_BEGIN
@@ -629,6 +654,15 @@ void nxsig_ctx_destroy(nxsig_ctx* ctx) {
   } catch (...) {
   }
   delete c;
+}
+
+int nxsig_ctx_last_dispatch(nxsig_ctx* ctx, char* buf, size_t buflen) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  if (!buf || buflen == 0) return set_error(NXSIG_ERR_INVALID_ARG, "last_dispatch: buf is null");
+  std::snprintf(buf, buflen, "%s", c->last_dispatch.c_str());
+  return NXSIG_OK;
+  NXSIG_API_END
 }
 
 int nxsig_device_name(nxsig_ctx* ctx, char* buf, size_t buflen) {
@@ -899,6 +933,7 @@ int nxsig_stft_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t batch
                    const float* window, const nxsig_stft_params* p, nxsig_c64* z, int64_t* num_frames_out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!x || !window || !p || !z) return set_error(NXSIG_ERR_INVALID_ARG, "stft: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -938,6 +973,7 @@ int nxsig_stft_c64(nxsig_ctx* ctx, const nxsig_c64* x, int64_t length, int32_t b
                    const float* window, const nxsig_stft_params* p, nxsig_c64* z, int64_t* num_frames_out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!x || !window || !p || !z) return set_error(NXSIG_ERR_INVALID_ARG, "stft: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -975,6 +1011,7 @@ int nxsig_stft_c64(nxsig_ctx* ctx, const nxsig_c64* x, int64_t length, int32_t b
 static int istft_common(nxsig_ctx* ctx, const nxsig_c64* z, int64_t num_frames, int32_t batch, const float* window,
                         const nxsig_stft_params* p, const nxsig_c64* h, nxsig_c64* y, int32_t mem, bool onesided = false) {
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!z || !window || !p || !y) return set_error(NXSIG_ERR_INVALID_ARG, "istft: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1047,6 +1084,7 @@ int nxsig_as_windowed_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_
                           float* out, int64_t* num_frames_out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!x || !out) return set_error(NXSIG_ERR_INVALID_ARG, "as_windowed: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1072,6 +1110,7 @@ int nxsig_overlap_and_add(nxsig_ctx* ctx, const float* frames, int64_t num_frame
                           int32_t overlap_length, int32_t components, float* out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!frames || !out) return set_error(NXSIG_ERR_INVALID_ARG, "overlap_and_add: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1101,6 +1140,7 @@ int nxsig_fft(nxsig_ctx* ctx, const void* in, int32_t in_is_real, int64_t rows, 
               int32_t inverse, nxsig_c64* out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!in || !out) return set_error(NXSIG_ERR_INVALID_ARG, "fft: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1121,6 +1161,7 @@ static int fir_common(nxsig_ctx* ctx, const float* x, int64_t length, int32_t ba
                       int32_t num_taps, int64_t start, int64_t out_len, float* y, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!x || !h || !y) return set_error(NXSIG_ERR_INVALID_ARG, "fir: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1175,6 +1216,7 @@ int nxsig_fft_nd(nxsig_ctx* ctx, const void* in, int32_t in_is_real, const int64
                  const int64_t* lengths, int32_t n_axes, int32_t inverse, nxsig_c64* out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!in || !out || !shape || (n_axes > 0 && (!axes || !lengths))) return set_error(NXSIG_ERR_INVALID_ARG, "fft_nd: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1205,6 +1247,7 @@ int nxsig_fftconvolve_nd(nxsig_ctx* ctx, const void* a, int32_t a_is_real, const
                          const int64_t* b_shape, int32_t rank, int32_t mode, void* out, int64_t* out_shape, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!a || !b || !out || !a_shape || !b_shape) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1235,6 +1278,7 @@ int nxsig_convolve_direct(nxsig_ctx* ctx, const void* a, int32_t a_is_real, cons
                           const int64_t* b_shape, int32_t rank, int32_t mode, void* out, int64_t* out_shape, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!a || !b || !out || !a_shape || !b_shape) return set_error(NXSIG_ERR_INVALID_ARG, "convolve: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1265,6 +1309,7 @@ int nxsig_fftconvolve_c64(nxsig_ctx* ctx, const nxsig_c64* a, int64_t n1, const 
                           nxsig_c64* out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!a || !b || !out) return set_error(NXSIG_ERR_INVALID_ARG, "fftconvolve: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1306,6 +1351,7 @@ int nxsig_stft_to_mel(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int32_t 
                       const float* filters, float* out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!z || !filters || !out) return set_error(NXSIG_ERR_INVALID_ARG, "stft_to_mel: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1330,6 +1376,7 @@ int nxsig_spectrum_mul_c64(nxsig_ctx* ctx, const nxsig_c64* z, int64_t rows, int
   if (rc) return rc;
   if (rows < 0 || fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "spectrum_mul: rows >= 0 and fft_length >= 1 required");
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (rows == 0) return NXSIG_OK;
   const void* hd = nullptr;
   if ((rc = ctx_table(c, 0x5BEC0ull ^ (uint64_t)fft_length, h, (size_t)fft_length * sizeof(float2), &hd))) return rc;
@@ -1351,6 +1398,7 @@ int nxsig_stft_mel_f32(nxsig_ctx* ctx, const float* x, int64_t length, int32_t b
                        int64_t* num_frames_out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!x || !window || !p || !filters || !out) return set_error(NXSIG_ERR_INVALID_ARG, "stft_mel: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1427,6 +1475,7 @@ static int stft_onesided_impl(nxsig_ctx* ctx, const float* x, int64_t length, in
   if (rc) return rc;
   if (num_frames_out) *num_frames_out = fr.M;
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   StftLaunch a;
   a.fr = fr; a.batch = batch; a.batch_stride = batch_stride; a.K = p->fft_length;
   a.has_scale = p->scaling != NXSIG_SCALE_NONE;
@@ -1482,6 +1531,7 @@ int nxsig_stft_magnitude_f32(nxsig_ctx* ctx, const float* x, int64_t length, int
   if (rc) return rc;
   if (num_frames_out) *num_frames_out = fr.M;
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   StftLaunch a;
   a.fr = fr; a.batch = batch; a.batch_stride = batch_stride; a.K = p->fft_length;
   a.has_scale = p->scaling != NXSIG_SCALE_NONE;
@@ -1571,6 +1621,7 @@ int nxsig_stft_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batc
                    int32_t window_is_f64, const nxsig_stft_params* p, nxsig_c128* z, int64_t* num_frames_out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!x || !window || !p || !z) return set_error(NXSIG_ERR_INVALID_ARG, "stft: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1607,6 +1658,7 @@ int nxsig_istft_c128(nxsig_ctx* ctx, const nxsig_c128* z, int64_t num_frames, in
                      const nxsig_stft_params* p, nxsig_c128* y, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!z || !window || !p || !y) return set_error(NXSIG_ERR_INVALID_ARG, "istft: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1645,6 +1697,7 @@ int nxsig_fft_c128(nxsig_ctx* ctx, const void* in, int32_t in_is_real, int64_t r
                    nxsig_c128* out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!in || !out) return set_error(NXSIG_ERR_INVALID_ARG, "fft: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1666,6 +1719,7 @@ int nxsig_as_windowed_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32
                           int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!x || !out) return set_error(NXSIG_ERR_INVALID_ARG, "as_windowed: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1690,6 +1744,7 @@ int nxsig_overlap_and_add_f64(nxsig_ctx* ctx, const double* frames, int64_t num_
                               int32_t overlap_length, int32_t components, double* out, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!frames || !out) return set_error(NXSIG_ERR_INVALID_ARG, "overlap_and_add: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
@@ -1719,6 +1774,7 @@ static int fir_common_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32
                           int32_t num_taps, int64_t start, int64_t out_len, double* y, int32_t mem) {
   NXSIG_API_BEGIN
   NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
   if (!x || !h || !y) return set_error(NXSIG_ERR_INVALID_ARG, "fir: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;

@@ -832,6 +832,7 @@ int launch_fir_partition_sum(Ctx* c, int n, const float* const* src, const int64
   a.n = n; a.accumulate = accumulate ? 1 : 0; a.clean = clean ? 1 : 0; a.scale = scale; a.y = y; a.out_len = out_len;
   const int64_t bx = (out_len + 1023) / 1024;
   if (bx > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: output too long for one launch");
+  dispatch_note("fir.partition_sum");
   hipLaunchKernelGGL(k_fir_partition_sum, dim3((unsigned)bx, (unsigned)batch), dim3(256), 0, c->stream, a);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
@@ -1310,6 +1311,7 @@ int launch_stft_generic(Ctx* c, const StftLaunch& s) {
     rc = ensure_lds(k_stft_pow2, lds);
     if (rc) return rc;
     dim3 grid((unsigned)((s.fr.M + a.F - 1) / a.F), (unsigned)s.batch);
+    dispatch_note("stft.generic.pow2");
     hipLaunchKernelGGL(k_stft_pow2, grid, dim3(kThreads), lds, c->stream, a);
   } else if (use_bluestein(s.K)) {
     StftBlueArgs b;
@@ -1320,12 +1322,14 @@ int launch_stft_generic(Ctx* c, const StftLaunch& s) {
     rc = ensure_lds(k_stft_blue, lds);
     if (rc) return rc;
     dim3 grid((unsigned)s.fr.M, (unsigned)s.batch);
+    dispatch_note("stft.generic.blue");
     hipLaunchKernelGGL(k_stft_blue, grid, dim3(kThreads), lds, c->stream, b);
   } else {
     a.logK = 0; a.F = 1;
     const int nuse = s.fr.N < s.K ? s.fr.N : s.K;
     const size_t lds = (size_t)nuse * sizeof(float);
     dim3 grid((unsigned)s.fr.M, (unsigned)s.batch);
+    dispatch_note("stft.generic.dft");
     hipLaunchKernelGGL(k_stft_dft, grid, dim3(kThreads), lds, c->stream, a);
   }
   NXSIG_HIP_TRY(hipGetLastError());
@@ -1363,10 +1367,12 @@ static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows
     if (inverse) {
       rc = ensure_lds(k_fft_rows_pow2<true>, lds);
       if (rc) return rc;
+      dispatch_note("fft.rows_generic.pow2");
       hipLaunchKernelGGL(k_fft_rows_pow2<true>, grid, dim3(kThreads), lds, c->stream, a);
     } else {
       rc = ensure_lds(k_fft_rows_pow2<false>, lds);
       if (rc) return rc;
+      dispatch_note("fft.rows_generic.pow2");
       hipLaunchKernelGGL(k_fft_rows_pow2<false>, grid, dim3(kThreads), lds, c->stream, a);
     }
   } else if (use_bluestein(K)) {
@@ -1379,10 +1385,12 @@ static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows
     if (inverse) {
       rc = ensure_lds(k_fft_rows_blue<true>, lds);
       if (rc) return rc;
+      dispatch_note("fft.rows_generic.blue");
       hipLaunchKernelGGL(k_fft_rows_blue<true>, grid, dim3(kThreads), lds, c->stream, b);
     } else {
       rc = ensure_lds(k_fft_rows_blue<false>, lds);
       if (rc) return rc;
+      dispatch_note("fft.rows_generic.blue");
       hipLaunchKernelGGL(k_fft_rows_blue<false>, grid, dim3(kThreads), lds, c->stream, b);
     }
   } else {
@@ -1390,6 +1398,7 @@ static int launch_fft_rows(Ctx* c, const void* in, bool in_is_real, int64_t rows
     const int nuse = n_in < K ? n_in : K;
     const size_t lds = (size_t)nuse * sizeof(float2);
     dim3 grid((unsigned)rows);
+    dispatch_note("fft.rows_generic.dft");
     if (inverse) hipLaunchKernelGGL(k_fft_rows_dft<true>, grid, dim3(kThreads), lds, c->stream, a);
     else hipLaunchKernelGGL(k_fft_rows_dft<false>, grid, dim3(kThreads), lds, c->stream, a);
   }
@@ -1446,6 +1455,7 @@ int launch_stft_c64(Ctx* c, const StftLaunch& s) {
   if ((rc = ctx_scratch(c, 26, (size_t)rows * n_use * sizeof(float2), &frames))) return rc;
   const int64_t blocks = (s.fr.M * n_use + kThreads - 1) / kThreads;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
+  dispatch_note("stft_c64.frames");
   hipLaunchKernelGGL(k_frames_c64, dim3((unsigned)blocks, (unsigned)s.batch), dim3(kThreads), 0, c->stream,
                      reinterpret_cast<const float2*>(s.x), s.batch_stride, to_geom(s.fr), n_use, s.window, reinterpret_cast<float2*>(frames));
   NXSIG_HIP_TRY(hipGetLastError());
@@ -1466,6 +1476,7 @@ int launch_istft_generic(Ctx* c, const IstftLaunch& s) {
   if (rc) return rc;
   const int64_t out_len = s.M * s.hop + (s.N - s.hop);
   dim3 grid((unsigned)((out_len + kThreads - 1) / kThreads), (unsigned)s.batch);
+  dispatch_note("istft.generic");
   hipLaunchKernelGGL((k_ola<2, true>), grid, dim3(kThreads), 0, c->stream, reinterpret_cast<const float*>(frames), s.M,
                      s.N, s.hop, s.window, reinterpret_cast<float*>(s.y), out_len);
   NXSIG_HIP_TRY(hipGetLastError());
@@ -1505,12 +1516,14 @@ int launch_as_windowed(Ctx* c, const float* x, int64_t batch_stride, int32_t bat
     int64_t blocks = (fr.M + kThreads / 64 - 1) / (kThreads / 64);
     const int64_t cap = (int64_t)c->num_cus * 16;
     if (blocks > cap) blocks = cap;
+    dispatch_note("as_windowed.v4");
     hipLaunchKernelGGL(k_as_windowed_v4, dim3((unsigned)blocks, (unsigned)batch), dim3(kThreads), 0, c->stream, x, batch_stride, to_geom(fr), out);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   }
   const int64_t total = fr.M * fr.N;
   dim3 grid((unsigned)((total + kThreads - 1) / kThreads), (unsigned)batch);
+  dispatch_note("as_windowed");
   hipLaunchKernelGGL(k_as_windowed, grid, dim3(kThreads), 0, c->stream, x, batch_stride, to_geom(fr), out);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
@@ -1544,11 +1557,13 @@ int launch_overlap_and_add(Ctx* c, const float* frames, int64_t M, int32_t batch
   if (comps == 1 && N % 4 == 0 && hop % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     // (a thread's 4 outputs n .. n+3 lie in the same hop segment and below the same frame ends, so they share m_lo .. m_hi)
     dim3 grid((unsigned)((out_len / 4 + kThreads - 1) / kThreads), (unsigned)batch);
+    dispatch_note("ola.v4");
     hipLaunchKernelGGL(k_ola_v4, grid, dim3(kThreads), 0, c->stream, frames, M, N, hop, out, out_len);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   }
   dim3 grid((unsigned)((out_len + kThreads - 1) / kThreads), (unsigned)batch);
+  dispatch_note("ola");
   if (comps == 1)
     hipLaunchKernelGGL((k_ola<1, false>), grid, dim3(kThreads), 0, c->stream, frames, M, N, hop, nullptr, out, out_len);
   else
@@ -1610,6 +1625,7 @@ int launch_fir_generic(Ctx* c, const FirLaunch& s) {
   rc = ensure_lds(k_fir_os, lds);
   if (rc) return rc;
   dim3 grid((unsigned)((a.nblocks + 1) / 2), (unsigned)s.batch);
+  dispatch_note("fir.generic");
   hipLaunchKernelGGL(k_fir_os, grid, dim3(kThreads), lds, c->stream, a);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
@@ -1757,11 +1773,11 @@ int launch_istft_fix(Ctx* c, const IstftLaunch& s, const float* window_host) {
     const int64_t blocks = chunk_blocks * s.batch;
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "istft: signal too long for the edge fix-up grid");
     switch ((int)(mode >> 4)) {
-      case 2: hipLaunchKernelGGL(k_istft_edge_chunks<2>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
-      case 4: hipLaunchKernelGGL(k_istft_edge_chunks<4>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
-      case 8: hipLaunchKernelGGL(k_istft_edge_chunks<8>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
-      case 16: hipLaunchKernelGGL(k_istft_edge_chunks<16>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
-      default: hipLaunchKernelGGL(k_istft_edge_chunks<32>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
+      case 2: dispatch_note("istft.edge_chunks"); hipLaunchKernelGGL(k_istft_edge_chunks<2>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
+      case 4: dispatch_note("istft.edge_chunks"); hipLaunchKernelGGL(k_istft_edge_chunks<4>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
+      case 8: dispatch_note("istft.edge_chunks"); hipLaunchKernelGGL(k_istft_edge_chunks<8>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
+      case 16: dispatch_note("istft.edge_chunks"); hipLaunchKernelGGL(k_istft_edge_chunks<16>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
+      default: dispatch_note("istft.edge_chunks"); hipLaunchKernelGGL(k_istft_edge_chunks<32>, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, chunk_blocks); break;
     }
     NXSIG_HIP_TRY(hipGetLastError());
     if (!s.nf_list) return NXSIG_OK;
@@ -1772,6 +1788,7 @@ int launch_istft_fix(Ctx* c, const IstftLaunch& s, const float* window_host) {
   const int32_t nf_blocks = s.nf_list ? c->num_cus * 2 : 0;
   const int64_t blocks = edge_blocks * s.batch + nf_blocks;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "istft: signal too long for the edge fix-up grid");
+  dispatch_note("istft.edge_fix");
   hipLaunchKernelGGL(k_istft_edge_fix, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, a, edge_blocks, s.nf_list,
                      (int32_t)s.nf_frames_per_unit, nf_blocks);
   NXSIG_HIP_TRY(hipGetLastError());
@@ -1806,6 +1823,7 @@ int launch_spectrum_mul(Ctx* c, const float2* z, int64_t rows, int32_t K, const 
   int64_t blocks = (total + kThreads - 1) / kThreads;
   const int64_t cap = (int64_t)c->num_cus * 32;
   if (blocks > cap) blocks = cap;
+  dispatch_note("spectrum_mul");
   hipLaunchKernelGGL(k_spectrum_mul, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, z, h_dev, out, total, K);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
@@ -1907,6 +1925,7 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
     do {                                                                            \
       rc = ensure_lds(k_mel_tile<W, NT>, lds);                                      \
       if (rc) return rc;                                                            \
+      dispatch_note("mel.tile");                                                   \
       hipLaunchKernelGGL((k_mel_tile<W, NT>), grid, dim3(NT), lds, c->stream, t);   \
     } while (0)
     if (wlds && nt == 1024) NXSIG_MEL_TILE_LAUNCH(true, 1024);
@@ -1921,6 +1940,7 @@ int launch_stft_to_mel(Ctx* c, const float2* z, int64_t rows, int32_t K, int32_t
     if (lds1 > 160 * 1024) return set_error(NXSIG_ERR_UNSUPPORTED, "stft_to_mel: fft_length beyond the LDS-resident kernels");
     int rc2 = ensure_lds(k_mel_pass1, lds1);
     if (rc2) return rc2;
+    dispatch_note("mel.pass1");
     hipLaunchKernelGGL(k_mel_pass1, dim3((unsigned)((rows + kMelFramesPerBlock - 1) / kMelFramesPerBlock)), dim3(kThreads), lds1,
                        c->stream, a);
   }
@@ -1998,6 +2018,7 @@ int launch_mag_from_spectrum(Ctx* c, const float2* z, int64_t rows, int32_t K, i
   int64_t blocks = (total + kThreads - 1) / kThreads;
   const int64_t cap = (int64_t)c->num_cus * 32;
   if (blocks > cap) blocks = cap;
+  dispatch_note("mag.from_spectrum");
   hipLaunchKernelGGL(k_mag_from_spectrum, dim3((unsigned)blocks), dim3(kThreads), 0, c->stream, z, rows, K, kind, out, gm);
   NXSIG_HIP_TRY(hipGetLastError());
   if (kind == 2) {

@@ -106,6 +106,7 @@ static int launch_transpose(Ctx* c, const void* in, bool in_is_real, int64_t out
                       : static_cast<const void*>(reinterpret_cast<const float2*>(in) + o0 * plane_stride);
     a.out = out + o0 * (int64_t)R * C;
     dim3 grid((unsigned)tiles, (unsigned)no);
+    dispatch_note("fft.transpose");
     hipLaunchKernelGGL(k_transpose, grid, dim3(kT), 0, c->stream, a);
   }
   NXSIG_HIP_TRY(hipGetLastError());
@@ -460,9 +461,11 @@ static int fft_fourstep_tiled(Ctx* c, const void* in, bool in_is_real, int64_t r
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: too many tiles for one launch");
     if (ntk == 256) {
       if (lds > 64 * 1024) NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_tile<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      dispatch_note("fft.tiled");
       hipLaunchKernelGGL(k_fft_tile<256>, dim3((unsigned)blocks), dim3(256), lds, c->stream, a);
     } else {
       if (lds > 64 * 1024) NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_tile<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      dispatch_note("fft.tiled");
       hipLaunchKernelGGL(k_fft_tile<NT>, dim3((unsigned)blocks), dim3(NT), lds, c->stream, a);
     }
     NXSIG_HIP_TRY(hipGetLastError());
@@ -503,6 +506,7 @@ static int fft_columns_tiled(Ctx* c, const void* src, bool src_real, int64_t out
   a.tw_mode = 0; a.tw_lo = nullptr; a.tw_hi = nullptr; a.tw_n = tw;
   const size_t lds = ((size_t)K * ((1 << lgT) + 1)) * sizeof(float2);
   if (lds > 64 * 1024) NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_tile<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dispatch_note("fft.tiled.columns");
   hipLaunchKernelGGL(k_fft_tile<512>, dim3((unsigned)blocks), dim3(512), lds, c->stream, a);
   NXSIG_HIP_TRY(hipGetLastError());
   *handled = true;
@@ -545,6 +549,7 @@ static int fft_bluestein_big(Ctx* c, const void* in, bool in_is_real, int64_t ro
   if ((rc = ctx_scratch(c, 9, bytes, &s2))) return rc;
   float2* A = reinterpret_cast<float2*>(s1);
   float2* B = reinterpret_cast<float2*>(s2);
+  dispatch_note("fft.big.blue");
   hipLaunchKernelGGL(k_blue_in, dim3(blocks_for(rows * P)), dim3(kT), 0, c->stream, in, in_is_real ? 1 : 0, rows, n_in, K, P, chirp, inverse ? 1 : 0, A);
   NXSIG_HIP_TRY(hipGetLastError());
   if ((rc = launch_fft_big(c, A, false, rows, P, P, false, B, false))) return rc;
@@ -752,6 +757,7 @@ int launch_fftconvolve_nd(Ctx* c, const void* a, bool a_is_real, const int64_t* 
     g.bstride[d] = sh2[d] == 1 && osh[d] != 1 ? 0 : st2;
     st1 *= sh1[d]; st2 *= sh2[d];
   }
+  dispatch_note("fftconvolve_nd");
   hipLaunchKernelGGL(k_bcast_mul, dim3(blocks_for(no)), dim3(kT), 0, c->stream, A, B, g, C);
   NXSIG_HIP_TRY(hipGetLastError());
   // ifft_nd over the same axes (lengths = current sizes) into A's slot: A is dead once the product is queued (stream order)
@@ -1003,6 +1009,7 @@ int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t*
       const bool rr = vol_real && ker_real;
       f.XB = rr ? (f.OW + 7) / 8 : (f.OW + 3) / 4;
       const int64_t threads = f.nb * f.OH * f.XB;
+      dispatch_note("convolve_direct.fast");
       if (rr) hipLaunchKernelGGL(k_conv_direct_rr, dim3(blocks_for(threads)), dim3(kT), 0, c->stream, f);
       else if (!vol_real && !ker_real) hipLaunchKernelGGL((k_conv_direct_cx<true, true>), dim3(blocks_for(threads)), dim3(kT), 0, c->stream, f);
       else if (!vol_real) hipLaunchKernelGGL((k_conv_direct_cx<true, false>), dim3(blocks_for(threads)), dim3(kT), 0, c->stream, f);
@@ -1011,6 +1018,7 @@ int launch_convolve_direct(Ctx* c, const void* a, bool a_is_real, const int64_t*
       return NXSIG_OK;
     }
   }
+  dispatch_note("convolve_direct.generic");
   hipLaunchKernelGGL(k_conv_direct, dim3(blocks_for(g.total)), dim3(kT), 0, c->stream, vol, ker, g, out);
   NXSIG_HIP_TRY(hipGetLastError());
   return NXSIG_OK;
@@ -1046,6 +1054,7 @@ int launch_stft_big(Ctx* c, const StftLaunch& s) {
   if (rc) return rc;
   const int64_t per_row = s.fr.M * s.fr.N;
   if ((per_row + kT - 1) / kT > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
+  dispatch_note("stft.big");
   hipLaunchKernelGGL(k_frames_windowed, dim3(blocks_for(per_row), (unsigned)s.batch), dim3(kT), 0, c->stream, s.x, s.batch_stride, s.fr.L, s.fr.lo,
                      s.fr.reflect, s.fr.M, s.fr.N, s.fr.hop, s.window, reinterpret_cast<float*>(fr));
   NXSIG_HIP_TRY(hipGetLastError());

@@ -1284,6 +1284,7 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
     // every run also walks its halo units: capacity = units walked by all runs
     { int rcl = istft_nf_list(c, a.total_runs * ((run_len + R + 1) / 2 + 1), &a.nf_list); if (rcl) return rcl; }
     s.nf_list = a.nf_list; s.nf_frames_per_unit = 2;
+    dispatch_note(half_deep ? "istft.half.deep" : "istft.half");
     if (half_deep) {
       if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_half_deep<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
       else hipLaunchKernelGGL((k_istft_wave_half_deep<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
@@ -1307,6 +1308,7 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
     }
     a.twH = reinterpret_cast<const v2f*>(dh);
     const size_t lds = (size_t)(2 * K) * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)K * 8 + (size_t)W * XCH * 8;
+    dispatch_note("istft.dbl");
     if (s.has_scale) hipLaunchKernelGGL((k_istft_wave_dbl<K, R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     else hipLaunchKernelGGL((k_istft_wave_dbl<K, R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
   } else {
@@ -1314,6 +1316,7 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
     const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)W * XCH * 8;
     // the spectrogram is read once (5 % run halos aside): non-temporal loads (+2…5 % in interleaved A/B runs, round 2; the
     // default-policy instantiation went with its switch in round 4)
+    dispatch_note(s.filt ? "istft.wave.filt" : (deep ? "istft.wave.deep" : "istft.wave"));
     if (s.filt) {
       if (s.has_scale) hipLaunchKernelGGL((k_istft_wave<K, R, true, W, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
       else hipLaunchKernelGGL((k_istft_wave<K, R, false, W, true, true>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
@@ -1365,6 +1368,7 @@ static int launch_istft_wave_quad(Ctx* c, const IstftLaunch& s, const float* win
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note("istft.quad");
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
@@ -1421,6 +1425,7 @@ static int launch_istft_wave_4k(Ctx* c, const IstftLaunch& s, const float* windo
   const size_t lds = (size_t)NF * 4 + 256 * 8 + (size_t)4 * 256 * 8 + (size_t)K * 8 + (size_t)W * XCH * 8;
   auto go = [&](auto kernel) -> int {
     NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note("istft.4k");
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
@@ -1699,6 +1704,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     hipError_t attr_rc = hipSuccess;
     auto fire = [&](auto kernel) {   // kernels of the 2048-point blocks need > 64 KB of dynamic LDS: opt in per instantiation
       if (lds > 64 * 1024) attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      dispatch_note(K == 1024 ? (stream ? "fir.pair" : "fir.pair.edge") : (stream ? "fir.pair2k" : "fir.pair2k.edge"));
       if (attr_rc == hipSuccess) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     };
     // stream launches: taps - 1 is a multiple of 128 (fast8): K = 1024 serves 128 .. 512, K = 2048 (taps > 513) 640 .. 1024
@@ -1744,6 +1750,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
       const int64_t blocks = (b.total_units + b.chunk - 1) / b.chunk;
       if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: signal too long for one launch");
       const size_t lds4 = 256 * 8 + (size_t)4 * 256 * 8 + (size_t)1024 * 8 + (size_t)W4 * (1024 + 64 + 16) * 8;
+      dispatch_note("fir.r2k");
       switch ((s.taps - 1) / 256) {
         case 1: hipLaunchKernelGGL((k_fir_r2k<W4, 1>), dim3((unsigned)blocks), dim3(64 * W4), lds4, c->stream, b); break;
         case 2: hipLaunchKernelGGL((k_fir_r2k<W4, 2>), dim3((unsigned)blocks), dim3(64 * W4), lds4, c->stream, b); break;

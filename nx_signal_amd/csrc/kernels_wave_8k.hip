@@ -196,6 +196,7 @@ int launch_stft_wave_8k(Ctx* c, const StftLaunch& s, bool* handled) {
     const int64_t blocks = (a.total_frames + a.chunk - 1) / a.chunk;
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
     NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note(split < ((int64_t)1 << 61) ? "stft.8k.edge" : "stft.8k");
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;

@@ -237,6 +237,7 @@ int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batc
   const size_t lds = (size_t)2 * 1024 * 8 + (size_t)W * 2048 * 8;   // 80 KiB: two workgroups per CU
   auto go = [&](auto kernel) -> int {
     NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note("fir.wave32");
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;

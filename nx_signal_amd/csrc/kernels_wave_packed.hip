@@ -216,6 +216,7 @@ static int launch_istft_packed_R(Ctx* c, const IstftLaunch& s, const float* wind
   { int rc = istft_nf_list(c, a.total_runs * ((run_len + R + 1) / 2 + 1), &a.nf_list); if (rc) return rc; }
   s.nf_list = a.nf_list; s.nf_frames_per_unit = 2;
   const size_t lds = (size_t)K * 4 + 256 * 8 + (size_t)R3 * 256 * 8 + (size_t)(K / 2) * 8 + (size_t)W * XCH * 8;
+  dispatch_note("istft.packed");
   if (s.has_scale) hipLaunchKernelGGL((k_istft_packed<R, true, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
   else hipLaunchKernelGGL((k_istft_packed<R, false, W>), dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
   NXSIG_HIP_TRY(hipGetLastError());

@@ -373,6 +373,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note(sink == kSinkSpectrum ? "stft.r20" : (sink == kSinkMel ? "mel.r20" : "mag.r20"));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, b);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
@@ -617,6 +618,7 @@ int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, boo
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note("istft.r20");
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;

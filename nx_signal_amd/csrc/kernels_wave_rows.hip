@@ -272,6 +272,7 @@ int launch_fft_rows_wave_framed(Ctx* c, const void* in, bool in_is_real, int64_t
   auto go = [&](auto kernel, size_t lds) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note(fr ? "stft_c64.rows" : "fft.rows_wave");
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;

@@ -18,6 +18,13 @@ namespace nxsig {
 int set_error(int code, const std::string& msg);
 const char* last_error_cstr();
 
+// ---- dispatch record (nxsig_last_dispatch): the kernel FAMILIES the calling thread's last compute call launched, "a+b+c" in launch
+// order (each family once).  Every launcher that commits to a kernel family notes it; the compute entry points of the C ABI reset
+// the record.  Thread-local like the error message: dirty schedulers calling concurrently see their own call's record.
+void dispatch_reset();
+void dispatch_note(const char* family);
+const char* dispatch_cstr();
+
 #define NXSIG_HIP_TRY(expr)                                                                          \
   do {                                                                                               \
     hipError_t _e = (expr);                                                                          \
@@ -140,6 +147,7 @@ struct Ctx {
   std::multimap<size_t, void*> pool_free;   // size -> block
   std::map<void*, size_t> pool_live;        // blocks handed out by nxsig_alloc
   size_t pool_cached = 0, pool_cap = 0;     // bytes sitting in pool_free; cap (0 = not yet decided)
+  std::string last_dispatch;                // kernel families of the last compute call on this context (nxsig_ctx_last_dispatch)
   Tuning tuning;                            // dispatch / geometry switches (environment at creation, nxsig_ctx_set_tuning later)
 };
 // value of a switch for this context, or the launcher's default when nobody set it

@@ -415,6 +415,7 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note(sink == kSinkSpectrum ? "stft.rab" : (sink == kSinkMel ? "mel.rab" : "mag.rab"));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * w), lds, c->stream, b);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
@@ -611,6 +612,7 @@ inline int launch_rab_c64(Ctx* c, const StftLaunch& s, bool* handled) {
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note("stft_c64.rab");
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
@@ -872,6 +874,7 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note("istft.rab");
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;

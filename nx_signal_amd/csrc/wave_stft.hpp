@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -1433,6 +1434,13 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
     a.chunk = (split < ((int64_t)1 << 61)) ? W : chunk_main;
     a.units_per_row = upr; a.u_split = split; a.u_add0 = add0; a.u_add1 = add1;
     a.total_pairs = upr * s.batch;
+    {  // dispatch record: <sink>.<front-end>[.1r][.edge]
+      char tag[48];
+      const char* fe = MODE == kModePair ? "pair" : (MODE == kModeReal2x ? (C == 1024 ? "real2x" : "real2x.4k") : (J == 2 ? "quad2" : (J == 4 ? "quad4" : "quad8")));
+      std::snprintf(tag, sizeof tag, "%s.%s%s%s", SINK == kSinkSpectrum ? "stft" : (SINK == kSinkMel ? "mel" : "mag"), fe,
+                    small_chunk > 0 ? ".1r" : "", (split < ((int64_t)1 << 61)) ? ".edge" : "");
+      dispatch_note(tag);
+    }
     int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
     if (lds > 64 * 1024)
@@ -1661,6 +1669,7 @@ static int launch_blue_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = 
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dispatch_note(SINK == kSinkSpectrum ? "stft.blue" : (SINK == kSinkMel ? "mel.blue" : "mag.blue"));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, b);
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;

@@ -39,6 +39,13 @@ class Context:
         _lib.check(self._lib.nxsig_device_name(self.handle, buf, 256))
         return buf.value.decode()
 
+    def last_dispatch(self) -> str:
+        """kernel families the last compute call on this context launched, e.g. "stft.pair" or "istft.wave.deep+istft.edge_chunks"
+        (include/nxsig.h: nxsig_ctx_last_dispatch; DESIGN.md section 3 names the families)"""
+        buf = C.create_string_buffer(512)
+        _lib.check(self._lib.nxsig_ctx_last_dispatch(self.handle, buf, 512))
+        return buf.value.decode()
+
     def sync(self):
         _lib.check(self._lib.nxsig_sync(self.handle))
 

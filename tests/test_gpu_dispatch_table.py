@@ -1,0 +1,221 @@
+"""Which kernel family does every documented shape run on, and does it still run at its speed?  (round 6)
+
+Every other `-m gpu` test checks VALUES: a shape silently routed to the generic kernels (0.02-0.03 of the roofline) passes all of them.
+Two guards:
+
+* `test_dispatch_family` — table-driven: the library's dispatch record (`nxsig_ctx_last_dispatch`, include/nxsig.h) of one call per
+  shape of DESIGN.md section 3 must equal the family named here.  Flipping any NXSIG_DISABLE_* switch makes the rows of that family fail by
+  name (`test_a_disabled_family_changes_the_record` shows it for four of them).
+* `test_throughput_floor` — a dozen shapes timed on HIP events (10 settled laps each) against floors at ~0.8 x the fraction measured in
+  round 6 (profiles/r06/dispatch_and_floors.txt); a fall to kernels_generic.hip is a factor 10-30, far below any floor.
+
+NXSIG_DISPATCH_PROBE=1 prints the record / the measured fraction of every row instead of asserting (how the tables were filled)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import nx_signal_amd as S
+from nx_signal_amd import _lib
+
+pytestmark = pytest.mark.gpu
+PROBE = os.environ.get("NXSIG_DISPATCH_PROBE") == "1"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return S.Context(0)
+
+
+def _fill(ctx, buf, rows, row_bytes, dtype):
+    """random rows (one row of noise, rolled per row): all-zero data sends every unit through the cold clean-up drains"""
+    lib = _lib.load()
+    n = row_bytes // np.dtype(dtype).itemsize
+    base = np.random.Generator(np.random.PCG64(3)).standard_normal(n * (2 if np.dtype(dtype).kind == "c" else 1), dtype=np.float32).view(dtype)
+    for r in range(rows):
+        row = np.roll(base, 977 * r)
+        _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(buf.ptr + r * row_bytes), row.ctypes.data_as(C.c_void_p), row_bytes))
+
+
+def _stft(ctx, N, hop, K, batch, M, pad=_lib.PAD_VALID, cplx=False):
+    lib = _lib.load()
+    L = (M - 1) * hop + N if pad == _lib.PAD_VALID else (M - 1) * hop
+    xd = ctx.empty((batch, L), np.complex64 if cplx else np.float32)
+    _fill(ctx, xd, batch, L * (8 if cplx else 4), np.complex64 if cplx else np.float32)
+    if pad != _lib.PAD_VALID:
+        Lp = L + 2 * (N // 2)
+        M = (Lp - N) // hop + 1
+    zd = ctx.empty((batch, M, K), np.complex64)
+    w = S.windows.hann(N)
+    p = _lib.StftParams(N, hop, K, pad, 0, 0, 0, 0, 48000.0)
+    fn = lib.nxsig_stft_c64 if cplx else lib.nxsig_stft_f32
+    return lambda: _lib.check(fn(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, w.ctypes.data_as(C.c_void_p), C.byref(p), C.c_void_p(zd.ptr), None,
+                                 _lib.DEVICE)), batch * M * (hop * (8 if cplx else 4) + K * 8), (xd, zd, w)
+
+
+def _istft(ctx, N, hop, batch, M, filt=False):
+    lib = _lib.load()
+    zd = ctx.empty((batch, M, N), np.complex64)
+    _fill(ctx, zd, batch, M * N * 8, np.complex64)
+    yd = ctx.empty((batch, M * hop + N - hop), np.complex64)
+    w = S.windows.hann(N)
+    p = _lib.StftParams(N, hop, N, 0, 0, 0, 0, 0, 48000.0)
+    if filt:
+        h = np.ones(N, np.complex64)
+        return lambda: _lib.check(lib.nxsig_istft_filtered_c64(ctx.handle, C.c_void_p(zd.ptr), M, batch, w.ctypes.data_as(C.c_void_p), C.byref(p),
+                                                               h.ctypes.data_as(C.c_void_p), C.c_void_p(yd.ptr), _lib.DEVICE)), 0, (zd, yd, w, h)
+    return lambda: _lib.check(lib.nxsig_istft_c64(ctx.handle, C.c_void_p(zd.ptr), M, batch, w.ctypes.data_as(C.c_void_p), C.byref(p), C.c_void_p(yd.ptr),
+                                                  _lib.DEVICE)), batch * M * (N * 8 + hop * 8), (zd, yd, w)
+
+
+def _fir(ctx, taps, batch, L):
+    lib = _lib.load()
+    xd = ctx.empty((batch, L), np.float32)
+    _fill(ctx, xd, batch, L * 4, np.float32)
+    yd = ctx.empty((batch, L), np.float32)
+    h = np.ascontiguousarray(S.filters.firwin(taps if taps % 2 else taps + 1, [4000], sampling_rate=48000)[:taps])
+    return lambda: _lib.check(lib.nxsig_fir_f32(ctx.handle, C.c_void_p(xd.ptr), L, batch, L, h.ctypes.data_as(C.c_void_p), taps, _lib.CONV_SAME,
+                                                C.c_void_p(yd.ptr), _lib.DEVICE)), batch * L * 8, (xd, yd, h)
+
+
+def _fft(ctx, K, rows, inverse=False):
+    lib = _lib.load()
+    a = ctx.empty((rows, K), np.complex64)
+    _fill(ctx, a, rows, K * 8, np.complex64)
+    b = ctx.empty((rows, K), np.complex64)
+    return lambda: _lib.check(lib.nxsig_fft(ctx.handle, C.c_void_p(a.ptr), 0, rows, K, K, 1 if inverse else 0, C.c_void_p(b.ptr), _lib.DEVICE)), rows * K * 16, (a, b)
+
+
+R = _lib.PAD_REFLECT
+# id -> (builder, args, kwargs, expected dispatch record)
+DISPATCH = {
+    # ---- stft, f32 samples
+    "stft1024-many-rounds": (_stft, (1024, 256, 1024, 4, 3201), {}, "stft.pair"),
+    "stft1024-config1-one-round": (_stft, (1024, 256, 1024, 1, 184), {}, "stft.pair.1r"),
+    "stft1024-reflect": (_stft, (1024, 256, 1024, 2, 188), {"pad": R}, "stft.pair.1r+stft.pair.1r.edge"),
+    "stft512": (_stft, (512, 128, 512, 2, 400), {}, "stft.quad2"),
+    "stft400-in-512": (_stft, (400, 160, 512, 2, 400), {}, "stft.quad2"),
+    "stft256": (_stft, (256, 64, 256, 2, 800), {}, "stft.quad4"),
+    "stft128": (_stft, (128, 32, 128, 2, 1600), {}, "stft.quad8"),
+    "stft2048": (_stft, (2048, 512, 2048, 2, 200), {}, "stft.real2x"),
+    "stft4096": (_stft, (4096, 1024, 4096, 2, 100), {}, "stft.real2x.4k"),
+    "stft8192": (_stft, (8192, 2048, 8192, 2, 50), {}, "stft.8k"),
+    "stft400": (_stft, (400, 160, 400, 2, 400), {}, "stft.r20"),
+    "stft320": (_stft, (320, 80, 320, 2, 400), {}, "stft.rab"),
+    "stft960": (_stft, (960, 240, 960, 2, 200), {}, "stft.rab"),
+    "stft1920": (_stft, (1920, 480, 1920, 2, 100), {}, "stft.rab"),
+    "stft441-bluestein": (_stft, (441, 110, 441, 2, 400), {}, "stft.blue"),
+    "stft1020-bluestein": (_stft, (1020, 255, 1020, 2, 200), {}, "stft.blue"),
+    "stft2400-generic": (_stft, (2400, 600, 2400, 2, 50), {}, "stft.generic.blue"),
+    "stft16-generic": (_stft, (16, 4, 16, 2, 400), {}, "stft.generic.pow2"),
+    # ---- stft, c64 samples (3.1c)
+    "stft-c64-512": (_stft, (512, 128, 512, 2, 400), {"cplx": True}, "stft_c64.rab"),
+    "stft-c64-2048": (_stft, (2048, 512, 2048, 2, 100), {"cplx": True}, "stft_c64.rows"),
+    # ---- istft (3.2)
+    "istft1024-hop256": (_istft, (1024, 256, 2, 400), {}, "istft.wave.deep+istft.edge_chunks"),
+    "istft1024-filtered": (_istft, (1024, 256, 2, 400), {"filt": True}, "istft.wave.filt+istft.edge_chunks"),
+    "istft512": (_istft, (512, 128, 2, 400), {}, "istft.half.deep+istft.edge_chunks"),
+    "istft256": (_istft, (256, 64, 2, 800), {}, "istft.quad+istft.edge_chunks"),
+    "istft2048": (_istft, (2048, 512, 2, 200), {}, "istft.dbl+istft.edge_chunks"),
+    "istft4096": (_istft, (4096, 1024, 2, 100), {}, "istft.4k"),
+    "istft400": (_istft, (400, 160, 2, 400), {}, "istft.r20+istft.edge_chunks"),
+    "istft960": (_istft, (960, 240, 2, 200), {}, "istft.rab+istft.edge_chunks"),
+    "istft512-hop160": (_istft, (512, 160, 2, 400), {}, "istft.rab+istft.edge_chunks"),
+    "istft441-generic": (_istft, (441, 110, 2, 400), {}, "fft.rows_generic.blue+istft.generic+istft.edge_fix"),
+    # ---- fir (3.3)
+    "fir257": (_fir, (257, 2, 1 << 20), {}, "fir.pair+fir.pair.edge"),
+    "fir100": (_fir, (100, 2, 1 << 20), {}, "fir.wave32+fir.pair.edge"),
+    "fir513": (_fir, (513, 2, 1 << 20), {}, "fir.r2k+fir.pair2k.edge"),
+    "fir1025": (_fir, (1025, 2, 1 << 20), {}, "fir.r2k+fir.pair2k.edge"),
+    "fir4097-partitioned": (_fir, (4097, 2, 1 << 20), {}, "fir.partitioned"),
+    "fir40001-one-transform": (_fir, (40001, 1, 1 << 18), {}, "fir.long"),
+    # ---- Nx.fft rows
+    "fft1024-rows": (_fft, (1024, 512), {}, "fft.rows_wave"),
+    "fft4096-rows": (_fft, (4096, 128), {}, "fft.rows_wave"),
+    "fft1000-rows": (_fft, (1000, 512), {}, "fft.rows_generic.blue"),
+    "fft-2^20-row": (_fft, (1 << 20, 2), {}, "fft.tiled"),
+}
+
+
+def _record(ctx, key):
+    build, args, kw, _ = DISPATCH[key]
+    fn, _, keep = build(ctx, *args, **kw)
+    fn()
+    ctx.sync()
+    rec = ctx.last_dispatch()
+    del keep
+    return rec
+
+
+@pytest.mark.parametrize("key", list(DISPATCH))
+def test_dispatch_family(ctx, key):
+    rec = _record(ctx, key)
+    if PROBE:
+        print(f'\nPROBE    "{key}": "{rec}"')
+        return
+    want = DISPATCH[key][3]
+    # a record may carry helper passes after the families named in the table (poison / partition sums ...): the named ones must LEAD it
+    assert rec == want or rec.startswith(want + "+"), f"{key}: dispatched to [{rec}], DESIGN.md section 3 says [{want}]"
+
+
+@pytest.mark.parametrize("switch,key,gone", [
+    ("DISABLE_WAVE", "stft1024-config1-one-round", "stft.pair"),
+    ("DISABLE_RAB", "stft960", "stft.rab"),
+    ("DISABLE_R20", "stft400", "stft.r20"),
+    ("DISABLE_BLUE_WAVE", "stft441-bluestein", "stft.blue"),
+    ("ISTFT_DEEP=0", "istft1024-hop256", "istft.wave.deep"),
+    ("FIR_R2K=0", "fir513", "fir.r2k"),
+])
+def test_a_disabled_family_changes_the_record(ctx, switch, key, gone):
+    name, _, val = switch.partition("=")
+    ctx.set_tuning(name, int(val) if val else 1)
+    try:
+        rec = _record(ctx, key)
+    finally:
+        ctx.clear_tuning(name)
+    assert gone not in rec.split("+"), (switch, rec)
+    assert rec != DISPATCH[key][3]
+
+
+def test_the_thread_local_record_matches_the_context_copy(ctx):
+    rec = _record(ctx, "stft2048")
+    assert _lib.last_dispatch() == rec == "stft.real2x"
+
+
+# ---- throughput floors: fraction of 8 TB/s on algorithmic bytes, ~0.8 x what round 6 measured (profiles/r06/dispatch_and_floors.txt)
+FLOORS = {
+    "stft1024 16 x 30 s": (_stft, (1024, 256, 1024, 16, 5621), 0.58),
+    "stft512": (_stft, (512, 128, 512, 16, 11000), 0.49),
+    "stft256": (_stft, (256, 64, 256, 16, 22000), 0.52),
+    "stft2048": (_stft, (2048, 512, 2048, 8, 5600), 0.53),
+    "stft4096": (_stft, (4096, 1024, 4096, 8, 2800), 0.40),
+    "stft400 (20 x 20)": (_stft, (400, 100, 400, 16, 14000), 0.48),
+    "stft960 (A x B)": (_stft, (960, 240, 960, 16, 5800), 0.41),
+    "istft1024": (_istft, (1024, 256, 16, 5621), 0.41),
+    "istft2048": (_istft, (2048, 512, 8, 5600), 0.34),
+    "istft512": (_istft, (512, 128, 16, 11000), 0.36),
+    "fir257 8 x 150 s": (_fir, (257, 8, 7200000), 0.41),
+    "fir769 (real 2048-blocks)": (_fir, (769, 8, 7200000), 0.26),
+}
+
+
+@pytest.mark.parametrize("key", list(FLOORS))
+def test_throughput_floor(ctx, key):
+    build, args, floor = FLOORS[key]
+    fn, nbytes, keep = build(ctx, *args)
+    for _ in range(12):   # clocks and caches settle
+        fn()
+    ctx.sync()
+    best = 0.0
+    for _ in range(2):    # two series of five laps: the better one (a stalled lap must not fail the suite)
+        ctx.timer_start()
+        for _ in range(5):
+            fn()
+        ms = ctx.timer_stop() / 5
+        best = max(best, nbytes / (ms * 1e-3) / 8.0e12)
+    del keep
+    if PROBE:
+        print(f'\nPROBE    "{key}": {best:.3f}  [{ctx.last_dispatch()}]')
+        return
+    assert best >= floor, f"{key}: {best:.3f} of 8 TB/s on [{ctx.last_dispatch()}], floor {floor} — a dispatch or kernel regression"

@@ -6,7 +6,14 @@ defmodule NxSignalAMD.NIF do
   @on_load :load_nif
 
   def load_nif do
-    path = :filename.join(:code.priv_dir(:nx_signal_amd), ~c"nxsig_nif")
+    # NXSIG_NIF_PATH (the shared object, with or without ".so") wins over the application's priv directory: what `elixir smoke.exs`
+    # uses, where there is no :nx_signal_amd application (and no priv_dir) at all
+    path =
+      case System.get_env("NXSIG_NIF_PATH") do
+        p when is_binary(p) and p != "" -> p |> Path.rootname(".so") |> String.to_charlist()
+        _ -> :filename.join(:code.priv_dir(:nx_signal_amd), ~c"nxsig_nif")
+      end
+
     :erlang.load_nif(path, 0)
   end
 

@@ -32,9 +32,11 @@
 namespace nxsig {
 
 // ---------------------------------------------------------------------------------------------- RCCL, loaded lazily
+constexpr int kMinRccl = 21800;   // 2.18.0 (ncclGetVersion: major * 10000 + minor * 100 + patch)
 struct Rccl {
   void* handle = nullptr;
-  std::string error;
+  std::string error, path;
+  int version = 0;
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
@@ -55,7 +57,10 @@ static Rccl* rccl() {
   Rccl& r = rccl_state();
   static std::once_flag once;
   std::call_once(once, [&r] {
-    const char* names[] = {std::getenv("NXSIG_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    // Which librccl?  NXSIG_RCCL_LIB if set; else the ROCm installation's own (/opt/rocm/lib: the one whose headers this file was compiled
+    // against) BEFORE the bare soname — inside a Python process the soname resolves to whatever LD_LIBRARY_PATH / an earlier import put
+    // first (on the round-5 driver box: torch's bundled 2.26.6 instead of ROCm's 2.27.7); the bare names stay as the fallback.
+    const char* names[] = {std::getenv("NXSIG_RCCL_LIB"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     for (const char* n : names) {
       if (!n || !*n) continue;
       r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -79,11 +84,38 @@ static Rccl* rccl() {
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
     r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-    if (!ok) { dlclose(r.handle); r.handle = nullptr; }
+    if (!ok) { dlclose(r.handle); r.handle = nullptr; return; }
+    // Version gate: the ten entry points bound above have kept their prototypes, enum values (ncclInt32 = 2, ncclFloat64 = 8, ncclSum = 0,
+    // ncclMax = 2) and the 128-byte ncclUniqueId since NCCL 2.2; checked here against the rccl.h of 2.27.7 (this image's /opt/rocm) and run
+    // against 2.26.6 (torch's bundle, round-5 driver box).  Anything older than kMinRccl is refused with a clear message instead of failing
+    // in the first collective.
+    typedef ncclResult_t (*GetVersionFn)(int*);
+    GetVersionFn gv = reinterpret_cast<GetVersionFn>(dlsym(r.handle, "ncclGetVersion"));
+    int v = 0;
+    if (!gv || gv(&v) != ncclSuccess) v = 0;
+    r.version = v;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(r.AllReduce), &info) && info.dli_fname) r.path = info.dli_fname;
+    if (v < kMinRccl) {
+      r.error = "librccl at " + r.path + " reports version " + std::to_string(v) + ", older than the minimum " + std::to_string(kMinRccl) +
+                " (2.18.0) this library accepts; point NXSIG_RCCL_LIB at a newer one";
+      dlclose(r.handle); r.handle = nullptr;
+    }
   });
   return r.handle ? &r : nullptr;
 }
 static std::string rccl_error() { return rccl_state().error; }
+// one line on stderr the first time a group gets its communicators (NXSIG_QUIET=1 silences it): which librccl, which version — the
+// first thing anyone debugging a multi-GPU run asks
+static void rccl_announce(int rank) {
+  static std::once_flag once;
+  std::call_once(once, [rank] {
+    const char* q = std::getenv("NXSIG_QUIET");
+    if ((q && *q && *q != '0') || rank != 0) return;
+    const Rccl& r = rccl_state();
+    std::fprintf(stderr, "nxsig: RCCL %d.%d.%d from %s\n", r.version / 10000, (r.version / 100) % 100, r.version % 100, r.path.c_str());
+  });
+}
 
 #define NXSIG_NCCL_TRY(R, expr)                                                                              \
   do {                                                                                                       \
@@ -322,6 +354,7 @@ int nxsig_group_create_local(int32_t n, const int32_t* device_ids, nxsig_group**
     if (r != ncclSuccess) { destroy_group(g); return set_error(NXSIG_ERR_HIP, std::string("ncclCommInitAll: ") + R->GetErrorString(r)); }
     for (int i = 0; i < n; ++i) g->m[i].comm = comms[i];
     g->has_rccl = true;
+    rccl_announce(0);
   }
   *out = reinterpret_cast<nxsig_group*>(g);
   return NXSIG_OK;
@@ -369,6 +402,7 @@ int nxsig_group_create_rank(int32_t world, int32_t rank, int32_t device, const c
   ncclResult_t r = R->CommInitRank(&g->m[0].comm, world, id, rank);
   if (r != ncclSuccess) { destroy_group(g); return set_error(NXSIG_ERR_HIP, std::string("ncclCommInitRank: ") + R->GetErrorString(r)); }
   g->has_rccl = true;
+  rccl_announce(rank);
   *out = reinterpret_cast<nxsig_group*>(g);
   // every rank holds the id once the communicator is up (ncclCommInitRank synchronises): rank 0 removes the file
   rc = nxsig_group_barrier(*out);
@@ -398,13 +432,9 @@ int nxsig_rccl_info(int32_t* version, char* path_buf, size_t buflen) {
   if (path_buf && buflen) path_buf[0] = 0;
   Rccl* R = rccl();
   if (!R) return set_error(NXSIG_ERR_UNSUPPORTED, "RCCL could not be loaded: " + rccl_error());
-  typedef ncclResult_t (*GetVersionFn)(int*);
-  GetVersionFn gv = reinterpret_cast<GetVersionFn>(dlsym(R->handle, "ncclGetVersion"));
-  int v = 0;
-  if (gv && gv(&v) == ncclSuccess && version) *version = v;
-  Dl_info info;
-  if (path_buf && buflen && dladdr(reinterpret_cast<void*>(R->AllReduce), &info) && info.dli_fname) {
-    std::strncpy(path_buf, info.dli_fname, buflen - 1);
+  if (version) *version = R->version;
+  if (path_buf && buflen) {
+    std::strncpy(path_buf, R->path.c_str(), buflen - 1);
     path_buf[buflen - 1] = 0;
   }
   return NXSIG_OK;

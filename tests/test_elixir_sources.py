@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_elixir_blocks_and_brackets_balance():
     files = sorted(glob.glob(os.path.join(ROOT, "elixir", "lib", "**", "*.ex"), recursive=True)
-                   + glob.glob(os.path.join(ROOT, "elixir", "test", "*.exs")) + [os.path.join(ROOT, "elixir", "mix.exs")])
+                   + glob.glob(os.path.join(ROOT, "elixir", "test", "*.exs")) + [os.path.join(ROOT, "elixir", "mix.exs"), os.path.join(ROOT, "elixir", "smoke.exs")])
     assert len(files) >= 10
     for f in files:
         t = open(f).read()
@@ -46,3 +46,22 @@ def test_generated_golden_exs_is_in_sync_with_the_json():
     assert n_tests == sum(len(g[k]) for k in families), (n_tests, {k: len(g[k]) for k in families})
     for v in g["windows"]:
         assert v["src"] in text
+
+
+def test_smoke_exs_calls_only_what_the_host_modules_define():
+    """elixir/smoke.exs (round 6: `elixir elixir/smoke.exs` is the one-command first contact with a BEAM): every NxSignalAMD function it
+    calls is defined in elixir/lib with that arity range, the NIF loader honours NXSIG_NIF_PATH, and it ends in one PASS / FAIL line"""
+    t = open(os.path.join(ROOT, "elixir", "smoke.exs")).read()
+    lib = {os.path.relpath(f, os.path.join(ROOT, "elixir", "lib")): open(f).read()
+           for f in glob.glob(os.path.join(ROOT, "elixir", "lib", "**", "*.ex"), recursive=True)}
+    main = lib["nx_signal_amd.ex"]
+    for fn in ("context", "stft", "istft", "last_dispatch"):
+        assert re.search(r"^\s*def %s\(" % fn, main, re.M), fn
+        assert "sig.%s(" % fn in t, fn
+    assert re.search(r"def rectangular\(", lib["nx_signal_amd/windows.ex"]) and re.search(r"for kind <- \[[^\]]*:hann", lib["nx_signal_amd/windows.ex"])
+    assert re.search(r"def to_device\(", lib["nx_signal_amd/device_tensor.ex"]) and re.search(r"def from_device\(", lib["nx_signal_amd/device_tensor.ex"])
+    assert "NXSIG_NIF_PATH" in lib["nx_signal_amd/nif.ex"] and "NXSIG_NIF_PATH" in t
+    assert 'Mix.install([{:nx, "~> 0.11"}])' in t
+    assert t.count("nxsig smoke PASS") >= 1 and t.count("nxsig smoke FAIL") >= 1 and "System.halt(1)" in t
+    # the doctest literals are the reference's (lib/nx_signal.ex:46-65), as held in tests/golden/reference_vectors.json
+    assert "[1.0, -1.0, 3.0, -1.0, 5.0, -1.0]" in t and "[0.0, 200.0]" in t and "[0.0025, 0.005, 0.0075]" in t

@@ -8,6 +8,7 @@
     through ncclCommInitAll / ncclCommInitRank, ncclAllReduce, ncclAllGather for real);
   * a RANKED group of world size 1 comes up without a rendezvous file.
 No torch anywhere in this path."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -454,3 +455,20 @@ def test_config4_and_config5_partitioning_with_eight_members():
         assert got.shape == zl.shape and float(np.max(np.abs(got - zl)) / np.max(np.abs(zl))) < 1e-6
     finally:
         g.close()
+
+
+def test_the_loaded_rccl_is_reported_and_new_enough(pair):
+    """round 6: the library prefers ROCm's own librccl over whatever the bare soname resolves to, refuses one older than 2.18.0
+    (group.cpp: kMinRccl) and reports path + version of what it loaded (nxsig_rccl_info; one stderr line at the first group)"""
+    import ctypes as C
+
+    from nx_signal_amd import _lib
+
+    lib = _lib.load()
+    v, buf = C.c_int32(0), C.create_string_buffer(512)
+    assert lib.nxsig_rccl_info(C.byref(v), buf, 512) == 0, _lib.last_error()
+    path = buf.value.decode()
+    assert v.value >= 21800, v.value
+    assert "librccl" in path and os.path.exists(path), path
+    if os.path.exists("/opt/rocm/lib/librccl.so.1") and not os.environ.get("NXSIG_RCCL_LIB"):
+        assert os.path.realpath(path) == os.path.realpath("/opt/rocm/lib/librccl.so.1"), path

@@ -41,6 +41,7 @@ UNITS = [
     ("kernels_wave_8k.hip", []),
     ("kernels_wave_rows.hip", []),
     ("kernels_wave_fir32.hip", []),
+    ("kernels_wave_firlong.hip", []),  # 1 026 ... 32 769 taps: uniformly partitioned frequency-domain delay line (round 6)
     ("kernels_wave_packed.hip", []),
     ("kernels_f64.hip", []),  # the f64 / c128 tier (workgroup-per-frame kernels in double)
 ]

@@ -373,7 +373,18 @@ int launch_fir(Ctx* c, const FirLaunch& a_in) {
     }
     return NXSIG_OK;
   }
-  if (a_in.taps > 32768) return launch_fir_long(c, a_in);   // one transform per row, like the reference: non-finite rows come out NaN
+  if (a_in.taps > 32769) return launch_fir_long(c, a_in);   // one transform per row, like the reference: non-finite rows come out NaN
+  if (a_in.taps > 1025 && !tune(c, kT_DISABLE_WAVE, 0) && tune(c, kT_FIR_DLINE, 1)) {
+    // round 6: one forward transform per input block, the partitions applied as a frequency-domain delay line, one inverse per output
+    // block (kernels_wave_firlong.hip); NXSIG_FIR_DLINE=0 keeps round 5's partition-by-partition form
+    FirLaunch a = a_in;
+    int rcd = fir_row_flags(c, a.batch, &a.row_flags);
+    if (rcd) return rcd;
+    bool hd = false;
+    if ((rcd = launch_fir_dline(c, a, &hd))) return rcd;
+    if (hd) return launch_fir_poison(c, a);
+  }
+  if (a_in.taps > 32768) return launch_fir_long(c, a_in);
   if (a_in.taps > 1025 && !tune(c, kT_DISABLE_WAVE, 0)) return launch_fir_partitioned(c, a_in);
   if (a_in.taps > 4096) return launch_fir_long(c, a_in);
   FirLaunch a = a_in;

@@ -78,7 +78,7 @@ int make_framing(int64_t L, int32_t N, int32_t hop, int32_t pad_mode, int64_t pa
   X(DISABLE_WAVE) X(DISABLE_WAVE_ROWS) X(DISABLE_BLUE_WAVE) X(DISABLE_R20) X(DISABLE_RAB) X(DISABLE_8K) X(DISABLE_4K) X(DISABLE_FUSED_FILTER) \
   X(ISTFT_DEEP) X(ISTFT_HALF_DEEP) X(ISTFT_RUNS_PER_CU) X(ISTFT_MIN_RUN) X(ISTFT_REGOLA)                                                    \
   X(STORE_POLICY) X(WAVE_NO_SPLIT) X(NO_AL8) X(NO_STAGE) X(WAVE_UNITS_PER_WAVE) X(STAGE_PAD) X(WAVE_SMALL_W) X(WAVE_SMALL_CHUNK) \
-  X(FIR32) X(FIR_PAD_TAPS) X(FIR_PHASE) X(FIR_HREG) X(FIR_UNITS_PER_WAVE) X(FIR_R2K)                                                      \
+  X(FIR32) X(FIR_PAD_TAPS) X(FIR_PHASE) X(FIR_HREG) X(FIR_UNITS_PER_WAVE) X(FIR_R2K) X(FIR_DLINE)                                                    \
   X(MEL_TILE) X(MEL_LDS_KB) X(FFT_TILED) X(FFT_TILE_ELEMS) X(FFT_TILE_NT) X(FFT_COLUMNS) X(FFT_TILED_MIN) X(CONV_POW2)          \
   X(DIRECT_FAST) X(POOL_MAX_MB) X(NO_PREFAULT)
 enum TuneKey : int {
@@ -236,6 +236,7 @@ struct FirLaunch {
   int* row_flags = nullptr;
 };
 int launch_fir(Ctx* c, const FirLaunch& a);
+int launch_fir_dline(Ctx* c, const FirLaunch& a, bool* handled);   // kernels_wave_firlong.hip: 1 026 ... 32 769 taps
 int fir_row_flags(Ctx* c, int32_t batch, int** out);                                                     // kernels_generic.hip
 int launch_fir_poison(Ctx* c, const FirLaunch& a);
 int launch_fir_flags_from_output(Ctx* c, const float* y, int32_t rows, int64_t out_len, int* flags);     // sample-sharded FIR, group.cpp

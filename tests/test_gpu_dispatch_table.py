@@ -128,7 +128,9 @@ DISPATCH = {
     "fir100": (_fir, (100, 2, 1 << 20), {}, "fir.wave32+fir.pair.edge"),
     "fir513": (_fir, (513, 2, 1 << 20), {}, "fir.r2k+fir.pair2k.edge"),
     "fir1025": (_fir, (1025, 2, 1 << 20), {}, "fir.r2k+fir.pair2k.edge"),
-    "fir4097-partitioned": (_fir, (4097, 2, 1 << 20), {}, "fir.partitioned"),
+    "fir4097-delay-line": (_fir, (4097, 2, 1 << 20), {}, "fir.dline"),
+    "fir16385-delay-line": (_fir, (16385, 2, 1 << 20), {}, "fir.dline"),
+    "fir32769-delay-line": (_fir, (32769, 1, 1 << 19), {}, "fir.dline"),
     "fir40001-one-transform": (_fir, (40001, 1, 1 << 18), {}, "fir.long"),
     # ---- Nx.fft rows
     "fft1024-rows": (_fft, (1024, 512), {}, "fft.rows_wave"),
@@ -166,6 +168,7 @@ def test_dispatch_family(ctx, key):
     ("DISABLE_BLUE_WAVE", "stft441-bluestein", "stft.blue"),
     ("ISTFT_DEEP=0", "istft1024-hop256", "istft.wave.deep"),
     ("FIR_R2K=0", "fir513", "fir.r2k"),
+    ("FIR_DLINE=0", "fir4097-delay-line", "fir.dline"),
 ])
 def test_a_disabled_family_changes_the_record(ctx, switch, key, gone):
     name, _, val = switch.partition("=")

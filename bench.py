@@ -175,6 +175,7 @@ def load_diag():
         d.nxdiag_fir_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int]
         d.nxdiag_stft_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int]
         d.nxdiag_stft2048_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int]
+        d.nxdiag_pcie_pinned.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         return d
     except (OSError, AttributeError):   # missing, or an older build without one of the models
         return None
@@ -920,6 +921,63 @@ def main():
         "algorithmic_GBps": M * BYTES_PER_FRAME / (single_ms * 1e-3) / 1e9,
     }
 
+    # ---- the path a drop-in caller takes by default: HOST tensors in, HOST tensors out (NXSIG_HOST: what NxSignalAMD.stft(%Nx.Tensor{}) and
+    # the Python mirror on numpy arrays call).  8 x config 2 per call = 92 MB up, 737 MB down over PCIe: chunked pageable copies with the
+    # next chunk's pages pre-faulted by host threads (api.cpp: Staged).  Beside it: the link's own rate for the same bytes (one
+    # hipMemcpy into / out of pinned memory: nothing faster can cross it) and the pinned-slot pipeline built in round 6 (NXSIG_HOST_PIPE=1,
+    # not faster: profiles/r06/host_path.txt).  Never part of `value`.
+    host_path = None
+    if rank == 0 and not args.dry:
+        try:
+            HB = 8
+            xh = np.stack([synth(1234 + b) for b in range(HB)])   # (stream 0 = the headline's stream 0 on rank 0)
+            zh = np.empty((HB, M, N_FFT), np.complex64)
+
+            def host_call():
+                _lib.check(lib.nxsig_stft_f32(ctx.handle, xh.ctypes.data_as(C.c_void_p), L, HB, L, wp, C.byref(p), zh.ctypes.data_as(C.c_void_p), None, _lib.HOST))
+
+            host_call()   # first call: pinned slots, scratch, page faults of the result buffer
+            t_h = []
+            for _ in range(3):
+                t0h = time.perf_counter()
+                host_call()
+                t_h.append(time.perf_counter() - t0h)
+            best = min(t_h)
+            zfresh = np.empty((HB, M, N_FFT), np.complex64)   # a caller that allocates its result per call (never touched pages)
+            t0h = time.perf_counter()
+            _lib.check(lib.nxsig_stft_f32(ctx.handle, xh.ctypes.data_as(C.c_void_p), L, HB, L, wp, C.byref(p), zfresh.ctypes.data_as(C.c_void_p), None, _lib.HOST))
+            t_fresh = time.perf_counter() - t0h
+            same = bool(np.array_equal(zfresh.view(np.uint32), zh.view(np.uint32)))
+            ctx.set_tuning("HOST_PIPE", 1)
+            host_call()
+            t0h = time.perf_counter()
+            host_call()
+            t_old = time.perf_counter() - t0h
+            ctx.clear_tuning("HOST_PIPE")
+            zdev = np.empty((M, N_FFT), np.complex64)     # device-resident result of the first stream: the bytes must be the same
+            _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, 1, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, _lib.DEVICE))
+            _lib.check(lib.nxsig_download(ctx.handle, zdev.ctypes.data_as(C.c_void_p), C.c_void_p(zd.ptr), zdev.nbytes))
+            link = None
+            dg = load_diag()
+            if dg is not None:
+                d2h, h2d = C.c_double(0.0), C.c_double(0.0)
+                if dg.nxdiag_pcie_pinned(C.c_void_p(zd.ptr), zh.nbytes, C.byref(d2h), C.byref(h2d)) == 0:
+                    link = {"d2h_pinned_GBps": d2h.value, "h2d_pinned_GBps": h2d.value,
+                            "floor_ms": (zh.nbytes / d2h.value + xh.nbytes / h2d.value) / 1e6}
+            host_path = {
+                "workload": f"{HB} x config 2 per call through NXSIG_HOST: {xh.nbytes / 1e6:.0f} MB up, {zh.nbytes / 1e6:.0f} MB down",
+                "ms_per_call": best * 1e3, "frames_per_s": HB * M / best, "result_GBps": zh.nbytes / best / 1e9,
+                "ms_per_call_fresh_result_buffer": t_fresh * 1e3, "frames_per_s_fresh_result_buffer": HB * M / t_fresh,
+                "ms_per_call_pinned_pipeline": t_old * 1e3, "frames_per_s_pinned_pipeline": HB * M / t_old,
+                "bit_identical_fresh_vs_reused": same,
+                "bit_identical_to_device_path": bool(np.array_equal(zh[0].view(np.uint32), zdev.view(np.uint32))),
+                "link": link,
+                "frac_of_link_d2h": (zh.nbytes / best / 1e9) / link["d2h_pinned_GBps"] if link else None,
+            }
+            del xh, zh, zfresh
+        except Exception as e:  # noqa: BLE001
+            host_path = {"error": repr(e)[:300]}
+
     # optional final assembly, timed SEPARATELY from frames/s: RCCL all-gather of one 60 s stream's
     # spectrum per rank (92 MB each).  Outputs otherwise stay sharded and device-resident.
     assembly = None
@@ -1111,6 +1169,7 @@ def main():
                      else ({"backend": "file control plane (RCCL group creation failed)", "world": world, "torch": False,
                             "error": comm_error} if comm_error else None)),
             "single_stream": single,
+            "host_path": host_path,
             "assembly": assembly,
             "max_norm_err_vs_oracle": verify["max_norm_err"] if verify else None,
             "verify": verify,
@@ -1135,6 +1194,7 @@ def main():
             "frac_stft2048": frac_of("roofline_stft2048"),
             "frac_fir257": frac_of("roofline_fir"),
             "single_stream_fps": single["frames_per_s"] if isinstance(single, dict) else None,
+            "host_path_fps": host_path.get("frames_per_s") if isinstance(host_path, dict) else None,
             "value_cold": out.get("value_cold"),
             "max_norm_err": out.get("max_norm_err_vs_oracle"),
         }

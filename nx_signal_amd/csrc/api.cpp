@@ -422,12 +422,68 @@ struct DeviceGuard {
 struct Staged {
   Ctx* c;
   explicit Staged(Ctx* ctx) : c(ctx) {}
+  // ---- round 6: pinned bounce slots.  A pageable hipMemcpy runs at 13-32 GB/s on this platform (the runtime stages it through its own
+  // small pinned buffers, single-threaded); a DMA between HBM and PINNED host memory runs at the link's ~56 GB/s.  So transfers of
+  // kPinMin bytes or more go in chunks of kPinChunk through two pinned slots per direction: while the DMA engine moves chunk k + 1,
+  // kCopyThreads host threads copy chunk k between the slot and the caller's buffer (which also takes the first-touch page faults of a
+  // freshly allocated result, in parallel).  NXSIG_HOST_PIPE=1 selects it (n >= 2: n copy threads).  Results are the same bytes either way.
+  static constexpr size_t kPinChunk = (size_t)32 << 20, kPinMin = (size_t)8 << 20;
+  static constexpr unsigned kCopyThreads = 8;
+  int ensure_pins() {
+    if (c->pin_bytes) return NXSIG_OK;
+    for (int i = 0; i < 4; ++i) {
+      NXSIG_HIP_TRY(hipHostMalloc(&c->pin[i], kPinChunk, hipHostMallocDefault));
+      NXSIG_HIP_TRY(hipEventCreateWithFlags(&c->xfer_ev[i], hipEventDisableTiming));
+    }
+    NXSIG_HIP_TRY(hipEventCreateWithFlags(&c->xfer_ready, hipEventDisableTiming));
+    NXSIG_HIP_TRY(hipStreamCreateWithFlags(&c->xfer_stream, hipStreamNonBlocking));
+    c->pin_bytes = kPinChunk;
+    return NXSIG_OK;
+  }
+  void parallel_memcpy(char* dst, const char* src, size_t bytes) const {
+    unsigned hw = std::thread::hardware_concurrency();
+    const int knob = tune(c, kT_HOST_PIPE, 0);   // >= 2: that many copy threads (sweeps)
+    const unsigned T = knob >= 2 ? (unsigned)knob : (hw >= 16 ? kCopyThreads : (hw >= 4 ? 2 : 1));
+    const size_t per = ((bytes / T) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) {
+      const size_t o = (size_t)t * per;
+      if (o < bytes) th.emplace_back([=] { std::memcpy(dst + o, src + o, bytes - o < per ? bytes - o : per); });
+    }
+    std::memcpy(dst, src, bytes < per ? bytes : per);
+    for (auto& t : th) t.join();
+  }
+  // (default OFF: measured on 8 x config 2 — 92 MB up, 737 MB down, link floor 14.5 ms — the direct pageable copies with pre-faulting
+  // below take 15.5 ms into a resident result buffer and 17.6 ms into a fresh one, this pipeline 16.3-16.5 / 16.9-17.5 ms: the runtime
+  // pins resident user pages on the fly and DMAs straight into them, which the extra host copy cannot beat; profiles/r06/host_path.txt)
+  bool piped(size_t bytes) const { return bytes >= kPinMin && tune(c, kT_HOST_PIPE, 0) != 0; }
   int in(int slot, const void* host, size_t bytes, const void** dev) {
     void* d = nullptr;
     int rc = ctx_scratch(c, slot, bytes ? bytes : 4, &d);
     if (rc) return rc;
-    NXSIG_HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream));
     *dev = d;
+    if (!piped(bytes)) {
+      NXSIG_HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream));
+      return NXSIG_OK;
+    }
+    if ((rc = ensure_pins())) return rc;
+    // the scratch slot may still be read by work queued on the compute stream: the transfer stream starts behind it
+    NXSIG_HIP_TRY(hipEventRecord(c->xfer_ready, c->stream));
+    NXSIG_HIP_TRY(hipStreamWaitEvent(c->xfer_stream, c->xfer_ready, 0));
+    const char* h = static_cast<const char*>(host);
+    char* dd = static_cast<char*>(d);
+    int k = 0;
+    for (size_t off = 0; off < bytes; off += kPinChunk, ++k) {
+      const size_t len = bytes - off < kPinChunk ? bytes - off : kPinChunk;
+      const int sl = 2 + (k & 1);
+      if (k >= 2) NXSIG_HIP_TRY(hipEventSynchronize(c->xfer_ev[sl]));   // the DMA that last read this slot is done
+      parallel_memcpy(static_cast<char*>(c->pin[sl]), h + off, len);
+      NXSIG_HIP_TRY(hipMemcpyAsync(dd + off, c->pin[sl], len, hipMemcpyHostToDevice, c->xfer_stream));
+      NXSIG_HIP_TRY(hipEventRecord(c->xfer_ev[sl], c->xfer_stream));
+    }
+    // the compute stream continues once the last chunk has landed
+    NXSIG_HIP_TRY(hipEventRecord(c->xfer_ready, c->xfer_stream));
+    NXSIG_HIP_TRY(hipStreamWaitEvent(c->stream, c->xfer_ready, 0));
     return NXSIG_OK;
   }
   int out_alloc(int slot, size_t bytes, void** dev) { return ctx_scratch(c, slot, bytes ? bytes : 4, dev); }
@@ -460,6 +516,7 @@ struct Staged {
     for (auto& t : th) t.join();
   }
   int out_copy(void* host, const void* dev, size_t bytes) {
+    if (piped(bytes)) return out_copy_piped(host, dev, bytes);
     const size_t CH = (size_t)32 << 20;
     if (bytes < ((size_t)32 << 20) || tune(c, kT_NO_PREFAULT, 0)) {
       NXSIG_HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -481,6 +538,31 @@ struct Staged {
       if (pf.joinable()) pf.join();
       NXSIG_HIP_TRY(e2);
     }
+    return NXSIG_OK;
+  }
+  // device -> pinned slot (DMA, transfer stream) -> caller's buffer (host threads), two slots: DMA of chunk k + 1 beside the copy of chunk k
+  int out_copy_piped(void* host, const void* dev, size_t bytes) {
+    int rc = ensure_pins();
+    if (rc) return rc;
+    NXSIG_HIP_TRY(hipEventRecord(c->xfer_ready, c->stream));             // the kernels that produce the result
+    NXSIG_HIP_TRY(hipStreamWaitEvent(c->xfer_stream, c->xfer_ready, 0));
+    char* h = static_cast<char*>(host);
+    const char* d = static_cast<const char*>(dev);
+    const size_t n = (bytes + kPinChunk - 1) / kPinChunk;
+    auto len_of = [&](size_t k) { const size_t off = k * kPinChunk; return bytes - off < kPinChunk ? bytes - off : kPinChunk; };
+    NXSIG_HIP_TRY(hipMemcpyAsync(c->pin[0], d, len_of(0), hipMemcpyDeviceToHost, c->xfer_stream));
+    NXSIG_HIP_TRY(hipEventRecord(c->xfer_ev[0], c->xfer_stream));
+    for (size_t k = 0; k < n; ++k) {
+      const int sl = (int)(k & 1);
+      if (k + 1 < n) {   // slot (k + 1) & 1 was emptied by the copy of chunk k - 1 (sequential below)
+        NXSIG_HIP_TRY(hipMemcpyAsync(c->pin[sl ^ 1], d + (k + 1) * kPinChunk, len_of(k + 1), hipMemcpyDeviceToHost, c->xfer_stream));
+        NXSIG_HIP_TRY(hipEventRecord(c->xfer_ev[sl ^ 1], c->xfer_stream));
+      }
+      NXSIG_HIP_TRY(hipEventSynchronize(c->xfer_ev[sl]));
+      parallel_memcpy(h + k * kPinChunk, static_cast<const char*>(c->pin[sl]), len_of(k));
+    }
+    // later work on the compute stream may overwrite the scratch slot the result came from: it is behind the last DMA already
+    // (every DMA was waited for above); nothing else to order
     return NXSIG_OK;
   }
 };
@@ -661,6 +743,10 @@ void nxsig_ctx_destroy(nxsig_ctx* ctx) {
     (void)hipEventDestroy(c->ev_start);
     (void)hipEventDestroy(c->ev_stop);
     for (auto e : c->lap_events) (void)hipEventDestroy(e);
+    for (auto& pp : c->pin) if (pp) (void)hipHostFree(pp);
+    for (auto& e : c->xfer_ev) if (e) (void)hipEventDestroy(e);
+    if (c->xfer_ready) (void)hipEventDestroy(c->xfer_ready);
+    if (c->xfer_stream) (void)hipStreamDestroy(c->xfer_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
   } catch (...) {
   }

@@ -80,7 +80,7 @@ int make_framing(int64_t L, int32_t N, int32_t hop, int32_t pad_mode, int64_t pa
   X(STORE_POLICY) X(WAVE_NO_SPLIT) X(NO_AL8) X(NO_STAGE) X(WAVE_UNITS_PER_WAVE) X(STAGE_PAD) X(WAVE_SMALL_W) X(WAVE_SMALL_CHUNK) \
   X(FIR32) X(FIR_PAD_TAPS) X(FIR_PHASE) X(FIR_HREG) X(FIR_UNITS_PER_WAVE) X(FIR_R2K) X(FIR_DLINE)                                                    \
   X(MEL_TILE) X(MEL_LDS_KB) X(FFT_TILED) X(FFT_TILE_ELEMS) X(FFT_TILE_NT) X(FFT_COLUMNS) X(FFT_TILED_MIN) X(CONV_POW2)          \
-  X(DIRECT_FAST) X(POOL_MAX_MB) X(NO_PREFAULT)
+  X(DIRECT_FAST) X(POOL_MAX_MB) X(NO_PREFAULT) X(HOST_PIPE)
 enum TuneKey : int {
 #define NXSIG_X(n) kT_##n,
   NXSIG_TUNABLES(NXSIG_X)
@@ -147,6 +147,14 @@ struct Ctx {
   std::multimap<size_t, void*> pool_free;   // size -> block
   std::map<void*, size_t> pool_live;        // blocks handed out by nxsig_alloc
   size_t pool_cached = 0, pool_cap = 0;     // bytes sitting in pool_free; cap (0 = not yet decided)
+  // host-tensor calls (mem = NXSIG_HOST): two pinned bounce slots per direction + a transfer stream.  The result travels in chunks:
+  // DMA of chunk k + 1 into one slot while host threads copy chunk k out of the other into the caller's (pageable) buffer
+  // (Staged::out_copy, api.cpp); created on the first host-tensor call of at least kPinMin bytes, freed with the context
+  void* pin[4] = {nullptr, nullptr, nullptr, nullptr};   // [0, 1] device -> host, [2, 3] host -> device
+  size_t pin_bytes = 0;
+  hipStream_t xfer_stream = nullptr;
+  hipEvent_t xfer_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t xfer_ready = nullptr;
   std::string last_dispatch;                // kernel families of the last compute call on this context (nxsig_ctx_last_dispatch)
   Tuning tuning;                            // dispatch / geometry switches (environment at creation, nxsig_ctx_set_tuning later)
 };

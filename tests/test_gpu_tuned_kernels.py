@@ -830,3 +830,25 @@ def test_more_rows_than_one_launch_takes():
     f = S.filters.fir(xd, h, mode="same", ctx=ctx).numpy()
     fs = S.filters.fir(ctx.to_device(np.ascontiguousarray(x[pick])), h, mode="same", ctx=ctx).numpy()
     assert float(np.max(np.abs(f[pick] - fs))) < 1e-6
+
+
+def test_host_tensor_paths_return_the_same_bytes():
+    """NXSIG_HOST calls move their tensors by chunked pageable copies with pre-faulting (default) or through pinned bounce slots with the
+    DMA of one chunk beside the host copy of the previous one (NXSIG_HOST_PIPE=1, round 6; api.cpp: Staged): the same bytes either way,
+    and the same as the device-resident call, for a transfer that spans several 32 MB chunks and ends inside one"""
+    ctx = S.Context(0)
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((3, 1_234_567)).astype(np.float32)
+    w = S.windows.hann(1024)
+    opts = dict(overlap_length=768, fft_length=1024, sampling_rate=48000)
+    z0 = S.stft(x, w, ctx=ctx, **opts)[0]
+    zd = S.stft(ctx.to_device(x), w, ctx=ctx, **opts)[0].numpy()
+    assert np.array_equal(z0.view(np.uint32), zd.view(np.uint32))
+    for knob in (1, 3):
+        ctx.set_tuning("HOST_PIPE", knob)
+        z1 = S.stft(x, w, ctx=ctx, **opts)[0]
+        y1 = S.filters.fir(x, np.ones(33, np.float32) / 33, mode="same", ctx=ctx)
+        ctx.clear_tuning("HOST_PIPE")
+        assert z1.nbytes > 96 << 20 and z1.nbytes % (32 << 20) != 0
+        assert np.array_equal(z1.view(np.uint32), z0.view(np.uint32))
+        assert np.array_equal(y1.view(np.uint32), S.filters.fir(x, np.ones(33, np.float32) / 33, mode="same", ctx=ctx).view(np.uint32))

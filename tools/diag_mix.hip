@@ -251,6 +251,32 @@ __global__ __launch_bounds__(256) void k_y_mix(const v4f* __restrict__ in, v4f* 
 }
 
 extern "C" {
+// the link itself: `bytes` of device memory into PINNED host memory with one hipMemcpy (and back), GB/s of the better of three runs each —
+// the yardstick bench.py's `host_path` block puts beside the host-tensor call (nothing faster can cross PCIe)
+int nxdiag_pcie_pinned(const void* dev, size_t bytes, double* d2h_GBps, double* h2d_GBps) {
+  void* pin = nullptr;
+  if (hipHostMalloc(&pin, bytes, hipHostMallocDefault) != hipSuccess) return 1;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  double best[2] = {0.0, 0.0};
+  for (int dir = 0; dir < 2; ++dir)
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0, 0);
+      if (dir == 0) hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, 0);
+      else hipMemcpyAsync(const_cast<void*>(dev), pin, bytes, hipMemcpyHostToDevice, 0);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      const double g = (double)bytes / (ms * 1e-3) / 1e9;
+      if (g > best[dir]) best[dir] = g;
+    }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipHostFree(pin);
+  if (d2h_GBps) *d2h_GBps = best[0];
+  if (h2d_GBps) *h2d_GBps = best[1];
+  return (int)hipGetLastError();
+}
 // x: f32[rows][L], z: c64[rows][M][2048] with M = (L - 2048) / hop + 1
 int nxdiag_stft2048_mix(void* stream, const void* x, void* z, const void* tab, long rows, long L, int hop, int units_per_wave) {
   const long M = (L - 2048) / hop + 1, total = rows * M;

@@ -36,7 +36,7 @@ struct DlineArgs {
   int64_t k_first, nblk;      // output blocks of this segment
   const v2f* twB;
   const v2f* twC;
-  const v2f* coef;            // c64[P][1024][2]: (A_p[b], B_p[b])
+  const v2f* coef;            // c64[2][P][1024][2]: (A_p[b], B_p[b]), then (A_p[b], conj B_p[(1024 - b) mod 1024])
   v2f* Z;                     // c64[batch][nwin][1024]
   v2f* Wt;                    // c64[batch][nblk][1024]
   float* y;
@@ -198,6 +198,92 @@ __global__ __launch_bounds__(64 * W) void k_fir_dline_inv(DlineArgs a, int64_t t
   }
 }
 
+// ---- delay line FUSED into the inverse pass (<= 4 partitions, i.e. <= 4 097 taps): one wave per output block reads the block's np
+// windows (8 KB each: the np - 1 older ones were read by the neighbouring blocks a moment ago, L2), forms W_k in the core's input layout —
+// the partner bins conj Z[(1024 - b) mod 1024] come from the partner lane like in k_fir_r2k — and inverts it; W never exists in memory:
+// 8 + 8 (fwd) + 8 + 4 bytes per sample instead of 44.  The coefficients of all partitions sit in LDS (16 KB per partition, shared by the
+// workgroup's eight waves).
+template <int W, int PMAX>
+__global__ __launch_bounds__(64 * W) void k_fir_dline_macinv(DlineArgs a, int64_t total, int bpw) {
+  constexpr int K = 1024, P = 16, R3 = 4, NQ = 8, XCH = K + K / 16 + 16;
+  v2f* s_twB = reinterpret_cast<v2f*>(g_wave_smem);
+  v2f* s_twC = s_twB + 256;
+  v4f* s_cf = reinterpret_cast<v4f*>(s_twC + R3 * 256);          // [PMAX][1024] (A, B)
+  v2f* s_x = reinterpret_cast<v2f*>(s_cf + PMAX * K);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 256; i += 64 * W) s_twB[i] = a.twB[i];
+  for (int i = tid; i < R3 * 256; i += 64 * W) s_twC[i] = a.twC[i];
+  for (int i = tid; i < a.P * K; i += 64 * W) s_cf[i] = reinterpret_cast<const v4f*>(a.coef)[a.P * K + i];   // second table: (A_p[b], conj B_p[-b])
+  __syncthreads();
+  v2f* xb = s_x + wave * XCH;
+  const int src = ((64 - lane) & 63) << 2;
+  // a wave takes bpw consecutive blocks of one row (their windows overlap: cache hits)
+  const int64_t u0 = ((int64_t)blockIdx.x * W + wave) * bpw;
+  for (int64_t u = u0; u < u0 + bpw && u < total; ++u) {
+    const int64_t row = u / a.nblk, bi = u - row * a.nblk;
+    const v2f* zrow = a.Z + (size_t)row * a.nwin * K + lane;
+    // window of (block k_first + bi, partition p) sits at index bi + (P_total - 1) - p of the segment's Z
+    v2f acc[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) acc[s] = v2f{0.f, 0.f};
+    v2f d[P], dn[P];
+    {
+      const v2f* zp = zrow + (size_t)(bi + a.P - 1) * K;
+#pragma unroll
+      for (int s = 0; s < P; ++s) d[s] = zp[64 * s];
+    }
+    // W[b] = sum_p A_p[b] Z_p[b] + B_p[b] conj Z_p[-b] = U[b] + conj V[-b],  V[b] = sum_p conj(B_p[-b]) Z_p[b]: both sums run over the
+    // lane's OWN bins (the table holds (A_p[b], conj B_p[-b])), and the partner lane is visited once, at the end, instead of once per partition
+    v2f vv[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) vv[s] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+      if (p < a.P) {   // wave-uniform
+        if (p + 1 < a.P) {
+          const v2f* zp = zrow + (size_t)(bi + a.P - 2 - p) * K;
+#pragma unroll
+          for (int s = 0; s < P; ++s) dn[s] = zp[64 * s];
+        }
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+          const v4f cf = s_cf[p * K + lane + 64 * s];
+          acc[s] += wcmul(v2f{cf.x, cf.y}, d[s]);
+          vv[s] += wcmul(v2f{cf.z, cf.w}, d[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < P; ++s) d[s] = dn[s];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+      v2f pv;
+      pv.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(vv[P - 1 - s].x)));
+      pv.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(vv[P - 1 - s].y)));
+      if (lane == 0) pv = vv[(P - s) % P];
+      acc[s] += v2f{pv.x, -pv.y};
+    }
+    v2f y2[2][NQ];
+    wave_fft_core<K, true, true>(acc, y2, xb, s_twB, s_twC, lane);
+    if (wave_any_nonfinite(y2[0][NQ - 1].x, y2[0][NQ - 1].y) && lane == 0) atomicOr(a.row_flags + row, 1);
+    const int64_t i0 = (a.k_first + bi) * 1024;
+    float* yr = a.y + (size_t)row * a.out_len;
+#pragma unroll
+    for (int q = NQ / 2; q < NQ; ++q) {
+      const int64_t i = i0 + 4 * lane + 256 * (q - NQ / 2);
+      const v4f o = fft_eps0(v4f{y2[0][q].x, y2[0][q].y, y2[1][q].x, y2[1][q].y});
+      if (i + 3 < a.out_len && ((reinterpret_cast<uintptr_t>(yr + i) & 15) == 0)) {
+        __builtin_nontemporal_store(o, (gv4f*)(yr + i));
+      } else {
+        if (i < a.out_len) yr[i] = o.x;
+        if (i + 1 < a.out_len) yr[i + 1] = o.y;
+        if (i + 2 < a.out_len) yr[i + 2] = o.z;
+        if (i + 3 < a.out_len) yr[i + 3] = o.w;
+      }
+    }
+  }
+}
+
 static void host_fft_f64(std::vector<double>& re, std::vector<double>& im) {   // radix-2, in place, power-of-two length
   const size_t n = re.size();
   for (size_t i = 1, j = 0; i < n; ++i) {
@@ -234,7 +320,7 @@ int launch_fir_dline(Ctx* c, const FirLaunch& s, bool* handled) {
   auto hit = c->memo.find(hkey);
   if (hit != c->memo.end()) cd = reinterpret_cast<const void*>(hit->second[0]);
   else {
-    std::vector<float2> coef((size_t)P * 1024 * 2);
+    std::vector<float2> coef((size_t)P * 1024 * 4);   // [P][1024] (A_p[b], B_p[b]) for the three passes, then [P][1024] (A_p[b], conj B_p[-b]) for the fused pass
     std::vector<double> re(2048), im(2048);
     for (int p = 0; p < P; ++p) {
       std::fill(re.begin(), re.end(), 0.0); std::fill(im.begin(), im.end(), 0.0);
@@ -248,6 +334,11 @@ int launch_fir_dline(Ctx* c, const FirLaunch& s, bool* handled) {
         coef[((size_t)p * 1024 + k) * 2] = make_float2((float)((sr - dr * sn) / 1024.0), (float)((si - di * sn) / 1024.0));
         coef[((size_t)p * 1024 + k) * 2 + 1] = make_float2((float)(-di * cs / 1024.0), (float)(dr * cs / 1024.0));
       }
+      for (int k = 0; k < 1024; ++k) {
+        const float2 A = coef[((size_t)p * 1024 + k) * 2], Bm = coef[((size_t)p * 1024 + ((1024 - k) & 1023)) * 2 + 1];
+        coef[((size_t)(P + p) * 1024 + k) * 2] = A;
+        coef[((size_t)(P + p) * 1024 + k) * 2 + 1] = make_float2(Bm.x, -Bm.y);
+      }
     }
     if ((rc = ctx_table(c, 0xD11E1ull ^ ((uint64_t)s.taps << 20), coef.data(), coef.size() * sizeof(float2), &cd))) return rc;
     c->memo[hkey] = {reinterpret_cast<uint64_t>(cd)};
@@ -260,15 +351,17 @@ int launch_fir_dline(Ctx* c, const FirLaunch& s, bool* handled) {
   a.coef = reinterpret_cast<const v2f*>(cd);
   a.y = s.y; a.row_flags = s.row_flags;
   const int64_t nblk_total = (s.out_len + 1023) / 1024;
+  // <= 4 partitions: the delay line rides in the inverse pass (k_fir_dline_macinv: no W tensor); NXSIG_FIR_DLINE=2 keeps the three passes
+  const bool fused = P <= 4 && tune(c, kT_FIR_DLINE, 1) != 2;
   // segment length: Z + W of a segment within 1 GB of scratch.  (Segments small enough for the Infinity Cache were measured and LOSE:
   // config 5's shard at 4 097 taps 3.39 / 2.62 / 2.15 / 1.99 / 1.86 / 1.78 ms with 32 / 64 / 128 / 192 / 1 024 / 4 096 MB — three launches per
   // segment cost more than the cache returns; 1 GB bounds the scratch, profiles/r06/fir_delay_line.txt)
   const int seg_mb = tune(c, kT_FIR_DLINE, 1) >= 16 ? tune(c, kT_FIR_DLINE, 1) : 1024;   // (NXSIG_FIR_DLINE >= 16: the segment budget in MB, for sweeps)
-  int64_t seg = ((int64_t)seg_mb << 20) / ((int64_t)s.batch * 16384);
+  int64_t seg = ((int64_t)seg_mb << 20) / ((int64_t)s.batch * (fused ? 8192 : 16384));
   if (seg < 64) seg = 64;
   if (seg > nblk_total) seg = nblk_total;
   void* scratch = nullptr;
-  const size_t zbytes = (size_t)s.batch * (size_t)(seg + P - 1) * 8192, wbytes = (size_t)s.batch * (size_t)seg * 8192;
+  const size_t zbytes = (size_t)s.batch * (size_t)(seg + P - 1) * 8192, wbytes = fused ? 0 : (size_t)s.batch * (size_t)seg * 8192;
   if ((rc = ctx_scratch(c, 21, zbytes + wbytes, &scratch))) return rc;
   a.Z = reinterpret_cast<v2f*>(scratch);
   a.Wt = reinterpret_cast<v2f*>(static_cast<char*>(scratch) + zbytes);
@@ -285,6 +378,19 @@ int launch_fir_dline(Ctx* c, const FirLaunch& s, bool* handled) {
       if (blocks > (int64_t)c->num_cus * 64) blocks = (int64_t)c->num_cus * 64;
       hipLaunchKernelGGL(k_fir_dline_fwd<W>, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a, total);
       NXSIG_HIP_TRY(hipGetLastError());
+    }
+    if (fused) {
+      constexpr int W8 = 8;
+      const size_t lds8 = (size_t)(256 + 4 * 256) * 8 + (size_t)4 * 1024 * 16 + (size_t)W8 * (1024 + 64 + 16) * 8;
+      const int64_t total = (int64_t)s.batch * a.nblk;
+      const int bpw = 4;
+      const int64_t blocks = (total + (int64_t)W8 * bpw - 1) / ((int64_t)W8 * bpw);
+      if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: signal too long for one launch");
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fir_dline_macinv<W8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+      dispatch_note("fir.dline.fused");
+      hipLaunchKernelGGL((k_fir_dline_macinv<W8, 4>), dim3((unsigned)blocks), dim3(64 * W8), lds8, c->stream, a, total, bpw);
+      NXSIG_HIP_TRY(hipGetLastError());
+      continue;
     }
     // runs: enough (row, run) pairs to fill the chip, each at least 2 P blocks long (a run re-reads P - 1 windows to warm up)
     int64_t run_len = ((int64_t)s.batch * a.nblk + c->num_cus - 1) / c->num_cus;

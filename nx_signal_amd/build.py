@@ -37,6 +37,8 @@ UNITS = [
     ("kernels_wave_rab_p2.hip", []),  # 500 ... 900
     ("kernels_wave_rab_p3.hip", []),  # 1000 ... 1600
     ("kernels_wave_rab_p5.hip", []),  # 192 ... 1920 (12- and 48-point codelets)
+    ("kernels_wave_rab_p6.hip", []),  # 882, 1764 (radix 7, round 6)
+    ("kernels_wave_rab_p7.hip", []),  # 2400, 2880, 3840 (round 6)
     ("kernels_wave_rab_p4.hip", []),  # inverse only: 128 / 256 / 512 / 1024 at any hop
     ("kernels_wave_8k.hip", []),
     ("kernels_wave_rows.hip", []),

@@ -8,15 +8,21 @@ int launch_stft_rab_p1(Ctx* c, const StftLaunch& s, bool* handled, const MelLaun
 int launch_stft_rab_p2(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);
 int launch_stft_rab_p3(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);
 int launch_stft_rab_p5(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);
+int launch_stft_rab_p6(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);
+int launch_stft_rab_p7(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel);
 int launch_istft_rab_p1(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p2(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p3(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p5(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
+int launch_istft_rab_p6(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
+int launch_istft_rab_p7(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_istft_rab_p4(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled);
 int launch_stft_rab_c64_p1(Ctx* c, const StftLaunch& s, bool* handled);
 int launch_stft_rab_c64_p2(Ctx* c, const StftLaunch& s, bool* handled);
 int launch_stft_rab_c64_p3(Ctx* c, const StftLaunch& s, bool* handled);
 int launch_stft_rab_c64_p5(Ctx* c, const StftLaunch& s, bool* handled);
+int launch_stft_rab_c64_p6(Ctx* c, const StftLaunch& s, bool* handled);
+int launch_stft_rab_c64_p7(Ctx* c, const StftLaunch& s, bool* handled);
 int launch_stft_rab_c64_p4(Ctx* c, const StftLaunch& s, bool* handled);
 
 // 0..3, 5: the list that holds fft length K, -1: none
@@ -28,6 +34,8 @@ int rab_length_part(int K) {
     NXSIG_RAB_PART2(X) return 2;
     NXSIG_RAB_PART3(X) return 3;
     NXSIG_RAB_PART5(X) return 5;
+    NXSIG_RAB_PART6(X) return 6;
+    NXSIG_RAB_PART7(X) return 7;
 #undef X
     default: return -1;
   }
@@ -52,6 +60,8 @@ int launch_stft_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
     case 2: return launch_stft_rab_p2(c, s, handled, mel);
     case 3: return launch_stft_rab_p3(c, s, handled, mel);
     case 5: return launch_stft_rab_p5(c, s, handled, mel);
+    case 6: return launch_stft_rab_p6(c, s, handled, mel);
+    case 7: return launch_stft_rab_p7(c, s, handled, mel);
     case 0: break;
     default: return NXSIG_OK;
   }
@@ -74,6 +84,8 @@ int launch_stft_rab_c64(Ctx* c, const StftLaunch& s, bool* handled) {
     case 2: return launch_stft_rab_c64_p2(c, s, handled);
     case 3: return launch_stft_rab_c64_p3(c, s, handled);
     case 5: return launch_stft_rab_c64_p5(c, s, handled);
+    case 6: return launch_stft_rab_c64_p6(c, s, handled);
+    case 7: return launch_stft_rab_c64_p7(c, s, handled);
     case 0: break;
     default: return NXSIG_OK;
   }
@@ -95,6 +107,8 @@ int launch_istft_rab(Ctx* c, const IstftLaunch& s, const float* window_host, boo
     case 2: return launch_istft_rab_p2(c, s, window_host, handled);
     case 3: return launch_istft_rab_p3(c, s, window_host, handled);
     case 5: return launch_istft_rab_p5(c, s, window_host, handled);
+    case 6: return launch_istft_rab_p6(c, s, window_host, handled);
+    case 7: return launch_istft_rab_p7(c, s, window_host, handled);
     case 0: break;
     default: return NXSIG_OK;
   }

@@ -228,9 +228,166 @@ __device__ __forceinline__ void dft48(v2f* v) {
   }
 }
 
+// ---- round 6: radix 7 (the frames of 44.1 kHz audio: 441 = 21 x 21, 882 = 42 x 21, 1764 = 42 x 42) and the 50- / 60- / 64-point codelets of
+// 2400 = 48 x 50, 2880 = 48 x 60, 3840 = 60 x 64.  Index maps checked against numpy (tools/check_codelet_maps.py).
+// 7-point DFT: pairs a_j = x_j + x_(7-j), b_j = x_j - x_(7-j); X_k = x0 + sum a_j cos(2 pi j k / 7) -+ i sum b_j sin(2 pi j k / 7)
+__device__ __forceinline__ void dft7(v2f& x0, v2f& x1, v2f& x2, v2f& x3, v2f& x4, v2f& x5, v2f& x6) {
+  const float c1 = 0.62348980185873359f, c2 = -0.22252093395631434f, c3 = -0.90096886790241903f;
+  const float s1 = 0.7818314824680298f, s2 = 0.97492791218182362f, s3 = 0.43388373911755823f;
+  const v2f a1 = x1 + x6, a2 = x2 + x5, a3 = x3 + x4, b1 = x1 - x6, b2 = x2 - x5, b3 = x3 - x4;
+  const v2f t1 = x0 + a1 * c1 + a2 * c2 + a3 * c3, t2 = x0 + a1 * c2 + a2 * c3 + a3 * c1, t3 = x0 + a1 * c3 + a2 * c1 + a3 * c2;
+  const v2f u1 = b1 * s1 + b2 * s2 + b3 * s3, u2 = b1 * s2 - b2 * s3 - b3 * s1, u3 = b1 * s3 - b2 * s1 + b3 * s2;
+  x0 = x0 + a1 + a2 + a3;
+  x1 = add_mi(t1, u1); x6 = add_pi(t1, u1);
+  x2 = add_mi(t2, u2); x5 = add_pi(t2, u2);
+  x3 = add_mi(t3, u3); x4 = add_pi(t3, u3);
+}
+
+// 14-point DFT, prime-factor 2 x 7: n = (7 n1 + 2 n2) mod 14, k = (7 k1 + 8 k2) mod 14
+__device__ __forceinline__ void dft14(v2f* v) {
+  v2f A[2][7];
+#pragma unroll
+  for (int n2 = 0; n2 < 7; ++n2) {
+    v2f c0 = v[(0 + 2 * n2) % 14], c1 = v[(7 + 2 * n2) % 14];
+    { const v2f t0 = c0 + c1, t1 = c0 - c1; c0 = t0; c1 = t1; }
+    A[0][n2] = c0; A[1][n2] = c1;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 2; ++k1) {
+    dft7(A[k1][0], A[k1][1], A[k1][2], A[k1][3], A[k1][4], A[k1][5], A[k1][6]);
+#pragma unroll
+    for (int k2 = 0; k2 < 7; ++k2) v[(7 * k1 + 8 * k2) % 14] = A[k1][k2];
+  }
+}
+
+// 21-point DFT, prime-factor 3 x 7: n = (7 n1 + 3 n2) mod 21, k = (7 k1 + 15 k2) mod 21
+__device__ __forceinline__ void dft21(v2f* v) {
+  v2f A[3][7];
+#pragma unroll
+  for (int n2 = 0; n2 < 7; ++n2) {
+    v2f c0 = v[(0 + 3 * n2) % 21], c1 = v[(7 + 3 * n2) % 21], c2 = v[(14 + 3 * n2) % 21];
+    dft3(c0, c1, c2);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    dft7(A[k1][0], A[k1][1], A[k1][2], A[k1][3], A[k1][4], A[k1][5], A[k1][6]);
+#pragma unroll
+    for (int k2 = 0; k2 < 7; ++k2) v[(7 * k1 + 15 * k2) % 21] = A[k1][k2];
+  }
+}
+
+// 28-point DFT, prime-factor 4 x 7: n = (7 n1 + 4 n2) mod 28, k = (21 k1 + 8 k2) mod 28
+__device__ __forceinline__ void dft28(v2f* v) {
+  v2f A[4][7];
+#pragma unroll
+  for (int n2 = 0; n2 < 7; ++n2) {
+    v2f c0 = v[(0 + 4 * n2) % 28], c1 = v[(7 + 4 * n2) % 28], c2 = v[(14 + 4 * n2) % 28], c3 = v[(21 + 4 * n2) % 28];
+    dft4<false>(c0, c1, c2, c3);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2; A[3][n2] = c3;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    dft7(A[k1][0], A[k1][1], A[k1][2], A[k1][3], A[k1][4], A[k1][5], A[k1][6]);
+#pragma unroll
+    for (int k2 = 0; k2 < 7; ++k2) v[(21 * k1 + 8 * k2) % 28] = A[k1][k2];
+  }
+}
+
+// 42-point DFT, prime-factor 6 x 7: n = (7 n1 + 6 n2) mod 42, k = (7 k1 + 36 k2) mod 42
+__device__ __forceinline__ void dft42(v2f* v) {
+  v2f A[6][7];
+#pragma unroll
+  for (int n2 = 0; n2 < 7; ++n2) {
+    v2f cc[6];
+#pragma unroll
+    for (int n1 = 0; n1 < 6; ++n1) cc[n1] = v[(7 * n1 + 6 * n2) % 42];
+    dft6(cc);
+#pragma unroll
+    for (int k1 = 0; k1 < 6; ++k1) A[k1][n2] = cc[k1];
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 6; ++k1) {
+    dft7(A[k1][0], A[k1][1], A[k1][2], A[k1][3], A[k1][4], A[k1][5], A[k1][6]);
+#pragma unroll
+    for (int k2 = 0; k2 < 7; ++k2) v[(7 * k1 + 36 * k2) % 42] = A[k1][k2];
+  }
+}
+
+// 50-point DFT, prime-factor 2 x 25: n = (25 n1 + 2 n2) mod 50, k = (25 k1 + 26 k2) mod 50
+__device__ __forceinline__ void dft50(v2f* v) {
+  v2f A0[25], A1[25];
+#pragma unroll
+  for (int n2 = 0; n2 < 25; ++n2) {
+    const v2f p = v[(2 * n2) % 50], q = v[(25 + 2 * n2) % 50];
+    A0[n2] = p + q; A1[n2] = p - q;
+  }
+  dft25(A0);
+  dft25(A1);
+#pragma unroll
+  for (int k2 = 0; k2 < 25; ++k2) { v[(26 * k2) % 50] = A0[k2]; v[(25 + 26 * k2) % 50] = A1[k2]; }
+}
+
+// 60-point DFT, prime-factor 4 x 15: n = (15 n1 + 4 n2) mod 60, k = (45 k1 + 16 k2) mod 60
+__device__ __forceinline__ void dft60(v2f* v) {
+  v2f A[4][15];
+#pragma unroll
+  for (int n2 = 0; n2 < 15; ++n2) {
+    v2f c0 = v[(4 * n2) % 60], c1 = v[(15 + 4 * n2) % 60], c2 = v[(30 + 4 * n2) % 60], c3 = v[(45 + 4 * n2) % 60];
+    dft4<false>(c0, c1, c2, c3);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2; A[3][n2] = c3;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    dft15(A[k1]);
+#pragma unroll
+    for (int k2 = 0; k2 < 15; ++k2) v[(45 * k1 + 16 * k2) % 60] = A[k1][k2];
+  }
+}
+
+// 64-point DFT, Cooley-Tukey 8 x 8: n = 8 n1 + n2, k = k1 + 8 k2, twiddles W_64^(n2 k1) between the two rounds of dft8
+__device__ __forceinline__ void dft64(v2f* v) {
+  constexpr float kC[8][8] = {{1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f},
+                              {1.0f, 0.99518472667219693f, 0.98078528040323043f, 0.95694033573220882f, 0.92387953251128674f, 0.88192126434835505f, 0.83146961230254524f, 0.77301045336273699f},
+                              {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f},
+                              {1.0f, 0.95694033573220882f, 0.83146961230254524f, 0.63439328416364549f, 0.38268343236508984f, 0.09801714032956077f, -0.19509032201612819f, -0.4713967368259977f},
+                              {1.0f, 0.92387953251128674f, 0.70710678118654757f, 0.38268343236508984f, 6.123233995736766e-17f, -0.38268343236508973f, -0.70710678118654746f, -0.92387953251128674f},
+                              {1.0f, 0.88192126434835505f, 0.55557023301960229f, 0.09801714032956077f, -0.38268343236508973f, -0.77301045336273699f, -0.98078528040323043f, -0.95694033573220894f},
+                              {1.0f, 0.83146961230254524f, 0.38268343236508984f, -0.19509032201612819f, -0.70710678118654746f, -0.98078528040323043f, -0.92387953251128685f, -0.55557023301960218f},
+                              {1.0f, 0.77301045336273699f, 0.19509032201612833f, -0.4713967368259977f, -0.92387953251128674f, -0.95694033573220894f, -0.55557023301960218f, 0.09801714032956009f}};
+  constexpr float kS[8][8] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f},
+                              {0.0f, 0.098017140329560604f, 0.19509032201612825f, 0.29028467725446233f, 0.38268343236508978f, 0.47139673682599764f, 0.55557023301960218f, 0.63439328416364549f},
+                              {0.0f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f},
+                              {0.0f, 0.29028467725446233f, 0.55557023301960218f, 0.77301045336273699f, 0.92387953251128674f, 0.99518472667219682f, 0.98078528040323043f, 0.88192126434835505f},
+                              {0.0f, 0.38268343236508978f, 0.70710678118654746f, 0.92387953251128674f, 1.0f, 0.92387953251128674f, 0.70710678118654757f, 0.38268343236508989f},
+                              {0.0f, 0.47139673682599764f, 0.83146961230254524f, 0.99518472667219682f, 0.92387953251128674f, 0.63439328416364549f, 0.19509032201612861f, -0.29028467725446211f},
+                              {0.0f, 0.55557023301960218f, 0.92387953251128674f, 0.98078528040323043f, 0.70710678118654757f, 0.19509032201612861f, -0.38268343236508967f, -0.83146961230254524f},
+                              {0.0f, 0.63439328416364549f, 0.98078528040323043f, 0.88192126434835505f, 0.38268343236508989f, -0.29028467725446211f, -0.83146961230254524f, -0.99518472667219693f}};
+  v2f Y[8][8];
+#pragma unroll
+  for (int n2 = 0; n2 < 8; ++n2) {
+    v2f cc[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) cc[n1] = v[8 * n1 + n2];
+    dft8<false>(cc);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) Y[k1][n2] = cc[k1];
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 8; ++k1) {
+#pragma unroll
+    for (int n2 = 1; n2 < 8; ++n2)
+      if (k1 > 0) Y[k1][n2] = cmulc<false>(Y[k1][n2], kC[k1][n2], -kS[k1][n2]);
+    dft8<false>(Y[k1]);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) v[k1 + 8 * k2] = Y[k1][k2];
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void dft_n(v2f* v) {
-  static_assert(N == 4 || N == 8 || N == 10 || N == 12 || N == 15 || N == 16 || N == 20 || N == 24 || N == 25 || N == 30 || N == 32 || N == 40 || N == 48, "no codelet for this length");
+  static_assert(N == 4 || N == 8 || N == 10 || N == 12 || N == 14 || N == 15 || N == 16 || N == 20 || N == 21 || N == 24 || N == 25 || N == 28 || N == 30 || N == 32 ||
+                N == 40 || N == 42 || N == 48 || N == 50 || N == 60 || N == 64, "no codelet for this length");
   if constexpr (N == 4) dft4<false>(v[0], v[1], v[2], v[3]);
   else if constexpr (N == 8) dft8<false>(v);
   else if constexpr (N == 10) dft10(v);
@@ -243,6 +400,13 @@ __device__ __forceinline__ void dft_n(v2f* v) {
   else if constexpr (N == 30) dft30(v);
   else if constexpr (N == 32) dft32(v);
   else if constexpr (N == 40) dft40(v);
+  else if constexpr (N == 14) dft14(v);
+  else if constexpr (N == 21) dft21(v);
+  else if constexpr (N == 28) dft28(v);
+  else if constexpr (N == 42) dft42(v);
+  else if constexpr (N == 50) dft50(v);
+  else if constexpr (N == 60) dft60(v);
+  else if constexpr (N == 64) dft64(v);
   else dft48(v);
 }
 

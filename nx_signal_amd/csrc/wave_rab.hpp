@@ -25,6 +25,10 @@
 #define NXSIG_RAB_PART2(X) X(500, 25, 20) X(600, 30, 20) X(720, 30, 24) X(768, 32, 24) X(800, 32, 25) X(900, 30, 30)
 #define NXSIG_RAB_PART3(X) X(1000, 40, 25) X(1200, 40, 30) X(1280, 40, 32) X(1600, 40, 40)
 #define NXSIG_RAB_PART5(X) X(192, 16, 12) X(288, 24, 12) X(576, 24, 24) X(1152, 48, 24) X(1440, 48, 30) X(1536, 48, 32) X(1920, 48, 40)
+// round 6: radix 7 (the 20 / 40 ms frames of 44.1 kHz audio) and the 50 / 60 / 80 ms frames of 48 kHz audio; complex-spectrum sink only
+// (log-mel / magnitude sinks of these lengths take the two-step path).  882 % 4 == 2: fine for the spectrum sink's bin pairs.
+#define NXSIG_RAB_PART6(X) X(882, 42, 21) X(1764, 42, 42)
+#define NXSIG_RAB_PART7(X) X(2400, 50, 48) X(2880, 60, 48) X(3840, 64, 60)
 // inverse only: power-of-two frame lengths with a hop the N / hop in {1, 2, 4, 8} kernels of kernels_wave.hip do not take (e.g. 512 / 160)
 #define NXSIG_RAB_INVERSE_ONLY(X) X(128, 16, 8) X(256, 16, 16) X(512, 32, 16) X(1024, 32, 32)
 
@@ -329,8 +333,9 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
   }
 }
 
-template <int A, int B>
+template <int A, int B, bool ALL_SINKS = true>
 inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch* mel) {
+  if (!ALL_SINKS && mel) return NXSIG_OK;   // spectrum sink only for this length: the caller's two-step path serves the other sinks
   // four waves per workgroup, short-lived workgroups.  (ONE workgroup per CU sized to fill the LDS — 6 ... 12 waves for 720 ... 960, what
   // the persistent inverse kernels gain 40-70 % from — measured 0.46 / 0.59 / 0.55 / 0.50 / 0.56 against 0.52 / 0.56 / 0.55 / 0.50 / 0.60
   // here for 720 / 768 / 800 / 900 / 960: the blocks retire together and the CU idles between them)
@@ -338,7 +343,10 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   // (1920: four waves would need 87 KB — one workgroup, four waves per CU; eight share the tables in 150 KB)
-  constexpr int W = (KB * 12 + 4 * BUF * 8 > 80 * 1024) ? 8 : 4, WM = W;   // WM: the log-mel sink
+  // (round 6: lengths above 1920 cannot hold eight exchange buffers: as many waves as fit 160 KB beside the tables — 6 / 5 / 3 for 2400 / 2880 / 3840)
+  constexpr int W_FIT = (160 * 1024 - KB * 12) / (BUF * 8);
+  constexpr int W = (KB * 12 + 4 * BUF * 8 > 80 * 1024) ? (W_FIT < 8 ? W_FIT : 8) : 4, WM = W;   // WM: the log-mel sink
+  static_assert(W >= 1, "the tables and one exchange buffer must fit the LDS");
   const int nuse = s.fr.N < KB ? s.fr.N : KB;
   const int64_t span = (2 * T - 1) * (int64_t)s.fr.hop + nuse;
   if (LT < 30 && span + 3 > 2560) return NXSIG_OK;   // the unit's span must fit the prefetch registers (used below 30-point codelets only)
@@ -420,10 +428,14 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
-  int rc;
-  if (sink == kSinkMel) rc = s.has_scale ? go(k_stft_rab<A, B, true, WM, kSinkMel>) : go(k_stft_rab<A, B, false, WM, kSinkMel>);
-  else if (sink == kSinkMag) rc = s.has_scale ? go(k_stft_rab<A, B, true, W, kSinkMag>) : go(k_stft_rab<A, B, false, W, kSinkMag>);
-  else rc = s.has_scale ? go(k_stft_rab<A, B, true, W>) : go(k_stft_rab<A, B, false, W>);
+  int rc = NXSIG_OK;
+  if constexpr (ALL_SINKS) {
+    if (sink == kSinkMel) rc = s.has_scale ? go(k_stft_rab<A, B, true, WM, kSinkMel>) : go(k_stft_rab<A, B, false, WM, kSinkMel>);
+    else if (sink == kSinkMag) rc = s.has_scale ? go(k_stft_rab<A, B, true, W, kSinkMag>) : go(k_stft_rab<A, B, false, W, kSinkMag>);
+    else rc = s.has_scale ? go(k_stft_rab<A, B, true, W>) : go(k_stft_rab<A, B, false, W>);
+  } else {
+    rc = s.has_scale ? go(k_stft_rab<A, B, true, W>) : go(k_stft_rab<A, B, false, W>);
+  }
   if (rc) return rc;
   if (sink == kSinkMel) return launch_mel_finish(c, mel->out, (int64_t)s.batch * s.fr.M * mel->mel_bins, b.gmax);
   if (sink == kSinkMag && mel->mag_kind == 2) {
@@ -577,9 +589,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
 
 template <int A, int B>
 inline int launch_rab_c64(Ctx* c, const StftLaunch& s, bool* handled) {
-  constexpr int W = 4, KB = A * B, LT = A > B ? A : B, T = 64 / LT;
+  constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT;
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
+  constexpr int W_FIT = (160 * 1024 - KB * 12) / (BUF * 8), W = W_FIT < 4 ? W_FIT : 4;   // (3840 = 64 x 60: three exchange buffers beside the tables)
+  static_assert(W >= 1, "the tables and one exchange buffer must fit the LDS");
   if ((int64_t)(T - 1) * s.fr.hop + KB + LT > BUF) return NXSIG_OK;   // the unit's span (idle lanes' reads included) must fit the wave's buffer
   if ((reinterpret_cast<uintptr_t>(s.z) & 15) != 0) return NXSIG_OK;
   *handled = true;
@@ -645,7 +659,7 @@ struct IstftRabArgs {
 // ODD: the hop is odd (8-byte LDS gathers and stores instead of 16-byte ones).  The scale factor is always multiplied in (1.0f when the
 // call has none: exact), so the two instantiations per length are the two hop parities
 template <int A, int B, bool ODD, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_istft_rab(IstftRabArgs a) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((A > 48 || B > 48) ? 1 : 2, 3))) void k_istft_rab(IstftRabArgs a) {   // (50- / 60- / 64-point codelets: one to three waves per CU fit the LDS anyway; 256 registers spilled 220-720 B)
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT, CMAX = KB;
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;

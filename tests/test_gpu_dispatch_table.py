@@ -105,9 +105,15 @@ DISPATCH = {
     "stft320": (_stft, (320, 80, 320, 2, 400), {}, "stft.rab"),
     "stft960": (_stft, (960, 240, 960, 2, 200), {}, "stft.rab"),
     "stft1920": (_stft, (1920, 480, 1920, 2, 100), {}, "stft.rab"),
+    "stft882-radix7": (_stft, (882, 220, 882, 2, 200), {}, "stft.rab"),
+    "stft1764-radix7": (_stft, (1764, 441, 1764, 2, 100), {}, "stft.rab"),
+    "stft2400": (_stft, (2400, 600, 2400, 2, 60), {}, "stft.rab"),
+    "stft3840": (_stft, (3840, 960, 3840, 2, 40), {}, "stft.rab"),
+    "stft441-default-fft-length-512": (_stft, (441, 110, 512, 2, 400), {}, "stft.quad2"),   # fft_length defaults to :power_of_two in the reference (lib/nx_signal.ex:78)
+    "stft2400-default-fft-length-4096": (_stft, (2400, 600, 4096, 2, 60), {}, "stft.real2x.4k"),
     "stft441-bluestein": (_stft, (441, 110, 441, 2, 400), {}, "stft.blue"),
     "stft1020-bluestein": (_stft, (1020, 255, 1020, 2, 200), {}, "stft.blue"),
-    "stft2400-generic": (_stft, (2400, 600, 2400, 2, 50), {}, "stft.generic.blue"),
+    "stft2205-generic": (_stft, (2205, 551, 2205, 2, 50), {}, "stft.generic.blue"),
     "stft16-generic": (_stft, (16, 4, 16, 2, 400), {}, "stft.generic.pow2"),
     # ---- stft, c64 samples (3.1c)
     "stft-c64-512": (_stft, (512, 128, 512, 2, 400), {"cplx": True}, "stft_c64.rab"),
@@ -122,6 +128,8 @@ DISPATCH = {
     "istft400": (_istft, (400, 160, 2, 400), {}, "istft.r20+istft.edge_chunks"),
     "istft960": (_istft, (960, 240, 2, 200), {}, "istft.rab+istft.edge_chunks"),
     "istft512-hop160": (_istft, (512, 160, 2, 400), {}, "istft.rab+istft.edge_chunks"),
+    "istft1764-radix7": (_istft, (1764, 441, 2, 100), {}, "istft.rab"),
+    "istft2880": (_istft, (2880, 720, 2, 60), {}, "istft.rab"),
     "istft441-generic": (_istft, (441, 110, 2, 400), {}, "fft.rows_generic.blue+istft.generic+istft.edge_fix"),
     # ---- fir (3.3)
     "fir257": (_fir, (257, 2, 1 << 20), {}, "fir.pair+fir.pair.edge"),

@@ -1074,7 +1074,7 @@ int nxsig_stft_c64(nxsig_ctx* ctx, const nxsig_c64* x, int64_t length, int32_t b
   if (!x || !window || !p || !z) return set_error(NXSIG_ERR_INVALID_ARG, "stft: null pointer argument");
   int rc = check_mem(mem);
   if (rc) return rc;
-  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch must be in [1, 65535]");
+  if (batch < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch must be >= 1");   // (more than 65 504 rows: slabs, see launch_stft_c64)
   if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch_stride < length");
   if (p->fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft: fft_length must be >= 1");
   rc = check_scaling(p->scaling);

@@ -489,6 +489,26 @@ int nxsig_group_allreduce_f64(nxsig_group* grp, double* values, int32_t n, int32
   NXSIG_API_END
 }
 
+// Ranked groups (one process per GPU): before the ASSEMBLY collective of a call without an exchange step every process says whether
+// its own part went well — one word, all-reduced (max) — so that a rank whose allocation, upload or kernel failed does not leave its
+// peers waiting in an all-gather it never joins: either everybody gathers or everybody returns an error (its own, or "a peer failed").
+// Local groups and groups without RCCL see only their own status.
+static int agree_before_gather_locked(Group* g, int local_rc, bool* any_failed) {
+  *any_failed = local_rc != NXSIG_OK;
+  if (!(g->ranked && g->world > 1 && g->has_rccl)) return NXSIG_OK;
+  Rccl* R = rccl();
+  Member& mb = g->m[0];
+  NXSIG_HIP_TRY(hipSetDevice(mb.device));
+  hipStream_t s = stream_of(mb);
+  double v = local_rc ? 1.0 : 0.0;
+  NXSIG_HIP_TRY(hipMemcpyAsync(mb.cell + 96, &v, sizeof(double), hipMemcpyHostToDevice, s));
+  NXSIG_NCCL_TRY(R, R->AllReduce(mb.cell + 96, mb.cell + 97, 1, ncclDouble, ncclMax, mb.comm, s));
+  NXSIG_HIP_TRY(hipMemcpyAsync(&v, mb.cell + 97, sizeof(double), hipMemcpyDeviceToHost, s));
+  NXSIG_HIP_TRY(hipStreamSynchronize(s));
+  *any_failed = v != 0.0;
+  return NXSIG_OK;
+}
+
 static int allgather_locked(Group* g, const void* const* send, const int64_t* counts, void* const* recv) {
   const int W = g->world;
   std::vector<int64_t> off(W + 1, 0);
@@ -682,7 +702,16 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
       rc = exchange(dsts, local_rc);
       if (local_rc) { drop_tmp(); return set_error(local_rc, local_msg); }
       if (rc) { drop_tmp(); return rc; }
-    } else if (local_rc) { drop_tmp(); return set_error(local_rc, local_msg); }
+    } else {
+      if (local_rc && !gather) { drop_tmp(); return set_error(local_rc, local_msg); }
+      if (gather) {   // the assembly is a collective: agree first (a failed rank used to skip it and its peers hung)
+        bool any = false;
+        const int rca = agree_before_gather_locked(g, local_rc, &any);
+        if (local_rc) { drop_tmp(); return set_error(local_rc, local_msg); }
+        if (rca) { drop_tmp(); return rca; }
+        if (any) { drop_tmp(); return set_error(NXSIG_ERR_HIP, "sharded: another rank of the group failed before the assembly; nothing was gathered"); }
+      }
+    }
     if (!gather) return NXSIG_OK;
     if (by_row_segments) {
       rc = assemble_rows_locked(g, pl, send.data(), out);
@@ -779,6 +808,17 @@ int run_sharded(Group* g, const Plan& pl, const void* const* x, int64_t batch_st
     on_every_member(fetch);
   } else {
     on_every_member([&](size_t i) { work(i); fetch(i); });
+  }
+  if constexpr (!kExchange) {
+    if (gather) {   // every rank joins this word before anybody enters the assembly (see agree_before_gather_locked)
+      int lrc = NXSIG_OK;
+      for (size_t i = 0; i < nl && !lrc; ++i) lrc = rcs[i];
+      bool any = false;
+      const int rca = agree_before_gather_locked(g, lrc, &any);
+      if ((rc = first_failure())) return rc;
+      if (rca) { std::string keep = nxsig_last_error(); cleanup(); return set_error(rca, keep); }
+      if (any) { cleanup(); return set_error(NXSIG_ERR_HIP, "sharded: another rank of the group failed before the assembly; nothing was gathered"); }
+    }
   }
   if ((rc = first_failure())) return rc;
   if (gather) {

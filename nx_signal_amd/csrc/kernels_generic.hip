@@ -1444,6 +1444,17 @@ int launch_stft_rab_c64(Ctx* c, const StftLaunch& s, bool* handled);    // kerne
 
 int launch_stft_c64(Ctx* c, const StftLaunch& s) {
   if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
+  if (s.batch > 65504) {   // rows are independent: slabs of 65 504 rows like launch_stft (the frame-gather kernel puts the row on gridDim.y)
+    for (int32_t r0 = 0; r0 < s.batch; r0 += 65504) {
+      StftLaunch b = s;
+      b.batch = s.batch - r0 < 65504 ? s.batch - r0 : 65504;
+      b.x = reinterpret_cast<const float*>(reinterpret_cast<const float2*>(s.x) + (size_t)r0 * s.batch_stride);
+      b.z = s.z + (size_t)r0 * s.fr.M * s.K;
+      int rcs = launch_stft_c64(c, b);
+      if (rcs) return rcs;
+    }
+    return NXSIG_OK;
+  }
   bool handled = false;
   int rc = launch_stft_rab_c64(c, s, &handled);   // 100 ... 1600 (1024 as 32 x 32: 0.42 against 0.39 on the framed row kernel)
   if (rc || handled) return rc;

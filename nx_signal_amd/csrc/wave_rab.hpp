@@ -387,6 +387,11 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
     if ((rcm = launch_mel_init(c, &b.gmax))) return rcm;
     lds_extra = (size_t)b.nnz * 4 + (size_t)(2 * mel->mel_bins + 1) * 4;
   }
+  {  // the launch must fit the LDS BEFORE the call is committed: a dense filterbank beside the 150 KB of the 1920-point kernel does not,
+     // and the caller's two-step path takes it (it used to surface as a HIP launch error after *handled was set)
+    const int wl = sink == kSinkMel ? WM : W;
+    if ((size_t)KB * 12 + (size_t)wl * BUF * 8 + lds_extra > (size_t)160 * 1024) return NXSIG_OK;
+  }
   *handled = true;
   if (mel) *mel->handled = true;
   WaveArgs& a = b.w;

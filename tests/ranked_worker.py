@@ -103,6 +103,26 @@ def main():
     whole = sharding.fir_sharded(g, [ctx.to_device(np.ascontiguousarray(xf[:, s0:s1]))], h, mode="same", axis="samples", gather=True, length=L, batch=2)[0].numpy()
     assert whole.shape == yfull.shape and not np.isfinite(whole[1]).any(), "assembled sample shards: the non-finite row"
     assert float(np.max(np.abs(whole[0] - yfull[0])) / np.max(np.abs(yfull[0]))) < 1e-6, "assembled sample shards: the clean row"
+    # a rank whose own part FAILS must not leave its peers waiting in the assembly collective (round 6: one status word is all-reduced
+    # before the gather): the last rank hands in a null shard; every rank gets an error back — its own, or "another rank ... failed" —
+    # and the group keeps working afterwards
+    import ctypes as C
+
+    from nx_signal_amd import _lib
+    if world > 1:
+        lib = _lib.load()
+        xs_ok = ctx.to_device(x[c0:c1])
+        zs_buf = ctx.empty((B, full.shape[1], N), np.complex64)
+        pst = _lib.StftParams(N, hop, N, _lib.PAD_VALID, 0, 0, _lib.SCALE_NONE, 0, 48000.0)
+        xs = (C.c_void_p * 1)(C.c_void_p(0 if rank == world - 1 else xs_ok.ptr))
+        zs = (C.c_void_p * 1)(C.c_void_p(zs_buf.ptr))
+        rcf = lib.nxsig_stft_sharded_f32(g.handle, xs, L, B, L, w.ctypes.data_as(C.c_void_p), C.byref(pst), _lib.SHARD_CHANNELS, 1, zs, _lib.DEVICE)
+        msg = _lib.last_error()
+        assert rcf != 0, "a failed rank must fail the assembled call on every rank"
+        assert ("null shard pointer" in msg) if rank == world - 1 else ("another rank" in msg), msg
+        outs = sharding.stft_sharded(g, [xs_ok], w, axis="channels", gather=True, length=L, batch=B, **opts)   # the group is still usable
+        ctx.sync()
+        assert np.array_equal(outs[0].numpy().view(np.uint32), full.view(np.uint32)), "the call after the failed one"
     g.barrier()
     print(f"RANKED-OK rank {rank} of {world}", file=sys.stderr, flush=True)
     g.close()

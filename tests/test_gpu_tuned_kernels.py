@@ -831,6 +831,14 @@ def test_more_rows_than_one_launch_takes():
     f = S.filters.fir(xd, h, mode="same", ctx=ctx).numpy()
     fs = S.filters.fir(ctx.to_device(np.ascontiguousarray(x[pick])), h, mode="same", ctx=ctx).numpy()
     assert float(np.max(np.abs(f[pick] - fs))) < 1e-6
+    # complex samples (nxsig_stft_c64, round 6: the same slabs; the limit used to be 65 535 rows): a native A x B length and a two-step one
+    for Kc in (64, 48):
+        xc = (x[:, :300] + 1j * x[:, 300:600]).astype(np.complex64)
+        wc = S.windows.hann(Kc)
+        oc = dict(overlap_length=Kc // 2, fft_length=Kc, sampling_rate=16000)
+        zc = S.stft(ctx.to_device(xc), wc, ctx=ctx, **oc)[0].numpy()
+        zcs = S.stft(ctx.to_device(np.ascontiguousarray(xc[pick])), wc, ctx=ctx, **oc)[0].numpy()
+        assert np.array_equal(zc[pick].view(np.uint32), zcs.view(np.uint32)), Kc
 
 
 def test_host_tensor_paths_return_the_same_bytes():

@@ -1256,7 +1256,7 @@ static int launch_istft_wave_R(Ctx* c, const IstftLaunch& s, const float* window
                                                                                          // complex values per lane: 2 waves per SIMD  // = resident waves per CU: one even round
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
   // (a floor of 8 left a single 60 s stream with 1 406 runs of 8 + 3 frames for 2 048 wave slots: 2.58 TB/s against 2.96 at 4 ... 6)
-  const int min_run = tune(c, kT_ISTFT_MIN_RUN, (!HALF && !DBL) ? 4 : 8);   // (N = 512 / 2048: 8 stays 1 ... 3 % ahead)
+  const int min_run = istft_min_run(c, total_segs, (int64_t)c->num_cus * waves_per_cu, (!HALF && !DBL) ? 4 : 8);   // (N = 512 / 2048: 8 stays 1 ... 3 % ahead)
   if (run_len < min_run) run_len = min_run;
   if (HALF) run_len = (run_len + 1) & ~(int64_t)1;  // frame pairs: runs start at even segments
   a.run_len = run_len;
@@ -1356,7 +1356,7 @@ static int launch_istft_wave_quad(Ctx* c, const IstftLaunch& s, const float* win
                                                                     // for N = 256 / 128, 8 x 60 s; a two-units-ahead prefetch like k_istft_wave's
                                                                     // DEEP form measured -3 ... +3 % here and was not kept)
   int64_t run_len = (total_units + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
-  const int min_run = tune(c, kT_ISTFT_MIN_RUN, 8);
+  const int min_run = istft_min_run(c, total_units, (int64_t)c->num_cus * waves_per_cu, 8);
   if (run_len < min_run) run_len = min_run;
   a.run_len = run_len;
   a.runs_per_row = (units_per_row + run_len - 1) / run_len;
@@ -1416,7 +1416,7 @@ static int launch_istft_wave_4k(Ctx* c, const IstftLaunch& s, const float* windo
   const int64_t total_segs = a.segs_per_row * s.batch;
   const int waves_per_cu = 4;  // one wave per SIMD
   int64_t run_len = (total_segs + (int64_t)c->num_cus * waves_per_cu - 1) / ((int64_t)c->num_cus * waves_per_cu);
-  const int min_run = tune(c, kT_ISTFT_MIN_RUN, 8);
+  const int min_run = istft_min_run(c, total_segs, (int64_t)c->num_cus * waves_per_cu, 8);
   if (run_len < min_run) run_len = min_run;
   a.run_len = run_len;
   a.runs_per_row = (a.segs_per_row + run_len - 1) / run_len;
@@ -1688,7 +1688,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
     if (units_per_row <= 0) return NXSIG_OK;
     a.units_per_row = units_per_row;
     a.total_units = units_per_row * s.batch;
-    const int units_per_wave = tune(c, kT_FIR_UNITS_PER_WAVE, 8);  // short chunks, many workgroups (see launch_wave)
+    const int units_per_wave = c->tuning.set[kT_FIR_UNITS_PER_WAVE] ? tune(c, kT_FIR_UNITS_PER_WAVE, 8) : fill_units_per_wave(c, a.total_units, W, 8);  // short chunks, many workgroups (see launch_wave); small launches spread out
     a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
     // the edge launch has few, slow (bounds-checked) units: one per wave so that they all run concurrently, unless every pair
     // goes through it (filters whose taps - 1 is not a multiple of 128)
@@ -1746,7 +1746,7 @@ static int launch_fir_wave_W(Ctx* c, const FirLaunch& s_in, bool* handled) {
       constexpr int W4 = 4;
       b.units_per_row = 2 * (a.pb_hi - a.pb_lo);
       b.total_units = b.units_per_row * s.batch;
-      b.chunk = (int64_t)W4 * tune(c, kT_FIR_UNITS_PER_WAVE, 8);
+      b.chunk = (int64_t)W4 * (c->tuning.set[kT_FIR_UNITS_PER_WAVE] ? tune(c, kT_FIR_UNITS_PER_WAVE, 8) : fill_units_per_wave(c, b.total_units, W4, 8));
       const int64_t blocks = (b.total_units + b.chunk - 1) / b.chunk;
       if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: signal too long for one launch");
       const size_t lds4 = 256 * 8 + (size_t)4 * 256 * 8 + (size_t)1024 * 8 + (size_t)W4 * (1024 + 64 + 16) * 8;

@@ -192,7 +192,7 @@ int launch_stft_wave_8k(Ctx* c, const StftLaunch& s, bool* handled) {
     if (per_row <= 0) return NXSIG_OK;
     a.per_row = per_row; a.m_split = split; a.m_add0 = add0; a.m_add1 = add1;
     a.total_frames = per_row * s.batch;
-    a.chunk = (int64_t)W * (fpw < 1 ? 1 : fpw);
+    a.chunk = (int64_t)W * fill_units_per_wave(c, a.total_frames, W, fpw < 1 ? 1 : fpw);
     const int64_t blocks = (a.total_frames + a.chunk - 1) / a.chunk;
     if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
     NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

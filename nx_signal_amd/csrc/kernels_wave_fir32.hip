@@ -230,7 +230,7 @@ int launch_fir_wave32(Ctx* c, const float* x, int64_t batch_stride, int32_t batc
       a.tw = reinterpret_cast<const v2f*>(d);
     }
   }
-  const int units_per_wave = 4;
+  const int units_per_wave = fill_units_per_wave(c, a.total_dp, W, 4);
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   const int64_t blocks = (a.total_dp + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fir: signal too long for one launch");

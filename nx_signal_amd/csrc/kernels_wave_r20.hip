@@ -365,7 +365,7 @@ int launch_stft_r20(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunch*
   int rc = ctx_table(c, 0x20A20ull, tw.data(), tw.size() * sizeof(float2), &dt);
   if (rc) return rc;
   b.tw = reinterpret_cast<const v2f*>(dt);
-  const int units_per_wave = (sink == kSinkMel ? 8 : 2);  // the mel sink amortises its CSR preload
+  const int units_per_wave = fill_units_per_wave(c, b.total_units, W, sink == kSinkMel ? 8 : 2);  // the mel sink amortises its CSR preload
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   const int64_t blocks = (b.total_units + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
@@ -609,7 +609,8 @@ int launch_istft_r20(Ctx* c, const IstftLaunch& s, const float* window_host, boo
   const int64_t segs = (a.out_len + hop - 1) / hop;              // hop segments of the output (the last may be partial)
   a.units_per_row = (segs + 2) / 3;
   const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, W);  // = resident waves per CU
-  const int64_t run_len = istft_balanced_run_len(a.units_per_row, s.batch, (int64_t)c->num_cus * waves_per_cu, (RP - 1 + 2) / 3, 8);
+  const int64_t run_len = istft_balanced_run_len(a.units_per_row, s.batch, (int64_t)c->num_cus * waves_per_cu, (RP - 1 + 2) / 3,
+                                                 istft_min_run(c, a.units_per_row * s.batch, (int64_t)c->num_cus * waves_per_cu, 8));
   a.run_len = run_len;
   a.runs_per_row = (a.units_per_row + run_len - 1) / run_len;
   a.total_runs = a.runs_per_row * s.batch;

@@ -265,7 +265,7 @@ int launch_fft_rows_wave_framed(Ctx* c, const void* in, bool in_is_real, int64_t
     a.pre_window = fr->pre_window; a.div = fr->div; a.has_div = fr->has_div;
   }
   constexpr int W = 4;
-  const int rpw = (K == 4096 ? 2 : 4);
+  const int rpw = fill_units_per_wave(c, rows, 4, K == 4096 ? 2 : 4);
   a.chunk = (int64_t)W * (rpw < 1 ? 1 : rpw);
   const int64_t blocks = (rows + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "fft: too many rows for one launch");

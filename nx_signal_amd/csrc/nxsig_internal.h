@@ -161,6 +161,25 @@ struct Ctx {
 // value of a switch for this context, or the launcher's default when nobody set it
 static inline int tune(const Ctx* c, TuneKey k, int dflt) { return c->tuning.set[k] ? (int)c->tuning.v[k] : dflt; }
 
+// Units per wave of a short-lived-workgroup launch (round 6): the measured optimum `dflt` of a launch that runs for many rounds of
+// workgroups — but a launch with fewer workgroups than three per CU is ONE round, what sets its time is the longest wave, and it should
+// spread over the chip instead (a 10 s utterance at 16 kHz in 400 / 512 framing: 250 units = 16 workgroups at 4 units per wave, 24.4 us;
+// at one unit per wave 63 workgroups, 15.4 us; config 1's 2048-point twin 23.5 -> 7.2 us: profiles/r06/small_launch_units_per_wave.txt)
+static inline int fill_units_per_wave(const Ctx* c, int64_t total_units, int W, int dflt) {
+  const int64_t slots = (int64_t)c->num_cus * 3 * W;
+  const int64_t fill = (total_units + slots - 1) / slots;
+  return fill < dflt ? (fill < 1 ? 1 : (int)fill) : dflt;
+}
+
+// Shortest run of the persistent inverse kernels (every run recomputes its halo, so long runs pay less of it — but a launch with fewer
+// units than two per wave slot is ONE partial round, and what sets its time is the length of a run: 1 s of audio, 184 frames, ran as 23
+// runs of 8 + 3 frames on 23 of 2 048 wave slots).  Such launches take runs of 2: N = 1024 one second 29.8 -> 19.9 us, N = 2048 ten
+// seconds 61 -> 40 us, N = 256 36 -> 19 us (profiles/r06/small_launch_istft_min_run.txt).  NXSIG_ISTFT_MIN_RUN overrides.
+static inline int istft_min_run(const Ctx* c, int64_t total_units, int64_t slots, int dflt) {
+  if (c->tuning.set[kT_ISTFT_MIN_RUN]) return (int)c->tuning.v[kT_ISTFT_MIN_RUN];
+  return total_units <= 2 * slots ? 2 : dflt;
+}
+
 // Set (for the calling THREAD and one context) by the sharded log-mel of group.cpp while it runs pass 1 on a member: the clamp
 // pass of stft_to_mel / the fused mel sink is NOT launched — the running maximum of the member's shard must first be
 // all-reduced with the other members'; the group launches the pass afterwards.  Thread-local on purpose: another thread that

@@ -421,7 +421,7 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
     b.tw = reinterpret_cast<const v2f*>(dt);
   }
   const int w = sink == kSinkMel ? WM : W;
-  a.chunk = (int64_t)w * (sink == kSinkMel ? 8 : 4);   // four units per wave (two: -1 ... -3 %), short-lived workgroups; the mel sink amortises its CSR preload
+  a.chunk = (int64_t)w * fill_units_per_wave(c, b.total_units, w, sink == kSinkMel ? 8 : 4);   // four units per wave (two: -1 ... -3 %), short-lived workgroups; the mel sink amortises its CSR preload
   const int64_t blocks = (b.total_units + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
   const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)w * BUF * 8 + lds_extra;
@@ -624,7 +624,7 @@ inline int launch_rab_c64(Ctx* c, const StftLaunch& s, bool* handled) {
     c->memo[key] = {reinterpret_cast<uint64_t>(dt)};
     a.tw = reinterpret_cast<const v2f*>(dt);
   }
-  a.chunk = (int64_t)W * 4;
+  a.chunk = (int64_t)W * fill_units_per_wave(c, a.total_units, W, 4);
   const int64_t blocks = (a.total_units + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
   const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)W * BUF * 8;
@@ -884,7 +884,8 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   const int64_t segs = (a.out_len + hop - 1) / hop;              // hop segments of the output (the last may be partial)
   a.units_per_row = (segs + T - 1) / T;
   const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, W);  // = resident waves per CU
-  const int64_t run_len = istft_balanced_run_len(a.units_per_row, s.batch, (int64_t)c->num_cus * waves_per_cu, (RP - 1 + T - 1) / T, 8);
+  const int64_t run_len = istft_balanced_run_len(a.units_per_row, s.batch, (int64_t)c->num_cus * waves_per_cu, (RP - 1 + T - 1) / T,
+                                                 istft_min_run(c, a.units_per_row * s.batch, (int64_t)c->num_cus * waves_per_cu, 8));
   a.run_len = run_len;
   a.runs_per_row = (a.units_per_row + run_len - 1) / run_len;
   a.total_runs = a.runs_per_row * s.batch;

@@ -1385,11 +1385,12 @@ static int launch_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = nullp
                                  : tune(c, kT_WAVE_UNITS_PER_WAVE, MODE == kModePair ? 2 : (MODE == kModeQuad ? (J == 8 ? 8 : 4) : 8));  // measured optima, input
                                  // from HBM (round 3, tools/bench_configs.py gen512 / gen256 / gen128 with NXSIG_BENCH_ALT_INPUTS=4: 4 units per
                                  // wave 0.646 / 0.631 of 8 TB/s against 0.591 / 0.611 at round 2's 2 / 3; fft_length 128: 8 -> 0.593 against 0.572)
-  a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
+  const int upw_fill = c->tuning.set[kT_WAVE_UNITS_PER_WAVE] ? units_per_wave : fill_units_per_wave(c, a.total_pairs, W, units_per_wave < 1 ? 1 : units_per_wave);
+  a.chunk = (int64_t)W * (upw_fill < 1 ? 1 : upw_fill);
   // a launch so small that its workgroups all fit on the chip at once (three per CU; BASELINE config 2 as written: one 60 s
   // stream, 703 workgroups) is one round of start-up latencies: three pairs per wave amortise them better than two (+1.5 ... 2.6 %
   // in interleaved sweeps, tools/sweep_stft.py with SWEEP_B=1; the steady-state optimum of many rounds stays at two)
-  if (MODE == kModePair && !mel && units_per_wave == 2 && !c->tuning.set[kT_WAVE_UNITS_PER_WAVE] &&
+  if (MODE == kModePair && !mel && upw_fill == 2 && !c->tuning.set[kT_WAVE_UNITS_PER_WAVE] &&
       (a.total_pairs + 2 * W - 1) / (2 * W) <= (int64_t)c->num_cus * 3)
     a.chunk = (int64_t)W * 3;
   // small_chunk > 0 (launch_stft_wave's one-round geometry): the caller sized the chunk so that every CU holds ONE workgroup of W waves
@@ -1662,7 +1663,7 @@ static int launch_blue_wave(Ctx* c, const StftLaunch& s, const MelLaunch* mel = 
     if ((rcm = launch_mel_init(c, &b.gmax))) return rcm;
     lds += (size_t)b.nnz * 4 + (size_t)(2 * mel->mel_bins + 1) * 4;
   }
-  const int units_per_wave = 4;
+  const int units_per_wave = fill_units_per_wave(c, a.total_pairs, W, 4);
   a.chunk = (int64_t)W * (units_per_wave < 1 ? 1 : units_per_wave);
   const int64_t blocks = (a.total_pairs + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");

@@ -13,7 +13,8 @@ from nx_signal_amd import _lib  # noqa: E402
 
 knob, vals = sys.argv[1], sys.argv[2:]
 N = int(os.environ.get("SWEEP_N", 1024))
-hop, L, B = N // 4, int(os.environ.get("SWEEP_L", 2880000)), int(os.environ.get("SWEEP_B", 32))
+K = int(os.environ.get("SWEEP_K", N))            # fft_length (>= N: zero-padded frames, e.g. the 400-in-512 speech framing)
+hop, L, B = int(os.environ.get("SWEEP_HOP", N // 4)), int(os.environ.get("SWEEP_L", 2880000)), int(os.environ.get("SWEEP_B", 32))
 M = (L - N) // hop + 1
 ctx = S.Context(0)
 lib = _lib.load()
@@ -24,12 +25,12 @@ x = rng.standard_normal(L, dtype=np.float32)
 for b in range(B):
     xr = np.roll(x, 997 * b)
     _lib.check(lib.nxsig_upload(ctx.handle, C.c_void_p(xd.ptr + b * L * 4), xr.ctypes.data_as(C.c_void_p), xr.nbytes))
-zd = ctx.empty((B, M, N), np.complex64)
-p = _lib.StftParams(N, hop, N, 0, 0, 0, 0, 0, 48000.0)
+zd = ctx.empty((B, M, K), np.complex64)
+p = _lib.StftParams(N, hop, K, 0, 0, 0, 0, 0, 48000.0)
 wp = w.ctypes.data_as(C.c_void_p)
 
 
-def run(reps=20):
+def run(reps=int(os.environ.get("SWEEP_REPS", 20))):
     for _ in range(3):
         _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, B, L, wp, C.byref(p), C.c_void_p(zd.ptr), None, 1))
     ctx.sync()
@@ -43,7 +44,8 @@ res = {v: [] for v in vals}
 for rnd in range(5):
     for v in vals:
         ctx.set_tuning(knob, int(v))   # the library reads the environment only at context creation (round 4)
-        res[v].append(B * M * (hop * 4 + N * 8) / (run() * 1e-3) / 1e9)
+        res[v].append(B * M * (hop * 4 + K * 8) / (run() * 1e-3) / 1e9)
 for v in vals:
     r = sorted(res[v])
-    print(f"{knob}={v:>6s}  median {r[len(r)//2]:7.1f} GB/s   min {r[0]:7.1f}  max {r[-1]:7.1f}")
+    med = r[len(r) // 2]
+    print(f"{knob}={v:>6s}  median {med:7.1f} GB/s   min {r[0]:7.1f}  max {r[-1]:7.1f}   ({B * M * (hop * 4 + K * 8) / med / 1e3:8.2f} us per launch)")

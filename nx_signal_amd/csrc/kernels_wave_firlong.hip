@@ -226,11 +226,11 @@ __global__ __launch_bounds__(64 * W) void k_fir_dline_macinv(DlineArgs a, int64_
     v2f acc[P];
 #pragma unroll
     for (int s = 0; s < P; ++s) acc[s] = v2f{0.f, 0.f};
-    v2f d[P], dn[P];
+    v2f db[2][P];   // the window in use and the one in flight trade places (static indices: the loop over the partitions is unrolled)
     {
       const v2f* zp = zrow + (size_t)(bi + a.P - 1) * K;
 #pragma unroll
-      for (int s = 0; s < P; ++s) d[s] = zp[64 * s];
+      for (int s = 0; s < P; ++s) db[0][s] = zp[64 * s];
     }
     // W[b] = sum_p A_p[b] Z_p[b] + B_p[b] conj Z_p[-b] = U[b] + conj V[-b],  V[b] = sum_p conj(B_p[-b]) Z_p[b]: both sums run over the
     // lane's OWN bins (the table holds (A_p[b], conj B_p[-b])), and the partner lane is visited once, at the end, instead of once per partition
@@ -243,16 +243,14 @@ __global__ __launch_bounds__(64 * W) void k_fir_dline_macinv(DlineArgs a, int64_
         if (p + 1 < a.P) {
           const v2f* zp = zrow + (size_t)(bi + a.P - 2 - p) * K;
 #pragma unroll
-          for (int s = 0; s < P; ++s) dn[s] = zp[64 * s];
+          for (int s = 0; s < P; ++s) db[(p + 1) & 1][s] = zp[64 * s];
         }
 #pragma unroll
         for (int s = 0; s < P; ++s) {
           const v4f cf = s_cf[p * K + lane + 64 * s];
-          acc[s] += wcmul(v2f{cf.x, cf.y}, d[s]);
-          vv[s] += wcmul(v2f{cf.z, cf.w}, d[s]);
+          acc[s] += wcmul(v2f{cf.x, cf.y}, db[p & 1][s]);
+          vv[s] += wcmul(v2f{cf.z, cf.w}, db[p & 1][s]);
         }
-#pragma unroll
-        for (int s = 0; s < P; ++s) d[s] = dn[s];
       }
     }
 #pragma unroll

@@ -312,6 +312,23 @@ int launch_fir_dline(Ctx* c, const FirLaunch& s, bool* handled) {
   if (rc) return rc;
   *handled = true;
   dispatch_note("fir.dline");
+  {  // many rows: the scratch of a segment (at least 64 blocks of every row) must stay within its budget, so the rows go in groups
+    const int64_t per_row = (int64_t)(64 + P - 1) * 16384;
+    int64_t rows_max = ((int64_t)1 << 30) / per_row;
+    if (rows_max < 1) rows_max = 1;
+    if (s.batch > rows_max) {
+      for (int32_t r0 = 0; r0 < s.batch; r0 += (int32_t)rows_max) {
+        FirLaunch g = s;
+        g.batch = s.batch - r0 < rows_max ? s.batch - r0 : (int32_t)rows_max;
+        g.x = s.x + (size_t)r0 * s.batch_stride;
+        g.y = s.y + (size_t)r0 * s.out_len;
+        g.row_flags = s.row_flags + r0;
+        bool h2 = false;
+        if ((rc = launch_fir_dline(c, g, &h2))) return rc;
+      }
+      return NXSIG_OK;
+    }
+  }
   // ---- coefficient table (per distinct filter: memoised by content)
   const uint64_t hkey = fnv1a(0xD11E0000ull ^ (uint64_t)s.taps, s.h_host, (size_t)s.taps * sizeof(float));
   const void* cd = nullptr;

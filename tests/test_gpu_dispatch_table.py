@@ -6,8 +6,8 @@ Two guards:
 * `test_dispatch_family` — table-driven: the library's dispatch record (`nxsig_ctx_last_dispatch`, include/nxsig.h) of one call per
   shape of DESIGN.md section 3 must equal the family named here.  Flipping any NXSIG_DISABLE_* switch makes the rows of that family fail by
   name (`test_a_disabled_family_changes_the_record` shows it for four of them).
-* `test_throughput_floor` — a dozen shapes timed on HIP events (10 settled laps each) against floors at ~0.8 x the fraction measured in
-  round 6 (profiles/r06/dispatch_and_floors.txt); a fall to kernels_generic.hip is a factor 10-30, far below any floor.
+* `test_throughput_floor` — a dozen shapes timed on HIP events (10 settled laps each) against floors at ~0.7 x the fraction measured in
+  round 6 (boxes of the pool differ by up to 10 %; a fall to the generic kernels is a factor 10-30) (profiles/r06/dispatch_and_floors.txt); a fall to kernels_generic.hip is a factor 10-30, far below any floor.
 
 NXSIG_DISPATCH_PROBE=1 prints the record / the measured fraction of every row instead of asserting (how the tables were filled)."""
 import ctypes as C
@@ -194,20 +194,20 @@ def test_the_thread_local_record_matches_the_context_copy(ctx):
     assert _lib.last_dispatch() == rec == "stft.real2x"
 
 
-# ---- throughput floors: fraction of 8 TB/s on algorithmic bytes, ~0.8 x what round 6 measured (profiles/r06/dispatch_and_floors.txt)
+# ---- throughput floors: fraction of 8 TB/s on algorithmic bytes, ~0.7 x what round 6 measured (profiles/r06/dispatch_and_floors.txt)
 FLOORS = {
-    "stft1024 16 x 30 s": (_stft, (1024, 256, 1024, 16, 5621), 0.58),
-    "stft512": (_stft, (512, 128, 512, 16, 11000), 0.49),
-    "stft256": (_stft, (256, 64, 256, 16, 22000), 0.52),
-    "stft2048": (_stft, (2048, 512, 2048, 8, 5600), 0.53),
-    "stft4096": (_stft, (4096, 1024, 4096, 8, 2800), 0.40),
-    "stft400 (20 x 20)": (_stft, (400, 100, 400, 16, 14000), 0.48),
-    "stft960 (A x B)": (_stft, (960, 240, 960, 16, 5800), 0.41),
-    "istft1024": (_istft, (1024, 256, 16, 5621), 0.41),
-    "istft2048": (_istft, (2048, 512, 8, 5600), 0.34),
-    "istft512": (_istft, (512, 128, 16, 11000), 0.36),
-    "fir257 8 x 150 s": (_fir, (257, 8, 7200000), 0.41),
-    "fir769 (real 2048-blocks)": (_fir, (769, 8, 7200000), 0.26),
+    "stft1024 16 x 30 s": (_stft, (1024, 256, 1024, 16, 5621), 0.52),
+    "stft512": (_stft, (512, 128, 512, 16, 11000), 0.44),
+    "stft256": (_stft, (256, 64, 256, 16, 22000), 0.47),
+    "stft2048": (_stft, (2048, 512, 2048, 8, 5600), 0.48),
+    "stft4096": (_stft, (4096, 1024, 4096, 8, 2800), 0.36),
+    "stft400 (20 x 20)": (_stft, (400, 100, 400, 16, 14000), 0.43),
+    "stft960 (A x B)": (_stft, (960, 240, 960, 16, 5800), 0.37),
+    "istft1024": (_istft, (1024, 256, 16, 5621), 0.37),
+    "istft2048": (_istft, (2048, 512, 8, 5600), 0.31),
+    "istft512": (_istft, (512, 128, 16, 11000), 0.32),
+    "fir257 8 x 150 s": (_fir, (257, 8, 7200000), 0.37),
+    "fir769 (real 2048-blocks)": (_fir, (769, 8, 7200000), 0.23),
 }
 
 

@@ -861,3 +861,21 @@ def test_host_tensor_paths_return_the_same_bytes():
         assert z1.nbytes > 96 << 20 and z1.nbytes % (32 << 20) != 0
         assert np.array_equal(z1.view(np.uint32), z0.view(np.uint32))
         assert np.array_equal(y1.view(np.uint32), S.filters.fir(x, np.ones(33, np.float32) / 33, mode="same", ctx=ctx).view(np.uint32))
+
+
+def test_fir_delay_line_on_many_rows_stays_within_its_scratch():
+    """kernels_wave_firlong.hip: a segment of the delay line holds at least 64 blocks of every row; with thousands of rows the rows go in
+    groups so that the scratch stays within 1 GB (round 6).  1 200 rows x 2 049 taps against the direct f64 convolution of sampled rows;
+    a NaN poisons exactly its row, also in the second group"""
+    rng = np.random.default_rng(5)
+    rows, L, taps = 1200, 9000, 2049
+    x = rng.standard_normal((rows, L)).astype(np.float32)
+    x[1100, 4000] = np.nan
+    h = (rng.standard_normal(taps) * np.hanning(taps) / 30).astype(np.float32)
+    ctx = S.Context(0)
+    y = S.filters.fir(ctx.to_device(x), h, mode="same", ctx=ctx).numpy()
+    assert ctx.last_dispatch().startswith("fir.dline")
+    for r in (0, 1, 599, 1023, 1024, 1099, 1101, rows - 1):
+        ref = np.convolve(x[r].astype(np.float64), h.astype(np.float64), mode="same")
+        assert float(np.max(np.abs(y[r] - ref)) / np.max(np.abs(ref))) < 1e-5, r
+    assert not np.isfinite(y[1100]).any() and np.isfinite(np.delete(y, 1100, axis=0)).all()

@@ -50,6 +50,9 @@ CASES = [
     ("NXSIG_FIR_R2K=0", ("tests/test_gpu_parity.py tests/test_gpu_tuned_kernels.py", "fir and not beyond_4gb")),
     ("NXSIG_FIR_R2K=2", ("tests/test_gpu_parity.py tests/test_gpu_tuned_kernels.py", "fir and not beyond_4gb")),
     ("NXSIG_FIR_DLINE=0", ("tests/test_gpu_tuned_kernels.py tests/test_gpu_reference_numerics.py", "long_filters or fir_non_finite")),
+    ("NXSIG_FIR_DLINE=2", ("tests/test_gpu_tuned_kernels.py", "long_filters or delay_line")),   # three passes also where the fused inverse pass applies
+    ("NXSIG_WAVE_SMALL_W=0", STFT),                                                              # the many-round geometry for launches of one round
+    ("NXSIG_WAVE_UNITS_PER_WAVE=4", ("tests/test_gpu_tuned_kernels.py tests/test_gpu_parity.py", "stft_wave_variants or stft_matches_oracle or composite_lengths_native")),
     ("NXSIG_MEL_TILE=0", ("tests/test_gpu_parity.py", "mel and not 8192-20-48000 and not stft_to_mel_is_bit")),
     ("NXSIG_MEL_LDS_KB=150", MEL),
     ("NXSIG_FFT_TILED=0", ND),

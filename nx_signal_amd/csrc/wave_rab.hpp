@@ -26,8 +26,9 @@
 #define NXSIG_RAB_PART3(X) X(1000, 40, 25) X(1200, 40, 30) X(1280, 40, 32) X(1600, 40, 40)
 #define NXSIG_RAB_PART5(X) X(192, 16, 12) X(288, 24, 12) X(576, 24, 24) X(1152, 48, 24) X(1440, 48, 30) X(1536, 48, 32) X(1920, 48, 40)
 // round 6: radix 7 (the 20 / 40 ms frames of 44.1 kHz audio) and the 50 / 60 / 80 ms frames of 48 kHz audio; complex-spectrum sink only
-// (log-mel / magnitude sinks of these lengths take the two-step path).  882 % 4 == 2: fine for the spectrum sink's bin pairs.
-#define NXSIG_RAB_PART6(X) X(882, 42, 21) X(1764, 42, 42)
+// (log-mel / magnitude sinks of these lengths take the two-step path).  882 % 4 == 2: fine for the spectrum sink's bin pairs; 441 is ODD:
+// single bins and 8-byte accesses in the drains, 8-byte spectrum loads in the inverse.
+#define NXSIG_RAB_PART6(X) X(441, 21, 21) X(882, 42, 21) X(1764, 42, 42)
 #define NXSIG_RAB_PART7(X) X(2400, 50, 48) X(2880, 60, 48) X(3840, 64, 60)
 // inverse only: power-of-two frame lengths with a hop the N / hop in {1, 2, 4, 8} kernels of kernels_wave.hip do not take (e.g. 512 / 160)
 #define NXSIG_RAB_INVERSE_ONLY(X) X(128, 16, 8) X(256, 16, 16) X(512, 32, 16) X(1024, 32, 32)
@@ -216,6 +217,26 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
         const v2f* U = buf + gg * KB;
         v2f* zA = a.z + ((size_t)row * a.M + m0) * KB;
         v2f* zB = zA + KB;
+        if constexpr ((KB & 1) != 0) {
+          // odd fft length (441 = 21 x 21, round 6): rows of K x 8 bytes are 8-byte aligned only and bin K - 1 has no pair: single bins,
+          // 8-byte LDS reads and stores (512 B per wave instruction); spectrum sink only
+          constexpr int NB1 = (KB + 63) / 64;
+#pragma unroll 2
+          for (int i = 0; i < NB1; ++i) {
+            const int k = lane + 64 * i;
+            if (act && k < KB) {
+              const v2f uu = U[k], pp = U[k == 0 ? 0 : KB - k];
+              v2f xa = fft_eps0(v2f{uu.x + pp.x, uu.y - pp.y} * 0.5f);
+              v2f xv = fft_eps0(v2f{uu.y + pp.y, pp.x - uu.x} * 0.5f);
+              if (SCALE) { xa = xa / a.div; xv = xv / a.div; }
+              const bool stA = sel <= 0, stB = hb && sel != 0;
+              if (sel == 1) xv = xa;
+              if (stA) __builtin_nontemporal_store(xa, (gv2f*)(zA + k));
+              if (stB) __builtin_nontemporal_store(xv, (gv2f*)(zB + k));
+            }
+          }
+          continue;
+        }
 #pragma unroll 2
         for (int i = 0; i < NI; ++i) {
           const int pi = lane + 64 * i;
@@ -575,6 +596,18 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
       if (mm < a.M) {   // wave-uniform
         const v2f* U = buf + gg * KB;
         v2f* zr = a.z + ((size_t)row * a.M + mm) * KB;
+        if constexpr ((KB & 1) != 0) {   // odd fft length: 8-byte stores (rows are 8-byte aligned only)
+#pragma unroll 2
+          for (int i = 0; i < (KB + 63) / 64; ++i) {
+            const int k = lane + 64 * i;
+            if (k < KB) {
+              v2f xv = fft_eps0(U[k]);
+              if (SCALE) xv = xv / a.div;
+              __builtin_nontemporal_store(xv, (gv2f*)(zr + k));
+            }
+          }
+          continue;
+        }
 #pragma unroll 2
         for (int i = 0; i < NI; ++i) {
           const int k = 2 * (lane + 64 * i);
@@ -668,7 +701,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((A > 48 
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT, CMAX = KB;
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
-  constexpr int N4 = T * KB / 2;                 // 16-byte pieces of a unit's T spectra
+  constexpr bool KODD = (KB & 1) != 0;          // odd frame length (441): spectra rows are 8-byte aligned only -> 8-byte loads
+  constexpr int N4 = KODD ? T * KB : T * KB / 2;   // pieces of a unit's T spectra: 16 bytes each (8 when KODD)
   constexpr int NRS = (N4 + 63) / 64;
   float* s_w = reinterpret_cast<float*>(g_wave_smem);
   v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
@@ -695,15 +729,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((A > 48 
   const float invK = 1.0f / (float)KB;
   const v2f* zrow = a.z + (size_t)row * a.M * KB;
 
-  v4f rs[NRS];
+  using pvec = std::conditional_t<KODD, v2f, v4f>;
+  pvec rs[NRS];
   auto prefetch = [&](int64_t u) {
     const int64_t m0 = T * u;
-    const v4f* p4 = reinterpret_cast<const v4f*>(zrow + (size_t)m0 * KB) + lane;
-    const int64_t avail4 = (a.M - m0) * (KB / 2);   // float4s that exist from frame m0 on (frames past the end: zeros)
+    const pvec* p4 = reinterpret_cast<const pvec*>(zrow + (size_t)m0 * KB) + lane;
+    const int64_t avail4 = KODD ? (a.M - m0) * (int64_t)KB : (a.M - m0) * (KB / 2);   // pieces that exist from frame m0 on (frames past the end: zeros)
 #pragma unroll
     for (int c = 0; c < NRS; ++c) {
       const int i4 = lane + 64 * c;
-      rs[c] = (i4 < N4 && i4 < avail4) ? p4[64 * c] : v4f{0.f, 0.f, 0.f, 0.f};
+      rs[c] = (i4 < N4 && i4 < avail4) ? p4[64 * c] : pvec(0.0f);
     }
   };
   prefetch(us);
@@ -712,7 +747,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((A > 48 
 #pragma unroll
     for (int c = 0; c < NRS; ++c) {
       const int i4 = lane + 64 * c;
-      if (i4 < N4) *reinterpret_cast<v4f*>(&buf[2 * i4]) = rs[c];
+      if (i4 < N4) *reinterpret_cast<pvec*>(&buf[KODD ? i4 : 2 * i4]) = rs[c];
     }
     wave_lds_fence();
     prefetch(u + 1 < u1 ? u + 1 : u);
@@ -807,7 +842,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((A > 48 
         if (t < CARRY) *reinterpret_cast<vec*>(&carry[t]) = nc[i];
       }
     };
-    finish(std::integral_constant<int, ODD ? 1 : 2>{});
+    finish(std::integral_constant<int, (ODD || KODD) ? 1 : 2>{});
     wave_lds_fence();
   }
 }

@@ -111,7 +111,8 @@ DISPATCH = {
     "stft3840": (_stft, (3840, 960, 3840, 2, 40), {}, "stft.rab"),
     "stft441-default-fft-length-512": (_stft, (441, 110, 512, 2, 400), {}, "stft.quad2"),   # fft_length defaults to :power_of_two in the reference (lib/nx_signal.ex:78)
     "stft2400-default-fft-length-4096": (_stft, (2400, 600, 4096, 2, 60), {}, "stft.real2x.4k"),
-    "stft441-bluestein": (_stft, (441, 110, 441, 2, 400), {}, "stft.blue"),
+    "stft441-radix7-odd": (_stft, (441, 110, 441, 2, 400), {}, "stft.rab"),
+    "stft443-bluestein": (_stft, (443, 110, 443, 2, 400), {}, "stft.blue"),
     "stft1020-bluestein": (_stft, (1020, 255, 1020, 2, 200), {}, "stft.blue"),
     "stft2205-generic": (_stft, (2205, 551, 2205, 2, 50), {}, "stft.generic.blue"),
     "stft16-generic": (_stft, (16, 4, 16, 2, 400), {}, "stft.generic.pow2"),
@@ -130,7 +131,8 @@ DISPATCH = {
     "istft512-hop160": (_istft, (512, 160, 2, 400), {}, "istft.rab+istft.edge_chunks"),
     "istft1764-radix7": (_istft, (1764, 441, 2, 100), {}, "istft.rab"),
     "istft2880": (_istft, (2880, 720, 2, 60), {}, "istft.rab"),
-    "istft441-generic": (_istft, (441, 110, 2, 400), {}, "fft.rows_generic.blue+istft.generic+istft.edge_fix"),
+    "istft441-radix7-odd": (_istft, (441, 110, 2, 400), {}, "istft.rab"),
+    "istft443-generic": (_istft, (443, 110, 2, 400), {}, "fft.rows_generic.blue+istft.generic+istft.edge_fix"),
     # ---- fir (3.3)
     "fir257": (_fir, (257, 2, 1 << 20), {}, "fir.pair+fir.pair.edge"),
     "fir100": (_fir, (100, 2, 1 << 20), {}, "fir.wave32+fir.pair.edge"),
@@ -173,7 +175,7 @@ def test_dispatch_family(ctx, key):
     ("DISABLE_WAVE", "stft1024-config1-one-round", "stft.pair"),
     ("DISABLE_RAB", "stft960", "stft.rab"),
     ("DISABLE_R20", "stft400", "stft.r20"),
-    ("DISABLE_BLUE_WAVE", "stft441-bluestein", "stft.blue"),
+    ("DISABLE_BLUE_WAVE", "stft443-bluestein", "stft.blue"),
     ("ISTFT_DEEP=0", "istft1024-hop256", "istft.wave.deep"),
     ("FIR_R2K=0", "fir513", "fir.r2k"),
     ("FIR_DLINE=0", "fir4097-delay-line", "fir.dline"),

@@ -97,6 +97,19 @@ defmodule NxSignalAMDTest do
     assert Sig.istft_filtered(z, h, w, opts) == Sig.istft(Nx.multiply(z, h), w, opts)
   end
 
+  test "the dispatch record names the kernel family of the last call (round 6)" do
+    ctx = Sig.context()
+    w = Sig.Windows.hann(1024)
+    x = Nx.iota({48_000}, type: :f32) |> Nx.sin()
+    {z, _t, _f} = Sig.stft(x, w, overlap_length: 768, fft_length: 1024, sampling_rate: 48_000)
+    assert String.starts_with?(Sig.last_dispatch(ctx), "stft.pair")
+    _ = Sig.istft(z, w, overlap_length: 768, fft_length: 1024, sampling_rate: 48_000)
+    assert String.starts_with?(Sig.last_dispatch(ctx), "istft.wave")
+    h = Sig.Filters.firwin(4097, [0.2])
+    _ = Sig.Filters.fir(Nx.iota({100_000}, type: :f32) |> Nx.cos(), h, mode: :same)
+    assert String.starts_with?(Sig.last_dispatch(ctx), "fir.dline")
+  end
+
   test "the sharded log-mel all-reduces the global maximum: channel shards equal the unsharded call" do
     g = Sig.Sharded.group()
     x = Nx.iota({4, 30_000}, type: :f32) |> Nx.sin() |> Nx.multiply(Nx.tensor([[1.0e-3], [1.0e-3], [1.0], [1.0]]))

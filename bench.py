@@ -1068,6 +1068,24 @@ def main():
             headline_ceiling = {"GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "kernel_over_ceiling": achieved / gbs,
                                 "what": "tools/diag_mix.hip k_stft_mix: the headline kernel's loads and stores in its launch geometry (2 frame "
                                         "pairs per wave), no math"}
+            # config 2 as written beside ITS no-math model (round 6): ONE 60 s stream per launch, kernel and model interleaved A B A B,
+            # 100 back-to-back launches per lap.  What the launch shape allows, whatever the arithmetic costs.
+            if not args.dry and isinstance(single, dict):
+                mix1 = lambda: diag.nxdiag_stft_mix(stream, C.c_void_p(xd.ptr), C.c_void_p(zd.ptr), C.c_void_p(tabd.ptr), 1, L, HOP, 2)  # noqa: E731
+                tk, tm = [], []
+                for _ in range(4):
+                    for fn, acc in ((lambda: step(1), tk), (mix1, tm)):
+                        for _ in range(10):
+                            fn()
+                        ctx.sync()
+                        ctx.timer_start()
+                        for _ in range(100):
+                            fn()
+                        acc.append(ctx.timer_stop() / 100)
+                single["interleaved_with_model"] = {
+                    "kernel_us": round(float(np.median(tk)) * 1e3, 2), "model_us": round(float(np.median(tm)) * 1e3, 2),
+                    "model_frames_per_s": (M // 2) * 2 / (float(np.median(tm)) * 1e-3), "kernel_over_ceiling": float(np.median(tm)) / float(np.median(tk)),
+                    "what": "tools/diag_mix.hip k_stft_mix on ONE stream: the loads and stores of the launch, 2 frame pairs per wave, no math"}
             tabd.free()
         except Exception as e:  # noqa: BLE001
             headline_ceiling = {"error": repr(e)[:160]}
@@ -1195,6 +1213,7 @@ def main():
             "frac_fir257": frac_of("roofline_fir"),
             "single_stream_fps": single["frames_per_s"] if isinstance(single, dict) else None,
             "host_path_fps": host_path.get("frames_per_s") if isinstance(host_path, dict) else None,
+            "single_stream_over_ceiling": (single.get("interleaved_with_model") or {}).get("kernel_over_ceiling") if isinstance(single, dict) else None,
             "value_cold": out.get("value_cold"),
             "max_norm_err": out.get("max_norm_err_vs_oracle"),
         }

@@ -874,7 +874,8 @@ def test_fir_delay_line_on_many_rows_stays_within_its_scratch():
     h = (rng.standard_normal(taps) * np.hanning(taps) / 30).astype(np.float32)
     ctx = S.Context(0)
     y = S.filters.fir(ctx.to_device(x), h, mode="same", ctx=ctx).numpy()
-    assert ctx.last_dispatch().startswith("fir.dline")
+    native = not ctx.get_tuning("DISABLE_WAVE")[0] and ctx.get_tuning("FIR_DLINE") != (0, True)   # (the switch matrix runs this test under them)
+    assert not native or ctx.last_dispatch().startswith("fir.dline"), ctx.last_dispatch()
     for r in (0, 1, 599, 1023, 1024, 1099, 1101, rows - 1):
         ref = np.convolve(x[r].astype(np.float64), h.astype(np.float64), mode="same")
         assert float(np.max(np.abs(y[r] - ref)) / np.max(np.abs(ref))) < 1e-5, r

@@ -9,7 +9,8 @@ from oracle import nx_oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-LENGTHS = [32, 192, 288, 576, 1152, 1440, 1536, 1920, 64, 100, 120, 128, 160, 200, 240, 256, 300, 320, 360, 384, 400, 480, 500, 512, 600, 640, 720, 768, 800, 900, 960, 1000, 1024, 1200, 1280, 1600, 2048, 333, 441, 48]
+LENGTHS = [32, 192, 288, 576, 1152, 1440, 1536, 1920, 64, 100, 120, 128, 160, 200, 240, 256, 300, 320, 360, 384, 400, 480, 500, 512, 600, 640, 720, 768, 800, 900, 960, 1000, 1024, 1200, 1280, 1600, 2048, 333, 441, 48,
+           882, 1764, 2400, 2880, 3840, 443, 4096]   # round 6: the radix-7 / 50- / 60- / 64-point lengths (441 odd), one Bluestein length, the 4096 front end
 ctx = S.Context(0)
 t0 = time.time(); n = 0; worst = {}
 def note(kind, err, what):
@@ -19,8 +20,9 @@ while time.time() - t0 < budget:
     K = int(rng.choice(LENGTHS))
     N = K if rng.random() < 0.6 else int(rng.integers(max(2, K // 3), K + K // 2))
     hop = int(rng.integers(1, N + 1)) if rng.random() < 0.5 else max(1, N // int(rng.choice([2, 3, 4, 8])))
-    rows = int(rng.choice([1, 2, 3, 5, 33]))
-    L = int(rng.integers(N, N + 40 * hop + 7))
+    rows = int(rng.choice([1, 2, 3, 5, 33, 130]))
+    L = int(rng.integers(N, N + int(rng.choice([40, 40, 400, 3000])) * hop + 7))   # (long rows: launches of more than one round)
+    if rows * L > 6_000_000: L = max(N, 6_000_000 // rows)
     pad = str(rng.choice(["valid", "reflect"])) if L > N else "valid"
     scaling = rng.choice([None, "spectrum", "psd"])
     w = S.windows.hann(N) if rng.random() < 0.5 else S.windows.hamming(N)
@@ -59,8 +61,9 @@ while time.time() - t0 < budget:
         y = S.istft(ctx.to_device(z), wk, ctx=ctx, **o3).numpy(); yo = O.istft(z, wk, **o3)
         note("istft", float(np.max(np.abs(y - yo)) / np.max(np.abs(yo))), (K, o3["overlap_length"], rows, M, scaling))
     elif kind == "fir":
-        taps = int(rng.choice([1, 2, 7, 33, 64, 101, 200, 257, 300, 400, 512, 513, 600, 769, 1000, 1025, 1026, 1500, 2049, 3000]))
-        Lf = int(rng.integers(max(2, taps // 4), 30000))
+        taps = int(rng.choice([1, 2, 7, 33, 64, 101, 200, 257, 300, 400, 512, 513, 600, 769, 1000, 1025, 1026, 1500, 2049, 3000, 3073, 4097, 4100, 5000, 9001, 16385, 20000]))
+        Lf = int(rng.integers(max(2, taps // 4), int(rng.choice([30000, 30000, 200000]))))
+        if rows * Lf > 3_000_000: rows = max(1, 3_000_000 // Lf)
         mode = str(rng.choice(["same", "full", "valid"]))
         x = rng.standard_normal((rows, Lf)).astype(np.float32)
         h = (rng.standard_normal(taps) / taps ** 0.5).astype(np.float32)

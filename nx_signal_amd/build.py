@@ -20,7 +20,9 @@ OUT = os.path.join(HERE, "libnxsig.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 
 ARCH = "gfx950"
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}"]
+# --offload-compress: the gfx950 code objects are stored compressed in the fat binary (the HIP runtime inflates them when the module is
+# registered): libnxsig.so 24.8 MB -> 7.5 MB
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "--offload-compress", f"-I{os.path.join(ROOT, 'include')}"]
 UNITS = [
     # (source, extra flags)
     ("host_numerics.cpp", ["-x", "hip", "-ffp-contract=off"]),  # BinaryBackend rounding: no FMA contraction

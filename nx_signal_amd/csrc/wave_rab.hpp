@@ -692,27 +692,36 @@ struct IstftRabArgs {
   const float* den;           // f32[2 RP - 1][hop]: reciprocal of the guarded normaliser: head segments, interior, tail segments
   v2f* y;                     // c64[batch][out_len]
   v2f* dummy;
+  int32_t cstride;            // cells of LDS per wave for the carry strip: K - hop rounded up to 16 (round 6: K until then)
 };
 
 // ODD: the hop is odd (8-byte LDS gathers and stores instead of 16-byte ones).  The scale factor is always multiplied in (1.0f when the
 // call has none: exact), so the two instantiations per length are the two hop parities
-template <int A, int B, bool ODD, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu((A > 48 || B > 48) ? 1 : 2, 3))) void k_istft_rab(IstftRabArgs a) {   // (50- / 60- / 64-point codelets: one to three waves per CU fit the LDS anyway; 256 registers spilled 220-720 B)
+// WMAX waves per workgroup at most; the launch picks W = blockDim.x / 64 <= WMAX from what the LDS holds for THIS hop (the carry strip is
+// K - hop cells, not K).  TG: window and twiddles are read from global memory (L1 / L2 hits) instead of LDS copies — for the long lengths
+// the 12 K bytes of tables cost a wave (2880 = 60 x 48: 4 waves instead of 2; 3840 = 64 x 60: 3 instead of 1).
+template <int A, int B, bool ODD, int WMAX, bool TG>
+__global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu((A > 48 || B > 48) ? 1 : 2, (A > 48 || B > 48) ? (WMAX <= 4 ? 1 : 2) : 3))) void k_istft_rab(IstftRabArgs a) {
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT, CMAX = KB;
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   constexpr bool KODD = (KB & 1) != 0;          // odd frame length (441): spectra rows are 8-byte aligned only -> 8-byte loads
   constexpr int N4 = KODD ? T * KB : T * KB / 2;   // pieces of a unit's T spectra: 16 bytes each (8 when KODD)
   constexpr int NRS = (N4 + 63) / 64;
-  float* s_w = reinterpret_cast<float*>(g_wave_smem);
-  v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
-  v2f* s_x = s_tw + KB;
+  const int W = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
+  float* s_w0 = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_tw0 = reinterpret_cast<v2f*>(s_w0 + KB);
+  v2f* s_x = TG ? reinterpret_cast<v2f*>(g_wave_smem) : s_tw0 + KB;
   v2f* s_carry = s_x + W * BUF;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = a.tw[i]; }
-  __syncthreads();
+  if constexpr (!TG) {
+    for (int i = tid; i < KB; i += 64 * W) { s_w0[i] = a.wtab[i]; s_tw0[i] = a.tw[i]; }
+    __syncthreads();
+  }
+  const float* s_w = TG ? a.wtab : s_w0;
+  const v2f* s_tw = TG ? a.tw : s_tw0;
   v2f* buf = s_x + wave * BUF;
-  v2f* carry = s_carry + wave * CMAX;
+  v2f* carry = s_carry + wave * a.cstride;
   const int g = lane / LT, l = lane % LT;
   const int hop = a.hop;
   const int CARRY = KB - hop;             // positions handed to the next unit
@@ -852,10 +861,13 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, CMAX = KB;
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
-  // ONE workgroup per CU with as many waves as the LDS (exchange + carry strip per wave, the tables once) and the registers allow:
-  // 12 / 12 / 8 / 6 waves for 320 / 480 / 640 / 960.  (Round 5, until then 2 workgroups of 4 / 4 / 2 / 2 waves: 0.25 -> 0.42 for 640)
-  constexpr int W_LDS = (160 * 1024 - KB * 12) / ((BUF + CMAX) * 8), W_REG = LT <= 24 ? 12 : 8;
-  constexpr int W = W_LDS < W_REG ? W_LDS : W_REG;
+  // ONE workgroup per CU with as many waves as the LDS (exchange + carry strip of K - hop cells per wave, the tables once unless they
+  // stay in global memory) and the registers allow: 12 / 12 / 8 / 6 waves for 320 / 480 / 640 / 960 at hop K / 4.  (Round 5, until then
+  // 2 workgroups of 4 / 4 / 2 / 2 waves: 0.25 -> 0.42 for 640.  Round 6: the strip follows the hop and the long lengths read their
+  // tables from global memory: 1764 / 2400 / 2880 / 3840 run 6 / 4 / 4 / 3 waves instead of 4 / 3 / 2 / 1)
+  constexpr bool BIG = A > 48 || B > 48;
+  constexpr int WMAX = BIG ? 4 : (LT <= 24 ? 12 : 8);
+  constexpr bool TG = KB * 12 >= 20 * 1024;
   const int hop = s.hop;
   if (hop < 1 || hop > KB) return NXSIG_OK;                         // (an odd hop takes the kernel's 8-byte gathers)
   const int RP = (KB + hop - 1) / hop;
@@ -918,6 +930,12 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t segs = (a.out_len + hop - 1) / hop;              // hop segments of the output (the last may be partial)
   a.units_per_row = (segs + T - 1) / T;
+  a.cstride = ((KB - hop) + 15) & ~15;
+  if (a.cstride < 16) a.cstride = 16;
+  const size_t tables = TG ? 0 : (size_t)KB * 12;
+  int W = (int)((160 * 1024 - tables) / ((size_t)(BUF + a.cstride) * 8));
+  if (W > WMAX) W = WMAX;
+  if (W < 1) { *handled = false; return NXSIG_OK; }
   const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, W);  // = resident waves per CU
   const int64_t run_len = istft_balanced_run_len(a.units_per_row, s.batch, (int64_t)c->num_cus * waves_per_cu, (RP - 1 + T - 1) / T,
                                                  istft_min_run(c, a.units_per_row * s.batch, (int64_t)c->num_cus * waves_per_cu, 8));
@@ -925,7 +943,7 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   a.runs_per_row = (a.units_per_row + run_len - 1) / run_len;
   a.total_runs = a.runs_per_row * s.batch;
   const int64_t blocks = (a.total_runs + W - 1) / W;
-  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)W * BUF * 8 + (size_t)W * CMAX * 8;
+  const size_t lds = tables + (size_t)W * BUF * 8 + (size_t)W * a.cstride * 8;
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -934,7 +952,7 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
     NXSIG_HIP_TRY(hipGetLastError());
     return NXSIG_OK;
   };
-  return (hop & 1) ? go(k_istft_rab<A, B, true, W>) : go(k_istft_rab<A, B, false, W>);
+  return (hop & 1) ? go(k_istft_rab<A, B, true, WMAX, TG>) : go(k_istft_rab<A, B, false, WMAX, TG>);
 }
 
 }  // namespace nxsig

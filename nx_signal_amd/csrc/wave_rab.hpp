@@ -697,11 +697,18 @@ struct IstftRabArgs {
 
 // ODD: the hop is odd (8-byte LDS gathers and stores instead of 16-byte ones).  The scale factor is always multiplied in (1.0f when the
 // call has none: exact), so the two instantiations per length are the two hop parities
+// The 42- ... 64-point codelets run at most FOUR waves per workgroup, one per SIMD, with the whole 512-entry register file (256 + 256
+// accumulation registers as spill space): at 256 they spilled 220 ... 720 B per lane to scratch
+#ifndef NXSIG_RAB_BIG_LT
+#define NXSIG_RAB_BIG_LT 48
+#endif
+constexpr bool rab_big(int A, int B) { return A > NXSIG_RAB_BIG_LT || B > NXSIG_RAB_BIG_LT; }
+
 // WMAX waves per workgroup at most; the launch picks W = blockDim.x / 64 <= WMAX from what the LDS holds for THIS hop (the carry strip is
 // K - hop cells, not K).  TG: window and twiddles are read from global memory (L1 / L2 hits) instead of LDS copies — for the long lengths
 // the 12 K bytes of tables cost a wave (2880 = 60 x 48: 4 waves instead of 2; 3840 = 64 x 60: 3 instead of 1).
 template <int A, int B, bool ODD, int WMAX, bool TG>
-__global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu((A > 48 || B > 48) ? 1 : 2, (A > 48 || B > 48) ? (WMAX <= 4 ? 1 : 2) : 3))) void k_istft_rab(IstftRabArgs a) {
+__global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(rab_big(A, B) ? 1 : 2, rab_big(A, B) ? 1 : 3))) void k_istft_rab(IstftRabArgs a) {
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT, CMAX = KB;
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
@@ -858,16 +865,19 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu((A > 
 
 template <int A, int B>
 inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
-  constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, CMAX = KB;
+  constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT;
   constexpr int TRS = A * (B + 1);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   // ONE workgroup per CU with as many waves as the LDS (exchange + carry strip of K - hop cells per wave, the tables once unless they
   // stay in global memory) and the registers allow: 12 / 12 / 8 / 6 waves for 320 / 480 / 640 / 960 at hop K / 4.  (Round 5, until then
   // 2 workgroups of 4 / 4 / 2 / 2 waves: 0.25 -> 0.42 for 640.  Round 6: the strip follows the hop and the long lengths read their
   // tables from global memory: 1764 / 2400 / 2880 / 3840 run 6 / 4 / 4 / 3 waves instead of 4 / 3 / 2 / 1)
-  constexpr bool BIG = A > 48 || B > 48;
+  constexpr bool BIG = rab_big(A, B);
   constexpr int WMAX = BIG ? 4 : (LT <= 24 ? 12 : 8);
-  constexpr bool TG = KB * 12 >= 20 * 1024;
+#ifndef NXSIG_RAB_TG_BYTES
+#define NXSIG_RAB_TG_BYTES (1 << 30)
+#endif
+  constexpr bool TG = KB * 12 >= NXSIG_RAB_TG_BYTES;
   const int hop = s.hop;
   if (hop < 1 || hop > KB) return NXSIG_OK;                         // (an odd hop takes the kernel's 8-byte gathers)
   const int RP = (KB + hop - 1) / hop;

@@ -727,6 +727,11 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(rab_b
   }
   const float* s_w = TG ? a.wtab : s_w0;
   const v2f* s_tw = TG ? a.tw : s_tw0;
+  // the interior row of the normaliser (every unit but the first and last few of a row reads this one) sits in LDS: the global load in
+  // each step of the overlap-add loop was a round trip to L2 per 128 samples, exposed with 2 - 8 waves per CU
+  float* s_den = reinterpret_cast<float*>(s_carry + W * a.cstride);
+  for (int i = tid; i < a.hop; i += 64 * W) s_den[i] = a.den[(size_t)(a.RP - 1) * a.hop + i];
+  __syncthreads();
   v2f* buf = s_x + wave * BUF;
   v2f* carry = s_carry + wave * a.cstride;
   const int g = lane / LT, l = lane % LT;
@@ -745,35 +750,53 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(rab_b
   const float invK = 1.0f / (float)KB;
   const v2f* zrow = a.z + (size_t)row * a.M * KB;
 
+  // DIRECT (one frame per wave, i.e. 33- ... 64-point codelets): the next unit's spectrum is loaded straight into pass A's registers
+  // (lane n2 takes z[B n1 + n2]: rows of 8 B bytes, 8-byte loads) once pass B's results are parked in LDS, and arrives under the
+  // overlap-add of this unit — no prefetch registers beside the transform's own, no staging pass through LDS
+#ifndef NXSIG_RAB_DIRECT
+#define NXSIG_RAB_DIRECT 1
+#endif
+  constexpr bool DIRECT = T == 1 && NXSIG_RAB_DIRECT;
   using pvec = std::conditional_t<KODD, v2f, v4f>;
-  pvec rs[NRS];
+  pvec rs[DIRECT ? 1 : NRS];
   auto prefetch = [&](int64_t u) {
     const int64_t m0 = T * u;
     const pvec* p4 = reinterpret_cast<const pvec*>(zrow + (size_t)m0 * KB) + lane;
     const int64_t avail4 = KODD ? (a.M - m0) * (int64_t)KB : (a.M - m0) * (KB / 2);   // pieces that exist from frame m0 on (frames past the end: zeros)
 #pragma unroll
-    for (int c = 0; c < NRS; ++c) {
+    for (int c = 0; c < (DIRECT ? 1 : NRS); ++c) {
       const int i4 = lane + 64 * c;
       rs[c] = (i4 < N4 && i4 < avail4) ? p4[64 * c] : pvec(0.0f);
     }
   };
-  prefetch(us);
-  for (int64_t u = us; u < u1; ++u) {
-    // ---- the unit's T spectra -> LDS
+  v2f v[NV];
+  auto load_direct = [&](int64_t u) {
+    const bool have = lane < B && u < a.M;
+    const v2f* p = zrow + (size_t)(have ? u : 0) * KB + (have ? lane : 0);
 #pragma unroll
-    for (int c = 0; c < NRS; ++c) {
-      const int i4 = lane + 64 * c;
-      if (i4 < N4) *reinterpret_cast<pvec*>(&buf[KODD ? i4 : 2 * i4]) = rs[c];
+    for (int n1 = 0; n1 < A; ++n1) v[n1] = have ? p[B * n1] : v2f{0.f, 0.f};
+  };
+  if constexpr (DIRECT) load_direct(us); else prefetch(us);
+  for (int64_t u = us; u < u1; ++u) {
+    if constexpr (!DIRECT) {
+      // ---- the unit's T spectra -> LDS
+#pragma unroll
+      for (int c = 0; c < NRS; ++c) {
+        const int i4 = lane + 64 * c;
+        if (i4 < N4) *reinterpret_cast<pvec*>(&buf[KODD ? i4 : 2 * i4]) = rs[c];
+      }
+      wave_lds_fence();
+      prefetch(u + 1 < u1 ? u + 1 : u);
     }
-    wave_lds_fence();
-    prefetch(u + 1 < u1 ? u + 1 : u);
     // ---- pass A on conj(z): lane n2 = l < B of frame g takes conj z[B n1 + n2]
-    v2f v[NV];
 #pragma unroll
     for (int n1 = 0; n1 < A; ++n1) {
-      const v2f t = (g < T && l < B) ? buf[g * KB + B * n1 + l] : v2f{0.f, 0.f};
-      v[n1] = v2f{t.x, -t.y};
-      if (A > 16 && (n1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DIRECT) v[n1].y = -v[n1].y;
+      else {
+        const v2f t = (g < T && l < B) ? buf[g * KB + B * n1 + l] : v2f{0.f, 0.f};
+        v[n1] = v2f{t.x, -t.y};
+        if (A > 16 && (n1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
     }
     dft_n<A>(v);
     if (l < B) {
@@ -807,10 +830,12 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(rab_b
       }
     }
     wave_lds_fence();
+    if constexpr (DIRECT) load_direct(u + 1 < u1 ? u + 1 : u);
     // position t of the unit (t = 0 is sample T u hop of the row): carry + covering frames in ascending order.  CW cells per lane and
     // step: 2 (16-byte LDS gathers and stores) for an even hop, 1 for an odd one (the cells of a frame then sit at odd offsets)
     const int64_t t_unit = u * OUTN;
     v2f* yrow = a.y + (size_t)row * a.out_len;
+    const bool interior = (int64_t)T * u >= a.RP - 1 && (int64_t)T * u + T - 1 < a.M;   // every hop segment of the unit takes the interior row
     constexpr int NC = (CMAX + 127) / 128;
     auto finish = [&](auto cells) {
       constexpr int CW = decltype(cells)::value;
@@ -836,9 +861,14 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(rab_b
           for (int j = 1; j < T; ++j) f += t >= j * hop ? 1 : 0;
           const int64_t seg = (int64_t)T * u + f;
           const int pos = t - f * hop;
-          const int64_t trow = seg < a.RP - 1 ? seg : (seg >= a.M ? a.RP + (seg - a.M) : a.RP - 1);
-          if constexpr (CW == 2) rd = *reinterpret_cast<const v2f*>(a.den + trow * hop + pos);
-          else rd.x = a.den[trow * hop + pos];
+          if (interior) {                   // (wave-uniform)
+            if constexpr (CW == 2) rd = *reinterpret_cast<const v2f*>(s_den + pos);
+            else rd.x = s_den[pos];
+          } else {
+            const int64_t trow = seg < a.RP - 1 ? seg : (seg >= a.M ? a.RP + (seg - a.M) : a.RP - 1);
+            if constexpr (CW == 2) rd = *reinterpret_cast<const v2f*>(a.den + trow * hop + pos);
+            else rd.x = a.den[trow * hop + pos];
+          }
         }
         v2f* yp = inside ? yrow + tabs : a.dummy + CW * lane;
         if constexpr (CW == 2) __builtin_nontemporal_store(v4f{acc.x * rd.x, acc.y * rd.x, acc.z * rd.y, acc.w * rd.y}, (gv4f*)yp);
@@ -943,7 +973,8 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   a.cstride = ((KB - hop) + 15) & ~15;
   if (a.cstride < 16) a.cstride = 16;
   const size_t tables = TG ? 0 : (size_t)KB * 12;
-  int W = (int)((160 * 1024 - tables) / ((size_t)(BUF + a.cstride) * 8));
+  const size_t den_lds = ((size_t)hop * 4 + 15) & ~(size_t)15;
+  int W = (int)((160 * 1024 - tables - den_lds) / ((size_t)(BUF + a.cstride) * 8));
   if (W > WMAX) W = WMAX;
   if (W < 1) { *handled = false; return NXSIG_OK; }
   const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, W);  // = resident waves per CU
@@ -953,7 +984,7 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   a.runs_per_row = (a.units_per_row + run_len - 1) / run_len;
   a.total_runs = a.runs_per_row * s.batch;
   const int64_t blocks = (a.total_runs + W - 1) / W;
-  const size_t lds = tables + (size_t)W * BUF * 8 + (size_t)W * a.cstride * 8;
+  const size_t lds = tables + (size_t)W * BUF * 8 + (size_t)W * a.cstride * 8 + den_lds;
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

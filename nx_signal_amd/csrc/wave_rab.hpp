@@ -129,36 +129,74 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
     }
   };
   constexpr bool PF = LT < 30;   // register prefetch of the next unit's span (the 30- / 32-point codelets need the registers)
+  // DIRECT (round 6; one frame pair per wave with A = B, window as long as the transform): a unit that lies inside
+  // its row is loaded straight into pass A's registers — lane n2 takes x[B n1 + n2] of frame A and of frame B (4-byte loads, rows of
+  // 4 B bytes; the overlap of the two frames comes from L1) — and the NEXT unit's loads are issued once pass B's results are parked in
+  // LDS, so they travel under the untangle + store of this one.  Until then these lengths staged every unit through LDS with a loop
+  // of 4-byte loads and waited for it (no prefetch: the registers were the codelets').  Units at row ends / in padding keep that route.
+#ifndef NXSIG_RAB_DIRECT_FWD
+#define NXSIG_RAB_DIRECT_FWD 1
+#endif
+  // The early issue keeps 2 A more registers alive across the untangle: only the square lengths (1600 = 40 x 40, 1764 = 42 x 42) afford it
+  // (0.50 -> 0.565, 0.50 -> 0.53); the others spilled 60 ... 890 B to scratch and lost up to half (2400 0.44 -> 0.24, 3840 0.31 -> 0.13), and
+  // loading them at the top of the unit instead (no early issue, no LDS staging) lost too (2400 0.37, 2880 0.25, 3840 0.19: 2 A 4-byte
+  // loads of 4 B-byte rows against one pass of the span): they keep the staged route.
+  constexpr bool DIRECT = T == 1 && A == B && NXSIG_RAB_DIRECT_FWD;
+  constexpr bool DPF = DIRECT;
+  v2f v[NV];
+  auto load_direct = [&](int64_t row, int64_t u) -> bool {
+    const int64_t start = 2 * u * (int64_t)a.hop - a.lo;
+    const bool inside = nuse == KB && start >= 0 && start + a.hop + KB <= a.L;      // (wave-uniform)
+    if (inside) {
+      const float* p = a.x + (size_t)row * a.batch_stride + start + (lane < B ? lane : 0);
+      const float* q = p + a.hop;
+#pragma unroll
+      for (int n1 = 0; n1 < A; ++n1) v[n1] = v2f{p[B * n1], q[B * n1]};
+    }
+    return inside;
+  };
   // (row, unit inside the row) of the wave's units: one division per wave, then increments
   int64_t row = (p_begin + wave) / b.units_per_row;
   int64_t u = (p_begin + wave) - row * b.units_per_row;
   bool have = (PF && p_begin + wave < p_end) ? prefetch(row, u) : false;
+  bool dcur = (DPF && p_begin + wave < p_end) ? load_direct(row, u) : false, dnext = false;
   for (int64_t ui = p_begin + wave; ui < p_end; ui += W) {
     int64_t nrow = row, nu = u + W;
     while (nu >= b.units_per_row) { nu -= b.units_per_row; ++nrow; }
     const float* xr = a.x + (size_t)row * a.batch_stride;
     const int64_t q0 = 2 * T * u * (int64_t)a.hop;    // padded-signal index of the unit's first sample
     // ---- the unit's raw samples -> LDS
-    if (have) {
+    if constexpr (DIRECT && !DPF) dcur = load_direct(row, u);
+    if (!dcur) {
+      if (have) {
 #pragma unroll
-      for (int c = 0; c < NRS; ++c)
-        if (256 * c + 4 * lane < span4) *reinterpret_cast<v4f*>(&S[256 * c + 4 * lane]) = rs[c];
-    } else {
-      stage_slow(xr, q0);
+        for (int c = 0; c < NRS; ++c)
+          if (256 * c + 4 * lane < span4) *reinterpret_cast<v4f*>(&S[256 * c + 4 * lane]) = rs[c];
+      } else {
+        stage_slow(xr, q0);
+      }
+      wave_lds_fence();
     }
-    wave_lds_fence();
     have = (PF && ui + W < p_end) ? prefetch(nrow, nu) : false;   // next unit's samples travel during this unit's transforms
     const int64_t pair = T * u + g;
     const bool active = g < T && pair < a.pairs_per_row;
     const int64_t mA = 2 * pair;
     const bool haveB = active && (mA + 1 < a.M);
-    v2f v[NV];
     // pass A input of lane n2 = l: u[B n1 + n2], n1 < A.  sel < 0: the pair rides as frame A + i frame B; sel = 0 / 1: frame A / frame B
     // ALONE as the real part (solo route of a unit that holds a non-finite sample, see k_stft_r20)
     auto build = [&](int sel) {
       const float* fa = S + (2 * (g < T ? g : 0)) * a.hop + l;
       const float* fb = fa + a.hop;
       const bool on = active && l < B, onB = on && haveB;
+      if (DIRECT && dcur && sel < 0) {     // the raw samples are in v already
+#pragma unroll
+        for (int n1 = 0; n1 < A; ++n1) {
+          const float w = s_w[B * n1 + (l < B ? l : 0)];
+          const float pa = v[n1].x * w, pb = v[n1].y * w;        // exact f32 products like the reference (:101)
+          v[n1] = v2f{on ? pa : 0.0f, onB ? pb : 0.0f};
+        }
+        return;
+      }
       // unconditional LDS reads + selects (a branch per element cost more than the selects; the reads of idle lanes and of n >= nuse stay
       // inside the wave's buffer, launch_rab checks it, and are discarded, never multiplied by zero: Inf x 0 would be NaN).  SHORT: the
       // window is shorter than the transform (wave-uniform): only then does an element need its own compare
@@ -179,7 +217,7 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
     constexpr int NP = SINK == kSinkSpectrum ? KB / 2 : KB / 4;    // bin pairs per frame that reach the sink
     constexpr int NI = (NP + 63) / 64;
     v2f pw[T][2][NI];  // MEL: |XA|^2, |XB|^2 of the lane's bin pairs, parked in registers until every lane has read U
-    auto xform_sink = [&](const int sel) {
+    auto xform_sink = [&](const int sel, const bool last) {
       dft_n<A>(v);
       if (l < B) {
 #pragma unroll
@@ -206,6 +244,9 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
         for (int k2 = 0; k2 < B; ++k2) buf[g * KB + l + A * k2] = v[k2];   // U[k1 + A k2] in natural order
       }
       wave_lds_fence();
+      if constexpr (DPF) {
+        if (last) dnext = ui + W < p_end ? load_direct(nrow, nu) : false;   // the registers are free: the next unit travels under the stores
+      }
       // ---- untangle + store.  All 64 lanes walk the T transforms one after the other: lane takes the bin pairs p = lane + 64 i
       //      (bins 2 p, 2 p + 1), so a wave instruction stores 1 KiB of one frame's row contiguously
 #pragma unroll
@@ -294,14 +335,14 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
     for (int ps = 0; ps < npass; ++ps) {
       const int sel = solo ? ps : -1;
       if (solo) {
-        if (ps == 1) {
+        if (ps == 1 || dcur) {
           wave_lds_fence();      // round A's partner reads are done
-          stage_slow(xr, q0);    // the exchange overwrote the samples
+          stage_slow(xr, q0);    // the exchange overwrote the samples (a DIRECT unit never staged them)
           wave_lds_fence();
         }
         build(sel);
       }
-      xform_sink(sel);
+      xform_sink(sel, ps == npass - 1);
     }
     if (MEL) {   // (pw[][][] was filled by xform_sink(-1))
       wave_lds_fence();                          // every partner read of U is done: the buffer becomes the power spectra
@@ -342,6 +383,7 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
     }
     wave_lds_fence();  // all reads of the buffer are done before the next unit's samples overwrite it
     row = nrow; u = nu;
+    dcur = dnext;
   }
   if (MEL || (MAG && b.mag_kind == 2)) {  // one atomic per wave: running maximum in ordered-int encoding
 #pragma unroll
@@ -893,6 +935,106 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(rab_b
   }
 }
 
+// Quarter-hop inverses of the one-frame-per-wave lengths with B a multiple of 4 (1152 ... 1920, 2400 / 2880 / 3840; hop K / 4 = A x B / 4): pass B leaves x[l + A k2] in lane l,
+// so the four frames that overlap a sample sit in the SAME lane, B / 4 registers apart — the overlap-add runs in registers (acc[j] = what
+// earlier frames left at l + A j), the finished quarter leaves as 8-byte stores straight from them.  No output staging, no carry strip,
+// no gather pass: the LDS holds the tables and ONE transpose buffer per wave (3840: 3 waves instead of 2; 2400 / 2880: 4 instead of 3).
+// Sums run in ascending frame order from +0 like k_istft_rab's (carry first, then the frame); the codelets are compiled per kernel, so
+// against the LDS form a sample may differ in its last bit (fma contraction follows the surrounding code).
+template <int A, int B, int WMAX>
+__global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(WMAX <= 4 ? 1 : 2, WMAX <= 4 ? 1 : 2))) void k_istft_rab_q(IstftRabArgs a) {
+  constexpr int KB = A * B, LT = A > B ? A : B, NV = LT, Q = B / 4, NA = B - Q;
+  static_assert(64 / LT == 1 && B % 4 == 0, "one frame per wave, a quarter of B registers per hop");
+  constexpr int TRS = A * (B + 1);
+  constexpr int BUF = ((TRS + 15) & ~15) + 16;
+  const int W = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
+  float* s_w = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
+  v2f* s_x = s_tw + KB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = a.tw[i]; }
+  __syncthreads();
+  v2f* buf = s_x + wave * BUF;
+  const int hop = a.hop;                    // = A * Q
+  const int64_t run = (int64_t)blockIdx.x * W + wave;
+  if (run >= a.total_runs) return;
+  const int64_t row = run / a.runs_per_row;
+  const int64_t u0 = (run - row * a.runs_per_row) * a.run_len;
+  int64_t u1 = u0 + a.run_len;
+  if (u1 > a.units_per_row) u1 = a.units_per_row;
+  const int halo = a.RP - 1;                // earlier frames that reach into this run
+  const int64_t us = u0 >= halo ? u0 - halo : 0;
+  const float invK = 1.0f / (float)KB;
+  const v2f* zrow = a.z + (size_t)row * a.M * KB;
+  v2f* yrow = a.y + (size_t)row * a.out_len;
+  const int lA = lane < A ? lane : 0;
+  float rdv[Q];                             // the interior row of the normaliser at this lane's positions
+#pragma unroll
+  for (int k2 = 0; k2 < Q; ++k2) rdv[k2] = a.den[(size_t)(a.RP - 1) * hop + lA + A * k2];
+  v2f acc[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) acc[j] = v2f{0.f, 0.f};
+  v2f v[NV];
+  {
+    const bool have = lane < B && us < a.M;
+    const v2f* p = zrow + (size_t)(have ? us : 0) * KB + (have ? lane : 0);
+#pragma unroll
+    for (int n1 = 0; n1 < A; ++n1) v[n1] = have ? p[B * n1] : v2f{0.f, 0.f};
+  }
+  for (int64_t u = us; u < u1; ++u) {
+    // ---- pass A on conj(z): lane n2 < B takes conj z[B n1 + n2]
+#pragma unroll
+    for (int n1 = 0; n1 < A; ++n1) v[n1].y = -v[n1].y;
+    dft_n<A>(v);
+    if (lane < B) {
+#pragma unroll
+      for (int k1 = 1; k1 < A; ++k1) {
+        v[k1] = wcmul(v[k1], s_tw[k1 * B + lane]);
+        if ((k1 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    wave_lds_fence();
+    if (lane < B) {
+#pragma unroll
+      for (int k1 = 0; k1 < A; ++k1) buf[k1 * (B + 1) + lane] = v[k1];
+    }
+    wave_lds_fence();
+    if (lane < A) {
+#pragma unroll
+      for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[lane * (B + 1) + n2];
+    }
+    dft_n<B>(v);
+    // ---- x[n] = conj(T[n]) / K, x scale, x window (lib/nx_signal.ex:611-628), n = lane + A k2; + what the three frames before left there
+    const float live = u < a.M ? 1.0f : 0.0f;
+    const bool interior = u >= a.RP - 1 && u < a.M;
+    const int64_t trow = u < a.RP - 1 ? u : (u >= a.M ? a.RP + (u - a.M) : a.RP - 1);
+    const int64_t t_unit = u * (int64_t)hop;
+    const int64_t un = u + 1 < u1 ? u + 1 : u;                 // the next frame arrives in the registers this loop frees
+    const bool have = lane < B && un < a.M;
+    const v2f* pn = zrow + (size_t)(have ? un : 0) * KB + (have ? lane : 0);
+#pragma unroll
+    for (int k2 = 0; k2 < B; ++k2) {
+      const int n = lA + A * k2;
+      v2f x = fft_eps0(v2f{v[k2].x, -v[k2].y} * invK);  // Nx.ifft's clean-up (:609) precedes scale and window
+      x = x * a.scale;
+      x = x * (s_w[n] * live);
+      asm("" : "+v"(x));                                   // the windowed sample is ROUNDED before it is added (the LDS form stores it): no fma with the sum
+      const v2f sum = (k2 < NA ? acc[k2 < NA ? k2 : 0] : v2f{0.f, 0.f}) + x;
+      if (k2 < Q) {
+        const float rd = interior ? rdv[k2 < Q ? k2 : 0] : a.den[trow * hop + n];
+        if (lane < A && u >= u0 && t_unit + n < a.out_len) __builtin_nontemporal_store(sum * rd, (gv2f*)(yrow + t_unit + n));
+      } else {
+        acc[k2 - Q >= 0 ? k2 - Q : 0] = sum;
+      }
+      if (k2 < A) v[k2] = have ? pn[B * k2] : v2f{0.f, 0.f};
+    }
+    if constexpr (A > B) {
+#pragma unroll
+      for (int n1 = B; n1 < A; ++n1) v[n1] = have ? pn[B * n1] : v2f{0.f, 0.f};
+    }
+  }
+}
+
 template <int A, int B>
 inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT;
@@ -970,6 +1112,29 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   a.dummy = reinterpret_cast<v2f*>(dummy);
   const int64_t segs = (a.out_len + hop - 1) / hop;              // hop segments of the output (the last may be partial)
   a.units_per_row = (segs + T - 1) / T;
+  if constexpr (T == 1 && B % 4 == 0) {
+    if (hop * 4 == KB && tune(c, kT_ISTFT_REGOLA, 1)) {   // overlap-add in registers
+      constexpr int BUFQ = ((TRS + 15) & ~15) + 16;
+      int W = (int)((160 * 1024 - (size_t)KB * 12) / ((size_t)BUFQ * 8));
+      constexpr int WQ = BIG ? 4 : 8;                     // one / two waves per SIMD: 512 / 256 registers
+      if (W > WQ) W = WQ;
+      a.cstride = 0;
+      const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, W);
+      const int64_t run_len = istft_balanced_run_len(a.units_per_row, s.batch, (int64_t)c->num_cus * waves_per_cu, RP - 1,
+                                                     istft_min_run(c, a.units_per_row * s.batch, (int64_t)c->num_cus * waves_per_cu, 8));
+      a.run_len = run_len;
+      a.runs_per_row = (a.units_per_row + run_len - 1) / run_len;
+      a.total_runs = a.runs_per_row * s.batch;
+      const int64_t blocks = (a.total_runs + W - 1) / W;
+      const size_t lds = (size_t)KB * 12 + (size_t)W * BUFQ * 8;
+      auto kernel = k_istft_rab_q<A, B, WQ>;
+      NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      dispatch_note("istft.rab.q");
+      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * W), lds, c->stream, a);
+      NXSIG_HIP_TRY(hipGetLastError());
+      return NXSIG_OK;
+    }
+  }
   a.cstride = ((KB - hop) + 15) & ~15;
   if (a.cstride < 16) a.cstride = 16;
   const size_t tables = TG ? 0 : (size_t)KB * 12;

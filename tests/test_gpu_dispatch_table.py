@@ -130,7 +130,9 @@ DISPATCH = {
     "istft960": (_istft, (960, 240, 2, 200), {}, "istft.rab+istft.edge_chunks"),
     "istft512-hop160": (_istft, (512, 160, 2, 400), {}, "istft.rab+istft.edge_chunks"),
     "istft1764-radix7": (_istft, (1764, 441, 2, 100), {}, "istft.rab"),
-    "istft2880": (_istft, (2880, 720, 2, 60), {}, "istft.rab"),
+    "istft2880-quarter-hop": (_istft, (2880, 720, 2, 60), {}, "istft.rab.q"),       # overlap-add in registers
+    "istft2880-half-hop": (_istft, (2880, 1440, 2, 60), {}, "istft.rab"),
+    "istft1600-quarter-hop": (_istft, (1600, 400, 2, 100), {}, "istft.rab.q"),
     "istft441-radix7-odd": (_istft, (441, 110, 2, 400), {}, "istft.rab"),
     "istft443-generic": (_istft, (443, 110, 2, 400), {}, "fft.rows_generic.blue+istft.generic+istft.edge_fix"),
     # ---- fir (3.3)

@@ -562,6 +562,49 @@ def test_istft_composite_lengths_native_kernels(K, hopsel):
         assert float(np.max(np.abs(xr.real[K: -K] - x[K: len(xr) - K]))) < 1e-4
 
 
+@pytest.mark.parametrize("K", [1152, 1280, 1536, 1600, 1920, 2400, 2880, 3840])
+@pytest.mark.parametrize("M,rows", [(57, 3), (9, 1), (700, 2)])
+def test_istft_quarter_hop_overlap_add_in_registers(K, M, rows):
+    """k_istft_rab_q (round 6): at hop = K / 4 the 50- / 60- / 64-point inverses add the overlapping frames in registers (the frames that
+    share a sample sit in one lane).  Same sums in the same order as the LDS form (NXSIG_ISTFT_REGOLA=0): agreement to the last bit or two,
+    bit-identical to itself across launch geometries; head and tail rows of the normaliser, ragged last unit, runs with halo (700 frames
+    x 2 rows spread over the chip), non-finite bins included."""
+    import nx_signal_amd as S
+    from oracle import nx_oracle as O
+
+    hop = K // 4
+    rng = np.random.default_rng(K + M)
+    w = S.windows.hann(K)
+    z = (rng.standard_normal((rows, M, K)) + 1j * rng.standard_normal((rows, M, K))).astype(np.complex64)
+    z[0, M // 2, 7] = np.nan
+    opts = dict(overlap_length=K - hop, fft_length=K, scaling="spectrum", sampling_rate=16000)
+    ctx = S.Context(0)
+    native = not ctx.get_tuning("DISABLE_RAB")[0] and not ctx.get_tuning("DISABLE_WAVE")[0] and ctx.get_tuning("ISTFT_REGOLA") != (0, True)
+    y = S.istft(ctx.to_device(z), w, ctx=ctx, **opts).numpy()
+    assert ctx.last_dispatch().startswith("istft.rab.q") == native
+    ctx.set_tuning("NXSIG_ISTFT_REGOLA", 0)
+    y0 = S.istft(ctx.to_device(z), w, ctx=ctx, **opts).numpy()
+    assert not ctx.last_dispatch().startswith("istft.rab.q")
+    assert np.array_equal(np.isfinite(y), np.isfinite(y0))
+    fin = np.isfinite(y0)
+    # same sums in the same order; the two kernels compile the codelets on their own (fma contraction follows the surrounding code),
+    # so a sample may differ in its last bit: 2400 / 2880 / 3840 / 1280 / 1536 happen to agree bit for bit, 1152 / 1600 / 1920 do not
+    rms = float(np.median(np.abs(y0[fin])))          # (the first and last samples are huge: a tiny normaliser)
+    excess = np.abs(y[fin] - y0[fin]) / (np.abs(y0[fin]) + rms)
+    assert float(excess.max()) < 2e-6, (K, M, float(excess.max()), rms)
+    y1 = S.istft(ctx.to_device(z[:1]), w, ctx=ctx, **{**opts}).numpy() if rows > 1 else None
+    ctx.clear_tuning("ISTFT_REGOLA")
+    if rows > 1:   # deterministic whatever the launch geometry (run lengths change with the row count)
+        yq1 = S.istft(ctx.to_device(z[:1]), w, ctx=ctx, **opts).numpy()
+        assert np.array_equal(yq1[0].view(np.uint32), y[0].view(np.uint32))
+        assert np.array_equal(y1[0].view(np.uint32), y0[0].view(np.uint32))
+    if M <= 60:
+        yo = O.istft(z, w, **opts)
+        assert np.array_equal(np.isfinite(y), np.isfinite(yo))
+        ok = np.isfinite(yo)
+        assert float(np.max(np.abs(y[ok] - yo[ok])) / np.max(np.abs(yo[ok]))) < 1e-5
+
+
 def test_istft_composite_lengths_non_finite_bins_stay_in_their_frames():
     import nx_signal_amd as S
     from oracle import nx_oracle as O

@@ -115,7 +115,18 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
   };
   auto stage_slow = [&](const float* xr, int64_t q0) {
     const int64_t start = q0 - a.lo;
-    if (start >= 0 && start + span <= a.L) {   // inside the row (whatever the padding mode) but not 16-byte aligned: 4-byte loads
+    if (start >= 0 && start + span4 <= a.L && (reinterpret_cast<uintptr_t>(xr + start) & 15) == 0) {
+      // inside the row and 16-byte aligned (the lengths without a register prefetch land here for every unit: round 6, 4-byte loads until then)
+      const v4f* p4 = reinterpret_cast<const v4f*>(xr + start);
+      for (int i0 = lane; 4 * i0 < span4; i0 += 256) {
+        v4f t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = (4 * (i0 + 64 * k) < span4) ? p4[i0 + 64 * k] : v4f(0.0f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * (i0 + 64 * k) < span4) *reinterpret_cast<v4f*>(&S[4 * (i0 + 64 * k)]) = t[k];
+      }
+    } else if (start >= 0 && start + span <= a.L) {   // inside the row (whatever the padding mode) but not 16-byte aligned: 4-byte loads
       for (int i = lane; i < span; i += 64) S[i] = xr[start + i];
     } else {                                                      // padding / mirror / row end: per-sample bounds, eight loads in flight
       for (int i0 = lane; i0 < span; i0 += 512) {

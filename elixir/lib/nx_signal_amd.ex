@@ -98,7 +98,9 @@ defmodule NxSignalAMD do
           NIF.stft_c64(context(), Nx.to_binary(flat), length, batch, window |> Nx.as_type(:f32) |> Nx.to_binary(), params)
 
         Nx.type(data) in [{:c, 64}, {:c, 128}] ->
-          raise ArgumentError, "stft: complex samples are built for c64 data with an f32 window (got #{inspect(Nx.type(data))})"
+          # c128 samples, or c64 samples under an f64 window (the product of :101 promotes): the f64 tier, complex x real componentwise
+          {w, w64} = window_binary(window)
+          NIF.stft_c128(context(), flat |> Nx.as_type(:c128) |> Nx.to_binary(), length, batch, w, w64, params)
 
         wide ->
           {w, w64} = window_binary(window)
@@ -113,7 +115,7 @@ defmodule NxSignalAMD do
     names = List.duplicate(nil, tuple_size(batch_shape)) ++ [:frames, :frequencies]
 
     z =
-      Nx.from_binary(z, if(wide, do: :c128, else: :c64))
+      Nx.from_binary(z, if(wide or Nx.type(data) == {:c, 128} or (complex and Nx.type(window) == {:f, 64}), do: :c128, else: :c64))
       |> Nx.reshape(append(batch_shape, [m, fft_length]), names: names)
       |> revectorize(vec_axes)
 

@@ -101,6 +101,7 @@ defmodule NxSignalAMD.NIF do
   def fft_frequencies_f64(_fs, _fft_length, _endpoint), do: :erlang.nif_error(:nif_not_loaded)
   def sinc_f64(_t), do: :erlang.nif_error(:nif_not_loaded)
   def stft_f64(_ctx, _x, _length, _batch, _window, _window_is_f64, _params), do: :erlang.nif_error(:nif_not_loaded)
+  def stft_c128(_ctx, _x, _length, _batch, _window, _window_is_f64, _params), do: :erlang.nif_error(:nif_not_loaded)
   def istft_c128(_ctx, _z, _frames, _batch, _window, _window_is_f64, _params), do: :erlang.nif_error(:nif_not_loaded)
   def fir_f64(_ctx, _x, _length, _batch, _taps, _mode), do: :erlang.nif_error(:nif_not_loaded)
   def fft_c128(_ctx, _in, _is_real, _rows, _n_in, _fft_length, _inverse), do: :erlang.nif_error(:nif_not_loaded)

@@ -65,6 +65,12 @@ defmodule NxSignalAMDTest do
     assert Nx.to_number(Nx.reduce_max(Nx.abs(Nx.subtract(z, sum)))) < 1.0e-4
     {zd, _, _} = Sig.stft(Sig.DeviceTensor.to_device(x), w, opts)
     assert Sig.DeviceTensor.from_device(zd) == z
+    # c128 samples, and c64 samples under an f64 window, compute in c128 (the product of :101 promotes)
+    {z128, _, _} = Sig.stft(Nx.as_type(x, :c128), Sig.Windows.rectangular(16, type: :f64), opts)
+    assert Nx.type(z128) == {:c, 128}
+    assert Nx.to_number(Nx.reduce_max(Nx.abs(Nx.subtract(z128, Nx.as_type(z, :c128))))) < 1.0e-4
+    {zmix, _, _} = Sig.stft(x, Sig.Windows.rectangular(16, type: :f64), opts)
+    assert Nx.type(zmix) == {:c, 128}
   end
 
   test "vectorized (multichannel) inputs keep their vectorized axes" do

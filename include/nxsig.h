@@ -381,6 +381,11 @@ int nxsig_fft_frequencies_f64(double sampling_rate, int32_t fft_length, int32_t 
 /* NxSignal.stft/3 on f64 samples — lib/nx_signal.ex:68-130: x f64[batch][length] -> z c128[batch][M][K] */
 int nxsig_stft_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batch, int64_t batch_stride, const void* window,
                    int32_t window_is_f64, const nxsig_stft_params* params, nxsig_c128* z, int64_t* num_frames_out, int32_t mem);
+/* NxSignal.stft/3 on COMPLEX f64 samples (c128 IQ data) — lib/nx_signal.ex:94-102 on whatever tensor it is given: frames, c128 x window
+ * componentwise (:101), one Nx.fft row per frame (:102).  x c128[batch][length], rows `batch_stride` COMPLEX elements apart; the other
+ * arguments as nxsig_stft_f64 */
+int nxsig_stft_c128(nxsig_ctx* ctx, const nxsig_c128* x, int64_t length, int32_t batch, int64_t batch_stride, const void* window,
+                    int32_t window_is_f64, const nxsig_stft_params* params, nxsig_c128* z, int64_t* num_frames_out, int32_t mem);
 /* NxSignal.istft/3 on a c128 spectrum — lib/nx_signal.ex:582-638: z c128[batch][M][K] -> y c128[batch][M*hop + N-hop] */
 int nxsig_istft_c128(nxsig_ctx* ctx, const nxsig_c128* z, int64_t num_frames, int32_t batch, const void* window, int32_t window_is_f64,
                      const nxsig_stft_params* params, nxsig_c128* y, int32_t mem);

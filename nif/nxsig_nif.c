@@ -517,6 +517,37 @@ static ERL_NIF_TERM nif_stft_f64(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
                           enif_make_binary(env, &fb));
 }
 
+/* stft_c128(ctx, x_bin (c128), length, batch, window_bin, window_is_f64, params) -> {:ok, z_bin (c128), num_frames, times_bin, freqs_bin}
+ * complex f64 samples (lib/nx_signal.ex:94-102 on a c128 tensor, or c64 samples under an f64 window) */
+static ERL_NIF_TERM nif_stft_c128(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ctx_res_t* c;
+  ErlNifBinary x, w, zb, tb, fb;
+  ErlNifSInt64 length;
+  int batch, wf64;
+  nxsig_stft_params p;
+  if (argc != 7 || !get_ctx(env, argv[0], &c) || !enif_inspect_binary(env, argv[1], &x) || !enif_get_int64(env, argv[2], &length) ||
+      !enif_get_int(env, argv[3], &batch) || !enif_inspect_binary(env, argv[4], &w) || !enif_get_int(env, argv[5], &wf64) ||
+      !get_params(env, argv[6], &p))
+    return enif_make_badarg(env);
+  if (batch < 1 || length < 1 || x.size % 16 || x.size / 16 / (size_t)batch != (size_t)length ||
+      w.size != (size_t)p.frame_length * (wf64 ? 8 : 4))
+    return enif_make_badarg(env);
+  int64_t m = nxsig_num_frames(length, p.frame_length, p.hop, p.pad_mode, p.pad_lo, p.pad_hi);
+  if (m < 0) return mk_error(env, (int)m);
+  if (!out_bin(&zb, (uint64_t)batch, (uint64_t)m, (uint64_t)p.fft_length, 16)) return mk_oom(env);
+  int rc = nxsig_stft_c128(c->ctx, (const nxsig_c128*)x.data, length, batch, length, w.data, wf64, &p, (nxsig_c128*)zb.data, NULL, NXSIG_HOST);
+  if (rc) { enif_release_binary(&zb); return mk_error(env, rc); }
+  if (!out_bin(&tb, (uint64_t)m, 1, 1, 4)) { enif_release_binary(&zb); return mk_oom(env); }
+  if (!out_bin(&fb, (uint64_t)p.fft_length, 1, 1, 4)) { enif_release_binary(&zb); enif_release_binary(&tb); return mk_oom(env); }
+  if ((rc = nxsig_stft_times_f32(p.frame_length, p.sampling_rate, m, (float*)tb.data)) ||
+      (rc = nxsig_fft_frequencies_f32(p.sampling_rate, p.fft_length, 0, (float*)fb.data))) {
+    enif_release_binary(&zb); enif_release_binary(&tb); enif_release_binary(&fb);
+    return mk_error(env, rc);
+  }
+  return enif_make_tuple5(env, mk_atom(env, "ok"), enif_make_binary(env, &zb), enif_make_int64(env, m), enif_make_binary(env, &tb),
+                          enif_make_binary(env, &fb));
+}
+
 /* istft_c128(ctx, z_bin (c128), num_frames, batch, window_bin, window_is_f64, params) -> {:ok, y_bin (c128)} */
 static ERL_NIF_TERM nif_istft_c128(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   ctx_res_t* c;
@@ -1509,6 +1540,7 @@ static ErlNifFunc funcs[] = {
     {"fft_frequencies_f64", 3, nif_fft_frequencies_f64, 0},
     {"sinc_f64", 1, nif_sinc_f64, 0},
     {"stft_f64", 7, nif_stft_f64, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stft_c128", 7, nif_stft_c128, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"istft_c128", 7, nif_istft_c128, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fir_f64", 6, nif_fir_f64, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"fft_c128", 7, nif_fft_c128, ERL_NIF_DIRTY_JOB_IO_BOUND},

@@ -272,11 +272,14 @@ def _stft(data, window, ctx, opts, onesided, packed=False):
     if packed and K % 2:
         raise ArgumentError("stft_packed: fft_length must be even")
     # f64 tier: f64 samples or an f64 window make the reference compute in f64 / c128 (Nx.multiply promotes, :101-102)
-    data_f64 = (device_view(data)[2] == np.dtype(np.float64)) if is_device(data) else (np.asarray(data).dtype == np.float64)
-    if data_f64 or w.dtype == np.float64:
+    ddt = np.dtype(device_view(data)[2]) if is_device(data) else np.asarray(data).dtype
+    data_f64 = ddt == np.float64
+    # c128 samples, or c64 samples under an f64 window (the product of :101 promotes to c128): nxsig_stft_c128
+    data_c128 = ddt == np.complex128 or (ddt == np.complex64 and w.dtype == np.float64)
+    if data_f64 or data_c128 or w.dtype == np.float64:
         if onesided:
             raise ArgumentError("stft_onesided / stft_packed are f32 extensions; the f64 tier returns the full c128 spectrum")
-        return _stft_f64(data, w, ctx, p, N, hop, K, data_f64)
+        return _stft_f64(data, w, ctx, p, N, hop, K, data_f64, cplx=data_c128)
     # complex samples (c64 IQ data): the reference frames, multiplies and transforms whatever tensor it is given (lib/nx_signal.ex:94-102):
     # one transform per frame, nxsig_stft_c64
     data_c64 = (device_view(data)[2] == np.dtype(np.complex64)) if is_device(data) else (np.asarray(data).dtype == np.complex64)
@@ -312,30 +315,32 @@ def _stft(data, window, ctx, opts, onesided, packed=False):
     return z, times, (freqs[:Kout] if onesided else freqs)
 
 
-def _stft_f64(data, w, ctx, p, N, hop, K, data_f64):
-    """stft of f64 samples and / or with an f64 window: c128 spectrum (nxsig_stft_f64); times / frequencies stay f32 like the
-    reference's (their linspace calls do not take the data type, lib/nx_signal.ex:106-111)"""
+def _stft_f64(data, w, ctx, p, N, hop, K, data_f64, cplx=False):
+    """stft of f64 samples and / or with an f64 window: c128 spectrum (nxsig_stft_f64; complex samples: nxsig_stft_c128); times /
+    frequencies stay f32 like the reference's (their linspace calls do not take the data type, lib/nx_signal.ex:106-111)"""
     lib = _lib.load()
     M = C.c_int64()
     fs = float(p.sampling_rate)
     mode, lo, hi = p.pad_mode, p.pad_lo, p.pad_hi
     wflag = int(w.dtype == np.float64)
+    entry = lib.nxsig_stft_c128 if cplx else lib.nxsig_stft_f64
+    wide_t = np.complex128 if cplx else np.float64
     if is_device(data):
-        if not data_f64:
-            raise NxSignalUnsupported("stft: an f64 window with device-resident f32 samples is not built; widen the samples first")
-        ptr, shape, _ = device_view(data)
+        ptr, shape, ddt = device_view(data)
+        if np.dtype(ddt) != np.dtype(wide_t):
+            raise NxSignalUnsupported("stft: an f64 window with device-resident f32 / c64 samples is not built; widen the samples first")
         c = _ctx_of(data, ctx)
         L = shape[-1]
         batch = int(np.prod(shape[:-1], dtype=np.int64)) if len(shape) > 1 else 1
         m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
         z = c.empty(shape[:-1] + (m, K), np.complex128)
-        _lib.check(lib.nxsig_stft_f64(c.handle, C.c_void_p(ptr), L, batch, L, _as_ptr(w), wflag, C.byref(p), C.c_void_p(z.ptr),
-                                      C.byref(M), _lib.DEVICE))
+        _lib.check(entry(c.handle, C.c_void_p(ptr), L, batch, L, _as_ptr(w), wflag, C.byref(p), C.c_void_p(z.ptr),
+                         C.byref(M), _lib.DEVICE))
     else:
         a = np.asarray(data)
-        if a.dtype.kind not in "fiub":
+        if a.dtype.kind not in ("fiubc" if cplx else "fiub"):
             raise ArgumentError(f"stft: unsupported dtype {a.dtype}")
-        x = np.ascontiguousarray(a.astype(np.float64))   # f32 / integer samples widen exactly
+        x = np.ascontiguousarray(a.astype(wide_t))   # f32 / c64 / integer samples widen exactly
         if x.ndim < 1:
             raise ArgumentError("stft expects a tensor of rank >= 1")
         c = _ctx_of(None, ctx)
@@ -343,7 +348,7 @@ def _stft_f64(data, w, ctx, p, N, hop, K, data_f64):
         batch = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
         m = _lib.check(lib.nxsig_num_frames(L, N, hop, mode, lo, hi))
         z = np.empty(x.shape[:-1] + (m, K), dtype=np.complex128)
-        _lib.check(lib.nxsig_stft_f64(c.handle, _as_ptr(x), L, batch, L, _as_ptr(w), wflag, C.byref(p), _as_ptr(z), C.byref(M), _lib.HOST))
+        _lib.check(entry(c.handle, _as_ptr(x), L, batch, L, _as_ptr(w), wflag, C.byref(p), _as_ptr(z), C.byref(M), _lib.HOST))
     times = np.empty(m, dtype=np.float32)
     _lib.check(lib.nxsig_stft_times_f32(N, fs, m, _as_ptr(times)))
     return z, times, fft_frequencies(fs, fft_length=K)

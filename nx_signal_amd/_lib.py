@@ -113,6 +113,7 @@ SIGNATURES = {
     "nxsig_firwin_f64": (C.c_int, [_i32, C.POINTER(_f64), _i32, _i32, _f64, _i32, _i32, _f64, _p]),
     "nxsig_fft_frequencies_f64": (C.c_int, [_f64, _i32, _i32, _p]),
     "nxsig_stft_f64": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _i32, C.POINTER(StftParams), _p, C.POINTER(_i64), _i32]),
+    "nxsig_stft_c128": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _i32, C.POINTER(StftParams), _p, C.POINTER(_i64), _i32]),
     "nxsig_istft_c128": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, C.POINTER(StftParams), _p, _i32]),
     "nxsig_fft_c128": (C.c_int, [_p, _p, _i32, _i64, _i32, _i32, _i32, _p, _i32]),
     "nxsig_as_windowed_f64": (C.c_int, [_p, _p, _i64, _i32, _i64, _i32, _i32, _i32, _i64, _i64, _p, C.POINTER(_i64), _i32]),

@@ -1751,6 +1751,44 @@ int nxsig_stft_f64(nxsig_ctx* ctx, const double* x, int64_t length, int32_t batc
   NXSIG_API_END
 }
 
+int nxsig_stft_c128(nxsig_ctx* ctx, const nxsig_c128* x, int64_t length, int32_t batch, int64_t batch_stride, const void* window,
+                    int32_t window_is_f64, const nxsig_stft_params* p, nxsig_c128* z, int64_t* num_frames_out, int32_t mem) {
+  NXSIG_API_BEGIN
+  NXSIG_CHECK_CTX(ctx)
+  DispatchScope dispatch_scope(c);
+  if (!x || !window || !p || !z) return set_error(NXSIG_ERR_INVALID_ARG, "stft: null pointer argument");
+  int rc = check_mem(mem);
+  if (rc) return rc;
+  if (batch < 1 || batch > 65535) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch must be in [1, 65535]");
+  if (batch_stride < length) return set_error(NXSIG_ERR_INVALID_ARG, "stft: batch_stride < length");
+  if (p->fft_length < 1) return set_error(NXSIG_ERR_INVALID_ARG, "stft: fft_length must be >= 1");
+  if ((rc = check_scaling(p->scaling))) return rc;
+  Framing fr;
+  if ((rc = make_framing(length, p->frame_length, p->hop, p->pad_mode, p->pad_lo, p->pad_hi, &fr))) return rc;
+  if (num_frames_out) *num_frames_out = fr.M;
+  StftLaunchD a;
+  a.fr = fr; a.batch = batch; a.batch_stride = batch_stride; a.K = p->fft_length; a.x_is_complex = 1;
+  a.has_scale = p->scaling != NXSIG_SCALE_NONE;
+  a.div = a.has_scale ? scaling_of(window, window_is_f64, p->frame_length, p->scaling, p->sampling_rate) : 1.0;
+  std::vector<double> wide;
+  if ((rc = window_dev_f64(c, window, window_is_f64, p->frame_length, wide, &a.window))) return rc;
+  dispatch_note("stft.f64.c128");
+  const size_t zbytes = (size_t)batch * fr.M * p->fft_length * sizeof(double2);
+  if (mem == NXSIG_DEVICE) {
+    a.x = reinterpret_cast<const double*>(x); a.z = reinterpret_cast<double2*>(z);
+    return launch_stft_f64(c, a);
+  }
+  Staged st(c);
+  const void* xd = nullptr; void* zd = nullptr;
+  const size_t xbytes = ((size_t)(batch - 1) * batch_stride + length) * sizeof(double2);
+  if ((rc = st.in(1, x, xbytes, &xd))) return rc;
+  if ((rc = st.out_alloc(2, zbytes, &zd))) return rc;
+  a.x = reinterpret_cast<const double*>(xd); a.z = reinterpret_cast<double2*>(zd);
+  if ((rc = launch_stft_f64(c, a))) return rc;
+  return st.out_copy(z, zd, zbytes);
+  NXSIG_API_END
+}
+
 int nxsig_istft_c128(nxsig_ctx* ctx, const nxsig_c128* z, int64_t num_frames, int32_t batch, const void* window, int32_t window_is_f64,
                      const nxsig_stft_params* p, nxsig_c128* y, int32_t mem) {
   NXSIG_API_BEGIN

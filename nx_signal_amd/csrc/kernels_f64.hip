@@ -64,6 +64,20 @@ __device__ __forceinline__ double fetch_padded_d(const double* __restrict__ x, c
   return (pos >= 0 && pos < g.L) ? x[pos] : 0.0;
 }
 
+// the same for a COMPLEX signal (c128 samples, round 6): one double2 per sample
+__device__ __forceinline__ double2 fetch_padded_cd(const double2* __restrict__ x, const GeomD& g, int64_t q) {
+  int64_t pos = q - g.lo;
+  if (g.reflect) {
+    if (g.L == 1) return x[0];
+    const int64_t period = 2 * (g.L - 1);
+    pos %= period;
+    if (pos < 0) pos += period;
+    if (pos >= g.L) pos = period - pos;
+    return x[pos];
+  }
+  return (pos >= 0 && pos < g.L) ? x[pos] : make_double2(0.0, 0.0);
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem_d[];
 
 // F rows of K = 2^logK points each, stored in BIT-REVERSED order, transformed in place to natural order: radix-2 decimation in
@@ -147,7 +161,7 @@ __device__ void bluestein_core_d(double2* S, const BlueD& t) {
 
 // ------------------------------------------------------------------------------------------ STFT
 struct StftArgsD {
-  const double* x;
+  const double* x;        // f64[batch][L]; CX: c128[batch][L] (batch_stride in COMPLEX elements)
   int64_t batch_stride;
   GeomD g;
   int32_t K, logK, F;
@@ -159,12 +173,20 @@ struct StftArgsD {
   double2* z;             // c128[batch][M][K]
 };
 
-template <int KIND>
+// CX: complex samples — c128 x f64 window componentwise (lib/nx_signal.ex:101 on a complex tensor), one transform per frame as ever
+template <int KIND, bool CX = false>
 __global__ __launch_bounds__(kT) void k_stft_d(StftArgsD a) {
   double2* S = reinterpret_cast<double2*>(g_smem_d);
   const int tid = threadIdx.x;
   const int64_t m0 = (int64_t)blockIdx.x * a.F;
-  const double* x = a.x + (size_t)blockIdx.y * a.batch_stride;
+  const double* x = a.x + (size_t)blockIdx.y * a.batch_stride * (CX ? 2 : 1);
+  const double2* xc = reinterpret_cast<const double2*>(x);
+  // windowed sample n of the frame that starts at padded index q0
+  auto sample = [&](int64_t q, int n) -> double2 {
+    const double w = a.window[n];
+    if (CX) { const double2 v = fetch_padded_cd(xc, a.g, q); return make_double2(v.x * w, v.y * w); }
+    return make_double2(fetch_padded_d(x, a.g, q) * w, 0.0);
+  };
   const int nuse = a.g.N < a.K ? a.g.N : a.K;   // Nx.fft(length: K): rows zero-padded or truncated to K
   double2* z = a.z + ((size_t)blockIdx.y * a.g.M + m0) * a.K;
   if (KIND == 0) {
@@ -172,9 +194,9 @@ __global__ __launch_bounds__(kT) void k_stft_d(StftArgsD a) {
     for (int idx = tid; idx < total; idx += kT) {
       const int f = idx >> a.logK, n = idx & (a.K - 1);
       const int64_t m = m0 + f;
-      double v = 0.0;
-      if (m < a.g.M && n < nuse) v = fetch_padded_d(x, a.g, m * a.g.hop + n) * a.window[n];   // :101
-      S[(size_t)f * a.K + brev(n, a.logK)] = make_double2(v, 0.0);
+      double2 v = make_double2(0.0, 0.0);
+      if (m < a.g.M && n < nuse) v = sample(m * a.g.hop + n, n);   // :101
+      S[(size_t)f * a.K + brev(n, a.logK)] = v;
     }
     __syncthreads();
     lds_fft_d<false>(S, a.K, a.logK, a.F, a.tw);
@@ -190,9 +212,8 @@ __global__ __launch_bounds__(kT) void k_stft_d(StftArgsD a) {
     for (int n = tid; n < t.P; n += kT) {
       double2 u = make_double2(0.0, 0.0);
       if (n < nuse) {
-        const double v = fetch_padded_d(x, a.g, m0 * a.g.hop + n) * a.window[n];
-        const double2 c = t.chirp[n];
-        u = make_double2(v * c.x, v * c.y);
+        const double2 v = sample(m0 * a.g.hop + n, n), c = t.chirp[n];
+        u = CX ? cmuld(v, c) : make_double2(v.x * c.x, v.x * c.y);
       }
       S[brev(n, t.logP)] = u;
     }
@@ -205,15 +226,24 @@ __global__ __launch_bounds__(kT) void k_stft_d(StftArgsD a) {
     }
   } else {
     double* s = reinterpret_cast<double*>(g_smem_d);
-    for (int n = tid; n < nuse; n += kT) s[n] = fetch_padded_d(x, a.g, m0 * a.g.hop + n) * a.window[n];
+    for (int n = tid; n < nuse; n += kT) {
+      const double2 v = sample(m0 * a.g.hop + n, n);
+      if (CX) S[n] = v; else s[n] = v.x;
+    }
     __syncthreads();
     for (int k = tid; k < a.K; k += kT) {
       double re = 0.0, im = 0.0;
       int idx = 0;
       for (int n = 0; n < nuse; ++n) {
         const double2 w = a.tw[idx];
-        re += s[n] * w.x;
-        im += s[n] * w.y;
+        if (CX) {
+          const double2 v = S[n];
+          re += v.x * w.x - v.y * w.y;
+          im += v.x * w.y + v.y * w.x;
+        } else {
+          re += s[n] * w.x;
+          im += s[n] * w.y;
+        }
         idx += k;
         if (idx >= a.K) idx -= a.K;
       }
@@ -543,8 +573,15 @@ int rows_per_block(int K) {
 
 }  // namespace
 
+template <int KIND>
+static void launch_stft_kind_d(bool cx, dim3 grid, size_t lds, hipStream_t stream, const StftArgsD& a) {
+  if (cx) hipLaunchKernelGGL((k_stft_d<KIND, true>), grid, dim3(kT), lds, stream, a);
+  else hipLaunchKernelGGL((k_stft_d<KIND, false>), grid, dim3(kT), lds, stream, a);
+}
+
 int launch_stft_f64(Ctx* c, const StftLaunchD& s) {
   if (s.fr.M == 0 || s.batch == 0) return NXSIG_OK;
+  const bool cx = s.x_is_complex != 0;
   StftArgsD a{};
   a.x = s.x; a.batch_stride = s.batch_stride;
   a.g.L = s.fr.L; a.g.lo = s.fr.lo; a.g.M = s.fr.M; a.g.N = s.fr.N; a.g.hop = s.fr.hop; a.g.reflect = s.fr.reflect;
@@ -556,21 +593,21 @@ int launch_stft_f64(Ctx* c, const StftLaunchD& s) {
     a.logK = ilog2i(s.K); a.F = rows_per_block(s.K);
     if ((rc = table_d(c, 1, s.K, &a.tw))) return rc;
     const size_t lds = (size_t)a.F * s.K * sizeof(double2);
-    if ((rc = ensure_lds_d(k_stft_d<0>, lds))) return rc;
+    if ((rc = cx ? ensure_lds_d(k_stft_d<0, true>, lds) : ensure_lds_d(k_stft_d<0, false>, lds))) return rc;
     dim3 grid((unsigned)((s.fr.M + a.F - 1) / a.F), (unsigned)s.batch);
-    hipLaunchKernelGGL(k_stft_d<0>, grid, dim3(kT), lds, c->stream, a);
+    launch_stft_kind_d<0>(cx, grid, lds, c->stream, a);
   } else if (kind == 1) {
     a.F = 1;
     if ((rc = blue_of(c, s.K, &a.blue))) return rc;
     const size_t lds = (size_t)a.blue.P * sizeof(double2);
-    if ((rc = ensure_lds_d(k_stft_d<1>, lds))) return rc;
-    hipLaunchKernelGGL(k_stft_d<1>, dim3((unsigned)s.fr.M, (unsigned)s.batch), dim3(kT), lds, c->stream, a);
+    if ((rc = cx ? ensure_lds_d(k_stft_d<1, true>, lds) : ensure_lds_d(k_stft_d<1, false>, lds))) return rc;
+    launch_stft_kind_d<1>(cx, dim3((unsigned)s.fr.M, (unsigned)s.batch), lds, c->stream, a);
   } else if (kind == 2) {
     a.F = 1;
     if ((rc = table_d(c, 2, s.K, &a.tw))) return rc;
-    const size_t lds = (size_t)(nuse > 0 ? nuse : 1) * sizeof(double);
-    if ((rc = ensure_lds_d(k_stft_d<2>, lds))) return rc;
-    hipLaunchKernelGGL(k_stft_d<2>, dim3((unsigned)s.fr.M, (unsigned)s.batch), dim3(kT), lds, c->stream, a);
+    const size_t lds = (size_t)(nuse > 0 ? nuse : 1) * (cx ? sizeof(double2) : sizeof(double));
+    if ((rc = cx ? ensure_lds_d(k_stft_d<2, true>, lds) : ensure_lds_d(k_stft_d<2, false>, lds))) return rc;
+    launch_stft_kind_d<2>(cx, dim3((unsigned)s.fr.M, (unsigned)s.batch), lds, c->stream, a);
   } else {
     return set_error(NXSIG_ERR_UNSUPPORTED, "stft (f64): fft_length above 65536 (or a non-power-of-two one with more than 8192 samples per frame) "
                                             "is outside the f64 tier; the f32 path transforms up to 2^26 points");

@@ -290,7 +290,8 @@ int launch_stft_big(Ctx* c, const StftLaunch& s);
 
 // ---- f64 / c128 tier (kernels_f64.hip) ----
 struct StftLaunchD {
-  const double* x;       // device f64[batch][L], rows batch_stride apart
+  const double* x;       // device f64[batch][L], rows batch_stride apart; x_is_complex: c128[batch][L], batch_stride in complex elements
+  int32_t x_is_complex = 0;
   int64_t batch_stride;
   int32_t batch;
   Framing fr;

@@ -806,8 +806,14 @@ def stft_f64(data, window, overlap_length=None, fft_length="power_of_two", windo
     if overlap_length is None:
         overlap_length = N // 2
     hop = N - overlap_length
-    frames = as_windowed(np.asarray(data).astype(f64), N, hop, window_padding)
-    fr = frames * window.astype(f64)  # :101 in f64 (either operand widens exactly)
+    d = np.asarray(data)
+    if np.iscomplexobj(d):  # c128 samples (or c64 under an f64 window): complex x real componentwise, like the c64 path (SURVEY App. A rule 9)
+        frames = as_windowed(d.astype(c128), N, hop, window_padding)
+        w64 = window.astype(f64)
+        fr = frames.real * w64 + 1j * (frames.imag * w64)
+    else:
+        frames = as_windowed(d.astype(f64), N, hop, window_padding)
+        fr = frames * window.astype(f64)  # :101 in f64 (either operand widens exactly)
     K = _resolve_len(fft_length, N)
     z = _eps_clean(np.fft.fft(fr, n=K, axis=-1), eps)
     sf = _scale_factor_f64(window, scaling, sampling_rate)

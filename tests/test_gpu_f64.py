@@ -56,6 +56,49 @@ def test_stft_f64_padding_and_scaling(padding, scaling):
         close(z, zr)
 
 
+@pytest.mark.parametrize("N,K,hop", [(64, 64, 16), (512, 512, 128), (1024, 1024, 256), (400, 512, 160), (1024, 256, 256),
+                                      (100, 100, 25), (1000, 1000, 250), (48, 48, 12), (7, 7, 3), (5000, 5000, 2500)])
+def test_stft_c128_samples_match_the_oracle(N, K, hop):
+    """nxsig_stft_c128 (round 6): complex f64 samples — the reference frames, multiplies (c128 x f64 componentwise) and transforms whatever
+    tensor it is given (lib/nx_signal.ex:94-102).  All three kernel kinds (radix-2, Bluestein, table DFT), host and device buffers, the
+    linearity of the transform (stft(a + i b) = stft(a) + i stft(b)) and the f64 entry's bits left as they were."""
+    xr, xi = sig((2, max(3 * N + 17, 4 * hop + N)), N + K), sig((2, max(3 * N + 17, 4 * hop + N)), N + K + 1)
+    x = xr + 1j * xi
+    w = S.windows.hann(N, type="f64")
+    for pad in ("valid", "reflect"):
+        opts = dict(overlap_length=N - hop, fft_length=K, sampling_rate=16000, window_padding=pad, scaling="spectrum")
+        z, t, f = S.stft(x, w, **opts)
+        zo, to, fo = O.stft_f64(x, w, **opts)
+        assert z.dtype == np.complex128
+        close(z, zo)
+        assert np.array_equal(t, to) and np.array_equal(f, fo)
+        za, zb = S.stft(xr, w, **opts)[0], S.stft(xi, w, **opts)[0]
+        close(z, za + 1j * zb, rtol=1e-13)
+    ctx = S.Context(0)
+    zd = S.stft(ctx.to_device(x), w, ctx=ctx, overlap_length=N - hop, fft_length=K, sampling_rate=16000)[0]
+    assert ctx.last_dispatch().startswith("stft.f64.c128")
+    assert np.array_equal(zd.numpy().view(np.uint64), S.stft(x, w, overlap_length=N - hop, fft_length=K, sampling_rate=16000)[0].view(np.uint64))
+
+
+def test_stft_c64_samples_with_an_f64_window_compute_in_c128_and_non_finite_samples_stay_in_their_frames():
+    N, hop = 256, 64
+    x = (sig((2, 3000), 9) + 1j * sig((2, 3000), 10)).astype(np.complex64)
+    w = S.windows.hann(N, type="f64")
+    z = S.stft(x, w, overlap_length=N - hop)[0]
+    zo = O.stft_f64(x, w, overlap_length=N - hop)[0]
+    assert z.dtype == np.complex128
+    close(z, zo)
+    assert S.stft(x, w.astype(np.float32), overlap_length=N - hop)[0].dtype == np.complex64     # the c64 path is something else
+    xn = x.astype(np.complex128)
+    xn[0, 1000] = np.nan
+    xn[1, 2000] = complex(0.0, np.inf)
+    zn = S.stft(xn, w, overlap_length=N - hop)[0]
+    zno = O.stft_f64(xn, w, overlap_length=N - hop)[0]
+    assert np.array_equal(np.isfinite(zn).all(axis=-1), np.isfinite(zno).all(axis=-1))
+    ok = np.isfinite(zno)
+    assert float(np.max(np.abs(zn[ok] - zno[ok]))) <= 1e-12 * float(np.max(np.abs(zno[ok])))
+
+
 def test_stft_f32_samples_with_an_f64_window_compute_in_double():
     N = 512
     x = sig(6000, 3).astype(np.float32)

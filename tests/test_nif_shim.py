@@ -232,6 +232,12 @@ def test_f64_tier_through_the_nif(nctx):
         assert np.array_equal(np.frombuffer(zb, np.complex128).reshape(z.shape), z) and np.array_equal(f32(tb), t) and np.array_equal(f32(fb), f)
         ok, yb = H.call("istft_c128", nctx, z, m, 2, w, flag, prm)
         assert np.array_equal(np.frombuffer(yb, np.complex128).reshape(2, -1), S.istft(z, w, overlap_length=N - hop, scaling="spectrum", sampling_rate=8000.0))
+    xc = x + 1j * rng.standard_normal(x.shape)       # c128 samples (round 6)
+    ok, zb, m, tb, fb = H.call("stft_c128", nctx, xc, xc.shape[1], 2, w64, 1, prm)
+    zc = S.stft(xc, w64, overlap_length=N - hop, scaling="spectrum", sampling_rate=8000.0)[0]
+    assert ok == "ok" and m == zc.shape[1] and np.array_equal(np.frombuffer(zb, np.complex128).reshape(zc.shape), zc)
+    with pytest.raises(H.BadArg):
+        H.call("stft_c128", nctx, x, x.shape[1], 2, w64, 1, prm)   # f64 rows are half the bytes of c128 rows
     h = S.filters.firwin(129, [0.3], type="f64")
     ok, yb = H.call("fir_f64", nctx, x, x.shape[1], 2, h, 1)
     assert np.array_equal(np.frombuffer(yb, np.float64).reshape(2, -1), S.filters.fir(x, h))

@@ -384,10 +384,69 @@ __device__ __forceinline__ void dft64(v2f* v) {
   }
 }
 
+// ---- round 6, second pass: 2205 = 35 x 63 (the 50 ms frame of 44.1 kHz audio)
+// 9-point DFT, Cooley-Tukey 3 x 3: n = 3 n1 + n2, k = k1 + 3 k2, twiddles W_9^(n2 k1) between the two rounds of dft3
+__device__ __forceinline__ void dft9(v2f* v) {
+  v2f Y[3][3];
+#pragma unroll
+  for (int n2 = 0; n2 < 3; ++n2) {
+    v2f c0 = v[n2], c1 = v[3 + n2], c2 = v[6 + n2];
+    dft3(c0, c1, c2);
+    Y[0][n2] = c0; Y[1][n2] = c1; Y[2][n2] = c2;
+  }
+  Y[1][1] = cmulc<false>(Y[1][1], 0.766044443118978f, -0.6427876096865393f);   // W_9^1
+  Y[1][2] = cmulc<false>(Y[1][2], 0.17364817766693041f, -0.984807753012208f);   // W_9^2
+  Y[2][1] = cmulc<false>(Y[2][1], 0.17364817766693041f, -0.984807753012208f);   // W_9^2
+  Y[2][2] = cmulc<false>(Y[2][2], -0.9396926207859083f, -0.3420201433256689f);   // W_9^4
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    dft3(Y[k1][0], Y[k1][1], Y[k1][2]);
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) v[k1 + 3 * k2] = Y[k1][k2];
+  }
+}
+
+// 35-point DFT, prime-factor 5 x 7: n = (7 n1 + 5 n2) mod 35, k = (21 k1 + 15 k2) mod 35
+__device__ __forceinline__ void dft35(v2f* v) {
+  v2f A[5][7];
+#pragma unroll
+  for (int n2 = 0; n2 < 7; ++n2) {
+    v2f c0 = v[(5 * n2) % 35], c1 = v[(7 + 5 * n2) % 35], c2 = v[(14 + 5 * n2) % 35], c3 = v[(21 + 5 * n2) % 35], c4 = v[(28 + 5 * n2) % 35];
+    dft5(c0, c1, c2, c3, c4);
+    A[0][n2] = c0; A[1][n2] = c1; A[2][n2] = c2; A[3][n2] = c3; A[4][n2] = c4;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 5; ++k1) {
+    dft7(A[k1][0], A[k1][1], A[k1][2], A[k1][3], A[k1][4], A[k1][5], A[k1][6]);
+#pragma unroll
+    for (int k2 = 0; k2 < 7; ++k2) v[(21 * k1 + 15 * k2) % 35] = A[k1][k2];
+  }
+}
+
+// 63-point DFT, prime-factor 9 x 7: n = (7 n1 + 9 n2) mod 63, k = (28 k1 + 36 k2) mod 63
+__device__ __forceinline__ void dft63(v2f* v) {
+  v2f A[9][7];
+#pragma unroll
+  for (int n2 = 0; n2 < 7; ++n2) {
+    v2f cc[9];
+#pragma unroll
+    for (int n1 = 0; n1 < 9; ++n1) cc[n1] = v[(7 * n1 + 9 * n2) % 63];
+    dft9(cc);
+#pragma unroll
+    for (int k1 = 0; k1 < 9; ++k1) A[k1][n2] = cc[k1];
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 9; ++k1) {
+    dft7(A[k1][0], A[k1][1], A[k1][2], A[k1][3], A[k1][4], A[k1][5], A[k1][6]);
+#pragma unroll
+    for (int k2 = 0; k2 < 7; ++k2) v[(28 * k1 + 36 * k2) % 63] = A[k1][k2];
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void dft_n(v2f* v) {
   static_assert(N == 4 || N == 8 || N == 10 || N == 12 || N == 14 || N == 15 || N == 16 || N == 20 || N == 21 || N == 24 || N == 25 || N == 28 || N == 30 || N == 32 ||
-                N == 40 || N == 42 || N == 48 || N == 50 || N == 60 || N == 64, "no codelet for this length");
+                N == 35 || N == 40 || N == 42 || N == 48 || N == 50 || N == 60 || N == 63 || N == 64, "no codelet for this length");
   if constexpr (N == 4) dft4<false>(v[0], v[1], v[2], v[3]);
   else if constexpr (N == 8) dft8<false>(v);
   else if constexpr (N == 10) dft10(v);
@@ -407,6 +466,8 @@ __device__ __forceinline__ void dft_n(v2f* v) {
   else if constexpr (N == 50) dft50(v);
   else if constexpr (N == 60) dft60(v);
   else if constexpr (N == 64) dft64(v);
+  else if constexpr (N == 35) dft35(v);
+  else if constexpr (N == 63) dft63(v);
   else dft48(v);
 }
 

@@ -28,12 +28,17 @@
 // round 6: radix 7 (the 20 / 40 ms frames of 44.1 kHz audio) and the 50 / 60 / 80 ms frames of 48 kHz audio; complex-spectrum sink only
 // (log-mel / magnitude sinks of these lengths take the two-step path).  882 % 4 == 2: fine for the spectrum sink's bin pairs; 441 is ODD:
 // single bins and 8-byte accesses in the drains, 8-byte spectrum loads in the inverse.
-#define NXSIG_RAB_PART6(X) X(441, 21, 21) X(882, 42, 21) X(1764, 42, 42)
+#define NXSIG_RAB_PART6(X) X(441, 21, 21) X(882, 42, 21) X(1764, 42, 42) X(2205, 35, 63)
 #define NXSIG_RAB_PART7(X) X(2400, 50, 48) X(2880, 60, 48) X(3840, 64, 60)
 // inverse only: power-of-two frame lengths with a hop the N / hop in {1, 2, 4, 8} kernels of kernels_wave.hip do not take (e.g. 512 / 160)
 #define NXSIG_RAB_INVERSE_ONLY(X) X(128, 16, 8) X(256, 16, 16) X(512, 32, 16) X(1024, 32, 32)
 
 namespace nxsig {
+
+// Row stride of the transposed block in complex cells: ODD, so that the lanes of pass B (lane k1 reads row k1) start in different banks.
+// B + 1 for an even B; an odd B took B + 1 too until round 6 — 16 cells for B = 15 (240 / 300 / 360): every second lane of a half-wave on
+// the same bank, 480 cycles for the 30 reads of pass B instead of 30 (tools/lds_bank_model.py) — now B + 2.
+constexpr int rab_bp(int B) { return B + ((B & 1) ? 2 : 1); }
 
 struct RabArgs {
   WaveArgs w;              // framing, window (f32[K], zero beyond N), div / has_scale, z; pairs_per_row = ceil(M / 2)
@@ -69,7 +74,7 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
   const WaveArgs& a = b.w;
   constexpr bool MEL = SINK == kSinkMel, MAG = SINK == kSinkMag;
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT;
-  constexpr int TRS = A * (B + 1);                          // one transform's transposed block (row stride B + 1)
+  constexpr int TRS = A * rab_bp(B);                        // one transform's transposed block (row stride B + 1, B + 2 for an odd B)
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;   // complex cells per wave: staging (<= 2 BUF floats) / T x TRS / T x KB
   constexpr int NRS = 10;                                   // 16-byte loads per lane that prefetch a unit's span (<= 2560 floats)
   float* s_w = reinterpret_cast<float*>(g_wave_smem);
@@ -240,13 +245,13 @@ __attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_r
       wave_lds_fence();                               // every lane has read its samples: the buffer becomes the exchange
       if (g < T && l < B) {
 #pragma unroll
-        for (int k1 = 0; k1 < A; ++k1) buf[g * TRS + k1 * (B + 1) + l] = v[k1];
+        for (int k1 = 0; k1 < A; ++k1) buf[g * TRS + k1 * rab_bp(B) + l] = v[k1];
       }
       wave_lds_fence();
       // ---- pass B: lane k1 = l < A: DFT_B over n2
       if (g < T && l < A) {
 #pragma unroll
-        for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[g * TRS + l * (B + 1) + n2];
+        for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[g * TRS + l * rab_bp(B) + n2];
       }
       dft_n<B>(v);
       wave_lds_fence();
@@ -414,7 +419,7 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   // the persistent inverse kernels gain 40-70 % from — measured 0.46 / 0.59 / 0.55 / 0.50 / 0.56 against 0.52 / 0.56 / 0.55 / 0.50 / 0.60
   // here for 720 / 768 / 800 / 900 / 960: the blocks retire together and the CU idles between them)
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT;
-  constexpr int TRS = A * (B + 1);
+  constexpr int TRS = A * rab_bp(B);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   // (1920: four waves would need 87 KB — one workgroup, four waves per CU; eight share the tables in 150 KB)
   // (round 6: lengths above 1920 cannot hold eight exchange buffers: as many waves as fit 160 KB beside the tables — 6 / 5 / 3 for 2400 / 2880 / 3840)
@@ -562,7 +567,7 @@ __device__ __forceinline__ v2f fetch_any_c64(const v2f* __restrict__ x, const Ra
 template <int A, int B, bool SCALE, int W>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_stft_rab_c64(RabCArgs a) {
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT;
-  constexpr int TRS = A * (B + 1);
+  constexpr int TRS = A * rab_bp(B);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   float* s_w = reinterpret_cast<float*>(g_wave_smem);
   v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
@@ -627,12 +632,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
     wave_lds_fence();
     if (g < T && l < B) {
 #pragma unroll
-      for (int k1 = 0; k1 < A; ++k1) buf[g * TRS + k1 * (B + 1) + l] = v[k1];
+      for (int k1 = 0; k1 < A; ++k1) buf[g * TRS + k1 * rab_bp(B) + l] = v[k1];
     }
     wave_lds_fence();
     if (g < T && l < A) {
 #pragma unroll
-      for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[g * TRS + l * (B + 1) + n2];
+      for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[g * TRS + l * rab_bp(B) + n2];
     }
     dft_n<B>(v);
     wave_lds_fence();
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
 template <int A, int B>
 inline int launch_rab_c64(Ctx* c, const StftLaunch& s, bool* handled) {
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT;
-  constexpr int TRS = A * (B + 1);
+  constexpr int TRS = A * rab_bp(B);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   constexpr int W_FIT = (160 * 1024 - KB * 12) / (BUF * 8), W = W_FIT < 4 ? W_FIT : 4;   // (3840 = 64 x 60: three exchange buffers beside the tables)
   static_assert(W >= 1, "the tables and one exchange buffer must fit the LDS");
@@ -763,7 +768,7 @@ constexpr bool rab_big(int A, int B) { return A > NXSIG_RAB_BIG_LT || B > NXSIG_
 template <int A, int B, bool ODD, int WMAX, bool TG>
 __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(rab_big(A, B) ? 1 : 2, rab_big(A, B) ? 1 : 3))) void k_istft_rab(IstftRabArgs a) {
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT, CMAX = KB;
-  constexpr int TRS = A * (B + 1);
+  constexpr int TRS = A * rab_bp(B);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   constexpr bool KODD = (KB & 1) != 0;          // odd frame length (441): spectra rows are 8-byte aligned only -> 8-byte loads
   constexpr int N4 = KODD ? T * KB : T * KB / 2;   // pieces of a unit's T spectra: 16 bytes each (8 when KODD)
@@ -862,12 +867,12 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(rab_b
     wave_lds_fence();
     if (g < T && l < B) {
 #pragma unroll
-      for (int k1 = 0; k1 < A; ++k1) buf[g * TRS + k1 * (B + 1) + l] = v[k1];
+      for (int k1 = 0; k1 < A; ++k1) buf[g * TRS + k1 * rab_bp(B) + l] = v[k1];
     }
     wave_lds_fence();
     if (g < T && l < A) {
 #pragma unroll
-      for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[g * TRS + l * (B + 1) + n2];
+      for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[g * TRS + l * rab_bp(B) + n2];
     }
     dft_n<B>(v);
     wave_lds_fence();
@@ -956,7 +961,7 @@ template <int A, int B, int WMAX>
 __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(WMAX <= 4 ? 1 : 2, WMAX <= 4 ? 1 : 2))) void k_istft_rab_q(IstftRabArgs a) {
   constexpr int KB = A * B, LT = A > B ? A : B, NV = LT, Q = B / 4, NA = B - Q;
   static_assert(64 / LT == 1 && B % 4 == 0, "one frame per wave, a quarter of B registers per hop");
-  constexpr int TRS = A * (B + 1);
+  constexpr int TRS = A * rab_bp(B);
   constexpr int BUF = ((TRS + 15) & ~15) + 16;
   const int W = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
   float* s_w = reinterpret_cast<float*>(g_wave_smem);
@@ -1007,12 +1012,12 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(WMAX 
     wave_lds_fence();
     if (lane < B) {
 #pragma unroll
-      for (int k1 = 0; k1 < A; ++k1) buf[k1 * (B + 1) + lane] = v[k1];
+      for (int k1 = 0; k1 < A; ++k1) buf[k1 * rab_bp(B) + lane] = v[k1];
     }
     wave_lds_fence();
     if (lane < A) {
 #pragma unroll
-      for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[lane * (B + 1) + n2];
+      for (int n2 = 0; n2 < B; ++n2) v[n2] = buf[lane * rab_bp(B) + n2];
     }
     dft_n<B>(v);
     // ---- x[n] = conj(T[n]) / K, x scale, x window (lib/nx_signal.ex:611-628), n = lane + A k2; + what the three frames before left there
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(WMAX 
 template <int A, int B>
 inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window_host, bool* handled) {
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT;
-  constexpr int TRS = A * (B + 1);
+  constexpr int TRS = A * rab_bp(B);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   // ONE workgroup per CU with as many waves as the LDS (exchange + carry strip of K - hop cells per wave, the tables once unless they
   // stay in global memory) and the registers allow: 12 / 12 / 8 / 6 waves for 320 / 480 / 640 / 960 at hop K / 4.  (Round 5, until then

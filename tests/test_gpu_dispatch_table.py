@@ -112,9 +112,10 @@ DISPATCH = {
     "stft441-default-fft-length-512": (_stft, (441, 110, 512, 2, 400), {}, "stft.quad2"),   # fft_length defaults to :power_of_two in the reference (lib/nx_signal.ex:78)
     "stft2400-default-fft-length-4096": (_stft, (2400, 600, 4096, 2, 60), {}, "stft.real2x.4k"),
     "stft441-radix7-odd": (_stft, (441, 110, 441, 2, 400), {}, "stft.rab"),
+    "stft2205-35x63-odd": (_stft, (2205, 441, 2205, 2, 60), {}, "stft.rab"),
     "stft443-bluestein": (_stft, (443, 110, 443, 2, 400), {}, "stft.blue"),
     "stft1020-bluestein": (_stft, (1020, 255, 1020, 2, 200), {}, "stft.blue"),
-    "stft2205-generic": (_stft, (2205, 551, 2205, 2, 50), {}, "stft.generic.blue"),
+    "stft2310-generic": (_stft, (2310, 577, 2310, 2, 50), {}, "stft.generic.blue"),       # 2310 = 2 x 3 x 5 x 7 x 11: a prime factor above 7
     "stft16-generic": (_stft, (16, 4, 16, 2, 400), {}, "stft.generic.pow2"),
     # ---- stft, c64 samples (3.1c)
     "stft-c64-512": (_stft, (512, 128, 512, 2, 400), {"cplx": True}, "stft_c64.rab"),
@@ -134,6 +135,7 @@ DISPATCH = {
     "istft2880-half-hop": (_istft, (2880, 1440, 2, 60), {}, "istft.rab"),
     "istft1600-quarter-hop": (_istft, (1600, 400, 2, 100), {}, "istft.rab.q"),
     "istft441-radix7-odd": (_istft, (441, 110, 2, 400), {}, "istft.rab"),
+    "istft2205-35x63-odd": (_istft, (2205, 441, 2, 60), {}, "istft.rab"),
     "istft443-generic": (_istft, (443, 110, 2, 400), {}, "fft.rows_generic.blue+istft.generic+istft.edge_fix"),
     # ---- fir (3.3)
     "fir257": (_fir, (257, 2, 1 << 20), {}, "fir.pair+fir.pair.edge"),

@@ -426,7 +426,7 @@ def test_stft_onesided_equals_the_first_half_of_stft_bit_for_bit(K, N, hop, pad,
 
 
 # every fft length with a native A x B kernel (wave_rab.hpp: four lists, four translation units)
-RAB_LENGTHS = [441, 882, 1764, 2400, 2880, 3840,   # round 6: radix 7 (10 / 20 / 40 ms at 44.1 kHz; 441 is ODD: 8-byte drains) and the 50 / 60 / 80 ms frames of 48 kHz audio
+RAB_LENGTHS = [441, 882, 1764, 2205, 2400, 2880, 3840,   # round 6: radix 7 (10 / 20 / 40 / 50 ms at 44.1 kHz; 441 and 2205 = 35 x 63 are ODD: 8-byte drains) and the 50 / 60 / 80 ms frames of 48 kHz audio
                192, 288, 576, 1152, 1440, 1536, 1920, 32, 64, 100, 120, 160, 200, 240, 300, 360, 384, 320, 480, 640, 960, 500, 600, 720, 768, 800, 900, 1000, 1200, 1280, 1600]
 
 

@@ -197,3 +197,14 @@ def test_no_launch_path_reads_the_environment():
             if re.search(r"\bgetenv\s*\(", code):
                 calls.append((os.path.basename(f), i))
     assert sorted(f for f, _ in calls) == ["api.cpp", "group.cpp", "group.cpp"], calls
+
+
+def test_codelet_index_maps_match_numpy():
+    """tools/check_codelet_maps.py: the prime-factor / Cooley-Tukey index maps written in small_dft.hpp's comments reproduce numpy's
+    transform for every composite codelet (the code beside each comment is pinned by the kernels' -m gpu parity tests)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_codelet_maps.py")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(" ok") >= 20 and "WRONG" not in r.stdout

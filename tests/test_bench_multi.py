@@ -64,6 +64,23 @@ def test_self_spawn_sets_a_launcher_environment(monkeypatch):
     assert bench.self_spawn(argparse.Namespace(gpus=8, share_gpu=False)) == 2 and not seen
 
 
+def _bench_line(cmd, env, timeout):
+    """Runs a ranked bench.py command and returns its ONE JSON line.  N ranks on ONE device bootstrap RCCL over loopback sockets (test
+    mode); on a loaded box that bootstrap failed once in seven full-suite runs — bench.py then falls back to its file control plane (or,
+    with --dry, exits 3 with the reason), as designed.  One retry for exactly that; a second failure fails the test with bench.py's stderr."""
+    for attempt in (0, 1):
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        rccl_down = (r.returncode == 3 and lines and '"preflight_failed": "RCCL"' in lines[-1]) or (
+            r.returncode == 0 and len(lines) == 1 and not json.loads(lines[0])["comm"]["backend"].startswith("RCCL"))
+        if rccl_down and attempt == 0:
+            continue
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert len(lines) == 1, r.stdout[-2000:]
+        assert json.loads(lines[0])["comm"]["backend"].startswith("RCCL"), r.stderr[-3000:]
+        return lines[0]
+
+
 def _check_line(line, n):
     d = json.loads(line)
     assert d["n_gpus"] == n and d["scaling"] == "weak"
@@ -84,12 +101,7 @@ def test_gpus_n_self_spawns_and_measures_configs_4_and_5(n):
     """plain `python bench.py --gpus 2 --share-gpu` (no launcher): n_gpus == 2, RCCL, config 3 / 4 / 5 blocks, both assemblies"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--share-gpu"] + SMALL, env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, r.stdout[-2000:]
-    _check_line(lines[0], n)
+    _check_line(_bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--share-gpu"] + SMALL, env, 900), n)
 
 
 @pytest.mark.gpu
@@ -99,12 +111,7 @@ def test_dry_preflight_allocates_and_launches_everything_once():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
     small = [a for a in SMALL if a not in ("--no-verify",)]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dry"] + small, env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    d = json.loads(_bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dry"] + small, env, 900))
     assert d["dry"] is True and d["n_gpus"] == 2 and d["steps"] == 1
     pf = d["preflight"]
     assert len(pf["high_water_GiB_per_rank"]) == 2 and all(v > 0 for v in pf["high_water_GiB_per_rank"])
@@ -125,11 +132,7 @@ def test_driver_launch_line_four_ranks_share_gpu():
     env.update(NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--share-gpu"] + SMALL
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    _check_line(lines[0], 4)
+    _check_line(_bench_line(cmd, env, 1200), 4)
 
 
 def test_reduce_secondary_takes_the_slowest_rank_and_survives_a_failed_block():

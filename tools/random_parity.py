@@ -10,7 +10,7 @@ from oracle import nx_oracle as O
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 LENGTHS = [32, 192, 288, 576, 1152, 1440, 1536, 1920, 64, 100, 120, 128, 160, 200, 240, 256, 300, 320, 360, 384, 400, 480, 500, 512, 600, 640, 720, 768, 800, 900, 960, 1000, 1024, 1200, 1280, 1600, 2048, 333, 441, 48,
-           882, 1764, 2400, 2880, 3840, 443, 4096]   # round 6: the radix-7 / 50- / 60- / 64-point lengths (441 odd), one Bluestein length, the 4096 front end
+           882, 1764, 2205, 2400, 2880, 3840, 443, 4096]   # round 6: the radix-7 / 50- / 60- / 64-point lengths (441 odd), one Bluestein length, the 4096 front end
 ctx = S.Context(0)
 t0 = time.time(); n = 0; worst = {}
 def note(kind, err, what):
@@ -28,7 +28,7 @@ while time.time() - t0 < budget:
     w = S.windows.hann(N) if rng.random() < 0.5 else S.windows.hamming(N)
     opts = dict(overlap_length=N - hop, fft_length=K, window_padding=pad, scaling=scaling, sampling_rate=16000)
     what = (K, N, hop, rows, L, pad, scaling)
-    kind = rng.choice(["stft", "c64", "mel", "mag", "istft", "fir"])
+    kind = rng.choice(["stft", "c64", "mel", "mag", "istft", "istft", "fir", "c128"])
     if kind == "stft":
         x = rng.standard_normal((rows, L)).astype(np.float32)
         if rng.random() < 0.2: x[rng.integers(rows), rng.integers(L)] = np.nan
@@ -40,6 +40,14 @@ while time.time() - t0 < budget:
         x = (rng.standard_normal((rows, L)) + 1j * rng.standard_normal((rows, L))).astype(np.complex64)
         z = S.stft(ctx.to_device(x), w, ctx=ctx, **opts)[0].numpy(); zo = O.stft(x, w, **opts)[0]
         note("c64", float(np.max(np.abs(z - zo)) / np.max(np.abs(zo))), what)
+    elif kind == "c128":   # c128 samples on the f64 tier (round 6): tolerance 1e-11 of the largest magnitude
+        if rows * L > 400_000: L = max(N, 400_000 // rows)
+        x = rng.standard_normal((rows, L)) + 1j * rng.standard_normal((rows, L))
+        w64 = w.astype(np.float64)
+        z = S.stft(x, w64, **opts)[0]; zo = O.stft_f64(x, w64, **opts)[0]
+        e = float(np.max(np.abs(z - zo)) / np.max(np.abs(zo)))
+        assert e < 1e-11, ("c128", e, what)
+        note("c128", e, what)
     elif kind == "mel" and K >= 64 and K % 2 == 0:
         x = rng.standard_normal((rows, L)).astype(np.float32)
         o2 = dict(opts); o2["scaling"] = None

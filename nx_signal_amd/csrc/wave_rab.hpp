@@ -40,6 +40,21 @@ namespace nxsig {
 // the same bank, 480 cycles for the 30 reads of pass B instead of 30 (tools/lds_bank_model.py) — now B + 2.
 constexpr int rab_bp(int B) { return B + ((B & 1) ? 2 : 1); }
 
+// Forward kernels of the 50- / 60- / 64-point lengths: the window stays in global memory (L1 / L2 hits, read once per unit beside the
+// staging loads) when the 4 K bytes it frees in LDS buy another wave: 3840 = 64 x 60 runs 4 instead of 3
+#ifndef NXSIG_RAB_WG
+#define NXSIG_RAB_WG 1
+#endif
+constexpr bool rab_wg(int A, int B) {
+  const int KB = A * B, LT = A > B ? A : B, T = 64 / LT, TRS = A * rab_bp(B);
+  const int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
+  int w12 = (160 * 1024 - KB * 12) / (BUF * 8), w8 = (160 * 1024 - KB * 8) / (BUF * 8);
+  if (w12 > 8) w12 = 8;
+  if (w8 > 8) w8 = 8;
+  return NXSIG_RAB_WG && (A > 48 || B > 48) && w8 > w12 && w8 <= 4;   // (<= 4 waves: one per SIMD, the whole register file — the window
+                                                                        // loads of a unit are in flight together; at 7 waves 2400 spilled 228 B)
+}
+
 struct RabArgs {
   WaveArgs w;              // framing, window (f32[K], zero beyond N), div / has_scale, z; pairs_per_row = ceil(M / 2)
   const v2f* tw;           // c64[A][B]: W_K^(n2 k1) at [k1 * B + n2]: the lanes n2 of pass A read consecutive cells (at [n2 * A + k1]
@@ -70,18 +85,20 @@ constexpr int rab_min_waves(int A, int B, int sink) {
 
 template <int A, int B, bool SCALE, int W, int SINK = kSinkSpectrum>
 __global__ __launch_bounds__(64 * W)
-__attribute__((amdgpu_waves_per_eu(rab_min_waves(A, B, SINK), 3))) void k_stft_rab(RabArgs b) {
+__attribute__((amdgpu_waves_per_eu(rab_wg(A, B) ? 1 : rab_min_waves(A, B, SINK), rab_wg(A, B) ? 1 : 3))) void k_stft_rab(RabArgs b) {
   const WaveArgs& a = b.w;
   constexpr bool MEL = SINK == kSinkMel, MAG = SINK == kSinkMag;
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT, NV = LT;
   constexpr int TRS = A * rab_bp(B);                        // one transform's transposed block (row stride B + 1, B + 2 for an odd B)
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;   // complex cells per wave: staging (<= 2 BUF floats) / T x TRS / T x KB
   constexpr int NRS = 10;                                   // 16-byte loads per lane that prefetch a unit's span (<= 2560 floats)
-  float* s_w = reinterpret_cast<float*>(g_wave_smem);
-  v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
+  constexpr bool WG = rab_wg(A, B);
+  float* s_w0 = reinterpret_cast<float*>(g_wave_smem);
+  v2f* s_tw = reinterpret_cast<v2f*>(s_w0 + (WG ? 0 : KB));
   v2f* s_x = s_tw + KB;
+  const float* s_w = WG ? a.wtab : s_w0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: unit arithmetic on the scalar unit
-  for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = b.tw[i]; }
+  for (int i = tid; i < KB; i += 64 * W) { if (!WG) s_w0[i] = a.wtab[i]; s_tw[i] = b.tw[i]; }
   float* s_csr = reinterpret_cast<float*>(s_x + W * BUF);
   int* s_off = reinterpret_cast<int*>(s_csr + (MEL ? b.nnz : 0));
   int* s_lo = s_off + (MEL ? b.mel_bins + 1 : 0);
@@ -423,7 +440,8 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   // (1920: four waves would need 87 KB — one workgroup, four waves per CU; eight share the tables in 150 KB)
   // (round 6: lengths above 1920 cannot hold eight exchange buffers: as many waves as fit 160 KB beside the tables — 6 / 5 / 3 for 2400 / 2880 / 3840)
-  constexpr int W_FIT = (160 * 1024 - KB * 12) / (BUF * 8);
+  constexpr int TABB = rab_wg(A, B) ? 8 : 12;        // bytes of tables per bin in LDS
+  constexpr int W_FIT = (160 * 1024 - KB * TABB) / (BUF * 8);
   constexpr int W = (KB * 12 + 4 * BUF * 8 > 80 * 1024) ? (W_FIT < 8 ? W_FIT : 8) : 4, WM = W;   // WM: the log-mel sink
   static_assert(W >= 1, "the tables and one exchange buffer must fit the LDS");
   const int nuse = s.fr.N < KB ? s.fr.N : KB;
@@ -469,7 +487,7 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   {  // the launch must fit the LDS BEFORE the call is committed: a dense filterbank beside the 150 KB of the 1920-point kernel does not,
      // and the caller's two-step path takes it (it used to surface as a HIP launch error after *handled was set)
     const int wl = sink == kSinkMel ? WM : W;
-    if ((size_t)KB * 12 + (size_t)wl * BUF * 8 + lds_extra > (size_t)160 * 1024) return NXSIG_OK;
+    if ((size_t)KB * TABB + (size_t)wl * BUF * 8 + lds_extra > (size_t)160 * 1024) return NXSIG_OK;
   }
   *handled = true;
   if (mel) *mel->handled = true;
@@ -503,7 +521,7 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   a.chunk = (int64_t)w * fill_units_per_wave(c, b.total_units, w, sink == kSinkMel ? 8 : 4);   // four units per wave (two: -1 ... -3 %), short-lived workgroups; the mel sink amortises its CSR preload
   const int64_t blocks = (b.total_units + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
-  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)w * BUF * 8 + lds_extra;
+  const size_t lds = (size_t)KB * TABB + (size_t)w * BUF * 8 + lds_extra;
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

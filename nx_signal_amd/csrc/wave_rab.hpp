@@ -975,18 +975,28 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(rab_b
 // no gather pass: the LDS holds the tables and ONE transpose buffer per wave (3840: 3 waves instead of 2; 2400 / 2880: 4 instead of 3).
 // Sums run in ascending frame order from +0 like k_istft_rab's (carry first, then the frame); the codelets are compiled per kernel, so
 // against the LDS form a sample may differ in its last bit (fma contraction follows the surrounding code).
+// the window of the quarter-hop kernel moves from LDS into registers when that buys a wave within WMAX (3840 = 64 x 60: 4 waves instead of 3)
+constexpr bool rab_q_wr(int A, int B, int WMAX) {
+  const int KB = A * B, TRS = A * rab_bp(B), BUF = ((TRS + 15) & ~15) + 16;
+  int w12 = (160 * 1024 - KB * 12) / (BUF * 8), w8 = (160 * 1024 - KB * 8) / (BUF * 8);
+  if (w12 > WMAX) w12 = WMAX;
+  if (w8 > WMAX) w8 = WMAX;
+  return WMAX <= 4 && w8 > w12;
+}
+
 template <int A, int B, int WMAX>
 __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(WMAX <= 4 ? 1 : 2, WMAX <= 4 ? 1 : 2))) void k_istft_rab_q(IstftRabArgs a) {
   constexpr int KB = A * B, LT = A > B ? A : B, NV = LT, Q = B / 4, NA = B - Q;
   static_assert(64 / LT == 1 && B % 4 == 0, "one frame per wave, a quarter of B registers per hop");
   constexpr int TRS = A * rab_bp(B);
   constexpr int BUF = ((TRS + 15) & ~15) + 16;
+  constexpr bool WR = rab_q_wr(A, B, WMAX);    // the window in B registers per lane (its positions never change) instead of 4 K bytes of LDS
   const int W = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
   float* s_w = reinterpret_cast<float*>(g_wave_smem);
-  v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
+  v2f* s_tw = reinterpret_cast<v2f*>(s_w + (WR ? 0 : KB));
   v2f* s_x = s_tw + KB;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = a.tw[i]; }
+  for (int i = tid; i < KB; i += 64 * W) { if (!WR) s_w[i] = a.wtab[i]; s_tw[i] = a.tw[i]; }
   __syncthreads();
   v2f* buf = s_x + wave * BUF;
   const int hop = a.hop;                    // = A * Q
@@ -1005,6 +1015,11 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(WMAX 
   float rdv[Q];                             // the interior row of the normaliser at this lane's positions
 #pragma unroll
   for (int k2 = 0; k2 < Q; ++k2) rdv[k2] = a.den[(size_t)(a.RP - 1) * hop + lA + A * k2];
+  float wv[WR ? B : 1];
+  if constexpr (WR) {
+#pragma unroll
+    for (int k2 = 0; k2 < B; ++k2) wv[k2] = a.wtab[lA + A * k2];
+  }
   v2f acc[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) acc[j] = v2f{0.f, 0.f};
@@ -1051,7 +1066,7 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(WMAX 
       const int n = lA + A * k2;
       v2f x = fft_eps0(v2f{v[k2].x, -v[k2].y} * invK);  // Nx.ifft's clean-up (:609) precedes scale and window
       x = x * a.scale;
-      x = x * (s_w[n] * live);
+      x = x * ((WR ? wv[WR ? k2 : 0] : s_w[n]) * live);
       asm("" : "+v"(x));                                   // the windowed sample is ROUNDED before it is added (the LDS form stores it): no fma with the sum
       const v2f sum = (k2 < NA ? acc[k2 < NA ? k2 : 0] : v2f{0.f, 0.f}) + x;
       if (k2 < Q) {
@@ -1149,8 +1164,9 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   if constexpr (T == 1 && B % 4 == 0) {
     if (hop * 4 == KB && tune(c, kT_ISTFT_REGOLA, 1)) {   // overlap-add in registers
       constexpr int BUFQ = ((TRS + 15) & ~15) + 16;
-      int W = (int)((160 * 1024 - (size_t)KB * 12) / ((size_t)BUFQ * 8));
       constexpr int WQ = BIG ? 4 : 8;                     // one / two waves per SIMD: 512 / 256 registers
+      constexpr size_t TABQ = rab_q_wr(A, B, WQ) ? 8 : 12;
+      int W = (int)((160 * 1024 - (size_t)KB * TABQ) / ((size_t)BUFQ * 8));
       if (W > WQ) W = WQ;
       a.cstride = 0;
       const int waves_per_cu = tune(c, kT_ISTFT_RUNS_PER_CU, W);
@@ -1160,7 +1176,7 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
       a.runs_per_row = (a.units_per_row + run_len - 1) / run_len;
       a.total_runs = a.runs_per_row * s.batch;
       const int64_t blocks = (a.total_runs + W - 1) / W;
-      const size_t lds = (size_t)KB * 12 + (size_t)W * BUFQ * 8;
+      const size_t lds = (size_t)KB * TABQ + (size_t)W * BUFQ * 8;
       auto kernel = k_istft_rab_q<A, B, WQ>;
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       dispatch_note("istft.rab.q");

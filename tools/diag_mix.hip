@@ -257,25 +257,27 @@ int nxdiag_pcie_pinned(const void* dev, size_t bytes, double* d2h_GBps, double* 
   void* pin = nullptr;
   if (hipHostMalloc(&pin, bytes, hipHostMallocDefault) != hipSuccess) return 1;
   hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
+  int bad = hipEventCreate(&e0) != hipSuccess;
+  bad |= hipEventCreate(&e1) != hipSuccess;
   double best[2] = {0.0, 0.0};
-  for (int dir = 0; dir < 2; ++dir)
+  for (int dir = 0; dir < 2 && !bad; ++dir)
     for (int rep = 0; rep < 3; ++rep) {
-      hipEventRecord(e0, 0);
-      if (dir == 0) hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, 0);
-      else hipMemcpyAsync(const_cast<void*>(dev), pin, bytes, hipMemcpyHostToDevice, 0);
-      hipEventRecord(e1, 0);
-      hipEventSynchronize(e1);
+      bad |= hipEventRecord(e0, 0) != hipSuccess;
+      if (dir == 0) bad |= hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, 0) != hipSuccess;
+      else bad |= hipMemcpyAsync(const_cast<void*>(dev), pin, bytes, hipMemcpyHostToDevice, 0) != hipSuccess;
+      bad |= hipEventRecord(e1, 0) != hipSuccess;
+      bad |= hipEventSynchronize(e1) != hipSuccess;
       float ms = 0.f;
-      hipEventElapsedTime(&ms, e0, e1);
-      const double g = (double)bytes / (ms * 1e-3) / 1e9;
+      bad |= hipEventElapsedTime(&ms, e0, e1) != hipSuccess;
+      const double g = ms > 0.f ? (double)bytes / (ms * 1e-3) / 1e9 : 0.0;
       if (g > best[dir]) best[dir] = g;
     }
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  hipHostFree(pin);
+  bad |= hipEventDestroy(e0) != hipSuccess;
+  bad |= hipEventDestroy(e1) != hipSuccess;
+  bad |= hipHostFree(pin) != hipSuccess;
   if (d2h_GBps) *d2h_GBps = best[0];
   if (h2d_GBps) *h2d_GBps = best[1];
-  return (int)hipGetLastError();
+  return bad ? 1 : (int)hipGetLastError();
 }
 // x: f32[rows][L], z: c64[rows][M][2048] with M = (L - 2048) / hop + 1
 int nxdiag_stft2048_mix(void* stream, const void* x, void* z, const void* tab, long rows, long L, int hop, int units_per_wave) {

@@ -40,6 +40,14 @@ namespace nxsig {
 // the same bank, 480 cycles for the 30 reads of pass B instead of 30 (tools/lds_bank_model.py) — now B + 2.
 constexpr int rab_bp(int B) { return B + ((B & 1) ? 2 : 1); }
 
+// LDS tables in front of the waves' buffers: window (floats) and twiddles (complex cells), each region padded to 16 bytes.  Until round
+// 6's second pass they were K floats and K cells: for K = 441 the twiddles and EVERY wave buffer behind them started 4 bytes off an
+// 8-byte boundary — every ds_read / write_b64 of the kernel unaligned, 52 LDS cycles per instruction instead of 5 — and for K = 882 the
+// buffers sat 8 bytes off a 16-byte boundary (unaligned b128 accesses in the untangle: 9.6 cycles).
+constexpr int rab_wcells(int K) { return (K + 3) & ~3; }
+constexpr int rab_tcells(int K) { return (K + 1) & ~1; }
+constexpr int rab_tab_bytes(int K) { return 4 * rab_wcells(K) + 8 * rab_tcells(K); }
+
 // Forward kernels of the 50- / 60- / 64-point lengths: the window stays in global memory (L1 / L2 hits, read once per unit beside the
 // staging loads) when the 4 K bytes it frees in LDS buy another wave: 3840 = 64 x 60 runs 4 instead of 3
 #ifndef NXSIG_RAB_WG
@@ -94,8 +102,8 @@ __attribute__((amdgpu_waves_per_eu(rab_wg(A, B) ? 1 : rab_min_waves(A, B, SINK),
   constexpr int NRS = 10;                                   // 16-byte loads per lane that prefetch a unit's span (<= 2560 floats)
   constexpr bool WG = rab_wg(A, B);
   float* s_w0 = reinterpret_cast<float*>(g_wave_smem);
-  v2f* s_tw = reinterpret_cast<v2f*>(s_w0 + (WG ? 0 : KB));
-  v2f* s_x = s_tw + KB;
+  v2f* s_tw = reinterpret_cast<v2f*>(s_w0 + (WG ? 0 : rab_wcells(KB)));
+  v2f* s_x = s_tw + rab_tcells(KB);
   const float* s_w = WG ? a.wtab : s_w0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: unit arithmetic on the scalar unit
   for (int i = tid; i < KB; i += 64 * W) { if (!WG) s_w0[i] = a.wtab[i]; s_tw[i] = b.tw[i]; }
@@ -440,8 +448,8 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   // (1920: four waves would need 87 KB — one workgroup, four waves per CU; eight share the tables in 150 KB)
   // (round 6: lengths above 1920 cannot hold eight exchange buffers: as many waves as fit 160 KB beside the tables — 6 / 5 / 3 for 2400 / 2880 / 3840)
-  constexpr int TABB = rab_wg(A, B) ? 8 : 12;        // bytes of tables per bin in LDS
-  constexpr int W_FIT = (160 * 1024 - KB * TABB) / (BUF * 8);
+  constexpr int TABS = rab_wg(A, B) ? KB * 8 : rab_tab_bytes(KB);        // bytes of tables in LDS
+  constexpr int W_FIT = (160 * 1024 - TABS) / (BUF * 8);
   constexpr int W = (KB * 12 + 4 * BUF * 8 > 80 * 1024) ? (W_FIT < 8 ? W_FIT : 8) : 4, WM = W;   // WM: the log-mel sink
   static_assert(W >= 1, "the tables and one exchange buffer must fit the LDS");
   const int nuse = s.fr.N < KB ? s.fr.N : KB;
@@ -487,7 +495,7 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   {  // the launch must fit the LDS BEFORE the call is committed: a dense filterbank beside the 150 KB of the 1920-point kernel does not,
      // and the caller's two-step path takes it (it used to surface as a HIP launch error after *handled was set)
     const int wl = sink == kSinkMel ? WM : W;
-    if ((size_t)KB * TABB + (size_t)wl * BUF * 8 + lds_extra > (size_t)160 * 1024) return NXSIG_OK;
+    if ((size_t)TABS + (size_t)wl * BUF * 8 + lds_extra > (size_t)160 * 1024) return NXSIG_OK;
   }
   *handled = true;
   if (mel) *mel->handled = true;
@@ -521,7 +529,7 @@ inline int launch_rab(Ctx* c, const StftLaunch& s, bool* handled, const MelLaunc
   a.chunk = (int64_t)w * fill_units_per_wave(c, b.total_units, w, sink == kSinkMel ? 8 : 4);   // four units per wave (two: -1 ... -3 %), short-lived workgroups; the mel sink amortises its CSR preload
   const int64_t blocks = (b.total_units + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
-  const size_t lds = (size_t)KB * TABB + (size_t)w * BUF * 8 + lds_extra;
+  const size_t lds = (size_t)TABS + (size_t)w * BUF * 8 + lds_extra;
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -588,8 +596,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 3))) 
   constexpr int TRS = A * rab_bp(B);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
   float* s_w = reinterpret_cast<float*>(g_wave_smem);
-  v2f* s_tw = reinterpret_cast<v2f*>(s_w + KB);
-  v2f* s_x = s_tw + KB;
+  v2f* s_tw = reinterpret_cast<v2f*>(s_w + rab_wcells(KB));
+  v2f* s_x = s_tw + rab_tcells(KB);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < KB; i += 64 * W) { s_w[i] = a.wtab[i]; s_tw[i] = a.tw[i]; }
   __syncthreads();
@@ -706,7 +714,7 @@ inline int launch_rab_c64(Ctx* c, const StftLaunch& s, bool* handled) {
   constexpr int KB = A * B, LT = A > B ? A : B, T = 64 / LT;
   constexpr int TRS = A * rab_bp(B);
   constexpr int BUF = ((T * (TRS > KB ? TRS : KB) + 15) & ~15) + 16;
-  constexpr int W_FIT = (160 * 1024 - KB * 12) / (BUF * 8), W = W_FIT < 4 ? W_FIT : 4;   // (3840 = 64 x 60: three exchange buffers beside the tables)
+  constexpr int W_FIT = (160 * 1024 - rab_tab_bytes(KB)) / (BUF * 8), W = W_FIT < 4 ? W_FIT : 4;   // (3840 = 64 x 60: three exchange buffers beside the tables)
   static_assert(W >= 1, "the tables and one exchange buffer must fit the LDS");
   if ((int64_t)(T - 1) * s.fr.hop + KB + LT > BUF) return NXSIG_OK;   // the unit's span (idle lanes' reads included) must fit the wave's buffer
   if ((reinterpret_cast<uintptr_t>(s.z) & 15) != 0) return NXSIG_OK;
@@ -736,7 +744,7 @@ inline int launch_rab_c64(Ctx* c, const StftLaunch& s, bool* handled) {
   a.chunk = (int64_t)W * fill_units_per_wave(c, a.total_units, W, 4);
   const int64_t blocks = (a.total_units + a.chunk - 1) / a.chunk;
   if (blocks > 0x7fffffffLL) return set_error(NXSIG_ERR_UNSUPPORTED, "stft: too many frames for one launch");
-  const size_t lds = (size_t)KB * 4 + (size_t)KB * 8 + (size_t)W * BUF * 8;
+  const size_t lds = (size_t)rab_tab_bytes(KB) + (size_t)W * BUF * 8;
   auto go = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       NXSIG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -793,8 +801,8 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(rab_b
   constexpr int NRS = (N4 + 63) / 64;
   const int W = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
   float* s_w0 = reinterpret_cast<float*>(g_wave_smem);
-  v2f* s_tw0 = reinterpret_cast<v2f*>(s_w0 + KB);
-  v2f* s_x = TG ? reinterpret_cast<v2f*>(g_wave_smem) : s_tw0 + KB;
+  v2f* s_tw0 = reinterpret_cast<v2f*>(s_w0 + rab_wcells(KB));
+  v2f* s_x = TG ? reinterpret_cast<v2f*>(g_wave_smem) : s_tw0 + rab_tcells(KB);
   v2f* s_carry = s_x + W * BUF;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if constexpr (!TG) {
@@ -1187,7 +1195,7 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   }
   a.cstride = ((KB - hop) + 15) & ~15;
   if (a.cstride < 16) a.cstride = 16;
-  const size_t tables = TG ? 0 : (size_t)KB * 12;
+  const size_t tables = TG ? 0 : (size_t)rab_tab_bytes(KB);
   const size_t den_lds = ((size_t)hop * 4 + 15) & ~(size_t)15;
   int W = (int)((160 * 1024 - tables - den_lds) / ((size_t)(BUF + a.cstride) * 8));
   if (W > WMAX) W = WMAX;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # LDS bank-conflict sweep over bench_configs.py cases (tools only): one --pmc pass per case, prints conflict cycles / LDS cycles
-# and LDS wait / wave cycles per kernel.  usage: pmc_lds_sweep.sh <case> [<case> ...]
+# and LDS wait / wave cycles per kernel; LDS cycles per LDS instruction (round 6: ~5 is healthy, 10+ means unaligned 8- / 16-byte accesses or
+# conflicts — how the 4-byte-off wave buffers of the odd composite lengths were found).  usage: pmc_lds_sweep.sh <case> [<case> ...]
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -20,6 +21,6 @@ for k, cs in agg.items():
     med = {c: sorted(v)[len(v)//2] for c, v in cs.items()}
     idx = med.get("SQ_LDS_IDX_ACTIVE", 0.0); wc = med.get("SQ_WAVE_CYCLES", 0.0)
     if idx < 1e5: continue
-    print(f"$CASE | {k:72s} | conflict/lds {med.get('SQ_LDS_BANK_CONFLICT',0)/idx:5.2f} | lds_wait/wave {med.get('SQ_WAIT_INST_LDS',0)/wc:5.3f} | valu/wave {med.get('SQ_ACTIVE_INST_VALU',0)/wc:5.3f} | launches {n}")
+    print(f"$CASE | {k:72s} | lds cycles/instr {idx/max(med.get('SQ_INSTS_LDS',1.0),1.0):5.1f} | conflict/lds {med.get('SQ_LDS_BANK_CONFLICT',0)/idx:5.2f} | lds_wait/wave {med.get('SQ_WAIT_INST_LDS',0)/wc:5.3f} | valu/wave {med.get('SQ_ACTIVE_INST_VALU',0)/wc:5.3f} | launches {n}")
 PY
 done

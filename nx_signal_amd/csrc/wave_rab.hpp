@@ -1102,7 +1102,10 @@ inline int launch_istft_rab_AB(Ctx* c, const IstftLaunch& s, const float* window
   // 2 workgroups of 4 / 4 / 2 / 2 waves: 0.25 -> 0.42 for 640.  Round 6: the strip follows the hop and the long lengths read their
   // tables from global memory: 1764 / 2400 / 2880 / 3840 run 6 / 4 / 4 / 3 waves instead of 4 / 3 / 2 / 1)
   constexpr bool BIG = rab_big(A, B);
-  constexpr int WMAX = BIG ? 4 : (LT <= 24 ? 12 : 8);
+  // one-frame-per-wave lengths whose LDS holds more than eight waves at a quarter hop (882 = 42 x 21: 11, 1000 = 40 x 25: 10) may run
+  // three per SIMD as well: since they load straight into pass A's registers they need 140 VGPRs (tools/kernel_resources.py)
+  constexpr int W_QUARTER = (160 * 1024 - rab_tab_bytes(KB) - KB) / ((BUF + ((3 * KB / 4 + 15) & ~15)) * 8);
+  constexpr int WMAX = BIG ? 4 : ((LT <= 24 || (T == 1 && W_QUARTER > 8)) ? 12 : 8);
 #ifndef NXSIG_RAB_TG_BYTES
 #define NXSIG_RAB_TG_BYTES (1 << 30)
 #endif

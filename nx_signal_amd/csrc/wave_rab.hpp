@@ -783,6 +783,9 @@ struct IstftRabArgs {
 // call has none: exact), so the two instantiations per length are the two hop parities
 // The 42- ... 64-point codelets run at most FOUR waves per workgroup, one per SIMD, with the whole 512-entry register file (256 + 256
 // accumulation registers as spill space): at 256 they spilled 220 ... 720 B per lane to scratch
+#ifndef NXSIG_RAB_TOUCH
+#define NXSIG_RAB_TOUCH 1
+#endif
 #ifndef NXSIG_RAB_BIG_LT
 #define NXSIG_RAB_BIG_LT 48
 #endif
@@ -1031,6 +1034,7 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(WMAX 
   v2f acc[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) acc[j] = v2f{0.f, 0.f};
+  float junk = 0.0f;
   v2f v[NV];
   {
     const bool have = lane < B && us < a.M;
@@ -1039,6 +1043,20 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(WMAX 
     for (int n1 = 0; n1 < A; ++n1) v[n1] = have ? p[B * n1] : v2f{0.f, 0.f};
   }
   for (int64_t u = us; u < u1; ++u) {
+    // the frame after this one is touched a line per lane NOW (its loads are issued at the end of the unit, into the registers the
+    // overlap-add frees, and pass A needs them at once: with one wave per SIMD nothing else covers the trip to HBM); the touched values
+    // are summed into `junk` at the END of the unit (behind a scheduling barrier) so that the wait for them lands there
+    constexpr int NTOUCH = NXSIG_RAB_TOUCH ? (KB * 8 + 8191) / 8192 : 0;
+    float touch[NTOUCH > 0 ? NTOUCH : 1];
+    const bool touching = NTOUCH > 0 && u + 1 < u1 && u + 1 < a.M;
+    if (touching) {
+      const char* nb = reinterpret_cast<const char*>(zrow + (size_t)(u + 1) * KB);
+#pragma unroll
+      for (int j = 0; j < NTOUCH; ++j) {
+        const int off = 128 * (lane + 64 * j);
+        touch[j] = *reinterpret_cast<const float*>(nb + (off < KB * 8 ? off : 0));
+      }
+    }
     // ---- pass A on conj(z): lane n2 < B takes conj z[B n1 + n2]
 #pragma unroll
     for (int n1 = 0; n1 < A; ++n1) v[n1].y = -v[n1].y;
@@ -1089,7 +1107,13 @@ __global__ __launch_bounds__(64 * WMAX) __attribute__((amdgpu_waves_per_eu(WMAX 
 #pragma unroll
       for (int n1 = B; n1 < A; ++n1) v[n1] = have ? pn[B * n1] : v2f{0.f, 0.f};
     }
+    if (touching) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NTOUCH; ++j) junk += touch[j];
+    }
   }
+  if (junk == 1.2345e-38f && a.hop < 0) a.dummy[lane] = v2f{junk, junk};   // (never: keeps the touches alive)
 }
 
 template <int A, int B>

@@ -217,9 +217,37 @@ FLOORS = {
 }
 
 
+HEALTHY_COPY = 0.70   # hipMemcpyDtoD of 1 GiB on the boxes the floors were measured on: 0.67-0.72 of 8 TB/s (read + write bytes)
+
+
+@pytest.fixture(scope="module")
+def box_scale(ctx):
+    """The floors are fractions of 8 TB/s measured on healthy boxes.  One box in round 6 ran its memory system a quarter slower (memcpy
+    0.45 instead of 0.67, the whole suite 14 x slower on the host side) and failed two floors with no regression in the code: the floor is
+    scaled by what a plain device-to-device copy reaches on THIS box, capped at 1."""
+    hip = C.CDLL("libamdhip64.so")
+    n = 1 << 30
+    a, b = ctx.empty((n,), np.uint8), ctx.empty((n,), np.uint8)
+    import time
+    for _ in range(3):
+        hip.hipMemcpyDtoD(C.c_void_p(b.ptr), C.c_void_p(a.ptr), C.c_size_t(n))
+    hip.hipDeviceSynchronize()
+    best = 0.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(8):
+            hip.hipMemcpyDtoD(C.c_void_p(b.ptr), C.c_void_p(a.ptr), C.c_size_t(n))
+        hip.hipDeviceSynchronize()
+        best = max(best, 8 * 2 * n / (time.perf_counter() - t0) / 8.0e12)
+    del a, b
+    return min(1.0, best / HEALTHY_COPY), best
+
+
 @pytest.mark.parametrize("key", list(FLOORS))
-def test_throughput_floor(ctx, key):
+def test_throughput_floor(ctx, box_scale, key):
     build, args, floor = FLOORS[key]
+    scale, copy_frac = box_scale
+    floor = floor * scale
     fn, nbytes, keep = build(ctx, *args)
     for _ in range(12):   # clocks and caches settle
         fn()
@@ -235,4 +263,5 @@ def test_throughput_floor(ctx, key):
     if PROBE:
         print(f'\nPROBE    "{key}": {best:.3f}  [{ctx.last_dispatch()}]')
         return
-    assert best >= floor, f"{key}: {best:.3f} of 8 TB/s on [{ctx.last_dispatch()}], floor {floor} — a dispatch or kernel regression"
+    assert best >= floor, (f"{key}: {best:.3f} of 8 TB/s on [{ctx.last_dispatch()}], floor {floor:.3f} (this box copies at {copy_frac:.2f}) "
+                           f"— a dispatch or kernel regression")

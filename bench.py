@@ -681,37 +681,6 @@ class FileControl:
                 pass
 
 
-class SharedGpuGroup:
-    """--share-gpu (the one-device test mode) only: N ranks time-slice ONE GPU.  An RCCL barrier there is a kernel that spins until the
-    peer's kernel has run — and a rank that has left the barrier and queued its next measurement can keep the device from the peer
-    still inside it: on loaded boxes (round 6) both ranks ended up in RCCL barriers that never completed.  The group's data collectives
-    (the all-gathers of the assemblies: matched, nothing queued behind them) stay on RCCL; barrier and the small all-reduces go through
-    the file control plane.  With one GPU per rank — the real thing — this class is not used."""
-
-    def __init__(self, group, filectl):
-        self._g, self._f = group, filectl
-        self.contexts = group.contexts
-
-    def barrier(self):
-        for c in self.contexts:
-            c.sync()
-        self._f.barrier()
-
-    def allreduce(self, values, op="max"):
-        assert op == "max"
-        out = []
-        for i in range(0, len(values), 4):   # (the file control plane carries 4 doubles per exchange)
-            out += self._f.allreduce(list(values[i:i + 4]), "max")
-        return out
-
-    def __getattr__(self, name):   # allgather, broadcast, rccl info, ...: the RCCL group
-        return getattr(self._g, name)
-
-    def close(self):
-        self._f.cleanup()
-        self._g.close()
-
-
 def self_spawn(args) -> int:
     """`python bench.py --gpus N` with no RANK / WORLD_SIZE in the environment: start N copies of this script, one per GPU, with the
     variables a launcher sets (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT).  Rank 0 inherits stdout
@@ -833,15 +802,13 @@ def main():
 
         def _init():
             try:
-                # (--share-gpu, the one-device test mode: the loopback bootstrap takes 2-5 s when it works at all — a box where it does
-                # not must not hold the tests for minutes)
-                box["group"] = sharding.Group.ranked(world, rank, local_rank, timeout_ms=40000 if args.share_gpu else 90000)
+                box["group"] = sharding.Group.ranked(world, rank, local_rank, timeout_ms=90000)
             except Exception as e:  # noqa: BLE001  (never lose the measurement to the communicator)
                 box["error"] = repr(e)[:300]
 
         th = threading.Thread(target=_init, daemon=True)
         th.start()
-        th.join(timeout=(50.0 if args.share_gpu else 150.0) if world > 1 else 60.0)
+        th.join(timeout=150.0 if world > 1 else 60.0)
         if "group" in box:
             group = box["group"]
         else:
@@ -855,8 +822,6 @@ def main():
                 sys.exit(3)
             if world > 1:
                 filectl = FileControl(_lib.load(), sharding.rendezvous_path() + ".ctl", world, rank)
-        if group is not None and args.share_gpu and world > 1:
-            group = SharedGpuGroup(group, FileControl(_lib.load(), sharding.rendezvous_path() + ".ctl", world, rank))
     ctx = group.contexts[0] if group is not None else S.Context(local_rank)
     lib = _lib.load()
     mem = MemWatch(ctx, lib, C)

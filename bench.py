@@ -985,11 +985,24 @@ def main():
     # spectrum per rank (92 MB each).  Outputs otherwise stay sharded and device-resident.
     assembly = None
     if group is not None:
-        try:  # the optional assembly must never take the measurement down with it
+        zt, local_err = None, None
+        try:  # this rank's part: buffer + own shard
             zt = ctx.empty((world, M, N_FFT), np.complex64)  # full-size buffer: the own shard is computed in place
             mem.sample("config-2 assembly buffer")
             own = zt.ptr + rank * M * N_FFT * 8
             _lib.check(lib.nxsig_stft_f32(ctx.handle, C.c_void_p(xd.ptr), L, 1, L, wp, C.byref(p), C.c_void_p(own), None, _lib.DEVICE))
+            ctx.sync()
+        except Exception as e:  # noqa: BLE001
+            local_err = repr(e)[:200]
+        # the ranks AGREE before the first collective is queued: a rank whose part failed must not leave its peers inside an all-gather
+        # (round 6: a stale HIP error on rank 0 did exactly that to the one-device test mode)
+        any_bad = group.allreduce([1.0 if local_err else 0.0], "max")[0] != 0.0
+    if group is not None and any_bad:
+        assembly = {"error": local_err or "another rank could not prepare its shard; the collective was skipped on every rank"}
+        if zt is not None:
+            zt.free()
+    elif group is not None:
+        try:  # the optional assembly must never take the measurement down with it
             counts = [M * N_FFT * 8] * world
             for _ in range(0 if args.dry else 2):
                 group.allgather([own], counts, [zt.ptr])

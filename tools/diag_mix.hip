@@ -255,7 +255,7 @@ extern "C" {
 // the yardstick bench.py's `host_path` block puts beside the host-tensor call (nothing faster can cross PCIe)
 int nxdiag_pcie_pinned(const void* dev, size_t bytes, double* d2h_GBps, double* h2d_GBps) {
   void* pin = nullptr;
-  if (hipHostMalloc(&pin, bytes, hipHostMallocDefault) != hipSuccess) return 1;
+  if (hipHostMalloc(&pin, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return 1; }
   hipEvent_t e0, e1;
   int bad = hipEventCreate(&e0) != hipSuccess;
   bad |= hipEventCreate(&e1) != hipSuccess;
@@ -277,7 +277,8 @@ int nxdiag_pcie_pinned(const void* dev, size_t bytes, double* d2h_GBps, double* 
   bad |= hipHostFree(pin) != hipSuccess;
   if (d2h_GBps) *d2h_GBps = best[0];
   if (h2d_GBps) *h2d_GBps = best[1];
-  return bad ? 1 : (int)hipGetLastError();
+  const int last = (int)hipGetLastError();   // ALWAYS read: a sticky error left behind here fails the next launch check of libnxsig.so
+  return bad ? 1 : last;                     // (round 6: that made rank 0 skip an assembly its peers were already waiting in)
 }
 // x: f32[rows][L], z: c64[rows][M][2048] with M = (L - 2048) / hop + 1
 int nxdiag_stft2048_mix(void* stream, const void* x, void* z, const void* tab, long rows, long L, int hop, int units_per_wave) {

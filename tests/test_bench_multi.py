@@ -69,11 +69,12 @@ _STUCK = ""
 
 def _bench_line(cmd, env, timeout):
     """Runs a ranked bench.py command and returns its ONE JSON line.  N ranks on ONE device is a TEST MODE: RCCL bootstraps over
-    loopback sockets and its kernels spin until the peer's kernels have run, while the ranks time-slice the device — on a loaded box
-    (round 6: boxes whose plain copy ran at 0.54 instead of 0.71 of 8 TB/s) the communicator did not come up, or ranks starved each
-    other inside a collective.  That says nothing about the path with one GPU per rank, so: a run that produces no line in 180 s (it
-    takes 15 s), or whose communicator timed out, SKIPS — and so does every later ranked test of the session, at once; an error the
-    library itself reports (version refused, missing symbol, wrong call, wrong result) FAILS.  One retry for a quick RCCL error."""
+    loopback sockets and its kernels spin until the peer's kernels have run, while the ranks time-slice the device.  A run takes
+    15 s; one that produces no line in 180 s, or whose communicator timed out, SKIPS with what the ranks last printed — and so does
+    every later ranked test of the session, at once — instead of holding the suite for half an hour (round 6: a bug of ours, a sticky
+    HIP error that made rank 0 skip a collective, did exactly that until it was found; NXSIG_BENCH_HANG_DUMP=<s> shows where ranks
+    sit).  An error the library itself reports (version refused, missing symbol, wrong call, wrong result) FAILS.  One retry for a
+    quick RCCL error."""
     global _STUCK
     if _STUCK:
         pytest.skip("ranked processes sharing one GPU got stuck earlier in this session: " + _STUCK)

@@ -29,9 +29,9 @@ def test_ranked_processes_share_one_gpu(tmp_path, world):
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
-            # (the run takes 10-20 s.)  Ranks that time-slice ONE device can starve each other inside RCCL's spinning kernels when the
-            # box is loaded (round 6: boxes whose plain copy ran a quarter slow hung here and in bench.py --share-gpu): a property of the
-            # one-device test mode, not of one GPU per rank — skip; a wrong result or an error from the library fails below as before
+            # (the run takes 10-20 s.)  Ranks that time-slice ONE device depend on RCCL's spinning kernels being co-scheduled: a run that
+            # produces nothing in 200 s is skipped rather than holding the suite; a wrong result or an error from the library fails
+            # below as before
             pytest.skip(f"{world} ranked processes sharing one GPU produced no result in 200 s (RCCL over loopback, time-sliced device)")
     for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, (rank, se[-3000:])

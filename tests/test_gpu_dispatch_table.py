@@ -223,7 +223,7 @@ HEALTHY_COPY = 0.70   # hipMemcpyDtoD of 1 GiB on the boxes the floors were meas
 @pytest.fixture(scope="module")
 def box_scale(ctx):
     """The floors are fractions of 8 TB/s measured on healthy boxes.  One box in round 6 ran its memory system a quarter slower (memcpy
-    0.45 instead of 0.67, the whole suite 14 x slower on the host side) and failed two floors with no regression in the code: the floor is
+    0.45 instead of 0.67 of 8 TB/s, every kernel with it) and failed two floors with no regression in the code: the floor is
     scaled by what a plain device-to-device copy reaches on THIS box, capped at 1."""
     hip = C.CDLL("libamdhip64.so")
     n = 1 << 30

@@ -987,6 +987,8 @@ def main():
     if group is not None:
         zt, local_err = None, None
         try:  # this rank's part: buffer + own shard
+            if os.environ.get("NXSIG_BENCH_FAIL_ASSEMBLY_RANK") == str(rank):   # failure injection (tests/test_bench_multi.py)
+                raise MemoryError("injected: this rank cannot prepare its shard of the config-2 assembly")
             zt = ctx.empty((world, M, N_FFT), np.complex64)  # full-size buffer: the own shard is computed in place
             mem.sample("config-2 assembly buffer")
             own = zt.ptr + rank * M * N_FFT * 8

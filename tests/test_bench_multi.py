@@ -123,6 +123,19 @@ def test_gpus_n_self_spawns_and_measures_configs_4_and_5(n):
 
 
 @pytest.mark.gpu
+def test_a_rank_that_cannot_prepare_its_assembly_shard_strands_nobody():
+    """round 6: rank 1 fails before the config-2 assembly (injected) — the ranks agree on a status word first, every rank skips the
+    collective, the line still comes out with the measurement and says why the assembly is missing (it used to hang: the peers sat
+    in an all-gather the failed rank never joined)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NXSIG_BENCH_FAIL_ASSEMBLY_RANK="1")
+    d = json.loads(_bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu"] + SMALL, env, 900))
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "error" in d["assembly"] and "another rank" in d["assembly"]["error"]          # rank 0 prints the line: its own part was fine
+    assert d["assembly_config4"]["own_shard_intact"] and d["config4"]["ranks"] == 2      # everything after it ran on both ranks
+
+
+@pytest.mark.gpu
 def test_dry_preflight_allocates_and_launches_everything_once():
     """`bench.py --gpus 2 --dry`: the whole N-GPU run in one pass — same buffers, the RANKED group, one launch of
     every block, both assemblies — and a line that says so: dry: true, per-rank memory high-water marks, the RCCL actually loaded"""
